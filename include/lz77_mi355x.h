@@ -1,0 +1,121 @@
+/*
+ * lz77_mi355x.h -- C ABI of the MI355X-native LZ77 hot path (liblz77_mi355x.so).
+ *
+ * Drop-in boundary for cstdvd/lz77.  The reference's hot path is entered through
+ * exactly two functions, called only from main.c:150,161:
+ *
+ *     void encode(FILE *file, struct bitFILE *out, int la, int sb);   lz77.h:14 / lz77.c:51
+ *     void decode(struct bitFILE *file, FILE *out);                   lz77.h:15 / lz77.c:148
+ *
+ * Everything below them (tree.c's BST match finder, bitio.c's bit-at-a-time file
+ * I/O) is replaced outright by HIP kernels; the wire format and the
+ * token choice -- including the history-dependent choice among equal-length
+ * matches (A.5) -- are reproduced bit for bit.
+ *
+ * Plain C, plain pointers and sizes.  No global state is required between calls;
+ * a lazily created per-process context caches device scratch buffers.
+ * All functions return 0 on success or a negative LZ77X_E_* code and never print.
+ */
+#ifndef LZ77_MI355X_H
+#define LZ77_MI355X_H
+
+#include <stddef.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LZ77X_OK          0
+#define LZ77X_E_ARG      (-1)   /* bad -s/-l or NULL pointer (main.c:35-38 limits; -s 0 is rejected) */
+#define LZ77X_E_NOMEM    (-2)   /* host allocation failed */
+#define LZ77X_E_HIP      (-3)   /* a HIP runtime call failed (see lz77x_last_error) */
+#define LZ77X_E_NODEV    (-4)   /* no gfx950 device visible: there is NO CPU fallback */
+#define LZ77X_E_FORMAT   (-5)   /* stream shorter than its 4-byte header / zero sb or la */
+#define LZ77X_E_CAP      (-6)   /* caller-provided output buffer too small (*out_n holds the need) */
+#define LZ77X_E_IO       (-7)   /* fread/fwrite failed */
+#define LZ77X_E_TOOBIG   (-8)   /* input >= 4 GiB in one call (positions are 32-bit on device) */
+
+#define LZ77X_DEFAULT_LA 15     /* lz77.c:21 */
+#define LZ77X_DEFAULT_SB 4095   /* lz77.c:22 */
+
+/* ---- buffer level (host memory in, host memory out) ---------------------------------- */
+
+/* Replaces encode() (lz77.c:51-140) on an in-memory file.  sb in [1,65535], la in
+ * [2,255]; -1 selects the default like lz77.c:65-66.  *out is malloc'ed by the
+ * library (release with lz77x_free); *out_n = 4 + ceil(ntok*T/8) bytes. */
+int lz77x_encode(const uint8_t *in, size_t n, int sb, int la, uint8_t **out, size_t *out_n);
+
+/* Replaces decode() (lz77.c:148-197).  The header inside the stream supplies sb/la
+ * (lz77.c:157-158); a trailing partial token is dropped (lz77.c:271-280). */
+int lz77x_decode(const uint8_t *z, size_t zn, uint8_t **out, size_t *out_n);
+
+void lz77x_free(void *p);
+
+/* Upper bound of lz77x_encode's output for n input bytes (every token a bare literal). */
+size_t lz77x_encode_bound(size_t n, int sb, int la);
+
+/* ---- device level (buffers already resident in HBM; what bench.py times) -------------- */
+
+/* d_in/d_out are device pointers on the current HIP device.  stream is a hipStream_t
+ * (NULL = default stream) on which all kernels of the call are enqueued; the call
+ * returns after the result is complete.  out_cap >= lz77x_encode_bound(). */
+int lz77x_encode_device(const void *d_in, size_t n, int sb, int la,
+                        void *d_out, size_t out_cap, size_t *out_n, void *stream);
+
+/* Decode needs the decoded size before the caller can size d_out: call with
+ * d_out == NULL to get *out_n, then again with a buffer of at least that many bytes. */
+int lz77x_decode_device(const void *d_z, size_t zn,
+                        void *d_out, size_t out_cap, size_t *out_n, void *stream);
+
+/* ---- FILE* level: what main() of the reference calls -------------------------------- */
+
+/* Same argument meaning and ORDER as encode(file,out,la,sb) (lz77.h:14): la then sb,
+ * -1 = default (main.c:67).  Reads `in` to EOF, writes the complete stream to `out`. */
+int lz77x_encode_file(FILE *in, FILE *out, int la, int sb);
+int lz77x_decode_file(FILE *in, FILE *out);
+
+/* ---- configuration / introspection --------------------------------------------------- */
+
+/* Number of logical shards the positions of one input are split into (default 1, or
+ * env LZ77X_SHARDS).  Shards are spread round-robin over the visible devices; output
+ * bytes are identical for every shard count. */
+int lz77x_set_shards(int shards);
+int lz77x_device_count(void);
+const char *lz77x_strerror(int code);
+const char *lz77x_last_error(void);       /* detail of the last LZ77X_E_HIP, thread local */
+const char *lz77x_version(void);
+
+/* Per-call timing of the last encode/decode on this thread, milliseconds.  Kernel
+ * times are hipEvent pairs on the call's stream; host_* are wall clock. */
+typedef struct lz77x_stats {
+    double total_ms;          /* whole call */
+    double k_match_ms;        /* region kernel: window sort + pair scan (stage A + longest match) */
+    double k_token_ms;        /* transfer index + tie-break + token pack kernels */
+    double k_decode_ms;       /* parse + scan + copy-resolution kernels */
+    double host_chain_ms;     /* greedy parse chain walk (host) */
+    double host_stageb_ms;    /* sequential priority recurrence (host) */
+    double copy_ms;           /* H2D + D2H of intermediates, not overlapped part */
+    uint64_t n;               /* uncompressed bytes */
+    uint64_t zn;              /* compressed bytes */
+    uint64_t ntok;            /* tokens */
+    uint64_t transfers;       /* stage-B priority hand-overs */
+    uint32_t match_launches;  /* launches of the region kernel in the call */
+    uint32_t decode_rounds;   /* pointer-jumping rounds */
+} lz77x_stats;
+int lz77x_last_stats(lz77x_stats *st);
+
+/* ---- stage-level entry points (kernel parity tests; not needed by a drop-in user) ----- */
+
+/* maxlen[p] for every position, host buffers */
+int lz77x_stage_maxlen(const uint8_t *in, size_t n, int sb, int la, uint8_t *maxlen);
+/* in-order predecessor/successor distances of every evicted position (SURVEY A.5 stage A) */
+int lz77x_stage_neighbours(const uint8_t *in, size_t n, int sb, int la, uint16_t *P, uint16_t *S);
+/* host sequential stage (A.5 stage B) on caller-provided P/S: xval[x] or 0xFFFFFFFF */
+int lz77x_stage_priorities(const uint16_t *P, const uint16_t *S, size_t n, int sb, uint32_t *xval);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,191 @@
+"""lz77_amd -- Python host-side mirror of the C ABI in include/lz77_mi355x.h.
+
+The product is liblz77_mi355x.so (hand-written HIP for gfx950 + a C host layer) and the
+`lz77` CLI next to it; this module only binds that library with ctypes so tests and
+bench.py can drive it.  The function names follow the reference's interface
+(lz77.h:14-15): encode(data, la, sb) / decode(stream), la BEFORE sb, -1 = default.
+
+There is no CPU fallback: if the library or a GPU is missing every call raises.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+__all__ = ["encode", "decode", "encode_device", "decode_device", "last_stats", "build", "lib",
+           "Lz77Error", "LIB_PATH", "CLI_PATH"]
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(_HERE)
+LIB_PATH = os.path.join(_HERE, "liblz77_mi355x.so")
+CLI_PATH = os.path.join(_HERE, "lz77")
+
+DEFAULT_LA = 15      # lz77.c:21
+DEFAULT_SB = 4095    # lz77.c:22
+
+E_CAP = -6
+
+
+class Lz77Error(RuntimeError):
+    def __init__(self, code: int, what: str, detail: str = ""):
+        self.code = code
+        super().__init__("%s (code %d)%s" % (what, code, (": " + detail) if detail else ""))
+
+
+class Stats(ctypes.Structure):
+    _fields_ = [("total_ms", ctypes.c_double), ("k_match_ms", ctypes.c_double), ("k_token_ms", ctypes.c_double),
+                ("k_decode_ms", ctypes.c_double), ("host_chain_ms", ctypes.c_double),
+                ("host_stageb_ms", ctypes.c_double), ("copy_ms", ctypes.c_double),
+                ("n", ctypes.c_uint64), ("zn", ctypes.c_uint64), ("ntok", ctypes.c_uint64),
+                ("transfers", ctypes.c_uint64), ("match_launches", ctypes.c_uint32),
+                ("decode_rounds", ctypes.c_uint32)]
+
+    def as_dict(self) -> dict:
+        return {k: getattr(self, k) for k, _ in self._fields_}
+
+
+def build(force: bool = False) -> str:
+    """Compile the HIP extension in-tree (hipcc --offload-arch=gfx950); works without a GPU."""
+    srcdir = os.path.join(_HERE, "csrc")
+    if force:
+        subprocess.check_call(["make", "-s", "-C", srcdir, "clean"])
+    subprocess.check_call(["make", "-s", "-C", srcdir])
+    return LIB_PATH
+
+
+_lib = None
+
+_sz = ctypes.c_size_t
+_vp = ctypes.c_void_p
+_u8pp = ctypes.POINTER(ctypes.POINTER(ctypes.c_uint8))
+
+# every symbol include/lz77_mi355x.h declares, with its ctypes signature
+SYMBOLS = {
+    "lz77x_encode": (ctypes.c_int, [_vp, _sz, ctypes.c_int, ctypes.c_int, _u8pp, ctypes.POINTER(_sz)]),
+    "lz77x_decode": (ctypes.c_int, [_vp, _sz, _u8pp, ctypes.POINTER(_sz)]),
+    "lz77x_free": (None, [_vp]),
+    "lz77x_encode_bound": (_sz, [_sz, ctypes.c_int, ctypes.c_int]),
+    "lz77x_encode_device": (ctypes.c_int, [_vp, _sz, ctypes.c_int, ctypes.c_int, _vp, _sz, ctypes.POINTER(_sz), _vp]),
+    "lz77x_decode_device": (ctypes.c_int, [_vp, _sz, _vp, _sz, ctypes.POINTER(_sz), _vp]),
+    "lz77x_encode_file": (ctypes.c_int, [_vp, _vp, ctypes.c_int, ctypes.c_int]),
+    "lz77x_decode_file": (ctypes.c_int, [_vp, _vp]),
+    "lz77x_set_shards": (ctypes.c_int, [ctypes.c_int]),
+    "lz77x_device_count": (ctypes.c_int, []),
+    "lz77x_strerror": (ctypes.c_char_p, [ctypes.c_int]),
+    "lz77x_last_error": (ctypes.c_char_p, []),
+    "lz77x_version": (ctypes.c_char_p, []),
+    "lz77x_last_stats": (ctypes.c_int, [ctypes.POINTER(Stats)]),
+    "lz77x_stage_maxlen": (ctypes.c_int, [_vp, _sz, ctypes.c_int, ctypes.c_int, _vp]),
+    "lz77x_stage_neighbours": (ctypes.c_int, [_vp, _sz, ctypes.c_int, ctypes.c_int, _vp, _vp]),
+    "lz77x_stage_priorities": (ctypes.c_int, [_vp, _vp, _sz, ctypes.c_int, _vp]),
+}
+
+
+def lib():
+    """dlopen liblz77_mi355x.so (fails loudly if it has not been built)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise Lz77Error(-4, "liblz77_mi355x.so is not built (run `python -c 'import __graft_entry__ as g; g.build()'`)")
+        L = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SYMBOLS.items():
+            fn = getattr(L, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def _check(rc: int):
+    if rc != 0:
+        L = lib()
+        raise Lz77Error(rc, L.lz77x_strerror(rc).decode(), L.lz77x_last_error().decode())
+
+
+def _u8(data) -> np.ndarray:
+    if isinstance(data, np.ndarray):
+        return np.ascontiguousarray(data, dtype=np.uint8)
+    return np.frombuffer(bytes(data), dtype=np.uint8)
+
+
+def encode(data, la: int = -1, sb: int = -1) -> bytes:
+    """encode(file, out, la, sb) of lz77.c:51 on an in-memory buffer -> compressed stream."""
+    a = _u8(data)
+    out = ctypes.POINTER(ctypes.c_uint8)()
+    zn = _sz(0)
+    _check(lib().lz77x_encode(a.ctypes.data, a.size, int(sb), int(la), ctypes.byref(out), ctypes.byref(zn)))
+    try:
+        return ctypes.string_at(out, zn.value)
+    finally:
+        lib().lz77x_free(out)
+
+
+def decode(stream) -> bytes:
+    """decode(file, out) of lz77.c:148 on an in-memory stream -> original bytes."""
+    a = _u8(stream)
+    out = ctypes.POINTER(ctypes.c_uint8)()
+    n = _sz(0)
+    _check(lib().lz77x_decode(a.ctypes.data, a.size, ctypes.byref(out), ctypes.byref(n)))
+    try:
+        return ctypes.string_at(out, n.value)
+    finally:
+        lib().lz77x_free(out)
+
+
+def encode_bound(n: int, la: int = -1, sb: int = -1) -> int:
+    return int(lib().lz77x_encode_bound(n, int(sb), int(la)))
+
+
+def encode_device(d_in: int, n: int, d_out: int, out_cap: int, la: int = -1, sb: int = -1, stream: int = 0) -> int:
+    """Device-resident encode: raw device pointers (e.g. torch.Tensor.data_ptr()); returns stream size."""
+    zn = _sz(0)
+    _check(lib().lz77x_encode_device(d_in, n, int(sb), int(la), d_out, out_cap, ctypes.byref(zn), stream))
+    return zn.value
+
+
+def decoded_size_device(d_z: int, zn: int, stream: int = 0) -> int:
+    n = _sz(0)
+    _check(lib().lz77x_decode_device(d_z, zn, None, 0, ctypes.byref(n), stream))
+    return n.value
+
+
+def decode_device(d_z: int, zn: int, d_out: int, out_cap: int, stream: int = 0) -> int:
+    n = _sz(0)
+    _check(lib().lz77x_decode_device(d_z, zn, d_out, out_cap, ctypes.byref(n), stream))
+    return n.value
+
+
+def last_stats() -> dict:
+    st = Stats()
+    _check(lib().lz77x_last_stats(ctypes.byref(st)))
+    return st.as_dict()
+
+
+def stage_maxlen(data, la: int = -1, sb: int = -1) -> np.ndarray:
+    a = _u8(data)
+    la = DEFAULT_LA if la == -1 else la
+    sb = DEFAULT_SB if sb == -1 else sb
+    out = np.zeros(max(a.size, 1), dtype=np.uint8)
+    _check(lib().lz77x_stage_maxlen(a.ctypes.data, a.size, sb, la, out.ctypes.data))
+    return out[:a.size]
+
+
+def stage_neighbours(data, la: int = -1, sb: int = -1):
+    a = _u8(data)
+    la = DEFAULT_LA if la == -1 else la
+    sb = DEFAULT_SB if sb == -1 else sb
+    P = np.zeros(max(a.size, 1), dtype=np.uint16)
+    S = np.zeros(max(a.size, 1), dtype=np.uint16)
+    _check(lib().lz77x_stage_neighbours(a.ctypes.data, a.size, sb, la, P.ctypes.data, S.ctypes.data))
+    return P[:a.size], S[:a.size]
+
+
+def stage_priorities(P: np.ndarray, S: np.ndarray, sb: int) -> np.ndarray:
+    P = np.ascontiguousarray(P, dtype=np.uint16)
+    S = np.ascontiguousarray(S, dtype=np.uint16)
+    xval = np.empty(max(P.size, 1), dtype=np.uint32)
+    _check(lib().lz77x_stage_priorities(P.ctypes.data, S.ctypes.data, P.size, int(sb), xval.ctypes.data))
+    return xval[:P.size]

@@ -1,0 +1,72 @@
+/*
+ * fileio.c -- FILE*-level drop-ins for the two functions main() of the reference calls:
+ *     encode(FILE*, struct bitFILE*, int la, int sb)   lz77.h:14, called at main.c:150
+ *     decode(struct bitFILE*, FILE*)                   lz77.h:15, called at main.c:161
+ * The reference streams through a 3*SB+LA window (lz77.c:113-129) and a 4 KiB bit buffer
+ * (bitio.c:20); here the whole file crosses the host/device boundary once per direction.
+ */
+#include "../../include/lz77_mi355x.h"
+#include <stdlib.h>
+#include <string.h>
+
+static int slurp(FILE *f, uint8_t **data, size_t *n)
+{
+    size_t cap = 1 << 20, len = 0;
+    uint8_t *buf = (uint8_t *)malloc(cap);
+    if (!buf) return LZ77X_E_NOMEM;
+    for (;;) {
+        if (len == cap) {
+            size_t ncap = cap * 2;
+            uint8_t *nb = (uint8_t *)realloc(buf, ncap);
+            if (!nb) { free(buf); return LZ77X_E_NOMEM; }
+            buf = nb;
+            cap = ncap;
+        }
+        size_t got = fread(buf + len, 1, cap - len, f);
+        len += got;
+        if (got == 0) {
+            if (ferror(f)) { free(buf); return LZ77X_E_IO; }
+            break;
+        }
+    }
+    *data = buf;
+    *n = len;
+    return LZ77X_OK;
+}
+
+static int spill(FILE *f, const uint8_t *data, size_t n)
+{
+    if (n && fwrite(data, 1, n, f) != n) return LZ77X_E_IO;
+    if (fflush(f) != 0) return LZ77X_E_IO;
+    return LZ77X_OK;
+}
+
+int lz77x_encode_file(FILE *in, FILE *out, int la, int sb)
+{
+    if (!in || !out) return LZ77X_E_ARG;
+    uint8_t *data = NULL, *z = NULL;
+    size_t n = 0, zn = 0;
+    int rc = slurp(in, &data, &n);
+    if (rc) return rc;
+    rc = lz77x_encode(data, n, sb, la, &z, &zn);
+    free(data);
+    if (rc) return rc;
+    rc = spill(out, z, zn);
+    lz77x_free(z);
+    return rc;
+}
+
+int lz77x_decode_file(FILE *in, FILE *out)
+{
+    if (!in || !out) return LZ77X_E_ARG;
+    uint8_t *z = NULL, *data = NULL;
+    size_t zn = 0, n = 0;
+    int rc = slurp(in, &z, &zn);
+    if (rc) return rc;
+    rc = lz77x_decode(z, zn, &data, &n);
+    free(z);
+    if (rc) return rc;
+    rc = spill(out, data, n);
+    lz77x_free(data);
+    return rc;
+}

@@ -1,0 +1,95 @@
+/*
+ * hoststage.c -- the sequential host part of the encode hot path (plain C).
+ *
+ * Two recurrences of the reference are inherently serial over the byte stream and
+ * stay on a host core:
+ *   - the greedy parse chain  p <- p + len + 1                      (lz77.c:89-98)
+ *   - which node a tree.c:182-243 delete() promotes, restated as a priority
+ *     hand-over between a position and its in-order successor       (SURVEY A.5 stage B)
+ * Both consume per-position results of the match kernel and are O(1) per byte.
+ */
+#include "lz77x_internal.h"
+#include <stdlib.h>
+#include <string.h>
+
+/* bitio.c:41-43: (int)ceil(log(n)/log(2)) for n >= 1, in integers */
+int lz77x_bitof(int n)
+{
+    int b = 0;
+    while (b < 31 && (1 << b) < n) b++;
+    return b;
+}
+
+void lz77x_make_geom(lz77x_geom *g, int sb, int la)
+{
+    g->sb = sb;
+    g->la = la;
+    g->ob = lz77x_bitof(sb);
+    g->lb = lz77x_bitof(la);
+    g->T = g->ob + g->lb + 8;                       /* lz77.c:249-251 */
+    g->SBu = ((uint32_t)sb + 3u) & ~3u;
+    uint32_t rp = 4096;
+    while (rp < 4u * g->SBu) rp <<= 1;
+    g->RP = rp;
+    g->TILE = (rp - g->SBu - (uint32_t)sb) & ~3u;
+    g->fast = rp <= 16384u;
+}
+
+size_t lz77x_host_chain(const uint8_t *maxlen, size_t limit, size_t p, uint32_t *chain, size_t *ntok)
+{
+    size_t k = *ntok;
+    while (p < limit) {
+        chain[k++] = (uint32_t)p;
+        p += (size_t)maxlen[p] + 1;
+    }
+    *ntok = k;
+    return p;
+}
+
+int lz77x_prio_init(lz77x_prio_state *st, int sb)
+{
+    uint32_t size = 1;
+    while (size < (uint32_t)sb + 1u) size <<= 1;
+    st->ring = (uint32_t *)malloc(sizeof(uint32_t) * (size_t)size);
+    st->mask = size - 1;
+    st->next = 0;
+    st->transfers = 0;
+    return st->ring != NULL;
+}
+
+void lz77x_prio_free(lz77x_prio_state *st)
+{
+    free(st->ring);
+    st->ring = NULL;
+}
+
+/* Inserting position t (priority t) is preceded, once the window is full, by evicting
+ * x = t - sb.  tree.c:202-231: a node with two children is replaced by its in-order
+ * successor, which thereby inherits the node's place (priority); a node with fewer
+ * children just splices out.  "x has two children" <=> both in-order neighbours lie in
+ * x's subtrees <=> both have larger priority than x. */
+void lz77x_prio_run(lz77x_prio_state *st, const uint32_t *ps, int sb, size_t upto, uint32_t *xval)
+{
+    uint32_t *ring = st->ring;
+    const uint32_t mask = st->mask;
+    const size_t usb = (size_t)sb;
+    size_t t = st->next;
+    uint64_t moved = 0;
+    for (; t < upto && t < usb; t++) ring[t & mask] = (uint32_t)t;
+    for (; t < upto; t++) {
+        const size_t x = t - usb;
+        const uint32_t v = ps[x];
+        const uint32_t P = v & 0xFFFFu, S = v >> 16;
+        const uint32_t mine = ring[x & mask];
+        const uint32_t sidx = (uint32_t)(x + S) & mask;
+        const uint32_t pp = ring[(uint32_t)(x + P) & mask];
+        const uint32_t sp = ring[sidx];
+        const int go = (P != 0) & (S != 0) & (pp > mine) & (sp > mine);
+        ring[sidx] = go ? mine : sp;          /* S==0: sidx==x&mask, rewritten below or dead */
+        xval[x] = go ? mine : LZ77X_NONE32;
+        moved += (uint64_t)go;
+        ring[t & mask] = (uint32_t)t;
+    }
+    st->next = t;
+    st->transfers += moved;
+}

@@ -1,0 +1,686 @@
+/*
+ * kernels.hip -- hand-written HIP kernels of the LZ77 hot path for gfx950 (MI355X).
+ *
+ * What replaces what (reference file:line):
+ *   k_match      tree.c:62-243 (insert/delete/find on the BST) -> per-region key sort +
+ *                rank-difference pair scan.  For every position x it yields
+ *                  - maxlen[x]: the longest match in the SB window (tree.c:118-152 result len)
+ *                  - P[x],S[x]: in-order predecessor/successor of x among the SB-1 positions
+ *                    that follow it, i.e. x's neighbours in the BST at the moment
+ *                    tree.c:182 delete() evicts it.
+ *   k_xfer_*     index of the priority hand-overs produced by the host stage
+ *   k_tokens     tree.c:139-141 "first strictly longer on the search path wins": among the
+ *                equal-length candidates pick the one nearest the BST root (min priority)
+ *   k_pack       lz77.c:246-252 writecode + bitio.c:203-239 bitIO_write as computed bit offsets
+ *   k_dec_*      lz77.c:148-197 decode, lz77.c:260-283 readcode, bitio.c:256-298 bitIO_read
+ *
+ * Byte/integer work only: no MFMA.  wave = 64 lanes; LDS staged windows; packed 16-bit
+ * VALU (v_pk_sub/min/max_u16) in the pair scan; coalesced dword global traffic.
+ */
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "lz77x_internal.h"
+
+#define MATCH_BLOCK 1024
+
+typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+
+/* ------------------------------------------------------------------ helpers ---------- */
+
+__device__ __forceinline__ uint32_t ld32u(const uint8_t *p)
+{
+    uint32_t v;
+    __builtin_memcpy(&v, p, 4);          /* gfx950: unaligned dword access is native (LDS and global) */
+    return v;
+}
+
+__device__ __forceinline__ uint64_t ld64u(const uint8_t *p)
+{
+    uint64_t v;
+    __builtin_memcpy(&v, p, 8);
+    return v;
+}
+
+/* first `la` bytes at a vs b as big-endian words; ties -> lower index first.
+ * tree.c:77 orders nodes with memcmp over the lookahead; bytes past the end of input are
+ * 0xFF on device, which reproduces the shrinking key length at EOF (DESIGN.md "key order"). */
+__device__ __forceinline__ bool key_less(const uint8_t *by, uint32_t a, uint32_t b, int la)
+{
+    for (int w = 0; w < la; w += 4) {
+        uint32_t va = __builtin_bswap32(ld32u(by + a + w));
+        uint32_t vb = __builtin_bswap32(ld32u(by + b + w));
+        int rem = la - w;
+        if (rem < 4) {
+            uint32_t m = 0xFFFFFFFFu << (8 * (4 - rem));
+            va &= m;
+            vb &= m;
+        }
+        if (va != vb) return va < vb;
+    }
+    return a < b;
+}
+
+__device__ __forceinline__ int lcp_capped(const uint8_t *a, const uint8_t *b, int cap)
+{
+    int i = 0;
+    while (i + 4 <= cap) {
+        uint32_t x = ld32u(a + i) ^ ld32u(b + i);
+        if (x) return i + (__builtin_ctz(x) >> 3);
+        i += 4;
+    }
+    while (i < cap && a[i] == b[i]) i++;
+    return i;
+}
+
+/* ------------------------------------------------------------------ k_match ---------- */
+
+template <bool FAST> struct rank_traits;
+template <> struct rank_traits<true>  { typedef uint16_t rank_t; static constexpr uint32_t HALF = 0x8000u; static constexpr uint32_t MASK = 0xFFFFu; };
+template <> struct rank_traits<false> { typedef uint32_t rank_t; static constexpr uint32_t HALF = 0x80000000u; static constexpr uint32_t MASK = 0xFFFFFFFFu; };
+
+/* running min / max of rank differences u = rank[y]-rank[x] (mod 2^16 or 2^32) for the four
+ * positions a thread owns.  With all ranks < HALF, positive differences are < HALF and
+ * negative ones wrap to >= HALF, so
+ *     min u  = distance to the in-order successor  (valid iff < HALF)
+ *     max u  = -distance to the in-order predecessor (valid iff >= HALF)
+ * which turns the BST neighbour search into sub/min/max on packed 16-bit lanes. */
+template <bool FAST> struct acc4;
+
+template <> struct acc4<true> {
+    us2 mn[4], mx[4], xr[4];
+    __device__ __forceinline__ void init(const uint16_t *rk, uint32_t lx0)
+    {
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            uint16_t r = rk[lx0 + i];
+            xr[i] = (us2){r, r};
+            mn[i] = (us2){0xFFFF, 0xFFFF};
+            mx[i] = (us2){0, 0};
+        }
+    }
+    __device__ __forceinline__ void reset()
+    {
+#pragma unroll
+        for (int i = 0; i < 4; i++) { mn[i] = (us2){0xFFFF, 0xFFFF}; mx[i] = (us2){0, 0}; }
+    }
+    /* all 16 pairs of chunk m with the four owned positions */
+    __device__ __forceinline__ void chunk(const uint16_t *rk, uint32_t m)
+    {
+        uint2 v = *reinterpret_cast<const uint2 *>(rk + 4 * m);
+        us2 A = __builtin_bit_cast(us2, v.x), B = __builtin_bit_cast(us2, v.y);
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            us2 dA = A - xr[i], dB = B - xr[i];
+            mn[i] = __builtin_elementwise_min(mn[i], dA);
+            mx[i] = __builtin_elementwise_max(mx[i], dA);
+            mn[i] = __builtin_elementwise_min(mn[i], dB);
+            mx[i] = __builtin_elementwise_max(mx[i], dB);
+        }
+    }
+    __device__ __forceinline__ void one(int i, uint32_t ry)
+    {
+        uint16_t u = (uint16_t)(ry - xr[i].x);
+        mn[i].x = u < mn[i].x ? u : mn[i].x;
+        mx[i].x = u > mx[i].x ? u : mx[i].x;
+    }
+    __device__ __forceinline__ uint32_t minu(int i) const { return mn[i].x < mn[i].y ? mn[i].x : mn[i].y; }
+    __device__ __forceinline__ uint32_t maxu(int i) const { return mx[i].x > mx[i].y ? mx[i].x : mx[i].y; }
+    __device__ __forceinline__ uint32_t xrank(int i) const { return xr[i].x; }
+};
+
+template <> struct acc4<false> {
+    uint32_t mn[4], mx[4], xr[4];
+    __device__ __forceinline__ void init(const uint32_t *rk, uint32_t lx0)
+    {
+#pragma unroll
+        for (int i = 0; i < 4; i++) { xr[i] = rk[lx0 + i]; mn[i] = 0xFFFFFFFFu; mx[i] = 0; }
+    }
+    __device__ __forceinline__ void reset()
+    {
+#pragma unroll
+        for (int i = 0; i < 4; i++) { mn[i] = 0xFFFFFFFFu; mx[i] = 0; }
+    }
+    __device__ __forceinline__ void chunk(const uint32_t *rk, uint32_t m)
+    {
+        uint4 v = *reinterpret_cast<const uint4 *>(rk + 4 * m);
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            uint32_t d0 = v.x - xr[i], d1 = v.y - xr[i], d2 = v.z - xr[i], d3 = v.w - xr[i];
+            uint32_t lo = min(min(d0, d1), min(d2, d3)), hi = max(max(d0, d1), max(d2, d3));
+            mn[i] = min(mn[i], lo);
+            mx[i] = max(mx[i], hi);
+        }
+    }
+    __device__ __forceinline__ void one(int i, uint32_t ry)
+    {
+        uint32_t u = ry - xr[i];
+        mn[i] = min(mn[i], u);
+        mx[i] = max(mx[i], u);
+    }
+    __device__ __forceinline__ uint32_t minu(int i) const { return mn[i]; }
+    __device__ __forceinline__ uint32_t maxu(int i) const { return mx[i]; }
+    __device__ __forceinline__ uint32_t xrank(int i) const { return xr[i]; }
+};
+
+/*
+ * One workgroup per region.
+ *   FAST   : ranks/index are uint16 in LDS and the window bytes are staged in LDS (RP <= 16384)
+ *            else they are uint32 in a per-region global scratch and bytes come from L1/L2.
+ *   PACKED : use the unmasked 16-pairs-per-chunk interior loop (else every pair goes through
+ *            the masked path: slow, used as an on-device self check).
+ */
+template <bool FAST, bool PACKED>
+__global__ __launch_bounds__(MATCH_BLOCK) void k_match(const uint8_t *__restrict__ in, uint32_t n, int sb, int la,
+                                                       uint32_t SBu, uint32_t RP, uint32_t TILE, uint32_t region0,
+                                                       uint32_t *__restrict__ ps, uint8_t *__restrict__ maxlen,
+                                                       uint32_t *__restrict__ scratch)
+{
+    typedef typename rank_traits<FAST>::rank_t rank_t;
+    constexpr uint32_t HALF = rank_traits<FAST>::HALF;
+    constexpr uint32_t RMASK = rank_traits<FAST>::MASK;
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+
+    const uint32_t tid = threadIdx.x;
+    const uint32_t region = region0 + blockIdx.x;
+    const uint64_t t0_64 = (uint64_t)region * TILE;
+    if (t0_64 >= n) return;
+    const uint32_t t0 = (uint32_t)t0_64;
+    const uint32_t rstart = t0 >= SBu ? t0 - SBu : 0;
+    const uint64_t rend64 = (uint64_t)t0 + TILE + (uint32_t)sb - 1;
+    const uint32_t rend = rend64 < n ? (uint32_t)rend64 : n;
+    const uint32_t R = rend - rstart;                      /* valid local indices [0,R) */
+    const uint32_t lt0 = t0 - rstart;
+    const uint32_t lt1 = ((uint64_t)t0 + TILE < n ? t0 + TILE : n) - rstart;
+
+    rank_t *rk, *ix;
+    const uint8_t *by;
+    if constexpr (FAST) {
+        rk = reinterpret_cast<rank_t *>(smem);             /* RP + 8 */
+        ix = rk + RP + 8;                                  /* RP */
+        uint8_t *stage = reinterpret_cast<uint8_t *>(ix + RP);
+        const uint32_t nb = (R + (uint32_t)la + 3 + 3) & ~3u;
+        for (uint32_t i = tid * 4; i < nb; i += MATCH_BLOCK * 4)
+            *reinterpret_cast<uint32_t *>(stage + i) = *reinterpret_cast<const uint32_t *>(in + rstart + i);
+        by = stage;
+    } else {
+        rk = reinterpret_cast<rank_t *>(scratch + (size_t)blockIdx.x * (2 * (size_t)RP + 8));
+        ix = rk + RP + 8;
+        by = in + rstart;
+    }
+    for (uint32_t i = tid; i < RP; i += MATCH_BLOCK) ix[i] = (rank_t)i;
+    for (uint32_t i = tid; i < RP + 8; i += MATCH_BLOCK) rk[i] = 0;
+    __syncthreads();
+
+    /* ---- bitonic sort of local indices by (key, index); indices >= R sort last ---- */
+    for (uint32_t k = 2; k <= RP; k <<= 1) {
+        for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+            for (uint32_t t = tid; t < (RP >> 1); t += MATCH_BLOCK) {
+                const uint32_t i = 2 * t - (t & (j - 1));
+                const uint32_t l = i + j;
+                const uint32_t a = ix[i], b = ix[l];
+                const bool up = (i & k) == 0;
+                bool b_lt_a, a_lt_b;
+                if (a >= R || b >= R) { b_lt_a = b < a; a_lt_b = a < b; }
+                else { b_lt_a = key_less(by, b, a, la); a_lt_b = !b_lt_a; }
+                if (up ? b_lt_a : a_lt_b) { ix[i] = (rank_t)b; ix[l] = (rank_t)a; }
+            }
+            __syncthreads();
+        }
+    }
+    for (uint32_t r = tid; r < RP; r += MATCH_BLOCK) {
+        const uint32_t a = ix[r];
+        if (a < R) rk[a] = (rank_t)r;
+    }
+    __syncthreads();
+
+    /* ---- pair scan: four consecutive positions per thread, window read in chunks of 4 ---- */
+    const uint32_t usb = (uint32_t)sb;
+    for (uint32_t lx0 = lt0 + 4 * tid; lx0 < lt1; lx0 += 4 * MATCH_BLOCK) {
+        const uint32_t g = lx0 >> 2;
+        acc4<FAST> acc;
+        acc.init(rk, lx0);
+
+        /* forward window y in [x+1, x+sb-1], y < R : in-order neighbours at eviction time */
+        {
+            const uint32_t mlast = min((lx0 + 3 + usb - 1) >> 2, (R - 1) >> 2);
+            uint32_t m = g;
+            uint32_t ilo = g + 1, ihi = 0;                         /* interior chunks [ilo, ihi] */
+            if (PACKED && usb >= 8 && R >= 4) ihi = min(g + (usb - 4) / 4, (R - 4) >> 2);
+            for (; m <= mlast; m++) {
+                if (m >= ilo && m <= ihi) { acc.chunk(rk, m); continue; }
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    const uint32_t y = 4 * m + j;
+                    if (y >= R) continue;
+                    const uint32_t ry = rk[y];
+#pragma unroll
+                    for (int i = 0; i < 4; i++) {
+                        const int32_t d = (int32_t)y - (int32_t)(lx0 + i);
+                        if (d >= 1 && d <= sb - 1) acc.one(i, ry);
+                    }
+                }
+            }
+        }
+        uint32_t psv[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const uint32_t x = lx0 + i;
+            uint32_t P = 0, S = 0;
+            if (x < lt1 && (uint64_t)rstart + x + usb < n) {       /* only evicted positions matter */
+                const uint32_t mnu = acc.minu(i), mxu = acc.maxu(i), xr = acc.xrank(i);
+                if (mnu < HALF) S = (uint32_t)ix[(xr + mnu) & RMASK] - x;
+                if (mxu >= HALF) P = (uint32_t)ix[(xr + mxu) & RMASK] - x;
+            }
+            psv[i] = P | (S << 16);
+        }
+
+        /* backward window c in [x-sb, x-1], c >= 0 : longest match (tree.c:118-152 length) */
+        acc.reset();
+        {
+            const uint32_t mfirst = lx0 >= usb ? (lx0 - usb) >> 2 : 0;
+            uint32_t ilo = 1, ihi = 0;
+            if (PACKED && usb >= 7 && g >= 1) {
+                const uint32_t span = (usb - 3) / 4;                /* g-m in [1, span] is unmasked */
+                ihi = g - 1;
+                ilo = g > span ? g - span : 0;
+            }
+            for (uint32_t m = mfirst; m <= g; m++) {
+                if (m >= ilo && m <= ihi) { acc.chunk(rk, m); continue; }
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    const uint32_t c = 4 * m + j;
+                    if (c >= R) continue;
+                    const uint32_t rc = rk[c];
+#pragma unroll
+                    for (int i = 0; i < 4; i++) {
+                        const int32_t d = (int32_t)(lx0 + i) - (int32_t)c;
+                        if (d >= 1 && d <= sb) acc.one(i, rc);
+                    }
+                }
+            }
+        }
+        uint32_t mlv = 0;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const uint32_t x = lx0 + i;
+            uint32_t best = 0;
+            if (x < lt1) {
+                const uint32_t left = n - (rstart + x);
+                const int cap = (int)(left < (uint32_t)la ? left : (uint32_t)la) - 1;
+                const uint32_t mnu = acc.minu(i), mxu = acc.maxu(i), xr = acc.xrank(i);
+                if (mnu < HALF) best = (uint32_t)lcp_capped(by + (uint32_t)ix[(xr + mnu) & RMASK], by + x, cap);
+                if (mxu >= HALF) {
+                    const uint32_t l2 = (uint32_t)lcp_capped(by + (uint32_t)ix[(xr + mxu) & RMASK], by + x, cap);
+                    best = l2 > best ? l2 : best;
+                }
+            }
+            mlv |= best << (8 * i);
+        }
+
+        const uint32_t xa = rstart + lx0;
+        if (lx0 + 4 <= lt1) {
+            *reinterpret_cast<uint4 *>(ps + xa) = make_uint4(psv[0], psv[1], psv[2], psv[3]);
+            *reinterpret_cast<uint32_t *>(maxlen + xa) = mlv;
+        } else {
+            for (int i = 0; i < 4 && lx0 + i < lt1; i++) {
+                ps[xa + i] = psv[i];
+                maxlen[xa + i] = (uint8_t)(mlv >> (8 * i));
+            }
+        }
+    }
+}
+
+size_t lz77k_match_lds_bytes(const lz77x_geom &g)
+{
+    if (!g.fast) return 0;
+    return (size_t)(g.RP + 8) * 2 + (size_t)g.RP * 2 + (size_t)g.RP + 256 + 32;
+}
+
+size_t lz77k_match_scratch_bytes(const lz77x_geom &g, uint32_t nregions)
+{
+    if (g.fast) return 0;
+    return (size_t)nregions * (2 * (size_t)g.RP + 8) * sizeof(uint32_t);
+}
+
+template <bool FAST, bool PACKED>
+static hipError_t launch_match(const uint8_t *d_in, uint32_t n, const lz77x_geom &g, uint32_t region0, uint32_t nregions,
+                               uint32_t *d_ps, uint8_t *d_maxlen, void *d_scratch, hipStream_t s)
+{
+    const size_t lds = lz77k_match_lds_bytes(g);
+    auto fn = k_match<FAST, PACKED>;
+    if (lds > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(fn, dim3(nregions), dim3(MATCH_BLOCK), lds, s, d_in, n, g.sb, g.la, g.SBu, g.RP, g.TILE, region0,
+                       d_ps, d_maxlen, reinterpret_cast<uint32_t *>(d_scratch));
+    return hipGetLastError();
+}
+
+hipError_t lz77k_match(const uint8_t *d_in, uint32_t n, const lz77x_geom &g, uint32_t region0, uint32_t nregions,
+                       uint32_t *d_ps, uint8_t *d_maxlen, void *d_scratch, int variant, hipStream_t s)
+{
+    if (nregions == 0) return hipSuccess;
+    if (g.fast) {
+        return variant == 0 ? launch_match<true, true>(d_in, n, g, region0, nregions, d_ps, d_maxlen, d_scratch, s)
+                            : launch_match<true, false>(d_in, n, g, region0, nregions, d_ps, d_maxlen, d_scratch, s);
+    }
+    return variant == 0 ? launch_match<false, true>(d_in, n, g, region0, nregions, d_ps, d_maxlen, d_scratch, s)
+                        : launch_match<false, false>(d_in, n, g, region0, nregions, d_ps, d_maxlen, d_scratch, s);
+}
+
+/* ------------------------------------------------------------------ small utilities -- */
+
+__global__ void k_fill_pad(uint8_t *in, uint32_t n)
+{
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < LZ77X_PAD) in[(size_t)n + i] = 0xFF;
+}
+
+hipError_t lz77k_fill_pad(uint8_t *d_in, uint32_t n, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_fill_pad, dim3((LZ77X_PAD + 255) / 256), dim3(256), 0, s, d_in, n);
+    return hipGetLastError();
+}
+
+/* ---- exclusive scan (uint32), 3 phases, recursive on block sums ---- */
+
+#define SCAN_THREADS 256
+#define SCAN_ITEMS 8
+#define SCAN_CHUNK (SCAN_THREADS * SCAN_ITEMS)
+
+__global__ __launch_bounds__(SCAN_THREADS) void k_scan_local(const uint32_t *in, uint32_t *out,   /* may alias */
+                                                             uint32_t m, uint32_t *sums)
+{
+    __shared__ uint32_t wsum[SCAN_THREADS / 64];
+    const uint32_t base = blockIdx.x * SCAN_CHUNK + threadIdx.x * SCAN_ITEMS;
+    uint32_t v[SCAN_ITEMS], tot = 0;
+#pragma unroll
+    for (int i = 0; i < SCAN_ITEMS; i++) {
+        v[i] = base + i < m ? in[base + i] : 0;
+        tot += v[i];
+    }
+    /* inclusive scan of tot across the wave, then across the 4 waves */
+    uint32_t incl = tot;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        uint32_t t = __shfl_up(incl, d, 64);
+        if (lane >= d) incl += t;
+    }
+    if (lane == 63) wsum[wave] = incl;
+    __syncthreads();
+    uint32_t woff = 0, btot = 0;
+#pragma unroll
+    for (int w = 0; w < SCAN_THREADS / 64; w++) {
+        if (w < wave) woff += wsum[w];
+        btot += wsum[w];
+    }
+    uint32_t run = woff + incl - tot;
+#pragma unroll
+    for (int i = 0; i < SCAN_ITEMS; i++) {
+        if (base + i < m) out[base + i] = run;
+        run += v[i];
+    }
+    if (threadIdx.x == 0 && sums) sums[blockIdx.x] = btot;
+}
+
+__global__ __launch_bounds__(SCAN_THREADS) void k_scan_add(uint32_t *__restrict__ out, uint32_t m, const uint32_t *__restrict__ offs)
+{
+    const uint32_t add = offs[blockIdx.x];
+    const uint32_t base = blockIdx.x * SCAN_CHUNK + threadIdx.x * SCAN_ITEMS;
+#pragma unroll
+    for (int i = 0; i < SCAN_ITEMS; i++)
+        if (base + i < m) out[base + i] += add;
+}
+
+size_t lz77k_scan_tmp_bytes(uint32_t m)
+{
+    size_t total = 0;
+    uint64_t cur = m;
+    while (cur > SCAN_CHUNK) {
+        cur = (cur + SCAN_CHUNK - 1) / SCAN_CHUNK;
+        total += (cur + 64) * sizeof(uint32_t);
+    }
+    return total + 256;
+}
+
+hipError_t lz77k_scan_u32(const uint32_t *d_in, uint32_t *d_out, uint32_t m, void *d_tmp, hipStream_t s)
+{
+    if (m == 0) return hipSuccess;
+    const uint32_t blocks = (uint32_t)(((uint64_t)m + SCAN_CHUNK - 1) / SCAN_CHUNK);
+    if (blocks == 1) {
+        hipLaunchKernelGGL(k_scan_local, dim3(1), dim3(SCAN_THREADS), 0, s, d_in, d_out, m, (uint32_t *)nullptr);
+        return hipGetLastError();
+    }
+    uint32_t *sums = reinterpret_cast<uint32_t *>(d_tmp);
+    hipLaunchKernelGGL(k_scan_local, dim3(blocks), dim3(SCAN_THREADS), 0, s, d_in, d_out, m, sums);
+    hipError_t e = lz77k_scan_u32(sums, sums, blocks, sums + blocks + 64, s);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k_scan_add, dim3(blocks), dim3(SCAN_THREADS), 0, s, d_out, m, sums);
+    return hipGetLastError();
+}
+
+/* ------------------------------------------------------------------ transfer index --- */
+
+/* The host stage hands back xval[x] = priority moved from x to its successor S[x] when x is
+ * evicted (or NONE).  Group these hand-overs by destination so that k_tokens can ask
+ * "what priority did candidate c hold at time p". */
+__global__ void k_xfer_count(const uint32_t *__restrict__ ps, const uint32_t *__restrict__ xval, uint32_t nx, uint32_t *__restrict__ cnt)
+{
+    for (uint32_t x = blockIdx.x * blockDim.x + threadIdx.x; x < nx; x += gridDim.x * blockDim.x)
+        if (xval[x] != LZ77X_NONE32) atomicAdd(&cnt[x + (ps[x] >> 16)], 1u);
+}
+
+__global__ void k_xfer_fill(const uint32_t *__restrict__ ps, const uint32_t *__restrict__ xval, uint32_t nx,
+                            uint32_t *__restrict__ ofs, uint2 *__restrict__ ent)
+{
+    for (uint32_t x = blockIdx.x * blockDim.x + threadIdx.x; x < nx; x += gridDim.x * blockDim.x) {
+        const uint32_t v = xval[x];
+        if (v != LZ77X_NONE32) {
+            const uint32_t slot = atomicAdd(&ofs[x + (ps[x] >> 16)], 1u);
+            ent[slot] = make_uint2(x, v);
+        }
+    }
+}
+
+hipError_t lz77k_xfer_index(const uint32_t *d_ps, const uint32_t *d_xval, uint32_t nx, uint32_t n,
+                            uint32_t *d_ofs, uint2 *d_ent, void *d_scan_tmp, hipStream_t s)
+{
+    hipError_t e = hipMemsetAsync(d_ofs, 0, ((size_t)n + 1) * sizeof(uint32_t), s);
+    if (e != hipSuccess) return e;
+    if (nx == 0) return hipSuccess;
+    const uint32_t blocks = min((nx + 255u) / 256u, 256u * 16u);
+    hipLaunchKernelGGL(k_xfer_count, dim3(blocks), dim3(256), 0, s, d_ps, d_xval, nx, d_ofs);
+    e = lz77k_scan_u32(d_ofs, d_ofs, n + 1, d_scan_tmp, s);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k_xfer_fill, dim3(blocks), dim3(256), 0, s, d_ps, d_xval, nx, d_ofs, d_ent);
+    return hipGetLastError();
+}
+
+/* ------------------------------------------------------------------ k_tokens --------- */
+
+/* One wave per token.  Lanes stride the SB candidates; a candidate qualifies when it shares
+ * the first len bytes with p (len is already the maximum, so lcp == len); its priority at
+ * time p is the value of the latest hand-over into it that happened before p, else its own
+ * position.  The wave min over (priority, position) is the node nearest the BST root. */
+__global__ __launch_bounds__(256) void k_tokens(const uint8_t *__restrict__ in, uint32_t n, int sb, int ob, int lb,
+                                                const uint32_t *__restrict__ chain, uint32_t ntok,
+                                                const uint8_t *__restrict__ maxlen,
+                                                const uint32_t *__restrict__ ofs, const uint2 *__restrict__ ent,
+                                                uint32_t *__restrict__ tokval)
+{
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t k = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (k >= ntok) return;
+    const uint32_t p = chain[k];
+    const uint32_t len = maxlen[p];
+    const uint32_t next = in[p + len];
+    uint32_t off = 0;
+    if (len > 0) {
+        const uint8_t *q = in + p;
+        const uint32_t head = ld32u(q);
+        const uint32_t hmask = len >= 4 ? 0xFFFFFFFFu : (1u << (8 * len)) - 1u;
+        const uint32_t c0 = p > (uint32_t)sb ? p - (uint32_t)sb : 0;
+        uint64_t best = ~0ull;
+        for (uint32_t c = c0 + lane; c < p; c += 64) {
+            const uint8_t *r = in + c;
+            if ((ld32u(r) ^ head) & hmask) continue;
+            bool same = true;
+            for (uint32_t i = 4; i < len; i += 4) {
+                uint32_t x = ld32u(r + i) ^ ld32u(q + i);
+                const uint32_t rem = len - i;
+                if (rem < 4) x &= (1u << (8 * rem)) - 1u;
+                if (x) { same = false; break; }
+            }
+            if (!same) continue;
+            uint32_t prio = c;
+            const uint32_t lo = c ? ofs[c - 1] : 0, hi = ofs[c];
+            uint32_t latest = 0;
+            bool any = false;
+            for (uint32_t e = lo; e < hi; e++) {
+                const uint2 t = ent[e];
+                /* hand-over at eviction of t.x happens after the match at time t.x+sb */
+                if ((uint64_t)t.x + (uint32_t)sb < p && (!any || t.x > latest)) { any = true; latest = t.x; prio = t.y; }
+            }
+            const uint64_t key = ((uint64_t)prio << 32) | c;
+            best = key < best ? key : best;
+        }
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) {
+            const uint64_t o = (uint64_t)__shfl_xor((unsigned long long)best, d, 64);
+            best = o < best ? o : best;
+        }
+        off = p - (uint32_t)(best & 0xFFFFFFFFu);
+    }
+    if (lane == 0) {
+        const uint32_t omask = ob >= 32 ? 0xFFFFFFFFu : (1u << ob) - 1u;
+        tokval[k] = (off & omask) | (len << ob) | (next << (ob + lb));      /* lz77.c:249-251 */
+    }
+}
+
+hipError_t lz77k_tokens(const uint8_t *d_in, uint32_t n, const lz77x_geom &g, const uint32_t *d_chain, uint32_t ntok,
+                        const uint8_t *d_maxlen, const uint32_t *d_ofs, const uint2 *d_ent, uint32_t *d_tokval, hipStream_t s)
+{
+    if (ntok == 0) return hipSuccess;
+    const uint32_t blocks = (ntok + 3) / 4;
+    hipLaunchKernelGGL(k_tokens, dim3(blocks), dim3(256), 0, s, d_in, n, g.sb, g.ob, g.lb, d_chain, ntok, d_maxlen, d_ofs, d_ent, d_tokval);
+    return hipGetLastError();
+}
+
+/* ------------------------------------------------------------------ k_pack ----------- */
+
+/* bitio.c:203-239 without the per-bit loop: token k occupies stream bits [32+kT, 32+(k+1)T);
+ * stream bit b is bit (b & 31) of little-endian word b >> 5.  One thread assembles one word. */
+__global__ void k_pack(const uint32_t *__restrict__ tokval, uint64_t ntok, int sb, int la, int T,
+                       uint32_t *__restrict__ out, uint64_t nwords)
+{
+    const uint64_t w = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (w >= nwords) return;
+    if (w == 0) { out[0] = (uint32_t)sb | ((uint32_t)la << 16); return; }      /* lz77.c:74-75 */
+    const uint64_t b0 = 32 * (w - 1);                     /* first token-area bit of this word */
+    uint64_t k = b0 / (uint64_t)T;
+    uint32_t word = 0;
+    for (; k < ntok; k++) {
+        const int64_t sh = (int64_t)(k * (uint64_t)T) - (int64_t)b0;
+        if (sh >= 32) break;
+        const uint32_t v = tokval[k];
+        word |= sh >= 0 ? (v << sh) : (v >> (-sh));
+    }
+    out[w] = word;
+}
+
+hipError_t lz77k_pack(const uint32_t *d_tokval, uint64_t ntok, const lz77x_geom &g, uint32_t *d_out_words, uint64_t nwords, hipStream_t s)
+{
+    if (nwords == 0) return hipSuccess;
+    const uint32_t blocks = (uint32_t)((nwords + 255) / 256);
+    hipLaunchKernelGGL(k_pack, dim3(blocks), dim3(256), 0, s, d_tokval, ntok, g.sb, g.la, g.T, d_out_words, nwords);
+    return hipGetLastError();
+}
+
+/* ------------------------------------------------------------------ decode ----------- */
+
+/* lz77.c:260-283 + bitio.c:256-298: fixed-width tokens, so token k is simply bits [32+kT, ..) */
+__global__ void k_dec_parse(const uint8_t *__restrict__ z, uint32_t ntok, int ob, int lb, int T,
+                            uint32_t *__restrict__ tokval, uint32_t *__restrict__ len1)
+{
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= ntok) return;
+    const uint64_t bit = 32 + (uint64_t)k * (uint64_t)T;
+    uint64_t v = ld64u(z + (bit >> 3)) >> (bit & 7);
+    v &= T >= 32 ? 0xFFFFFFFFull : ((1ull << T) - 1);
+    tokval[k] = (uint32_t)v;
+    len1[k] = (((uint32_t)v >> ob) & ((1u << lb) - 1u)) + 1u;
+}
+
+/* lz77.c:178-194 as data flow: every copied byte j points at j-off, every literal at itself.
+ * Position n is a zero byte that degenerate tokens (off==0 or off>j) point at. */
+__global__ void k_dec_expand(const uint32_t *__restrict__ tokval, const uint32_t *__restrict__ dst, uint32_t ntok,
+                             int ob, int lb, uint8_t *__restrict__ out, uint32_t *__restrict__ ptr, uint32_t n)
+{
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k == 0) { out[n] = 0; ptr[n] = n; }
+    if (k >= ntok) return;
+    const uint32_t v = tokval[k];
+    const uint32_t off = ob ? (v & ((1u << ob) - 1u)) : 0;
+    const uint32_t len = (v >> ob) & ((1u << lb) - 1u);
+    const uint32_t lit = (v >> (ob + lb)) & 0xFFu;
+    const uint32_t j0 = dst[k];
+    for (uint32_t i = 0; i < len; i++) {
+        const uint32_t j = j0 + i;
+        ptr[j] = (off > 0 && off <= j) ? j - off : n;
+    }
+    out[j0 + len] = (uint8_t)lit;
+    ptr[j0 + len] = j0 + len;
+}
+
+/* pointer doubling: ptr[j] <- ptr[ptr[j]] until every byte points at a literal (<= log2(depth) rounds) */
+__global__ void k_dec_jump(uint32_t *__restrict__ ptr, uint32_t n, uint32_t *__restrict__ changed)
+{
+    bool any = false;
+    for (uint32_t j = blockIdx.x * blockDim.x + threadIdx.x; j < n; j += gridDim.x * blockDim.x) {
+        const uint32_t p = ptr[j];
+        if (p == j) continue;
+        const uint32_t q = ptr[p];
+        if (q != p) { ptr[j] = q; any = true; }
+    }
+    if (any) *changed = 1;
+}
+
+__global__ void k_dec_gather(uint8_t *__restrict__ out, const uint32_t *__restrict__ ptr, uint32_t n)
+{
+    for (uint32_t j = blockIdx.x * blockDim.x + threadIdx.x; j < n; j += gridDim.x * blockDim.x) {
+        const uint32_t p = ptr[j];
+        if (p != j) out[j] = out[p];
+    }
+}
+
+hipError_t lz77k_dec_parse(const uint8_t *d_z, uint32_t ntok, const lz77x_geom &g, uint32_t *d_tokval, uint32_t *d_len1, hipStream_t s)
+{
+    if (ntok == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_dec_parse, dim3((ntok + 255) / 256), dim3(256), 0, s, d_z, ntok, g.ob, g.lb, g.T, d_tokval, d_len1);
+    return hipGetLastError();
+}
+
+hipError_t lz77k_dec_expand(const uint32_t *d_tokval, const uint32_t *d_dst, uint32_t ntok, const lz77x_geom &g,
+                            uint8_t *d_out, uint32_t *d_ptr, uint32_t n, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_dec_expand, dim3(ntok ? (ntok + 255) / 256 : 1), dim3(256), 0, s, d_tokval, d_dst, ntok, g.ob, g.lb, d_out, d_ptr, n);
+    return hipGetLastError();
+}
+
+hipError_t lz77k_dec_jump(uint32_t *d_ptr, uint32_t n, uint32_t *d_changed, hipStream_t s)
+{
+    if (n == 0) return hipSuccess;
+    const uint32_t blocks = min((n + 255u) / 256u, 256u * 32u);
+    hipLaunchKernelGGL(k_dec_jump, dim3(blocks), dim3(256), 0, s, d_ptr, n, d_changed);
+    return hipGetLastError();
+}
+
+hipError_t lz77k_dec_gather(uint8_t *d_out, const uint32_t *d_ptr, uint32_t n, hipStream_t s)
+{
+    if (n == 0) return hipSuccess;
+    const uint32_t blocks = min((n + 255u) / 256u, 256u * 32u);
+    hipLaunchKernelGGL(k_dec_gather, dim3(blocks), dim3(256), 0, s, d_out, d_ptr, n);
+    return hipGetLastError();
+}

@@ -1,0 +1,102 @@
+/*
+ * lz77x_internal.h -- shared between the HIP translation unit (kernels.hip), the
+ * host pipeline (pipeline.cpp) and the sequential host stage (hoststage.c).
+ * Not part of the public ABI (that is include/lz77_mi355x.h).
+ */
+#ifndef LZ77X_INTERNAL_H
+#define LZ77X_INTERNAL_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#define LZ77X_PAD      1024u          /* 0xFF bytes kept after the input on device (>= LA + 16) */
+#define LZ77X_NONE32   0xFFFFFFFFu
+#define LZ77X_MAX_N    0xFFF00000u    /* positions are 32-bit on device */
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Geometry of one call: token widths and the region decomposition of the match kernel.
+ *
+ * A region is the unit one workgroup owns: the TILE positions [t0, t0+TILE) whose
+ * results it writes, plus the read-only halo it needs: SBu >= SB positions to the left
+ * (backward window of the longest-match search) and SB-1 to the right
+ * (forward window of the in-order neighbour search, A.5 stage A).  RP is the padded
+ * (power of two) number of positions sorted per region.
+ */
+typedef struct lz77x_geom {
+    int sb, la;            /* search buffer, lookahead */
+    int ob, lb, T;         /* bitof(sb), bitof(la), token bits (lz77.c:249-251) */
+    uint32_t SBu;          /* sb rounded up to a multiple of 4 */
+    uint32_t RP;           /* padded region size (power of two) */
+    uint32_t TILE;         /* positions produced per region (multiple of 4) */
+    int fast;              /* 1: ranks are 16-bit and live in LDS (RP <= 32768) */
+} lz77x_geom;
+
+int  lz77x_bitof(int n);                                   /* bitio.c:41-43, integer form */
+void lz77x_make_geom(lz77x_geom *g, int sb, int la);
+
+/* ---- sequential host stage (hoststage.c) -------------------------------------------- */
+
+/* Greedy parse chain (lz77.c:98: p += len+1) from maxlen[]; appends chain positions to
+ * chain[] starting at *ntok; resumes at *p for positions < limit.  Returns new *p. */
+size_t lz77x_host_chain(const uint8_t *maxlen, size_t limit, size_t p, uint32_t *chain, size_t *ntok);
+
+typedef struct lz77x_prio_state {
+    uint32_t *ring;        /* priority of live position q at ring[q & mask] */
+    uint32_t mask;
+    size_t next;           /* next position to insert (== positions processed) */
+    uint64_t transfers;
+} lz77x_prio_state;
+
+int  lz77x_prio_init(lz77x_prio_state *st, int sb);
+void lz77x_prio_free(lz77x_prio_state *st);
+/* Advance the recurrence (SURVEY A.5 stage B) over insert times [st->next, upto);
+ * ps[x] = P | S<<16 must be available for x < upto - sb; writes xval[x] for those x. */
+void lz77x_prio_run(lz77x_prio_state *st, const uint32_t *ps, int sb, size_t upto, uint32_t *xval);
+
+#ifdef __cplusplus
+}
+#endif
+
+#ifdef __cplusplus
+#include <hip/hip_runtime_api.h>
+
+/* ---- kernel launchers (kernels.hip).  All enqueue on `s` and return immediately. ----- */
+
+size_t lz77k_match_scratch_bytes(const lz77x_geom &g, uint32_t nregions);
+size_t lz77k_match_lds_bytes(const lz77x_geom &g);
+/* regions [region0, region0+nregions) of an n-byte padded input; variant 0 = packed
+ * interior loop, 1 = all-masked reference loop (self-check) */
+hipError_t lz77k_match(const uint8_t *d_in, uint32_t n, const lz77x_geom &g,
+                       uint32_t region0, uint32_t nregions,
+                       uint32_t *d_ps, uint8_t *d_maxlen, void *d_scratch, int variant, hipStream_t s);
+
+hipError_t lz77k_fill_pad(uint8_t *d_in, uint32_t n, hipStream_t s);
+
+/* exclusive scan of m uint32 (in place allowed); d_tmp needs lz77k_scan_tmp_bytes(m) */
+size_t lz77k_scan_tmp_bytes(uint32_t m);
+hipError_t lz77k_scan_u32(const uint32_t *d_in, uint32_t *d_out, uint32_t m, void *d_tmp, hipStream_t s);
+
+/* transfer index: after the call list(c) = ent[ (c ? ofs[c-1] : 0) .. ofs[c] ) */
+hipError_t lz77k_xfer_index(const uint32_t *d_ps, const uint32_t *d_xval, uint32_t nx, uint32_t n,
+                            uint32_t *d_ofs /* n+1 */, uint2 *d_ent, void *d_scan_tmp, hipStream_t s);
+
+hipError_t lz77k_tokens(const uint8_t *d_in, uint32_t n, const lz77x_geom &g,
+                        const uint32_t *d_chain, uint32_t ntok, const uint8_t *d_maxlen,
+                        const uint32_t *d_ofs, const uint2 *d_ent, uint32_t *d_tokval, hipStream_t s);
+
+/* words [w0, w0+nw) of the output stream (word 0 = header) from tokval[0..ntok) */
+hipError_t lz77k_pack(const uint32_t *d_tokval, uint64_t ntok, const lz77x_geom &g,
+                      uint32_t *d_out_words, uint64_t nwords, hipStream_t s);
+
+hipError_t lz77k_dec_parse(const uint8_t *d_z, uint32_t ntok, const lz77x_geom &g,
+                           uint32_t *d_tokval, uint32_t *d_len1, hipStream_t s);
+hipError_t lz77k_dec_expand(const uint32_t *d_tokval, const uint32_t *d_dst, uint32_t ntok,
+                            const lz77x_geom &g, uint8_t *d_out, uint32_t *d_ptr, uint32_t n, hipStream_t s);
+hipError_t lz77k_dec_jump(uint32_t *d_ptr, uint32_t n, uint32_t *d_changed, hipStream_t s);
+hipError_t lz77k_dec_gather(uint8_t *d_out, const uint32_t *d_ptr, uint32_t n, hipStream_t s);
+#endif
+
+#endif

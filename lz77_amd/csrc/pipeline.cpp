@@ -1,0 +1,529 @@
+/*
+ * pipeline.cpp -- host side of the hot path and the C ABI (include/lz77_mi355x.h).
+ *
+ * encode (replaces lz77.c:51-140):
+ *     input -> HBM -> k_match (longest match + in-order neighbours, all positions)
+ *           -> D2H {ps, maxlen} -> host: parse chain + priority recurrence (hoststage.c)
+ *           -> H2D {chain, xval} -> k_xfer_* -> k_tokens -> k_pack -> stream in HBM
+ * decode (replaces lz77.c:148-197):
+ *     stream -> HBM -> k_dec_parse -> scan -> k_dec_expand -> k_dec_jump* -> k_dec_gather
+ *
+ * There is NO CPU fallback: without a HIP device every entry point returns LZ77X_E_NODEV.
+ */
+#include "lz77x_internal.h"
+#include "../../include/lz77_mi355x.h"
+
+#include <hip/hip_runtime_api.h>
+
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+
+namespace {
+
+thread_local char g_err[256] = "";
+thread_local lz77x_stats g_stats;
+int g_shards = 0;
+
+#define HIPCHK(expr)                                                                           \
+    do {                                                                                       \
+        hipError_t e_ = (expr);                                                                \
+        if (e_ != hipSuccess) {                                                                \
+            snprintf(g_err, sizeof g_err, "%s:%d %s -> %s", __FILE__, __LINE__, #expr, hipGetErrorString(e_)); \
+            return LZ77X_E_HIP;                                                                \
+        }                                                                                      \
+    } while (0)
+
+double now_ms()
+{
+    using namespace std::chrono;
+    return duration<double, std::milli>(steady_clock::now().time_since_epoch()).count();
+}
+
+struct DevBuf {
+    void *p = nullptr;
+    size_t cap = 0;
+    int need(size_t bytes)
+    {
+        if (bytes <= cap) return LZ77X_OK;
+        if (p) { hipError_t e0 = hipFree(p); (void)e0; p = nullptr; cap = 0; }
+        size_t want = bytes + bytes / 8 + 4096;
+        HIPCHK(hipMalloc(&p, want));
+        cap = want;
+        return LZ77X_OK;
+    }
+    template <class T> T *as() const { return reinterpret_cast<T *>(p); }
+};
+
+struct PinBuf {
+    void *p = nullptr;
+    size_t cap = 0;
+    int need(size_t bytes)
+    {
+        if (bytes <= cap) return LZ77X_OK;
+        if (p) { hipError_t e0 = hipHostFree(p); (void)e0; p = nullptr; cap = 0; }
+        size_t want = bytes + bytes / 8 + 4096;
+        HIPCHK(hipHostMalloc(&p, want, hipHostMallocDefault));
+        cap = want;
+        return LZ77X_OK;
+    }
+    template <class T> T *as() const { return reinterpret_cast<T *>(p); }
+};
+
+struct Ctx {
+    bool ready = false;
+    int ndev = 0;
+    hipStream_t stream = nullptr;            /* used when the caller passes none (host-level API) */
+    hipEvent_t ev[6] = {};
+    DevBuf in, ps, maxlen, scratch, xval, chain, ofs, ent, tokval, out, scantmp;
+    DevBuf z, len1, dst, ptr, flag;
+    PinBuf h_ps, h_maxlen, h_xval, h_chain, h_small;
+};
+
+Ctx g_ctx;
+std::mutex g_mu;
+
+int ctx_init(Ctx &c)
+{
+    if (c.ready) return LZ77X_OK;
+    int nd = 0;
+    hipError_t e = hipGetDeviceCount(&nd);
+    if (e != hipSuccess || nd <= 0) {
+        snprintf(g_err, sizeof g_err, "no HIP device (%s)", e == hipSuccess ? "count 0" : hipGetErrorString(e));
+        return LZ77X_E_NODEV;
+    }
+    c.ndev = nd;
+    HIPCHK(hipStreamCreateWithFlags(&c.stream, hipStreamNonBlocking));
+    for (auto &ev : c.ev) HIPCHK(hipEventCreate(&ev));
+    c.ready = true;
+    return LZ77X_OK;
+}
+
+int check_geom(int &sb, int &la)
+{
+    if (sb == -1) sb = LZ77X_DEFAULT_SB;     /* lz77.c:65-66 */
+    if (la == -1) la = LZ77X_DEFAULT_LA;
+    if (sb < 1 || sb > 65535 || la < 2 || la > 255) return LZ77X_E_ARG;   /* main.c:35-38; -s 0 crashes the reference */
+    return LZ77X_OK;
+}
+
+size_t stream_bytes(uint64_t ntok, int T) { return 4 + (size_t)((ntok * (uint64_t)T + 7) / 8); }
+
+/* ---------------------------------------------------------------- encode ------------ */
+
+/* src is a device pointer (src_on_device) or a host pointer.  On success the stream is in
+ * c.out (device) and *zn holds its size. */
+int encode_core(Ctx &c, const void *src, bool src_on_device, size_t n, const lz77x_geom &g, hipStream_t s, size_t *zn)
+{
+    const double t_begin = now_ms();
+    memset(&g_stats, 0, sizeof g_stats);
+    if (n > LZ77X_MAX_N) return LZ77X_E_TOOBIG;
+    const uint32_t n32 = (uint32_t)n;
+    int rc;
+
+    if ((rc = c.in.need(n + LZ77X_PAD + 16))) return rc;
+    if (n) HIPCHK(hipMemcpyAsync(c.in.p, src, n, src_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, s));
+    HIPCHK(lz77k_fill_pad(c.in.as<uint8_t>(), n32, s));
+
+    uint32_t ntok = 0;
+    uint64_t transfers = 0;
+    if (n) {
+        if ((rc = c.ps.need((n + 8) * 4))) return rc;
+        if ((rc = c.maxlen.need(n + 8))) return rc;
+        if ((rc = c.h_ps.need((n + 8) * 4))) return rc;
+        if ((rc = c.h_maxlen.need(n + 8))) return rc;
+        if ((rc = c.h_xval.need((n + 8) * 4))) return rc;
+        if ((rc = c.h_chain.need((n + 8) * 4))) return rc;
+
+        /* -- match kernel over all regions (batched only to bound the generic path's scratch) -- */
+        const uint32_t nregions = (uint32_t)((n + g.TILE - 1) / g.TILE);
+        uint32_t batch = nregions;
+        if (!g.fast) {
+            const size_t per = lz77k_match_scratch_bytes(g, 1);
+            const size_t budget = (size_t)2 << 30;
+            batch = (uint32_t)(budget / per);
+            if (batch < 1) batch = 1;
+            if (batch > nregions) batch = nregions;
+            if ((rc = c.scratch.need(lz77k_match_scratch_bytes(g, batch)))) return rc;
+        }
+        const char *vs = getenv("LZ77X_MATCH_VARIANT");
+        const int variant = vs ? atoi(vs) : 0;
+        HIPCHK(hipEventRecord(c.ev[0], s));
+        for (uint32_t r0 = 0; r0 < nregions; r0 += batch) {
+            const uint32_t nr = nregions - r0 < batch ? nregions - r0 : batch;
+            HIPCHK(lz77k_match(c.in.as<uint8_t>(), n32, g, r0, nr, c.ps.as<uint32_t>(), c.maxlen.as<uint8_t>(),
+                               c.scratch.p, variant, s));
+            g_stats.match_launches++;
+        }
+        HIPCHK(hipEventRecord(c.ev[1], s));
+
+        /* -- intermediates to the host -- */
+        HIPCHK(hipMemcpyAsync(c.h_maxlen.p, c.maxlen.p, n, hipMemcpyDeviceToHost, s));
+        const size_t nx = n > (size_t)g.sb ? n - (size_t)g.sb : 0;     /* evicted positions */
+        if (nx) HIPCHK(hipMemcpyAsync(c.h_ps.p, c.ps.p, nx * 4, hipMemcpyDeviceToHost, s));
+        HIPCHK(hipStreamSynchronize(s));
+        const double t_host0 = now_ms();
+
+        /* -- sequential host stage -- */
+        size_t ntok_sz = 0;
+        lz77x_host_chain(c.h_maxlen.as<uint8_t>(), n, 0, c.h_chain.as<uint32_t>(), &ntok_sz);
+        ntok = (uint32_t)ntok_sz;
+        const double t_host1 = now_ms();
+        lz77x_prio_state st;
+        if (!lz77x_prio_init(&st, g.sb)) return LZ77X_E_NOMEM;
+        lz77x_prio_run(&st, c.h_ps.as<uint32_t>(), g.sb, n, c.h_xval.as<uint32_t>());
+        transfers = st.transfers;
+        lz77x_prio_free(&st);
+        const double t_host2 = now_ms();
+        g_stats.host_chain_ms = t_host1 - t_host0;
+        g_stats.host_stageb_ms = t_host2 - t_host1;
+
+        /* -- back to the device: tie-break + pack -- */
+        if ((rc = c.xval.need((n + 8) * 4))) return rc;
+        if ((rc = c.chain.need(((size_t)ntok + 8) * 4))) return rc;
+        if ((rc = c.ofs.need((n + 8) * 4))) return rc;
+        if ((rc = c.ent.need((transfers + 8) * 8))) return rc;
+        if ((rc = c.tokval.need(((size_t)ntok + 8) * 4))) return rc;
+        if ((rc = c.scantmp.need(lz77k_scan_tmp_bytes(n32 + 1)))) return rc;
+        if (nx) HIPCHK(hipMemcpyAsync(c.xval.p, c.h_xval.p, nx * 4, hipMemcpyHostToDevice, s));
+        HIPCHK(hipMemcpyAsync(c.chain.p, c.h_chain.p, (size_t)ntok * 4, hipMemcpyHostToDevice, s));
+        HIPCHK(hipEventRecord(c.ev[2], s));
+        HIPCHK(lz77k_xfer_index(c.ps.as<uint32_t>(), c.xval.as<uint32_t>(), (uint32_t)nx, n32, c.ofs.as<uint32_t>(),
+                                c.ent.as<uint2>(), c.scantmp.p, s));
+        HIPCHK(lz77k_tokens(c.in.as<uint8_t>(), n32, g, c.chain.as<uint32_t>(), ntok, c.maxlen.as<uint8_t>(),
+                            c.ofs.as<uint32_t>(), c.ent.as<uint2>(), c.tokval.as<uint32_t>(), s));
+    } else {
+        if ((rc = c.tokval.need(64))) return rc;
+        HIPCHK(hipEventRecord(c.ev[0], s));
+        HIPCHK(hipEventRecord(c.ev[1], s));
+        HIPCHK(hipEventRecord(c.ev[2], s));
+    }
+    *zn = stream_bytes(ntok, g.T);
+    const uint64_t nwords = (*zn + 3) / 4;
+    if ((rc = c.out.need(nwords * 4 + 16))) return rc;
+    HIPCHK(lz77k_pack(c.tokval.as<uint32_t>(), ntok, g, c.out.as<uint32_t>(), nwords, s));
+    HIPCHK(hipEventRecord(c.ev[3], s));
+    HIPCHK(hipStreamSynchronize(s));
+
+    float ms = 0;
+    HIPCHK(hipEventElapsedTime(&ms, c.ev[0], c.ev[1]));
+    g_stats.k_match_ms = ms;
+    HIPCHK(hipEventElapsedTime(&ms, c.ev[2], c.ev[3]));
+    g_stats.k_token_ms = ms;
+    g_stats.n = n;
+    g_stats.zn = *zn;
+    g_stats.ntok = ntok;
+    g_stats.transfers = transfers;
+    g_stats.total_ms = now_ms() - t_begin;
+    g_stats.copy_ms = g_stats.total_ms - g_stats.k_match_ms - g_stats.k_token_ms - g_stats.host_chain_ms - g_stats.host_stageb_ms;
+    return LZ77X_OK;
+}
+
+/* ---------------------------------------------------------------- decode ------------ */
+
+/* Stream must already be in c.z (device, padded).  Computes geometry and decoded size;
+ * when want_data the decoded bytes end up in c.out. */
+int decode_core(Ctx &c, size_t zn, hipStream_t s, bool want_data, size_t *n_out)
+{
+    const double t_begin = now_ms();
+    memset(&g_stats, 0, sizeof g_stats);
+    if (zn < 4) return LZ77X_E_FORMAT;
+    int rc;
+    if ((rc = c.h_small.need(64))) return rc;
+    uint8_t *hdr = c.h_small.as<uint8_t>();
+    HIPCHK(hipMemcpyAsync(hdr, c.z.p, 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    const int sb = hdr[0] | (hdr[1] << 8), la = hdr[2] | (hdr[3] << 8);       /* lz77.c:157-158 */
+    if (sb < 1 || la < 1) return LZ77X_E_FORMAT;
+    lz77x_geom g;
+    lz77x_make_geom(&g, sb, la);
+    const uint64_t ntok64 = ((uint64_t)zn * 8 - 32) / (uint64_t)g.T;          /* lz77.c:271: short read = EOF */
+    if (ntok64 > LZ77X_MAX_N) return LZ77X_E_TOOBIG;
+    const uint32_t ntok = (uint32_t)ntok64;
+
+    uint64_t n = 0;
+    HIPCHK(hipEventRecord(c.ev[0], s));
+    if (ntok) {
+        if ((rc = c.tokval.need(((size_t)ntok + 8) * 4))) return rc;
+        if ((rc = c.len1.need(((size_t)ntok + 8) * 4))) return rc;
+        if ((rc = c.dst.need(((size_t)ntok + 8) * 4))) return rc;
+        if ((rc = c.scantmp.need(lz77k_scan_tmp_bytes(ntok + 1)))) return rc;
+        HIPCHK(lz77k_dec_parse(c.z.as<uint8_t>(), ntok, g, c.tokval.as<uint32_t>(), c.len1.as<uint32_t>(), s));
+        HIPCHK(hipMemsetAsync(c.len1.as<uint32_t>() + ntok, 0, 4, s));
+        /* decoded size can exceed 32 bits for hostile streams: bound it before trusting the scan */
+        if ((uint64_t)ntok * ((1u << g.lb)) > LZ77X_MAX_N) {
+            /* exact check with a 64-bit host sum of a strided sample is not sound; do it fully */
+            PinBuf tmp;
+            if ((rc = tmp.need((size_t)ntok * 4))) return rc;
+            HIPCHK(hipMemcpyAsync(tmp.p, c.len1.p, (size_t)ntok * 4, hipMemcpyDeviceToHost, s));
+            HIPCHK(hipStreamSynchronize(s));
+            uint64_t tot = 0;
+            const uint32_t *l = tmp.as<uint32_t>();
+            for (uint32_t k = 0; k < ntok; k++) tot += l[k];
+            hipError_t e0 = hipHostFree(tmp.p); (void)e0;
+            if (tot > LZ77X_MAX_N) return LZ77X_E_TOOBIG;
+        }
+        HIPCHK(lz77k_scan_u32(c.len1.as<uint32_t>(), c.dst.as<uint32_t>(), ntok + 1, c.scantmp.p, s));
+        uint32_t *tot = reinterpret_cast<uint32_t *>(hdr + 16);
+        HIPCHK(hipMemcpyAsync(tot, c.dst.as<uint32_t>() + ntok, 4, hipMemcpyDeviceToHost, s));
+        HIPCHK(hipStreamSynchronize(s));
+        n = *tot;
+    }
+    *n_out = (size_t)n;
+    uint32_t rounds = 0;
+    if (want_data && n) {
+        const uint32_t n32 = (uint32_t)n;
+        if ((rc = c.out.need(n + 16))) return rc;
+        if ((rc = c.ptr.need((n + 8) * 4))) return rc;
+        if ((rc = c.flag.need(64))) return rc;
+        HIPCHK(lz77k_dec_expand(c.tokval.as<uint32_t>(), c.dst.as<uint32_t>(), ntok, g, c.out.as<uint8_t>(),
+                                c.ptr.as<uint32_t>(), n32, s));
+        uint32_t *hflag = reinterpret_cast<uint32_t *>(hdr + 32);
+        for (;;) {
+            HIPCHK(hipMemsetAsync(c.flag.p, 0, 4, s));
+            HIPCHK(lz77k_dec_jump(c.ptr.as<uint32_t>(), n32, c.flag.as<uint32_t>(), s));
+            HIPCHK(lz77k_dec_jump(c.ptr.as<uint32_t>(), n32, c.flag.as<uint32_t>(), s));
+            rounds += 2;
+            HIPCHK(hipMemcpyAsync(hflag, c.flag.p, 4, hipMemcpyDeviceToHost, s));
+            HIPCHK(hipStreamSynchronize(s));
+            if (!*hflag || rounds > 80) break;
+        }
+        HIPCHK(lz77k_dec_gather(c.out.as<uint8_t>(), c.ptr.as<uint32_t>(), n32, s));
+    }
+    HIPCHK(hipEventRecord(c.ev[1], s));
+    HIPCHK(hipStreamSynchronize(s));
+    float ms = 0;
+    HIPCHK(hipEventElapsedTime(&ms, c.ev[0], c.ev[1]));
+    g_stats.k_decode_ms = ms;
+    g_stats.n = n;
+    g_stats.zn = zn;
+    g_stats.ntok = ntok;
+    g_stats.decode_rounds = rounds;
+    g_stats.total_ms = now_ms() - t_begin;
+    g_stats.copy_ms = g_stats.total_ms - g_stats.k_decode_ms;
+    return LZ77X_OK;
+}
+
+int load_stream(Ctx &c, const void *src, bool on_device, size_t zn, hipStream_t s)
+{
+    int rc;
+    if ((rc = c.z.need(zn + 32))) return rc;
+    HIPCHK(hipMemsetAsync(c.z.as<uint8_t>() + zn, 0, 32, s));
+    if (zn) HIPCHK(hipMemcpyAsync(c.z.p, src, zn, on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, s));
+    return LZ77X_OK;
+}
+
+}  // namespace
+
+/* ==================================================================== C ABI ========= */
+
+extern "C" {
+
+size_t lz77x_encode_bound(size_t n, int sb, int la)
+{
+    if (check_geom(sb, la) != LZ77X_OK) return 0;
+    lz77x_geom g;
+    lz77x_make_geom(&g, sb, la);
+    return stream_bytes(n, g.T);
+}
+
+int lz77x_encode(const uint8_t *in, size_t n, int sb, int la, uint8_t **out, size_t *out_n)
+{
+    if (!out || !out_n || (!in && n)) return LZ77X_E_ARG;
+    int rc = check_geom(sb, la);
+    if (rc) return rc;
+    std::lock_guard<std::mutex> lk(g_mu);
+    if ((rc = ctx_init(g_ctx))) return rc;
+    lz77x_geom g;
+    lz77x_make_geom(&g, sb, la);
+    size_t zn = 0;
+    if ((rc = encode_core(g_ctx, in, false, n, g, g_ctx.stream, &zn))) return rc;
+    uint8_t *buf = (uint8_t *)malloc(zn ? zn : 1);
+    if (!buf) return LZ77X_E_NOMEM;
+    HIPCHK(hipMemcpy(buf, g_ctx.out.p, zn, hipMemcpyDeviceToHost));
+    *out = buf;
+    *out_n = zn;
+    return LZ77X_OK;
+}
+
+int lz77x_encode_device(const void *d_in, size_t n, int sb, int la, void *d_out, size_t out_cap, size_t *out_n, void *stream)
+{
+    if (!out_n || (!d_in && n) || !d_out) return LZ77X_E_ARG;
+    int rc = check_geom(sb, la);
+    if (rc) return rc;
+    std::lock_guard<std::mutex> lk(g_mu);
+    if ((rc = ctx_init(g_ctx))) return rc;
+    lz77x_geom g;
+    lz77x_make_geom(&g, sb, la);
+    hipStream_t s = (hipStream_t)stream;
+    size_t zn = 0;
+    if ((rc = encode_core(g_ctx, d_in, true, n, g, s, &zn))) return rc;
+    *out_n = zn;
+    if (zn > out_cap) return LZ77X_E_CAP;
+    HIPCHK(hipMemcpyAsync(d_out, g_ctx.out.p, zn, hipMemcpyDeviceToDevice, s));
+    HIPCHK(hipStreamSynchronize(s));
+    return LZ77X_OK;
+}
+
+int lz77x_decode(const uint8_t *z, size_t zn, uint8_t **out, size_t *out_n)
+{
+    if (!out || !out_n || (!z && zn)) return LZ77X_E_ARG;
+    std::lock_guard<std::mutex> lk(g_mu);
+    int rc;
+    if ((rc = ctx_init(g_ctx))) return rc;
+    if (zn < 4) return LZ77X_E_FORMAT;
+    if ((rc = load_stream(g_ctx, z, false, zn, g_ctx.stream))) return rc;
+    size_t n = 0;
+    if ((rc = decode_core(g_ctx, zn, g_ctx.stream, true, &n))) return rc;
+    uint8_t *buf = (uint8_t *)malloc(n ? n : 1);
+    if (!buf) return LZ77X_E_NOMEM;
+    if (n) HIPCHK(hipMemcpy(buf, g_ctx.out.p, n, hipMemcpyDeviceToHost));
+    *out = buf;
+    *out_n = n;
+    return LZ77X_OK;
+}
+
+int lz77x_decode_device(const void *d_z, size_t zn, void *d_out, size_t out_cap, size_t *out_n, void *stream)
+{
+    if (!out_n || (!d_z && zn)) return LZ77X_E_ARG;
+    std::lock_guard<std::mutex> lk(g_mu);
+    int rc;
+    if ((rc = ctx_init(g_ctx))) return rc;
+    if (zn < 4) return LZ77X_E_FORMAT;
+    hipStream_t s = (hipStream_t)stream;
+    if ((rc = load_stream(g_ctx, d_z, true, zn, s))) return rc;
+    size_t n = 0;
+    if (!d_out) return decode_core(g_ctx, zn, s, false, out_n);
+    if ((rc = decode_core(g_ctx, zn, s, true, &n))) return rc;
+    *out_n = n;
+    if (n > out_cap) return LZ77X_E_CAP;
+    if (n) HIPCHK(hipMemcpyAsync(d_out, g_ctx.out.p, n, hipMemcpyDeviceToDevice, s));
+    HIPCHK(hipStreamSynchronize(s));
+    return LZ77X_OK;
+}
+
+void lz77x_free(void *p) { free(p); }
+
+int lz77x_set_shards(int shards)
+{
+    if (shards < 1 || shards > 64) return LZ77X_E_ARG;
+    g_shards = shards;
+    return LZ77X_OK;
+}
+
+int lz77x_device_count(void)
+{
+    int nd = 0;
+    if (hipGetDeviceCount(&nd) != hipSuccess) return 0;
+    return nd;
+}
+
+const char *lz77x_strerror(int code)
+{
+    switch (code) {
+    case LZ77X_OK: return "ok";
+    case LZ77X_E_ARG: return "bad argument";
+    case LZ77X_E_NOMEM: return "out of host memory";
+    case LZ77X_E_HIP: return "HIP runtime error";
+    case LZ77X_E_NODEV: return "no MI355X/HIP device available (there is no CPU fallback)";
+    case LZ77X_E_FORMAT: return "not an lz77 stream";
+    case LZ77X_E_CAP: return "output buffer too small";
+    case LZ77X_E_IO: return "I/O error";
+    case LZ77X_E_TOOBIG: return "input too large for one call";
+    default: return "unknown error";
+    }
+}
+
+const char *lz77x_last_error(void) { return g_err; }
+const char *lz77x_version(void) { return "lz77-mi355x 0.1 (gfx950)"; }
+
+int lz77x_last_stats(lz77x_stats *st)
+{
+    if (!st) return LZ77X_E_ARG;
+    *st = g_stats;
+    return LZ77X_OK;
+}
+
+/* ---- stage-level entry points ---- */
+
+static int run_match_only(const uint8_t *in, size_t n, int sb, int la, lz77x_geom *g)
+{
+    int rc = check_geom(sb, la);
+    if (rc) return rc;
+    if ((rc = ctx_init(g_ctx))) return rc;
+    if (n > LZ77X_MAX_N) return LZ77X_E_TOOBIG;
+    lz77x_make_geom(g, sb, la);
+    Ctx &c = g_ctx;
+    hipStream_t s = c.stream;
+    if ((rc = c.in.need(n + LZ77X_PAD + 16))) return rc;
+    if ((rc = c.ps.need((n + 8) * 4))) return rc;
+    if ((rc = c.maxlen.need(n + 8))) return rc;
+    if (n) HIPCHK(hipMemcpyAsync(c.in.p, in, n, hipMemcpyHostToDevice, s));
+    HIPCHK(lz77k_fill_pad(c.in.as<uint8_t>(), (uint32_t)n, s));
+    HIPCHK(hipMemsetAsync(c.ps.p, 0, (n + 8) * 4, s));
+    const uint32_t nregions = (uint32_t)((n + g->TILE - 1) / g->TILE);
+    uint32_t batch = nregions;
+    if (!g->fast && nregions) {
+        const size_t per = lz77k_match_scratch_bytes(*g, 1);
+        batch = (uint32_t)(((size_t)2 << 30) / per);
+        if (batch < 1) batch = 1;
+        if (batch > nregions) batch = nregions;
+        if ((rc = c.scratch.need(lz77k_match_scratch_bytes(*g, batch)))) return rc;
+    }
+    const char *vs = getenv("LZ77X_MATCH_VARIANT");
+    const int variant = vs ? atoi(vs) : 0;
+    for (uint32_t r0 = 0; r0 < nregions; r0 += batch) {
+        const uint32_t nr = nregions - r0 < batch ? nregions - r0 : batch;
+        HIPCHK(lz77k_match(c.in.as<uint8_t>(), (uint32_t)n, *g, r0, nr, c.ps.as<uint32_t>(), c.maxlen.as<uint8_t>(),
+                           c.scratch.p, variant, s));
+    }
+    HIPCHK(hipStreamSynchronize(s));
+    return LZ77X_OK;
+}
+
+int lz77x_stage_maxlen(const uint8_t *in, size_t n, int sb, int la, uint8_t *maxlen)
+{
+    if ((!in || !maxlen) && n) return LZ77X_E_ARG;
+    std::lock_guard<std::mutex> lk(g_mu);
+    lz77x_geom g;
+    int rc = run_match_only(in, n, sb, la, &g);
+    if (rc) return rc;
+    if (n) HIPCHK(hipMemcpy(maxlen, g_ctx.maxlen.p, n, hipMemcpyDeviceToHost));
+    return LZ77X_OK;
+}
+
+int lz77x_stage_neighbours(const uint8_t *in, size_t n, int sb, int la, uint16_t *P, uint16_t *S)
+{
+    if ((!in || !P || !S) && n) return LZ77X_E_ARG;
+    std::lock_guard<std::mutex> lk(g_mu);
+    lz77x_geom g;
+    int rc = run_match_only(in, n, sb, la, &g);
+    if (rc) return rc;
+    if (!n) return LZ77X_OK;
+    uint32_t *tmp = (uint32_t *)malloc(n * 4);
+    if (!tmp) return LZ77X_E_NOMEM;
+    hipError_t e = hipMemcpy(tmp, g_ctx.ps.p, n * 4, hipMemcpyDeviceToHost);
+    if (e != hipSuccess) { free(tmp); HIPCHK(e); }
+    for (size_t i = 0; i < n; i++) { P[i] = (uint16_t)(tmp[i] & 0xFFFF); S[i] = (uint16_t)(tmp[i] >> 16); }
+    free(tmp);
+    return LZ77X_OK;
+}
+
+int lz77x_stage_priorities(const uint16_t *P, const uint16_t *S, size_t n, int sb, uint32_t *xval)
+{
+    if ((!P || !S || !xval) && n) return LZ77X_E_ARG;
+    if (sb < 1 || sb > 65535) return LZ77X_E_ARG;
+    uint32_t *ps = (uint32_t *)malloc((n + 1) * 4);
+    if (!ps) return LZ77X_E_NOMEM;
+    for (size_t i = 0; i < n; i++) { ps[i] = (uint32_t)P[i] | ((uint32_t)S[i] << 16); xval[i] = LZ77X_NONE32; }
+    lz77x_prio_state st;
+    if (!lz77x_prio_init(&st, sb)) { free(ps); return LZ77X_E_NOMEM; }
+    lz77x_prio_run(&st, ps, sb, n, xval);
+    lz77x_prio_free(&st);
+    free(ps);
+    return LZ77X_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,192 @@
+"""GPU parity: the HIP path (through the C ABI) against the oracle and the golden fixtures.
+
+Bit-exact everywhere (integer/byte work).  Run on the GPU box:  pytest -m gpu
+"""
+import hashlib
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import lz77_amd as L
+import oracle_lib as O
+from lz77_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def sha(b) -> str:
+    return hashlib.sha256(bytes(b)).hexdigest()
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _need_gpu():
+    assert os.path.exists(L.LIB_PATH), "HIP extension not built"
+    assert L.lib().lz77x_device_count() > 0, "no HIP device: the product has no CPU fallback"
+
+
+STAGE_CASES = [
+    ("text", 51, 30000, 4095, 15), ("random", 52, 20000, 4095, 15), ("lowent", 53, 20000, 1000, 10),
+    ("mixed", 54, 30000, 255, 7), ("text", 55, 3000, 100, 200), ("lowent", 56, 4000, 5, 3),
+    ("zeros", 0, 9000, 4095, 15), ("code", 57, 20000, 4096, 16), ("text", 58, 12000, 1, 15),
+    ("text", 59, 70000, 4095, 15), ("random", 60, 9000, 3, 2), ("text", 61, 50000, 2048, 31),
+    ("mixed", 62, 140000, 65535, 255), ("lowent", 63, 30000, 8192, 16), ("code", 64, 50000, 8191, 15),
+]
+
+
+@pytest.mark.parametrize("kind,seed,n,sb,la", STAGE_CASES)
+def test_stage_neighbours(kind, seed, n, sb, la):
+    """k_match forward scan == in-order neighbours in the live BST at eviction (tree.c:182)"""
+    data = synth.make(kind, n, seed)
+    P, S, _ = O.stage_a(data, sb, la, tree=True)
+    gP, gS = L.stage_neighbours(data, la, sb)
+    nx = max(n - sb, 0)
+    assert np.array_equal(gP[:nx], P[:nx])
+    assert np.array_equal(gS[:nx], S[:nx])
+
+
+@pytest.mark.parametrize("kind,seed,n,sb,la", STAGE_CASES)
+def test_stage_maxlen_on_chain(kind, seed, n, sb, la):
+    """k_match backward scan == find()'s length at every parse-chain position (tree.c:118-152)"""
+    data = synth.make(kind, n, seed)
+    z = O.encode_bst(data, sb, la)
+    _, _, off, ln, nx = O.tokens(z)
+    ml = L.stage_maxlen(data, la, sb)
+    chain = np.concatenate([[0], np.cumsum(ln + 1)[:-1]]).astype(np.int64)
+    assert np.array_equal(ml[chain], ln.astype(np.uint8))
+
+
+@pytest.mark.parametrize("kind,seed,n,sb,la", STAGE_CASES[:9])
+def test_stage_maxlen_everywhere(kind, seed, n, sb, la):
+    data = synth.make(kind, n, seed)
+    assert np.array_equal(L.stage_maxlen(data, la, sb), O.maxlen(data, sb, la))
+
+
+@pytest.mark.parametrize("kind,seed,n,sb,la", STAGE_CASES[:6])
+def test_masked_variant_agrees(kind, seed, n, sb, la, monkeypatch):
+    """the all-masked pair loop (self-check build of the kernel) gives the same arrays"""
+    data = synth.make(kind, n, seed)
+    a = L.stage_neighbours(data, la, sb), L.stage_maxlen(data, la, sb)
+    monkeypatch.setenv("LZ77X_MATCH_VARIANT", "1")
+    b = L.stage_neighbours(data, la, sb), L.stage_maxlen(data, la, sb)
+    assert np.array_equal(a[0][0], b[0][0]) and np.array_equal(a[0][1], b[0][1]) and np.array_equal(a[1], b[1])
+
+
+def test_kat(golden):
+    for k in golden["kat"]:
+        data = bytes.fromhex(k["input_hex"])
+        z = bytes.fromhex(k["lz_hex"])
+        assert L.encode(data, k["la"], k["sb"]) == z, (k["name"], k["sb"], k["la"])
+        if k["sb"] & (k["sb"] - 1):
+            assert L.decode(z) == bytes.fromhex(k["decoded_hex"]), (k["name"], k["sb"], k["la"])
+
+
+def test_defaults_match_reference_defaults():
+    data = b"abracadabra abracadabra abracadabra"
+    assert L.encode(data) == L.encode(data, 15, 4095) == O.encode_bst(data, 4095, 15)   # lz77.c:21-22
+
+
+def test_grid(golden):
+    for g in golden["grid"]:
+        data = synth.make(g["kind"], g["n"], g["seed"])
+        z = L.encode(data, g["la"], g["sb"])
+        assert len(z) == g["zn"] and sha(z) == g["sha256_lz"], g
+        if g["sb"] & (g["sb"] - 1):
+            assert L.decode(z) == data.tobytes(), g
+
+
+def test_small_files(golden, golden_dir):
+    for s in golden["small"]:
+        data = np.fromfile(os.path.join(golden_dir, s["stem"] + ".bin"), dtype=np.uint8)
+        z = open(os.path.join(golden_dir, s["stem"] + ".lz"), "rb").read()
+        assert L.encode(data, s["la"], s["sb"]) == z, s["stem"]
+        assert L.decode(z) == data.tobytes(), s["stem"]
+
+
+def test_bulk(golden):
+    for b in golden["bulk"]:
+        data = synth.make(b["kind"], b["n"], b["seed"])
+        assert sha(data) == b["sha256_in"]
+        z = L.encode(data, b["la"], b["sb"])
+        assert len(z) == b["zn"] and sha(z) == b["sha256_lz"], b
+        if b["sb"] & (b["sb"] - 1):
+            assert L.decode(z) == data.tobytes(), b
+
+
+def test_truncated_stream(golden_dir):
+    z = open(os.path.join(golden_dir, "small_text_4095_15.lz"), "rb").read()
+    for cut in (1, 2, 3, 5):
+        assert L.decode(z[:-cut]) == O.decode(z[:-cut])                    # lz77.c:271-280
+    assert L.decode(z[:4]) == b""
+    with pytest.raises(L.Lz77Error):
+        L.decode(z[:3])
+
+
+def test_foreign_streams_decode():
+    """legal streams no reference encoder would emit: deep copy chains, off<len overlap, off>pos"""
+    import struct
+    def stream(tokens, sb=4095, la=15):
+        out = bytearray(struct.pack("<HH", sb, la))
+        for off, ln, ch in tokens:
+            v = off | (ln << 12) | (ch << 16)
+            out += struct.pack("<I", v)[:3]
+        return bytes(out)
+    toks = [(0, 0, 65)] + [(1, 14, 66)] * 50 + [(15, 14, 67)] * 400 + [(3000, 5, 68), (0, 3, 69)]
+    z = stream(toks)
+    assert L.decode(z) == O.decode(z)
+
+
+def test_roundtrip_properties_large():
+    """size-independent properties at a size the oracle would not finish quickly"""
+    data = synth.text(48 << 20, 0x5EED0001)
+    z = L.encode(data)
+    st = L.last_stats()
+    assert st["n"] == data.size and st["zn"] == len(z)
+    assert (len(z) - 4) * 8 // 24 == st["ntok"]
+    back = L.decode(z)
+    assert sha(back) == sha(data)
+    # prefix property: the stream of a prefix is a prefix of the stream up to the tokens that see EOF
+    z2 = L.encode(data[: 8 << 20])
+    common = os.path.commonprefix([z, z2])
+    assert len(common) >= len(z2) - 3 * 16
+
+
+def test_arg_errors():
+    for la, sb in ((1, 4095), (256, 4095), (15, 0), (15, 65536)):
+        with pytest.raises(L.Lz77Error) as e:
+            L.encode(b"hello", la, sb)
+        assert e.value.code == -1
+
+
+def test_cli_roundtrip(tmp_path, golden_dir):
+    """README.md:25-40 usage: -c then -d restores the file; stream equals the reference's"""
+    src = os.path.join(golden_dir, "small_text_4095_15.bin")
+    lz = str(tmp_path / "a.lz")
+    out = str(tmp_path / "a.out")
+    r = subprocess.run([L.CLI_PATH, "-c", "-i", src, "-o", lz], capture_output=True)
+    assert r.returncode == 0 and r.stdout == b"" and r.stderr == b""
+    assert open(lz, "rb").read() == open(os.path.join(golden_dir, "small_text_4095_15.lz"), "rb").read()
+    r = subprocess.run([L.CLI_PATH, "-d", "-i", lz, "-o", out], capture_output=True)
+    assert r.returncode == 0 and r.stdout == b"" and r.stderr == b""
+    assert open(out, "rb").read() == open(src, "rb").read()
+    r = subprocess.run([L.CLI_PATH, "-c", "-i", src, "-o", lz, "-s", "1000", "-l", "10"], capture_output=True)
+    assert r.returncode == 0
+    assert open(lz, "rb").read() == O.encode_bst(np.fromfile(src, dtype=np.uint8), 1000, 10)
+
+
+def test_device_api_with_torch():
+    import torch
+    data = synth.text(3 << 20, 77)
+    d_in = torch.from_numpy(data).cuda()
+    cap = L.encode_bound(data.size)
+    d_out = torch.empty(cap, dtype=torch.uint8, device="cuda")
+    stream = torch.cuda.current_stream().cuda_stream
+    zn = L.encode_device(d_in.data_ptr(), data.size, d_out.data_ptr(), cap, stream=stream)
+    z = d_out[:zn].cpu().numpy().tobytes()
+    assert z == O.encode_bst(data)
+    n = L.decoded_size_device(d_out.data_ptr(), zn, stream=stream)
+    assert n == data.size
+    d_back = torch.empty(n, dtype=torch.uint8, device="cuda")
+    assert L.decode_device(d_out.data_ptr(), zn, d_back.data_ptr(), n, stream=stream) == n
+    assert torch.equal(d_back, d_in)
