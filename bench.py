@@ -1,0 +1,196 @@
+#!/usr/bin/env python3
+"""bench.py -- encode+decode throughput of the LZ77 hot path on N MI355X GPUs.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+           --master-port P bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json configs[1]; the real enwik8 is not available offline): the S1
+"enwik8-like" synthetic text stream, 100,000,000 bytes, s=4095 l=15.  One step = encode
+that stream and decode the result, inputs and outputs resident in HBM.  With N>1 every
+rank owns an independent stream of the same size (seed + rank): chunks shard with no
+data-path collective, so scaling is weak; `value` is the whole-job rate
+N * bytes * K / max-over-ranks wall time.
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import subprocess
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def cpu_baseline(data, sb, la, budget_bytes):
+    """Reference CPU encode()+decode() timed on this host, single thread, bounded sample."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib as O
+    sample = data[:budget_bytes]
+    n = int(sample.size)
+    if O.have_ref():
+        kind = "reference"
+        tmp = "/dev/shm" if os.path.isdir("/dev/shm") else "/tmp"
+        fin, flz, fout = (os.path.join(tmp, "lz77bench_%d.%s" % (os.getpid(), e)) for e in ("in", "lz", "out"))
+        sample.tofile(fin)
+        try:
+            t0 = time.perf_counter()
+            subprocess.check_call([O.REF_BIN, "-c", "-i", fin, "-o", flz, "-s", str(sb), "-l", str(la)])
+            t1 = time.perf_counter()
+            subprocess.check_call([O.REF_BIN, "-d", "-i", flz, "-o", fout])
+            t2 = time.perf_counter()
+        finally:
+            for p in (fin, flz, fout):
+                if os.path.exists(p):
+                    os.unlink(p)
+    else:
+        kind = "port"
+        O.lib()
+        t0 = time.perf_counter()
+        z = O.encode_bst(sample, sb, la)
+        t1 = time.perf_counter()
+        O.decode(z)
+        t2 = time.perf_counter()
+    return {"value": round(n / (t2 - t0) / 1e6, 3), "unit": "MB/s", "cores": 1, "kind": kind,
+            "sample": "first %d bytes of the same S1 stream, encode then decode, single thread" % n,
+            "encode_MBps": round(n / (t1 - t0) / 1e6, 3), "decode_MBps": round(n / (t2 - t1) / 1e6, 3),
+            "host": _cpu_model()}
+
+
+def _cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return "%s (%d logical cpus)" % (line.split(":", 1)[1].strip(), os.cpu_count())
+    except OSError:
+        pass
+    return "unknown"
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--bytes", type=int, default=100_000_000)
+    ap.add_argument("--sb", type=int, default=4095)
+    ap.add_argument("--la", type=int, default=15)
+    ap.add_argument("--kind", default="text")
+    ap.add_argument("--cpu-sample", type=int, default=32_000_000)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    a = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the product has no CPU fallback")
+    torch.cuda.set_device(local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    import lz77_amd as L
+    from lz77_amd import synth
+
+    n = a.bytes
+    data = synth.make(a.kind, n, synth.SEED_S1 + rank)
+    d_in = torch.from_numpy(data).cuda()
+    cap = L.encode_bound(n, a.la, a.sb)
+    d_z = torch.empty(cap, dtype=torch.uint8, device="cuda")
+    d_back = torch.empty(n, dtype=torch.uint8, device="cuda")
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def step():
+        zn = L.encode_device(d_in.data_ptr(), n, d_z.data_ptr(), cap, a.la, a.sb, stream)
+        se = L.last_stats()
+        m = L.decode_device(d_z.data_ptr(), zn, d_back.data_ptr(), n, stream)
+        sd = L.last_stats()
+        assert m == n
+        return zn, se, sd
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    enc_stats, dec_stats = [], []
+    zn = 0
+    for _ in range(a.steps):
+        zn, se, sd = step()
+        enc_stats.append(se)
+        dec_stats.append(sd)
+    barrier()
+    dt = time.perf_counter() - t0
+    ok = bool(torch.equal(d_back, d_in))                 # round trip checked outside the timed region
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+        okt = torch.tensor([1 if ok else 0], device="cuda")
+        dist.all_reduce(okt, op=dist.ReduceOp.MIN)
+        ok = bool(okt.item())
+
+    if rank == 0:
+        K = max(a.steps, 1)
+        mean = lambda xs, k: sum(x[k] for x in xs) / max(len(xs), 1)
+        k_match_ms = mean(enc_stats, "k_match_ms")
+        launches = max(int(mean(enc_stats, "match_launches")), 1)
+        alg_bytes = n + zn                                # encode reads n, writes zn
+        achieved = alg_bytes / launches / (k_match_ms / launches * 1e-3) / 1e9 if k_match_ms > 0 else 0.0
+        traffic = None
+        tfile = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tfile):
+            try:
+                traffic = json.load(open(tfile)).get("k_match_hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "encode+decode MB/s on enwik8-like synthetic text, s=%d l=%d" % (a.sb, a.la),
+            "value": round(world * n * K / dt / 1e6, 3),
+            "unit": "MB/s",
+            "n_gpus": world,
+            "steps": a.steps,
+            "warmup": a.warmup,
+            "ms_per_step": round(dt / K * 1e3, 3),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "u8",
+            "data": "synthetic",
+            "config": {"workload": "S1 enwik8-like text (lz77_amd.synth.text, seed 0x5EED0001+rank), %d bytes per GPU, "
+                                   "s=%d l=%d; step = encode then decode, buffers resident in HBM" % (n, a.sb, a.la),
+                       "bytes_per_gpu": n, "sb": a.sb, "la": a.la, "parallelism": "independent stream per GPU"},
+            "roofline": {"bound": "hbm", "kernel": "k_match", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic,
+                         "algorithmic_bytes_per_launch": alg_bytes // launches,
+                         "kernel_ms_per_launch": round(k_match_ms / launches, 3)},
+            "roundtrip_ok": ok,
+            "ratio": round(zn / n, 4),
+            "encode_MBps": round(n / (mean(enc_stats, "total_ms") * 1e-3) / 1e6, 2),
+            "decode_MBps": round(n / (mean(dec_stats, "total_ms") * 1e-3) / 1e6, 2),
+            "encode_breakdown_ms": {k: round(mean(enc_stats, k), 2) for k in
+                                    ("total_ms", "k_match_ms", "k_token_ms", "host_chain_ms", "host_stageb_ms", "copy_ms")},
+            "decode_breakdown_ms": {k: round(mean(dec_stats, k), 2) for k in ("total_ms", "k_decode_ms")},
+        }
+        if world == 1 and not a.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(data, a.sb, a.la, min(a.cpu_sample, n))
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -90,6 +90,14 @@ def lib():
     if _lib is None:
         if not os.path.exists(LIB_PATH):
             raise Lz77Error(-4, "liblz77_mi355x.so is not built (run `python -c 'import __graft_entry__ as g; g.build()'`)")
+        # torch ships its own libamdhip64.so.7; whichever HIP runtime is mapped first serves the
+        # whole process, and device pointers are only shareable within ONE runtime.  Let torch
+        # (the memory/stream plumbing of tests and bench.py) map its copy before we bind ours.
+        if os.environ.get("LZ77X_NO_TORCH") != "1":
+            try:
+                import torch  # noqa: F401
+            except Exception:
+                pass
         L = ctypes.CDLL(LIB_PATH)
         for name, (res, args) in SYMBOLS.items():
             fn = getattr(L, name)
