@@ -1,0 +1,168 @@
+"""CPU-side checks of the product: the C ABI loads and exports what the header declares,
+host-only entry points agree with the oracle, the CLI keeps the reference's contract
+ and the multi-rank plan is consistent (gloo, world_size 2).  No kernels run."""
+import ctypes
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import lz77_amd as L
+import oracle_lib as O
+from lz77_amd import shard, synth
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+NO_GPU = L.lib().lz77x_device_count() == 0
+
+
+def test_header_symbols_all_exported():
+    hdr = open(os.path.join(ROOT, "include", "lz77_mi355x.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(lz77x_[a-z_0-9]+)\s*\(", hdr))
+    assert declared == set(L.SYMBOLS), declared ^ set(L.SYMBOLS)
+    raw = ctypes.CDLL(L.LIB_PATH)
+    for name in declared:
+        assert getattr(raw, name) is not None
+
+
+def test_library_is_the_hip_build():
+    out = subprocess.run(["ldd", L.LIB_PATH], capture_output=True, text=True).stdout
+    assert "libamdhip64" in out
+    blob = open(L.LIB_PATH, "rb").read()
+    assert b"gfx950" in blob                    # embedded code object target
+    assert b"lz77o_" not in blob                # the oracle is not linked into the product
+
+
+def test_strerror_and_version():
+    lib = L.lib()
+    assert lib.lz77x_version().startswith(b"lz77-mi355x")
+    assert lib.lz77x_strerror(0) == b"ok"
+    assert b"no CPU fallback" in lib.lz77x_strerror(-4)
+
+
+def test_encode_bound_formula():
+    for sb, la, n in ((4095, 15, 0), (4095, 15, 1), (4095, 15, 1000), (65535, 255, 12345), (1000, 10, 7), (255, 7, 9)):
+        T = O.bitof(sb) + O.bitof(la) + 8
+        assert L.encode_bound(n, la, sb) == 4 + (n * T + 7) // 8
+    assert L.encode_bound(5) == 4 + 15                               # defaults 15/4095 -> 24-bit tokens
+    assert L.encode_bound(5, 1, 4095) == 0 and L.encode_bound(5, 15, 0) == 0
+
+
+@pytest.mark.skipif(not NO_GPU, reason="only meaningful without a GPU")
+def test_no_cpu_fallback():
+    with pytest.raises(L.Lz77Error) as e:
+        L.encode(b"abracadabra")
+    assert e.value.code == -4
+    with pytest.raises(L.Lz77Error) as e:
+        L.decode(bytes.fromhex("ff0f0f00000061"))
+    assert e.value.code == -4
+
+
+@pytest.mark.parametrize("kind,seed,n,sb,la", [("text", 71, 60000, 4095, 15), ("random", 72, 30000, 1000, 10),
+                                              ("lowent", 73, 40000, 255, 7), ("zeros", 0, 20000, 4095, 15)])
+def test_host_priority_stage_matches_oracle(kind, seed, n, sb, la):
+    """hoststage.c lz77x_prio_run (ring buffer, branchless) == oracle stage B == live BST"""
+    data = synth.make(kind, n, seed)
+    P, S, two = O.stage_a(data, sb, la, tree=True)
+    xv = L.stage_priorities(P, S, sb)
+    assert np.array_equal(xv, O.stage_b(P, S, sb))
+    nx = max(n - sb, 0)
+    assert np.array_equal(xv[:nx] != 0xFFFFFFFF, two[:nx].astype(bool))
+
+
+def test_geometry_mirror():
+    for sb, la in ((4095, 15), (65535, 255), (1, 2), (5, 3), (1000, 10), (4096, 16), (8191, 15), (8192, 16)):
+        g = shard.geometry(sb, la)
+        assert g["T"] == O.token_bits(sb, la)
+        assert g["TILE"] % 4 == 0 and g["TILE"] >= 4 and g["TILE"] + g["SBu"] + sb <= g["RP"]
+        assert g["RP"] & (g["RP"] - 1) == 0
+    assert shard.geometry(4095, 15)["TILE"] == 8192 and shard.geometry(4095, 15)["fast"]
+    assert not shard.geometry(65535, 255)["fast"]
+
+
+# ---- CLI contract (main.c:59-180 of the reference; none of these reach the device) ----
+
+def cli(*args):
+    r = subprocess.run([L.CLI_PATH, *args], capture_output=True, text=True)
+    return r.returncode, r.stdout, r.stderr
+
+
+def test_cli_messages(tmp_path):
+    f = str(tmp_path / "in")
+    open(f, "wb").write(b"hello")
+    o = str(tmp_path / "out")
+    assert cli("-c", "-o", o) == (1, "", "Input file must be provided\n")
+    assert cli("-c", "-i", f) == (1, "", "Output file must be provided\n")
+    assert cli("-i", f, "-o", o) == (1, "", "Select ENCODE or DECODE mode\n")
+    assert cli("-c", "-i", f, "-i", f, "-o", o) == (1, "", "Multiple input files not allowed.\n")
+    assert cli("-c", "-i", f, "-o", o, "-o", o) == (1, "", "Multiple output files not allowed.\n")
+    for bad in ("1", "256", "abc", "-3"):
+        assert cli("-c", "-i", f, "-o", o, "-l", bad) == (1, "", "Bad lookahead size value.\n")
+    for bad in ("65536", "-1", "0"):
+        assert cli("-c", "-i", f, "-o", o, "-s", bad) == (1, "", "Bad search-buffer size value.\n")
+    rc, out, err = cli("-c", "-i", str(tmp_path / "missing"), "-o", o)
+    assert rc == 1 and out == "" and err.startswith("Opening input file: ")
+    rc, out, err = cli("-c", "-i", f, "-o", str(tmp_path / "nodir" / "x"))
+    assert rc == 1 and err.startswith("Opening output file: ")
+    rc, out, err = cli("-h")
+    assert rc == 1 and out.startswith("Usage: lz77 <options>\n") and out.count("\n") == 9
+    assert err == "Input file must be provided\n"
+
+
+@pytest.mark.skipif(not O.have_ref(), reason="compiled reference only in the build container")
+def test_cli_messages_equal_reference(tmp_path):
+    f = str(tmp_path / "in")
+    open(f, "wb").write(b"hello")
+    o = str(tmp_path / "out")
+    for args in (["-c", "-o", o], ["-c", "-i", f], ["-i", f, "-o", o], ["-c", "-i", f, "-i", f, "-o", o],
+                 ["-c", "-i", f, "-o", o, "-l", "1"], ["-c", "-i", f, "-o", o, "-s", "70000"], ["-h"],
+                 ["-c", "-i", str(tmp_path / "missing"), "-o", o]):
+        a = subprocess.run([O.REF_BIN, *args], capture_output=True, text=True)
+        b = subprocess.run([L.CLI_PATH, *args], capture_output=True, text=True)
+        assert (a.returncode, a.stdout, a.stderr) == (b.returncode, b.stdout, b.stderr), args
+
+
+# ---- multi-rank plan (gloo, 2 processes) ------------------------------------------------
+
+_WORKER = r"""
+import os, sys
+sys.path.insert(0, %(root)r)
+import torch, torch.distributed as dist
+from lz77_amd import shard
+dist.init_process_group("gloo")
+rank, world = dist.get_rank(), dist.get_world_size()
+n, sb, la = 100_000_037, 4095, 15
+plan = shard.plan_positions(n, world, sb, la)
+mine = plan[rank]
+sizes = torch.tensor([mine.end - mine.begin, mine.nregions], dtype=torch.int64)
+allsz = [torch.zeros(2, dtype=torch.int64) for _ in range(world)]
+dist.all_gather(allsz, sizes)
+assert sum(int(s[0]) for s in allsz) == n
+g = shard.geometry(sb, la)
+assert sum(int(s[1]) for s in allsz) == (n + g["TILE"] - 1) // g["TILE"]
+for a, b in zip(plan, plan[1:]):
+    assert a.end == b.begin and a.region0 + a.nregions == b.region0
+assert mine.halo_begin <= mine.begin and mine.halo_end >= mine.end
+assert mine.begin - mine.halo_begin in (0, g["SBu"]) and mine.halo_end - mine.end <= sb + la
+seeds = [shard.stream_seed(0x5EED0001, r) for r in range(world)]
+assert len(set(seeds)) == world
+t = shard.aggregate_time(1.0 + rank, dist)
+assert t == float(world), t
+dist.barrier()
+dist.destroy_process_group()
+print("rank", rank, "ok")
+"""
+
+
+def test_two_rank_plan_gloo(tmp_path):
+    script = tmp_path / "w.py"
+    script.write_text(_WORKER % {"root": ROOT})
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", LZ77X_NO_TORCH="1")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                        "--master-addr", "127.0.0.1", "--master-port", "29541", str(script)],
+                       capture_output=True, text=True, env=env, timeout=240)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert r.stdout.count("ok") == 2
