@@ -96,7 +96,7 @@ typedef struct lz77x_stats {
     double k_decode_ms;       /* parse + scan + copy-resolution kernels */
     double host_chain_ms;     /* greedy parse chain walk (host) */
     double host_stageb_ms;    /* sequential priority recurrence (host) */
-    double copy_ms;           /* H2D + D2H of intermediates, not overlapped part */
+    double copy_ms;           /* host wall time blocked waiting for the device (not overlapped) */
     uint64_t n;               /* uncompressed bytes */
     uint64_t zn;              /* compressed bytes */
     uint64_t ntok;            /* tokens */

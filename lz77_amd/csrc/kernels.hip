@@ -169,7 +169,7 @@ template <> struct acc4<false> {
  *   PACKED : use the unmasked 16-pairs-per-chunk interior loop (else every pair goes through
  *            the masked path: slow, used as an on-device self check).
  */
-template <bool FAST, bool PACKED>
+template <bool FAST, int MODE>
 __global__ __launch_bounds__(MATCH_BLOCK) void k_match(const uint8_t *__restrict__ in, uint32_t n, int sb, int la,
                                                        uint32_t SBu, uint32_t RP, uint32_t TILE, uint32_t region0,
                                                        uint32_t *__restrict__ ps, uint8_t *__restrict__ maxlen,
@@ -178,6 +178,7 @@ __global__ __launch_bounds__(MATCH_BLOCK) void k_match(const uint8_t *__restrict
     typedef typename rank_traits<FAST>::rank_t rank_t;
     constexpr uint32_t HALF = rank_traits<FAST>::HALF;
     constexpr uint32_t RMASK = rank_traits<FAST>::MASK;
+    constexpr bool PACKED = MODE == 0;
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
 
     const uint32_t tid = threadIdx.x;
@@ -232,6 +233,8 @@ __global__ __launch_bounds__(MATCH_BLOCK) void k_match(const uint8_t *__restrict
         if (a < R) rk[a] = (rank_t)r;
     }
     __syncthreads();
+
+    if (MODE == 2) return;                                   /* timing probe: sort + ranks only */
 
     /* ---- pair scan: four consecutive positions per thread, window read in chunks of 4 ---- */
     const uint32_t usb = (uint32_t)sb;
@@ -342,12 +345,12 @@ size_t lz77k_match_scratch_bytes(const lz77x_geom &g, uint32_t nregions)
     return (size_t)nregions * (2 * (size_t)g.RP + 8) * sizeof(uint32_t);
 }
 
-template <bool FAST, bool PACKED>
+template <bool FAST, int MODE>
 static hipError_t launch_match(const uint8_t *d_in, uint32_t n, const lz77x_geom &g, uint32_t region0, uint32_t nregions,
                                uint32_t *d_ps, uint8_t *d_maxlen, void *d_scratch, hipStream_t s)
 {
     const size_t lds = lz77k_match_lds_bytes(g);
-    auto fn = k_match<FAST, PACKED>;
+    auto fn = k_match<FAST, MODE>;
     if (lds > 48 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
@@ -361,12 +364,16 @@ hipError_t lz77k_match(const uint8_t *d_in, uint32_t n, const lz77x_geom &g, uin
                        uint32_t *d_ps, uint8_t *d_maxlen, void *d_scratch, int variant, hipStream_t s)
 {
     if (nregions == 0) return hipSuccess;
+#define LZ77K_MATCH_ARGS d_in, n, g, region0, nregions, d_ps, d_maxlen, d_scratch, s
     if (g.fast) {
-        return variant == 0 ? launch_match<true, true>(d_in, n, g, region0, nregions, d_ps, d_maxlen, d_scratch, s)
-                            : launch_match<true, false>(d_in, n, g, region0, nregions, d_ps, d_maxlen, d_scratch, s);
+        if (variant == 1) return launch_match<true, 1>(LZ77K_MATCH_ARGS);
+        if (variant == 2) return launch_match<true, 2>(LZ77K_MATCH_ARGS);
+        return launch_match<true, 0>(LZ77K_MATCH_ARGS);
     }
-    return variant == 0 ? launch_match<false, true>(d_in, n, g, region0, nregions, d_ps, d_maxlen, d_scratch, s)
-                        : launch_match<false, false>(d_in, n, g, region0, nregions, d_ps, d_maxlen, d_scratch, s);
+    if (variant == 1) return launch_match<false, 1>(LZ77K_MATCH_ARGS);
+    if (variant == 2) return launch_match<false, 2>(LZ77K_MATCH_ARGS);
+    return launch_match<false, 0>(LZ77K_MATCH_ARGS);
+#undef LZ77K_MATCH_ARGS
 }
 
 /* ------------------------------------------------------------------ small utilities -- */
@@ -466,35 +473,41 @@ hipError_t lz77k_scan_u32(const uint32_t *d_in, uint32_t *d_out, uint32_t m, voi
 /* The host stage hands back xval[x] = priority moved from x to its successor S[x] when x is
  * evicted (or NONE).  Group these hand-overs by destination so that k_tokens can ask
  * "what priority did candidate c hold at time p". */
-__global__ void k_xfer_count(const uint32_t *__restrict__ ps, const uint32_t *__restrict__ xval, uint32_t nx, uint32_t *__restrict__ cnt)
+__global__ void k_xfer_count(const uint32_t *__restrict__ ps, const uint32_t *__restrict__ xval, uint32_t xa, uint32_t xb,
+                             uint32_t dbase, uint32_t *__restrict__ cnt)
 {
-    for (uint32_t x = blockIdx.x * blockDim.x + threadIdx.x; x < nx; x += gridDim.x * blockDim.x)
-        if (xval[x] != LZ77X_NONE32) atomicAdd(&cnt[x + (ps[x] >> 16)], 1u);
-}
-
-__global__ void k_xfer_fill(const uint32_t *__restrict__ ps, const uint32_t *__restrict__ xval, uint32_t nx,
-                            uint32_t *__restrict__ ofs, uint2 *__restrict__ ent)
-{
-    for (uint32_t x = blockIdx.x * blockDim.x + threadIdx.x; x < nx; x += gridDim.x * blockDim.x) {
-        const uint32_t v = xval[x];
-        if (v != LZ77X_NONE32) {
-            const uint32_t slot = atomicAdd(&ofs[x + (ps[x] >> 16)], 1u);
-            ent[slot] = make_uint2(x, v);
-        }
+    for (uint32_t x = xa + blockIdx.x * blockDim.x + threadIdx.x; x < xb; x += gridDim.x * blockDim.x) {
+        if (xval[x] == LZ77X_NONE32) continue;
+        const uint32_t dst = x + (ps[x] >> 16);
+        if (dst >= dbase) atomicAdd(&cnt[dst - dbase], 1u);
     }
 }
 
-hipError_t lz77k_xfer_index(const uint32_t *d_ps, const uint32_t *d_xval, uint32_t nx, uint32_t n,
+__global__ void k_xfer_fill(const uint32_t *__restrict__ ps, const uint32_t *__restrict__ xval, uint32_t xa, uint32_t xb,
+                            uint32_t dbase, uint32_t *__restrict__ ofs, uint2 *__restrict__ ent)
+{
+    for (uint32_t x = xa + blockIdx.x * blockDim.x + threadIdx.x; x < xb; x += gridDim.x * blockDim.x) {
+        const uint32_t v = xval[x];
+        if (v == LZ77X_NONE32) continue;
+        const uint32_t dst = x + (ps[x] >> 16);
+        if (dst >= dbase) ent[atomicAdd(&ofs[dst - dbase], 1u)] = make_uint2(x, v);
+    }
+}
+
+/* Index of the hand-overs of evictions x in [xa, xb) into destinations [dbase, dend):
+ * afterwards list(c) = ent[ (c > dbase ? ofs[c-dbase-1] : 0) .. ofs[c-dbase] ). */
+hipError_t lz77k_xfer_index(const uint32_t *d_ps, const uint32_t *d_xval, uint32_t xa, uint32_t xb, uint32_t dbase, uint32_t dend,
                             uint32_t *d_ofs, uint2 *d_ent, void *d_scan_tmp, hipStream_t s)
 {
-    hipError_t e = hipMemsetAsync(d_ofs, 0, ((size_t)n + 1) * sizeof(uint32_t), s);
+    const uint32_t nd = dend - dbase;
+    hipError_t e = hipMemsetAsync(d_ofs, 0, ((size_t)nd + 1) * sizeof(uint32_t), s);
     if (e != hipSuccess) return e;
-    if (nx == 0) return hipSuccess;
-    const uint32_t blocks = min((nx + 255u) / 256u, 256u * 16u);
-    hipLaunchKernelGGL(k_xfer_count, dim3(blocks), dim3(256), 0, s, d_ps, d_xval, nx, d_ofs);
-    e = lz77k_scan_u32(d_ofs, d_ofs, n + 1, d_scan_tmp, s);
+    if (xb <= xa) return hipSuccess;
+    const uint32_t blocks = min((xb - xa + 255u) / 256u, 256u * 16u);
+    hipLaunchKernelGGL(k_xfer_count, dim3(blocks), dim3(256), 0, s, d_ps, d_xval, xa, xb, dbase, d_ofs);
+    e = lz77k_scan_u32(d_ofs, d_ofs, nd + 1, d_scan_tmp, s);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(k_xfer_fill, dim3(blocks), dim3(256), 0, s, d_ps, d_xval, nx, d_ofs, d_ent);
+    hipLaunchKernelGGL(k_xfer_fill, dim3(blocks), dim3(256), 0, s, d_ps, d_xval, xa, xb, dbase, d_ofs, d_ent);
     return hipGetLastError();
 }
 
@@ -507,7 +520,7 @@ hipError_t lz77k_xfer_index(const uint32_t *d_ps, const uint32_t *d_xval, uint32
 __global__ __launch_bounds__(256) void k_tokens(const uint8_t *__restrict__ in, uint32_t n, int sb, int ob, int lb,
                                                 const uint32_t *__restrict__ chain, uint32_t ntok,
                                                 const uint8_t *__restrict__ maxlen,
-                                                const uint32_t *__restrict__ ofs, const uint2 *__restrict__ ent,
+                                                const uint32_t *__restrict__ ofs, const uint2 *__restrict__ ent, uint32_t dbase,
                                                 uint32_t *__restrict__ tokval)
 {
     const uint32_t lane = threadIdx.x & 63;
@@ -535,7 +548,7 @@ __global__ __launch_bounds__(256) void k_tokens(const uint8_t *__restrict__ in, 
             }
             if (!same) continue;
             uint32_t prio = c;
-            const uint32_t lo = c ? ofs[c - 1] : 0, hi = ofs[c];
+            const uint32_t lo = c > dbase ? ofs[c - dbase - 1] : 0, hi = c >= dbase ? ofs[c - dbase] : 0;
             uint32_t latest = 0;
             bool any = false;
             for (uint32_t e = lo; e < hi; e++) {
@@ -559,12 +572,148 @@ __global__ __launch_bounds__(256) void k_tokens(const uint8_t *__restrict__ in, 
     }
 }
 
+/* ---- tiled variant: window bytes and the hand-over lists of a tile staged in LDS ---- */
+
+#define TOK_TILE 2048u
+#define TOK_BLOCK 512
+
+__global__ void k_tok_bounds(const uint32_t *__restrict__ chain, uint32_t ntok, uint32_t pos0, uint32_t ntiles,
+                             uint32_t *__restrict__ tstart)
+{
+    /* tstart[t] = first token whose position is >= pos0 + t*TOK_TILE (tiles may be empty) */
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k > ntok) return;
+    const uint32_t first = k == 0 ? 0u : (chain[k - 1] - pos0) / TOK_TILE + 1;
+    const uint32_t last = k == ntok ? ntiles : (chain[k] - pos0) / TOK_TILE;
+    for (uint32_t t = first; t <= last; t++) tstart[t] = k;
+}
+
+__global__ __launch_bounds__(TOK_BLOCK) void k_tokens_tile(const uint8_t *__restrict__ in, uint32_t n, int sb, int la, int ob, int lb,
+                                                           const uint32_t *__restrict__ chain, const uint32_t *__restrict__ tstart,
+                                                           const uint8_t *__restrict__ maxlen,
+                                                           const uint32_t *__restrict__ ofs, const uint2 *__restrict__ ent,
+                                                           uint32_t dbase, uint32_t pos0, uint32_t pos1,
+                                                           uint32_t *__restrict__ tokval, uint32_t ent_cap, uint32_t lofs_off, uint32_t lent_off)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    uint8_t *by = smem;
+    uint16_t *lofs = reinterpret_cast<uint16_t *>(smem + lofs_off);
+    uint2 *lent = reinterpret_cast<uint2 *>(smem + lent_off);
+
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t usb = (uint32_t)sb;
+    const uint32_t t0 = pos0 + blockIdx.x * TOK_TILE;
+    const uint32_t t1 = min(t0 + TOK_TILE, pos1);
+    const uint32_t wbase = (t0 > usb ? t0 - usb : 0u) & ~3u;
+#define LIST_START(c) ((c) > dbase ? ofs[(c) - dbase - 1] : 0u)
+#define LIST_END(c) ((c) >= dbase ? ofs[(c) - dbase] : 0u)
+    const uint32_t nb = (t1 + (uint32_t)la + 8 - wbase + 3) & ~3u;
+    for (uint32_t i = tid * 4; i < nb; i += TOK_BLOCK * 4)
+        *reinterpret_cast<uint32_t *>(by + i) = *reinterpret_cast<const uint32_t *>(in + wbase + i);
+    const uint32_t NO = t1 - wbase;
+    const uint32_t ebase = LIST_START(wbase);
+    const uint32_t ecount = LIST_END(t1 - 1) - ebase;
+    const bool staged = ecount <= ent_cap && ecount < 65536u;
+    if (staged) {
+        for (uint32_t i = tid; i <= NO; i += TOK_BLOCK) {
+            const uint32_t c = wbase + i;
+            lofs[i] = (uint16_t)(LIST_START(c) - ebase);
+        }
+        for (uint32_t e = tid; e < ecount; e += TOK_BLOCK) lent[e] = ent[ebase + e];
+    }
+    __syncthreads();
+
+    const uint32_t omask = ob >= 32 ? 0xFFFFFFFFu : (1u << ob) - 1u;
+    const uint32_t k1 = tstart[blockIdx.x + 1];
+    for (uint32_t k = tstart[blockIdx.x] + wave; k < k1; k += TOK_BLOCK / 64) {
+        const uint32_t p = chain[k];
+        const uint32_t len = maxlen[p];
+        const uint8_t *q = by + (p - wbase);
+        const uint32_t next = q[len];
+        uint32_t off = 0;
+        if (len > 0) {
+            const uint32_t head = ld32u(q);
+            const uint32_t hmask = len >= 4 ? 0xFFFFFFFFu : (1u << (8 * len)) - 1u;
+            const uint32_t cmin = p > usb ? p - usb : 0u;
+            uint64_t best = ~0ull;
+            for (uint32_t cg = (cmin & ~3u) + lane * 4; cg < p; cg += 256) {
+                const uint8_t *r = by + (cg - wbase);
+                const uint32_t lo = *reinterpret_cast<const uint32_t *>(r);
+                const uint32_t hi = *reinterpret_cast<const uint32_t *>(r + 4);
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    const uint32_t c = cg + j;
+                    const uint32_t w = j == 0 ? lo : __builtin_amdgcn_alignbyte(hi, lo, j);
+                    if (((w ^ head) & hmask) != 0 || c < cmin || c >= p) continue;
+                    bool same = true;
+                    for (uint32_t i = 4; i < len; i += 4) {
+                        uint32_t x = ld32u(r + j + i) ^ ld32u(q + i);
+                        const uint32_t rem = len - i;
+                        if (rem < 4) x &= (1u << (8 * rem)) - 1u;
+                        if (x) { same = false; break; }
+                    }
+                    if (!same) continue;
+                    uint32_t prio = c, latest = 0;
+                    bool any = false;
+                    if (staged) {
+                        const uint32_t lc = c - wbase;
+                        for (uint32_t e = lofs[lc]; e < lofs[lc + 1]; e++) {
+                            const uint2 t = lent[e];
+                            if ((uint64_t)t.x + usb < p && (!any || t.x > latest)) { any = true; latest = t.x; prio = t.y; }
+                        }
+                    } else {
+                        for (uint32_t e = LIST_START(c); e < LIST_END(c); e++) {
+                            const uint2 t = ent[e];
+                            if ((uint64_t)t.x + usb < p && (!any || t.x > latest)) { any = true; latest = t.x; prio = t.y; }
+                        }
+                    }
+                    const uint64_t key = ((uint64_t)prio << 32) | c;
+                    best = key < best ? key : best;
+                }
+            }
+#pragma unroll
+            for (int d = 32; d > 0; d >>= 1) {
+                const uint64_t o = (uint64_t)__shfl_xor((unsigned long long)best, d, 64);
+                best = o < best ? o : best;
+            }
+            off = p - (uint32_t)(best & 0xFFFFFFFFu);
+        }
+        if (lane == 0) tokval[k] = (off & omask) | (len << ob) | (next << (ob + lb));
+    }
+}
+
+#undef LIST_START
+#undef LIST_END
+
+size_t lz77k_tokens_tmp_bytes(uint32_t n) { return ((size_t)(n / TOK_TILE) + 8) * sizeof(uint32_t); }
+
+/* tokens d_chain[0..ntok) all lie in [pos0, pos1); the hand-over index covers dst >= dbase */
 hipError_t lz77k_tokens(const uint8_t *d_in, uint32_t n, const lz77x_geom &g, const uint32_t *d_chain, uint32_t ntok,
-                        const uint8_t *d_maxlen, const uint32_t *d_ofs, const uint2 *d_ent, uint32_t *d_tokval, hipStream_t s)
+                        const uint8_t *d_maxlen, const uint32_t *d_ofs, const uint2 *d_ent, uint32_t dbase,
+                        uint32_t pos0, uint32_t pos1, uint32_t *d_tokval, uint32_t *d_tstart, int variant, hipStream_t s)
 {
     if (ntok == 0) return hipSuccess;
+    if (variant == 0 && g.sb <= 8192 && d_tstart) {
+        const uint32_t ntiles = (pos1 - pos0 + TOK_TILE - 1) / TOK_TILE;
+        const uint32_t span = TOK_TILE + (uint32_t)g.sb + 16;
+        const uint32_t lofs_off = (span + (uint32_t)g.la + 16 + 15) & ~15u;
+        const uint32_t lent_off = (lofs_off + 2 * (span + 2) + 15) & ~15u;
+        const uint32_t budget = 78u * 1024u;                         /* two workgroups per CU */
+        uint32_t ent_cap = lent_off + 8 * span < budget ? (budget - lent_off) / 8 : span;
+        const size_t lds = (size_t)lent_off + (size_t)ent_cap * 8;
+        if (lds > 48 * 1024) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_tokens_tile),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) return e;
+        }
+        hipLaunchKernelGGL(k_tok_bounds, dim3((ntok + 256) / 256), dim3(256), 0, s, d_chain, ntok, pos0, ntiles, d_tstart);
+        hipLaunchKernelGGL(k_tokens_tile, dim3(ntiles), dim3(TOK_BLOCK), lds, s, d_in, n, g.sb, g.la, g.ob, g.lb, d_chain,
+                           d_tstart, d_maxlen, d_ofs, d_ent, dbase, pos0, pos1, d_tokval, ent_cap, lofs_off, lent_off);
+        return hipGetLastError();
+    }
     const uint32_t blocks = (ntok + 3) / 4;
-    hipLaunchKernelGGL(k_tokens, dim3(blocks), dim3(256), 0, s, d_in, n, g.sb, g.ob, g.lb, d_chain, ntok, d_maxlen, d_ofs, d_ent, d_tokval);
+    hipLaunchKernelGGL(k_tokens, dim3(blocks), dim3(256), 0, s, d_in, n, g.sb, g.ob, g.lb, d_chain, ntok, d_maxlen, d_ofs, d_ent,
+                       dbase, d_tokval);
     return hipGetLastError();
 }
 

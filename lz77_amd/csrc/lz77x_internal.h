@@ -68,7 +68,7 @@ void lz77x_prio_run(lz77x_prio_state *st, const uint32_t *ps, int sb, size_t upt
 size_t lz77k_match_scratch_bytes(const lz77x_geom &g, uint32_t nregions);
 size_t lz77k_match_lds_bytes(const lz77x_geom &g);
 /* regions [region0, region0+nregions) of an n-byte padded input; variant 0 = packed
- * interior loop, 1 = all-masked reference loop (self-check) */
+ * interior loop, 1 = all-masked reference loop (self-check), 2 = sort only (timing probe) */
 hipError_t lz77k_match(const uint8_t *d_in, uint32_t n, const lz77x_geom &g,
                        uint32_t region0, uint32_t nregions,
                        uint32_t *d_ps, uint8_t *d_maxlen, void *d_scratch, int variant, hipStream_t s);
@@ -79,13 +79,21 @@ hipError_t lz77k_fill_pad(uint8_t *d_in, uint32_t n, hipStream_t s);
 size_t lz77k_scan_tmp_bytes(uint32_t m);
 hipError_t lz77k_scan_u32(const uint32_t *d_in, uint32_t *d_out, uint32_t m, void *d_tmp, hipStream_t s);
 
-/* transfer index: after the call list(c) = ent[ (c ? ofs[c-1] : 0) .. ofs[c] ) */
-hipError_t lz77k_xfer_index(const uint32_t *d_ps, const uint32_t *d_xval, uint32_t nx, uint32_t n,
-                            uint32_t *d_ofs /* n+1 */, uint2 *d_ent, void *d_scan_tmp, hipStream_t s);
+/* hand-over index of evictions x in [xa, xb) into destinations [dbase, dend):
+ * list(c) = ent[ (c > dbase ? ofs[c-dbase-1] : 0) .. ofs[c-dbase] ).  d_ofs: dend-dbase+1 words */
+hipError_t lz77k_xfer_index(const uint32_t *d_ps, const uint32_t *d_xval, uint32_t xa, uint32_t xb,
+                            uint32_t dbase, uint32_t dend, uint32_t *d_ofs, uint2 *d_ent,
+                            void *d_scan_tmp, hipStream_t s);
 
+/* tokens d_chain[0..ntok) lie in [pos0, pos1).  variant 0: tiled kernel (window + hand-over lists
+ * in LDS) when sb <= 8192; else / variant 1: one wave per token straight from global memory.
+ * d_tstart: lz77k_tokens_tmp_bytes(pos1-pos0). */
+size_t lz77k_tokens_tmp_bytes(uint32_t n);
 hipError_t lz77k_tokens(const uint8_t *d_in, uint32_t n, const lz77x_geom &g,
                         const uint32_t *d_chain, uint32_t ntok, const uint8_t *d_maxlen,
-                        const uint32_t *d_ofs, const uint2 *d_ent, uint32_t *d_tokval, hipStream_t s);
+                        const uint32_t *d_ofs, const uint2 *d_ent, uint32_t dbase,
+                        uint32_t pos0, uint32_t pos1, uint32_t *d_tokval,
+                        uint32_t *d_tstart, int variant, hipStream_t s);
 
 /* words [w0, w0+nw) of the output stream (word 0 = header) from tokval[0..ntok) */
 hipError_t lz77k_pack(const uint32_t *d_tokval, uint64_t ntok, const lz77x_geom &g,

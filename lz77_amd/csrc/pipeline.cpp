@@ -20,6 +20,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
+#include <vector>
 
 namespace {
 
@@ -76,9 +77,12 @@ struct Ctx {
     bool ready = false;
     int ndev = 0;
     hipStream_t stream = nullptr;            /* used when the caller passes none (host-level API) */
+    hipStream_t copy = nullptr;              /* D2H/H2D of intermediates, overlapped with kernels */
+    hipStream_t tok = nullptr;               /* per-chunk index + tie-break + pack kernels */
     hipEvent_t ev[6] = {};
+    std::vector<hipEvent_t> chunk_ev, tok_ev;
     DevBuf in, ps, maxlen, scratch, xval, chain, ofs, ent, tokval, out, scantmp;
-    DevBuf z, len1, dst, ptr, flag;
+    DevBuf z, len1, dst, ptr, flag, tstart;
     PinBuf h_ps, h_maxlen, h_xval, h_chain, h_small;
 };
 
@@ -96,6 +100,8 @@ int ctx_init(Ctx &c)
     }
     c.ndev = nd;
     HIPCHK(hipStreamCreateWithFlags(&c.stream, hipStreamNonBlocking));
+    HIPCHK(hipStreamCreateWithFlags(&c.copy, hipStreamNonBlocking));
+    HIPCHK(hipStreamCreateWithFlags(&c.tok, hipStreamNonBlocking));
     for (auto &ev : c.ev) HIPCHK(hipEventCreate(&ev));
     c.ready = true;
     return LZ77X_OK;
@@ -114,7 +120,13 @@ size_t stream_bytes(uint64_t ntok, int T) { return 4 + (size_t)((ntok * (uint64_
 /* ---------------------------------------------------------------- encode ------------ */
 
 /* src is a device pointer (src_on_device) or a host pointer.  On success the stream is in
- * c.out (device) and *zn holds its size. */
+ * c.out (device) and *zn holds its size.
+ *
+ * The match kernel is launched in chunks of regions; each chunk's {ps, maxlen} is copied to the
+ * host on a second stream as soon as its launch retires, and the host's sequential stage consumes
+ * chunk i while the GPU is already working on chunks i+1..  The host's products (xval, chain) go
+ * back chunk by chunk on the same copy stream, so when the last chunk has been consumed the
+ * device already holds everything the token kernels need. */
 int encode_core(Ctx &c, const void *src, bool src_on_device, size_t n, const lz77x_geom &g, hipStream_t s, size_t *zn)
 {
     const double t_begin = now_ms();
@@ -122,102 +134,169 @@ int encode_core(Ctx &c, const void *src, bool src_on_device, size_t n, const lz7
     if (n > LZ77X_MAX_N) return LZ77X_E_TOOBIG;
     const uint32_t n32 = (uint32_t)n;
     int rc;
+    double waited = 0;
 
     if ((rc = c.in.need(n + LZ77X_PAD + 16))) return rc;
     if (n) HIPCHK(hipMemcpyAsync(c.in.p, src, n, src_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, s));
     HIPCHK(lz77k_fill_pad(c.in.as<uint8_t>(), n32, s));
 
-    uint32_t ntok = 0;
+    uint32_t ntok = 0, nchunks_done = 0;
     uint64_t transfers = 0;
     if (n) {
+        const size_t nx = n > (size_t)g.sb ? n - (size_t)g.sb : 0;     /* evicted positions */
         if ((rc = c.ps.need((n + 8) * 4))) return rc;
         if ((rc = c.maxlen.need(n + 8))) return rc;
+        if ((rc = c.xval.need((n + 8) * 4))) return rc;
+        if ((rc = c.chain.need((n + 8) * 4))) return rc;
         if ((rc = c.h_ps.need((n + 8) * 4))) return rc;
         if ((rc = c.h_maxlen.need(n + 8))) return rc;
         if ((rc = c.h_xval.need((n + 8) * 4))) return rc;
         if ((rc = c.h_chain.need((n + 8) * 4))) return rc;
 
-        /* -- match kernel over all regions (batched only to bound the generic path's scratch) -- */
         const uint32_t nregions = (uint32_t)((n + g.TILE - 1) / g.TILE);
-        uint32_t batch = nregions;
+        uint32_t per_chunk = (uint32_t)(((size_t)4 << 20) / g.TILE);
+        if (per_chunk < 512) per_chunk = 512;                          /* keep >= 2 workgroups per CU in flight */
+        const char *cs = getenv("LZ77X_CHUNK_REGIONS");
+        if (cs && atoi(cs) > 0) per_chunk = (uint32_t)atoi(cs);
         if (!g.fast) {
             const size_t per = lz77k_match_scratch_bytes(g, 1);
-            const size_t budget = (size_t)2 << 30;
-            batch = (uint32_t)(budget / per);
-            if (batch < 1) batch = 1;
-            if (batch > nregions) batch = nregions;
-            if ((rc = c.scratch.need(lz77k_match_scratch_bytes(g, batch)))) return rc;
+            const uint32_t fit = (uint32_t)(((size_t)2 << 30) / per);
+            if (per_chunk > fit) per_chunk = fit ? fit : 1;
+            if ((rc = c.scratch.need(lz77k_match_scratch_bytes(g, per_chunk < nregions ? per_chunk : nregions)))) return rc;
+        }
+        const uint32_t nchunks = (nregions + per_chunk - 1) / per_chunk;
+        while (c.chunk_ev.size() < 3 * (size_t)nchunks) {
+            hipEvent_t e;
+            HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));   /* ordering only */
+            c.chunk_ev.push_back(e);
+        }
+        while (c.tok_ev.size() < 2 * (size_t)nchunks) {
+            hipEvent_t e;
+            HIPCHK(hipEventCreate(&e));                                    /* token-stream kernel time */
+            c.tok_ev.push_back(e);
         }
         const char *vs = getenv("LZ77X_MATCH_VARIANT");
         const int variant = vs ? atoi(vs) : 0;
+
+        /* -- enqueue every match launch and its D2H up front -- */
         HIPCHK(hipEventRecord(c.ev[0], s));
-        for (uint32_t r0 = 0; r0 < nregions; r0 += batch) {
-            const uint32_t nr = nregions - r0 < batch ? nregions - r0 : batch;
+        for (uint32_t ci = 0; ci < nchunks; ci++) {
+            const uint32_t r0 = ci * per_chunk;
+            const uint32_t nr = nregions - r0 < per_chunk ? nregions - r0 : per_chunk;
             HIPCHK(lz77k_match(c.in.as<uint8_t>(), n32, g, r0, nr, c.ps.as<uint32_t>(), c.maxlen.as<uint8_t>(),
                                c.scratch.p, variant, s));
             g_stats.match_launches++;
+            HIPCHK(hipEventRecord(c.chunk_ev[3 * ci], s));
+            HIPCHK(hipStreamWaitEvent(c.copy, c.chunk_ev[3 * ci], 0));
+            const size_t b = (size_t)r0 * g.TILE;
+            size_t e = (size_t)(r0 + nr) * g.TILE;
+            if (e > n) e = n;
+            HIPCHK(hipMemcpyAsync(c.h_maxlen.as<uint8_t>() + b, c.maxlen.as<uint8_t>() + b, e - b, hipMemcpyDeviceToHost, c.copy));
+            const size_t pe = e < nx ? e : nx;
+            if (pe > b)
+                HIPCHK(hipMemcpyAsync(c.h_ps.as<uint32_t>() + b, c.ps.as<uint32_t>() + b, (pe - b) * 4, hipMemcpyDeviceToHost, c.copy));
+            HIPCHK(hipEventRecord(c.chunk_ev[3 * ci + 1], c.copy));
         }
         HIPCHK(hipEventRecord(c.ev[1], s));
 
-        /* -- intermediates to the host -- */
-        HIPCHK(hipMemcpyAsync(c.h_maxlen.p, c.maxlen.p, n, hipMemcpyDeviceToHost, s));
-        const size_t nx = n > (size_t)g.sb ? n - (size_t)g.sb : 0;     /* evicted positions */
-        if (nx) HIPCHK(hipMemcpyAsync(c.h_ps.p, c.ps.p, nx * 4, hipMemcpyDeviceToHost, s));
-        HIPCHK(hipStreamSynchronize(s));
-        const double t_host0 = now_ms();
+        /* -- sequential host stage, chunk by chunk; each chunk's tokens are resolved on the
+         *    token stream while the host is already busy with the next chunk -- */
+        const size_t chunk_pos = (size_t)per_chunk * g.TILE;
+        const size_t idx_span = (chunk_pos < n ? chunk_pos : n) + 2 * (size_t)g.sb + 16;
+        if ((rc = c.ofs.need((idx_span + 8) * 4))) return rc;
+        if ((rc = c.ent.need((idx_span + 8) * 8))) return rc;
+        if ((rc = c.tokval.need((n + 8) * 4))) return rc;
+        if ((rc = c.scantmp.need(lz77k_scan_tmp_bytes((uint32_t)idx_span + 1)))) return rc;
+        if ((rc = c.tstart.need(lz77k_tokens_tmp_bytes((uint32_t)idx_span)))) return rc;
+        const char *tv = getenv("LZ77X_TOKEN_VARIANT");
+        const int tvariant = tv ? atoi(tv) : 0;
 
-        /* -- sequential host stage -- */
-        size_t ntok_sz = 0;
-        lz77x_host_chain(c.h_maxlen.as<uint8_t>(), n, 0, c.h_chain.as<uint32_t>(), &ntok_sz);
-        ntok = (uint32_t)ntok_sz;
-        const double t_host1 = now_ms();
         lz77x_prio_state st;
         if (!lz77x_prio_init(&st, g.sb)) return LZ77X_E_NOMEM;
-        lz77x_prio_run(&st, c.h_ps.as<uint32_t>(), g.sb, n, c.h_xval.as<uint32_t>());
+        size_t p = 0, ntok_sz = 0, tok_sent = 0, x_sent = 0;
+        double t_chain = 0, t_prio = 0;
+        int err = LZ77X_OK;
+        for (uint32_t ci = 0; ci < nchunks && err == LZ77X_OK; ci++) {
+            const uint32_t r0 = ci * per_chunk;
+            const uint32_t nr = nregions - r0 < per_chunk ? nregions - r0 : per_chunk;
+            const size_t b = (size_t)r0 * g.TILE;
+            size_t e = (size_t)(r0 + nr) * g.TILE;
+            if (e > n) e = n;
+            const double tw = now_ms();
+            hipError_t he = hipEventSynchronize(c.chunk_ev[3 * ci + 1]);
+            const double t0 = now_ms();
+            waited += t0 - tw;
+            if (he != hipSuccess) { err = LZ77X_E_HIP; snprintf(g_err, sizeof g_err, "chunk sync: %s", hipGetErrorString(he)); break; }
+            p = lz77x_host_chain(c.h_maxlen.as<uint8_t>(), e, p, c.h_chain.as<uint32_t>(), &ntok_sz);
+            const double t1 = now_ms();
+            lz77x_prio_run(&st, c.h_ps.as<uint32_t>(), g.sb, e, c.h_xval.as<uint32_t>());
+            const double t2 = now_ms();
+            t_chain += t1 - t0;
+            t_prio += t2 - t1;
+            const size_t x_done = e > (size_t)g.sb ? e - (size_t)g.sb : 0;
+            auto enqueue = [&]() -> hipError_t {
+                hipError_t q;
+                if (x_done > x_sent &&
+                    (q = hipMemcpyAsync(c.xval.as<uint32_t>() + x_sent, c.h_xval.as<uint32_t>() + x_sent, (x_done - x_sent) * 4,
+                                        hipMemcpyHostToDevice, c.copy)) != hipSuccess) return q;
+                if (ntok_sz > tok_sent &&
+                    (q = hipMemcpyAsync(c.chain.as<uint32_t>() + tok_sent, c.h_chain.as<uint32_t>() + tok_sent,
+                                        (ntok_sz - tok_sent) * 4, hipMemcpyHostToDevice, c.copy)) != hipSuccess) return q;
+                if ((q = hipEventRecord(c.chunk_ev[3 * ci + 2], c.copy)) != hipSuccess) return q;
+                if ((q = hipStreamWaitEvent(c.tok, c.chunk_ev[3 * ci + 2], 0)) != hipSuccess) return q;
+                if ((q = hipEventRecord(c.tok_ev[2 * ci], c.tok)) != hipSuccess) return q;
+                /* hand-overs that can matter to tokens in [b, e): evictions before e-sb into dst >= b-sb */
+                const uint32_t dbase = b > (size_t)g.sb ? (uint32_t)(b - (size_t)g.sb) : 0u;
+                const uint32_t xa = dbase > (uint32_t)g.sb ? dbase - (uint32_t)g.sb : 0u;
+                if ((q = lz77k_xfer_index(c.ps.as<uint32_t>(), c.xval.as<uint32_t>(), xa, (uint32_t)x_done, dbase, (uint32_t)e,
+                                          c.ofs.as<uint32_t>(), c.ent.as<uint2>(), c.scantmp.p, c.tok)) != hipSuccess) return q;
+                if ((q = lz77k_tokens(c.in.as<uint8_t>(), n32, g, c.chain.as<uint32_t>() + tok_sent, (uint32_t)(ntok_sz - tok_sent),
+                                      c.maxlen.as<uint8_t>(), c.ofs.as<uint32_t>(), c.ent.as<uint2>(), dbase, (uint32_t)b, (uint32_t)e,
+                                      c.tokval.as<uint32_t>() + tok_sent, c.tstart.as<uint32_t>(), tvariant, c.tok)) != hipSuccess) return q;
+                return hipEventRecord(c.tok_ev[2 * ci + 1], c.tok);
+            };
+            he = enqueue();
+            if (he != hipSuccess) { err = LZ77X_E_HIP; snprintf(g_err, sizeof g_err, "chunk enqueue: %s", hipGetErrorString(he)); break; }
+            x_sent = x_done;
+            tok_sent = ntok_sz;
+        }
+        ntok = (uint32_t)ntok_sz;
+        nchunks_done = nchunks;
         transfers = st.transfers;
         lz77x_prio_free(&st);
-        const double t_host2 = now_ms();
-        g_stats.host_chain_ms = t_host1 - t_host0;
-        g_stats.host_stageb_ms = t_host2 - t_host1;
-
-        /* -- back to the device: tie-break + pack -- */
-        if ((rc = c.xval.need((n + 8) * 4))) return rc;
-        if ((rc = c.chain.need(((size_t)ntok + 8) * 4))) return rc;
-        if ((rc = c.ofs.need((n + 8) * 4))) return rc;
-        if ((rc = c.ent.need((transfers + 8) * 8))) return rc;
-        if ((rc = c.tokval.need(((size_t)ntok + 8) * 4))) return rc;
-        if ((rc = c.scantmp.need(lz77k_scan_tmp_bytes(n32 + 1)))) return rc;
-        if (nx) HIPCHK(hipMemcpyAsync(c.xval.p, c.h_xval.p, nx * 4, hipMemcpyHostToDevice, s));
-        HIPCHK(hipMemcpyAsync(c.chain.p, c.h_chain.p, (size_t)ntok * 4, hipMemcpyHostToDevice, s));
-        HIPCHK(hipEventRecord(c.ev[2], s));
-        HIPCHK(lz77k_xfer_index(c.ps.as<uint32_t>(), c.xval.as<uint32_t>(), (uint32_t)nx, n32, c.ofs.as<uint32_t>(),
-                                c.ent.as<uint2>(), c.scantmp.p, s));
-        HIPCHK(lz77k_tokens(c.in.as<uint8_t>(), n32, g, c.chain.as<uint32_t>(), ntok, c.maxlen.as<uint8_t>(),
-                            c.ofs.as<uint32_t>(), c.ent.as<uint2>(), c.tokval.as<uint32_t>(), s));
+        if (err != LZ77X_OK) { hipError_t q = hipDeviceSynchronize(); (void)q; return err; }
+        g_stats.host_chain_ms = t_chain;
+        g_stats.host_stageb_ms = t_prio;
     } else {
         if ((rc = c.tokval.need(64))) return rc;
         HIPCHK(hipEventRecord(c.ev[0], s));
         HIPCHK(hipEventRecord(c.ev[1], s));
-        HIPCHK(hipEventRecord(c.ev[2], s));
     }
     *zn = stream_bytes(ntok, g.T);
     const uint64_t nwords = (*zn + 3) / 4;
     if ((rc = c.out.need(nwords * 4 + 16))) return rc;
-    HIPCHK(lz77k_pack(c.tokval.as<uint32_t>(), ntok, g, c.out.as<uint32_t>(), nwords, s));
-    HIPCHK(hipEventRecord(c.ev[3], s));
+    HIPCHK(lz77k_pack(c.tokval.as<uint32_t>(), ntok, g, c.out.as<uint32_t>(), nwords, c.tok));
+    HIPCHK(hipEventRecord(c.ev[3], c.tok));
+    HIPCHK(hipStreamWaitEvent(s, c.ev[3], 0));        /* later work on the caller's stream sees the result */
+    const double tw = now_ms();
     HIPCHK(hipStreamSynchronize(s));
+    waited += now_ms() - tw;
 
     float ms = 0;
     HIPCHK(hipEventElapsedTime(&ms, c.ev[0], c.ev[1]));
     g_stats.k_match_ms = ms;
-    HIPCHK(hipEventElapsedTime(&ms, c.ev[2], c.ev[3]));
-    g_stats.k_token_ms = ms;
+    double tok_ms = 0;
+    for (uint32_t ci = 0; ci < nchunks_done; ci++) {
+        HIPCHK(hipEventElapsedTime(&ms, c.tok_ev[2 * ci], c.tok_ev[2 * ci + 1]));
+        tok_ms += ms;
+    }
+    g_stats.k_token_ms = tok_ms;
     g_stats.n = n;
     g_stats.zn = *zn;
     g_stats.ntok = ntok;
     g_stats.transfers = transfers;
     g_stats.total_ms = now_ms() - t_begin;
-    g_stats.copy_ms = g_stats.total_ms - g_stats.k_match_ms - g_stats.k_token_ms - g_stats.host_chain_ms - g_stats.host_stageb_ms;
+    g_stats.copy_ms = waited;               /* host time blocked on the device (not overlapped) */
     return LZ77X_OK;
 }
 

@@ -21,3 +21,9 @@ for it in range(3):
     print("  dec", {k: (round(v, 2) if isinstance(v, float) else v) for k, v in sd.items()})
 assert back == data.tobytes()
 print("roundtrip ok sha", hashlib.sha256(z).hexdigest()[:16])
+# variants: sort-only probe and old token kernel
+for name, env in (("match sort-only", {"LZ77X_MATCH_VARIANT": "2"}), ("token v1 (global)", {"LZ77X_TOKEN_VARIANT": "1"})):
+    os.environ.update(env)
+    L.encode(data, la, sb); se = L.last_stats()
+    print(name, {k: round(v, 2) for k, v in se.items() if k.endswith("_ms")})
+    for k in env: del os.environ[k]
