@@ -27,11 +27,11 @@ void lz77x_make_geom(lz77x_geom *g, int sb, int la)
     g->ob = lz77x_bitof(sb);
     g->lb = lz77x_bitof(la);
     g->T = g->ob + g->lb + 8;                       /* lz77.c:249-251 */
-    g->SBu = ((uint32_t)sb + 3u) & ~3u;
+    g->SBu = ((uint32_t)sb + 7u) & ~7u;
     uint32_t rp = 4096;
     while (rp < 4u * g->SBu) rp <<= 1;
     g->RP = rp;
-    g->TILE = (rp - g->SBu - (uint32_t)sb) & ~3u;
+    g->TILE = (rp - g->SBu - (uint32_t)sb) & ~7u;
     g->fast = rp <= 16384u;
 }
 

@@ -41,14 +41,29 @@ __device__ __forceinline__ uint64_t ld64u(const uint8_t *p)
     return v;
 }
 
+/* dword at byte offset `off` of a byte array.  LDS: an unaligned ds_read_b32 is replayed for
+ * ~64 cycles per wave on gfx950, so fetch the two aligned dwords and funnel-shift; global
+ * memory serves unaligned dwords natively. */
+template <bool LDS>
+__device__ __forceinline__ uint32_t ld32_at(const uint8_t *by, uint32_t off)
+{
+    if constexpr (LDS) {
+        const uint32_t *w = reinterpret_cast<const uint32_t *>(by + (off & ~3u));
+        return __builtin_amdgcn_alignbyte(w[1], w[0], off & 3u);
+    } else {
+        return ld32u(by + off);
+    }
+}
+
 /* first `la` bytes at a vs b as big-endian words; ties -> lower index first.
  * tree.c:77 orders nodes with memcmp over the lookahead; bytes past the end of input are
  * 0xFF on device, which reproduces the shrinking key length at EOF (DESIGN.md "key order"). */
+template <bool LDS>
 __device__ __forceinline__ bool key_less(const uint8_t *by, uint32_t a, uint32_t b, int la)
 {
     for (int w = 0; w < la; w += 4) {
-        uint32_t va = __builtin_bswap32(ld32u(by + a + w));
-        uint32_t vb = __builtin_bswap32(ld32u(by + b + w));
+        uint32_t va = __builtin_bswap32(ld32_at<LDS>(by, a + w));
+        uint32_t vb = __builtin_bswap32(ld32_at<LDS>(by, b + w));
         int rem = la - w;
         if (rem < 4) {
             uint32_t m = 0xFFFFFFFFu << (8 * (4 - rem));
@@ -60,16 +75,16 @@ __device__ __forceinline__ bool key_less(const uint8_t *by, uint32_t a, uint32_t
     return a < b;
 }
 
-__device__ __forceinline__ int lcp_capped(const uint8_t *a, const uint8_t *b, int cap)
+template <bool LDS>
+__device__ __forceinline__ int lcp_capped(const uint8_t *by, uint32_t a, uint32_t b, int cap)
 {
     int i = 0;
-    while (i + 4 <= cap) {
-        uint32_t x = ld32u(a + i) ^ ld32u(b + i);
-        if (x) return i + (__builtin_ctz(x) >> 3);
+    while (i < cap) {
+        const uint32_t x = ld32_at<LDS>(by, a + i) ^ ld32_at<LDS>(by, b + i);
+        if (x) { i += __builtin_ctz(x) >> 3; break; }
         i += 4;
     }
-    while (i < cap && a[i] == b[i]) i++;
-    return i;
+    return i < cap ? i : cap;
 }
 
 /* ------------------------------------------------------------------ k_match ---------- */
@@ -78,48 +93,49 @@ template <bool FAST> struct rank_traits;
 template <> struct rank_traits<true>  { typedef uint16_t rank_t; static constexpr uint32_t HALF = 0x8000u; static constexpr uint32_t MASK = 0xFFFFu; };
 template <> struct rank_traits<false> { typedef uint32_t rank_t; static constexpr uint32_t HALF = 0x80000000u; static constexpr uint32_t MASK = 0xFFFFFFFFu; };
 
-/* running min / max of rank differences u = rank[y]-rank[x] (mod 2^16 or 2^32) for the four
- * positions a thread owns.  With all ranks < HALF, positive differences are < HALF and
- * negative ones wrap to >= HALF, so
- *     min u  = distance to the in-order successor  (valid iff < HALF)
+/* Running min / max of rank differences u = rank[y]-rank[x] (mod 2^16 or 2^32) for the eight
+ * consecutive positions ("octet") a thread owns.  With all ranks < HALF, positive differences
+ * are < HALF and negative ones wrap to >= HALF, so
+ *     min u  = distance to the in-order successor   (valid iff < HALF)
  *     max u  = -distance to the in-order predecessor (valid iff >= HALF)
- * which turns the BST neighbour search into sub/min/max on packed 16-bit lanes. */
-template <bool FAST> struct acc4;
+ * which turns the BST neighbour search into sub/min/max: 1.5 VALU ops per pair on packed
+ * 16-bit lanes (v_pk_sub_i16 / v_pk_min_u16 / v_pk_max_u16), no cross-lane traffic. */
+template <bool FAST> struct acc8;
 
-template <> struct acc4<true> {
-    us2 mn[4], mx[4], xr[4];
+template <> struct acc8<true> {
+    us2 mn[8], mx[8], xr[8];
     __device__ __forceinline__ void init(const uint16_t *rk, uint32_t lx0)
     {
+        const uint4 v = *reinterpret_cast<const uint4 *>(rk + lx0);
+        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
-        for (int i = 0; i < 4; i++) {
-            uint16_t r = rk[lx0 + i];
+        for (int i = 0; i < 8; i++) {
+            const uint16_t r = (uint16_t)(w[i >> 1] >> (16 * (i & 1)));
             xr[i] = (us2){r, r};
-            mn[i] = (us2){0xFFFF, 0xFFFF};
-            mx[i] = (us2){0, 0};
         }
+        reset();
     }
     __device__ __forceinline__ void reset()
     {
 #pragma unroll
-        for (int i = 0; i < 4; i++) { mn[i] = (us2){0xFFFF, 0xFFFF}; mx[i] = (us2){0, 0}; }
+        for (int i = 0; i < 8; i++) { mn[i] = (us2){0xFFFF, 0xFFFF}; mx[i] = (us2){0, 0}; }
     }
-    /* all 16 pairs of chunk m with the four owned positions */
-    __device__ __forceinline__ void chunk(const uint16_t *rk, uint32_t m)
+    /* all 64 pairs of the candidate octet v with the eight owned positions */
+    __device__ __forceinline__ void octet(const uint4 v)
     {
-        uint2 v = *reinterpret_cast<const uint2 *>(rk + 4 * m);
-        us2 A = __builtin_bit_cast(us2, v.x), B = __builtin_bit_cast(us2, v.y);
+        const us2 A = __builtin_bit_cast(us2, v.x), B = __builtin_bit_cast(us2, v.y);
+        const us2 C = __builtin_bit_cast(us2, v.z), D = __builtin_bit_cast(us2, v.w);
 #pragma unroll
-        for (int i = 0; i < 4; i++) {
-            us2 dA = A - xr[i], dB = B - xr[i];
-            mn[i] = __builtin_elementwise_min(mn[i], dA);
-            mx[i] = __builtin_elementwise_max(mx[i], dA);
-            mn[i] = __builtin_elementwise_min(mn[i], dB);
-            mx[i] = __builtin_elementwise_max(mx[i], dB);
+        for (int i = 0; i < 8; i++) {
+            const us2 dA = A - xr[i], dB = B - xr[i], dC = C - xr[i], dD = D - xr[i];
+            mn[i] = __builtin_elementwise_min(__builtin_elementwise_min(mn[i], dA), __builtin_elementwise_min(dB, __builtin_elementwise_min(dC, dD)));
+            mx[i] = __builtin_elementwise_max(__builtin_elementwise_max(mx[i], dA), __builtin_elementwise_max(dB, __builtin_elementwise_max(dC, dD)));
         }
     }
+    __device__ __forceinline__ static uint4 load(const uint16_t *rk, uint32_t M) { return *reinterpret_cast<const uint4 *>(rk + 8 * M); }
     __device__ __forceinline__ void one(int i, uint32_t ry)
     {
-        uint16_t u = (uint16_t)(ry - xr[i].x);
+        const uint16_t u = (uint16_t)(ry - xr[i].x);
         mn[i].x = u < mn[i].x ? u : mn[i].x;
         mx[i].x = u > mx[i].x ? u : mx[i].x;
     }
@@ -128,32 +144,46 @@ template <> struct acc4<true> {
     __device__ __forceinline__ uint32_t xrank(int i) const { return xr[i].x; }
 };
 
-template <> struct acc4<false> {
-    uint32_t mn[4], mx[4], xr[4];
+template <> struct acc8<false> {
+    uint32_t mn[8], mx[8], xr[8];
+    struct oct { uint4 a, b; };
     __device__ __forceinline__ void init(const uint32_t *rk, uint32_t lx0)
     {
-#pragma unroll
-        for (int i = 0; i < 4; i++) { xr[i] = rk[lx0 + i]; mn[i] = 0xFFFFFFFFu; mx[i] = 0; }
+        const uint4 a = *reinterpret_cast<const uint4 *>(rk + lx0), b = *reinterpret_cast<const uint4 *>(rk + lx0 + 4);
+        xr[0] = a.x; xr[1] = a.y; xr[2] = a.z; xr[3] = a.w; xr[4] = b.x; xr[5] = b.y; xr[6] = b.z; xr[7] = b.w;
+        reset();
     }
     __device__ __forceinline__ void reset()
     {
 #pragma unroll
-        for (int i = 0; i < 4; i++) { mn[i] = 0xFFFFFFFFu; mx[i] = 0; }
+        for (int i = 0; i < 8; i++) { mn[i] = 0xFFFFFFFFu; mx[i] = 0; }
     }
-    __device__ __forceinline__ void chunk(const uint32_t *rk, uint32_t m)
+    __device__ __forceinline__ void octet(const oct v)
     {
-        uint4 v = *reinterpret_cast<const uint4 *>(rk + 4 * m);
+        const uint32_t y[8] = {v.a.x, v.a.y, v.a.z, v.a.w, v.b.x, v.b.y, v.b.z, v.b.w};
 #pragma unroll
-        for (int i = 0; i < 4; i++) {
-            uint32_t d0 = v.x - xr[i], d1 = v.y - xr[i], d2 = v.z - xr[i], d3 = v.w - xr[i];
-            uint32_t lo = min(min(d0, d1), min(d2, d3)), hi = max(max(d0, d1), max(d2, d3));
-            mn[i] = min(mn[i], lo);
-            mx[i] = max(mx[i], hi);
+        for (int i = 0; i < 8; i++) {
+            uint32_t lo = mn[i], hi = mx[i];
+#pragma unroll
+            for (int j = 0; j < 8; j += 2) {
+                const uint32_t d0 = y[j] - xr[i], d1 = y[j + 1] - xr[i];
+                lo = min(lo, min(d0, d1));      /* v_min3_u32 */
+                hi = max(hi, max(d0, d1));      /* v_max3_u32 */
+            }
+            mn[i] = lo;
+            mx[i] = hi;
         }
+    }
+    __device__ __forceinline__ static oct load(const uint32_t *rk, uint32_t M)
+    {
+        oct o;
+        o.a = *reinterpret_cast<const uint4 *>(rk + 8 * M);
+        o.b = *reinterpret_cast<const uint4 *>(rk + 8 * M + 4);
+        return o;
     }
     __device__ __forceinline__ void one(int i, uint32_t ry)
     {
-        uint32_t u = ry - xr[i];
+        const uint32_t u = ry - xr[i];
         mn[i] = min(mn[i], u);
         mx[i] = max(mx[i], u);
     }
@@ -162,12 +192,31 @@ template <> struct acc4<false> {
     __device__ __forceinline__ uint32_t xrank(int i) const { return xr[i]; }
 };
 
+/* masked path for the few octets that straddle a window edge: y = 8M+j against x = lx0+i,
+ * pair kept iff lo <= (fwd ? y-x : x-y) <= hi */
+template <bool FAST, bool FWD, class RankT>
+__device__ __forceinline__ void edge_octet(acc8<FAST> &acc, const RankT *rk, uint32_t M, uint32_t lx0, uint32_t R, int lo, int hi)
+{
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        const uint32_t y = 8 * M + j;
+        if (y >= R) continue;
+        const uint32_t ry = rk[y];
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            const int32_t d = FWD ? (int32_t)y - (int32_t)(lx0 + i) : (int32_t)(lx0 + i) - (int32_t)y;
+            if (d >= lo && d <= hi) acc.one(i, ry);
+        }
+    }
+}
+
 /*
  * One workgroup per region.
- *   FAST   : ranks/index are uint16 in LDS and the window bytes are staged in LDS (RP <= 16384)
- *            else they are uint32 in a per-region global scratch and bytes come from L1/L2.
- *   PACKED : use the unmasked 16-pairs-per-chunk interior loop (else every pair goes through
- *            the masked path: slow, used as an on-device self check).
+ *   FAST : ranks/index are uint16 in LDS and the window bytes are staged in LDS (RP <= 16384)
+ *          else they are uint32 in a per-region global scratch and bytes come from L1/L2.
+ *   MODE : 0 = production (unmasked octets inside the window, masked octets on its edges)
+ *          1 = every octet through the masked path (slow; on-device self check)
+ *          2 = sort + ranks only (timing probe)
  */
 template <bool FAST, int MODE>
 __global__ __launch_bounds__(MATCH_BLOCK) void k_match(const uint8_t *__restrict__ in, uint32_t n, int sb, int la,
@@ -178,7 +227,6 @@ __global__ __launch_bounds__(MATCH_BLOCK) void k_match(const uint8_t *__restrict
     typedef typename rank_traits<FAST>::rank_t rank_t;
     constexpr uint32_t HALF = rank_traits<FAST>::HALF;
     constexpr uint32_t RMASK = rank_traits<FAST>::MASK;
-    constexpr bool PACKED = MODE == 0;
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
 
     const uint32_t tid = threadIdx.x;
@@ -190,16 +238,19 @@ __global__ __launch_bounds__(MATCH_BLOCK) void k_match(const uint8_t *__restrict
     const uint64_t rend64 = (uint64_t)t0 + TILE + (uint32_t)sb - 1;
     const uint32_t rend = rend64 < n ? (uint32_t)rend64 : n;
     const uint32_t R = rend - rstart;                      /* valid local indices [0,R) */
-    const uint32_t lt0 = t0 - rstart;
+    const uint32_t lt0 = t0 - rstart;                      /* multiple of 8 */
     const uint32_t lt1 = ((uint64_t)t0 + TILE < n ? t0 + TILE : n) - rstart;
 
     rank_t *rk, *ix;
     const uint8_t *by;
     if constexpr (FAST) {
-        rk = reinterpret_cast<rank_t *>(smem);             /* RP + 8 */
-        ix = rk + RP + 8;                                  /* RP */
-        uint8_t *stage = reinterpret_cast<uint8_t *>(ix + RP);
-        const uint32_t nb = (R + (uint32_t)la + 3 + 3) & ~3u;
+        /* LDS: ix[RP] | union { window bytes (sort phase), rk[RP+8] (scan phase) }.  The bytes are
+         * only needed by the key compares of the sort; sharing their space with the ranks keeps
+         * a C1 region at 64 KiB so two workgroups fit one CU. */
+        ix = reinterpret_cast<rank_t *>(smem);             /* RP */
+        rk = ix + RP;                                      /* RP + 8, written after the sort */
+        uint8_t *stage = reinterpret_cast<uint8_t *>(rk);  /* R + la + 11 <= 2*RP + 16 bytes */
+        const uint32_t nb = (R + (uint32_t)la + 8 + 3) & ~3u;
         for (uint32_t i = tid * 4; i < nb; i += MATCH_BLOCK * 4)
             *reinterpret_cast<uint32_t *>(stage + i) = *reinterpret_cast<const uint32_t *>(in + rstart + i);
         by = stage;
@@ -209,7 +260,8 @@ __global__ __launch_bounds__(MATCH_BLOCK) void k_match(const uint8_t *__restrict
         by = in + rstart;
     }
     for (uint32_t i = tid; i < RP; i += MATCH_BLOCK) ix[i] = (rank_t)i;
-    for (uint32_t i = tid; i < RP + 8; i += MATCH_BLOCK) rk[i] = 0;
+    if constexpr (!FAST)
+        for (uint32_t i = tid; i < RP + 8; i += MATCH_BLOCK) rk[i] = 0;
     __syncthreads();
 
     /* ---- bitonic sort of local indices by (key, index); indices >= R sort last ---- */
@@ -222,51 +274,51 @@ __global__ __launch_bounds__(MATCH_BLOCK) void k_match(const uint8_t *__restrict
                 const bool up = (i & k) == 0;
                 bool b_lt_a, a_lt_b;
                 if (a >= R || b >= R) { b_lt_a = b < a; a_lt_b = a < b; }
-                else { b_lt_a = key_less(by, b, a, la); a_lt_b = !b_lt_a; }
+                else { b_lt_a = key_less<FAST>(by, b, a, la); a_lt_b = !b_lt_a; }
                 if (up ? b_lt_a : a_lt_b) { ix[i] = (rank_t)b; ix[l] = (rank_t)a; }
             }
             __syncthreads();
         }
+    }
+    if constexpr (FAST) {                                    /* bytes are dead from here on: reuse as ranks */
+        for (uint32_t i = tid; i < RP + 8; i += MATCH_BLOCK) rk[i] = 0;
+        __syncthreads();
+        by = in + rstart;                                    /* the few remaining byte reads (LCPs) go to L1/L2 */
     }
     for (uint32_t r = tid; r < RP; r += MATCH_BLOCK) {
         const uint32_t a = ix[r];
         if (a < R) rk[a] = (rank_t)r;
     }
     __syncthreads();
-
     if (MODE == 2) return;                                   /* timing probe: sort + ranks only */
 
-    /* ---- pair scan: four consecutive positions per thread, window read in chunks of 4 ---- */
+    /* ---- pair scan: one octet of positions per thread, window streamed in octets ---- */
     const uint32_t usb = (uint32_t)sb;
-    for (uint32_t lx0 = lt0 + 4 * tid; lx0 < lt1; lx0 += 4 * MATCH_BLOCK) {
-        const uint32_t g = lx0 >> 2;
-        acc4<FAST> acc;
+    const uint32_t Mlast = (R - 1) >> 3;                     /* last octet holding a valid index */
+    for (uint32_t lx0 = lt0 + 8 * tid; lx0 < lt1; lx0 += 8 * MATCH_BLOCK) {
+        const uint32_t G = lx0 >> 3;
+        acc8<FAST> acc;
         acc.init(rk, lx0);
 
-        /* forward window y in [x+1, x+sb-1], y < R : in-order neighbours at eviction time */
+        /* forward window y in [x+1, x+sb-1], y < R : in-order neighbours at eviction time.
+         * Octets G+1 .. G+(sb-8)/8 lie inside every owned position's window. */
         {
-            const uint32_t mlast = min((lx0 + 3 + usb - 1) >> 2, (R - 1) >> 2);
-            uint32_t m = g;
-            uint32_t ilo = g + 1, ihi = 0;                         /* interior chunks [ilo, ihi] */
-            if (PACKED && usb >= 8 && R >= 4) ihi = min(g + (usb - 4) / 4, (R - 4) >> 2);
-            for (; m <= mlast; m++) {
-                if (m >= ilo && m <= ihi) { acc.chunk(rk, m); continue; }
-#pragma unroll
-                for (int j = 0; j < 4; j++) {
-                    const uint32_t y = 4 * m + j;
-                    if (y >= R) continue;
-                    const uint32_t ry = rk[y];
-#pragma unroll
-                    for (int i = 0; i < 4; i++) {
-                        const int32_t d = (int32_t)y - (int32_t)(lx0 + i);
-                        if (d >= 1 && d <= sb - 1) acc.one(i, ry);
-                    }
-                }
+            const uint32_t mend = min((lx0 + 7 + usb - 1) >> 3, Mlast);
+            uint32_t ilo = G + 1, ihi = G;                   /* empty */
+            if (MODE == 0 && usb >= 16 && R >= 8) ihi = min(G + (usb - 8) / 8, (R - 8) >> 3);
+            edge_octet<FAST, true>(acc, rk, G, lx0, R, 1, sb - 1);
+            uint32_t M = ilo;
+            for (; M + 1 <= ihi; M += 2) {
+                const auto v0 = acc8<FAST>::load(rk, M), v1 = acc8<FAST>::load(rk, M + 1);
+                acc.octet(v0);
+                acc.octet(v1);
             }
+            if (M <= ihi) { acc.octet(acc8<FAST>::load(rk, M)); M++; }
+            for (; M <= mend; M++) edge_octet<FAST, true>(acc, rk, M, lx0, R, 1, sb - 1);
         }
-        uint32_t psv[4];
+        uint32_t psv[8];
 #pragma unroll
-        for (int i = 0; i < 4; i++) {
+        for (int i = 0; i < 8; i++) {
             const uint32_t x = lx0 + i;
             uint32_t P = 0, S = 0;
             if (x < lt1 && (uint64_t)rstart + x + usb < n) {       /* only evicted positions matter */
@@ -277,57 +329,53 @@ __global__ __launch_bounds__(MATCH_BLOCK) void k_match(const uint8_t *__restrict
             psv[i] = P | (S << 16);
         }
 
-        /* backward window c in [x-sb, x-1], c >= 0 : longest match (tree.c:118-152 length) */
+        /* backward window c in [x-sb, x-1], c >= 0 : longest match (tree.c:118-152 length).
+         * Octets G-(sb-7)/8 .. G-1 lie inside every owned position's window. */
         acc.reset();
         {
-            const uint32_t mfirst = lx0 >= usb ? (lx0 - usb) >> 2 : 0;
-            uint32_t ilo = 1, ihi = 0;
-            if (PACKED && usb >= 7 && g >= 1) {
-                const uint32_t span = (usb - 3) / 4;                /* g-m in [1, span] is unmasked */
-                ihi = g - 1;
-                ilo = g > span ? g - span : 0;
+            const uint32_t mfirst = lx0 >= usb ? (lx0 - usb) >> 3 : 0;
+            uint32_t ilo = G, ihi = G;                       /* ihi exclusive here; empty */
+            if (MODE == 0 && usb >= 15 && G >= 1) {
+                const uint32_t span = (usb - 7) / 8;
+                ilo = G > span ? G - span : 0;
             }
-            for (uint32_t m = mfirst; m <= g; m++) {
-                if (m >= ilo && m <= ihi) { acc.chunk(rk, m); continue; }
-#pragma unroll
-                for (int j = 0; j < 4; j++) {
-                    const uint32_t c = 4 * m + j;
-                    if (c >= R) continue;
-                    const uint32_t rc = rk[c];
-#pragma unroll
-                    for (int i = 0; i < 4; i++) {
-                        const int32_t d = (int32_t)(lx0 + i) - (int32_t)c;
-                        if (d >= 1 && d <= sb) acc.one(i, rc);
-                    }
-                }
+            uint32_t M = mfirst;
+            for (; M < ilo; M++) edge_octet<FAST, false>(acc, rk, M, lx0, R, 1, sb);
+            for (; M + 1 < ihi; M += 2) {
+                const auto v0 = acc8<FAST>::load(rk, M), v1 = acc8<FAST>::load(rk, M + 1);
+                acc.octet(v0);
+                acc.octet(v1);
             }
+            if (M < ihi) { acc.octet(acc8<FAST>::load(rk, M)); M++; }
+            edge_octet<FAST, false>(acc, rk, G, lx0, R, 1, sb);
         }
-        uint32_t mlv = 0;
+        uint32_t mlv[2] = {0, 0};
 #pragma unroll
-        for (int i = 0; i < 4; i++) {
+        for (int i = 0; i < 8; i++) {
             const uint32_t x = lx0 + i;
             uint32_t best = 0;
             if (x < lt1) {
                 const uint32_t left = n - (rstart + x);
                 const int cap = (int)(left < (uint32_t)la ? left : (uint32_t)la) - 1;
                 const uint32_t mnu = acc.minu(i), mxu = acc.maxu(i), xr = acc.xrank(i);
-                if (mnu < HALF) best = (uint32_t)lcp_capped(by + (uint32_t)ix[(xr + mnu) & RMASK], by + x, cap);
+                if (mnu < HALF) best = (uint32_t)lcp_capped<false>(by, (uint32_t)ix[(xr + mnu) & RMASK], x, cap);
                 if (mxu >= HALF) {
-                    const uint32_t l2 = (uint32_t)lcp_capped(by + (uint32_t)ix[(xr + mxu) & RMASK], by + x, cap);
+                    const uint32_t l2 = (uint32_t)lcp_capped<false>(by, (uint32_t)ix[(xr + mxu) & RMASK], x, cap);
                     best = l2 > best ? l2 : best;
                 }
             }
-            mlv |= best << (8 * i);
+            mlv[i >> 2] |= best << (8 * (i & 3));
         }
 
         const uint32_t xa = rstart + lx0;
-        if (lx0 + 4 <= lt1) {
+        if (lx0 + 8 <= lt1) {
             *reinterpret_cast<uint4 *>(ps + xa) = make_uint4(psv[0], psv[1], psv[2], psv[3]);
-            *reinterpret_cast<uint32_t *>(maxlen + xa) = mlv;
+            *reinterpret_cast<uint4 *>(ps + xa + 4) = make_uint4(psv[4], psv[5], psv[6], psv[7]);
+            *reinterpret_cast<uint2 *>(maxlen + xa) = make_uint2(mlv[0], mlv[1]);
         } else {
-            for (int i = 0; i < 4 && lx0 + i < lt1; i++) {
+            for (int i = 0; i < 8 && lx0 + i < lt1; i++) {
                 ps[xa + i] = psv[i];
-                maxlen[xa + i] = (uint8_t)(mlv >> (8 * i));
+                maxlen[xa + i] = (uint8_t)(mlv[i >> 2] >> (8 * (i & 3)));
             }
         }
     }
@@ -336,7 +384,7 @@ __global__ __launch_bounds__(MATCH_BLOCK) void k_match(const uint8_t *__restrict
 size_t lz77k_match_lds_bytes(const lz77x_geom &g)
 {
     if (!g.fast) return 0;
-    return (size_t)(g.RP + 8) * 2 + (size_t)g.RP * 2 + (size_t)g.RP + 256 + 32;
+    return (size_t)g.RP * 2 + (size_t)(g.RP + 8) * 2;      /* ix + union{bytes, rk}: RP >= 4096 > la + 11 */
 }
 
 size_t lz77k_match_scratch_bytes(const lz77x_geom &g, uint32_t nregions)

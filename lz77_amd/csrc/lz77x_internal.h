@@ -28,9 +28,9 @@ extern "C" {
 typedef struct lz77x_geom {
     int sb, la;            /* search buffer, lookahead */
     int ob, lb, T;         /* bitof(sb), bitof(la), token bits (lz77.c:249-251) */
-    uint32_t SBu;          /* sb rounded up to a multiple of 4 */
+    uint32_t SBu;          /* sb rounded up to a multiple of 8 */
     uint32_t RP;           /* padded region size (power of two) */
-    uint32_t TILE;         /* positions produced per region (multiple of 4) */
+    uint32_t TILE;         /* positions produced per region (multiple of 8) */
     int fast;              /* 1: ranks are 16-bit and live in LDS (RP <= 32768) */
 } lz77x_geom;
 

@@ -210,6 +210,8 @@ int encode_core(Ctx &c, const void *src, bool src_on_device, size_t n, const lz7
         if ((rc = c.tstart.need(lz77k_tokens_tmp_bytes((uint32_t)idx_span)))) return rc;
         const char *tv = getenv("LZ77X_TOKEN_VARIANT");
         const int tvariant = tv ? atoi(tv) : 0;
+        const char *sv = getenv("LZ77X_SERIAL");               /* profiling aid: token kernels queue behind */
+        const hipStream_t tok_stream = (sv && atoi(sv)) ? s : c.tok;   /* the match launches, no overlap */
 
         lz77x_prio_state st;
         if (!lz77x_prio_init(&st, g.sb)) return LZ77X_E_NOMEM;
@@ -243,17 +245,18 @@ int encode_core(Ctx &c, const void *src, bool src_on_device, size_t n, const lz7
                     (q = hipMemcpyAsync(c.chain.as<uint32_t>() + tok_sent, c.h_chain.as<uint32_t>() + tok_sent,
                                         (ntok_sz - tok_sent) * 4, hipMemcpyHostToDevice, c.copy)) != hipSuccess) return q;
                 if ((q = hipEventRecord(c.chunk_ev[3 * ci + 2], c.copy)) != hipSuccess) return q;
-                if ((q = hipStreamWaitEvent(c.tok, c.chunk_ev[3 * ci + 2], 0)) != hipSuccess) return q;
-                if ((q = hipEventRecord(c.tok_ev[2 * ci], c.tok)) != hipSuccess) return q;
+                if ((q = hipStreamWaitEvent(tok_stream, c.chunk_ev[3 * ci + 2], 0)) != hipSuccess) return q;
+                if ((q = hipEventRecord(c.tok_ev[2 * ci], tok_stream)) != hipSuccess) return q;
                 /* hand-overs that can matter to tokens in [b, e): evictions before e-sb into dst >= b-sb */
                 const uint32_t dbase = b > (size_t)g.sb ? (uint32_t)(b - (size_t)g.sb) : 0u;
                 const uint32_t xa = dbase > (uint32_t)g.sb ? dbase - (uint32_t)g.sb : 0u;
                 if ((q = lz77k_xfer_index(c.ps.as<uint32_t>(), c.xval.as<uint32_t>(), xa, (uint32_t)x_done, dbase, (uint32_t)e,
-                                          c.ofs.as<uint32_t>(), c.ent.as<uint2>(), c.scantmp.p, c.tok)) != hipSuccess) return q;
+                                          c.ofs.as<uint32_t>(), c.ent.as<uint2>(), c.scantmp.p, tok_stream)) != hipSuccess) return q;
                 if ((q = lz77k_tokens(c.in.as<uint8_t>(), n32, g, c.chain.as<uint32_t>() + tok_sent, (uint32_t)(ntok_sz - tok_sent),
                                       c.maxlen.as<uint8_t>(), c.ofs.as<uint32_t>(), c.ent.as<uint2>(), dbase, (uint32_t)b, (uint32_t)e,
-                                      c.tokval.as<uint32_t>() + tok_sent, c.tstart.as<uint32_t>(), tvariant, c.tok)) != hipSuccess) return q;
-                return hipEventRecord(c.tok_ev[2 * ci + 1], c.tok);
+                                      c.tokval.as<uint32_t>() + tok_sent, c.tstart.as<uint32_t>(), tvariant, tok_stream)) != hipSuccess) return q;
+                if ((q = hipEventRecord(c.tok_ev[2 * ci + 1], tok_stream)) != hipSuccess) return q;
+                return tok_stream == c.tok ? hipSuccess : hipStreamWaitEvent(c.tok, c.tok_ev[2 * ci + 1], 0);
             };
             he = enqueue();
             if (he != hipSuccess) { err = LZ77X_E_HIP; snprintf(g_err, sizeof g_err, "chunk enqueue: %s", hipGetErrorString(he)); break; }

@@ -24,12 +24,12 @@ def bitof(n: int) -> int:
 
 def geometry(sb: int, la: int) -> dict:
     """Mirror of lz77x_make_geom (csrc/hoststage.c)."""
-    sbu = (sb + 3) & ~3
+    sbu = (sb + 7) & ~7
     rp = 4096
     while rp < 4 * sbu:
         rp <<= 1
     return {"sb": sb, "la": la, "ob": bitof(sb), "lb": bitof(la), "T": bitof(sb) + bitof(la) + 8,
-            "SBu": sbu, "RP": rp, "TILE": (rp - sbu - sb) & ~3, "fast": rp <= 16384}
+            "SBu": sbu, "RP": rp, "TILE": (rp - sbu - sb) & ~7, "fast": rp <= 16384}
 
 
 def stream_seed(base_seed: int, rank: int) -> int:

@@ -77,7 +77,7 @@ def test_geometry_mirror():
     for sb, la in ((4095, 15), (65535, 255), (1, 2), (5, 3), (1000, 10), (4096, 16), (8191, 15), (8192, 16)):
         g = shard.geometry(sb, la)
         assert g["T"] == O.token_bits(sb, la)
-        assert g["TILE"] % 4 == 0 and g["TILE"] >= 4 and g["TILE"] + g["SBu"] + sb <= g["RP"]
+        assert g["TILE"] % 8 == 0 and g["TILE"] >= 8 and g["TILE"] + g["SBu"] + sb <= g["RP"]
         assert g["RP"] & (g["RP"] - 1) == 0
     assert shard.geometry(4095, 15)["TILE"] == 8192 and shard.geometry(4095, 15)["fast"]
     assert not shard.geometry(65535, 255)["fast"]
