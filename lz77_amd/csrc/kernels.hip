@@ -19,6 +19,7 @@
  */
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include "lz77x_internal.h"
 
 #define MATCH_BLOCK 1024
@@ -291,6 +292,16 @@ __global__ __launch_bounds__(MATCH_BLOCK) void k_match(const uint8_t *__restrict
     }
     __syncthreads();
     if (MODE == 2) return;                                   /* timing probe: sort + ranks only */
+    if constexpr (FAST && MODE == 3) {
+        /* hand the order to the window walkers: rank[] and its inverse, 16-bit, per region */
+        uint16_t *grk = reinterpret_cast<uint16_t *>(scratch) + (size_t)blockIdx.x * 2 * RP;
+        uint16_t *gix = grk + RP;
+        for (uint32_t i = tid * 8; i < RP; i += MATCH_BLOCK * 8) {
+            *reinterpret_cast<uint4 *>(grk + i) = *reinterpret_cast<const uint4 *>(rk + i);
+            *reinterpret_cast<uint4 *>(gix + i) = *reinterpret_cast<const uint4 *>(ix + i);
+        }
+        return;
+    }
 
     /* ---- pair scan: one octet of positions per thread, window streamed in octets ---- */
     const uint32_t usb = (uint32_t)sb;
@@ -381,6 +392,186 @@ __global__ __launch_bounds__(MATCH_BLOCK) void k_match(const uint8_t *__restrict
     }
 }
 
+/* ------------------------------------------------------------------ window walkers --- */
+
+/*
+ * Sliding-window neighbour search in O(1) per position (replaces the O(SB) pair scan whenever
+ * a region's rank space fits a per-lane LDS bitmap, RP <= 16384).
+ *
+ * A walker is ONE LANE.  It owns a bitmap over the region's rank space (bit r set <=> the
+ * position with rank r is inside the current window) plus a one-bit-per-word summary, and slides
+ * the window one position at a time: clear the bit of the position that leaves, set the bit of
+ * the one that enters, then find the first set bit above / below the query's own rank -- the
+ * in-order successor / predecessor tree.c's BST would hold.  64 walkers share a wavefront; their
+ * bitmaps are word-interleaved in LDS (word w of lane l at (w*64+l)*4) so every access of the
+ * wave hits 64 distinct banks.  dir 0: forward window (x, x+sb) -> P/S at eviction time;
+ * dir 1: backward window [x-sb, x) -> longest-match candidates.
+ */
+#define WALK_NONE 0xFFFFu
+
+__global__ __launch_bounds__(64) void k_walk(const uint16_t *__restrict__ ranks, uint32_t n, int sb, uint32_t SBu, uint32_t RP,
+                                             uint32_t TILE, uint32_t region0, uint32_t nregions, uint32_t run_len,
+                                             uint32_t runs_per_tile, uint32_t *__restrict__ wf, uint32_t *__restrict__ wb)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t bm[];
+    const uint32_t lane = threadIdx.x;
+    const uint32_t NW = RP >> 5, NS = (NW + 31) >> 5;
+#define BM_WORD(w) bm[(w) * 64u + lane]
+#define BM_SUMM(w) bm[(NW + (w)) * 64u + lane]
+    const uint32_t id = blockIdx.x * 64u + lane;
+    const uint32_t dir = id & 1u;
+    const uint32_t run = (id >> 1) % runs_per_tile;
+    const uint32_t reg = (id >> 1) / runs_per_tile;
+    if (reg >= nregions) return;
+    const uint64_t t0_64 = (uint64_t)(region0 + reg) * TILE;
+    if (t0_64 >= n) return;
+    const uint32_t t0 = (uint32_t)t0_64;
+    const uint32_t rstart = t0 >= SBu ? t0 - SBu : 0;
+    const uint64_t rend64 = (uint64_t)t0 + TILE + (uint32_t)sb - 1;
+    const uint32_t R = (rend64 < n ? (uint32_t)rend64 : n) - rstart;
+    const uint32_t lt0 = t0 - rstart;
+    const uint32_t lt1 = ((uint64_t)t0 + TILE < n ? t0 + TILE : n) - rstart;
+    const uint32_t xa = lt0 + run * run_len;
+    if (xa >= lt1) return;
+    const uint32_t xb = min(xa + run_len, lt1);
+    const uint16_t *rk = ranks + (size_t)reg * 2 * RP;
+    uint32_t *out = (dir ? wb : wf) + (size_t)reg * TILE;                /* indexed by position - t0 */
+    const int32_t isb = sb;
+
+    for (uint32_t w = 0; w < NW + NS; w++) bm[w * 64u + lane] = 0;
+    auto set_bit = [&](uint32_t r) {
+        atomicOr(&BM_WORD(r >> 5), 1u << (r & 31));
+        atomicOr(&BM_SUMM(r >> 10), 1u << ((r >> 5) & 31));
+    };
+    auto clear_bit = [&](uint32_t r) {
+        const uint32_t bit = 1u << (r & 31);
+        const uint32_t old = atomicAnd(&BM_WORD(r >> 5), ~bit);
+        if ((old & ~bit) == 0) atomicAnd(&BM_SUMM(r >> 10), ~(1u << ((r >> 5) & 31)));
+    };
+    auto load8 = [&](int32_t i, uint32_t (&v)[4]) {          /* ranks i..i+7, any alignment */
+        if (i >= 0 && i + 8 <= (int32_t)RP) {
+            uint4 t;
+            __builtin_memcpy(&t, rk + i, 16);
+            v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const int32_t i0 = i + 2 * j, i1 = i0 + 1;
+                const uint32_t lo = (i0 >= 0 && i0 < (int32_t)RP) ? rk[i0] : 0u, hi = (i1 >= 0 && i1 < (int32_t)RP) ? rk[i1] : 0u;
+                v[j] = lo | (hi << 16);
+            }
+        }
+    };
+    /* window of the first query */
+    {
+        const int32_t lo = dir ? (int32_t)xa - isb : (int32_t)xa + 1;
+        const int32_t hi = dir ? (int32_t)xa - 1 : (int32_t)xa + isb - 1;
+        const int32_t a = lo < 0 ? 0 : lo, b = hi >= (int32_t)R ? (int32_t)R - 1 : hi;
+        int32_t i = a;
+        for (; i + 8 <= b + 1; i += 8) {
+            uint32_t v[4];
+            load8(i, v);
+#pragma unroll
+            for (int j = 0; j < 8; j++) set_bit((v[j >> 1] >> (16 * (j & 1))) & 0xFFFFu);
+        }
+        for (; i <= b; i++) set_bit(rk[i]);
+    }
+    /* one step: neighbours of q in the current window, then slide (enter before leave: with
+     * sb == 1 the entering and the leaving index coincide) */
+    auto step = [&](uint32_t q, uint32_t r_add, uint32_t r_rem) -> uint32_t {
+        const uint32_t w0 = q >> 5, b0 = q & 31;
+        const uint32_t here = BM_WORD(w0);
+        uint32_t succ = WALK_NONE, pred = WALK_NONE;
+        {
+            uint32_t w = w0, m = here & ~((2u << b0) - 1u);
+            if (!m) {
+                uint32_t sw = w >> 5, sm = BM_SUMM(sw) & ~((2u << (w & 31)) - 1u);
+                while (!sm && ++sw < NS) sm = BM_SUMM(sw);
+                if (sm) { w = (sw << 5) + (uint32_t)__builtin_ctz(sm); m = BM_WORD(w); }
+            }
+            if (m) succ = (w << 5) + (uint32_t)__builtin_ctz(m);
+        }
+        {
+            uint32_t w = w0, m = here & ((1u << b0) - 1u);
+            if (!m) {
+                int32_t sw = (int32_t)(w >> 5);
+                uint32_t sm = BM_SUMM(sw) & ((1u << (w & 31)) - 1u);
+                while (!sm && --sw >= 0) sm = BM_SUMM(sw);
+                if (sm) { w = ((uint32_t)sw << 5) + 31u - (uint32_t)__builtin_clz(sm); m = BM_WORD(w); }
+            }
+            if (m) pred = (w << 5) + 31u - (uint32_t)__builtin_clz(m);
+        }
+        if (r_add != WALK_NONE) set_bit(r_add);
+        if (r_rem != WALK_NONE) clear_bit(r_rem);
+        return succ | (pred << 16);
+    };
+    /* index of the position that enters / leaves after the query at x */
+    const int32_t add = dir ? 0 : isb, rem = dir ? -isb : 1;
+    auto valid = [&](int32_t i) { return i >= 0 && i < (int32_t)R; };
+    uint32_t x = xa;
+    /* groups of 8 steps: three 16-byte rank loads, two 16-byte result stores */
+    for (; x + 8 <= xb; x += 8) {
+        uint32_t vq[4], va[4], vr[4], res[8];
+        load8((int32_t)x, vq);
+        load8((int32_t)x + add, va);
+        load8((int32_t)x + rem, vr);
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            const uint32_t q = (vq[j >> 1] >> (16 * (j & 1))) & 0xFFFFu;
+            const uint32_t ra = valid((int32_t)x + j + add) ? (va[j >> 1] >> (16 * (j & 1))) & 0xFFFFu : WALK_NONE;
+            const uint32_t rr = valid((int32_t)x + j + rem) ? (vr[j >> 1] >> (16 * (j & 1))) & 0xFFFFu : WALK_NONE;
+            res[j] = step(q, ra, rr);
+        }
+        uint4 *o = reinterpret_cast<uint4 *>(out + (x - lt0));
+        o[0] = make_uint4(res[0], res[1], res[2], res[3]);
+        o[1] = make_uint4(res[4], res[5], res[6], res[7]);
+    }
+    for (; x < xb; x++) {
+        const int32_t ia = (int32_t)x + add, ir = (int32_t)x + rem;
+        out[x - lt0] = step(rk[x], valid(ia) ? (uint32_t)rk[ia] : WALK_NONE, valid(ir) ? (uint32_t)rk[ir] : WALK_NONE);
+    }
+#undef BM_WORD
+#undef BM_SUMM
+}
+
+/* ranks -> positions -> the two per-position results of the match stage */
+__global__ __launch_bounds__(256) void k_walk_final(const uint8_t *__restrict__ in, uint32_t n, int sb, int la, uint32_t SBu,
+                                                    uint32_t RP, uint32_t TILE, uint32_t region0, uint32_t nregions,
+                                                    const uint16_t *__restrict__ ranks, const uint32_t *__restrict__ wf,
+                                                    const uint32_t *__restrict__ wb, uint32_t *__restrict__ ps,
+                                                    uint8_t *__restrict__ maxlen)
+{
+    const uint64_t rel = (uint64_t)blockIdx.x * 256u + threadIdx.x;      /* position relative to region0*TILE */
+    const uint32_t reg = (uint32_t)(rel / TILE);
+    if (reg >= nregions) return;
+    const uint64_t x64 = (uint64_t)region0 * TILE + rel;
+    if (x64 >= n) return;
+    const uint32_t x = (uint32_t)x64;
+    const uint32_t t0 = (region0 + reg) * TILE;
+    const uint32_t rstart = t0 >= SBu ? t0 - SBu : 0;
+    const uint32_t lx = x - rstart;
+    const uint16_t *ix = ranks + (size_t)reg * 2 * RP + RP;
+    const uint32_t f = wf[rel], b = wb[rel];
+    uint32_t P = 0, S = 0;
+    if ((uint64_t)x + (uint32_t)sb < n) {
+        if ((f & 0xFFFFu) != WALK_NONE) S = (uint32_t)ix[f & 0xFFFFu] - lx;
+        if ((f >> 16) != WALK_NONE) P = (uint32_t)ix[f >> 16] - lx;
+    }
+    ps[x] = P | (S << 16);
+    const uint32_t left = n - x;
+    const int cap = (int)(left < (uint32_t)la ? left : (uint32_t)la) - 1;
+    const uint8_t *by = in + rstart;
+    uint32_t best = 0;
+    if ((b & 0xFFFFu) != WALK_NONE) best = (uint32_t)lcp_capped<false>(by, (uint32_t)ix[b & 0xFFFFu], lx, cap);
+    if ((b >> 16) != WALK_NONE) {
+        const uint32_t l2 = (uint32_t)lcp_capped<false>(by, (uint32_t)ix[b >> 16], lx, cap);
+        best = l2 > best ? l2 : best;
+    }
+    maxlen[x] = (uint8_t)best;
+}
+
+#define WALK_RUN_DEFAULT 2048u
+
 size_t lz77k_match_lds_bytes(const lz77x_geom &g)
 {
     if (!g.fast) return 0;
@@ -389,7 +580,8 @@ size_t lz77k_match_lds_bytes(const lz77x_geom &g)
 
 size_t lz77k_match_scratch_bytes(const lz77x_geom &g, uint32_t nregions)
 {
-    if (g.fast) return 0;
+    /* fast: rank + inverse (uint16 each) per region, then the walkers' fwd/bwd results per position */
+    if (g.fast) return (size_t)nregions * ((size_t)g.RP * 4 + (size_t)g.TILE * 8) + 256;
     return (size_t)nregions * (2 * (size_t)g.RP + 8) * sizeof(uint32_t);
 }
 
@@ -416,7 +608,30 @@ hipError_t lz77k_match(const uint8_t *d_in, uint32_t n, const lz77x_geom &g, uin
     if (g.fast) {
         if (variant == 1) return launch_match<true, 1>(LZ77K_MATCH_ARGS);
         if (variant == 2) return launch_match<true, 2>(LZ77K_MATCH_ARGS);
-        return launch_match<true, 0>(LZ77K_MATCH_ARGS);
+        if (variant == 3) return launch_match<true, 0>(LZ77K_MATCH_ARGS);      /* exhaustive packed pair scan */
+        /* production: sort -> per-lane bitmap walkers -> finalize */
+        hipError_t e = launch_match<true, 3>(LZ77K_MATCH_ARGS);
+        if (e != hipSuccess) return e;
+        uint16_t *ranks = reinterpret_cast<uint16_t *>(d_scratch);
+        uint32_t *wf = reinterpret_cast<uint32_t *>(ranks + (size_t)nregions * 2 * g.RP);
+        uint32_t *wb = wf + (size_t)nregions * g.TILE;
+        const char *rl = getenv("LZ77X_WALK_RUN");
+        uint32_t run_len = rl && atoi(rl) > 0 ? (uint32_t)atoi(rl) : WALK_RUN_DEFAULT;
+        run_len = (run_len + 7u) & ~7u;
+        if (run_len > g.TILE) run_len = g.TILE;
+        const uint32_t runs = (g.TILE + run_len - 1) / run_len;
+        const uint64_t walkers = (uint64_t)nregions * runs * 2;
+        const size_t lds = ((size_t)(g.RP >> 5) + (((g.RP >> 5) + 31) >> 5)) * 64 * sizeof(uint32_t);
+        if (lds > 48 * 1024) {
+            e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_walk), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) return e;
+        }
+        hipLaunchKernelGGL(k_walk, dim3((uint32_t)((walkers + 63) / 64)), dim3(64), lds, s, ranks, n, g.sb, g.SBu, g.RP, g.TILE,
+                           region0, nregions, run_len, runs, wf, wb);
+        const uint64_t npos = (uint64_t)nregions * g.TILE;
+        hipLaunchKernelGGL(k_walk_final, dim3((uint32_t)((npos + 255) / 256)), dim3(256), 0, s, d_in, n, g.sb, g.la, g.SBu, g.RP,
+                           g.TILE, region0, nregions, ranks, wf, wb, d_ps, d_maxlen);
+        return hipGetLastError();
     }
     if (variant == 1) return launch_match<false, 1>(LZ77K_MATCH_ARGS);
     if (variant == 2) return launch_match<false, 2>(LZ77K_MATCH_ARGS);

@@ -67,8 +67,9 @@ void lz77x_prio_run(lz77x_prio_state *st, const uint32_t *ps, int sb, size_t upt
 
 size_t lz77k_match_scratch_bytes(const lz77x_geom &g, uint32_t nregions);
 size_t lz77k_match_lds_bytes(const lz77x_geom &g);
-/* regions [region0, region0+nregions) of an n-byte padded input; variant 0 = packed
- * interior loop, 1 = all-masked reference loop (self-check), 2 = sort only (timing probe) */
+/* regions [region0, region0+nregions) of an n-byte padded input; variant 0 = production
+ * (fast geometry: sort + bitmap window walkers; else exhaustive pair scan), 1 = all-masked pair scan
+ * (self-check), 2 = sort only (timing probe), 3 = exhaustive packed pair scan */
 hipError_t lz77k_match(const uint8_t *d_in, uint32_t n, const lz77x_geom &g,
                        uint32_t region0, uint32_t nregions,
                        uint32_t *d_ps, uint8_t *d_maxlen, void *d_scratch, int variant, hipStream_t s);

@@ -158,11 +158,16 @@ int encode_core(Ctx &c, const void *src, bool src_on_device, size_t n, const lz7
         if (per_chunk < 512) per_chunk = 512;                          /* keep >= 2 workgroups per CU in flight */
         const char *cs = getenv("LZ77X_CHUNK_REGIONS");
         if (cs && atoi(cs) > 0) per_chunk = (uint32_t)atoi(cs);
-        if (!g.fast) {
+        uint32_t group = 8;                                            /* host chunks per match launch */
+        const char *gs = getenv("LZ77X_MATCH_GROUP");
+        if (gs && atoi(gs) > 0) group = (uint32_t)atoi(gs);
+        {
             const size_t per = lz77k_match_scratch_bytes(g, 1);
             const uint32_t fit = (uint32_t)(((size_t)2 << 30) / per);
             if (per_chunk > fit) per_chunk = fit ? fit : 1;
-            if ((rc = c.scratch.need(lz77k_match_scratch_bytes(g, per_chunk < nregions ? per_chunk : nregions)))) return rc;
+            if ((uint64_t)per_chunk * group > fit) group = fit / per_chunk ? fit / per_chunk : 1;
+            const uint64_t most = (uint64_t)per_chunk * group < nregions ? (uint64_t)per_chunk * group : nregions;
+            if ((rc = c.scratch.need(lz77k_match_scratch_bytes(g, (uint32_t)most)))) return rc;
         }
         const uint32_t nchunks = (nregions + per_chunk - 1) / per_chunk;
         while (c.chunk_ev.size() < 3 * (size_t)nchunks) {
@@ -178,24 +183,31 @@ int encode_core(Ctx &c, const void *src, bool src_on_device, size_t n, const lz7
         const char *vs = getenv("LZ77X_MATCH_VARIANT");
         const int variant = vs ? atoi(vs) : 0;
 
-        /* -- enqueue every match launch and its D2H up front -- */
+        /* -- enqueue every match launch and its D2H up front.  Match launches cover groups of
+         *    host chunks (the window walkers want >= 256 wavefronts per launch); the first group
+         *    is a single chunk so that the host stage can start early. -- */
         HIPCHK(hipEventRecord(c.ev[0], s));
-        for (uint32_t ci = 0; ci < nchunks; ci++) {
+        for (uint32_t ci = 0; ci < nchunks;) {
+            const uint32_t gchunks = ci == 0 ? 1u : group;
             const uint32_t r0 = ci * per_chunk;
-            const uint32_t nr = nregions - r0 < per_chunk ? nregions - r0 : per_chunk;
+            uint32_t nr = gchunks * per_chunk;
+            if (nr > nregions - r0) nr = nregions - r0;
             HIPCHK(lz77k_match(c.in.as<uint8_t>(), n32, g, r0, nr, c.ps.as<uint32_t>(), c.maxlen.as<uint8_t>(),
                                c.scratch.p, variant, s));
             g_stats.match_launches++;
             HIPCHK(hipEventRecord(c.chunk_ev[3 * ci], s));
             HIPCHK(hipStreamWaitEvent(c.copy, c.chunk_ev[3 * ci], 0));
-            const size_t b = (size_t)r0 * g.TILE;
-            size_t e = (size_t)(r0 + nr) * g.TILE;
-            if (e > n) e = n;
-            HIPCHK(hipMemcpyAsync(c.h_maxlen.as<uint8_t>() + b, c.maxlen.as<uint8_t>() + b, e - b, hipMemcpyDeviceToHost, c.copy));
-            const size_t pe = e < nx ? e : nx;
-            if (pe > b)
-                HIPCHK(hipMemcpyAsync(c.h_ps.as<uint32_t>() + b, c.ps.as<uint32_t>() + b, (pe - b) * 4, hipMemcpyDeviceToHost, c.copy));
-            HIPCHK(hipEventRecord(c.chunk_ev[3 * ci + 1], c.copy));
+            for (uint32_t cj = ci; cj < nchunks && cj < ci + gchunks; cj++) {
+                const size_t b = (size_t)cj * per_chunk * g.TILE;
+                size_t e = (size_t)(cj + 1) * per_chunk * g.TILE;
+                if (e > n) e = n;
+                HIPCHK(hipMemcpyAsync(c.h_maxlen.as<uint8_t>() + b, c.maxlen.as<uint8_t>() + b, e - b, hipMemcpyDeviceToHost, c.copy));
+                const size_t pe = e < nx ? e : nx;
+                if (pe > b)
+                    HIPCHK(hipMemcpyAsync(c.h_ps.as<uint32_t>() + b, c.ps.as<uint32_t>() + b, (pe - b) * 4, hipMemcpyDeviceToHost, c.copy));
+                HIPCHK(hipEventRecord(c.chunk_ev[3 * cj + 1], c.copy));
+            }
+            ci += gchunks;
         }
         HIPCHK(hipEventRecord(c.ev[1], s));
 
@@ -547,7 +559,7 @@ static int run_match_only(const uint8_t *in, size_t n, int sb, int la, lz77x_geo
     HIPCHK(hipMemsetAsync(c.ps.p, 0, (n + 8) * 4, s));
     const uint32_t nregions = (uint32_t)((n + g->TILE - 1) / g->TILE);
     uint32_t batch = nregions;
-    if (!g->fast && nregions) {
+    if (nregions) {
         const size_t per = lz77k_match_scratch_bytes(*g, 1);
         batch = (uint32_t)(((size_t)2 << 30) / per);
         if (batch < 1) batch = 1;
