@@ -88,7 +88,8 @@ void lz77x_prio_run(lz77x_prio_state *st, const uint32_t *ps, int sb, size_t upt
          * branch here mispredicts every third position */
         const uint64_t dp = (uint64_t)mine - (uint64_t)pp;         /* bit 63 set <=> mine < pp */
         const uint64_t ds = (uint64_t)mine - (uint64_t)sp;
-        const uint32_t go = (uint32_t)((dp & ds) >> 63) & ((0u - P) >> 31) & ((0u - S) >> 31);
+        /* a missing neighbour has distance 0, i.e. it reads x's own slot: mine < mine is false */
+        const uint32_t go = (uint32_t)((dp & ds) >> 63);
         const uint32_t m = 0u - go;
         ring[sidx] = sp ^ ((sp ^ mine) & m);  /* S==0: sidx==x&mask, dead slot, rewritten below */
         xval[x] = mine | ~m;                  /* LZ77X_NONE32 when nothing moves */

@@ -851,17 +851,32 @@ __global__ void k_tok_bounds(const uint32_t *__restrict__ chain, uint32_t ntok, 
     for (uint32_t t = first; t <= last; t++) tstart[t] = k;
 }
 
+#define TOK_HASH 1024u
+__device__ __forceinline__ uint32_t tok_hash(uint32_t b0, uint32_t b1) { return (b0 * 251u + b1 * 7u) & (TOK_HASH - 1u); }
+
+/*
+ * One workgroup per tile of TOK_TILE positions.  Staged in LDS: the window bytes, the hand-over
+ * lists of every candidate position, and (BUCKET) an index of the candidate positions by a hash
+ * of their first two bytes, so that a token of length >= 2 only visits the handful of window
+ * positions that start with its own two bytes instead of all SB of them.
+ */
+template <bool BUCKET>
 __global__ __launch_bounds__(TOK_BLOCK) void k_tokens_tile(const uint8_t *__restrict__ in, uint32_t n, int sb, int la, int ob, int lb,
                                                            const uint32_t *__restrict__ chain, const uint32_t *__restrict__ tstart,
                                                            const uint8_t *__restrict__ maxlen,
                                                            const uint32_t *__restrict__ ofs, const uint2 *__restrict__ ent,
                                                            uint32_t dbase, uint32_t pos0, uint32_t pos1,
-                                                           uint32_t *__restrict__ tokval, uint32_t ent_cap, uint32_t lofs_off, uint32_t lent_off)
+                                                           uint32_t *__restrict__ tokval, uint32_t ent_cap, uint32_t lofs_off,
+                                                           uint32_t lent_off, uint32_t bkt_off)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     uint8_t *by = smem;
     uint16_t *lofs = reinterpret_cast<uint16_t *>(smem + lofs_off);
     uint2 *lent = reinterpret_cast<uint2 *>(smem + lent_off);
+    uint32_t *bstart = reinterpret_cast<uint32_t *>(smem + bkt_off);          /* TOK_HASH + 1 (+pad) */
+    uint32_t *bcur = bstart + TOK_HASH + 8;                                    /* TOK_HASH */
+    uint16_t *blist = reinterpret_cast<uint16_t *>(bcur + TOK_HASH);           /* one entry per candidate */
+    __shared__ uint32_t wsum[TOK_BLOCK / 64];
 
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint32_t usb = (uint32_t)sb;
@@ -884,43 +899,69 @@ __global__ __launch_bounds__(TOK_BLOCK) void k_tokens_tile(const uint8_t *__rest
         }
         for (uint32_t e = tid; e < ecount; e += TOK_BLOCK) lent[e] = ent[ebase + e];
     }
+    if (BUCKET)
+        for (uint32_t i = tid; i < TOK_HASH; i += TOK_BLOCK) bcur[i] = 0;
     __syncthreads();
+    if (BUCKET) {
+        /* counting sort of the candidate positions by hash(first two bytes) */
+        for (uint32_t i = tid; i < NO; i += TOK_BLOCK) atomicAdd(&bcur[tok_hash(by[i], by[i + 1])], 1u);
+        __syncthreads();
+        {
+            static_assert(TOK_HASH == 2 * TOK_BLOCK, "two buckets per thread");
+            const uint32_t c0 = bcur[2 * tid], c1 = bcur[2 * tid + 1];
+            uint32_t incl = c0 + c1;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const uint32_t t = __shfl_up(incl, d, 64);
+                if (lane >= (uint32_t)d) incl += t;
+            }
+            if (lane == 63) wsum[wave] = incl;
+            __syncthreads();
+            uint32_t woff = 0;
+            for (uint32_t w = 0; w < wave; w++) woff += wsum[w];
+            const uint32_t excl = woff + incl - (c0 + c1);
+            bstart[2 * tid] = excl;
+            bstart[2 * tid + 1] = excl + c0;
+            if (tid == TOK_BLOCK - 1) bstart[TOK_HASH] = excl + c0 + c1;
+        }
+        __syncthreads();
+        for (uint32_t i = tid; i < TOK_HASH; i += TOK_BLOCK) bcur[i] = bstart[i];
+        __syncthreads();
+        for (uint32_t i = tid; i < NO; i += TOK_BLOCK) blist[atomicAdd(&bcur[tok_hash(by[i], by[i + 1])], 1u)] = (uint16_t)i;
+        __syncthreads();
+    }
 
     const uint32_t omask = ob >= 32 ? 0xFFFFFFFFu : (1u << ob) - 1u;
-    const uint32_t k1 = tstart[blockIdx.x + 1];
-    for (uint32_t k = tstart[blockIdx.x] + wave; k < k1; k += TOK_BLOCK / 64) {
-        const uint32_t p = chain[k];
-        const uint32_t len = maxlen[p];
-        const uint8_t *q = by + (p - wbase);
-        const uint32_t next = q[len];
-        uint32_t off = 0;
-        if (len > 0) {
-            const uint32_t head = ld32u(q);
-            const uint32_t hmask = len >= 4 ? 0xFFFFFFFFu : (1u << (8 * len)) - 1u;
-            const uint32_t cmin = p > usb ? p - usb : 0u;
-            uint64_t best = ~0ull;
-            for (uint32_t cg = (cmin & ~3u) + lane * 4; cg < p; cg += 256) {
-                const uint8_t *r = by + (cg - wbase);
-                const uint32_t lo = *reinterpret_cast<const uint32_t *>(r);
-                const uint32_t hi = *reinterpret_cast<const uint32_t *>(r + 4);
-#pragma unroll
-                for (int j = 0; j < 4; j++) {
-                    const uint32_t c = cg + j;
-                    const uint32_t w = j == 0 ? lo : __builtin_amdgcn_alignbyte(hi, lo, j);
-                    if (((w ^ head) & hmask) != 0 || c < cmin || c >= p) continue;
-                    bool same = true;
-                    for (uint32_t i = 4; i < len; i += 4) {
-                        uint32_t x = ld32u(r + j + i) ^ ld32u(q + i);
+    const uint32_t k0 = tstart[blockIdx.x], k1 = tstart[blockIdx.x + 1];
+    /* each wave takes tokens k0+wave, k0+wave+8, ...; their (position, length) are fetched 64 at a
+     * time, one per lane, so that the per-token loop never waits on global memory */
+    for (uint32_t kb = k0 + wave; kb < k1; kb += 64 * (TOK_BLOCK / 64)) {
+        const uint32_t kmine = kb + lane * (TOK_BLOCK / 64);
+        uint32_t p_l = 0, len_l = 0;
+        if (kmine < k1) { p_l = chain[kmine]; len_l = maxlen[p_l]; }
+        for (uint32_t j = 0; j < 64; j++) {
+            const uint32_t k = kb + j * (TOK_BLOCK / 64);
+            if (k >= k1) break;
+            const uint32_t p = __shfl(p_l, j, 64), len = __shfl(len_l, j, 64);
+            const uint32_t qo = p - wbase;
+            const uint32_t next = by[qo + len];
+            uint32_t off = 0;
+            if (len > 0) {
+                const uint32_t cmin = p > usb ? p - usb : 0u;
+                uint64_t best = ~0ull;
+                /* candidate c shares len bytes with p?  then its priority at time p */
+                auto consider = [&](uint32_t c) {
+                    const uint32_t co = c - wbase;
+                    for (uint32_t i = 0; i < len; i += 4) {
+                        uint32_t x = ld32_at<true>(by, co + i) ^ ld32_at<true>(by, qo + i);
                         const uint32_t rem = len - i;
                         if (rem < 4) x &= (1u << (8 * rem)) - 1u;
-                        if (x) { same = false; break; }
+                        if (x) return;
                     }
-                    if (!same) continue;
                     uint32_t prio = c, latest = 0;
                     bool any = false;
                     if (staged) {
-                        const uint32_t lc = c - wbase;
-                        for (uint32_t e = lofs[lc]; e < lofs[lc + 1]; e++) {
+                        for (uint32_t e = lofs[co]; e < lofs[co + 1]; e++) {
                             const uint2 t = lent[e];
                             if ((uint64_t)t.x + usb < p && (!any || t.x > latest)) { any = true; latest = t.x; prio = t.y; }
                         }
@@ -932,16 +973,38 @@ __global__ __launch_bounds__(TOK_BLOCK) void k_tokens_tile(const uint8_t *__rest
                     }
                     const uint64_t key = ((uint64_t)prio << 32) | c;
                     best = key < best ? key : best;
-                }
-            }
+                };
+                if (BUCKET && len >= 2) {
+                    const uint32_t h = tok_hash(by[qo], by[qo + 1]);
+                    const uint32_t e1 = bstart[h + 1];
+                    for (uint32_t i = bstart[h] + lane; i < e1; i += 64) {
+                        const uint32_t c = wbase + blist[i];
+                        if (c >= cmin && c < p) consider(c);
+                    }
+                } else {
+                    const uint32_t head = ld32_at<true>(by, qo);
+                    const uint32_t hmask = len >= 4 ? 0xFFFFFFFFu : (1u << (8 * len)) - 1u;
+                    for (uint32_t cg = (cmin & ~3u) + lane * 4; cg < p; cg += 256) {
+                        const uint8_t *r = by + (cg - wbase);
+                        const uint32_t lo = *reinterpret_cast<const uint32_t *>(r);
+                        const uint32_t hi = *reinterpret_cast<const uint32_t *>(r + 4);
 #pragma unroll
-            for (int d = 32; d > 0; d >>= 1) {
-                const uint64_t o = (uint64_t)__shfl_xor((unsigned long long)best, d, 64);
-                best = o < best ? o : best;
+                        for (int jj = 0; jj < 4; jj++) {
+                            const uint32_t c = cg + jj;
+                            const uint32_t w = jj == 0 ? lo : __builtin_amdgcn_alignbyte(hi, lo, jj);
+                            if (((w ^ head) & hmask) == 0 && c >= cmin && c < p) consider(c);
+                        }
+                    }
+                }
+#pragma unroll
+                for (int d = 32; d > 0; d >>= 1) {
+                    const uint64_t o = (uint64_t)__shfl_xor((unsigned long long)best, d, 64);
+                    best = o < best ? o : best;
+                }
+                off = p - (uint32_t)(best & 0xFFFFFFFFu);
             }
-            off = p - (uint32_t)(best & 0xFFFFFFFFu);
+            if (lane == 0) tokval[k] = (off & omask) | (len << ob) | (next << (ob + lb));
         }
-        if (lane == 0) tokval[k] = (off & omask) | (len << ob) | (next << (ob + lb));
     }
 }
 
@@ -956,22 +1019,25 @@ hipError_t lz77k_tokens(const uint8_t *d_in, uint32_t n, const lz77x_geom &g, co
                         uint32_t pos0, uint32_t pos1, uint32_t *d_tokval, uint32_t *d_tstart, int variant, hipStream_t s)
 {
     if (ntok == 0) return hipSuccess;
-    if (variant == 0 && g.sb <= 8192 && d_tstart) {
+    if ((variant == 0 || variant == 2) && g.sb <= 8192 && d_tstart) {
+        const bool bucket = variant == 0;
         const uint32_t ntiles = (pos1 - pos0 + TOK_TILE - 1) / TOK_TILE;
         const uint32_t span = TOK_TILE + (uint32_t)g.sb + 16;
         const uint32_t lofs_off = (span + (uint32_t)g.la + 16 + 15) & ~15u;
-        const uint32_t lent_off = (lofs_off + 2 * (span + 2) + 15) & ~15u;
+        const uint32_t bkt_off = (lofs_off + 2 * (span + 2) + 15) & ~15u;
+        const uint32_t bkt_bytes = bucket ? ((TOK_HASH + 8) * 4 + TOK_HASH * 4 + 2 * span + 15) & ~15u : 0u;
+        const uint32_t lent_off = bkt_off + bkt_bytes;
         const uint32_t budget = 78u * 1024u;                         /* two workgroups per CU */
-        uint32_t ent_cap = lent_off + 8 * span < budget ? (budget - lent_off) / 8 : span;
+        uint32_t ent_cap = lent_off + 5 * span < budget ? (budget - lent_off) / 8 : span;
         const size_t lds = (size_t)lent_off + (size_t)ent_cap * 8;
+        auto fn = bucket ? k_tokens_tile<true> : k_tokens_tile<false>;
         if (lds > 48 * 1024) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_tokens_tile),
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             if (e != hipSuccess) return e;
         }
         hipLaunchKernelGGL(k_tok_bounds, dim3((ntok + 256) / 256), dim3(256), 0, s, d_chain, ntok, pos0, ntiles, d_tstart);
-        hipLaunchKernelGGL(k_tokens_tile, dim3(ntiles), dim3(TOK_BLOCK), lds, s, d_in, n, g.sb, g.la, g.ob, g.lb, d_chain,
-                           d_tstart, d_maxlen, d_ofs, d_ent, dbase, pos0, pos1, d_tokval, ent_cap, lofs_off, lent_off);
+        hipLaunchKernelGGL(fn, dim3(ntiles), dim3(TOK_BLOCK), lds, s, d_in, n, g.sb, g.la, g.ob, g.lb, d_chain,
+                           d_tstart, d_maxlen, d_ofs, d_ent, dbase, pos0, pos1, d_tokval, ent_cap, lofs_off, lent_off, bkt_off);
         return hipGetLastError();
     }
     const uint32_t blocks = (ntok + 3) / 4;

@@ -86,8 +86,9 @@ hipError_t lz77k_xfer_index(const uint32_t *d_ps, const uint32_t *d_xval, uint32
                             uint32_t dbase, uint32_t dend, uint32_t *d_ofs, uint2 *d_ent,
                             void *d_scan_tmp, hipStream_t s);
 
-/* tokens d_chain[0..ntok) lie in [pos0, pos1).  variant 0: tiled kernel (window + hand-over lists
- * in LDS) when sb <= 8192; else / variant 1: one wave per token straight from global memory.
+/* tokens d_chain[0..ntok) lie in [pos0, pos1).  variant 0: tiled kernel (window, hand-over lists and a
+ * two-byte candidate index in LDS) when sb <= 8192; variant 2: same without the index (every
+ * candidate visited); else / variant 1: one wave per token straight from global memory.
  * d_tstart: lz77k_tokens_tmp_bytes(pos1-pos0). */
 size_t lz77k_tokens_tmp_bytes(uint32_t n);
 hipError_t lz77k_tokens(const uint8_t *d_in, uint32_t n, const lz77x_geom &g,

@@ -19,7 +19,9 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <atomic>
 #include <mutex>
+#include <thread>
 #include <vector>
 
 namespace {
@@ -227,26 +229,47 @@ int encode_core(Ctx &c, const void *src, bool src_on_device, size_t n, const lz7
 
         lz77x_prio_state st;
         if (!lz77x_prio_init(&st, g.sb)) return LZ77X_E_NOMEM;
-        size_t p = 0, ntok_sz = 0, tok_sent = 0, x_sent = 0;
-        double t_chain = 0, t_prio = 0;
+
+        /* The two host recurrences are independent of each other (SURVEY A.2 vs A.5), so the greedy
+         * parse chain runs on a helper thread and publishes, per chunk, how many tokens exist up
+         * to the chunk's end; the calling thread runs the priority recurrence. */
+        std::vector<std::atomic<uint64_t>> toks_upto(nchunks);
+        for (auto &t : toks_upto) t.store(~0ull, std::memory_order_relaxed);
+        std::atomic<int> chain_err{0};
+        double t_chain = 0;
+        std::thread chain_thread([&]() {
+            size_t pp = 0, kk = 0;
+            for (uint32_t ci = 0; ci < nchunks; ci++) {
+                size_t e = (size_t)(ci + 1) * per_chunk * g.TILE;
+                if (e > n) e = n;
+                if (hipEventSynchronize(c.chunk_ev[3 * ci + 1]) != hipSuccess) { chain_err.store(1); }
+                const double t0 = now_ms();
+                pp = lz77x_host_chain(c.h_maxlen.as<uint8_t>(), e, pp, c.h_chain.as<uint32_t>(), &kk);
+                t_chain += now_ms() - t0;
+                toks_upto[ci].store(kk, std::memory_order_release);
+            }
+        });
+        struct Joiner { std::thread &t; ~Joiner() { if (t.joinable()) t.join(); } } joiner{chain_thread};
+
+        size_t ntok_sz = 0, tok_sent = 0, x_sent = 0;
+        double t_prio = 0;
         int err = LZ77X_OK;
         for (uint32_t ci = 0; ci < nchunks && err == LZ77X_OK; ci++) {
-            const uint32_t r0 = ci * per_chunk;
-            const uint32_t nr = nregions - r0 < per_chunk ? nregions - r0 : per_chunk;
-            const size_t b = (size_t)r0 * g.TILE;
-            size_t e = (size_t)(r0 + nr) * g.TILE;
+            const size_t b = (size_t)ci * per_chunk * g.TILE;
+            size_t e = (size_t)(ci + 1) * per_chunk * g.TILE;
             if (e > n) e = n;
             const double tw = now_ms();
             hipError_t he = hipEventSynchronize(c.chunk_ev[3 * ci + 1]);
-            const double t0 = now_ms();
-            waited += t0 - tw;
-            if (he != hipSuccess) { err = LZ77X_E_HIP; snprintf(g_err, sizeof g_err, "chunk sync: %s", hipGetErrorString(he)); break; }
-            p = lz77x_host_chain(c.h_maxlen.as<uint8_t>(), e, p, c.h_chain.as<uint32_t>(), &ntok_sz);
             const double t1 = now_ms();
+            waited += t1 - tw;
+            if (he != hipSuccess) { err = LZ77X_E_HIP; snprintf(g_err, sizeof g_err, "chunk sync: %s", hipGetErrorString(he)); break; }
             lz77x_prio_run(&st, c.h_ps.as<uint32_t>(), g.sb, e, c.h_xval.as<uint32_t>());
             const double t2 = now_ms();
-            t_chain += t1 - t0;
             t_prio += t2 - t1;
+            uint64_t upto;
+            while ((upto = toks_upto[ci].load(std::memory_order_acquire)) == ~0ull) std::this_thread::yield();
+            waited += now_ms() - t2;
+            ntok_sz = (size_t)upto;
             const size_t x_done = e > (size_t)g.sb ? e - (size_t)g.sb : 0;
             auto enqueue = [&]() -> hipError_t {
                 hipError_t q;
@@ -275,6 +298,8 @@ int encode_core(Ctx &c, const void *src, bool src_on_device, size_t n, const lz7
             x_sent = x_done;
             tok_sent = ntok_sz;
         }
+        chain_thread.join();
+        if (chain_err.load()) err = LZ77X_E_HIP;
         ntok = (uint32_t)ntok_sz;
         nchunks_done = nchunks;
         transfers = st.transfers;
