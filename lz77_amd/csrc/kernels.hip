@@ -88,6 +88,115 @@ __device__ __forceinline__ int lcp_capped(const uint8_t *by, uint32_t a, uint32_
     return i < cap ? i : cap;
 }
 
+/*
+ * Bitonic sort of RP = 16*1024 local indices held in LDS, organised by how far apart the two
+ * elements of a compare-exchange are:
+ *   stride <  16   : both live in ONE thread (a thread owns 16 consecutive slots): registers only,
+ *                    with the first four key bytes cached so most compares never touch LDS bytes
+ *   stride < 1024  : both live in the 1024-slot segment ONE wave owns: LDS, no workgroup barrier
+ *   stride >= 1024 : across waves: LDS + __syncthreads (10 of the 105 steps)
+ */
+__device__ __forceinline__ bool sort_less(const uint8_t *by, uint32_t a, uint32_t pa, uint32_t b, uint32_t pb, uint32_t R, int la)
+{
+    if (pa != pb) return pa < pb;
+    if (a >= R || b >= R) return a < b;
+    return key_less<true>(by, a, b, la);
+}
+
+template <int J, bool STATIC_DIR>
+__device__ __forceinline__ void sort_local_pass(uint32_t (&v)[16], uint32_t (&pf)[16], const uint8_t *by, uint32_t R, int la,
+                                                int k_static, bool up_uniform)
+{
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+        if (r & J) continue;
+        const int s = r | J;
+        const bool up = STATIC_DIR ? ((r & k_static) == 0) : up_uniform;
+        const bool s_lt_r = sort_less(by, v[s], pf[s], v[r], pf[r], R, la);
+        if (up ? s_lt_r : !s_lt_r) {
+            const uint32_t tv = v[r], tp = pf[r];
+            v[r] = v[s]; pf[r] = pf[s];
+            v[s] = tv; pf[s] = tp;
+        }
+    }
+}
+
+__device__ __forceinline__ void region_sort_blocked(uint16_t *ix, const uint8_t *by, uint32_t R, uint32_t RP, int la, uint32_t tid)
+{
+    const uint32_t lane = tid & 63, wave = tid >> 6;
+    const uint32_t pmask = la >= 4 ? 0xFFFFFFFFu : 0xFFFFFFFFu << (8 * (4 - la));
+    uint32_t v[16], pf[16];
+    auto load_mine = [&]() {
+        const uint4 a = *reinterpret_cast<const uint4 *>(ix + 16 * tid), b = *reinterpret_cast<const uint4 *>(ix + 16 * tid + 8);
+        const uint32_t w[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            v[r] = (w[r >> 1] >> (16 * (r & 1))) & 0xFFFFu;
+            pf[r] = v[r] < R ? (__builtin_bswap32(ld32_at<true>(by, v[r])) & pmask) : 0xFFFFFFFFu;
+        }
+    };
+    auto store_mine = [&]() {
+        uint32_t w[8];
+#pragma unroll
+        for (int r = 0; r < 8; r++) w[r] = v[2 * r] | (v[2 * r + 1] << 16);
+        *reinterpret_cast<uint4 *>(ix + 16 * tid) = make_uint4(w[0], w[1], w[2], w[3]);
+        *reinterpret_cast<uint4 *>(ix + 16 * tid + 8) = make_uint4(w[4], w[5], w[6], w[7]);
+    };
+    auto lds_step = [&](uint32_t k, uint32_t j, uint32_t t) {         /* compare-exchange pair t of stride j */
+        const uint32_t i = 2 * t - (t & (j - 1)), l = i + j;
+        const uint32_t a = ix[i], b = ix[l];
+        const bool up = (i & k) == 0;
+        bool b_lt_a;
+        if (a >= R || b >= R) b_lt_a = b < a;
+        else b_lt_a = key_less<true>(by, b, a, la);
+        if (up ? b_lt_a : !b_lt_a) { ix[i] = (uint16_t)b; ix[l] = (uint16_t)a; }
+    };
+
+    /* phases k = 2..16: entirely inside a thread */
+    load_mine();
+    sort_local_pass<1, true>(v, pf, by, R, la, 2, false);
+    sort_local_pass<2, true>(v, pf, by, R, la, 4, false);
+    sort_local_pass<1, true>(v, pf, by, R, la, 4, false);
+    sort_local_pass<4, true>(v, pf, by, R, la, 8, false);
+    sort_local_pass<2, true>(v, pf, by, R, la, 8, false);
+    sort_local_pass<1, true>(v, pf, by, R, la, 8, false);
+    {
+        const bool up = ((16 * tid) & 16) == 0;
+        sort_local_pass<8, false>(v, pf, by, R, la, 0, up);
+        sort_local_pass<4, false>(v, pf, by, R, la, 0, up);
+        sort_local_pass<2, false>(v, pf, by, R, la, 0, up);
+        sort_local_pass<1, false>(v, pf, by, R, la, 0, up);
+    }
+    store_mine();
+    for (uint32_t k = 32; k <= RP; k <<= 1) {
+        uint32_t j = k >> 1;
+        if (j >= 1024) {
+            __syncthreads();                                          /* other waves' segments are read next */
+            for (; j >= 1024; j >>= 1) {
+                for (uint32_t t = tid; t < (RP >> 1); t += MATCH_BLOCK) lds_step(k, j, t);
+                __syncthreads();
+            }
+        } else {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        }
+        for (; j >= 16; j >>= 1) {                                    /* inside this wave's 1024 slots */
+#pragma unroll 2
+            for (uint32_t u = 0; u < 8; u++) lds_step(k, j, 512 * wave + lane + 64 * u);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        }
+        load_mine();
+        const bool up = ((16 * tid) & k) == 0;
+        sort_local_pass<8, false>(v, pf, by, R, la, 0, up);
+        sort_local_pass<4, false>(v, pf, by, R, la, 0, up);
+        sort_local_pass<2, false>(v, pf, by, R, la, 0, up);
+        sort_local_pass<1, false>(v, pf, by, R, la, 0, up);
+        store_mine();
+    }
+    __syncthreads();
+}
+
 /* ------------------------------------------------------------------ k_match ---------- */
 
 template <bool FAST> struct rank_traits;
@@ -223,7 +332,7 @@ template <bool FAST, int MODE>
 __global__ __launch_bounds__(MATCH_BLOCK) void k_match(const uint8_t *__restrict__ in, uint32_t n, int sb, int la,
                                                        uint32_t SBu, uint32_t RP, uint32_t TILE, uint32_t region0,
                                                        uint32_t *__restrict__ ps, uint8_t *__restrict__ maxlen,
-                                                       uint32_t *__restrict__ scratch)
+                                                       uint32_t *__restrict__ scratch, int sort_variant)
 {
     typedef typename rank_traits<FAST>::rank_t rank_t;
     constexpr uint32_t HALF = rank_traits<FAST>::HALF;
@@ -266,19 +375,23 @@ __global__ __launch_bounds__(MATCH_BLOCK) void k_match(const uint8_t *__restrict
     __syncthreads();
 
     /* ---- bitonic sort of local indices by (key, index); indices >= R sort last ---- */
-    for (uint32_t k = 2; k <= RP; k <<= 1) {
-        for (uint32_t j = k >> 1; j > 0; j >>= 1) {
-            for (uint32_t t = tid; t < (RP >> 1); t += MATCH_BLOCK) {
-                const uint32_t i = 2 * t - (t & (j - 1));
-                const uint32_t l = i + j;
-                const uint32_t a = ix[i], b = ix[l];
-                const bool up = (i & k) == 0;
-                bool b_lt_a, a_lt_b;
-                if (a >= R || b >= R) { b_lt_a = b < a; a_lt_b = a < b; }
-                else { b_lt_a = key_less<FAST>(by, b, a, la); a_lt_b = !b_lt_a; }
-                if (up ? b_lt_a : a_lt_b) { ix[i] = (rank_t)b; ix[l] = (rank_t)a; }
+    if (FAST && RP == 16 * MATCH_BLOCK && sort_variant == 0) {
+        region_sort_blocked(reinterpret_cast<uint16_t *>(ix), by, R, RP, la, tid);
+    } else {
+        for (uint32_t k = 2; k <= RP; k <<= 1) {
+            for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+                for (uint32_t t = tid; t < (RP >> 1); t += MATCH_BLOCK) {
+                    const uint32_t i = 2 * t - (t & (j - 1));
+                    const uint32_t l = i + j;
+                    const uint32_t a = ix[i], b = ix[l];
+                    const bool up = (i & k) == 0;
+                    bool b_lt_a, a_lt_b;
+                    if (a >= R || b >= R) { b_lt_a = b < a; a_lt_b = a < b; }
+                    else { b_lt_a = key_less<FAST>(by, b, a, la); a_lt_b = !b_lt_a; }
+                    if (up ? b_lt_a : a_lt_b) { ix[i] = (rank_t)b; ix[l] = (rank_t)a; }
+                }
+                __syncthreads();
             }
-            __syncthreads();
         }
     }
     if constexpr (FAST) {                                    /* bytes are dead from here on: reuse as ranks */
@@ -595,8 +708,9 @@ static hipError_t launch_match(const uint8_t *d_in, uint32_t n, const lz77x_geom
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
     }
+    const char *sv = getenv("LZ77X_SORT_VARIANT");
     hipLaunchKernelGGL(fn, dim3(nregions), dim3(MATCH_BLOCK), lds, s, d_in, n, g.sb, g.la, g.SBu, g.RP, g.TILE, region0,
-                       d_ps, d_maxlen, reinterpret_cast<uint32_t *>(d_scratch));
+                       d_ps, d_maxlen, reinterpret_cast<uint32_t *>(d_scratch), sv ? atoi(sv) : 0);
     return hipGetLastError();
 }
 
