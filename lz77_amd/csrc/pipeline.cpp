@@ -68,7 +68,7 @@ struct PinBuf {
         if (bytes <= cap) return LZ77X_OK;
         if (p) { hipError_t e0 = hipHostFree(p); (void)e0; p = nullptr; cap = 0; }
         size_t want = bytes + bytes / 8 + 4096;
-        HIPCHK(hipHostMalloc(&p, want, hipHostMallocDefault));
+        HIPCHK(hipHostMalloc(&p, want, hipHostMallocPortable));   /* every shard's device copies to/from it */
         cap = want;
         return LZ77X_OK;
     }
@@ -78,6 +78,7 @@ struct PinBuf {
 struct Ctx {
     bool ready = false;
     int ndev = 0;
+    int device = 0;                          /* physical HIP device this context lives on */
     hipStream_t stream = nullptr;            /* used when the caller passes none (host-level API) */
     hipStream_t copy = nullptr;              /* D2H/H2D of intermediates, overlapped with kernels */
     hipStream_t tok = nullptr;               /* per-chunk index + tie-break + pack kernels */
@@ -85,13 +86,14 @@ struct Ctx {
     std::vector<hipEvent_t> chunk_ev, tok_ev;
     DevBuf in, ps, maxlen, scratch, xval, chain, ofs, ent, tokval, out, scantmp;
     DevBuf z, len1, dst, ptr, flag, tstart;
-    PinBuf h_ps, h_maxlen, h_xval, h_chain, h_small;
+    PinBuf h_ps, h_maxlen, h_xval, h_chain, h_small, h_tok;
 };
 
-Ctx g_ctx;
+Ctx g_ctx;                                   /* context on the caller's current device */
+std::vector<Ctx *> g_more;                   /* contexts of the other shards (other devices) */
 std::mutex g_mu;
 
-int ctx_init(Ctx &c)
+int ctx_init(Ctx &c, int device = -1)
 {
     if (c.ready) return LZ77X_OK;
     int nd = 0;
@@ -101,6 +103,9 @@ int ctx_init(Ctx &c)
         return LZ77X_E_NODEV;
     }
     c.ndev = nd;
+    if (device < 0) HIPCHK(hipGetDevice(&device));
+    c.device = device;
+    HIPCHK(hipSetDevice(device));
     HIPCHK(hipStreamCreateWithFlags(&c.stream, hipStreamNonBlocking));
     HIPCHK(hipStreamCreateWithFlags(&c.copy, hipStreamNonBlocking));
     HIPCHK(hipStreamCreateWithFlags(&c.tok, hipStreamNonBlocking));
@@ -121,45 +126,75 @@ size_t stream_bytes(uint64_t ntok, int T) { return 4 + (size_t)((ntok * (uint64_
 
 /* ---------------------------------------------------------------- encode ------------ */
 
-/* src is a device pointer (src_on_device) or a host pointer.  On success the stream is in
- * c.out (device) and *zn holds its size.
+/* Contexts taking part in one encode: cs[0] is the caller's device (holds the pinned host buffers
+ * and the final stream), cs[1..] the other shards.  LZ77X_FAKE_DEVICES=k lets k contexts share one
+ * physical GPU so that the multi-device path can be exercised on a single-GPU box. */
+int shard_contexts(int want, std::vector<Ctx *> &cs)
+{
+    int rc = ctx_init(g_ctx);
+    if (rc) return rc;
+    cs.clear();
+    cs.push_back(&g_ctx);
+    int logical = g_ctx.ndev;
+    const char *fk = getenv("LZ77X_FAKE_DEVICES");
+    if (fk && atoi(fk) > logical) logical = atoi(fk);
+    if (want > logical) want = logical;
+    for (int i = 1; i < want; i++) {
+        if ((int)g_more.size() < i) g_more.push_back(new Ctx());
+        Ctx *c = g_more[i - 1];
+        if ((rc = ctx_init(*c, (g_ctx.device + i) % g_ctx.ndev))) return rc;
+        cs.push_back(c);
+    }
+    HIPCHK(hipSetDevice(g_ctx.device));
+    return LZ77X_OK;
+}
+
+/* src is a device pointer on cs[0]'s device (src_on_device, single shard only) or a host pointer.
+ * On success the stream is in cs[0]->out (device) and *zn holds its size.
  *
- * The match kernel is launched in chunks of regions; each chunk's {ps, maxlen} is copied to the
- * host on a second stream as soon as its launch retires, and the host's sequential stage consumes
- * chunk i while the GPU is already working on chunks i+1..  The host's products (xval, chain) go
- * back chunk by chunk on the same copy stream, so when the last chunk has been consumed the
- * device already holds everything the token kernels need. */
-int encode_core(Ctx &c, const void *src, bool src_on_device, size_t n, const lz77x_geom &g, hipStream_t s, size_t *zn)
+ * Positions are cut into host chunks of per_chunk regions; contiguous runs of chunks form the
+ * shards, one per context/device (read-only halos, no device-to-device traffic).
+ * Per device the match kernels are launched for groups of chunks; each chunk's {ps, maxlen} is
+ * copied to the host as soon as its launch retires, and the host's sequential stage consumes chunk
+ * i while the GPUs are already working on later chunks.  The host's products (xval, chain) go back
+ * to the chunk's owner, whose token stream resolves and emits that chunk's tokens at once. */
+int encode_core(std::vector<Ctx *> &cs, const void *src, bool src_on_device, size_t n, const lz77x_geom &g, hipStream_t s, size_t *zn)
 {
     const double t_begin = now_ms();
     memset(&g_stats, 0, sizeof g_stats);
     if (n > LZ77X_MAX_N) return LZ77X_E_TOOBIG;
+    Ctx &c0 = *cs[0];
+    const uint32_t D = (uint32_t)cs.size();
+    if (D > 1 && src_on_device) return LZ77X_E_ARG;
     const uint32_t n32 = (uint32_t)n;
     int rc;
     double waited = 0;
+    auto kstream = [&](uint32_t d) { return d == 0 ? s : cs[d]->stream; };
 
-    if ((rc = c.in.need(n + LZ77X_PAD + 16))) return rc;
-    if (n) HIPCHK(hipMemcpyAsync(c.in.p, src, n, src_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, s));
-    HIPCHK(lz77k_fill_pad(c.in.as<uint8_t>(), n32, s));
+    for (uint32_t d = 0; d < D; d++) {
+        Ctx &c = *cs[d];
+        HIPCHK(hipSetDevice(c.device));
+        if ((rc = c.in.need(n + LZ77X_PAD + 16))) return rc;
+        if (n) HIPCHK(hipMemcpyAsync(c.in.p, src, n, src_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, kstream(d)));
+        HIPCHK(lz77k_fill_pad(c.in.as<uint8_t>(), n32, kstream(d)));
+    }
+    HIPCHK(hipSetDevice(c0.device));
 
     uint32_t ntok = 0, nchunks_done = 0;
     uint64_t transfers = 0;
+    std::vector<uint32_t> owner;
     if (n) {
         const size_t nx = n > (size_t)g.sb ? n - (size_t)g.sb : 0;     /* evicted positions */
-        if ((rc = c.ps.need((n + 8) * 4))) return rc;
-        if ((rc = c.maxlen.need(n + 8))) return rc;
-        if ((rc = c.xval.need((n + 8) * 4))) return rc;
-        if ((rc = c.chain.need((n + 8) * 4))) return rc;
-        if ((rc = c.h_ps.need((n + 8) * 4))) return rc;
-        if ((rc = c.h_maxlen.need(n + 8))) return rc;
-        if ((rc = c.h_xval.need((n + 8) * 4))) return rc;
-        if ((rc = c.h_chain.need((n + 8) * 4))) return rc;
+        if ((rc = c0.h_ps.need((n + 8) * 4))) return rc;
+        if ((rc = c0.h_maxlen.need(n + 8))) return rc;
+        if ((rc = c0.h_xval.need((n + 8) * 4))) return rc;
+        if ((rc = c0.h_chain.need((n + 8) * 4))) return rc;
 
         const uint32_t nregions = (uint32_t)((n + g.TILE - 1) / g.TILE);
         uint32_t per_chunk = (uint32_t)(((size_t)4 << 20) / g.TILE);
         if (per_chunk < 512) per_chunk = 512;                          /* keep >= 2 workgroups per CU in flight */
-        const char *cs = getenv("LZ77X_CHUNK_REGIONS");
-        if (cs && atoi(cs) > 0) per_chunk = (uint32_t)atoi(cs);
+        const char *cs_env = getenv("LZ77X_CHUNK_REGIONS");
+        if (cs_env && atoi(cs_env) > 0) per_chunk = (uint32_t)atoi(cs_env);
         uint32_t group = 8;                                            /* host chunks per match launch */
         const char *gs = getenv("LZ77X_MATCH_GROUP");
         if (gs && atoi(gs) > 0) group = (uint32_t)atoi(gs);
@@ -168,64 +203,82 @@ int encode_core(Ctx &c, const void *src, bool src_on_device, size_t n, const lz7
             const uint32_t fit = (uint32_t)(((size_t)2 << 30) / per);
             if (per_chunk > fit) per_chunk = fit ? fit : 1;
             if ((uint64_t)per_chunk * group > fit) group = fit / per_chunk ? fit / per_chunk : 1;
-            const uint64_t most = (uint64_t)per_chunk * group < nregions ? (uint64_t)per_chunk * group : nregions;
-            if ((rc = c.scratch.need(lz77k_match_scratch_bytes(g, (uint32_t)most)))) return rc;
         }
         const uint32_t nchunks = (nregions + per_chunk - 1) / per_chunk;
-        while (c.chunk_ev.size() < 3 * (size_t)nchunks) {
-            hipEvent_t e;
-            HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));   /* ordering only */
-            c.chunk_ev.push_back(e);
-        }
-        while (c.tok_ev.size() < 2 * (size_t)nchunks) {
-            hipEvent_t e;
-            HIPCHK(hipEventCreate(&e));                                    /* token-stream kernel time */
-            c.tok_ev.push_back(e);
-        }
-        const char *vs = getenv("LZ77X_MATCH_VARIANT");
-        const int variant = vs ? atoi(vs) : 0;
-
-        /* -- enqueue every match launch and its D2H up front.  Match launches cover groups of
-         *    host chunks (the window walkers want >= 256 wavefronts per launch); the first group
-         *    is a single chunk so that the host stage can start early. -- */
-        HIPCHK(hipEventRecord(c.ev[0], s));
-        for (uint32_t ci = 0; ci < nchunks;) {
-            const uint32_t gchunks = ci == 0 ? 1u : group;
-            const uint32_t r0 = ci * per_chunk;
-            uint32_t nr = gchunks * per_chunk;
-            if (nr > nregions - r0) nr = nregions - r0;
-            HIPCHK(lz77k_match(c.in.as<uint8_t>(), n32, g, r0, nr, c.ps.as<uint32_t>(), c.maxlen.as<uint8_t>(),
-                               c.scratch.p, variant, s));
-            g_stats.match_launches++;
-            HIPCHK(hipEventRecord(c.chunk_ev[3 * ci], s));
-            HIPCHK(hipStreamWaitEvent(c.copy, c.chunk_ev[3 * ci], 0));
-            for (uint32_t cj = ci; cj < nchunks && cj < ci + gchunks; cj++) {
-                const size_t b = (size_t)cj * per_chunk * g.TILE;
-                size_t e = (size_t)(cj + 1) * per_chunk * g.TILE;
-                if (e > n) e = n;
-                HIPCHK(hipMemcpyAsync(c.h_maxlen.as<uint8_t>() + b, c.maxlen.as<uint8_t>() + b, e - b, hipMemcpyDeviceToHost, c.copy));
-                const size_t pe = e < nx ? e : nx;
-                if (pe > b)
-                    HIPCHK(hipMemcpyAsync(c.h_ps.as<uint32_t>() + b, c.ps.as<uint32_t>() + b, (pe - b) * 4, hipMemcpyDeviceToHost, c.copy));
-                HIPCHK(hipEventRecord(c.chunk_ev[3 * cj + 1], c.copy));
-            }
-            ci += gchunks;
-        }
-        HIPCHK(hipEventRecord(c.ev[1], s));
-
-        /* -- sequential host stage, chunk by chunk; each chunk's tokens are resolved on the
-         *    token stream while the host is already busy with the next chunk -- */
         const size_t chunk_pos = (size_t)per_chunk * g.TILE;
         const size_t idx_span = (chunk_pos < n ? chunk_pos : n) + 2 * (size_t)g.sb + 16;
-        if ((rc = c.ofs.need((idx_span + 8) * 4))) return rc;
-        if ((rc = c.ent.need((idx_span + 8) * 8))) return rc;
-        if ((rc = c.tokval.need((n + 8) * 4))) return rc;
-        if ((rc = c.scantmp.need(lz77k_scan_tmp_bytes((uint32_t)idx_span + 1)))) return rc;
-        if ((rc = c.tstart.need(lz77k_tokens_tmp_bytes((uint32_t)idx_span)))) return rc;
+        owner.resize(nchunks);
+        std::vector<uint32_t> first_chunk(D + 1, nchunks);
+        for (uint32_t ci = 0; ci < nchunks; ci++) {
+            owner[ci] = (uint32_t)((uint64_t)ci * D / nchunks);
+            if (first_chunk[owner[ci]] == nchunks) first_chunk[owner[ci]] = ci;
+        }
+        for (int d = (int)D - 1; d >= 0; d--)
+            if (first_chunk[d] == nchunks) first_chunk[d] = first_chunk[d + 1];      /* shard without chunks */
+
+        const char *vs = getenv("LZ77X_MATCH_VARIANT");
+        const int variant = vs ? atoi(vs) : 0;
         const char *tv = getenv("LZ77X_TOKEN_VARIANT");
         const int tvariant = tv ? atoi(tv) : 0;
         const char *sv = getenv("LZ77X_SERIAL");               /* profiling aid: token kernels queue behind */
-        const hipStream_t tok_stream = (sv && atoi(sv)) ? s : c.tok;   /* the match launches, no overlap */
+        const bool serial = sv && atoi(sv);                    /* the match launches, no overlap */
+        auto tstream = [&](uint32_t d) { return serial ? kstream(d) : cs[d]->tok; };
+
+        for (uint32_t d = 0; d < D; d++) {
+            Ctx &c = *cs[d];
+            HIPCHK(hipSetDevice(c.device));
+            const uint64_t most = (uint64_t)per_chunk * group < nregions ? (uint64_t)per_chunk * group : nregions;
+            if ((rc = c.scratch.need(lz77k_match_scratch_bytes(g, (uint32_t)most)))) return rc;
+            if ((rc = c.ps.need((n + 8) * 4))) return rc;
+            if ((rc = c.maxlen.need(n + 8))) return rc;
+            if ((rc = c.xval.need((n + 8) * 4))) return rc;
+            if ((rc = c.chain.need((n + 8) * 4))) return rc;
+            if ((rc = c.ofs.need((idx_span + 8) * 4))) return rc;
+            if ((rc = c.ent.need((idx_span + 8) * 8))) return rc;
+            if ((rc = c.tokval.need((n + 8) * 4))) return rc;
+            if ((rc = c.scantmp.need(lz77k_scan_tmp_bytes((uint32_t)idx_span + 1)))) return rc;
+            if ((rc = c.tstart.need(lz77k_tokens_tmp_bytes((uint32_t)idx_span)))) return rc;
+            while (c.chunk_ev.size() < 3 * (size_t)nchunks) {
+                hipEvent_t e;
+                HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));   /* ordering only */
+                c.chunk_ev.push_back(e);
+            }
+            while (c.tok_ev.size() < 2 * (size_t)nchunks) {
+                hipEvent_t e;
+                HIPCHK(hipEventCreate(&e));                                    /* token-stream kernel time */
+                c.tok_ev.push_back(e);
+            }
+
+            /* -- enqueue this shard's match launches and their D2H up front.  Launches cover groups
+             *    of host chunks (the window walkers want >= 256 wavefronts per launch); the very
+             *    first group is a single chunk so that the host stage can start early. -- */
+            if (d == 0) HIPCHK(hipEventRecord(c.ev[0], kstream(d)));
+            for (uint32_t ci = first_chunk[d]; ci < first_chunk[d + 1];) {
+                uint32_t gchunks = ci == 0 ? 1u : group;
+                if (ci + gchunks > first_chunk[d + 1]) gchunks = first_chunk[d + 1] - ci;
+                const uint32_t r0 = ci * per_chunk;
+                uint32_t nr = gchunks * per_chunk;
+                if (nr > nregions - r0) nr = nregions - r0;
+                HIPCHK(lz77k_match(c.in.as<uint8_t>(), n32, g, r0, nr, c.ps.as<uint32_t>(), c.maxlen.as<uint8_t>(),
+                                   c.scratch.p, variant, kstream(d)));
+                g_stats.match_launches++;
+                HIPCHK(hipEventRecord(c.chunk_ev[3 * ci], kstream(d)));
+                HIPCHK(hipStreamWaitEvent(c.copy, c.chunk_ev[3 * ci], 0));
+                for (uint32_t cj = ci; cj < ci + gchunks; cj++) {
+                    const size_t b = (size_t)cj * per_chunk * g.TILE;
+                    size_t e = (size_t)(cj + 1) * per_chunk * g.TILE;
+                    if (e > n) e = n;
+                    HIPCHK(hipMemcpyAsync(c0.h_maxlen.as<uint8_t>() + b, c.maxlen.as<uint8_t>() + b, e - b, hipMemcpyDeviceToHost, c.copy));
+                    const size_t pe = e < nx ? e : nx;
+                    if (pe > b)
+                        HIPCHK(hipMemcpyAsync(c0.h_ps.as<uint32_t>() + b, c.ps.as<uint32_t>() + b, (pe - b) * 4, hipMemcpyDeviceToHost, c.copy));
+                    HIPCHK(hipEventRecord(c.chunk_ev[3 * cj + 1], c.copy));
+                }
+                ci += gchunks;
+            }
+            if (d == 0) HIPCHK(hipEventRecord(c.ev[1], kstream(d)));
+        }
+        HIPCHK(hipSetDevice(c0.device));
 
         lz77x_prio_state st;
         if (!lz77x_prio_init(&st, g.sb)) return LZ77X_E_NOMEM;
@@ -242,19 +295,22 @@ int encode_core(Ctx &c, const void *src, bool src_on_device, size_t n, const lz7
             for (uint32_t ci = 0; ci < nchunks; ci++) {
                 size_t e = (size_t)(ci + 1) * per_chunk * g.TILE;
                 if (e > n) e = n;
-                if (hipEventSynchronize(c.chunk_ev[3 * ci + 1]) != hipSuccess) { chain_err.store(1); }
+                if (hipEventSynchronize(cs[owner[ci]]->chunk_ev[3 * ci + 1]) != hipSuccess) chain_err.store(1);
                 const double t0 = now_ms();
-                pp = lz77x_host_chain(c.h_maxlen.as<uint8_t>(), e, pp, c.h_chain.as<uint32_t>(), &kk);
+                pp = lz77x_host_chain(c0.h_maxlen.as<uint8_t>(), e, pp, c0.h_chain.as<uint32_t>(), &kk);
                 t_chain += now_ms() - t0;
                 toks_upto[ci].store(kk, std::memory_order_release);
             }
         });
         struct Joiner { std::thread &t; ~Joiner() { if (t.joinable()) t.join(); } } joiner{chain_thread};
 
-        size_t ntok_sz = 0, tok_sent = 0, x_sent = 0;
+        size_t ntok_sz = 0;
+        std::vector<size_t> tok_sent(D, 0), x_sent(D, 0);
         double t_prio = 0;
         int err = LZ77X_OK;
         for (uint32_t ci = 0; ci < nchunks && err == LZ77X_OK; ci++) {
+            const uint32_t d = owner[ci];
+            Ctx &c = *cs[d];
             const size_t b = (size_t)ci * per_chunk * g.TILE;
             size_t e = (size_t)(ci + 1) * per_chunk * g.TILE;
             if (e > n) e = n;
@@ -263,40 +319,50 @@ int encode_core(Ctx &c, const void *src, bool src_on_device, size_t n, const lz7
             const double t1 = now_ms();
             waited += t1 - tw;
             if (he != hipSuccess) { err = LZ77X_E_HIP; snprintf(g_err, sizeof g_err, "chunk sync: %s", hipGetErrorString(he)); break; }
-            lz77x_prio_run(&st, c.h_ps.as<uint32_t>(), g.sb, e, c.h_xval.as<uint32_t>());
+            lz77x_prio_run(&st, c0.h_ps.as<uint32_t>(), g.sb, e, c0.h_xval.as<uint32_t>());
             const double t2 = now_ms();
             t_prio += t2 - t1;
             uint64_t upto;
             while ((upto = toks_upto[ci].load(std::memory_order_acquire)) == ~0ull) std::this_thread::yield();
             waited += now_ms() - t2;
+            const size_t tok_before = ntok_sz;
             ntok_sz = (size_t)upto;
             const size_t x_done = e > (size_t)g.sb ? e - (size_t)g.sb : 0;
+            /* hand-overs that can matter to tokens in [b, e): evictions before e-sb into dst >= b-sb */
+            const uint32_t dbase = b > (size_t)g.sb ? (uint32_t)(b - (size_t)g.sb) : 0u;
+            const uint32_t xa = dbase > (uint32_t)g.sb ? dbase - (uint32_t)g.sb : 0u;
             auto enqueue = [&]() -> hipError_t {
                 hipError_t q;
-                if (x_done > x_sent &&
-                    (q = hipMemcpyAsync(c.xval.as<uint32_t>() + x_sent, c.h_xval.as<uint32_t>() + x_sent, (x_done - x_sent) * 4,
-                                        hipMemcpyHostToDevice, c.copy)) != hipSuccess) return q;
-                if (ntok_sz > tok_sent &&
-                    (q = hipMemcpyAsync(c.chain.as<uint32_t>() + tok_sent, c.h_chain.as<uint32_t>() + tok_sent,
-                                        (ntok_sz - tok_sent) * 4, hipMemcpyHostToDevice, c.copy)) != hipSuccess) return q;
+                if ((q = hipSetDevice(c.device)) != hipSuccess) return q;
+                if (ci == first_chunk[d]) {
+                    /* first chunk of a shard: its look-back window belongs to the previous shard */
+                    tok_sent[d] = tok_before;
+                    x_sent[d] = xa;
+                    if (d > 0 && b > xa &&
+                        (q = hipMemcpyAsync(c.ps.as<uint32_t>() + xa, c0.h_ps.as<uint32_t>() + xa, (b - xa) * 4,
+                                            hipMemcpyHostToDevice, c.copy)) != hipSuccess) return q;
+                }
+                if (x_done > x_sent[d] &&
+                    (q = hipMemcpyAsync(c.xval.as<uint32_t>() + x_sent[d], c0.h_xval.as<uint32_t>() + x_sent[d],
+                                        (x_done - x_sent[d]) * 4, hipMemcpyHostToDevice, c.copy)) != hipSuccess) return q;
+                if (ntok_sz > tok_sent[d] &&
+                    (q = hipMemcpyAsync(c.chain.as<uint32_t>() + tok_sent[d], c0.h_chain.as<uint32_t>() + tok_sent[d],
+                                        (ntok_sz - tok_sent[d]) * 4, hipMemcpyHostToDevice, c.copy)) != hipSuccess) return q;
                 if ((q = hipEventRecord(c.chunk_ev[3 * ci + 2], c.copy)) != hipSuccess) return q;
-                if ((q = hipStreamWaitEvent(tok_stream, c.chunk_ev[3 * ci + 2], 0)) != hipSuccess) return q;
-                if ((q = hipEventRecord(c.tok_ev[2 * ci], tok_stream)) != hipSuccess) return q;
-                /* hand-overs that can matter to tokens in [b, e): evictions before e-sb into dst >= b-sb */
-                const uint32_t dbase = b > (size_t)g.sb ? (uint32_t)(b - (size_t)g.sb) : 0u;
-                const uint32_t xa = dbase > (uint32_t)g.sb ? dbase - (uint32_t)g.sb : 0u;
+                if ((q = hipStreamWaitEvent(tstream(d), c.chunk_ev[3 * ci + 2], 0)) != hipSuccess) return q;
+                if ((q = hipEventRecord(c.tok_ev[2 * ci], tstream(d))) != hipSuccess) return q;
                 if ((q = lz77k_xfer_index(c.ps.as<uint32_t>(), c.xval.as<uint32_t>(), xa, (uint32_t)x_done, dbase, (uint32_t)e,
-                                          c.ofs.as<uint32_t>(), c.ent.as<uint2>(), c.scantmp.p, tok_stream)) != hipSuccess) return q;
-                if ((q = lz77k_tokens(c.in.as<uint8_t>(), n32, g, c.chain.as<uint32_t>() + tok_sent, (uint32_t)(ntok_sz - tok_sent),
+                                          c.ofs.as<uint32_t>(), c.ent.as<uint2>(), c.scantmp.p, tstream(d))) != hipSuccess) return q;
+                if ((q = lz77k_tokens(c.in.as<uint8_t>(), n32, g, c.chain.as<uint32_t>() + tok_sent[d], (uint32_t)(ntok_sz - tok_sent[d]),
                                       c.maxlen.as<uint8_t>(), c.ofs.as<uint32_t>(), c.ent.as<uint2>(), dbase, (uint32_t)b, (uint32_t)e,
-                                      c.tokval.as<uint32_t>() + tok_sent, c.tstart.as<uint32_t>(), tvariant, tok_stream)) != hipSuccess) return q;
-                if ((q = hipEventRecord(c.tok_ev[2 * ci + 1], tok_stream)) != hipSuccess) return q;
-                return tok_stream == c.tok ? hipSuccess : hipStreamWaitEvent(c.tok, c.tok_ev[2 * ci + 1], 0);
+                                      c.tokval.as<uint32_t>() + tok_sent[d], c.tstart.as<uint32_t>(), tvariant, tstream(d))) != hipSuccess) return q;
+                if ((q = hipEventRecord(c.tok_ev[2 * ci + 1], tstream(d))) != hipSuccess) return q;
+                return tstream(d) == c.tok ? hipSuccess : hipStreamWaitEvent(c.tok, c.tok_ev[2 * ci + 1], 0);
             };
             he = enqueue();
             if (he != hipSuccess) { err = LZ77X_E_HIP; snprintf(g_err, sizeof g_err, "chunk enqueue: %s", hipGetErrorString(he)); break; }
-            x_sent = x_done;
-            tok_sent = ntok_sz;
+            x_sent[d] = x_done;
+            tok_sent[d] = ntok_sz;
         }
         chain_thread.join();
         if (chain_err.load()) err = LZ77X_E_HIP;
@@ -304,29 +370,53 @@ int encode_core(Ctx &c, const void *src, bool src_on_device, size_t n, const lz7
         nchunks_done = nchunks;
         transfers = st.transfers;
         lz77x_prio_free(&st);
-        if (err != LZ77X_OK) { hipError_t q = hipDeviceSynchronize(); (void)q; return err; }
+        if (err != LZ77X_OK) {
+            for (Ctx *c : cs) { hipError_t q = hipSetDevice(c->device); q = hipDeviceSynchronize(); (void)q; }
+            hipError_t q = hipSetDevice(c0.device); (void)q;
+            return err;
+        }
         g_stats.host_chain_ms = t_chain;
         g_stats.host_stageb_ms = t_prio;
+
+        /* -- other shards hand their token values to the first device through the host -- */
+        if (D > 1) {
+            if ((rc = c0.h_tok.need(((size_t)ntok + 8) * 4))) return rc;
+            for (uint32_t d = 1; d < D; d++) {
+                Ctx &c = *cs[d];
+                if (first_chunk[d] >= first_chunk[d + 1]) continue;
+                const size_t ta = first_chunk[d] ? (size_t)toks_upto[first_chunk[d] - 1].load() : 0;
+                const size_t tb = (size_t)toks_upto[first_chunk[d + 1] - 1].load();
+                HIPCHK(hipSetDevice(c.device));
+                HIPCHK(hipMemcpyAsync(c0.h_tok.as<uint32_t>() + ta, c.tokval.as<uint32_t>() + ta, (tb - ta) * 4, hipMemcpyDeviceToHost, c.tok));
+                const double tw = now_ms();
+                HIPCHK(hipStreamSynchronize(c.tok));
+                waited += now_ms() - tw;
+                HIPCHK(hipSetDevice(c0.device));
+                HIPCHK(hipMemcpyAsync(c0.tokval.as<uint32_t>() + ta, c0.h_tok.as<uint32_t>() + ta, (tb - ta) * 4, hipMemcpyHostToDevice, c0.tok));
+            }
+            HIPCHK(hipSetDevice(c0.device));
+        }
     } else {
-        if ((rc = c.tokval.need(64))) return rc;
-        HIPCHK(hipEventRecord(c.ev[0], s));
-        HIPCHK(hipEventRecord(c.ev[1], s));
+        if ((rc = c0.tokval.need(64))) return rc;
+        HIPCHK(hipEventRecord(c0.ev[0], s));
+        HIPCHK(hipEventRecord(c0.ev[1], s));
     }
     *zn = stream_bytes(ntok, g.T);
     const uint64_t nwords = (*zn + 3) / 4;
-    if ((rc = c.out.need(nwords * 4 + 16))) return rc;
-    HIPCHK(lz77k_pack(c.tokval.as<uint32_t>(), ntok, g, c.out.as<uint32_t>(), nwords, c.tok));
-    HIPCHK(hipEventRecord(c.ev[3], c.tok));
-    HIPCHK(hipStreamWaitEvent(s, c.ev[3], 0));        /* later work on the caller's stream sees the result */
+    if ((rc = c0.out.need(nwords * 4 + 16))) return rc;
+    HIPCHK(lz77k_pack(c0.tokval.as<uint32_t>(), ntok, g, c0.out.as<uint32_t>(), nwords, c0.tok));
+    HIPCHK(hipEventRecord(c0.ev[3], c0.tok));
+    HIPCHK(hipStreamWaitEvent(s, c0.ev[3], 0));       /* later work on the caller's stream sees the result */
     const double tw = now_ms();
     HIPCHK(hipStreamSynchronize(s));
     waited += now_ms() - tw;
 
     float ms = 0;
-    HIPCHK(hipEventElapsedTime(&ms, c.ev[0], c.ev[1]));
+    HIPCHK(hipEventElapsedTime(&ms, c0.ev[0], c0.ev[1]));
     g_stats.k_match_ms = ms;
     double tok_ms = 0;
     for (uint32_t ci = 0; ci < nchunks_done; ci++) {
+        Ctx &c = *cs[owner[ci]];
         HIPCHK(hipEventElapsedTime(&ms, c.tok_ev[2 * ci], c.tok_ev[2 * ci + 1]));
         tok_ms += ms;
     }
@@ -454,11 +544,14 @@ int lz77x_encode(const uint8_t *in, size_t n, int sb, int la, uint8_t **out, siz
     int rc = check_geom(sb, la);
     if (rc) return rc;
     std::lock_guard<std::mutex> lk(g_mu);
-    if ((rc = ctx_init(g_ctx))) return rc;
+    std::vector<Ctx *> cs;
+    int shards = g_shards;
+    if (shards <= 0) { const char *e = getenv("LZ77X_SHARDS"); shards = e ? atoi(e) : 1; }
+    if ((rc = shard_contexts(shards < 1 ? 1 : shards, cs))) return rc;
     lz77x_geom g;
     lz77x_make_geom(&g, sb, la);
     size_t zn = 0;
-    if ((rc = encode_core(g_ctx, in, false, n, g, g_ctx.stream, &zn))) return rc;
+    if ((rc = encode_core(cs, in, false, n, g, g_ctx.stream, &zn))) return rc;
     uint8_t *buf = (uint8_t *)malloc(zn ? zn : 1);
     if (!buf) return LZ77X_E_NOMEM;
     HIPCHK(hipMemcpy(buf, g_ctx.out.p, zn, hipMemcpyDeviceToHost));
@@ -473,12 +566,13 @@ int lz77x_encode_device(const void *d_in, size_t n, int sb, int la, void *d_out,
     int rc = check_geom(sb, la);
     if (rc) return rc;
     std::lock_guard<std::mutex> lk(g_mu);
-    if ((rc = ctx_init(g_ctx))) return rc;
+    std::vector<Ctx *> cs;
+    if ((rc = shard_contexts(1, cs))) return rc;      /* device-resident buffers: the caller's device only */
     lz77x_geom g;
     lz77x_make_geom(&g, sb, la);
     hipStream_t s = (hipStream_t)stream;
     size_t zn = 0;
-    if ((rc = encode_core(g_ctx, d_in, true, n, g, s, &zn))) return rc;
+    if ((rc = encode_core(cs, d_in, true, n, g, s, &zn))) return rc;
     *out_n = zn;
     if (zn > out_cap) return LZ77X_E_CAP;
     HIPCHK(hipMemcpyAsync(d_out, g_ctx.out.p, zn, hipMemcpyDeviceToDevice, s));

@@ -152,6 +152,47 @@ def test_roundtrip_properties_large():
     assert len(common) >= len(z2) - 3 * 16
 
 
+@pytest.mark.parametrize("kind,seed,n,sb,la", [("text", 81, 3_000_000, 4095, 15), ("random", 82, 1_500_000, 4095, 15),
+                                              ("mixed", 83, 2_000_000, 1000, 10), ("mixed", 84, 1_200_000, 65535, 255)])
+def test_shards_give_identical_bytes(kind, seed, n, sb, la, monkeypatch):
+    """positions cut into 1/2/3/4/8 shards (one device context each; contexts share the
+    single physical GPU of the test box) -> the same stream, bit for bit.  Small chunks so that
+    every shard owns several and the cross-shard look-back (2*SB evictions) is exercised."""
+    data = synth.make(kind, n, seed)
+    want = O.encode_bst(data, sb, la)
+    monkeypatch.setenv("LZ77X_FAKE_DEVICES", "8")
+    monkeypatch.setenv("LZ77X_CHUNK_REGIONS", "2" if sb > 8192 else "8")
+    try:
+        for shards in (1, 2, 3, 4, 8):
+            assert L.lib().lz77x_set_shards(shards) == 0
+            assert L.encode(data, la, sb) == want, shards
+    finally:
+        L.lib().lz77x_set_shards(1)
+
+
+def test_small_chunks_pipeline(monkeypatch):
+    """many tiny host chunks and single-chunk match groups: same bytes as one big chunk"""
+    data = synth.text(5_000_000, 85)
+    want = O.encode_bst(data)
+    for chunk, group in (("1", "1"), ("3", "2"), ("64", "8")):
+        monkeypatch.setenv("LZ77X_CHUNK_REGIONS", chunk)
+        monkeypatch.setenv("LZ77X_MATCH_GROUP", group)
+        assert L.encode(data) == want, (chunk, group)
+
+
+@pytest.mark.parametrize("env", [{"LZ77X_MATCH_VARIANT": "1"}, {"LZ77X_MATCH_VARIANT": "3"}, {"LZ77X_SORT_VARIANT": "1"},
+                                 {"LZ77X_TOKEN_VARIANT": "1"}, {"LZ77X_TOKEN_VARIANT": "2"}, {"LZ77X_WALK_RUN": "64"},
+                                 {"LZ77X_WALK_RUN": "8192"}])
+def test_kernel_variants_agree(env, monkeypatch):
+    """independent formulations of the same stage (exhaustive pair scan vs bitmap walkers, plain vs
+    blocked sort, three token kernels) all reproduce the reference stream"""
+    data = synth.mixed(3_000_000, 86)
+    want = O.encode_bst(data)
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    assert L.encode(data) == want
+
+
 def test_arg_errors():
     for la, sb in ((1, 4095), (256, 4095), (15, 0), (15, 65536)):
         with pytest.raises(L.Lz77Error) as e:
