@@ -91,7 +91,8 @@ const char *lz77x_version(void);
  * times are hipEvent pairs on the call's stream; host_* are wall clock. */
 typedef struct lz77x_stats {
     double total_ms;          /* whole call */
-    double k_match_ms;        /* region kernel: window sort + pair scan (stage A + longest match) */
+    double k_match_ms;        /* match stage (replaces tree.c): region sort + window walkers + finalize */
+    double k_sort_ms;         /* of which: the region-sort kernel alone (0 if that path was not taken) */
     double k_token_ms;        /* transfer index + tie-break + token pack kernels */
     double k_decode_ms;       /* parse + scan + copy-resolution kernels */
     double host_chain_ms;     /* greedy parse chain walk (host) */

@@ -36,7 +36,8 @@ class Lz77Error(RuntimeError):
 
 
 class Stats(ctypes.Structure):
-    _fields_ = [("total_ms", ctypes.c_double), ("k_match_ms", ctypes.c_double), ("k_token_ms", ctypes.c_double),
+    _fields_ = [("total_ms", ctypes.c_double), ("k_match_ms", ctypes.c_double), ("k_sort_ms", ctypes.c_double),
+                ("k_token_ms", ctypes.c_double),
                 ("k_decode_ms", ctypes.c_double), ("host_chain_ms", ctypes.c_double),
                 ("host_stageb_ms", ctypes.c_double), ("copy_ms", ctypes.c_double),
                 ("n", ctypes.c_uint64), ("zn", ctypes.c_uint64), ("ntok", ctypes.c_uint64),

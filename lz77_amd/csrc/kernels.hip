@@ -715,17 +715,21 @@ static hipError_t launch_match(const uint8_t *d_in, uint32_t n, const lz77x_geom
 }
 
 hipError_t lz77k_match(const uint8_t *d_in, uint32_t n, const lz77x_geom &g, uint32_t region0, uint32_t nregions,
-                       uint32_t *d_ps, uint8_t *d_maxlen, void *d_scratch, int variant, hipStream_t s)
+                       uint32_t *d_ps, uint8_t *d_maxlen, void *d_scratch, int variant, hipStream_t s, hipEvent_t *ev_sort)
 {
     if (nregions == 0) return hipSuccess;
+    if (ev_sort && !(g.fast && (variant == 0 || variant > 3))) ev_sort = nullptr;
 #define LZ77K_MATCH_ARGS d_in, n, g, region0, nregions, d_ps, d_maxlen, d_scratch, s
     if (g.fast) {
         if (variant == 1) return launch_match<true, 1>(LZ77K_MATCH_ARGS);
         if (variant == 2) return launch_match<true, 2>(LZ77K_MATCH_ARGS);
         if (variant == 3) return launch_match<true, 0>(LZ77K_MATCH_ARGS);      /* exhaustive packed pair scan */
         /* production: sort -> per-lane bitmap walkers -> finalize */
-        hipError_t e = launch_match<true, 3>(LZ77K_MATCH_ARGS);
+        hipError_t e = ev_sort ? hipEventRecord(ev_sort[0], s) : hipSuccess;
         if (e != hipSuccess) return e;
+        e = launch_match<true, 3>(LZ77K_MATCH_ARGS);
+        if (e != hipSuccess) return e;
+        if (ev_sort && (e = hipEventRecord(ev_sort[1], s)) != hipSuccess) return e;
         uint16_t *ranks = reinterpret_cast<uint16_t *>(d_scratch);
         uint32_t *wf = reinterpret_cast<uint32_t *>(ranks + (size_t)nregions * 2 * g.RP);
         uint32_t *wb = wf + (size_t)nregions * g.TILE;

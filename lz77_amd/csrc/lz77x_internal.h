@@ -72,7 +72,8 @@ size_t lz77k_match_lds_bytes(const lz77x_geom &g);
  * (self-check), 2 = sort only (timing probe), 3 = exhaustive packed pair scan */
 hipError_t lz77k_match(const uint8_t *d_in, uint32_t n, const lz77x_geom &g,
                        uint32_t region0, uint32_t nregions,
-                       uint32_t *d_ps, uint8_t *d_maxlen, void *d_scratch, int variant, hipStream_t s);
+                       uint32_t *d_ps, uint8_t *d_maxlen, void *d_scratch, int variant, hipStream_t s,
+                       hipEvent_t *ev_sort = nullptr /* [2]: recorded around the region-sort kernel */);
 
 hipError_t lz77k_fill_pad(uint8_t *d_in, uint32_t n, hipStream_t s);
 

@@ -83,7 +83,7 @@ struct Ctx {
     hipStream_t copy = nullptr;              /* D2H/H2D of intermediates, overlapped with kernels */
     hipStream_t tok = nullptr;               /* per-chunk index + tie-break + pack kernels */
     hipEvent_t ev[6] = {};
-    std::vector<hipEvent_t> chunk_ev, tok_ev;
+    std::vector<hipEvent_t> chunk_ev, tok_ev, sort_ev;
     DevBuf in, ps, maxlen, scratch, xval, chain, ofs, ent, tokval, out, scantmp;
     DevBuf z, len1, dst, ptr, flag, tstart;
     PinBuf h_ps, h_maxlen, h_xval, h_chain, h_small, h_tok;
@@ -182,6 +182,7 @@ int encode_core(std::vector<Ctx *> &cs, const void *src, bool src_on_device, siz
 
     uint32_t ntok = 0, nchunks_done = 0;
     uint64_t transfers = 0;
+    bool sort_timed = false;
     std::vector<uint32_t> owner;
     if (n) {
         const size_t nx = n > (size_t)g.sb ? n - (size_t)g.sb : 0;     /* evicted positions */
@@ -247,6 +248,8 @@ int encode_core(std::vector<Ctx *> &cs, const void *src, bool src_on_device, siz
                 hipEvent_t e;
                 HIPCHK(hipEventCreate(&e));                                    /* token-stream kernel time */
                 c.tok_ev.push_back(e);
+                HIPCHK(hipEventCreate(&e));                                    /* region-sort kernel time */
+                c.sort_ev.push_back(e);
             }
 
             /* -- enqueue this shard's match launches and their D2H up front.  Launches cover groups
@@ -260,7 +263,8 @@ int encode_core(std::vector<Ctx *> &cs, const void *src, bool src_on_device, siz
                 uint32_t nr = gchunks * per_chunk;
                 if (nr > nregions - r0) nr = nregions - r0;
                 HIPCHK(lz77k_match(c.in.as<uint8_t>(), n32, g, r0, nr, c.ps.as<uint32_t>(), c.maxlen.as<uint8_t>(),
-                                   c.scratch.p, variant, kstream(d)));
+                                   c.scratch.p, variant, kstream(d), d == 0 ? &c.sort_ev[2 * g_stats.match_launches] : nullptr));
+                if (d == 0) sort_timed = g.fast && variant == 0;
                 g_stats.match_launches++;
                 HIPCHK(hipEventRecord(c.chunk_ev[3 * ci], kstream(d)));
                 HIPCHK(hipStreamWaitEvent(c.copy, c.chunk_ev[3 * ci], 0));
@@ -421,6 +425,14 @@ int encode_core(std::vector<Ctx *> &cs, const void *src, bool src_on_device, siz
         tok_ms += ms;
     }
     g_stats.k_token_ms = tok_ms;
+    if (sort_timed && D == 1) {
+        double sort_ms = 0;
+        for (uint32_t i = 0; i < g_stats.match_launches; i++) {
+            HIPCHK(hipEventElapsedTime(&ms, c0.sort_ev[2 * i], c0.sort_ev[2 * i + 1]));
+            sort_ms += ms;
+        }
+        g_stats.k_sort_ms = sort_ms;
+    }
     g_stats.n = n;
     g_stats.zn = *zn;
     g_stats.ntok = ntok;
