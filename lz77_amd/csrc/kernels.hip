@@ -404,7 +404,7 @@ __global__ __launch_bounds__(MATCH_BLOCK) void k_match(const uint8_t *__restrict
         if (a < R) rk[a] = (rank_t)r;
     }
     __syncthreads();
-    if (MODE == 2) return;                                   /* timing probe: sort + ranks only */
+    if (MODE == 2 || (!FAST && MODE == 3)) return;           /* sort + ranks only (generic path: they live in scratch) */
     if constexpr (FAST && MODE == 3) {
         /* hand the order to the window walkers: rank[] and its inverse, 16-bit, per region */
         uint16_t *grk = reinterpret_cast<uint16_t *>(scratch) + (size_t)blockIdx.x * 2 * RP;
@@ -683,6 +683,124 @@ __global__ __launch_bounds__(256) void k_walk_final(const uint8_t *__restrict__ 
     maxlen[x] = (uint8_t)best;
 }
 
+/* ---- large windows (RP > 16384): same walk, bitmap in global memory (L2 resident), 32-bit ranks.
+ * The walker converts neighbour ranks to distances itself: forward results go straight to ps[],
+ * backward ones (candidates of the longest match) to wb[] for k_walk_final_big. ---- */
+__global__ __launch_bounds__(64) void k_walk_big(const uint32_t *__restrict__ ranks, uint32_t n, int sb, uint32_t SBu, uint32_t RP,
+                                                 uint32_t TILE, uint32_t region0, uint32_t nregions, uint32_t run_len,
+                                                 uint32_t runs_per_tile, uint32_t *__restrict__ bitmaps,
+                                                 uint32_t *__restrict__ ps, uint32_t *__restrict__ wb)
+{
+    const uint32_t NW = RP >> 5, NS = (NW + 31) >> 5;
+    const uint32_t id = blockIdx.x * 64u + threadIdx.x;
+    const uint32_t dir = id & 1u;
+    const uint32_t run = (id >> 1) % runs_per_tile;
+    const uint32_t reg = (id >> 1) / runs_per_tile;
+    if (reg >= nregions) return;
+    const uint64_t t0_64 = (uint64_t)(region0 + reg) * TILE;
+    if (t0_64 >= n) return;
+    const uint32_t t0 = (uint32_t)t0_64;
+    const uint32_t rstart = t0 >= SBu ? t0 - SBu : 0;
+    const uint64_t rend64 = (uint64_t)t0 + TILE + (uint32_t)sb - 1;
+    const uint32_t R = (rend64 < n ? (uint32_t)rend64 : n) - rstart;
+    const uint32_t lt0 = t0 - rstart;
+    const uint32_t lt1 = ((uint64_t)t0 + TILE < n ? t0 + TILE : n) - rstart;
+    const uint32_t xa = lt0 + run * run_len;
+    if (xa >= lt1) return;
+    const uint32_t xb = min(xa + run_len, lt1);
+    const uint32_t *rk = ranks + (size_t)reg * (2 * (size_t)RP + 8);
+    const uint32_t *ix = rk + RP + 8;
+    uint32_t *word = bitmaps + (size_t)id * (NW + NS);       /* zeroed by the launcher */
+    uint32_t *summ = word + NW;
+    const int32_t isb = sb;
+    const uint32_t NONE = 0xFFFFFFFFu;
+
+    auto set_bit = [&](uint32_t r) {
+        atomicOr(&word[r >> 5], 1u << (r & 31));
+        atomicOr(&summ[r >> 10], 1u << ((r >> 5) & 31));
+    };
+    auto clear_bit = [&](uint32_t r) {
+        const uint32_t bit = 1u << (r & 31);
+        const uint32_t old = atomicAnd(&word[r >> 5], ~bit);
+        if ((old & ~bit) == 0) atomicAnd(&summ[r >> 10], ~(1u << ((r >> 5) & 31)));
+    };
+    {
+        const int32_t lo = dir ? (int32_t)xa - isb : (int32_t)xa + 1;
+        const int32_t hi = dir ? (int32_t)xa - 1 : (int32_t)xa + isb - 1;
+        const int32_t a = lo < 0 ? 0 : lo, b = hi >= (int32_t)R ? (int32_t)R - 1 : hi;
+        for (int32_t i = a; i <= b; i++) set_bit(rk[i]);
+    }
+    __threadfence_block();
+    const int32_t add = dir ? 0 : isb, rem = dir ? -isb : 1;
+    auto fetch = [&](int32_t i) -> uint32_t { return (i >= 0 && i < (int32_t)R) ? rk[i] : NONE; };
+    uint32_t q = rk[xa], r_add = fetch((int32_t)xa + add), r_rem = fetch((int32_t)xa + rem);
+    for (uint32_t x = xa; x < xb; x++) {
+        const uint32_t qn = x + 1 < xb ? rk[x + 1] : 0u;
+        const uint32_t an = fetch((int32_t)x + 1 + add), rn = fetch((int32_t)x + 1 + rem);
+        const uint32_t w0 = q >> 5, b0 = q & 31;
+        const uint32_t here = __hip_atomic_load(&word[w0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        uint32_t succ = NONE, pred = NONE;
+        {
+            uint32_t w = w0, m = here & ~((2u << b0) - 1u);
+            if (!m) {
+                uint32_t sw = w >> 5, sm = __hip_atomic_load(&summ[sw], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & ~((2u << (w & 31)) - 1u);
+                while (!sm && ++sw < NS) sm = __hip_atomic_load(&summ[sw], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (sm) { w = (sw << 5) + (uint32_t)__builtin_ctz(sm); m = __hip_atomic_load(&word[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+            }
+            if (m) succ = (w << 5) + (uint32_t)__builtin_ctz(m);
+        }
+        {
+            uint32_t w = w0, m = here & ((1u << b0) - 1u);
+            if (!m) {
+                int32_t sw = (int32_t)(w >> 5);
+                uint32_t sm = __hip_atomic_load(&summ[sw], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & ((1u << (w & 31)) - 1u);
+                while (!sm && --sw >= 0) sm = __hip_atomic_load(&summ[sw], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (sm) { w = ((uint32_t)sw << 5) + 31u - (uint32_t)__builtin_clz(sm); m = __hip_atomic_load(&word[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+            }
+            if (m) pred = (w << 5) + 31u - (uint32_t)__builtin_clz(m);
+        }
+        /* ranks -> distances */
+        const uint32_t ps_ = succ != NONE ? ix[succ] : 0u, pp_ = pred != NONE ? ix[pred] : 0u;
+        const uint32_t xabs = rstart + x;
+        if (dir == 0) {
+            uint32_t P = 0, S = 0;
+            if ((uint64_t)xabs + (uint32_t)sb < n) {
+                if (succ != NONE) S = ps_ - x;
+                if (pred != NONE) P = pp_ - x;
+            }
+            ps[xabs] = P | (S << 16);
+        } else {
+            wb[(size_t)reg * TILE + (x - lt0)] = (succ != NONE ? x - ps_ : 0u) | ((pred != NONE ? x - pp_ : 0u) << 16);
+        }
+        if (r_add != NONE) set_bit(r_add);
+        if (r_rem != NONE) clear_bit(r_rem);
+        q = qn; r_add = an; r_rem = rn;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_walk_final_big(const uint8_t *__restrict__ in, uint32_t n, int la, uint32_t TILE,
+                                                        uint32_t region0, uint32_t nregions, const uint32_t *__restrict__ wb,
+                                                        uint8_t *__restrict__ maxlen)
+{
+    const uint64_t rel = (uint64_t)blockIdx.x * 256u + threadIdx.x;
+    if (rel >= (uint64_t)nregions * TILE) return;
+    const uint64_t x64 = (uint64_t)region0 * TILE + rel;
+    if (x64 >= n) return;
+    const uint32_t x = (uint32_t)x64;
+    const uint32_t b = wb[rel];
+    const uint32_t left = n - x;
+    const int cap = (int)(left < (uint32_t)la ? left : (uint32_t)la) - 1;
+    uint32_t best = 0;
+    if (b & 0xFFFFu) best = (uint32_t)lcp_capped<false>(in, x - (b & 0xFFFFu), x, cap);
+    if (b >> 16) {
+        const uint32_t l2 = (uint32_t)lcp_capped<false>(in, x - (b >> 16), x, cap);
+        best = l2 > best ? l2 : best;
+    }
+    maxlen[x] = (uint8_t)best;
+}
+
+#define WALK_RUN_BIG_DEFAULT 16384u
+
 #define WALK_RUN_DEFAULT 2048u
 
 size_t lz77k_match_lds_bytes(const lz77x_geom &g)
@@ -695,7 +813,10 @@ size_t lz77k_match_scratch_bytes(const lz77x_geom &g, uint32_t nregions)
 {
     /* fast: rank + inverse (uint16 each) per region, then the walkers' fwd/bwd results per position */
     if (g.fast) return (size_t)nregions * ((size_t)g.RP * 4 + (size_t)g.TILE * 8) + 256;
-    return (size_t)nregions * (2 * (size_t)g.RP + 8) * sizeof(uint32_t);
+    /* generic: rank + inverse (uint32), one global bitmap per walker, backward results per position */
+    const size_t runs = (g.TILE + WALK_RUN_BIG_DEFAULT - 1) / WALK_RUN_BIG_DEFAULT;
+    const size_t nws = (g.RP >> 5) + (((g.RP >> 5) + 31) >> 5);
+    return (size_t)nregions * ((2 * (size_t)g.RP + 8) * 4 + runs * 2 * nws * 4 + (size_t)g.TILE * 4) + 256;
 }
 
 template <bool FAST, int MODE>
@@ -753,7 +874,27 @@ hipError_t lz77k_match(const uint8_t *d_in, uint32_t n, const lz77x_geom &g, uin
     }
     if (variant == 1) return launch_match<false, 1>(LZ77K_MATCH_ARGS);
     if (variant == 2) return launch_match<false, 2>(LZ77K_MATCH_ARGS);
-    return launch_match<false, 0>(LZ77K_MATCH_ARGS);
+    if (variant == 3) return launch_match<false, 0>(LZ77K_MATCH_ARGS);         /* exhaustive pair scan */
+    {
+        /* production for large windows: sort (ranks stay in scratch) -> global-bitmap walkers -> finalize */
+        hipError_t e = launch_match<false, 3>(LZ77K_MATCH_ARGS);
+        if (e != hipSuccess) return e;
+        const uint32_t run_len = WALK_RUN_BIG_DEFAULT < g.TILE ? WALK_RUN_BIG_DEFAULT : g.TILE;
+        const uint32_t runs = (g.TILE + run_len - 1) / run_len;
+        const size_t nws = (g.RP >> 5) + (((g.RP >> 5) + 31) >> 5);
+        uint32_t *ranks = reinterpret_cast<uint32_t *>(d_scratch);
+        uint32_t *bitmaps = ranks + (size_t)nregions * (2 * (size_t)g.RP + 8);
+        const uint64_t walkers = (uint64_t)nregions * runs * 2;
+        uint32_t *wb = bitmaps + walkers * nws;
+        e = hipMemsetAsync(bitmaps, 0, walkers * nws * sizeof(uint32_t), s);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(k_walk_big, dim3((uint32_t)((walkers + 63) / 64)), dim3(64), 0, s, ranks, n, g.sb, g.SBu, g.RP, g.TILE,
+                           region0, nregions, run_len, runs, bitmaps, d_ps, wb);
+        const uint64_t npos = (uint64_t)nregions * g.TILE;
+        hipLaunchKernelGGL(k_walk_final_big, dim3((uint32_t)((npos + 255) / 256)), dim3(256), 0, s, d_in, n, g.la, g.TILE, region0,
+                           nregions, wb, d_maxlen);
+        return hipGetLastError();
+    }
 #undef LZ77K_MATCH_ARGS
 }
 
@@ -1129,14 +1270,158 @@ __global__ __launch_bounds__(TOK_BLOCK) void k_tokens_tile(const uint8_t *__rest
 #undef LIST_START
 #undef LIST_END
 
+/* ---- large windows (sb > 8192): the candidate index lives in global memory -------------------
+ * Per tile of BIG_TT positions, every candidate position (tile + its SB look-back) is bucketed by
+ * its first two bytes (exact 16-bit key, so a length-1 token reads the 256 adjacent buckets of its
+ * first byte).  After the fill pass bucket k is blist[ (k ? bs[k-1] : 0) .. bs[k] ). ---- */
+#define BIG_TT 131072u
+#define BIG_KEYS 65536u
+
+__global__ __launch_bounds__(256) void k_bidx_count(const uint8_t *__restrict__ in, int sb, uint32_t pos0, uint32_t pos1,
+                                                    uint32_t *__restrict__ bs)
+{
+    const uint32_t tile = blockIdx.y;
+    const uint32_t t0 = pos0 + tile * BIG_TT, t1 = min(t0 + BIG_TT, pos1);
+    const uint32_t w0 = t0 > (uint32_t)sb ? t0 - (uint32_t)sb : 0u;
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (w0 + i >= t1) return;
+    const uint32_t c = w0 + i;
+    atomicAdd(&bs[(size_t)tile * BIG_KEYS + (((uint32_t)in[c] << 8) | in[c + 1])], 1u);
+}
+
+__global__ __launch_bounds__(1024) void k_bidx_scan(uint32_t *__restrict__ bs)
+{
+    __shared__ uint32_t wsum[16];
+    uint32_t *b = bs + (size_t)blockIdx.x * BIG_KEYS;
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    uint32_t v[64], tot = 0;
+#pragma unroll
+    for (int i = 0; i < 64; i += 4) {
+        const uint4 t = *reinterpret_cast<const uint4 *>(b + tid * 64 + i);
+        v[i] = t.x; v[i + 1] = t.y; v[i + 2] = t.z; v[i + 3] = t.w;
+        tot += t.x + t.y + t.z + t.w;
+    }
+    uint32_t incl = tot;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t t = __shfl_up(incl, d, 64);
+        if (lane >= (uint32_t)d) incl += t;
+    }
+    if (lane == 63) wsum[wave] = incl;
+    __syncthreads();
+    uint32_t run = incl - tot;
+    for (uint32_t w = 0; w < wave; w++) run += wsum[w];
+#pragma unroll
+    for (int i = 0; i < 64; i++) { const uint32_t c = v[i]; v[i] = run; run += c; }
+#pragma unroll
+    for (int i = 0; i < 64; i += 4)
+        *reinterpret_cast<uint4 *>(b + tid * 64 + i) = make_uint4(v[i], v[i + 1], v[i + 2], v[i + 3]);
+}
+
+__global__ __launch_bounds__(256) void k_bidx_fill(const uint8_t *__restrict__ in, int sb, uint32_t pos0, uint32_t pos1,
+                                                   uint32_t *__restrict__ bs, uint32_t *__restrict__ blist, uint32_t span)
+{
+    const uint32_t tile = blockIdx.y;
+    const uint32_t t0 = pos0 + tile * BIG_TT, t1 = min(t0 + BIG_TT, pos1);
+    const uint32_t w0 = t0 > (uint32_t)sb ? t0 - (uint32_t)sb : 0u;
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (w0 + i >= t1) return;
+    const uint32_t c = w0 + i;
+    const uint32_t slot = atomicAdd(&bs[(size_t)tile * BIG_KEYS + (((uint32_t)in[c] << 8) | in[c + 1])], 1u);
+    blist[(size_t)tile * span + slot] = c;
+}
+
+__global__ __launch_bounds__(256) void k_tokens_big(const uint8_t *__restrict__ in, uint32_t n, int sb, int ob, int lb,
+                                                    const uint32_t *__restrict__ chain, uint32_t ntok,
+                                                    const uint8_t *__restrict__ maxlen,
+                                                    const uint32_t *__restrict__ ofs, const uint2 *__restrict__ ent, uint32_t dbase,
+                                                    uint32_t pos0, const uint32_t *__restrict__ bs, const uint32_t *__restrict__ blist,
+                                                    uint32_t span, uint32_t *__restrict__ tokval)
+{
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t k = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (k >= ntok) return;
+    const uint32_t p = chain[k];
+    const uint32_t len = maxlen[p];
+    const uint32_t next = in[p + len];
+    uint32_t off = 0;
+    if (len > 0) {
+        const uint32_t tile = (p - pos0) / BIG_TT;
+        const uint32_t *b = bs + (size_t)tile * BIG_KEYS;
+        const uint32_t *list = blist + (size_t)tile * span;
+        const uint32_t klo = len >= 2 ? (((uint32_t)in[p] << 8) | in[p + 1]) : ((uint32_t)in[p] << 8);
+        const uint32_t khi = len >= 2 ? klo : (klo | 0xFFu);
+        const uint32_t i0 = klo ? b[klo - 1] : 0u, i1 = b[khi];
+        const uint32_t cmin = p > (uint32_t)sb ? p - (uint32_t)sb : 0u;
+        const uint8_t *q = in + p;
+        uint64_t best = ~0ull;
+        for (uint32_t i = i0 + lane; i < i1; i += 64) {
+            const uint32_t c = list[i];
+            if (c < cmin || c >= p) continue;
+            const uint8_t *r = in + c;
+            bool same = true;
+            for (uint32_t j = 0; j < len; j += 4) {
+                uint32_t x = ld32u(r + j) ^ ld32u(q + j);
+                const uint32_t rem = len - j;
+                if (rem < 4) x &= (1u << (8 * rem)) - 1u;
+                if (x) { same = false; break; }
+            }
+            if (!same) continue;
+            uint32_t prio = c, latest = 0;
+            bool any = false;
+            const uint32_t lo = c > dbase ? ofs[c - dbase - 1] : 0, hi = c >= dbase ? ofs[c - dbase] : 0;
+            for (uint32_t e = lo; e < hi; e++) {
+                const uint2 t = ent[e];
+                if ((uint64_t)t.x + (uint32_t)sb < p && (!any || t.x > latest)) { any = true; latest = t.x; prio = t.y; }
+            }
+            const uint64_t key = ((uint64_t)prio << 32) | c;
+            best = key < best ? key : best;
+        }
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) {
+            const uint64_t o = (uint64_t)__shfl_xor((unsigned long long)best, d, 64);
+            best = o < best ? o : best;
+        }
+        off = p - (uint32_t)(best & 0xFFFFFFFFu);
+    }
+    if (lane == 0) {
+        const uint32_t omask = ob >= 32 ? 0xFFFFFFFFu : (1u << ob) - 1u;
+        tokval[k] = (off & omask) | (len << ob) | (next << (ob + lb));
+    }
+}
+
+/* bytes of the global candidate index for token positions spanning npos (0 when the LDS tile kernel applies) */
+size_t lz77k_tokens_index_bytes(const lz77x_geom &g, size_t npos)
+{
+    if (g.sb <= 8192) return 0;
+    const size_t ntiles = (npos + BIG_TT - 1) / BIG_TT;
+    return ntiles * ((size_t)BIG_KEYS + BIG_TT + (size_t)g.sb + 8) * sizeof(uint32_t) + 256;
+}
+
 size_t lz77k_tokens_tmp_bytes(uint32_t n) { return ((size_t)(n / TOK_TILE) + 8) * sizeof(uint32_t); }
 
 /* tokens d_chain[0..ntok) all lie in [pos0, pos1); the hand-over index covers dst >= dbase */
 hipError_t lz77k_tokens(const uint8_t *d_in, uint32_t n, const lz77x_geom &g, const uint32_t *d_chain, uint32_t ntok,
                         const uint8_t *d_maxlen, const uint32_t *d_ofs, const uint2 *d_ent, uint32_t dbase,
-                        uint32_t pos0, uint32_t pos1, uint32_t *d_tokval, uint32_t *d_tstart, int variant, hipStream_t s)
+                        uint32_t pos0, uint32_t pos1, uint32_t *d_tokval, uint32_t *d_tstart, void *d_index, int variant,
+                        hipStream_t s)
 {
     if (ntok == 0) return hipSuccess;
+    if (variant == 0 && g.sb > 8192 && d_index) {
+        const uint32_t ntiles = (pos1 - pos0 + BIG_TT - 1) / BIG_TT;
+        const uint32_t span = BIG_TT + (uint32_t)g.sb + 8;
+        uint32_t *bs = reinterpret_cast<uint32_t *>(d_index);
+        uint32_t *blist = bs + (size_t)ntiles * BIG_KEYS;
+        hipError_t e = hipMemsetAsync(bs, 0, (size_t)ntiles * BIG_KEYS * sizeof(uint32_t), s);
+        if (e != hipSuccess) return e;
+        const dim3 grid((span + 255) / 256, ntiles);
+        hipLaunchKernelGGL(k_bidx_count, grid, dim3(256), 0, s, d_in, g.sb, pos0, pos1, bs);
+        hipLaunchKernelGGL(k_bidx_scan, dim3(ntiles), dim3(1024), 0, s, bs);
+        hipLaunchKernelGGL(k_bidx_fill, grid, dim3(256), 0, s, d_in, g.sb, pos0, pos1, bs, blist, span);
+        hipLaunchKernelGGL(k_tokens_big, dim3((ntok + 3) / 4), dim3(256), 0, s, d_in, n, g.sb, g.ob, g.lb, d_chain, ntok, d_maxlen,
+                           d_ofs, d_ent, dbase, pos0, bs, blist, span, d_tokval);
+        return hipGetLastError();
+    }
     if ((variant == 0 || variant == 2) && g.sb <= 8192 && d_tstart) {
         const bool bucket = variant == 0;
         const uint32_t ntiles = (pos1 - pos0 + TOK_TILE - 1) / TOK_TILE;

@@ -92,11 +92,13 @@ hipError_t lz77k_xfer_index(const uint32_t *d_ps, const uint32_t *d_xval, uint32
  * candidate visited); else / variant 1: one wave per token straight from global memory.
  * d_tstart: lz77k_tokens_tmp_bytes(pos1-pos0). */
 size_t lz77k_tokens_tmp_bytes(uint32_t n);
+/* large windows (sb > 8192): bytes of the global two-byte candidate index for npos token positions */
+size_t lz77k_tokens_index_bytes(const lz77x_geom &g, size_t npos);
 hipError_t lz77k_tokens(const uint8_t *d_in, uint32_t n, const lz77x_geom &g,
                         const uint32_t *d_chain, uint32_t ntok, const uint8_t *d_maxlen,
                         const uint32_t *d_ofs, const uint2 *d_ent, uint32_t dbase,
                         uint32_t pos0, uint32_t pos1, uint32_t *d_tokval,
-                        uint32_t *d_tstart, int variant, hipStream_t s);
+                        uint32_t *d_tstart, void *d_index, int variant, hipStream_t s);
 
 /* words [w0, w0+nw) of the output stream (word 0 = header) from tokval[0..ntok) */
 hipError_t lz77k_pack(const uint32_t *d_tokval, uint64_t ntok, const lz77x_geom &g,

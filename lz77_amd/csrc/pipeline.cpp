@@ -85,7 +85,7 @@ struct Ctx {
     hipEvent_t ev[6] = {};
     std::vector<hipEvent_t> chunk_ev, tok_ev, sort_ev;
     DevBuf in, ps, maxlen, scratch, xval, chain, ofs, ent, tokval, out, scantmp;
-    DevBuf z, len1, dst, ptr, flag, tstart;
+    DevBuf z, len1, dst, ptr, flag, tstart, bidx;
     PinBuf h_ps, h_maxlen, h_xval, h_chain, h_small, h_tok;
 };
 
@@ -239,6 +239,7 @@ int encode_core(std::vector<Ctx *> &cs, const void *src, bool src_on_device, siz
             if ((rc = c.tokval.need((n + 8) * 4))) return rc;
             if ((rc = c.scantmp.need(lz77k_scan_tmp_bytes((uint32_t)idx_span + 1)))) return rc;
             if ((rc = c.tstart.need(lz77k_tokens_tmp_bytes((uint32_t)idx_span)))) return rc;
+            if ((rc = c.bidx.need(lz77k_tokens_index_bytes(g, chunk_pos < n ? chunk_pos : n)))) return rc;
             while (c.chunk_ev.size() < 3 * (size_t)nchunks) {
                 hipEvent_t e;
                 HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));   /* ordering only */
@@ -359,7 +360,7 @@ int encode_core(std::vector<Ctx *> &cs, const void *src, bool src_on_device, siz
                                           c.ofs.as<uint32_t>(), c.ent.as<uint2>(), c.scantmp.p, tstream(d))) != hipSuccess) return q;
                 if ((q = lz77k_tokens(c.in.as<uint8_t>(), n32, g, c.chain.as<uint32_t>() + tok_sent[d], (uint32_t)(ntok_sz - tok_sent[d]),
                                       c.maxlen.as<uint8_t>(), c.ofs.as<uint32_t>(), c.ent.as<uint2>(), dbase, (uint32_t)b, (uint32_t)e,
-                                      c.tokval.as<uint32_t>() + tok_sent[d], c.tstart.as<uint32_t>(), tvariant, tstream(d))) != hipSuccess) return q;
+                                      c.tokval.as<uint32_t>() + tok_sent[d], c.tstart.as<uint32_t>(), c.bidx.p, tvariant, tstream(d))) != hipSuccess) return q;
                 if ((q = hipEventRecord(c.tok_ev[2 * ci + 1], tstream(d))) != hipSuccess) return q;
                 return tstream(d) == c.tok ? hipSuccess : hipStreamWaitEvent(c.tok, c.tok_ev[2 * ci + 1], 0);
             };
