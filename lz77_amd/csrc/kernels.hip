@@ -96,14 +96,15 @@ __device__ __forceinline__ int lcp_capped(const uint8_t *by, uint32_t a, uint32_
  *   stride < 1024  : both live in the 1024-slot segment ONE wave owns: LDS, no workgroup barrier
  *   stride >= 1024 : across waves: LDS + __syncthreads (10 of the 105 steps)
  */
+template <bool BYTES_LDS>
 __device__ __forceinline__ bool sort_less(const uint8_t *by, uint32_t a, uint32_t pa, uint32_t b, uint32_t pb, uint32_t R, int la)
 {
     if (pa != pb) return pa < pb;
     if (a >= R || b >= R) return a < b;
-    return key_less<true>(by, a, b, la);
+    return key_less<BYTES_LDS>(by, a, b, la);
 }
 
-template <int J, bool STATIC_DIR>
+template <int J, bool STATIC_DIR, bool BYTES_LDS>
 __device__ __forceinline__ void sort_local_pass(uint32_t (&v)[16], uint32_t (&pf)[16], const uint8_t *by, uint32_t R, int la,
                                                 int k_static, bool up_uniform)
 {
@@ -112,7 +113,7 @@ __device__ __forceinline__ void sort_local_pass(uint32_t (&v)[16], uint32_t (&pf
         if (r & J) continue;
         const int s = r | J;
         const bool up = STATIC_DIR ? ((r & k_static) == 0) : up_uniform;
-        const bool s_lt_r = sort_less(by, v[s], pf[s], v[r], pf[r], R, la);
+        const bool s_lt_r = sort_less<BYTES_LDS>(by, v[s], pf[s], v[r], pf[r], R, la);
         if (up ? s_lt_r : !s_lt_r) {
             const uint32_t tv = v[r], tp = pf[r];
             v[r] = v[s]; pf[r] = pf[s];
@@ -121,59 +122,84 @@ __device__ __forceinline__ void sort_local_pass(uint32_t (&v)[16], uint32_t (&pf
     }
 }
 
-__device__ __forceinline__ void region_sort_blocked(uint16_t *ix, const uint8_t *by, uint32_t R, uint32_t RP, int la, uint32_t tid)
+/* Sorts (tail_only = false) or finishes the top phase of (tail_only = true) CH = 16*1024 slots in
+ * LDS.  The top phase k == CH runs ascending iff top_up (a chunk of a larger bitonic network gets
+ * its direction from its position in that network). */
+template <class IdxT, bool BYTES_LDS>
+__device__ __forceinline__ void region_sort_blocked(IdxT *ix, const uint8_t *by, uint32_t R, int la, uint32_t tid, bool tail_only,
+                                                    bool top_up)
 {
+    constexpr uint32_t CH = 16 * MATCH_BLOCK;
     const uint32_t lane = tid & 63, wave = tid >> 6;
     const uint32_t pmask = la >= 4 ? 0xFFFFFFFFu : 0xFFFFFFFFu << (8 * (4 - la));
     uint32_t v[16], pf[16];
     auto load_mine = [&]() {
-        const uint4 a = *reinterpret_cast<const uint4 *>(ix + 16 * tid), b = *reinterpret_cast<const uint4 *>(ix + 16 * tid + 8);
-        const uint32_t w[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+        if constexpr (sizeof(IdxT) == 2) {
+            const uint4 a = *reinterpret_cast<const uint4 *>(ix + 16 * tid), b = *reinterpret_cast<const uint4 *>(ix + 16 * tid + 8);
+            const uint32_t w[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
 #pragma unroll
-        for (int r = 0; r < 16; r++) {
-            v[r] = (w[r >> 1] >> (16 * (r & 1))) & 0xFFFFu;
-            pf[r] = v[r] < R ? (__builtin_bswap32(ld32_at<true>(by, v[r])) & pmask) : 0xFFFFFFFFu;
+            for (int r = 0; r < 16; r++) v[r] = (w[r >> 1] >> (16 * (r & 1))) & 0xFFFFu;
+        } else {
+#pragma unroll
+            for (int r = 0; r < 16; r += 4) {
+                const uint4 a = *reinterpret_cast<const uint4 *>(ix + 16 * tid + r);
+                v[r] = a.x; v[r + 1] = a.y; v[r + 2] = a.z; v[r + 3] = a.w;
+            }
         }
+#pragma unroll
+        for (int r = 0; r < 16; r++)
+            pf[r] = v[r] < R ? (__builtin_bswap32(ld32_at<BYTES_LDS>(by, v[r])) & pmask) : 0xFFFFFFFFu;
     };
     auto store_mine = [&]() {
-        uint32_t w[8];
+        if constexpr (sizeof(IdxT) == 2) {
+            uint32_t w[8];
 #pragma unroll
-        for (int r = 0; r < 8; r++) w[r] = v[2 * r] | (v[2 * r + 1] << 16);
-        *reinterpret_cast<uint4 *>(ix + 16 * tid) = make_uint4(w[0], w[1], w[2], w[3]);
-        *reinterpret_cast<uint4 *>(ix + 16 * tid + 8) = make_uint4(w[4], w[5], w[6], w[7]);
+            for (int r = 0; r < 8; r++) w[r] = v[2 * r] | (v[2 * r + 1] << 16);
+            *reinterpret_cast<uint4 *>(ix + 16 * tid) = make_uint4(w[0], w[1], w[2], w[3]);
+            *reinterpret_cast<uint4 *>(ix + 16 * tid + 8) = make_uint4(w[4], w[5], w[6], w[7]);
+        } else {
+#pragma unroll
+            for (int r = 0; r < 16; r += 4)
+                *reinterpret_cast<uint4 *>(ix + 16 * tid + r) = make_uint4(v[r], v[r + 1], v[r + 2], v[r + 3]);
+        }
     };
-    auto lds_step = [&](uint32_t k, uint32_t j, uint32_t t) {         /* compare-exchange pair t of stride j */
+    auto lds_step = [&](bool up, uint32_t j, uint32_t t) {            /* compare-exchange pair t of stride j */
         const uint32_t i = 2 * t - (t & (j - 1)), l = i + j;
         const uint32_t a = ix[i], b = ix[l];
-        const bool up = (i & k) == 0;
         bool b_lt_a;
         if (a >= R || b >= R) b_lt_a = b < a;
-        else b_lt_a = key_less<true>(by, b, a, la);
-        if (up ? b_lt_a : !b_lt_a) { ix[i] = (uint16_t)b; ix[l] = (uint16_t)a; }
+        else b_lt_a = key_less<BYTES_LDS>(by, b, a, la);
+        if (up ? b_lt_a : !b_lt_a) { ix[i] = (IdxT)b; ix[l] = (IdxT)a; }
+    };
+    auto local_tail = [&](bool up) {
+        sort_local_pass<8, false, BYTES_LDS>(v, pf, by, R, la, 0, up);
+        sort_local_pass<4, false, BYTES_LDS>(v, pf, by, R, la, 0, up);
+        sort_local_pass<2, false, BYTES_LDS>(v, pf, by, R, la, 0, up);
+        sort_local_pass<1, false, BYTES_LDS>(v, pf, by, R, la, 0, up);
     };
 
-    /* phases k = 2..16: entirely inside a thread */
-    load_mine();
-    sort_local_pass<1, true>(v, pf, by, R, la, 2, false);
-    sort_local_pass<2, true>(v, pf, by, R, la, 4, false);
-    sort_local_pass<1, true>(v, pf, by, R, la, 4, false);
-    sort_local_pass<4, true>(v, pf, by, R, la, 8, false);
-    sort_local_pass<2, true>(v, pf, by, R, la, 8, false);
-    sort_local_pass<1, true>(v, pf, by, R, la, 8, false);
-    {
-        const bool up = ((16 * tid) & 16) == 0;
-        sort_local_pass<8, false>(v, pf, by, R, la, 0, up);
-        sort_local_pass<4, false>(v, pf, by, R, la, 0, up);
-        sort_local_pass<2, false>(v, pf, by, R, la, 0, up);
-        sort_local_pass<1, false>(v, pf, by, R, la, 0, up);
+    if (!tail_only) {
+        /* phases k = 2..16: entirely inside a thread */
+        load_mine();
+        sort_local_pass<1, true, BYTES_LDS>(v, pf, by, R, la, 2, false);
+        sort_local_pass<2, true, BYTES_LDS>(v, pf, by, R, la, 4, false);
+        sort_local_pass<1, true, BYTES_LDS>(v, pf, by, R, la, 4, false);
+        sort_local_pass<4, true, BYTES_LDS>(v, pf, by, R, la, 8, false);
+        sort_local_pass<2, true, BYTES_LDS>(v, pf, by, R, la, 8, false);
+        sort_local_pass<1, true, BYTES_LDS>(v, pf, by, R, la, 8, false);
+        local_tail(((16 * tid) & 16) == 0);
+        store_mine();
     }
-    store_mine();
-    for (uint32_t k = 32; k <= RP; k <<= 1) {
+    for (uint32_t k = tail_only ? CH : 32; k <= CH; k <<= 1) {
+        const bool top = k == CH;
         uint32_t j = k >> 1;
         if (j >= 1024) {
             __syncthreads();                                          /* other waves' segments are read next */
             for (; j >= 1024; j >>= 1) {
-                for (uint32_t t = tid; t < (RP >> 1); t += MATCH_BLOCK) lds_step(k, j, t);
+                for (uint32_t t = tid; t < (CH >> 1); t += MATCH_BLOCK) {
+                    const uint32_t i = 2 * t - (t & (j - 1));
+                    lds_step(top ? top_up : (i & k) == 0, j, t);
+                }
                 __syncthreads();
             }
         } else {
@@ -182,16 +208,16 @@ __device__ __forceinline__ void region_sort_blocked(uint16_t *ix, const uint8_t 
         }
         for (; j >= 16; j >>= 1) {                                    /* inside this wave's 1024 slots */
 #pragma unroll 2
-            for (uint32_t u = 0; u < 8; u++) lds_step(k, j, 512 * wave + lane + 64 * u);
+            for (uint32_t u = 0; u < 8; u++) {
+                const uint32_t t = 512 * wave + lane + 64 * u;
+                const uint32_t i = 2 * t - (t & (j - 1));
+                lds_step(top ? top_up : (i & k) == 0, j, t);
+            }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
         }
         load_mine();
-        const bool up = ((16 * tid) & k) == 0;
-        sort_local_pass<8, false>(v, pf, by, R, la, 0, up);
-        sort_local_pass<4, false>(v, pf, by, R, la, 0, up);
-        sort_local_pass<2, false>(v, pf, by, R, la, 0, up);
-        sort_local_pass<1, false>(v, pf, by, R, la, 0, up);
+        local_tail(top ? top_up : ((16 * tid) & k) == 0);
         store_mine();
     }
     __syncthreads();
@@ -376,7 +402,47 @@ __global__ __launch_bounds__(MATCH_BLOCK) void k_match(const uint8_t *__restrict
 
     /* ---- bitonic sort of local indices by (key, index); indices >= R sort last ---- */
     if (FAST && RP == 16 * MATCH_BLOCK && sort_variant == 0) {
-        region_sort_blocked(reinterpret_cast<uint16_t *>(ix), by, R, RP, la, tid);
+        if constexpr (FAST) region_sort_blocked<uint16_t, true>(reinterpret_cast<uint16_t *>(ix), by, R, la, tid, false, true);
+    } else if (!FAST && RP > 16 * MATCH_BLOCK && sort_variant == 0) {
+        if constexpr (!FAST) {
+            /* large region: bitonic network over RP/CH chunks; strides below CH run in LDS chunk by
+             * chunk (blocked routine above), strides >= CH directly on the global index array */
+            constexpr uint32_t CH = 16 * MATCH_BLOCK;
+            uint32_t *lix = reinterpret_cast<uint32_t *>(smem);          /* CH words */
+            uint32_t *gix = reinterpret_cast<uint32_t *>(ix);
+            const uint32_t NC = RP / CH;
+            for (uint32_t c = 0; c < NC; c++) {
+                for (uint32_t i = tid; i < CH; i += MATCH_BLOCK) lix[i] = c * CH + i;
+                __syncthreads();
+                region_sort_blocked<uint32_t, false>(lix, by, R, la, tid, false, (c & 1) == 0);
+                for (uint32_t i = tid * 4; i < CH; i += MATCH_BLOCK * 4)
+                    *reinterpret_cast<uint4 *>(gix + c * CH + i) = *reinterpret_cast<const uint4 *>(lix + i);
+                __syncthreads();
+            }
+            for (uint32_t k = 2 * CH; k <= RP; k <<= 1) {
+                for (uint32_t j = k >> 1; j >= CH; j >>= 1) {
+                    for (uint32_t t = tid; t < (RP >> 1); t += MATCH_BLOCK) {
+                        const uint32_t i = 2 * t - (t & (j - 1)), l = i + j;
+                        const uint32_t a = gix[i], b = gix[l];
+                        const bool up = (i & k) == 0;
+                        bool b_lt_a;
+                        if (a >= R || b >= R) b_lt_a = b < a;
+                        else b_lt_a = key_less<false>(by, b, a, la);
+                        if (up ? b_lt_a : !b_lt_a) { gix[i] = b; gix[l] = a; }
+                    }
+                    __syncthreads();
+                }
+                for (uint32_t c = 0; c < NC; c++) {
+                    for (uint32_t i = tid * 4; i < CH; i += MATCH_BLOCK * 4)
+                        *reinterpret_cast<uint4 *>(lix + i) = *reinterpret_cast<const uint4 *>(gix + c * CH + i);
+                    __syncthreads();
+                    region_sort_blocked<uint32_t, false>(lix, by, R, la, tid, true, ((c * CH) & k) == 0);
+                    for (uint32_t i = tid * 4; i < CH; i += MATCH_BLOCK * 4)
+                        *reinterpret_cast<uint4 *>(gix + c * CH + i) = *reinterpret_cast<const uint4 *>(lix + i);
+                    __syncthreads();
+                }
+            }
+        }
     } else {
         for (uint32_t k = 2; k <= RP; k <<= 1) {
             for (uint32_t j = k >> 1; j > 0; j >>= 1) {
@@ -724,13 +790,29 @@ __global__ __launch_bounds__(64) void k_walk_big(const uint32_t *__restrict__ ra
         const uint32_t old = atomicAnd(&word[r >> 5], ~bit);
         if ((old & ~bit) == 0) atomicAnd(&summ[r >> 10], ~(1u << ((r >> 5) & 31)));
     };
+    /* first window: the 64 walkers of the wave are filled one after the other by all 64 lanes
+     * (coalesced rank loads, independent atomics) instead of each lane walking its own SB ranks */
     {
         const int32_t lo = dir ? (int32_t)xa - isb : (int32_t)xa + 1;
         const int32_t hi = dir ? (int32_t)xa - 1 : (int32_t)xa + isb - 1;
         const int32_t a = lo < 0 ? 0 : lo, b = hi >= (int32_t)R ? (int32_t)R - 1 : hi;
-        for (int32_t i = a; i <= b; i++) set_bit(rk[i]);
+        const uint64_t live = __ballot(1);                    /* lanes without a walker have already left */
+        const int32_t nlive = __popcll(live), mine = __popcll(live & ((1ull << threadIdx.x) - 1ull));
+        for (uint32_t src = 0; src < 64; src++) {
+            if (!((live >> src) & 1ull)) continue;
+            const int32_t wa = __shfl(a, (int)src, 64), wb_ = __shfl(b, (int)src, 64);
+            const uint64_t rkp = (uint64_t)__shfl((unsigned long long)(uintptr_t)rk, (int)src, 64);
+            const uint64_t wdp = (uint64_t)__shfl((unsigned long long)(uintptr_t)word, (int)src, 64);
+            const uint32_t *srk = reinterpret_cast<const uint32_t *>((uintptr_t)rkp);
+            uint32_t *sword = reinterpret_cast<uint32_t *>((uintptr_t)wdp);
+            for (int32_t i = wa + mine; i <= wb_; i += nlive) {
+                const uint32_t r = srk[i];
+                atomicOr(&sword[r >> 5], 1u << (r & 31));
+                atomicOr(&sword[NW + (r >> 10)], 1u << ((r >> 5) & 31));
+            }
+        }
     }
-    __threadfence_block();
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "agent");
     const int32_t add = dir ? 0 : isb, rem = dir ? -isb : 1;
     auto fetch = [&](int32_t i) -> uint32_t { return (i >= 0 && i < (int32_t)R) ? rk[i] : NONE; };
     uint32_t q = rk[xa], r_add = fetch((int32_t)xa + add), r_rem = fetch((int32_t)xa + rem);
@@ -799,13 +881,13 @@ __global__ __launch_bounds__(256) void k_walk_final_big(const uint8_t *__restric
     maxlen[x] = (uint8_t)best;
 }
 
-#define WALK_RUN_BIG_DEFAULT 16384u
+#define WALK_RUN_BIG_DEFAULT 8192u
 
 #define WALK_RUN_DEFAULT 2048u
 
 size_t lz77k_match_lds_bytes(const lz77x_geom &g)
 {
-    if (!g.fast) return 0;
+    if (!g.fast) return g.RP > 16u * MATCH_BLOCK ? (size_t)16 * MATCH_BLOCK * sizeof(uint32_t) : 0;
     return (size_t)g.RP * 2 + (size_t)(g.RP + 8) * 2;      /* ix + union{bytes, rk}: RP >= 4096 > la + 11 */
 }
 

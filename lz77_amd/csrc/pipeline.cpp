@@ -192,16 +192,21 @@ int encode_core(std::vector<Ctx *> &cs, const void *src, bool src_on_device, siz
         if ((rc = c0.h_chain.need((n + 8) * 4))) return rc;
 
         const uint32_t nregions = (uint32_t)((n + g.TILE - 1) / g.TILE);
+        /* host chunk: >= 512 regions (~4M positions on the LDS path); match launch: a group of chunks
+         * (4096 LDS-path regions so that the walkers fill the chip; 512 large-window regions are one
+         * full round of resident workgroups already) */
         uint32_t per_chunk = (uint32_t)(((size_t)4 << 20) / g.TILE);
-        if (per_chunk < 512) per_chunk = 512;                          /* keep >= 2 workgroups per CU in flight */
+        if (per_chunk < 512) per_chunk = 512;
         const char *cs_env = getenv("LZ77X_CHUNK_REGIONS");
         if (cs_env && atoi(cs_env) > 0) per_chunk = (uint32_t)atoi(cs_env);
-        uint32_t group = 8;                                            /* host chunks per match launch */
+        uint32_t group = g.fast ? 8u : 1u;
         const char *gs = getenv("LZ77X_MATCH_GROUP");
         if (gs && atoi(gs) > 0) group = (uint32_t)atoi(gs);
         {
             const size_t per = lz77k_match_scratch_bytes(g, 1);
-            const uint32_t fit = (uint32_t)(((size_t)2 << 30) / per);
+            /* scratch budget of the match stage: small for the LDS path, generous for large windows
+             * (their walkers are latency bound and want every region of the input in one launch) */
+            const uint32_t fit = (uint32_t)(((size_t)(g.fast ? 2 : 12) << 30) / per);
             if (per_chunk > fit) per_chunk = fit ? fit : 1;
             if ((uint64_t)per_chunk * group > fit) group = fit / per_chunk ? fit / per_chunk : 1;
         }
