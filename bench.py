@@ -92,11 +92,19 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product has no CPU fallback")
+    ndev = torch.cuda.device_count()
+    backend = os.environ.get("LZ77_BENCH_BACKEND", "nccl")     # "gloo": several ranks on one GPU (plumbing test only)
+    if local >= ndev and backend == "nccl":
+        raise SystemExit("rank %d has no GPU (%d visible)" % (rank, ndev))
+    local %= ndev
     torch.cuda.set_device(local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend)
     import lz77_amd as L
     from lz77_amd import synth
 
@@ -136,10 +144,11 @@ def main():
     dt = time.perf_counter() - t0
     ok = bool(torch.equal(d_back, d_in))                 # round trip checked outside the timed region
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        red_dev = "cuda" if backend == "nccl" else "cpu"
+        t = torch.tensor([dt], dtype=torch.float64, device=red_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-        okt = torch.tensor([1 if ok else 0], device="cuda")
+        okt = torch.tensor([1 if ok else 0], device=red_dev)
         dist.all_reduce(okt, op=dist.ReduceOp.MIN)
         ok = bool(okt.item())
 
