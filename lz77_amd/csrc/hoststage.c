@@ -68,34 +68,38 @@ void lz77x_prio_free(lz77x_prio_state *st)
  * successor, which thereby inherits the node's place (priority); a node with fewer
  * children just splices out.  "x has two children" <=> both in-order neighbours lie in
  * x's subtrees <=> both have larger priority than x. */
-void lz77x_prio_run(lz77x_prio_state *st, const uint32_t *ps, int sb, size_t upto, uint32_t *xval)
+void lz77x_prio_run(lz77x_prio_state *st, const uint32_t *restrict ps, int sb, size_t upto, uint32_t *restrict xval)
 {
-    uint32_t *ring = st->ring;
+    uint32_t *restrict ring = st->ring;
     const uint32_t mask = st->mask;
     const size_t usb = (size_t)sb;
     size_t t = st->next;
     uint64_t moved = 0;
     for (; t < upto && t < usb; t++) ring[t & mask] = (uint32_t)t;
-    for (; t < upto; t++) {
-        const size_t x = t - usb;
-        const uint32_t v = ps[x];
-        const uint32_t P = v & 0xFFFFu, S = v >> 16;
-        const uint32_t mine = ring[x & mask];
-        const uint32_t sidx = (uint32_t)(x + S) & mask;
-        const uint32_t pp = ring[(uint32_t)(x + P) & mask];
-        const uint32_t sp = ring[sidx];
-        /* branch-free on purpose: `go` is taken ~2/3 of the time with no pattern, a compiled
-         * branch here mispredicts every third position */
-        const uint64_t dp = (uint64_t)mine - (uint64_t)pp;         /* bit 63 set <=> mine < pp */
-        const uint64_t ds = (uint64_t)mine - (uint64_t)sp;
-        /* a missing neighbour has distance 0, i.e. it reads x's own slot: mine < mine is false */
-        const uint32_t go = (uint32_t)((dp & ds) >> 63);
-        const uint32_t m = 0u - go;
-        ring[sidx] = sp ^ ((sp ^ mine) & m);  /* S==0: sidx==x&mask, dead slot, rewritten below */
-        xval[x] = mine | ~m;                  /* LZ77X_NONE32 when nothing moves */
-        moved += go;
-        ring[t & mask] = (uint32_t)t;
+    /* branch-free on purpose: `go` is taken ~2/3 of the time with no pattern, a compiled branch here
+     * mispredicts every third position.  A missing neighbour has distance 0, i.e. it reads x's own
+     * slot, and mine < mine is false. */
+#define LZ77X_PRIO_STEP(T)                                                              \
+    do {                                                                                \
+        const uint32_t x32 = (uint32_t)((T) - usb);                                     \
+        const uint32_t v = ps[(T) - usb];                                               \
+        const uint32_t sidx = (x32 + (v >> 16)) & mask;                                 \
+        const uint32_t mine = ring[x32 & mask];                                         \
+        const uint32_t pp = ring[(x32 + (v & 0xFFFFu)) & mask];                         \
+        const uint32_t sp = ring[sidx];                                                 \
+        const uint64_t lt = ((uint64_t)mine - (uint64_t)pp) & ((uint64_t)mine - (uint64_t)sp); \
+        const uint32_t m = (uint32_t)((int64_t)lt >> 63);          /* all ones iff mine < pp && mine < sp */ \
+        ring[sidx] = sp ^ ((sp ^ mine) & m);                                            \
+        xval[(T) - usb] = mine | ~m;                               /* LZ77X_NONE32 when nothing moves */ \
+        moved += m & 1u;                                                                \
+        ring[(uint32_t)(T) & mask] = (uint32_t)(T);                                     \
+    } while (0)
+    for (; t + 2 <= upto; t += 2) {
+        LZ77X_PRIO_STEP(t);
+        LZ77X_PRIO_STEP(t + 1);
     }
+    for (; t < upto; t++) LZ77X_PRIO_STEP(t);
+#undef LZ77X_PRIO_STEP
     st->next = t;
     st->transfers += moved;
 }
