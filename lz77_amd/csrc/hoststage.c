@@ -11,6 +11,16 @@
 #include "lz77x_internal.h"
 #include <stdlib.h>
 #include <string.h>
+#if defined(__SSE2__)
+#include <emmintrin.h>
+/* xval is written once, front to back, and next read by the DMA engine: a streaming store skips the
+ * read-for-ownership of every fresh cache line */
+#define LZ77X_STREAM_STORE(p, v) _mm_stream_si32((int *)(p), (int)(v))
+#define LZ77X_STREAM_FENCE() _mm_sfence()
+#else
+#define LZ77X_STREAM_STORE(p, v) (*(p) = (v))
+#define LZ77X_STREAM_FENCE() ((void)0)
+#endif
 
 /* bitio.c:41-43: (int)ceil(log(n)/log(2)) for n >= 1, in integers */
 int lz77x_bitof(int n)
@@ -46,10 +56,16 @@ size_t lz77x_host_chain(const uint8_t *maxlen, size_t limit, size_t p, uint32_t 
     return p;
 }
 
-int lz77x_prio_init(lz77x_prio_state *st, int sb)
+uint32_t lz77x_prio_mask(int sb)
 {
     uint32_t size = 1;
     while (size < (uint32_t)sb + 1u) size <<= 1;
+    return size - 1;
+}
+
+int lz77x_prio_init(lz77x_prio_state *st, int sb)
+{
+    const uint32_t size = lz77x_prio_mask(sb) + 1u;
     st->ring = (uint32_t *)malloc(sizeof(uint32_t) * (size_t)size);
     st->mask = size - 1;
     st->next = 0;
@@ -74,24 +90,21 @@ void lz77x_prio_run(lz77x_prio_state *st, const uint32_t *restrict ps, int sb, s
     const uint32_t mask = st->mask;
     const size_t usb = (size_t)sb;
     size_t t = st->next;
-    uint64_t moved = 0;
     for (; t < upto && t < usb; t++) ring[t & mask] = (uint32_t)t;
     /* branch-free on purpose: `go` is taken ~2/3 of the time with no pattern, a compiled branch here
-     * mispredicts every third position.  A missing neighbour has distance 0, i.e. it reads x's own
-     * slot, and mine < mine is false. */
+     * mispredicts every third position.  ps[x] holds the ring cells ((x+P)&mask, (x+S)&mask) of x's
+     * neighbours; a missing neighbour has distance 0, i.e. x's own cell, and mine < mine is false. */
 #define LZ77X_PRIO_STEP(T)                                                              \
     do {                                                                                \
-        const uint32_t x32 = (uint32_t)((T) - usb);                                     \
-        const uint32_t v = ps[(T) - usb];                                               \
-        const uint32_t sidx = (x32 + (v >> 16)) & mask;                                 \
-        const uint32_t mine = ring[x32 & mask];                                         \
-        const uint32_t pp = ring[(x32 + (v & 0xFFFFu)) & mask];                         \
+        const uint32_t v = ps[(T) - usb];      /* ring cells of P and S, packed by k_ps_cells */ \
+        const uint32_t sidx = v >> 16;                                                  \
+        const uint32_t mine = ring[(uint32_t)((T) - usb) & mask];                       \
+        const uint32_t pp = ring[v & 0xFFFFu];                                          \
         const uint32_t sp = ring[sidx];                                                 \
         const uint64_t lt = ((uint64_t)mine - (uint64_t)pp) & ((uint64_t)mine - (uint64_t)sp); \
         const uint32_t m = (uint32_t)((int64_t)lt >> 63);          /* all ones iff mine < pp && mine < sp */ \
         ring[sidx] = sp ^ ((sp ^ mine) & m);                                            \
-        xval[(T) - usb] = mine | ~m;                               /* LZ77X_NONE32 when nothing moves */ \
-        moved += m & 1u;                                                                \
+        LZ77X_STREAM_STORE(&xval[(T) - usb], mine | ~m);           /* LZ77X_NONE32 when nothing moves */ \
         ring[(uint32_t)(T) & mask] = (uint32_t)(T);                                     \
     } while (0)
     for (; t + 2 <= upto; t += 2) {
@@ -100,6 +113,6 @@ void lz77x_prio_run(lz77x_prio_state *st, const uint32_t *restrict ps, int sb, s
     }
     for (; t < upto; t++) LZ77X_PRIO_STEP(t);
 #undef LZ77X_PRIO_STEP
+    LZ77X_STREAM_FENCE();
     st->next = t;
-    st->transfers += moved;
 }

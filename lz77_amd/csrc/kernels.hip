@@ -988,6 +988,22 @@ __global__ void k_fill_pad(uint8_t *in, uint32_t n)
     if (i < LZ77X_PAD) in[(size_t)n + i] = 0xFF;
 }
 
+__global__ void k_ps_cells(const uint32_t *__restrict__ ps, uint32_t *__restrict__ cells, uint32_t x0, uint32_t x1, uint32_t mask)
+{
+    for (uint32_t x = x0 + blockIdx.x * blockDim.x + threadIdx.x; x < x1; x += gridDim.x * blockDim.x) {
+        const uint32_t v = ps[x];
+        cells[x] = ((x + (v & 0xFFFFu)) & mask) | (((x + (v >> 16)) & mask) << 16);
+    }
+}
+
+hipError_t lz77k_ps_cells(const uint32_t *d_ps, uint32_t *d_cells, uint32_t x0, uint32_t x1, uint32_t mask, hipStream_t s)
+{
+    if (x1 <= x0) return hipSuccess;
+    const uint32_t blocks = min((x1 - x0 + 255u) / 256u, 256u * 16u);
+    hipLaunchKernelGGL(k_ps_cells, dim3(blocks), dim3(256), 0, s, d_ps, d_cells, x0, x1, mask);
+    return hipGetLastError();
+}
+
 hipError_t lz77k_fill_pad(uint8_t *d_in, uint32_t n, hipStream_t s)
 {
     hipLaunchKernelGGL(k_fill_pad, dim3((LZ77X_PAD + 255) / 256), dim3(256), 0, s, d_in, n);
@@ -1078,12 +1094,19 @@ hipError_t lz77k_scan_u32(const uint32_t *d_in, uint32_t *d_out, uint32_t m, voi
  * evicted (or NONE).  Group these hand-overs by destination so that k_tokens can ask
  * "what priority did candidate c hold at time p". */
 __global__ void k_xfer_count(const uint32_t *__restrict__ ps, const uint32_t *__restrict__ xval, uint32_t xa, uint32_t xb,
-                             uint32_t dbase, uint32_t *__restrict__ cnt)
+                             uint32_t dbase, uint32_t *__restrict__ cnt, uint32_t x_new, unsigned long long *__restrict__ total)
 {
+    uint32_t mine = 0;
     for (uint32_t x = xa + blockIdx.x * blockDim.x + threadIdx.x; x < xb; x += gridDim.x * blockDim.x) {
         if (xval[x] == LZ77X_NONE32) continue;
+        mine += x >= x_new;
         const uint32_t dst = x + (ps[x] >> 16);
         if (dst >= dbase) atomicAdd(&cnt[dst - dbase], 1u);
+    }
+    if (total) {
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) mine += __shfl_xor(mine, d, 64);
+        if ((threadIdx.x & 63) == 0 && mine) atomicAdd(total, (unsigned long long)mine);
     }
 }
 
@@ -1101,14 +1124,15 @@ __global__ void k_xfer_fill(const uint32_t *__restrict__ ps, const uint32_t *__r
 /* Index of the hand-overs of evictions x in [xa, xb) into destinations [dbase, dend):
  * afterwards list(c) = ent[ (c > dbase ? ofs[c-dbase-1] : 0) .. ofs[c-dbase] ). */
 hipError_t lz77k_xfer_index(const uint32_t *d_ps, const uint32_t *d_xval, uint32_t xa, uint32_t xb, uint32_t dbase, uint32_t dend,
-                            uint32_t *d_ofs, uint2 *d_ent, void *d_scan_tmp, hipStream_t s)
+                            uint32_t *d_ofs, uint2 *d_ent, void *d_scan_tmp, hipStream_t s, uint32_t x_new,
+                            unsigned long long *d_total)
 {
     const uint32_t nd = dend - dbase;
     hipError_t e = hipMemsetAsync(d_ofs, 0, ((size_t)nd + 1) * sizeof(uint32_t), s);
     if (e != hipSuccess) return e;
     if (xb <= xa) return hipSuccess;
     const uint32_t blocks = min((xb - xa + 255u) / 256u, 256u * 16u);
-    hipLaunchKernelGGL(k_xfer_count, dim3(blocks), dim3(256), 0, s, d_ps, d_xval, xa, xb, dbase, d_ofs);
+    hipLaunchKernelGGL(k_xfer_count, dim3(blocks), dim3(256), 0, s, d_ps, d_xval, xa, xb, dbase, d_ofs, x_new, d_total);
     e = lz77k_scan_u32(d_ofs, d_ofs, nd + 1, d_scan_tmp, s);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(k_xfer_fill, dim3(blocks), dim3(256), 0, s, d_ps, d_xval, xa, xb, dbase, d_ofs, d_ent);

@@ -47,13 +47,15 @@ typedef struct lz77x_prio_state {
     uint32_t *ring;        /* priority of live position q at ring[q & mask] */
     uint32_t mask;
     size_t next;           /* next position to insert (== positions processed) */
-    uint64_t transfers;
+    uint64_t transfers;    /* unused by the hot loop (the device counts hand-overs while indexing them) */
 } lz77x_prio_state;
 
 int  lz77x_prio_init(lz77x_prio_state *st, int sb);
 void lz77x_prio_free(lz77x_prio_state *st);
 /* Advance the recurrence (SURVEY A.5 stage B) over insert times [st->next, upto);
- * ps[x] = P | S<<16 must be available for x < upto - sb; writes xval[x] for those x. */
+ * ps[x] = ((x+P) & mask) | ((x+S) & mask) << 16 (ring cells of x's neighbours, P/S = 0 when
+ * missing) must be available for x < upto - sb; writes xval[x] for those x. */
+uint32_t lz77x_prio_mask(int sb);
 void lz77x_prio_run(lz77x_prio_state *st, const uint32_t *ps, int sb, size_t upto, uint32_t *xval);
 
 #ifdef __cplusplus
@@ -77,6 +79,9 @@ hipError_t lz77k_match(const uint8_t *d_in, uint32_t n, const lz77x_geom &g,
 
 hipError_t lz77k_fill_pad(uint8_t *d_in, uint32_t n, hipStream_t s);
 
+/* cells[x] = ((x+P)&mask) | ((x+S)&mask)<<16 for x in [x0, x1): what the host recurrence indexes its ring with */
+hipError_t lz77k_ps_cells(const uint32_t *d_ps, uint32_t *d_cells, uint32_t x0, uint32_t x1, uint32_t mask, hipStream_t s);
+
 /* exclusive scan of m uint32 (in place allowed); d_tmp needs lz77k_scan_tmp_bytes(m) */
 size_t lz77k_scan_tmp_bytes(uint32_t m);
 hipError_t lz77k_scan_u32(const uint32_t *d_in, uint32_t *d_out, uint32_t m, void *d_tmp, hipStream_t s);
@@ -85,7 +90,8 @@ hipError_t lz77k_scan_u32(const uint32_t *d_in, uint32_t *d_out, uint32_t m, voi
  * list(c) = ent[ (c > dbase ? ofs[c-dbase-1] : 0) .. ofs[c-dbase] ).  d_ofs: dend-dbase+1 words */
 hipError_t lz77k_xfer_index(const uint32_t *d_ps, const uint32_t *d_xval, uint32_t xa, uint32_t xb,
                             uint32_t dbase, uint32_t dend, uint32_t *d_ofs, uint2 *d_ent,
-                            void *d_scan_tmp, hipStream_t s);
+                            void *d_scan_tmp, hipStream_t s,
+                            uint32_t x_new = 0, unsigned long long *d_total = nullptr /* += hand-overs with x >= x_new */);
 
 /* tokens d_chain[0..ntok) lie in [pos0, pos1).  variant 0: tiled kernel (window, hand-over lists and a
  * two-byte candidate index in LDS) when sb <= 8192; variant 2: same without the index (every

@@ -85,7 +85,7 @@ struct Ctx {
     hipEvent_t ev[6] = {};
     std::vector<hipEvent_t> chunk_ev, tok_ev, sort_ev;
     DevBuf in, ps, maxlen, scratch, xval, chain, ofs, ent, tokval, out, scantmp;
-    DevBuf z, len1, dst, ptr, flag, tstart, bidx;
+    DevBuf z, len1, dst, ptr, flag, tstart, bidx, cells;
     PinBuf h_ps, h_maxlen, h_xval, h_chain, h_small, h_tok;
 };
 
@@ -191,6 +191,7 @@ int encode_core(std::vector<Ctx *> &cs, const void *src, bool src_on_device, siz
         if ((rc = c0.h_xval.need((n + 8) * 4))) return rc;
         if ((rc = c0.h_chain.need((n + 8) * 4))) return rc;
 
+        const uint32_t ring_mask = lz77x_prio_mask(g.sb);
         const uint32_t nregions = (uint32_t)((n + g.TILE - 1) / g.TILE);
         /* host chunk: >= 512 regions (~4M positions on the LDS path); match launch: a group of chunks
          * (4096 LDS-path regions so that the walkers fill the chip; 512 large-window regions are one
@@ -236,6 +237,7 @@ int encode_core(std::vector<Ctx *> &cs, const void *src, bool src_on_device, siz
             const uint64_t most = (uint64_t)per_chunk * group < nregions ? (uint64_t)per_chunk * group : nregions;
             if ((rc = c.scratch.need(lz77k_match_scratch_bytes(g, (uint32_t)most)))) return rc;
             if ((rc = c.ps.need((n + 8) * 4))) return rc;
+            if ((rc = c.cells.need((n + 8) * 4))) return rc;
             if ((rc = c.maxlen.need(n + 8))) return rc;
             if ((rc = c.xval.need((n + 8) * 4))) return rc;
             if ((rc = c.chain.need((n + 8) * 4))) return rc;
@@ -244,6 +246,8 @@ int encode_core(std::vector<Ctx *> &cs, const void *src, bool src_on_device, siz
             if ((rc = c.tokval.need((n + 8) * 4))) return rc;
             if ((rc = c.scantmp.need(lz77k_scan_tmp_bytes((uint32_t)idx_span + 1)))) return rc;
             if ((rc = c.tstart.need(lz77k_tokens_tmp_bytes((uint32_t)idx_span)))) return rc;
+            if ((rc = c.flag.need(64))) return rc;
+            HIPCHK(hipMemsetAsync(c.flag.p, 0, 64, kstream(d)));
             if ((rc = c.bidx.need(lz77k_tokens_index_bytes(g, chunk_pos < n ? chunk_pos : n)))) return rc;
             while (c.chunk_ev.size() < 3 * (size_t)nchunks) {
                 hipEvent_t e;
@@ -259,11 +263,13 @@ int encode_core(std::vector<Ctx *> &cs, const void *src, bool src_on_device, siz
             }
 
             /* -- enqueue this shard's match launches and their D2H up front.  Launches cover groups
-             *    of host chunks (the window walkers want >= 256 wavefronts per launch); the very
-             *    first group is a single chunk so that the host stage can start early. -- */
+             *    of host chunks (the window walkers want >= 256 wavefronts per launch); the first
+             *    groups are small (1, 2, 4 chunks) so that the host stage can start early. -- */
             if (d == 0) HIPCHK(hipEventRecord(c.ev[0], kstream(d)));
+            uint32_t ramp = d == 0 ? 1u : group;        /* 1, 2, 4, ... chunks: each group retires just before the host needs it */
             for (uint32_t ci = first_chunk[d]; ci < first_chunk[d + 1];) {
-                uint32_t gchunks = ci == 0 ? 1u : group;
+                uint32_t gchunks = ramp < group ? ramp : group;
+                ramp = ramp < group ? ramp * 2 : group;
                 if (ci + gchunks > first_chunk[d + 1]) gchunks = first_chunk[d + 1] - ci;
                 const uint32_t r0 = ci * per_chunk;
                 uint32_t nr = gchunks * per_chunk;
@@ -272,6 +278,12 @@ int encode_core(std::vector<Ctx *> &cs, const void *src, bool src_on_device, siz
                                    c.scratch.p, variant, kstream(d), d == 0 ? &c.sort_ev[2 * g_stats.match_launches] : nullptr));
                 if (d == 0) sort_timed = g.fast && variant == 0;
                 g_stats.match_launches++;
+                {
+                    const size_t gb = (size_t)r0 * g.TILE;
+                    size_t ge = (size_t)(r0 + nr) * g.TILE;
+                    if (ge > nx) ge = nx;
+                    if (ge > gb) HIPCHK(lz77k_ps_cells(c.ps.as<uint32_t>(), c.cells.as<uint32_t>(), (uint32_t)gb, (uint32_t)ge, ring_mask, kstream(d)));
+                }
                 HIPCHK(hipEventRecord(c.chunk_ev[3 * ci], kstream(d)));
                 HIPCHK(hipStreamWaitEvent(c.copy, c.chunk_ev[3 * ci], 0));
                 for (uint32_t cj = ci; cj < ci + gchunks; cj++) {
@@ -281,7 +293,7 @@ int encode_core(std::vector<Ctx *> &cs, const void *src, bool src_on_device, siz
                     HIPCHK(hipMemcpyAsync(c0.h_maxlen.as<uint8_t>() + b, c.maxlen.as<uint8_t>() + b, e - b, hipMemcpyDeviceToHost, c.copy));
                     const size_t pe = e < nx ? e : nx;
                     if (pe > b)
-                        HIPCHK(hipMemcpyAsync(c0.h_ps.as<uint32_t>() + b, c.ps.as<uint32_t>() + b, (pe - b) * 4, hipMemcpyDeviceToHost, c.copy));
+                        HIPCHK(hipMemcpyAsync(c0.h_ps.as<uint32_t>() + b, c.cells.as<uint32_t>() + b, (pe - b) * 4, hipMemcpyDeviceToHost, c.copy));
                     HIPCHK(hipEventRecord(c.chunk_ev[3 * cj + 1], c.copy));
                 }
                 ci += gchunks;
@@ -316,6 +328,7 @@ int encode_core(std::vector<Ctx *> &cs, const void *src, bool src_on_device, siz
 
         size_t ntok_sz = 0;
         std::vector<size_t> tok_sent(D, 0), x_sent(D, 0);
+        std::vector<uint32_t> lookback;
         double t_prio = 0;
         int err = LZ77X_OK;
         for (uint32_t ci = 0; ci < nchunks && err == LZ77X_OK; ci++) {
@@ -341,6 +354,7 @@ int encode_core(std::vector<Ctx *> &cs, const void *src, bool src_on_device, siz
             /* hand-overs that can matter to tokens in [b, e): evictions before e-sb into dst >= b-sb */
             const uint32_t dbase = b > (size_t)g.sb ? (uint32_t)(b - (size_t)g.sb) : 0u;
             const uint32_t xa = dbase > (uint32_t)g.sb ? dbase - (uint32_t)g.sb : 0u;
+            const size_t x_new = b > (size_t)g.sb ? b - (size_t)g.sb : 0;     /* evictions first seen with this chunk */
             auto enqueue = [&]() -> hipError_t {
                 hipError_t q;
                 if ((q = hipSetDevice(c.device)) != hipSuccess) return q;
@@ -348,9 +362,18 @@ int encode_core(std::vector<Ctx *> &cs, const void *src, bool src_on_device, siz
                     /* first chunk of a shard: its look-back window belongs to the previous shard */
                     tok_sent[d] = tok_before;
                     x_sent[d] = xa;
-                    if (d > 0 && b > xa &&
-                        (q = hipMemcpyAsync(c.ps.as<uint32_t>() + xa, c0.h_ps.as<uint32_t>() + xa, (b - xa) * 4,
-                                            hipMemcpyHostToDevice, c.copy)) != hipSuccess) return q;
+                    if (d > 0 && b > xa) {
+                        /* the host holds ring cells; the index kernels want distances again */
+                        lookback.resize(b - xa);
+                        const uint32_t *hc = c0.h_ps.as<uint32_t>();
+                        for (size_t x = xa; x < b; x++) {
+                            const uint32_t v = hc[x], x32 = (uint32_t)x;
+                            lookback[x - xa] = (((v & 0xFFFFu) - x32) & ring_mask) | ((((v >> 16) - x32) & ring_mask) << 16);
+                        }
+                        if ((q = hipMemcpyAsync(c.ps.as<uint32_t>() + xa, lookback.data(), (b - xa) * 4,
+                                                hipMemcpyHostToDevice, c.copy)) != hipSuccess) return q;
+                        if ((q = hipStreamSynchronize(c.copy)) != hipSuccess) return q;      /* pageable source */
+                    }
                 }
                 if (x_done > x_sent[d] &&
                     (q = hipMemcpyAsync(c.xval.as<uint32_t>() + x_sent[d], c0.h_xval.as<uint32_t>() + x_sent[d],
@@ -362,7 +385,8 @@ int encode_core(std::vector<Ctx *> &cs, const void *src, bool src_on_device, siz
                 if ((q = hipStreamWaitEvent(tstream(d), c.chunk_ev[3 * ci + 2], 0)) != hipSuccess) return q;
                 if ((q = hipEventRecord(c.tok_ev[2 * ci], tstream(d))) != hipSuccess) return q;
                 if ((q = lz77k_xfer_index(c.ps.as<uint32_t>(), c.xval.as<uint32_t>(), xa, (uint32_t)x_done, dbase, (uint32_t)e,
-                                          c.ofs.as<uint32_t>(), c.ent.as<uint2>(), c.scantmp.p, tstream(d))) != hipSuccess) return q;
+                                          c.ofs.as<uint32_t>(), c.ent.as<uint2>(), c.scantmp.p, tstream(d),
+                                          (uint32_t)x_new, c.flag.as<unsigned long long>() + 1)) != hipSuccess) return q;
                 if ((q = lz77k_tokens(c.in.as<uint8_t>(), n32, g, c.chain.as<uint32_t>() + tok_sent[d], (uint32_t)(ntok_sz - tok_sent[d]),
                                       c.maxlen.as<uint8_t>(), c.ofs.as<uint32_t>(), c.ent.as<uint2>(), dbase, (uint32_t)b, (uint32_t)e,
                                       c.tokval.as<uint32_t>() + tok_sent[d], c.tstart.as<uint32_t>(), c.bidx.p, tvariant, tstream(d))) != hipSuccess) return q;
@@ -378,7 +402,6 @@ int encode_core(std::vector<Ctx *> &cs, const void *src, bool src_on_device, siz
         if (chain_err.load()) err = LZ77X_E_HIP;
         ntok = (uint32_t)ntok_sz;
         nchunks_done = nchunks;
-        transfers = st.transfers;
         lz77x_prio_free(&st);
         if (err != LZ77X_OK) {
             for (Ctx *c : cs) { hipError_t q = hipSetDevice(c->device); q = hipDeviceSynchronize(); (void)q; }
@@ -387,6 +410,17 @@ int encode_core(std::vector<Ctx *> &cs, const void *src, bool src_on_device, siz
         }
         g_stats.host_chain_ms = t_chain;
         g_stats.host_stageb_ms = t_prio;
+
+        /* hand-overs were counted by the index kernels (each eviction once, by the shard that first saw it) */
+        for (uint32_t d = 0; d < D; d++) {
+            Ctx &c = *cs[d];
+            unsigned long long cnt = 0;
+            HIPCHK(hipSetDevice(c.device));
+            HIPCHK(hipMemcpyAsync(&cnt, c.flag.as<unsigned long long>() + 1, 8, hipMemcpyDeviceToHost, tstream(d)));
+            HIPCHK(hipStreamSynchronize(tstream(d)));
+            transfers += cnt;
+        }
+        HIPCHK(hipSetDevice(c0.device));
 
         /* -- other shards hand their token values to the first device through the host -- */
         if (D > 1) {
@@ -748,7 +782,11 @@ int lz77x_stage_priorities(const uint16_t *P, const uint16_t *S, size_t n, int s
     if (sb < 1 || sb > 65535) return LZ77X_E_ARG;
     uint32_t *ps = (uint32_t *)malloc((n + 1) * 4);
     if (!ps) return LZ77X_E_NOMEM;
-    for (size_t i = 0; i < n; i++) { ps[i] = (uint32_t)P[i] | ((uint32_t)S[i] << 16); xval[i] = LZ77X_NONE32; }
+    const uint32_t rmask = lz77x_prio_mask(sb);
+    for (size_t i = 0; i < n; i++) {
+        ps[i] = (((uint32_t)i + P[i]) & rmask) | ((((uint32_t)i + S[i]) & rmask) << 16);
+        xval[i] = LZ77X_NONE32;
+    }
     lz77x_prio_state st;
     if (!lz77x_prio_init(&st, sb)) { free(ps); return LZ77X_E_NOMEM; }
     lz77x_prio_run(&st, ps, sb, n, xval);

@@ -15,6 +15,17 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def pytest_sessionstart(session):
+    """Make sure the product (HIP library + CLI) and the oracle are built; a no-op when up to date."""
+    import subprocess
+    lib = os.path.join(ROOT, "lz77_amd", "liblz77_mi355x.so")
+    cli = os.path.join(ROOT, "lz77_amd", "lz77")
+    if not (os.path.exists(lib) and os.path.exists(cli)):
+        subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "lz77_amd", "csrc")])
+    if not os.path.exists(os.path.join(ROOT, "oracle", "liblz77_oracle.so")):
+        subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle")])
+
+
 @pytest.fixture(scope="session")
 def golden():
     with open(os.path.join(HERE, "golden", "golden.json")) as f:
