@@ -305,31 +305,31 @@ int encode_core(std::vector<Ctx *> &cs, const void *src, bool src_on_device, siz
         lz77x_prio_state st;
         if (!lz77x_prio_init(&st, g.sb)) return LZ77X_E_NOMEM;
 
-        /* The two host recurrences are independent of each other (SURVEY A.2 vs A.5), so the greedy
-         * parse chain runs on a helper thread and publishes, per chunk, how many tokens exist up
-         * to the chunk's end; the calling thread runs the priority recurrence. */
-        std::vector<std::atomic<uint64_t>> toks_upto(nchunks);
-        for (auto &t : toks_upto) t.store(~0ull, std::memory_order_relaxed);
-        std::atomic<int> chain_err{0};
-        double t_chain = 0;
-        std::thread chain_thread([&]() {
-            size_t pp = 0, kk = 0;
+        /* The two host recurrences are independent of each other (SURVEY A.2 vs A.5).  The priority
+         * recurrence -- the critical path of the whole encode -- gets a thread of its own that does
+         * nothing else; the calling thread walks the parse chain (8x cheaper) and does all the HIP
+         * enqueueing for a chunk as soon as both are through it. */
+        std::vector<std::atomic<int>> prio_done(nchunks);
+        for (auto &t : prio_done) t.store(0, std::memory_order_relaxed);
+        std::atomic<int> prio_err{0};
+        double t_prio = 0;
+        std::thread prio_thread([&]() {
             for (uint32_t ci = 0; ci < nchunks; ci++) {
                 size_t e = (size_t)(ci + 1) * per_chunk * g.TILE;
                 if (e > n) e = n;
-                if (hipEventSynchronize(cs[owner[ci]]->chunk_ev[3 * ci + 1]) != hipSuccess) chain_err.store(1);
+                if (hipEventSynchronize(cs[owner[ci]]->chunk_ev[3 * ci + 1]) != hipSuccess) prio_err.store(1);
                 const double t0 = now_ms();
-                pp = lz77x_host_chain(c0.h_maxlen.as<uint8_t>(), e, pp, c0.h_chain.as<uint32_t>(), &kk);
-                t_chain += now_ms() - t0;
-                toks_upto[ci].store(kk, std::memory_order_release);
+                lz77x_prio_run(&st, c0.h_ps.as<uint32_t>(), g.sb, e, c0.h_xval.as<uint32_t>());
+                t_prio += now_ms() - t0;
+                prio_done[ci].store(1, std::memory_order_release);
             }
         });
-        struct Joiner { std::thread &t; ~Joiner() { if (t.joinable()) t.join(); } } joiner{chain_thread};
+        struct Joiner { std::thread &t; ~Joiner() { if (t.joinable()) t.join(); } } joiner{prio_thread};
 
-        size_t ntok_sz = 0;
-        std::vector<size_t> tok_sent(D, 0), x_sent(D, 0);
+        size_t ntok_sz = 0, chain_p = 0;
+        std::vector<size_t> tok_sent(D, 0), x_sent(D, 0), toks_at(nchunks + 1, 0);   /* tokens before chunk ci */
         std::vector<uint32_t> lookback;
-        double t_prio = 0;
+        double t_chain = 0;
         int err = LZ77X_OK;
         for (uint32_t ci = 0; ci < nchunks && err == LZ77X_OK; ci++) {
             const uint32_t d = owner[ci];
@@ -342,14 +342,11 @@ int encode_core(std::vector<Ctx *> &cs, const void *src, bool src_on_device, siz
             const double t1 = now_ms();
             waited += t1 - tw;
             if (he != hipSuccess) { err = LZ77X_E_HIP; snprintf(g_err, sizeof g_err, "chunk sync: %s", hipGetErrorString(he)); break; }
-            lz77x_prio_run(&st, c0.h_ps.as<uint32_t>(), g.sb, e, c0.h_xval.as<uint32_t>());
-            const double t2 = now_ms();
-            t_prio += t2 - t1;
-            uint64_t upto;
-            while ((upto = toks_upto[ci].load(std::memory_order_acquire)) == ~0ull) std::this_thread::yield();
-            waited += now_ms() - t2;
             const size_t tok_before = ntok_sz;
-            ntok_sz = (size_t)upto;
+            chain_p = lz77x_host_chain(c0.h_maxlen.as<uint8_t>(), e, chain_p, c0.h_chain.as<uint32_t>(), &ntok_sz);
+            const double t2 = now_ms();
+            t_chain += t2 - t1;
+            while (!prio_done[ci].load(std::memory_order_acquire)) std::this_thread::yield();
             const size_t x_done = e > (size_t)g.sb ? e - (size_t)g.sb : 0;
             /* hand-overs that can matter to tokens in [b, e): evictions before e-sb into dst >= b-sb */
             const uint32_t dbase = b > (size_t)g.sb ? (uint32_t)(b - (size_t)g.sb) : 0u;
@@ -397,9 +394,10 @@ int encode_core(std::vector<Ctx *> &cs, const void *src, bool src_on_device, siz
             if (he != hipSuccess) { err = LZ77X_E_HIP; snprintf(g_err, sizeof g_err, "chunk enqueue: %s", hipGetErrorString(he)); break; }
             x_sent[d] = x_done;
             tok_sent[d] = ntok_sz;
+            toks_at[ci + 1] = ntok_sz;
         }
-        chain_thread.join();
-        if (chain_err.load()) err = LZ77X_E_HIP;
+        prio_thread.join();
+        if (prio_err.load()) err = LZ77X_E_HIP;
         ntok = (uint32_t)ntok_sz;
         nchunks_done = nchunks;
         lz77x_prio_free(&st);
@@ -428,8 +426,7 @@ int encode_core(std::vector<Ctx *> &cs, const void *src, bool src_on_device, siz
             for (uint32_t d = 1; d < D; d++) {
                 Ctx &c = *cs[d];
                 if (first_chunk[d] >= first_chunk[d + 1]) continue;
-                const size_t ta = first_chunk[d] ? (size_t)toks_upto[first_chunk[d] - 1].load() : 0;
-                const size_t tb = (size_t)toks_upto[first_chunk[d + 1] - 1].load();
+                const size_t ta = toks_at[first_chunk[d]], tb = toks_at[first_chunk[d + 1]];
                 HIPCHK(hipSetDevice(c.device));
                 HIPCHK(hipMemcpyAsync(c0.h_tok.as<uint32_t>() + ta, c.tokval.as<uint32_t>() + ta, (tb - ta) * 4, hipMemcpyDeviceToHost, c.tok));
                 const double tw = now_ms();
