@@ -20,6 +20,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <atomic>
+#include <condition_variable>
 #include <mutex>
 #include <thread>
 #include <vector>
@@ -251,7 +252,8 @@ int encode_core(std::vector<Ctx *> &cs, const void *src, bool src_on_device, siz
             if ((rc = c.bidx.need(lz77k_tokens_index_bytes(g, chunk_pos < n ? chunk_pos : n)))) return rc;
             while (c.chunk_ev.size() < 3 * (size_t)nchunks) {
                 hipEvent_t e;
-                HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));   /* ordering only */
+                /* ordering only; host waiters sleep instead of spinning next to the recurrence thread */
+                HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming | hipEventBlockingSync));
                 c.chunk_ev.push_back(e);
             }
             while (c.tok_ev.size() < 2 * (size_t)nchunks) {
@@ -309,8 +311,9 @@ int encode_core(std::vector<Ctx *> &cs, const void *src, bool src_on_device, siz
          * recurrence -- the critical path of the whole encode -- gets a thread of its own that does
          * nothing else; the calling thread walks the parse chain (8x cheaper) and does all the HIP
          * enqueueing for a chunk as soon as both are through it. */
-        std::vector<std::atomic<int>> prio_done(nchunks);
-        for (auto &t : prio_done) t.store(0, std::memory_order_relaxed);
+        std::mutex pm;
+        std::condition_variable pcv;
+        uint32_t prio_chunks = 0;                      /* chunks the recurrence is through (guarded by pm) */
         std::atomic<int> prio_err{0};
         double t_prio = 0;
         std::thread prio_thread([&]() {
@@ -321,7 +324,8 @@ int encode_core(std::vector<Ctx *> &cs, const void *src, bool src_on_device, siz
                 const double t0 = now_ms();
                 lz77x_prio_run(&st, c0.h_ps.as<uint32_t>(), g.sb, e, c0.h_xval.as<uint32_t>());
                 t_prio += now_ms() - t0;
-                prio_done[ci].store(1, std::memory_order_release);
+                { std::lock_guard<std::mutex> lk(pm); prio_chunks = ci + 1; }
+                pcv.notify_one();
             }
         });
         struct Joiner { std::thread &t; ~Joiner() { if (t.joinable()) t.join(); } } joiner{prio_thread};
@@ -346,7 +350,7 @@ int encode_core(std::vector<Ctx *> &cs, const void *src, bool src_on_device, siz
             chain_p = lz77x_host_chain(c0.h_maxlen.as<uint8_t>(), e, chain_p, c0.h_chain.as<uint32_t>(), &ntok_sz);
             const double t2 = now_ms();
             t_chain += t2 - t1;
-            while (!prio_done[ci].load(std::memory_order_acquire)) std::this_thread::yield();
+            { std::unique_lock<std::mutex> lk(pm); pcv.wait(lk, [&] { return prio_chunks > ci; }); }
             const size_t x_done = e > (size_t)g.sb ? e - (size_t)g.sb : 0;
             /* hand-overs that can matter to tokens in [b, e): evictions before e-sb into dst >= b-sb */
             const uint32_t dbase = b > (size_t)g.sb ? (uint32_t)(b - (size_t)g.sb) : 0u;
