@@ -1103,10 +1103,15 @@ __global__ void k_xfer_count(const uint32_t *__restrict__ ps, const uint32_t *__
         const uint32_t dst = x + (ps[x] >> 16);
         if (dst >= dbase) atomicAdd(&cnt[dst - dbase], 1u);
     }
-    if (total) {
+    if (total) {                                  /* one global atomic per workgroup */
+        __shared__ uint32_t bsum;
+        if (threadIdx.x == 0) bsum = 0;
+        __syncthreads();
 #pragma unroll
         for (int d = 32; d > 0; d >>= 1) mine += __shfl_xor(mine, d, 64);
-        if ((threadIdx.x & 63) == 0 && mine) atomicAdd(total, (unsigned long long)mine);
+        if ((threadIdx.x & 63) == 0 && mine) atomicAdd(&bsum, mine);
+        __syncthreads();
+        if (threadIdx.x == 0 && bsum) atomicAdd(total, (unsigned long long)bsum);
     }
 }
 
@@ -1132,7 +1137,7 @@ hipError_t lz77k_xfer_index(const uint32_t *d_ps, const uint32_t *d_xval, uint32
     if (e != hipSuccess) return e;
     if (xb <= xa) return hipSuccess;
     const uint32_t blocks = min((xb - xa + 255u) / 256u, 256u * 16u);
-    hipLaunchKernelGGL(k_xfer_count, dim3(blocks), dim3(256), 0, s, d_ps, d_xval, xa, xb, dbase, d_ofs, x_new, d_total);
+    hipLaunchKernelGGL(k_xfer_count, dim3(min(blocks, 1024u)), dim3(256), 0, s, d_ps, d_xval, xa, xb, dbase, d_ofs, x_new, d_total);
     e = lz77k_scan_u32(d_ofs, d_ofs, nd + 1, d_scan_tmp, s);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(k_xfer_fill, dim3(blocks), dim3(256), 0, s, d_ps, d_xval, xa, xb, dbase, d_ofs, d_ent);
