@@ -163,13 +163,29 @@ __device__ __forceinline__ void region_sort_blocked(IdxT *ix, const uint8_t *by,
                 *reinterpret_cast<uint4 *>(ix + 16 * tid + r) = make_uint4(v[r], v[r + 1], v[r + 2], v[r + 3]);
         }
     };
-    auto lds_step = [&](bool up, uint32_t j, uint32_t t) {            /* compare-exchange pair t of stride j */
-        const uint32_t i = 2 * t - (t & (j - 1)), l = i + j;
-        const uint32_t a = ix[i], b = ix[l];
-        bool b_lt_a;
-        if (a >= R || b >= R) b_lt_a = b < a;
-        else b_lt_a = key_less<BYTES_LDS>(by, b, a, la);
-        if (up ? b_lt_a : !b_lt_a) { ix[i] = (IdxT)b; ix[l] = (IdxT)a; }
+    /* four disjoint compare-exchanges of stride j at pairs t0, t0+tstep, ...: all index loads first,
+     * then all key loads, then the stores: ~3 LDS round trips per four instead of 4x3, while staying
+     * within 64 VGPRs (two workgroups per CU) */
+    auto lds_step4 = [&](uint32_t k, bool top, uint32_t j, uint32_t t0, uint32_t tstep) {
+        uint32_t ii[4], a[4], b[4], ka[4], kb[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const uint32_t t = t0 + (uint32_t)u * tstep;
+            ii[u] = 2 * t - (t & (j - 1));
+            a[u] = ix[ii[u]];
+            b[u] = ix[ii[u] + j];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            ka[u] = a[u] < R ? (__builtin_bswap32(ld32_at<BYTES_LDS>(by, a[u])) & pmask) : 0xFFFFFFFFu;
+            kb[u] = b[u] < R ? (__builtin_bswap32(ld32_at<BYTES_LDS>(by, b[u])) & pmask) : 0xFFFFFFFFu;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const bool up = top ? top_up : (ii[u] & k) == 0;
+            const bool b_lt_a = sort_less<BYTES_LDS>(by, b[u], kb[u], a[u], ka[u], R, la);
+            if (up ? b_lt_a : !b_lt_a) { ix[ii[u]] = (IdxT)b[u]; ix[ii[u] + j] = (IdxT)a[u]; }
+        }
     };
     auto local_tail = [&](bool up) {
         sort_local_pass<8, false, BYTES_LDS>(v, pf, by, R, la, 0, up);
@@ -196,10 +212,8 @@ __device__ __forceinline__ void region_sort_blocked(IdxT *ix, const uint8_t *by,
         if (j >= 1024) {
             __syncthreads();                                          /* other waves' segments are read next */
             for (; j >= 1024; j >>= 1) {
-                for (uint32_t t = tid; t < (CH >> 1); t += MATCH_BLOCK) {
-                    const uint32_t i = 2 * t - (t & (j - 1));
-                    lds_step(top ? top_up : (i & k) == 0, j, t);
-                }
+                lds_step4(k, top, j, tid, MATCH_BLOCK);                  /* pairs tid, tid+1024, ... */
+                lds_step4(k, top, j, tid + 4 * MATCH_BLOCK, MATCH_BLOCK);
                 __syncthreads();
             }
         } else {
@@ -207,12 +221,8 @@ __device__ __forceinline__ void region_sort_blocked(IdxT *ix, const uint8_t *by,
             __builtin_amdgcn_wave_barrier();
         }
         for (; j >= 16; j >>= 1) {                                    /* inside this wave's 1024 slots */
-#pragma unroll 2
-            for (uint32_t u = 0; u < 8; u++) {
-                const uint32_t t = 512 * wave + lane + 64 * u;
-                const uint32_t i = 2 * t - (t & (j - 1));
-                lds_step(top ? top_up : (i & k) == 0, j, t);
-            }
+            lds_step4(k, top, j, 512 * wave + lane, 64);
+            lds_step4(k, top, j, 512 * wave + lane + 256, 64);
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
         }
@@ -355,7 +365,7 @@ __device__ __forceinline__ void edge_octet(acc8<FAST> &acc, const RankT *rk, uin
  *          2 = sort + ranks only (timing probe)
  */
 template <bool FAST, int MODE>
-__global__ __launch_bounds__(MATCH_BLOCK) void k_match(const uint8_t *__restrict__ in, uint32_t n, int sb, int la,
+__global__ __launch_bounds__(MATCH_BLOCK, (FAST && MODE == 3) ? 8 : 1) void k_match(const uint8_t *__restrict__ in, uint32_t n, int sb, int la,
                                                        uint32_t SBu, uint32_t RP, uint32_t TILE, uint32_t region0,
                                                        uint32_t *__restrict__ ps, uint8_t *__restrict__ maxlen,
                                                        uint32_t *__restrict__ scratch, int sort_variant)
