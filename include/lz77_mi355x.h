@@ -83,6 +83,9 @@ int lz77x_decode_file(FILE *in, FILE *out);
  * bytes are identical for every shard count. */
 int lz77x_set_shards(int shards);
 int lz77x_device_count(void);
+/* Release every cached device/pinned buffer, stream and event (they are otherwise kept for the
+ * life of the process and re-created on the next call). */
+void lz77x_shutdown(void);
 const char *lz77x_strerror(int code);
 const char *lz77x_last_error(void);       /* detail of the last LZ77X_E_HIP, thread local */
 const char *lz77x_version(void);

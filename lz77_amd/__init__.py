@@ -75,6 +75,7 @@ SYMBOLS = {
     "lz77x_decode_file": (ctypes.c_int, [_vp, _vp]),
     "lz77x_set_shards": (ctypes.c_int, [ctypes.c_int]),
     "lz77x_device_count": (ctypes.c_int, []),
+    "lz77x_shutdown": (None, []),
     "lz77x_strerror": (ctypes.c_char_p, [ctypes.c_int]),
     "lz77x_last_error": (ctypes.c_char_p, []),
     "lz77x_version": (ctypes.c_char_p, []),

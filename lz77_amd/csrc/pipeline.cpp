@@ -702,6 +702,42 @@ const char *lz77x_strerror(int code)
     }
 }
 
+static void ctx_release(Ctx &c)
+{
+    if (!c.ready) return;
+    hipError_t e = hipSetDevice(c.device);
+    e = hipDeviceSynchronize();
+    for (DevBuf *b : {&c.in, &c.ps, &c.maxlen, &c.scratch, &c.xval, &c.chain, &c.ofs, &c.ent, &c.tokval, &c.out, &c.scantmp,
+                      &c.z, &c.len1, &c.dst, &c.ptr, &c.flag, &c.tstart, &c.bidx, &c.cells}) {
+        if (b->p) e = hipFree(b->p);
+        b->p = nullptr;
+        b->cap = 0;
+    }
+    for (PinBuf *b : {&c.h_ps, &c.h_maxlen, &c.h_xval, &c.h_chain, &c.h_small, &c.h_tok}) {
+        if (b->p) e = hipHostFree(b->p);
+        b->p = nullptr;
+        b->cap = 0;
+    }
+    for (auto *v : {&c.chunk_ev, &c.tok_ev, &c.sort_ev}) {
+        for (hipEvent_t ev : *v) e = hipEventDestroy(ev);
+        v->clear();
+    }
+    for (auto &ev : c.ev) e = hipEventDestroy(ev);
+    e = hipStreamDestroy(c.stream);
+    e = hipStreamDestroy(c.copy);
+    e = hipStreamDestroy(c.tok);
+    (void)e;
+    c.ready = false;
+}
+
+void lz77x_shutdown(void)
+{
+    std::lock_guard<std::mutex> lk(g_mu);
+    for (Ctx *c : g_more) { ctx_release(*c); delete c; }
+    g_more.clear();
+    ctx_release(g_ctx);
+}
+
 const char *lz77x_last_error(void) { return g_err; }
 const char *lz77x_version(void) { return "lz77-mi355x 0.1 (gfx950)"; }
 

@@ -193,6 +193,38 @@ def test_kernel_variants_agree(env, monkeypatch):
     assert L.encode(data) == want
 
 
+def test_roundtrip_incompressible_large():
+    """S2-like: 256 MiB of splitmix64 bytes (the match-miss path): size formulas and round trip"""
+    n = 256 << 20
+    data = synth.random_bytes(n, synth.SEED_S2)
+    z = L.encode(data)
+    st = L.last_stats()
+    assert st["n"] == n and st["zn"] == len(z) == 4 + st["ntok"] * 3
+    _, _, off, ln, nx = O.tokens(z[:4 + 3 * 100000])
+    assert int(ln.max()) <= 14 and int(off.max()) <= 4095
+    assert 1.40 < len(z) / n < 1.50                           # reference expands random input by ~1.456
+    assert sha(L.decode(z)) == sha(data)
+
+
+def test_roundtrip_large_window():
+    """S3-like at the large-window geometry (global-bitmap walkers, chunked sort, global candidate index)"""
+    data = synth.mixed(48 << 20, synth.SEED_S3)
+    z = L.encode(data, 255, 65535)
+    assert z[:4] == bytes([0xFF, 0xFF, 0xFF, 0x00])           # header: s=65535 l=255
+    assert (len(z) - 4) % 4 == 0
+    assert sha(L.decode(z)) == sha(data)
+    # the first 8 MiB are pinned by a golden digest (bulk tier "gpu"); a prefix property ties the rest to it
+    z8 = L.encode(data[: 8 << 20], 255, 65535)
+    assert len(os.path.commonprefix([z, z8])) >= len(z8) - 4 * 300
+
+
+def test_shutdown_and_reuse():
+    data = synth.text(200_000, 3)
+    a = L.encode(data)
+    L.lib().lz77x_shutdown()
+    assert L.encode(data) == a and L.decode(a) == data.tobytes()
+
+
 def test_arg_errors():
     for la, sb in ((1, 4095), (256, 4095), (15, 0), (15, 65536)):
         with pytest.raises(L.Lz77Error) as e:
