@@ -87,7 +87,7 @@ struct Ctx {
     std::vector<hipEvent_t> chunk_ev, tok_ev, sort_ev;
     DevBuf in, ps, maxlen, scratch, xval, chain, ofs, ent, tokval, out, scantmp;
     DevBuf z, len1, dst, ptr, flag, tstart, bidx, cells;
-    PinBuf h_ps, h_maxlen, h_xval, h_chain, h_small, h_tok;
+    PinBuf h_ps, h_maxlen, h_xval, h_chain, h_small, h_tok, h_stage;
 };
 
 Ctx g_ctx;                                   /* context on the caller's current device */
@@ -577,6 +577,40 @@ int load_stream(Ctx &c, const void *src, bool on_device, size_t zn, hipStream_t 
     return LZ77X_OK;
 }
 
+
+/* device -> caller's pageable buffer through two pinned staging slots: the DMA of piece k+1 runs
+ * while the host copies piece k out (a direct hipMemcpy into pageable memory is ~2 GB/s) */
+int fetch_result(Ctx &c, uint8_t *dst, const void *d_src, size_t bytes)
+{
+    const size_t piece = (size_t)16 << 20;
+    int rc;
+    if ((rc = c.h_stage.need(2 * piece))) return rc;
+    uint8_t *slot[2] = {c.h_stage.as<uint8_t>(), c.h_stage.as<uint8_t>() + piece};
+    const uint8_t *src = reinterpret_cast<const uint8_t *>(d_src);
+    size_t issued = 0, done = 0;
+    int k = 0;
+    if (bytes) {
+        const size_t m = bytes < piece ? bytes : piece;
+        HIPCHK(hipMemcpyAsync(slot[0], src, m, hipMemcpyDeviceToHost, c.copy));
+        HIPCHK(hipEventRecord(c.ev[4], c.copy));
+        issued = m;
+    }
+    while (done < bytes) {
+        const size_t cur = (issued - done);
+        HIPCHK(hipEventSynchronize(c.ev[4 + (k & 1)]));
+        if (issued < bytes) {
+            const size_t m = bytes - issued < piece ? bytes - issued : piece;
+            HIPCHK(hipMemcpyAsync(slot[(k + 1) & 1], src + issued, m, hipMemcpyDeviceToHost, c.copy));
+            HIPCHK(hipEventRecord(c.ev[4 + ((k + 1) & 1)], c.copy));
+            issued += m;
+        }
+        memcpy(dst + done, slot[k & 1], cur);
+        done += cur;
+        k++;
+    }
+    return LZ77X_OK;
+}
+
 }  // namespace
 
 /* ==================================================================== C ABI ========= */
@@ -607,7 +641,7 @@ int lz77x_encode(const uint8_t *in, size_t n, int sb, int la, uint8_t **out, siz
     if ((rc = encode_core(cs, in, false, n, g, g_ctx.stream, &zn))) return rc;
     uint8_t *buf = (uint8_t *)malloc(zn ? zn : 1);
     if (!buf) return LZ77X_E_NOMEM;
-    HIPCHK(hipMemcpy(buf, g_ctx.out.p, zn, hipMemcpyDeviceToHost));
+    if ((rc = fetch_result(g_ctx, buf, g_ctx.out.p, zn))) { free(buf); return rc; }
     *out = buf;
     *out_n = zn;
     return LZ77X_OK;
@@ -645,7 +679,7 @@ int lz77x_decode(const uint8_t *z, size_t zn, uint8_t **out, size_t *out_n)
     if ((rc = decode_core(g_ctx, zn, g_ctx.stream, true, &n))) return rc;
     uint8_t *buf = (uint8_t *)malloc(n ? n : 1);
     if (!buf) return LZ77X_E_NOMEM;
-    if (n) HIPCHK(hipMemcpy(buf, g_ctx.out.p, n, hipMemcpyDeviceToHost));
+    if ((rc = fetch_result(g_ctx, buf, g_ctx.out.p, n))) { free(buf); return rc; }
     *out = buf;
     *out_n = n;
     return LZ77X_OK;
@@ -713,7 +747,7 @@ static void ctx_release(Ctx &c)
         b->p = nullptr;
         b->cap = 0;
     }
-    for (PinBuf *b : {&c.h_ps, &c.h_maxlen, &c.h_xval, &c.h_chain, &c.h_small, &c.h_tok}) {
+    for (PinBuf *b : {&c.h_ps, &c.h_maxlen, &c.h_xval, &c.h_chain, &c.h_small, &c.h_tok, &c.h_stage}) {
         if (b->p) e = hipHostFree(b->p);
         b->p = nullptr;
         b->cap = 0;
