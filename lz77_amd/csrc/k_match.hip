@@ -1,92 +1,16 @@
 /*
- * kernels.hip -- hand-written HIP kernels of the LZ77 hot path for gfx950 (MI355X).
+ * k_match.hip -- the match stage: what replaces tree.c:62-243 (insert / delete / find on the BST).
  *
- * What replaces what (reference file:line):
- *   k_match      tree.c:62-243 (insert/delete/find on the BST) -> per-region key sort +
- *                rank-difference pair scan.  For every position x it yields
- *                  - maxlen[x]: the longest match in the SB window (tree.c:118-152 result len)
- *                  - P[x],S[x]: in-order predecessor/successor of x among the SB-1 positions
- *                    that follow it, i.e. x's neighbours in the BST at the moment
- *                    tree.c:182 delete() evicts it.
- *   k_xfer_*     index of the priority hand-overs produced by the host stage
- *   k_tokens     tree.c:139-141 "first strictly longer on the search path wins": among the
- *                equal-length candidates pick the one nearest the BST root (min priority)
- *   k_pack       lz77.c:246-252 writecode + bitio.c:203-239 bitIO_write as computed bit offsets
- *   k_dec_*      lz77.c:148-197 decode, lz77.c:260-283 readcode, bitio.c:256-298 bitIO_read
- *
- * Byte/integer work only: no MFMA.  wave = 64 lanes; LDS staged windows; packed 16-bit
- * VALU (v_pk_sub/min/max_u16) in the pair scan; coalesced dword global traffic.
+ *   k_match      per-region key sort -> rank[] and its inverse (+ the exhaustive rank-difference pair
+ *                scan kept as a cross-check, LZ77X_MATCH_VARIANT=1/3)
+ *   k_walk       O(1)-per-position sliding-window neighbour search on per-lane bitmaps
+ *   k_walk_final ranks -> ps[x] (in-order neighbours at eviction time) and maxlen[x] (longest match)
  */
-#include <hip/hip_runtime.h>
-#include <stdint.h>
-#include <stdlib.h>
-#include "lz77x_internal.h"
+#include "kernels_common.h"
 
 #define MATCH_BLOCK 1024
 
 typedef unsigned short us2 __attribute__((ext_vector_type(2)));
-
-/* ------------------------------------------------------------------ helpers ---------- */
-
-__device__ __forceinline__ uint32_t ld32u(const uint8_t *p)
-{
-    uint32_t v;
-    __builtin_memcpy(&v, p, 4);          /* gfx950: unaligned dword access is native (LDS and global) */
-    return v;
-}
-
-__device__ __forceinline__ uint64_t ld64u(const uint8_t *p)
-{
-    uint64_t v;
-    __builtin_memcpy(&v, p, 8);
-    return v;
-}
-
-/* dword at byte offset `off` of a byte array.  LDS: an unaligned ds_read_b32 is replayed for
- * ~64 cycles per wave on gfx950, so fetch the two aligned dwords and funnel-shift; global
- * memory serves unaligned dwords natively. */
-template <bool LDS>
-__device__ __forceinline__ uint32_t ld32_at(const uint8_t *by, uint32_t off)
-{
-    if constexpr (LDS) {
-        const uint32_t *w = reinterpret_cast<const uint32_t *>(by + (off & ~3u));
-        return __builtin_amdgcn_alignbyte(w[1], w[0], off & 3u);
-    } else {
-        return ld32u(by + off);
-    }
-}
-
-/* first `la` bytes at a vs b as big-endian words; ties -> lower index first.
- * tree.c:77 orders nodes with memcmp over the lookahead; bytes past the end of input are
- * 0xFF on device, which reproduces the shrinking key length at EOF (DESIGN.md "key order"). */
-template <bool LDS>
-__device__ __forceinline__ bool key_less(const uint8_t *by, uint32_t a, uint32_t b, int la)
-{
-    for (int w = 0; w < la; w += 4) {
-        uint32_t va = __builtin_bswap32(ld32_at<LDS>(by, a + w));
-        uint32_t vb = __builtin_bswap32(ld32_at<LDS>(by, b + w));
-        int rem = la - w;
-        if (rem < 4) {
-            uint32_t m = 0xFFFFFFFFu << (8 * (4 - rem));
-            va &= m;
-            vb &= m;
-        }
-        if (va != vb) return va < vb;
-    }
-    return a < b;
-}
-
-template <bool LDS>
-__device__ __forceinline__ int lcp_capped(const uint8_t *by, uint32_t a, uint32_t b, int cap)
-{
-    int i = 0;
-    while (i < cap) {
-        const uint32_t x = ld32_at<LDS>(by, a + i) ^ ld32_at<LDS>(by, b + i);
-        if (x) { i += __builtin_ctz(x) >> 3; break; }
-        i += 4;
-    }
-    return i < cap ? i : cap;
-}
 
 /*
  * Bitonic sort of RP = 16*1024 local indices held in LDS, organised by how far apart the two
@@ -990,699 +914,3 @@ hipError_t lz77k_match(const uint8_t *d_in, uint32_t n, const lz77x_geom &g, uin
 #undef LZ77K_MATCH_ARGS
 }
 
-/* ------------------------------------------------------------------ small utilities -- */
-
-__global__ void k_fill_pad(uint8_t *in, uint32_t n)
-{
-    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < LZ77X_PAD) in[(size_t)n + i] = 0xFF;
-}
-
-__global__ void k_ps_cells(const uint32_t *__restrict__ ps, uint32_t *__restrict__ cells, uint32_t x0, uint32_t x1, uint32_t mask)
-{
-    for (uint32_t x = x0 + blockIdx.x * blockDim.x + threadIdx.x; x < x1; x += gridDim.x * blockDim.x) {
-        const uint32_t v = ps[x];
-        cells[x] = ((x + (v & 0xFFFFu)) & mask) | (((x + (v >> 16)) & mask) << 16);
-    }
-}
-
-hipError_t lz77k_ps_cells(const uint32_t *d_ps, uint32_t *d_cells, uint32_t x0, uint32_t x1, uint32_t mask, hipStream_t s)
-{
-    if (x1 <= x0) return hipSuccess;
-    const uint32_t blocks = min((x1 - x0 + 255u) / 256u, 256u * 16u);
-    hipLaunchKernelGGL(k_ps_cells, dim3(blocks), dim3(256), 0, s, d_ps, d_cells, x0, x1, mask);
-    return hipGetLastError();
-}
-
-hipError_t lz77k_fill_pad(uint8_t *d_in, uint32_t n, hipStream_t s)
-{
-    hipLaunchKernelGGL(k_fill_pad, dim3((LZ77X_PAD + 255) / 256), dim3(256), 0, s, d_in, n);
-    return hipGetLastError();
-}
-
-/* ---- exclusive scan (uint32), 3 phases, recursive on block sums ---- */
-
-#define SCAN_THREADS 256
-#define SCAN_ITEMS 8
-#define SCAN_CHUNK (SCAN_THREADS * SCAN_ITEMS)
-
-__global__ __launch_bounds__(SCAN_THREADS) void k_scan_local(const uint32_t *in, uint32_t *out,   /* may alias */
-                                                             uint32_t m, uint32_t *sums)
-{
-    __shared__ uint32_t wsum[SCAN_THREADS / 64];
-    const uint32_t base = blockIdx.x * SCAN_CHUNK + threadIdx.x * SCAN_ITEMS;
-    uint32_t v[SCAN_ITEMS], tot = 0;
-#pragma unroll
-    for (int i = 0; i < SCAN_ITEMS; i++) {
-        v[i] = base + i < m ? in[base + i] : 0;
-        tot += v[i];
-    }
-    /* inclusive scan of tot across the wave, then across the 4 waves */
-    uint32_t incl = tot;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        uint32_t t = __shfl_up(incl, d, 64);
-        if (lane >= d) incl += t;
-    }
-    if (lane == 63) wsum[wave] = incl;
-    __syncthreads();
-    uint32_t woff = 0, btot = 0;
-#pragma unroll
-    for (int w = 0; w < SCAN_THREADS / 64; w++) {
-        if (w < wave) woff += wsum[w];
-        btot += wsum[w];
-    }
-    uint32_t run = woff + incl - tot;
-#pragma unroll
-    for (int i = 0; i < SCAN_ITEMS; i++) {
-        if (base + i < m) out[base + i] = run;
-        run += v[i];
-    }
-    if (threadIdx.x == 0 && sums) sums[blockIdx.x] = btot;
-}
-
-__global__ __launch_bounds__(SCAN_THREADS) void k_scan_add(uint32_t *__restrict__ out, uint32_t m, const uint32_t *__restrict__ offs)
-{
-    const uint32_t add = offs[blockIdx.x];
-    const uint32_t base = blockIdx.x * SCAN_CHUNK + threadIdx.x * SCAN_ITEMS;
-#pragma unroll
-    for (int i = 0; i < SCAN_ITEMS; i++)
-        if (base + i < m) out[base + i] += add;
-}
-
-size_t lz77k_scan_tmp_bytes(uint32_t m)
-{
-    size_t total = 0;
-    uint64_t cur = m;
-    while (cur > SCAN_CHUNK) {
-        cur = (cur + SCAN_CHUNK - 1) / SCAN_CHUNK;
-        total += (cur + 64) * sizeof(uint32_t);
-    }
-    return total + 256;
-}
-
-hipError_t lz77k_scan_u32(const uint32_t *d_in, uint32_t *d_out, uint32_t m, void *d_tmp, hipStream_t s)
-{
-    if (m == 0) return hipSuccess;
-    const uint32_t blocks = (uint32_t)(((uint64_t)m + SCAN_CHUNK - 1) / SCAN_CHUNK);
-    if (blocks == 1) {
-        hipLaunchKernelGGL(k_scan_local, dim3(1), dim3(SCAN_THREADS), 0, s, d_in, d_out, m, (uint32_t *)nullptr);
-        return hipGetLastError();
-    }
-    uint32_t *sums = reinterpret_cast<uint32_t *>(d_tmp);
-    hipLaunchKernelGGL(k_scan_local, dim3(blocks), dim3(SCAN_THREADS), 0, s, d_in, d_out, m, sums);
-    hipError_t e = lz77k_scan_u32(sums, sums, blocks, sums + blocks + 64, s);
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(k_scan_add, dim3(blocks), dim3(SCAN_THREADS), 0, s, d_out, m, sums);
-    return hipGetLastError();
-}
-
-/* ------------------------------------------------------------------ transfer index --- */
-
-/* The host stage hands back xval[x] = priority moved from x to its successor S[x] when x is
- * evicted (or NONE).  Group these hand-overs by destination so that k_tokens can ask
- * "what priority did candidate c hold at time p". */
-__global__ void k_xfer_count(const uint32_t *__restrict__ ps, const uint32_t *__restrict__ xval, uint32_t xa, uint32_t xb,
-                             uint32_t dbase, uint32_t *__restrict__ cnt, uint32_t x_new, unsigned long long *__restrict__ total)
-{
-    uint32_t mine = 0;
-    for (uint32_t x = xa + blockIdx.x * blockDim.x + threadIdx.x; x < xb; x += gridDim.x * blockDim.x) {
-        if (xval[x] == LZ77X_NONE32) continue;
-        mine += x >= x_new;
-        const uint32_t dst = x + (ps[x] >> 16);
-        if (dst >= dbase) atomicAdd(&cnt[dst - dbase], 1u);
-    }
-    if (total) {                                  /* one global atomic per workgroup */
-        __shared__ uint32_t bsum;
-        if (threadIdx.x == 0) bsum = 0;
-        __syncthreads();
-#pragma unroll
-        for (int d = 32; d > 0; d >>= 1) mine += __shfl_xor(mine, d, 64);
-        if ((threadIdx.x & 63) == 0 && mine) atomicAdd(&bsum, mine);
-        __syncthreads();
-        if (threadIdx.x == 0 && bsum) atomicAdd(total, (unsigned long long)bsum);
-    }
-}
-
-__global__ void k_xfer_fill(const uint32_t *__restrict__ ps, const uint32_t *__restrict__ xval, uint32_t xa, uint32_t xb,
-                            uint32_t dbase, uint32_t *__restrict__ ofs, uint2 *__restrict__ ent)
-{
-    for (uint32_t x = xa + blockIdx.x * blockDim.x + threadIdx.x; x < xb; x += gridDim.x * blockDim.x) {
-        const uint32_t v = xval[x];
-        if (v == LZ77X_NONE32) continue;
-        const uint32_t dst = x + (ps[x] >> 16);
-        if (dst >= dbase) ent[atomicAdd(&ofs[dst - dbase], 1u)] = make_uint2(x, v);
-    }
-}
-
-/* Index of the hand-overs of evictions x in [xa, xb) into destinations [dbase, dend):
- * afterwards list(c) = ent[ (c > dbase ? ofs[c-dbase-1] : 0) .. ofs[c-dbase] ). */
-hipError_t lz77k_xfer_index(const uint32_t *d_ps, const uint32_t *d_xval, uint32_t xa, uint32_t xb, uint32_t dbase, uint32_t dend,
-                            uint32_t *d_ofs, uint2 *d_ent, void *d_scan_tmp, hipStream_t s, uint32_t x_new,
-                            unsigned long long *d_total)
-{
-    const uint32_t nd = dend - dbase;
-    hipError_t e = hipMemsetAsync(d_ofs, 0, ((size_t)nd + 1) * sizeof(uint32_t), s);
-    if (e != hipSuccess) return e;
-    if (xb <= xa) return hipSuccess;
-    const uint32_t blocks = min((xb - xa + 255u) / 256u, 256u * 16u);
-    hipLaunchKernelGGL(k_xfer_count, dim3(min(blocks, 1024u)), dim3(256), 0, s, d_ps, d_xval, xa, xb, dbase, d_ofs, x_new, d_total);
-    e = lz77k_scan_u32(d_ofs, d_ofs, nd + 1, d_scan_tmp, s);
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(k_xfer_fill, dim3(blocks), dim3(256), 0, s, d_ps, d_xval, xa, xb, dbase, d_ofs, d_ent);
-    return hipGetLastError();
-}
-
-/* ------------------------------------------------------------------ k_tokens --------- */
-
-/* One wave per token.  Lanes stride the SB candidates; a candidate qualifies when it shares
- * the first len bytes with p (len is already the maximum, so lcp == len); its priority at
- * time p is the value of the latest hand-over into it that happened before p, else its own
- * position.  The wave min over (priority, position) is the node nearest the BST root. */
-__global__ __launch_bounds__(256) void k_tokens(const uint8_t *__restrict__ in, uint32_t n, int sb, int ob, int lb,
-                                                const uint32_t *__restrict__ chain, uint32_t ntok,
-                                                const uint8_t *__restrict__ maxlen,
-                                                const uint32_t *__restrict__ ofs, const uint2 *__restrict__ ent, uint32_t dbase,
-                                                uint32_t *__restrict__ tokval)
-{
-    const uint32_t lane = threadIdx.x & 63;
-    const uint32_t k = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    if (k >= ntok) return;
-    const uint32_t p = chain[k];
-    const uint32_t len = maxlen[p];
-    const uint32_t next = in[p + len];
-    uint32_t off = 0;
-    if (len > 0) {
-        const uint8_t *q = in + p;
-        const uint32_t head = ld32u(q);
-        const uint32_t hmask = len >= 4 ? 0xFFFFFFFFu : (1u << (8 * len)) - 1u;
-        const uint32_t c0 = p > (uint32_t)sb ? p - (uint32_t)sb : 0;
-        uint64_t best = ~0ull;
-        for (uint32_t c = c0 + lane; c < p; c += 64) {
-            const uint8_t *r = in + c;
-            if ((ld32u(r) ^ head) & hmask) continue;
-            bool same = true;
-            for (uint32_t i = 4; i < len; i += 4) {
-                uint32_t x = ld32u(r + i) ^ ld32u(q + i);
-                const uint32_t rem = len - i;
-                if (rem < 4) x &= (1u << (8 * rem)) - 1u;
-                if (x) { same = false; break; }
-            }
-            if (!same) continue;
-            uint32_t prio = c;
-            const uint32_t lo = c > dbase ? ofs[c - dbase - 1] : 0, hi = c >= dbase ? ofs[c - dbase] : 0;
-            uint32_t latest = 0;
-            bool any = false;
-            for (uint32_t e = lo; e < hi; e++) {
-                const uint2 t = ent[e];
-                /* hand-over at eviction of t.x happens after the match at time t.x+sb */
-                if ((uint64_t)t.x + (uint32_t)sb < p && (!any || t.x > latest)) { any = true; latest = t.x; prio = t.y; }
-            }
-            const uint64_t key = ((uint64_t)prio << 32) | c;
-            best = key < best ? key : best;
-        }
-#pragma unroll
-        for (int d = 32; d > 0; d >>= 1) {
-            const uint64_t o = (uint64_t)__shfl_xor((unsigned long long)best, d, 64);
-            best = o < best ? o : best;
-        }
-        off = p - (uint32_t)(best & 0xFFFFFFFFu);
-    }
-    if (lane == 0) {
-        const uint32_t omask = ob >= 32 ? 0xFFFFFFFFu : (1u << ob) - 1u;
-        tokval[k] = (off & omask) | (len << ob) | (next << (ob + lb));      /* lz77.c:249-251 */
-    }
-}
-
-/* ---- tiled variant: window bytes and the hand-over lists of a tile staged in LDS ---- */
-
-#define TOK_TILE 2048u
-#define TOK_BLOCK 512
-
-__global__ void k_tok_bounds(const uint32_t *__restrict__ chain, uint32_t ntok, uint32_t pos0, uint32_t ntiles,
-                             uint32_t *__restrict__ tstart)
-{
-    /* tstart[t] = first token whose position is >= pos0 + t*TOK_TILE (tiles may be empty) */
-    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k > ntok) return;
-    const uint32_t first = k == 0 ? 0u : (chain[k - 1] - pos0) / TOK_TILE + 1;
-    const uint32_t last = k == ntok ? ntiles : (chain[k] - pos0) / TOK_TILE;
-    for (uint32_t t = first; t <= last; t++) tstart[t] = k;
-}
-
-#define TOK_HASH 1024u
-__device__ __forceinline__ uint32_t tok_hash(uint32_t b0, uint32_t b1) { return (b0 * 251u + b1 * 7u) & (TOK_HASH - 1u); }
-
-/*
- * One workgroup per tile of TOK_TILE positions.  Staged in LDS: the window bytes, the hand-over
- * lists of every candidate position, and (BUCKET) an index of the candidate positions by a hash
- * of their first two bytes, so that a token of length >= 2 only visits the handful of window
- * positions that start with its own two bytes instead of all SB of them.
- */
-template <bool BUCKET>
-__global__ __launch_bounds__(TOK_BLOCK) void k_tokens_tile(const uint8_t *__restrict__ in, uint32_t n, int sb, int la, int ob, int lb,
-                                                           const uint32_t *__restrict__ chain, const uint32_t *__restrict__ tstart,
-                                                           const uint8_t *__restrict__ maxlen,
-                                                           const uint32_t *__restrict__ ofs, const uint2 *__restrict__ ent,
-                                                           uint32_t dbase, uint32_t pos0, uint32_t pos1,
-                                                           uint32_t *__restrict__ tokval, uint32_t ent_cap, uint32_t lofs_off,
-                                                           uint32_t lent_off, uint32_t bkt_off)
-{
-    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    uint8_t *by = smem;
-    uint16_t *lofs = reinterpret_cast<uint16_t *>(smem + lofs_off);
-    uint2 *lent = reinterpret_cast<uint2 *>(smem + lent_off);
-    uint32_t *bstart = reinterpret_cast<uint32_t *>(smem + bkt_off);          /* TOK_HASH + 1 (+pad) */
-    uint32_t *bcur = bstart + TOK_HASH + 8;                                    /* TOK_HASH */
-    uint16_t *blist = reinterpret_cast<uint16_t *>(bcur + TOK_HASH);           /* one entry per candidate */
-    __shared__ uint32_t wsum[TOK_BLOCK / 64];
-
-    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const uint32_t usb = (uint32_t)sb;
-    const uint32_t t0 = pos0 + blockIdx.x * TOK_TILE;
-    const uint32_t t1 = min(t0 + TOK_TILE, pos1);
-    const uint32_t wbase = (t0 > usb ? t0 - usb : 0u) & ~3u;
-#define LIST_START(c) ((c) > dbase ? ofs[(c) - dbase - 1] : 0u)
-#define LIST_END(c) ((c) >= dbase ? ofs[(c) - dbase] : 0u)
-    const uint32_t nb = (t1 + (uint32_t)la + 8 - wbase + 3) & ~3u;
-    for (uint32_t i = tid * 4; i < nb; i += TOK_BLOCK * 4)
-        *reinterpret_cast<uint32_t *>(by + i) = *reinterpret_cast<const uint32_t *>(in + wbase + i);
-    const uint32_t NO = t1 - wbase;
-    const uint32_t ebase = LIST_START(wbase);
-    const uint32_t ecount = LIST_END(t1 - 1) - ebase;
-    const bool staged = ecount <= ent_cap && ecount < 65536u;
-    if (staged) {
-        for (uint32_t i = tid; i <= NO; i += TOK_BLOCK) {
-            const uint32_t c = wbase + i;
-            lofs[i] = (uint16_t)(LIST_START(c) - ebase);
-        }
-        for (uint32_t e = tid; e < ecount; e += TOK_BLOCK) lent[e] = ent[ebase + e];
-    }
-    if (BUCKET)
-        for (uint32_t i = tid; i < TOK_HASH; i += TOK_BLOCK) bcur[i] = 0;
-    __syncthreads();
-    if (BUCKET) {
-        /* counting sort of the candidate positions by hash(first two bytes) */
-        for (uint32_t i = tid; i < NO; i += TOK_BLOCK) atomicAdd(&bcur[tok_hash(by[i], by[i + 1])], 1u);
-        __syncthreads();
-        {
-            static_assert(TOK_HASH == 2 * TOK_BLOCK, "two buckets per thread");
-            const uint32_t c0 = bcur[2 * tid], c1 = bcur[2 * tid + 1];
-            uint32_t incl = c0 + c1;
-#pragma unroll
-            for (int d = 1; d < 64; d <<= 1) {
-                const uint32_t t = __shfl_up(incl, d, 64);
-                if (lane >= (uint32_t)d) incl += t;
-            }
-            if (lane == 63) wsum[wave] = incl;
-            __syncthreads();
-            uint32_t woff = 0;
-            for (uint32_t w = 0; w < wave; w++) woff += wsum[w];
-            const uint32_t excl = woff + incl - (c0 + c1);
-            bstart[2 * tid] = excl;
-            bstart[2 * tid + 1] = excl + c0;
-            if (tid == TOK_BLOCK - 1) bstart[TOK_HASH] = excl + c0 + c1;
-        }
-        __syncthreads();
-        for (uint32_t i = tid; i < TOK_HASH; i += TOK_BLOCK) bcur[i] = bstart[i];
-        __syncthreads();
-        for (uint32_t i = tid; i < NO; i += TOK_BLOCK) blist[atomicAdd(&bcur[tok_hash(by[i], by[i + 1])], 1u)] = (uint16_t)i;
-        __syncthreads();
-    }
-
-    const uint32_t omask = ob >= 32 ? 0xFFFFFFFFu : (1u << ob) - 1u;
-    const uint32_t k0 = tstart[blockIdx.x], k1 = tstart[blockIdx.x + 1];
-    /* each wave takes tokens k0+wave, k0+wave+8, ...; their (position, length) are fetched 64 at a
-     * time, one per lane, so that the per-token loop never waits on global memory */
-    for (uint32_t kb = k0 + wave; kb < k1; kb += 64 * (TOK_BLOCK / 64)) {
-        const uint32_t kmine = kb + lane * (TOK_BLOCK / 64);
-        uint32_t p_l = 0, len_l = 0;
-        if (kmine < k1) { p_l = chain[kmine]; len_l = maxlen[p_l]; }
-        for (uint32_t j = 0; j < 64; j++) {
-            const uint32_t k = kb + j * (TOK_BLOCK / 64);
-            if (k >= k1) break;
-            const uint32_t p = __shfl(p_l, j, 64), len = __shfl(len_l, j, 64);
-            const uint32_t qo = p - wbase;
-            const uint32_t next = by[qo + len];
-            uint32_t off = 0;
-            if (len > 0) {
-                const uint32_t cmin = p > usb ? p - usb : 0u;
-                uint64_t best = ~0ull;
-                /* candidate c shares len bytes with p?  then its priority at time p */
-                auto consider = [&](uint32_t c) {
-                    const uint32_t co = c - wbase;
-                    for (uint32_t i = 0; i < len; i += 4) {
-                        uint32_t x = ld32_at<true>(by, co + i) ^ ld32_at<true>(by, qo + i);
-                        const uint32_t rem = len - i;
-                        if (rem < 4) x &= (1u << (8 * rem)) - 1u;
-                        if (x) return;
-                    }
-                    uint32_t prio = c, latest = 0;
-                    bool any = false;
-                    if (staged) {
-                        for (uint32_t e = lofs[co]; e < lofs[co + 1]; e++) {
-                            const uint2 t = lent[e];
-                            if ((uint64_t)t.x + usb < p && (!any || t.x > latest)) { any = true; latest = t.x; prio = t.y; }
-                        }
-                    } else {
-                        for (uint32_t e = LIST_START(c); e < LIST_END(c); e++) {
-                            const uint2 t = ent[e];
-                            if ((uint64_t)t.x + usb < p && (!any || t.x > latest)) { any = true; latest = t.x; prio = t.y; }
-                        }
-                    }
-                    const uint64_t key = ((uint64_t)prio << 32) | c;
-                    best = key < best ? key : best;
-                };
-                if (BUCKET && len >= 2) {
-                    const uint32_t h = tok_hash(by[qo], by[qo + 1]);
-                    const uint32_t e1 = bstart[h + 1];
-                    for (uint32_t i = bstart[h] + lane; i < e1; i += 64) {
-                        const uint32_t c = wbase + blist[i];
-                        if (c >= cmin && c < p) consider(c);
-                    }
-                } else {
-                    const uint32_t head = ld32_at<true>(by, qo);
-                    const uint32_t hmask = len >= 4 ? 0xFFFFFFFFu : (1u << (8 * len)) - 1u;
-                    for (uint32_t cg = (cmin & ~3u) + lane * 4; cg < p; cg += 256) {
-                        const uint8_t *r = by + (cg - wbase);
-                        const uint32_t lo = *reinterpret_cast<const uint32_t *>(r);
-                        const uint32_t hi = *reinterpret_cast<const uint32_t *>(r + 4);
-#pragma unroll
-                        for (int jj = 0; jj < 4; jj++) {
-                            const uint32_t c = cg + jj;
-                            const uint32_t w = jj == 0 ? lo : __builtin_amdgcn_alignbyte(hi, lo, jj);
-                            if (((w ^ head) & hmask) == 0 && c >= cmin && c < p) consider(c);
-                        }
-                    }
-                }
-#pragma unroll
-                for (int d = 32; d > 0; d >>= 1) {
-                    const uint64_t o = (uint64_t)__shfl_xor((unsigned long long)best, d, 64);
-                    best = o < best ? o : best;
-                }
-                off = p - (uint32_t)(best & 0xFFFFFFFFu);
-            }
-            if (lane == 0) tokval[k] = (off & omask) | (len << ob) | (next << (ob + lb));
-        }
-    }
-}
-
-#undef LIST_START
-#undef LIST_END
-
-/* ---- large windows (sb > 8192): the candidate index lives in global memory -------------------
- * Per tile of BIG_TT positions, every candidate position (tile + its SB look-back) is bucketed by
- * its first two bytes (exact 16-bit key, so a length-1 token reads the 256 adjacent buckets of its
- * first byte).  After the fill pass bucket k is blist[ (k ? bs[k-1] : 0) .. bs[k] ). ---- */
-#define BIG_TT 131072u
-#define BIG_KEYS 65536u
-
-__global__ __launch_bounds__(256) void k_bidx_count(const uint8_t *__restrict__ in, int sb, uint32_t pos0, uint32_t pos1,
-                                                    uint32_t *__restrict__ bs)
-{
-    const uint32_t tile = blockIdx.y;
-    const uint32_t t0 = pos0 + tile * BIG_TT, t1 = min(t0 + BIG_TT, pos1);
-    const uint32_t w0 = t0 > (uint32_t)sb ? t0 - (uint32_t)sb : 0u;
-    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
-    if (w0 + i >= t1) return;
-    const uint32_t c = w0 + i;
-    atomicAdd(&bs[(size_t)tile * BIG_KEYS + (((uint32_t)in[c] << 8) | in[c + 1])], 1u);
-}
-
-__global__ __launch_bounds__(1024) void k_bidx_scan(uint32_t *__restrict__ bs)
-{
-    __shared__ uint32_t wsum[16];
-    uint32_t *b = bs + (size_t)blockIdx.x * BIG_KEYS;
-    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    uint32_t v[64], tot = 0;
-#pragma unroll
-    for (int i = 0; i < 64; i += 4) {
-        const uint4 t = *reinterpret_cast<const uint4 *>(b + tid * 64 + i);
-        v[i] = t.x; v[i + 1] = t.y; v[i + 2] = t.z; v[i + 3] = t.w;
-        tot += t.x + t.y + t.z + t.w;
-    }
-    uint32_t incl = tot;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const uint32_t t = __shfl_up(incl, d, 64);
-        if (lane >= (uint32_t)d) incl += t;
-    }
-    if (lane == 63) wsum[wave] = incl;
-    __syncthreads();
-    uint32_t run = incl - tot;
-    for (uint32_t w = 0; w < wave; w++) run += wsum[w];
-#pragma unroll
-    for (int i = 0; i < 64; i++) { const uint32_t c = v[i]; v[i] = run; run += c; }
-#pragma unroll
-    for (int i = 0; i < 64; i += 4)
-        *reinterpret_cast<uint4 *>(b + tid * 64 + i) = make_uint4(v[i], v[i + 1], v[i + 2], v[i + 3]);
-}
-
-__global__ __launch_bounds__(256) void k_bidx_fill(const uint8_t *__restrict__ in, int sb, uint32_t pos0, uint32_t pos1,
-                                                   uint32_t *__restrict__ bs, uint32_t *__restrict__ blist, uint32_t span)
-{
-    const uint32_t tile = blockIdx.y;
-    const uint32_t t0 = pos0 + tile * BIG_TT, t1 = min(t0 + BIG_TT, pos1);
-    const uint32_t w0 = t0 > (uint32_t)sb ? t0 - (uint32_t)sb : 0u;
-    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
-    if (w0 + i >= t1) return;
-    const uint32_t c = w0 + i;
-    const uint32_t slot = atomicAdd(&bs[(size_t)tile * BIG_KEYS + (((uint32_t)in[c] << 8) | in[c + 1])], 1u);
-    blist[(size_t)tile * span + slot] = c;
-}
-
-__global__ __launch_bounds__(256) void k_tokens_big(const uint8_t *__restrict__ in, uint32_t n, int sb, int ob, int lb,
-                                                    const uint32_t *__restrict__ chain, uint32_t ntok,
-                                                    const uint8_t *__restrict__ maxlen,
-                                                    const uint32_t *__restrict__ ofs, const uint2 *__restrict__ ent, uint32_t dbase,
-                                                    uint32_t pos0, const uint32_t *__restrict__ bs, const uint32_t *__restrict__ blist,
-                                                    uint32_t span, uint32_t *__restrict__ tokval)
-{
-    const uint32_t lane = threadIdx.x & 63;
-    const uint32_t k = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    if (k >= ntok) return;
-    const uint32_t p = chain[k];
-    const uint32_t len = maxlen[p];
-    const uint32_t next = in[p + len];
-    uint32_t off = 0;
-    if (len > 0) {
-        const uint32_t tile = (p - pos0) / BIG_TT;
-        const uint32_t *b = bs + (size_t)tile * BIG_KEYS;
-        const uint32_t *list = blist + (size_t)tile * span;
-        const uint32_t klo = len >= 2 ? (((uint32_t)in[p] << 8) | in[p + 1]) : ((uint32_t)in[p] << 8);
-        const uint32_t khi = len >= 2 ? klo : (klo | 0xFFu);
-        const uint32_t i0 = klo ? b[klo - 1] : 0u, i1 = b[khi];
-        const uint32_t cmin = p > (uint32_t)sb ? p - (uint32_t)sb : 0u;
-        const uint8_t *q = in + p;
-        uint64_t best = ~0ull;
-        for (uint32_t i = i0 + lane; i < i1; i += 64) {
-            const uint32_t c = list[i];
-            if (c < cmin || c >= p) continue;
-            const uint8_t *r = in + c;
-            bool same = true;
-            for (uint32_t j = 0; j < len; j += 4) {
-                uint32_t x = ld32u(r + j) ^ ld32u(q + j);
-                const uint32_t rem = len - j;
-                if (rem < 4) x &= (1u << (8 * rem)) - 1u;
-                if (x) { same = false; break; }
-            }
-            if (!same) continue;
-            uint32_t prio = c, latest = 0;
-            bool any = false;
-            const uint32_t lo = c > dbase ? ofs[c - dbase - 1] : 0, hi = c >= dbase ? ofs[c - dbase] : 0;
-            for (uint32_t e = lo; e < hi; e++) {
-                const uint2 t = ent[e];
-                if ((uint64_t)t.x + (uint32_t)sb < p && (!any || t.x > latest)) { any = true; latest = t.x; prio = t.y; }
-            }
-            const uint64_t key = ((uint64_t)prio << 32) | c;
-            best = key < best ? key : best;
-        }
-#pragma unroll
-        for (int d = 32; d > 0; d >>= 1) {
-            const uint64_t o = (uint64_t)__shfl_xor((unsigned long long)best, d, 64);
-            best = o < best ? o : best;
-        }
-        off = p - (uint32_t)(best & 0xFFFFFFFFu);
-    }
-    if (lane == 0) {
-        const uint32_t omask = ob >= 32 ? 0xFFFFFFFFu : (1u << ob) - 1u;
-        tokval[k] = (off & omask) | (len << ob) | (next << (ob + lb));
-    }
-}
-
-/* bytes of the global candidate index for token positions spanning npos (0 when the LDS tile kernel applies) */
-size_t lz77k_tokens_index_bytes(const lz77x_geom &g, size_t npos)
-{
-    if (g.sb <= 8192) return 0;
-    const size_t ntiles = (npos + BIG_TT - 1) / BIG_TT;
-    return ntiles * ((size_t)BIG_KEYS + BIG_TT + (size_t)g.sb + 8) * sizeof(uint32_t) + 256;
-}
-
-size_t lz77k_tokens_tmp_bytes(uint32_t n) { return ((size_t)(n / TOK_TILE) + 8) * sizeof(uint32_t); }
-
-/* tokens d_chain[0..ntok) all lie in [pos0, pos1); the hand-over index covers dst >= dbase */
-hipError_t lz77k_tokens(const uint8_t *d_in, uint32_t n, const lz77x_geom &g, const uint32_t *d_chain, uint32_t ntok,
-                        const uint8_t *d_maxlen, const uint32_t *d_ofs, const uint2 *d_ent, uint32_t dbase,
-                        uint32_t pos0, uint32_t pos1, uint32_t *d_tokval, uint32_t *d_tstart, void *d_index, int variant,
-                        hipStream_t s)
-{
-    if (ntok == 0) return hipSuccess;
-    if (variant == 0 && g.sb > 8192 && d_index) {
-        const uint32_t ntiles = (pos1 - pos0 + BIG_TT - 1) / BIG_TT;
-        const uint32_t span = BIG_TT + (uint32_t)g.sb + 8;
-        uint32_t *bs = reinterpret_cast<uint32_t *>(d_index);
-        uint32_t *blist = bs + (size_t)ntiles * BIG_KEYS;
-        hipError_t e = hipMemsetAsync(bs, 0, (size_t)ntiles * BIG_KEYS * sizeof(uint32_t), s);
-        if (e != hipSuccess) return e;
-        const dim3 grid((span + 255) / 256, ntiles);
-        hipLaunchKernelGGL(k_bidx_count, grid, dim3(256), 0, s, d_in, g.sb, pos0, pos1, bs);
-        hipLaunchKernelGGL(k_bidx_scan, dim3(ntiles), dim3(1024), 0, s, bs);
-        hipLaunchKernelGGL(k_bidx_fill, grid, dim3(256), 0, s, d_in, g.sb, pos0, pos1, bs, blist, span);
-        hipLaunchKernelGGL(k_tokens_big, dim3((ntok + 3) / 4), dim3(256), 0, s, d_in, n, g.sb, g.ob, g.lb, d_chain, ntok, d_maxlen,
-                           d_ofs, d_ent, dbase, pos0, bs, blist, span, d_tokval);
-        return hipGetLastError();
-    }
-    if ((variant == 0 || variant == 2) && g.sb <= 8192 && d_tstart) {
-        const bool bucket = variant == 0;
-        const uint32_t ntiles = (pos1 - pos0 + TOK_TILE - 1) / TOK_TILE;
-        const uint32_t span = TOK_TILE + (uint32_t)g.sb + 16;
-        const uint32_t lofs_off = (span + (uint32_t)g.la + 16 + 15) & ~15u;
-        const uint32_t bkt_off = (lofs_off + 2 * (span + 2) + 15) & ~15u;
-        const uint32_t bkt_bytes = bucket ? ((TOK_HASH + 8) * 4 + TOK_HASH * 4 + 2 * span + 15) & ~15u : 0u;
-        const uint32_t lent_off = bkt_off + bkt_bytes;
-        const uint32_t budget = 78u * 1024u;                         /* two workgroups per CU */
-        uint32_t ent_cap = lent_off + 5 * span < budget ? (budget - lent_off) / 8 : span;
-        const size_t lds = (size_t)lent_off + (size_t)ent_cap * 8;
-        auto fn = bucket ? k_tokens_tile<true> : k_tokens_tile<false>;
-        if (lds > 48 * 1024) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            if (e != hipSuccess) return e;
-        }
-        hipLaunchKernelGGL(k_tok_bounds, dim3((ntok + 256) / 256), dim3(256), 0, s, d_chain, ntok, pos0, ntiles, d_tstart);
-        hipLaunchKernelGGL(fn, dim3(ntiles), dim3(TOK_BLOCK), lds, s, d_in, n, g.sb, g.la, g.ob, g.lb, d_chain,
-                           d_tstart, d_maxlen, d_ofs, d_ent, dbase, pos0, pos1, d_tokval, ent_cap, lofs_off, lent_off, bkt_off);
-        return hipGetLastError();
-    }
-    const uint32_t blocks = (ntok + 3) / 4;
-    hipLaunchKernelGGL(k_tokens, dim3(blocks), dim3(256), 0, s, d_in, n, g.sb, g.ob, g.lb, d_chain, ntok, d_maxlen, d_ofs, d_ent,
-                       dbase, d_tokval);
-    return hipGetLastError();
-}
-
-/* ------------------------------------------------------------------ k_pack ----------- */
-
-/* bitio.c:203-239 without the per-bit loop: token k occupies stream bits [32+kT, 32+(k+1)T);
- * stream bit b is bit (b & 31) of little-endian word b >> 5.  One thread assembles one word. */
-__global__ void k_pack(const uint32_t *__restrict__ tokval, uint64_t ntok, int sb, int la, int T,
-                       uint32_t *__restrict__ out, uint64_t nwords)
-{
-    const uint64_t w = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (w >= nwords) return;
-    if (w == 0) { out[0] = (uint32_t)sb | ((uint32_t)la << 16); return; }      /* lz77.c:74-75 */
-    const uint64_t b0 = 32 * (w - 1);                     /* first token-area bit of this word */
-    uint64_t k = b0 / (uint64_t)T;
-    uint32_t word = 0;
-    for (; k < ntok; k++) {
-        const int64_t sh = (int64_t)(k * (uint64_t)T) - (int64_t)b0;
-        if (sh >= 32) break;
-        const uint32_t v = tokval[k];
-        word |= sh >= 0 ? (v << sh) : (v >> (-sh));
-    }
-    out[w] = word;
-}
-
-hipError_t lz77k_pack(const uint32_t *d_tokval, uint64_t ntok, const lz77x_geom &g, uint32_t *d_out_words, uint64_t nwords, hipStream_t s)
-{
-    if (nwords == 0) return hipSuccess;
-    const uint32_t blocks = (uint32_t)((nwords + 255) / 256);
-    hipLaunchKernelGGL(k_pack, dim3(blocks), dim3(256), 0, s, d_tokval, ntok, g.sb, g.la, g.T, d_out_words, nwords);
-    return hipGetLastError();
-}
-
-/* ------------------------------------------------------------------ decode ----------- */
-
-/* lz77.c:260-283 + bitio.c:256-298: fixed-width tokens, so token k is simply bits [32+kT, ..) */
-__global__ void k_dec_parse(const uint8_t *__restrict__ z, uint32_t ntok, int ob, int lb, int T,
-                            uint32_t *__restrict__ tokval, uint32_t *__restrict__ len1)
-{
-    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= ntok) return;
-    const uint64_t bit = 32 + (uint64_t)k * (uint64_t)T;
-    uint64_t v = ld64u(z + (bit >> 3)) >> (bit & 7);
-    v &= T >= 32 ? 0xFFFFFFFFull : ((1ull << T) - 1);
-    tokval[k] = (uint32_t)v;
-    len1[k] = (((uint32_t)v >> ob) & ((1u << lb) - 1u)) + 1u;
-}
-
-/* lz77.c:178-194 as data flow: every copied byte j points at j-off, every literal at itself.
- * Position n is a zero byte that degenerate tokens (off==0 or off>j) point at. */
-__global__ void k_dec_expand(const uint32_t *__restrict__ tokval, const uint32_t *__restrict__ dst, uint32_t ntok,
-                             int ob, int lb, uint8_t *__restrict__ out, uint32_t *__restrict__ ptr, uint32_t n)
-{
-    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k == 0) { out[n] = 0; ptr[n] = n; }
-    if (k >= ntok) return;
-    const uint32_t v = tokval[k];
-    const uint32_t off = ob ? (v & ((1u << ob) - 1u)) : 0;
-    const uint32_t len = (v >> ob) & ((1u << lb) - 1u);
-    const uint32_t lit = (v >> (ob + lb)) & 0xFFu;
-    const uint32_t j0 = dst[k];
-    for (uint32_t i = 0; i < len; i++) {
-        const uint32_t j = j0 + i;
-        ptr[j] = (off > 0 && off <= j) ? j - off : n;
-    }
-    out[j0 + len] = (uint8_t)lit;
-    ptr[j0 + len] = j0 + len;
-}
-
-/* pointer doubling: ptr[j] <- ptr[ptr[j]] until every byte points at a literal (<= log2(depth) rounds) */
-__global__ void k_dec_jump(uint32_t *__restrict__ ptr, uint32_t n, uint32_t *__restrict__ changed)
-{
-    bool any = false;
-    for (uint32_t j = blockIdx.x * blockDim.x + threadIdx.x; j < n; j += gridDim.x * blockDim.x) {
-        const uint32_t p = ptr[j];
-        if (p == j) continue;
-        const uint32_t q = ptr[p];
-        if (q != p) { ptr[j] = q; any = true; }
-    }
-    if (any) *changed = 1;
-}
-
-__global__ void k_dec_gather(uint8_t *__restrict__ out, const uint32_t *__restrict__ ptr, uint32_t n)
-{
-    for (uint32_t j = blockIdx.x * blockDim.x + threadIdx.x; j < n; j += gridDim.x * blockDim.x) {
-        const uint32_t p = ptr[j];
-        if (p != j) out[j] = out[p];
-    }
-}
-
-hipError_t lz77k_dec_parse(const uint8_t *d_z, uint32_t ntok, const lz77x_geom &g, uint32_t *d_tokval, uint32_t *d_len1, hipStream_t s)
-{
-    if (ntok == 0) return hipSuccess;
-    hipLaunchKernelGGL(k_dec_parse, dim3((ntok + 255) / 256), dim3(256), 0, s, d_z, ntok, g.ob, g.lb, g.T, d_tokval, d_len1);
-    return hipGetLastError();
-}
-
-hipError_t lz77k_dec_expand(const uint32_t *d_tokval, const uint32_t *d_dst, uint32_t ntok, const lz77x_geom &g,
-                            uint8_t *d_out, uint32_t *d_ptr, uint32_t n, hipStream_t s)
-{
-    hipLaunchKernelGGL(k_dec_expand, dim3(ntok ? (ntok + 255) / 256 : 1), dim3(256), 0, s, d_tokval, d_dst, ntok, g.ob, g.lb, d_out, d_ptr, n);
-    return hipGetLastError();
-}
-
-hipError_t lz77k_dec_jump(uint32_t *d_ptr, uint32_t n, uint32_t *d_changed, hipStream_t s)
-{
-    if (n == 0) return hipSuccess;
-    const uint32_t blocks = min((n + 255u) / 256u, 256u * 32u);
-    hipLaunchKernelGGL(k_dec_jump, dim3(blocks), dim3(256), 0, s, d_ptr, n, d_changed);
-    return hipGetLastError();
-}
-
-hipError_t lz77k_dec_gather(uint8_t *d_out, const uint32_t *d_ptr, uint32_t n, hipStream_t s)
-{
-    if (n == 0) return hipSuccess;
-    const uint32_t blocks = min((n + 255u) / 256u, 256u * 32u);
-    hipLaunchKernelGGL(k_dec_gather, dim3(blocks), dim3(256), 0, s, d_out, d_ptr, n);
-    return hipGetLastError();
-}

@@ -1,0 +1,114 @@
+/*
+ * k_util.hip -- small device utilities: input padding, ring-cell packing for the host recurrence,
+ * exclusive scan.
+ */
+#include "kernels_common.h"
+
+/* ------------------------------------------------------------------ small utilities -- */
+
+__global__ void k_fill_pad(uint8_t *in, uint32_t n)
+{
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < LZ77X_PAD) in[(size_t)n + i] = 0xFF;
+}
+
+__global__ void k_ps_cells(const uint32_t *__restrict__ ps, uint32_t *__restrict__ cells, uint32_t x0, uint32_t x1, uint32_t mask)
+{
+    for (uint32_t x = x0 + blockIdx.x * blockDim.x + threadIdx.x; x < x1; x += gridDim.x * blockDim.x) {
+        const uint32_t v = ps[x];
+        cells[x] = ((x + (v & 0xFFFFu)) & mask) | (((x + (v >> 16)) & mask) << 16);
+    }
+}
+
+hipError_t lz77k_ps_cells(const uint32_t *d_ps, uint32_t *d_cells, uint32_t x0, uint32_t x1, uint32_t mask, hipStream_t s)
+{
+    if (x1 <= x0) return hipSuccess;
+    const uint32_t blocks = min((x1 - x0 + 255u) / 256u, 256u * 16u);
+    hipLaunchKernelGGL(k_ps_cells, dim3(blocks), dim3(256), 0, s, d_ps, d_cells, x0, x1, mask);
+    return hipGetLastError();
+}
+
+hipError_t lz77k_fill_pad(uint8_t *d_in, uint32_t n, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_fill_pad, dim3((LZ77X_PAD + 255) / 256), dim3(256), 0, s, d_in, n);
+    return hipGetLastError();
+}
+
+/* ---- exclusive scan (uint32), 3 phases, recursive on block sums ---- */
+
+#define SCAN_THREADS 256
+#define SCAN_ITEMS 8
+#define SCAN_CHUNK (SCAN_THREADS * SCAN_ITEMS)
+
+__global__ __launch_bounds__(SCAN_THREADS) void k_scan_local(const uint32_t *in, uint32_t *out,   /* may alias */
+                                                             uint32_t m, uint32_t *sums)
+{
+    __shared__ uint32_t wsum[SCAN_THREADS / 64];
+    const uint32_t base = blockIdx.x * SCAN_CHUNK + threadIdx.x * SCAN_ITEMS;
+    uint32_t v[SCAN_ITEMS], tot = 0;
+#pragma unroll
+    for (int i = 0; i < SCAN_ITEMS; i++) {
+        v[i] = base + i < m ? in[base + i] : 0;
+        tot += v[i];
+    }
+    /* inclusive scan of tot across the wave, then across the 4 waves */
+    uint32_t incl = tot;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        uint32_t t = __shfl_up(incl, d, 64);
+        if (lane >= d) incl += t;
+    }
+    if (lane == 63) wsum[wave] = incl;
+    __syncthreads();
+    uint32_t woff = 0, btot = 0;
+#pragma unroll
+    for (int w = 0; w < SCAN_THREADS / 64; w++) {
+        if (w < wave) woff += wsum[w];
+        btot += wsum[w];
+    }
+    uint32_t run = woff + incl - tot;
+#pragma unroll
+    for (int i = 0; i < SCAN_ITEMS; i++) {
+        if (base + i < m) out[base + i] = run;
+        run += v[i];
+    }
+    if (threadIdx.x == 0 && sums) sums[blockIdx.x] = btot;
+}
+
+__global__ __launch_bounds__(SCAN_THREADS) void k_scan_add(uint32_t *__restrict__ out, uint32_t m, const uint32_t *__restrict__ offs)
+{
+    const uint32_t add = offs[blockIdx.x];
+    const uint32_t base = blockIdx.x * SCAN_CHUNK + threadIdx.x * SCAN_ITEMS;
+#pragma unroll
+    for (int i = 0; i < SCAN_ITEMS; i++)
+        if (base + i < m) out[base + i] += add;
+}
+
+size_t lz77k_scan_tmp_bytes(uint32_t m)
+{
+    size_t total = 0;
+    uint64_t cur = m;
+    while (cur > SCAN_CHUNK) {
+        cur = (cur + SCAN_CHUNK - 1) / SCAN_CHUNK;
+        total += (cur + 64) * sizeof(uint32_t);
+    }
+    return total + 256;
+}
+
+hipError_t lz77k_scan_u32(const uint32_t *d_in, uint32_t *d_out, uint32_t m, void *d_tmp, hipStream_t s)
+{
+    if (m == 0) return hipSuccess;
+    const uint32_t blocks = (uint32_t)(((uint64_t)m + SCAN_CHUNK - 1) / SCAN_CHUNK);
+    if (blocks == 1) {
+        hipLaunchKernelGGL(k_scan_local, dim3(1), dim3(SCAN_THREADS), 0, s, d_in, d_out, m, (uint32_t *)nullptr);
+        return hipGetLastError();
+    }
+    uint32_t *sums = reinterpret_cast<uint32_t *>(d_tmp);
+    hipLaunchKernelGGL(k_scan_local, dim3(blocks), dim3(SCAN_THREADS), 0, s, d_in, d_out, m, sums);
+    hipError_t e = lz77k_scan_u32(sums, sums, blocks, sums + blocks + 64, s);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k_scan_add, dim3(blocks), dim3(SCAN_THREADS), 0, s, d_out, m, sums);
+    return hipGetLastError();
+}
+

@@ -1,5 +1,5 @@
 /*
- * lz77x_internal.h -- shared between the HIP translation unit (kernels.hip), the
+ * lz77x_internal.h -- shared between the HIP translation units (k_*.hip), the
  * host pipeline (pipeline.cpp) and the sequential host stage (hoststage.c).
  * Not part of the public ABI (that is include/lz77_mi355x.h).
  */
@@ -65,7 +65,7 @@ void lz77x_prio_run(lz77x_prio_state *st, const uint32_t *ps, int sb, size_t upt
 #ifdef __cplusplus
 #include <hip/hip_runtime_api.h>
 
-/* ---- kernel launchers (kernels.hip).  All enqueue on `s` and return immediately. ----- */
+/* ---- kernel launchers (k_match.hip, k_tokens.hip, k_decode.hip, k_util.hip).  All enqueue on `s` and return immediately. ----- */
 
 size_t lz77k_match_scratch_bytes(const lz77x_geom &g, uint32_t nregions);
 size_t lz77k_match_lds_bytes(const lz77x_geom &g);
