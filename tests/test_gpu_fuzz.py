@@ -1,0 +1,93 @@
+"""Randomised GPU parity: many small (geometry, input) pairs against the oracle's BST encoder.
+
+Exercises every kernel path the geometry can select: LDS sort with RP 4096 / 8192 / 16384 (blocked),
+global sort with and without chunking, LDS and global-bitmap walkers, all three token kernels,
+byte-aligned and odd token widths, inputs shorter than the lookahead, power-of-two -s (offset
+truncation) and degenerate alphabets.
+"""
+import random
+
+import numpy as np
+import pytest
+
+import lz77_amd as L
+import oracle_lib as O
+
+pytestmark = pytest.mark.gpu
+
+
+def _cases(seed, count):
+    rng = random.Random(seed)
+    out = []
+    for _ in range(count):
+        sb = rng.choice([1, 2, 3, 5, 8, 16, 31, 64, 100, 255, 256, 511, 1000, 1024, 1025, 2047, 2048, 2049,
+                         4095, 4096, 4097, 8191, 8192, 8193, 12000, 20000, 65535])
+        la = rng.choice([2, 3, 4, 5, 7, 8, 15, 16, 17, 31, 32, 33, 64, 100, 255])
+        hi = min(6 * sb + 3 * la + 50, 60000) if sb < 4000 else rng.choice([sb // 2, sb + la + 7, 3 * sb + 11, 70000])
+        n = rng.randint(0, max(hi, 1))
+        alpha = rng.choice([1, 2, 3, 4, 16, 64, 256])
+        mode = rng.choice(["iid", "runs", "copy"])
+        out.append((sb, la, n, alpha, mode, rng.randrange(1 << 30)))
+    return out
+
+
+def _make(n, alpha, mode, seed):
+    rng = np.random.default_rng(seed)
+    if mode == "iid" or n < 8:
+        return rng.integers(0, alpha, n, dtype=np.uint8)
+    if mode == "runs":
+        vals = rng.integers(0, alpha, n // 3 + 1, dtype=np.uint8)
+        lens = rng.integers(1, 9, n // 3 + 1)
+        return np.repeat(vals, lens)[:n].copy()
+    base = rng.integers(0, alpha, n, dtype=np.uint8)          # self-copies at random distances
+    for _ in range(max(n // 200, 1)):
+        ln = int(rng.integers(4, 300))
+        src = int(rng.integers(0, max(n - ln, 1)))
+        dst = int(rng.integers(0, max(n - ln, 1)))
+        base[dst:dst + ln] = base[src:src + ln].copy()[: len(base[dst:dst + ln])]
+    return base
+
+
+@pytest.mark.parametrize("seed", [11, 22, 33, 44])
+def test_fuzz_encode_decode(seed):
+    for sb, la, n, alpha, mode, s in _cases(seed, 60):
+        data = _make(n, alpha, mode, s)
+        want = O.encode_bst(data, sb, la)
+        got = L.encode(data, la, sb)
+        assert got == want, (sb, la, n, alpha, mode, s)
+        if sb & (sb - 1):
+            assert L.decode(want) == data.tobytes(), (sb, la, n, alpha, mode, s)
+        else:
+            assert len(L.decode(want)) == n
+
+
+def test_fuzz_decode_foreign_streams():
+    """random legal token streams (not produced by any greedy encoder): decoder == oracle decoder"""
+    rng = np.random.default_rng(5)
+    for _ in range(40):
+        sb = int(rng.choice([7, 255, 1000, 4095, 65535]))
+        la = int(rng.choice([3, 7, 10, 15, 255]))
+        ob, lb = O.bitof(sb), O.bitof(la)
+        T = ob + lb + 8
+        ntok = int(rng.integers(1, 3000))
+        bits = []
+        pos = 0
+        acc = 0
+        nacc = 0
+        out = bytearray([sb & 255, sb >> 8, la & 255, la >> 8])
+        for _k in range(ntok):
+            ln = int(rng.integers(0, min(la, 1 << lb))) if pos > 0 else 0
+            off = int(rng.integers(1, min(pos, sb) + 1)) if ln else 0
+            lit = int(rng.integers(0, 256))
+            v = off | (ln << ob) | (lit << (ob + lb))
+            acc |= v << nacc
+            nacc += T
+            while nacc >= 8:
+                out.append(acc & 255)
+                acc >>= 8
+                nacc -= 8
+            pos += ln + 1
+        if nacc:
+            out.append(acc & 255)
+        z = bytes(out)
+        assert L.decode(z) == O.decode(z), (sb, la, ntok)
