@@ -94,6 +94,28 @@ void lz77x_prio_run(lz77x_prio_state *st, const uint32_t *restrict ps, int sb, s
     /* branch-free on purpose: `go` is taken ~2/3 of the time with no pattern, a compiled branch here
      * mispredicts every third position.  ps[x] holds the ring cells ((x+P)&mask, (x+S)&mask) of x's
      * neighbours; a missing neighbour has distance 0, i.e. x's own cell, and mine < mine is false. */
+    /* go <=> mine < min(pp, sp).  On x86-64 the two selects are written as cmp/cmov by hand: the
+     * compiler's own if-conversion either branches (mispredicting every third step) or spends
+     * twice the instructions on mask arithmetic, and this loop runs at the core's issue limit. */
+#if defined(__x86_64__) && defined(__GNUC__)
+#define LZ77X_SELECT(mine, pp, sp, ns, xv)                                              \
+    do {                                                                                \
+        uint32_t mn_ = (pp);                                                            \
+        (ns) = (sp);                                                                    \
+        (xv) = LZ77X_NONE32;                                                            \
+        __asm__("cmpl %[s], %[m]\n\tcmoval %[s], %[m]" : [m] "+r"(mn_) : [s] "r"(sp) : "cc"); \
+        __asm__("cmpl %[m], %[i]\n\tcmovbl %[i], %[n]\n\tcmovbl %[i], %[x]"             \
+                : [n] "+r"(ns), [x] "+r"(xv) : [m] "r"(mn_), [i] "r"(mine) : "cc");     \
+    } while (0)
+#else
+#define LZ77X_SELECT(mine, pp, sp, ns, xv)                                              \
+    do {                                                                                \
+        const uint64_t lt_ = ((uint64_t)(mine) - (uint64_t)(pp)) & ((uint64_t)(mine) - (uint64_t)(sp)); \
+        const uint32_t m_ = (uint32_t)((int64_t)lt_ >> 63);      /* all ones iff mine < pp && mine < sp */ \
+        (ns) = (sp) ^ (((sp) ^ (mine)) & m_);                                           \
+        (xv) = (mine) | ~m_;                                                            \
+    } while (0)
+#endif
 #define LZ77X_PRIO_STEP(T)                                                              \
     do {                                                                                \
         const uint32_t v = ps[(T) - usb];      /* ring cells of P and S, packed by k_ps_cells */ \
@@ -101,10 +123,10 @@ void lz77x_prio_run(lz77x_prio_state *st, const uint32_t *restrict ps, int sb, s
         const uint32_t mine = ring[(uint32_t)((T) - usb) & mask];                       \
         const uint32_t pp = ring[v & 0xFFFFu];                                          \
         const uint32_t sp = ring[sidx];                                                 \
-        const uint64_t lt = ((uint64_t)mine - (uint64_t)pp) & ((uint64_t)mine - (uint64_t)sp); \
-        const uint32_t m = (uint32_t)((int64_t)lt >> 63);          /* all ones iff mine < pp && mine < sp */ \
-        ring[sidx] = sp ^ ((sp ^ mine) & m);                                            \
-        LZ77X_STREAM_STORE(&xval[(T) - usb], mine | ~m);           /* LZ77X_NONE32 when nothing moves */ \
+        uint32_t ns, xv;                                                                \
+        LZ77X_SELECT(mine, pp, sp, ns, xv);                                             \
+        ring[sidx] = ns;                                                                \
+        LZ77X_STREAM_STORE(&xval[(T) - usb], xv);                  /* LZ77X_NONE32 when nothing moves */ \
         ring[(uint32_t)(T) & mask] = (uint32_t)(T);                                     \
     } while (0)
     for (; t + 2 <= upto; t += 2) {
@@ -113,6 +135,7 @@ void lz77x_prio_run(lz77x_prio_state *st, const uint32_t *restrict ps, int sb, s
     }
     for (; t < upto; t++) LZ77X_PRIO_STEP(t);
 #undef LZ77X_PRIO_STEP
+#undef LZ77X_SELECT
     LZ77X_STREAM_FENCE();
     st->next = t;
 }
