@@ -40,6 +40,17 @@ int g_shards = 0;
         }                                                                                      \
     } while (0)
 
+/* LZ77X_TRACE=1: phase timestamps on stderr (opt-in; the default run prints nothing) */
+bool trace_on()
+{
+    static int on = -1;
+    if (on < 0) { const char *e = getenv("LZ77X_TRACE"); on = e && atoi(e) ? 1 : 0; }
+    return on == 1;
+}
+#define TRACE(label, t0)                                                                  \
+    do { if (trace_on()) fprintf(stderr, "[lz77x] %-28s %8.2f ms\n", label, now_ms() - (t0)); } while (0)
+
+double now_ms();
 double now_ms()
 {
     using namespace std::chrono;
@@ -172,6 +183,7 @@ int encode_core(std::vector<Ctx *> &cs, const void *src, bool src_on_device, siz
     double waited = 0;
     auto kstream = [&](uint32_t d) { return d == 0 ? s : cs[d]->stream; };
 
+    TRACE("encode_core entry", t_begin);
     for (uint32_t d = 0; d < D; d++) {
         Ctx &c = *cs[d];
         HIPCHK(hipSetDevice(c.device));
@@ -187,10 +199,12 @@ int encode_core(std::vector<Ctx *> &cs, const void *src, bool src_on_device, siz
     std::vector<uint32_t> owner;
     if (n) {
         const size_t nx = n > (size_t)g.sb ? n - (size_t)g.sb : 0;     /* evicted positions */
+        const double t_pin = now_ms();
         if ((rc = c0.h_ps.need((n + 8) * 4))) return rc;
         if ((rc = c0.h_maxlen.need(n + 8))) return rc;
         if ((rc = c0.h_xval.need((n + 8) * 4))) return rc;
         if ((rc = c0.h_chain.need((n + 8) * 4))) return rc;
+        TRACE("pinned host buffers", t_pin);
 
         const uint32_t ring_mask = lz77x_prio_mask(g.sb);
         const uint32_t nregions = (uint32_t)((n + g.TILE - 1) / g.TILE);
@@ -303,6 +317,7 @@ int encode_core(std::vector<Ctx *> &cs, const void *src, bool src_on_device, siz
             if (d == 0) HIPCHK(hipEventRecord(c.ev[1], kstream(d)));
         }
         HIPCHK(hipSetDevice(c0.device));
+        TRACE("allocs + match enqueue", t_begin);
 
         lz77x_prio_state st;
         if (!lz77x_prio_init(&st, g.sb)) return LZ77X_E_NOMEM;
@@ -631,17 +646,23 @@ int lz77x_encode(const uint8_t *in, size_t n, int sb, int la, uint8_t **out, siz
     int rc = check_geom(sb, la);
     if (rc) return rc;
     std::lock_guard<std::mutex> lk(g_mu);
+    const double t0 = now_ms();
     std::vector<Ctx *> cs;
     int shards = g_shards;
     if (shards <= 0) { const char *e = getenv("LZ77X_SHARDS"); shards = e ? atoi(e) : 1; }
     if ((rc = shard_contexts(shards < 1 ? 1 : shards, cs))) return rc;
+    TRACE("runtime + context init", t0);
     lz77x_geom g;
     lz77x_make_geom(&g, sb, la);
     size_t zn = 0;
+    const double t1 = now_ms();
     if ((rc = encode_core(cs, in, false, n, g, g_ctx.stream, &zn))) return rc;
+    TRACE("encode_core (incl. allocs)", t1);
+    const double t2 = now_ms();
     uint8_t *buf = (uint8_t *)malloc(zn ? zn : 1);
     if (!buf) return LZ77X_E_NOMEM;
     if ((rc = fetch_result(g_ctx, buf, g_ctx.out.p, zn))) { free(buf); return rc; }
+    TRACE("fetch result", t2);
     *out = buf;
     *out_n = zn;
     return LZ77X_OK;
