@@ -92,10 +92,12 @@ struct Ctx {
     int ndev = 0;
     int device = 0;                          /* physical HIP device this context lives on */
     hipStream_t stream = nullptr;            /* used when the caller passes none (host-level API) */
-    hipStream_t copy = nullptr;              /* D2H/H2D of intermediates, overlapped with kernels */
+    hipStream_t copy = nullptr;              /* device->host copies of intermediates, overlapped with kernels */
+    hipStream_t up = nullptr;                /* host->device copies (own stream: never queued behind a D2H that
+                                                still waits for a later match launch) */
     hipStream_t tok = nullptr;               /* per-chunk index + tie-break + pack kernels */
     hipEvent_t ev[6] = {};
-    std::vector<hipEvent_t> chunk_ev, tok_ev, sort_ev;
+    std::vector<hipEvent_t> chunk_ev, tok_ev, sort_ev, match_ev;
     DevBuf in, ps, maxlen, scratch, xval, chain, ofs, ent, tokval, out, scantmp;
     DevBuf z, len1, dst, ptr, flag, tstart, bidx, cells;
     PinBuf h_ps, h_maxlen, h_xval, h_chain, h_small, h_tok, h_stage;
@@ -120,6 +122,7 @@ int ctx_init(Ctx &c, int device = -1)
     HIPCHK(hipSetDevice(device));
     HIPCHK(hipStreamCreateWithFlags(&c.stream, hipStreamNonBlocking));
     HIPCHK(hipStreamCreateWithFlags(&c.copy, hipStreamNonBlocking));
+    HIPCHK(hipStreamCreateWithFlags(&c.up, hipStreamNonBlocking));
     HIPCHK(hipStreamCreateWithFlags(&c.tok, hipStreamNonBlocking));
     for (auto &ev : c.ev) HIPCHK(hipEventCreate(&ev));
     c.ready = true;
@@ -193,19 +196,12 @@ int encode_core(std::vector<Ctx *> &cs, const void *src, bool src_on_device, siz
     }
     HIPCHK(hipSetDevice(c0.device));
 
-    uint32_t ntok = 0, nchunks_done = 0;
+    uint32_t ntok = 0, nchunks_done = 0, launches0_total = 0;
     uint64_t transfers = 0;
     bool sort_timed = false;
     std::vector<uint32_t> owner;
     if (n) {
         const size_t nx = n > (size_t)g.sb ? n - (size_t)g.sb : 0;     /* evicted positions */
-        const double t_pin = now_ms();
-        if ((rc = c0.h_ps.need((n + 8) * 4))) return rc;
-        if ((rc = c0.h_maxlen.need(n + 8))) return rc;
-        if ((rc = c0.h_xval.need((n + 8) * 4))) return rc;
-        if ((rc = c0.h_chain.need((n + 8) * 4))) return rc;
-        TRACE("pinned host buffers", t_pin);
-
         const uint32_t ring_mask = lz77x_prio_mask(g.sb);
         const uint32_t nregions = (uint32_t)((n + g.TILE - 1) / g.TILE);
         /* host chunk: >= 512 regions (~4M positions on the LDS path); match launch: a group of chunks
@@ -246,6 +242,40 @@ int encode_core(std::vector<Ctx *> &cs, const void *src, bool src_on_device, siz
         const bool serial = sv && atoi(sv);                    /* the match launches, no overlap */
         auto tstream = [&](uint32_t d) { return serial ? kstream(d) : cs[d]->tok; };
 
+        /* Pinned host memory is a set of rings of chunk-sized slots, not n-sized arrays (SURVEY 8f-2:
+         * host RAM must not scale with the input several times over): K slots receive {cells, maxlen}
+         * from the devices, K2 slots carry {xval, chain} back.  A slot is recycled once the chunk
+         * AFTER it has been consumed (both recurrences look sb positions back into the previous chunk;
+         * chunk_pos >= 2*sb by construction of TILE). */
+        uint32_t K = 32, K2 = 4;
+        const char *rs = getenv("LZ77X_RING_SLOTS");
+        if (rs && atoi(rs) > 0) K = (uint32_t)atoi(rs);
+        if (K < group + 2) K = group + 2;                      /* the group being filled + the two chunks in use */
+        if (K > nchunks) K = nchunks;
+        if (K2 > nchunks) K2 = nchunks;
+        const bool ring_d2h = K < nchunks, ring_h2d = K2 < nchunks;
+        {
+            const double t_pin = now_ms();
+            if ((rc = c0.h_ps.need(((size_t)K * chunk_pos + 8) * 4))) return rc;
+            if ((rc = c0.h_maxlen.need((size_t)K * chunk_pos + 8))) return rc;
+            if ((rc = c0.h_xval.need(((size_t)K2 * chunk_pos + 8) * 4))) return rc;
+            if ((rc = c0.h_chain.need(((size_t)K2 * chunk_pos + 8) * 4))) return rc;
+            TRACE("pinned host buffers", t_pin);
+        }
+        auto chunk_b = [&](uint32_t ci) { return (size_t)ci * chunk_pos; };
+        auto chunk_e = [&](uint32_t ci) { const size_t e = (size_t)(ci + 1) * chunk_pos; return e < n ? e : n; };
+        /* slot of chunk ci, and the same pointer rebased so that it can be indexed by absolute position */
+        auto ps_slot = [&](uint32_t ci) { return c0.h_ps.as<uint32_t>() + (size_t)(ci % K) * chunk_pos; };
+        auto ml_slot = [&](uint32_t ci) { return c0.h_maxlen.as<uint8_t>() + (size_t)(ci % K) * chunk_pos; };
+        auto xv_slot = [&](uint32_t ci) { return c0.h_xval.as<uint32_t>() + (size_t)(ci % K2) * chunk_pos; };
+        auto ch_slot = [&](uint32_t ci) { return c0.h_chain.as<uint32_t>() + (size_t)(ci % K2) * chunk_pos; };
+        auto rebase32 = [&](uint32_t *slot, uint32_t ci) {
+            return reinterpret_cast<uint32_t *>(reinterpret_cast<uintptr_t>(slot) - chunk_b(ci) * sizeof(uint32_t));
+        };
+        auto rebase8 = [&](uint8_t *slot, uint32_t ci) {
+            return reinterpret_cast<uint8_t *>(reinterpret_cast<uintptr_t>(slot) - chunk_b(ci));
+        };
+
         for (uint32_t d = 0; d < D; d++) {
             Ctx &c = *cs[d];
             HIPCHK(hipSetDevice(c.device));
@@ -276,48 +306,60 @@ int encode_core(std::vector<Ctx *> &cs, const void *src, bool src_on_device, siz
                 c.tok_ev.push_back(e);
                 HIPCHK(hipEventCreate(&e));                                    /* region-sort kernel time */
                 c.sort_ev.push_back(e);
+                HIPCHK(hipEventCreate(&e));                                    /* whole match group time */
+                c.match_ev.push_back(e);
             }
+        }
+        HIPCHK(hipSetDevice(c0.device));
 
-            /* -- enqueue this shard's match launches and their D2H up front.  Launches cover groups
-             *    of host chunks (the window walkers want >= 256 wavefronts per launch); the first
-             *    groups are small (1, 2, 4 chunks) so that the host stage can start early. -- */
-            if (d == 0) HIPCHK(hipEventRecord(c.ev[0], kstream(d)));
-            uint32_t ramp = d == 0 ? 1u : group;        /* 1, 2, 4, ... chunks: each group retires just before the host needs it */
+        /* -- match launches cover groups of host chunks (the window walkers want >= 256 wavefronts per
+         *    launch); the first groups are small (1, 2, 4 chunks) so that the host stage can start early.
+         *    Groups are enqueued in stream order as ring slots become free. -- */
+        struct Group { uint32_t d, ci, nchunks; };
+        std::vector<Group> groups;
+        for (uint32_t d = 0; d < D; d++) {
+            uint32_t ramp = d == 0 ? 1u : group;
             for (uint32_t ci = first_chunk[d]; ci < first_chunk[d + 1];) {
                 uint32_t gchunks = ramp < group ? ramp : group;
                 ramp = ramp < group ? ramp * 2 : group;
                 if (ci + gchunks > first_chunk[d + 1]) gchunks = first_chunk[d + 1] - ci;
-                const uint32_t r0 = ci * per_chunk;
-                uint32_t nr = gchunks * per_chunk;
-                if (nr > nregions - r0) nr = nregions - r0;
-                HIPCHK(lz77k_match(c.in.as<uint8_t>(), n32, g, r0, nr, c.ps.as<uint32_t>(), c.maxlen.as<uint8_t>(),
-                                   c.scratch.p, variant, kstream(d), d == 0 ? &c.sort_ev[2 * g_stats.match_launches] : nullptr));
-                if (d == 0) sort_timed = g.fast && variant == 0;
-                g_stats.match_launches++;
-                {
-                    const size_t gb = (size_t)r0 * g.TILE;
-                    size_t ge = (size_t)(r0 + nr) * g.TILE;
-                    if (ge > nx) ge = nx;
-                    if (ge > gb) HIPCHK(lz77k_ps_cells(c.ps.as<uint32_t>(), c.cells.as<uint32_t>(), (uint32_t)gb, (uint32_t)ge, ring_mask, kstream(d)));
-                }
-                HIPCHK(hipEventRecord(c.chunk_ev[3 * ci], kstream(d)));
-                HIPCHK(hipStreamWaitEvent(c.copy, c.chunk_ev[3 * ci], 0));
-                for (uint32_t cj = ci; cj < ci + gchunks; cj++) {
-                    const size_t b = (size_t)cj * per_chunk * g.TILE;
-                    size_t e = (size_t)(cj + 1) * per_chunk * g.TILE;
-                    if (e > n) e = n;
-                    HIPCHK(hipMemcpyAsync(c0.h_maxlen.as<uint8_t>() + b, c.maxlen.as<uint8_t>() + b, e - b, hipMemcpyDeviceToHost, c.copy));
-                    const size_t pe = e < nx ? e : nx;
-                    if (pe > b)
-                        HIPCHK(hipMemcpyAsync(c0.h_ps.as<uint32_t>() + b, c.cells.as<uint32_t>() + b, (pe - b) * 4, hipMemcpyDeviceToHost, c.copy));
-                    HIPCHK(hipEventRecord(c.chunk_ev[3 * cj + 1], c.copy));
-                }
+                groups.push_back({d, ci, gchunks});
                 ci += gchunks;
             }
-            if (d == 0) HIPCHK(hipEventRecord(c.ev[1], kstream(d)));
         }
-        HIPCHK(hipSetDevice(c0.device));
-        TRACE("allocs + match enqueue", t_begin);
+        uint32_t launches0 = 0;                                /* match launches on the first device (timed) */
+        auto enqueue_group = [&](const Group &G) -> int {
+            Ctx &c = *cs[G.d];
+            HIPCHK(hipSetDevice(c.device));
+            const uint32_t r0 = G.ci * per_chunk;
+            uint32_t nr = G.nchunks * per_chunk;
+            if (nr > nregions - r0) nr = nregions - r0;
+            if (G.d == 0) HIPCHK(hipEventRecord(c.match_ev[2 * launches0], kstream(G.d)));
+            HIPCHK(lz77k_match(c.in.as<uint8_t>(), n32, g, r0, nr, c.ps.as<uint32_t>(), c.maxlen.as<uint8_t>(),
+                               c.scratch.p, variant, kstream(G.d), G.d == 0 ? &c.sort_ev[2 * launches0] : nullptr));
+            g_stats.match_launches++;
+            {
+                const size_t gb = (size_t)r0 * g.TILE;
+                size_t ge = (size_t)(r0 + nr) * g.TILE;
+                if (ge > nx) ge = nx;
+                if (ge > gb) HIPCHK(lz77k_ps_cells(c.ps.as<uint32_t>(), c.cells.as<uint32_t>(), (uint32_t)gb, (uint32_t)ge, ring_mask, kstream(G.d)));
+            }
+            if (G.d == 0) {
+                HIPCHK(hipEventRecord(c.match_ev[2 * launches0 + 1], kstream(G.d)));
+                sort_timed = g.fast && variant == 0;
+                launches0++;
+            }
+            HIPCHK(hipEventRecord(c.chunk_ev[3 * G.ci], kstream(G.d)));
+            HIPCHK(hipStreamWaitEvent(c.copy, c.chunk_ev[3 * G.ci], 0));
+            for (uint32_t cj = G.ci; cj < G.ci + G.nchunks; cj++) {
+                const size_t b = chunk_b(cj), e = chunk_e(cj);
+                HIPCHK(hipMemcpyAsync(ml_slot(cj), c.maxlen.as<uint8_t>() + b, e - b, hipMemcpyDeviceToHost, c.copy));
+                const size_t pe = e < nx ? e : nx;
+                if (pe > b) HIPCHK(hipMemcpyAsync(ps_slot(cj), c.cells.as<uint32_t>() + b, (pe - b) * 4, hipMemcpyDeviceToHost, c.copy));
+                HIPCHK(hipEventRecord(c.chunk_ev[3 * cj + 1], c.copy));
+            }
+            return hipSetDevice(c0.device) == hipSuccess ? LZ77X_OK : LZ77X_E_HIP;
+        };
 
         lz77x_prio_state st;
         if (!lz77x_prio_init(&st, g.sb)) return LZ77X_E_NOMEM;
@@ -325,47 +367,90 @@ int encode_core(std::vector<Ctx *> &cs, const void *src, bool src_on_device, siz
         /* The two host recurrences are independent of each other (SURVEY A.2 vs A.5).  The priority
          * recurrence -- the critical path of the whole encode -- gets a thread of its own that does
          * nothing else; the calling thread walks the parse chain (8x cheaper) and does all the HIP
-         * enqueueing for a chunk as soon as both are through it. */
+         * enqueueing as ring slots, device results and the recurrence allow. */
         std::mutex pm;
         std::condition_variable pcv;
-        uint32_t prio_chunks = 0;                      /* chunks the recurrence is through (guarded by pm) */
+        uint32_t prio_chunks = 0;                      /* chunks the recurrence is through           (guarded by pm) */
+        uint32_t enq_chunks = 0;                       /* chunks whose device->host copy is enqueued (guarded by pm) */
+        uint32_t h2d_done = 0;                         /* chunks whose host->device copy has landed  (guarded by pm) */
+        bool abort_all = false;
         std::atomic<int> prio_err{0};
         double t_prio = 0;
         std::thread prio_thread([&]() {
             for (uint32_t ci = 0; ci < nchunks; ci++) {
-                size_t e = (size_t)(ci + 1) * per_chunk * g.TILE;
-                if (e > n) e = n;
+                const size_t b = chunk_b(ci), e = chunk_e(ci);
+                {
+                    std::unique_lock<std::mutex> lk(pm);
+                    /* xval slot of this chunk: free once the copy of the chunk K2-1 before it has landed */
+                    pcv.wait(lk, [&] { return abort_all || (enq_chunks > ci && (!ring_h2d || h2d_done + K2 >= ci + 2)); });
+                    if (abort_all) return;
+                }
                 if (hipEventSynchronize(cs[owner[ci]]->chunk_ev[3 * ci + 1]) != hipSuccess) prio_err.store(1);
                 const double t0 = now_ms();
-                lz77x_prio_run(&st, c0.h_ps.as<uint32_t>(), g.sb, e, c0.h_xval.as<uint32_t>());
+                if (ci > 0) {                          /* evictions x < b: their cells/xval live in the previous chunk's slots */
+                    const size_t upto = e < b + (size_t)g.sb ? e : b + (size_t)g.sb;
+                    lz77x_prio_run(&st, rebase32(ps_slot(ci - 1), ci - 1), g.sb, upto, rebase32(xv_slot(ci - 1), ci - 1));
+                }
+                lz77x_prio_run(&st, rebase32(ps_slot(ci), ci), g.sb, e, rebase32(xv_slot(ci), ci));
                 t_prio += now_ms() - t0;
                 { std::lock_guard<std::mutex> lk(pm); prio_chunks = ci + 1; }
-                pcv.notify_one();
+                pcv.notify_all();
             }
         });
-        struct Joiner { std::thread &t; ~Joiner() { if (t.joinable()) t.join(); } } joiner{prio_thread};
+        struct Joiner {
+            std::thread &t; std::mutex &m; std::condition_variable &cv; bool &flag;
+            ~Joiner() { { std::lock_guard<std::mutex> lk(m); flag = true; } cv.notify_all(); if (t.joinable()) t.join(); }
+        } joiner{prio_thread, pm, pcv, abort_all};
 
-        size_t ntok_sz = 0, chain_p = 0;
+        size_t ntok_sz = 0, chain_p = 0, gi = 0;
         std::vector<size_t> tok_sent(D, 0), x_sent(D, 0), toks_at(nchunks + 1, 0);   /* tokens before chunk ci */
         std::vector<uint32_t> lookback;
         double t_chain = 0;
         int err = LZ77X_OK;
+        HIPCHK(hipEventRecord(c0.ev[0], kstream(0)));
         for (uint32_t ci = 0; ci < nchunks && err == LZ77X_OK; ci++) {
             const uint32_t d = owner[ci];
             Ctx &c = *cs[d];
-            const size_t b = (size_t)ci * per_chunk * g.TILE;
-            size_t e = (size_t)(ci + 1) * per_chunk * g.TILE;
-            if (e > n) e = n;
+            const size_t b = chunk_b(ci), e = chunk_e(ci);
+            /* top up the device queue: a group may go out once every slot it lands in is free, i.e. the
+             * chunk K before each of its chunks AND that chunk's successor have been consumed by both
+             * host recurrences.  Chunk ci itself must be out before we can wait for it. */
+            for (;;) {
+                uint32_t through;
+                { std::lock_guard<std::mutex> lk(pm); through = prio_chunks; }
+                if (through > ci) through = ci;
+                while (gi < groups.size() &&
+                       (!ring_d2h || groups[gi].ci + groups[gi].nchunks + 1 <= (uint64_t)through + K)) {
+                    if ((rc = enqueue_group(groups[gi]))) { err = rc; break; }
+                    const uint32_t upto = groups[gi].ci + groups[gi].nchunks;
+                    gi++;
+                    { std::lock_guard<std::mutex> lk(pm); enq_chunks = upto; }
+                    pcv.notify_all();
+                }
+                if (err != LZ77X_OK) break;
+                {
+                    std::unique_lock<std::mutex> lk(pm);
+                    if (enq_chunks > ci) break;
+                    const uint32_t seen = prio_chunks;          /* ring full: wait for the recurrence to free a slot */
+                    pcv.wait(lk, [&] { return prio_chunks != seen; });
+                }
+            }
+            if (err != LZ77X_OK) break;
             const double tw = now_ms();
             hipError_t he = hipEventSynchronize(c.chunk_ev[3 * ci + 1]);
+            if (he == hipSuccess && ring_h2d && ci >= K2)      /* chain slot: the copy that last read it */
+                he = hipEventSynchronize(cs[owner[ci - K2]]->chunk_ev[3 * (ci - K2) + 2]);
             const double t1 = now_ms();
             waited += t1 - tw;
             if (he != hipSuccess) { err = LZ77X_E_HIP; snprintf(g_err, sizeof g_err, "chunk sync: %s", hipGetErrorString(he)); break; }
             const size_t tok_before = ntok_sz;
-            chain_p = lz77x_host_chain(c0.h_maxlen.as<uint8_t>(), e, chain_p, c0.h_chain.as<uint32_t>(), &ntok_sz);
+            chain_p = lz77x_host_chain(rebase8(ml_slot(ci), ci), e, chain_p,
+                                       reinterpret_cast<uint32_t *>(reinterpret_cast<uintptr_t>(ch_slot(ci)) - tok_before * sizeof(uint32_t)),
+                                       &ntok_sz);
             const double t2 = now_ms();
             t_chain += t2 - t1;
             { std::unique_lock<std::mutex> lk(pm); pcv.wait(lk, [&] { return prio_chunks > ci; }); }
+            if (prio_err.load()) { err = LZ77X_E_HIP; snprintf(g_err, sizeof g_err, "recurrence thread: event wait failed"); break; }
             const size_t x_done = e > (size_t)g.sb ? e - (size_t)g.sb : 0;
             /* hand-overs that can matter to tokens in [b, e): evictions before e-sb into dst >= b-sb */
             const uint32_t dbase = b > (size_t)g.sb ? (uint32_t)(b - (size_t)g.sb) : 0u;
@@ -381,23 +466,31 @@ int encode_core(std::vector<Ctx *> &cs, const void *src, bool src_on_device, siz
                     if (d > 0 && b > xa) {
                         /* the host holds ring cells; the index kernels want distances again */
                         lookback.resize(b - xa);
-                        const uint32_t *hc = c0.h_ps.as<uint32_t>();
+                        const uint32_t *hc = rebase32(ps_slot(ci - 1), ci - 1);      /* [xa, b) lies in the previous chunk */
                         for (size_t x = xa; x < b; x++) {
                             const uint32_t v = hc[x], x32 = (uint32_t)x;
                             lookback[x - xa] = (((v & 0xFFFFu) - x32) & ring_mask) | ((((v >> 16) - x32) & ring_mask) << 16);
                         }
                         if ((q = hipMemcpyAsync(c.ps.as<uint32_t>() + xa, lookback.data(), (b - xa) * 4,
-                                                hipMemcpyHostToDevice, c.copy)) != hipSuccess) return q;
-                        if ((q = hipStreamSynchronize(c.copy)) != hipSuccess) return q;      /* pageable source */
+                                                hipMemcpyHostToDevice, c.up)) != hipSuccess) return q;
+                        if ((q = hipStreamSynchronize(c.up)) != hipSuccess) return q;      /* pageable source */
                     }
                 }
-                if (x_done > x_sent[d] &&
-                    (q = hipMemcpyAsync(c.xval.as<uint32_t>() + x_sent[d], c0.h_xval.as<uint32_t>() + x_sent[d],
-                                        (x_done - x_sent[d]) * 4, hipMemcpyHostToDevice, c.copy)) != hipSuccess) return q;
-                if (ntok_sz > tok_sent[d] &&
-                    (q = hipMemcpyAsync(c.chain.as<uint32_t>() + tok_sent[d], c0.h_chain.as<uint32_t>() + tok_sent[d],
-                                        (ntok_sz - tok_sent[d]) * 4, hipMemcpyHostToDevice, c.copy)) != hipSuccess) return q;
-                if ((q = hipEventRecord(c.chunk_ev[3 * ci + 2], c.copy)) != hipSuccess) return q;
+                /* xval [x_sent, x_done): the part below b sits in the previous chunk's slot */
+                if (x_sent[d] < b && x_done > x_sent[d]) {
+                    const size_t hi = x_done < b ? x_done : b;
+                    if ((q = hipMemcpyAsync(c.xval.as<uint32_t>() + x_sent[d], rebase32(xv_slot(ci - 1), ci - 1) + x_sent[d],
+                                            (hi - x_sent[d]) * 4, hipMemcpyHostToDevice, c.up)) != hipSuccess) return q;
+                }
+                if (x_done > b) {
+                    const size_t lo = x_sent[d] > b ? x_sent[d] : b;
+                    if ((q = hipMemcpyAsync(c.xval.as<uint32_t>() + lo, rebase32(xv_slot(ci), ci) + lo, (x_done - lo) * 4,
+                                            hipMemcpyHostToDevice, c.up)) != hipSuccess) return q;
+                }
+                if (ntok_sz > tok_before &&
+                    (q = hipMemcpyAsync(c.chain.as<uint32_t>() + tok_before, ch_slot(ci), (ntok_sz - tok_before) * 4,
+                                        hipMemcpyHostToDevice, c.up)) != hipSuccess) return q;
+                if ((q = hipEventRecord(c.chunk_ev[3 * ci + 2], c.up)) != hipSuccess) return q;
                 if ((q = hipStreamWaitEvent(tstream(d), c.chunk_ev[3 * ci + 2], 0)) != hipSuccess) return q;
                 if ((q = hipEventRecord(c.tok_ev[2 * ci], tstream(d))) != hipSuccess) return q;
                 if ((q = lz77k_xfer_index(c.ps.as<uint32_t>(), c.xval.as<uint32_t>(), xa, (uint32_t)x_done, dbase, (uint32_t)e,
@@ -414,11 +507,22 @@ int encode_core(std::vector<Ctx *> &cs, const void *src, bool src_on_device, siz
             x_sent[d] = x_done;
             tok_sent[d] = ntok_sz;
             toks_at[ci + 1] = ntok_sz;
+            if (ring_h2d && ci >= 1) {
+                /* chunk ci-1's copy was queued one chunk ago: by now it has landed; tell the recurrence */
+                he = hipEventSynchronize(cs[owner[ci - 1]]->chunk_ev[3 * (ci - 1) + 2]);
+                if (he != hipSuccess) { err = LZ77X_E_HIP; snprintf(g_err, sizeof g_err, "h2d sync: %s", hipGetErrorString(he)); break; }
+                { std::lock_guard<std::mutex> lk(pm); h2d_done = ci; }
+                pcv.notify_all();
+            }
         }
+        if (err == LZ77X_OK && launches0) HIPCHK(hipEventRecord(c0.ev[1], kstream(0)));
+        { std::lock_guard<std::mutex> lk(pm); abort_all = err != LZ77X_OK; }
+        pcv.notify_all();
         prio_thread.join();
         if (prio_err.load()) err = LZ77X_E_HIP;
         ntok = (uint32_t)ntok_sz;
         nchunks_done = nchunks;
+        launches0_total = launches0;
         lz77x_prio_free(&st);
         if (err != LZ77X_OK) {
             for (Ctx *c : cs) { hipError_t q = hipSetDevice(c->device); q = hipDeviceSynchronize(); (void)q; }
@@ -472,8 +576,14 @@ int encode_core(std::vector<Ctx *> &cs, const void *src, bool src_on_device, siz
     waited += now_ms() - tw;
 
     float ms = 0;
-    HIPCHK(hipEventElapsedTime(&ms, c0.ev[0], c0.ev[1]));
-    g_stats.k_match_ms = ms;
+    {
+        double match_ms = 0;
+        for (uint32_t i = 0; i < launches0_total; i++) {
+            HIPCHK(hipEventElapsedTime(&ms, c0.match_ev[2 * i], c0.match_ev[2 * i + 1]));
+            match_ms += ms;
+        }
+        g_stats.k_match_ms = match_ms;
+    }
     double tok_ms = 0;
     for (uint32_t ci = 0; ci < nchunks_done; ci++) {
         Ctx &c = *cs[owner[ci]];
@@ -483,7 +593,7 @@ int encode_core(std::vector<Ctx *> &cs, const void *src, bool src_on_device, siz
     g_stats.k_token_ms = tok_ms;
     if (sort_timed && D == 1) {
         double sort_ms = 0;
-        for (uint32_t i = 0; i < g_stats.match_launches; i++) {
+        for (uint32_t i = 0; i < launches0_total; i++) {
             HIPCHK(hipEventElapsedTime(&ms, c0.sort_ev[2 * i], c0.sort_ev[2 * i + 1]));
             sort_ms += ms;
         }
@@ -773,13 +883,14 @@ static void ctx_release(Ctx &c)
         b->p = nullptr;
         b->cap = 0;
     }
-    for (auto *v : {&c.chunk_ev, &c.tok_ev, &c.sort_ev}) {
+    for (auto *v : {&c.chunk_ev, &c.tok_ev, &c.sort_ev, &c.match_ev}) {
         for (hipEvent_t ev : *v) e = hipEventDestroy(ev);
         v->clear();
     }
     for (auto &ev : c.ev) e = hipEventDestroy(ev);
     e = hipStreamDestroy(c.stream);
     e = hipStreamDestroy(c.copy);
+    e = hipStreamDestroy(c.up);
     e = hipStreamDestroy(c.tok);
     (void)e;
     c.ready = false;

@@ -170,6 +170,26 @@ def test_shards_give_identical_bytes(kind, seed, n, sb, la, monkeypatch):
         L.lib().lz77x_set_shards(1)
 
 
+@pytest.mark.parametrize("slots,chunk,group,shards", [("3", "1", "1", 1), ("4", "2", "2", 1), ("5", "1", "3", 1),
+                                                       ("6", "4", "4", 1), ("4", "1", "2", 3)])
+def test_pinned_rings_wrap(slots, chunk, group, shards, monkeypatch):
+    """host buffers as small rings (a few chunk slots, forced much smaller than the input): slot
+    recycling, the look-back into the previous slot and the flow control between the device queue,
+    the recurrence thread and the feeding thread must not change a byte"""
+    data = synth.mixed(2_600_000, 87)
+    want = O.encode_bst(data)
+    monkeypatch.setenv("LZ77X_RING_SLOTS", slots)
+    monkeypatch.setenv("LZ77X_CHUNK_REGIONS", chunk)
+    monkeypatch.setenv("LZ77X_MATCH_GROUP", group)
+    monkeypatch.setenv("LZ77X_FAKE_DEVICES", "4")
+    try:
+        assert L.lib().lz77x_set_shards(shards) == 0
+        for _ in range(2):
+            assert L.encode(data) == want
+    finally:
+        L.lib().lz77x_set_shards(1)
+
+
 def test_small_chunks_pipeline(monkeypatch):
     """many tiny host chunks and single-chunk match groups: same bytes as one big chunk"""
     data = synth.text(5_000_000, 85)
