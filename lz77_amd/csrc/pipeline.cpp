@@ -14,6 +14,10 @@
 #include "../../include/lz77_mi355x.h"
 
 #include <hip/hip_runtime_api.h>
+#include <sys/mman.h>
+#ifndef MADV_HUGEPAGE
+#define MADV_HUGEPAGE 14          /* Linux; not exposed in every compilation pass of hipcc */
+#endif
 
 #include <chrono>
 #include <cstdio>
@@ -72,14 +76,44 @@ struct DevBuf {
     template <class T> T *as() const { return reinterpret_cast<T *>(p); }
 };
 
+/* Pinned host memory.  Large buffers are 2 MiB-aligned anonymous memory advised to transparent huge
+ * pages and then registered with HIP (the host recurrence streams through them: fewer TLB misses,
+ * measured -6..8 % on it); small ones, or if anything in that path fails, plain hipHostMalloc. */
 struct PinBuf {
     void *p = nullptr;
     size_t cap = 0;
+    bool registered = false;
+    void release()
+    {
+        if (!p) return;
+        if (registered) { hipError_t e0 = hipHostUnregister(p); (void)e0; free(p); }
+        else { hipError_t e0 = hipHostFree(p); (void)e0; }
+        p = nullptr;
+        cap = 0;
+        registered = false;
+    }
     int need(size_t bytes)
     {
         if (bytes <= cap) return LZ77X_OK;
-        if (p) { hipError_t e0 = hipHostFree(p); (void)e0; p = nullptr; cap = 0; }
+        release();
         size_t want = bytes + bytes / 8 + 4096;
+        const char *hp = getenv("LZ77X_HUGEPAGES");
+        if (want >= ((size_t)8 << 20) && !(hp && !atoi(hp))) {
+            const size_t two_mb = (size_t)2 << 20;
+            want = (want + two_mb - 1) & ~(two_mb - 1);
+            void *q = nullptr;
+            if (posix_memalign(&q, two_mb, want) == 0) {
+                madvise(q, want, MADV_HUGEPAGE);
+                if (hipHostRegister(q, want, hipHostRegisterPortable) == hipSuccess) {
+                    p = q;
+                    cap = want;
+                    registered = true;
+                    return LZ77X_OK;
+                }
+                (void)hipGetLastError();
+                free(q);
+            }
+        }
         HIPCHK(hipHostMalloc(&p, want, hipHostMallocPortable));   /* every shard's device copies to/from it */
         cap = want;
         return LZ77X_OK;
@@ -649,7 +683,7 @@ int decode_core(Ctx &c, size_t zn, hipStream_t s, bool want_data, size_t *n_out)
             uint64_t tot = 0;
             const uint32_t *l = tmp.as<uint32_t>();
             for (uint32_t k = 0; k < ntok; k++) tot += l[k];
-            hipError_t e0 = hipHostFree(tmp.p); (void)e0;
+            tmp.release();
             if (tot > LZ77X_MAX_N) return LZ77X_E_TOOBIG;
         }
         HIPCHK(lz77k_scan_u32(c.len1.as<uint32_t>(), c.dst.as<uint32_t>(), ntok + 1, c.scantmp.p, s));
@@ -878,11 +912,7 @@ static void ctx_release(Ctx &c)
         b->p = nullptr;
         b->cap = 0;
     }
-    for (PinBuf *b : {&c.h_ps, &c.h_maxlen, &c.h_xval, &c.h_chain, &c.h_small, &c.h_tok, &c.h_stage}) {
-        if (b->p) e = hipHostFree(b->p);
-        b->p = nullptr;
-        b->cap = 0;
-    }
+    for (PinBuf *b : {&c.h_ps, &c.h_maxlen, &c.h_xval, &c.h_chain, &c.h_small, &c.h_tok, &c.h_stage}) b->release();
     for (auto *v : {&c.chunk_ev, &c.tok_ev, &c.sort_ev, &c.match_ev}) {
         for (hipEvent_t ev : *v) e = hipEventDestroy(ev);
         v->clear();
