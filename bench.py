@@ -75,8 +75,8 @@ def _cpu_model():
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--bytes", type=int, default=100_000_000)
     ap.add_argument("--sb", type=int, default=4095)
     ap.add_argument("--la", type=int, default=15)

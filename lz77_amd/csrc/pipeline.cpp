@@ -178,9 +178,25 @@ size_t stream_bytes(uint64_t ntok, int T) { return 4 + (size_t)((ntok * (uint64_
 /* Contexts taking part in one encode: cs[0] is the caller's device (holds the pinned host buffers
  * and the final stream), cs[1..] the other shards.  LZ77X_FAKE_DEVICES=k lets k contexts share one
  * physical GPU so that the multi-device path can be exercised on a single-GPU box. */
+void ctx_release(Ctx &c);
+
+/* The primary context lives on whatever device is current when the library is entered; if the
+ * caller has switched devices since the last call, the cached contexts are rebuilt there. */
+int primary_context()
+{
+    int cur = -1;
+    if (g_ctx.ready && hipGetDevice(&cur) == hipSuccess && cur != g_ctx.device) {
+        for (Ctx *c : g_more) { ctx_release(*c); delete c; }
+        g_more.clear();
+        ctx_release(g_ctx);
+        HIPCHK(hipSetDevice(cur));
+    }
+    return ctx_init(g_ctx);
+}
+
 int shard_contexts(int want, std::vector<Ctx *> &cs)
 {
-    int rc = ctx_init(g_ctx);
+    int rc = primary_context();
     if (rc) return rc;
     cs.clear();
     cs.push_back(&g_ctx);
@@ -837,7 +853,7 @@ int lz77x_decode(const uint8_t *z, size_t zn, uint8_t **out, size_t *out_n)
     if (!out || !out_n || (!z && zn)) return LZ77X_E_ARG;
     std::lock_guard<std::mutex> lk(g_mu);
     int rc;
-    if ((rc = ctx_init(g_ctx))) return rc;
+    if ((rc = primary_context())) return rc;
     if (zn < 4) return LZ77X_E_FORMAT;
     if ((rc = load_stream(g_ctx, z, false, zn, g_ctx.stream))) return rc;
     size_t n = 0;
@@ -855,7 +871,7 @@ int lz77x_decode_device(const void *d_z, size_t zn, void *d_out, size_t out_cap,
     if (!out_n || (!d_z && zn)) return LZ77X_E_ARG;
     std::lock_guard<std::mutex> lk(g_mu);
     int rc;
-    if ((rc = ctx_init(g_ctx))) return rc;
+    if ((rc = primary_context())) return rc;
     if (zn < 4) return LZ77X_E_FORMAT;
     hipStream_t s = (hipStream_t)stream;
     if ((rc = load_stream(g_ctx, d_z, true, zn, s))) return rc;
@@ -901,7 +917,10 @@ const char *lz77x_strerror(int code)
     }
 }
 
-static void ctx_release(Ctx &c)
+}  // extern "C" (reopened below)
+
+namespace {
+void ctx_release(Ctx &c)
 {
     if (!c.ready) return;
     hipError_t e = hipSetDevice(c.device);
@@ -925,6 +944,9 @@ static void ctx_release(Ctx &c)
     (void)e;
     c.ready = false;
 }
+}  // namespace
+
+extern "C" {
 
 void lz77x_shutdown(void)
 {
@@ -950,7 +972,7 @@ static int run_match_only(const uint8_t *in, size_t n, int sb, int la, lz77x_geo
 {
     int rc = check_geom(sb, la);
     if (rc) return rc;
-    if ((rc = ctx_init(g_ctx))) return rc;
+    if ((rc = primary_context())) return rc;
     if (n > LZ77X_MAX_N) return LZ77X_E_TOOBIG;
     lz77x_make_geom(g, sb, la);
     Ctx &c = g_ctx;
