@@ -721,8 +721,7 @@ int decode_core(Ctx &c, size_t zn, hipStream_t s, bool want_data, size_t *n_out)
         for (;;) {
             HIPCHK(hipMemsetAsync(c.flag.p, 0, 4, s));
             HIPCHK(lz77k_dec_jump(c.ptr.as<uint32_t>(), n32, c.flag.as<uint32_t>(), s));
-            HIPCHK(lz77k_dec_jump(c.ptr.as<uint32_t>(), n32, c.flag.as<uint32_t>(), s));
-            rounds += 2;
+            rounds += 1;
             HIPCHK(hipMemcpyAsync(hflag, c.flag.p, 4, hipMemcpyDeviceToHost, s));
             HIPCHK(hipStreamSynchronize(s));
             if (!*hflag || rounds > 80) break;
