@@ -1,5 +1,5 @@
 """Soak test of the encode pipeline's flow control: random inputs x random chunk / group / ring /
-shard settings, each checked against the oracle.  python tests/gpu_stress.py [seconds]"""
+shard settings, each checked against the oracle.  python tests/gpu_stress.py [seconds] [seed]"""
 import os, sys, time, random
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.dirname(HERE)); sys.path.insert(0, HERE)
@@ -9,7 +9,7 @@ import oracle_lib as O
 from lz77_amd import synth
 
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
-rng = random.Random(2026)
+rng = random.Random(int(sys.argv[2]) if len(sys.argv) > 2 else 2026)
 os.environ["LZ77X_FAKE_DEVICES"] = "4"
 t_end = time.time() + budget
 runs = 0

@@ -24,7 +24,7 @@ print("roundtrip ok sha", hashlib.sha256(z).hexdigest()[:16])
 # variants: sort-only probe and old token kernel
 if os.environ.get('LZ77X_SWEEP', '1') != '1':
     sys.exit(0)
-for name, env in (("match sort-only", {"LZ77X_MATCH_VARIANT": "2"}), ("sort-only old sort", {"LZ77X_MATCH_VARIANT": "2", "LZ77X_SORT_VARIANT": "1"}), ("match pair-scan", {"LZ77X_MATCH_VARIANT": "3"}),
+for name, env in (("match sort-only", {"LZ77X_MATCH_VARIANT": "2"}), ("sort-only plain bitonic", {"LZ77X_MATCH_VARIANT": "2", "LZ77X_SORT_VARIANT": "1"}), ("sort-only blocked bitonic", {"LZ77X_MATCH_VARIANT": "2", "LZ77X_SORT_VARIANT": "2"}), ("match pair-scan", {"LZ77X_MATCH_VARIANT": "3"}),
                   ("walk run 1024", {"LZ77X_WALK_RUN": "1024"}), ("walk run 4096", {"LZ77X_WALK_RUN": "4096"}), ("group 1", {"LZ77X_MATCH_GROUP": "1"}),
                   ("token v1 (global)", {"LZ77X_TOKEN_VARIANT": "1"}), ("token v2 (tile, no index)", {"LZ77X_TOKEN_VARIANT": "2"})):
     os.environ.update(env)

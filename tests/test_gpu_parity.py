@@ -201,16 +201,27 @@ def test_small_chunks_pipeline(monkeypatch):
 
 
 @pytest.mark.parametrize("env", [{"LZ77X_MATCH_VARIANT": "1"}, {"LZ77X_MATCH_VARIANT": "3"}, {"LZ77X_SORT_VARIANT": "1"},
-                                 {"LZ77X_TOKEN_VARIANT": "1"}, {"LZ77X_TOKEN_VARIANT": "2"}, {"LZ77X_WALK_RUN": "64"},
+                                 {"LZ77X_SORT_VARIANT": "2"}, {"LZ77X_TOKEN_VARIANT": "1"}, {"LZ77X_TOKEN_VARIANT": "2"}, {"LZ77X_WALK_RUN": "64"},
                                  {"LZ77X_WALK_RUN": "8192"}])
 def test_kernel_variants_agree(env, monkeypatch):
-    """independent formulations of the same stage (exhaustive pair scan vs bitmap walkers, plain vs
-    blocked sort, three token kernels) all reproduce the reference stream"""
+    """independent formulations of the same stage (exhaustive pair scan vs bitmap walkers, merge sort vs
+    plain / blocked bitonic sort, three token kernels) all reproduce the reference stream"""
     data = synth.mixed(3_000_000, 86)
     want = O.encode_bst(data)
     for k, v in env.items():
         monkeypatch.setenv(k, v)
     assert L.encode(data) == want
+
+
+@pytest.mark.parametrize("sortv", ["0", "1", "2"])
+@pytest.mark.parametrize("sb,la", [(65535, 255), (8192, 16), (20000, 40)])
+def test_large_window_sort_variants_agree(sortv, sb, la, monkeypatch):
+    """large regions (global index arrays): chunked merge sort + global merge levels (even and odd
+    level counts) vs plain and chunked bitonic"""
+    data = synth.mixed(700_000, 87)
+    want = O.encode_bst(data, sb, la)
+    monkeypatch.setenv("LZ77X_SORT_VARIANT", sortv)
+    assert L.encode(data, la, sb) == want
 
 
 def test_roundtrip_incompressible_large():
