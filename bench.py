@@ -98,6 +98,14 @@ def main():
         raise SystemExit("rank %d has no GPU (%d visible)" % (rank, ndev))
     local %= ndev
     torch.cuda.set_device(local)
+    numa_cpus = 0
+    if os.environ.get("LZ77_BENCH_NUMA", "1") != "0":
+        from lz77_amd.shard import bind_to_device_numa
+        pr = torch.cuda.get_device_properties(local)
+        try:
+            numa_cpus = bind_to_device_numa("%04x:%02x:%02x.0" % (pr.pci_domain_id, pr.pci_bus_id, pr.pci_device_id))
+        except AttributeError:
+            numa_cpus = 0
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -183,7 +191,8 @@ def main():
             "data": "synthetic",
             "config": {"workload": "S1 enwik8-like text (lz77_amd.synth.text, seed 0x5EED0001+rank), %d bytes per GPU, "
                                    "s=%d l=%d; step = encode then decode, buffers resident in HBM" % (n, a.sb, a.la),
-                       "bytes_per_gpu": n, "sb": a.sb, "la": a.la, "parallelism": "independent stream per GPU"},
+                       "bytes_per_gpu": n, "sb": a.sb, "la": a.la, "parallelism": "independent stream per GPU",
+                       "numa_bound_cpus": numa_cpus},
             "roofline": {"bound": "hbm", "kernel": "k_match<true,3> (region key sort, the largest GPU kernel)",
                          "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic,

@@ -41,8 +41,15 @@ void lz77x_make_geom(lz77x_geom *g, int sb, int la)
     uint32_t rp = 4096;
     while (rp < 4u * g->SBu) rp <<= 1;
     g->RP = rp;
-    g->TILE = (rp - g->SBu - (uint32_t)sb) & ~7u;
+    g->TILE = rp - g->SBu;
+    g->shifted = 1;
     g->fast = rp <= 16384u;
+}
+
+void lz77x_geom_legacy(lz77x_geom *g)
+{
+    g->TILE = (g->RP - g->SBu - (uint32_t)g->sb) & ~7u;
+    g->shifted = 0;
 }
 
 size_t lz77x_host_chain(const uint8_t *maxlen, size_t limit, size_t p, uint32_t *chain, size_t *ntok)

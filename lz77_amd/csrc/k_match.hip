@@ -458,8 +458,11 @@ __global__ __launch_bounds__(MATCH_BLOCK, (FAST && MODE == 3) ? 8 : 1) void k_ma
     const uint64_t t0_64 = (uint64_t)region * TILE;
     if (t0_64 >= n) return;
     const uint32_t t0 = (uint32_t)t0_64;
-    const uint32_t rstart = t0 >= SBu ? t0 - SBu : 0;
-    const uint64_t rend64 = (uint64_t)t0 + TILE + (uint32_t)sb - 1;
+    /* MODE >= 2 (production sort, probe): the region is [t0, t0+TILE+sb); pair scans: halos either side
+     * of [t0, t0+TILE) (the two layouts of lz77x_geom) */
+    constexpr bool SHIFTED = MODE >= 2;
+    const uint32_t rstart = SHIFTED ? t0 : (t0 >= SBu ? t0 - SBu : 0);
+    const uint64_t rend64 = (uint64_t)t0 + TILE + (uint32_t)sb - (SHIFTED ? 0u : 1u);
     const uint32_t rend = rend64 < n ? (uint32_t)rend64 : n;
     const uint32_t R = rend - rstart;                      /* valid local indices [0,R) */
     const uint32_t lt0 = t0 - rstart;                      /* multiple of 8 */
@@ -695,23 +698,31 @@ __global__ __launch_bounds__(MATCH_BLOCK, (FAST && MODE == 3) ? 8 : 1) void k_ma
 /* ------------------------------------------------------------------ window walkers --- */
 
 /*
- * Sliding-window neighbour search in O(1) per position (replaces the O(SB) pair scan whenever
- * a region's rank space fits a per-lane LDS bitmap, RP <= 16384).
+ * Sliding-window neighbour search in O(1) per position (replaces the O(SB) pair scan).
  *
  * A walker is ONE LANE.  It owns a bitmap over the region's rank space (bit r set <=> the
  * position with rank r is inside the current window) plus a one-bit-per-word summary, and slides
- * the window one position at a time: clear the bit of the position that leaves, set the bit of
- * the one that enters, then find the first set bit above / below the query's own rank -- the
- * in-order successor / predecessor tree.c's BST would hold.  64 walkers share a wavefront; their
- * bitmaps are word-interleaved in LDS (word w of lane l at (w*64+l)*4) so every access of the
- * wave hits 64 distinct banks.  dir 0: forward window (x, x+sb) -> P/S at eviction time;
- * dir 1: backward window [x-sb, x) -> longest-match candidates.
+ * the window W_t = [t, t+sb) one position at a time.  Step t:
+ *     set   rank[t+sb-1]                       -> bitmap = W_t
+ *     query rank[t+sb]  (not in the set)       -> backward result of y = t+sb: its in-order
+ *                                                 neighbours in [y-sb, y-1], the two candidates of the
+ *                                                 longest match (tree.c:118-152)
+ *     clear rank[t]
+ *     query rank[t]                            -> forward result of x = t: its in-order neighbours among
+ *                                                 the sb-1 positions after it, i.e. what the BST holds
+ *                                                 when x is evicted (tree.c:182)
+ * A query is "first set bit above / below a rank": the in-order successor / predecessor.  64 walkers
+ * share a wavefront; their bitmaps are word-interleaved in LDS (word w of lane l at (w*64+l)*4) so
+ * every access of the wave hits 64 distinct banks.  A walker covers run_len steps of one region after
+ * filling its first window (sb-1 sets); the very first walker of the input answers the backward
+ * queries of y < sb while it fills.
  */
 #define WALK_NONE 0xFFFFu
 
-__global__ __launch_bounds__(64) void k_walk(const uint16_t *__restrict__ ranks, uint32_t n, int sb, uint32_t SBu, uint32_t RP,
+__global__ __launch_bounds__(64) void k_walk(const uint16_t *__restrict__ ranks, uint32_t n, int sb, uint32_t RP,
                                              uint32_t TILE, uint32_t region0, uint32_t nregions, uint32_t run_len,
-                                             uint32_t runs_per_tile, uint32_t *__restrict__ wf, uint32_t *__restrict__ wb)
+                                             uint32_t runs_per_tile, uint32_t *__restrict__ wf, uint32_t *__restrict__ wb,
+                                             uint32_t *__restrict__ wb0)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t bm[];
     const uint32_t lane = threadIdx.x;
@@ -719,127 +730,185 @@ __global__ __launch_bounds__(64) void k_walk(const uint16_t *__restrict__ ranks,
 #define BM_WORD(w) bm[(w) * 64u + lane]
 #define BM_SUMM(w) bm[(NW + (w)) * 64u + lane]
     const uint32_t id = blockIdx.x * 64u + lane;
-    const uint32_t dir = id & 1u;
-    const uint32_t run = (id >> 1) % runs_per_tile;
-    const uint32_t reg = (id >> 1) / runs_per_tile;
+    const uint32_t run = id % runs_per_tile;
+    const uint32_t reg = id / runs_per_tile;
     if (reg >= nregions) return;
     const uint64_t t0_64 = (uint64_t)(region0 + reg) * TILE;
     if (t0_64 >= n) return;
     const uint32_t t0 = (uint32_t)t0_64;
-    const uint32_t rstart = t0 >= SBu ? t0 - SBu : 0;
-    const uint64_t rend64 = (uint64_t)t0 + TILE + (uint32_t)sb - 1;
-    const uint32_t R = (rend64 < n ? (uint32_t)rend64 : n) - rstart;
-    const uint32_t lt0 = t0 - rstart;
-    const uint32_t lt1 = ((uint64_t)t0 + TILE < n ? t0 + TILE : n) - rstart;
-    const uint32_t xa = lt0 + run * run_len;
-    if (xa >= lt1) return;
-    const uint32_t xb = min(xa + run_len, lt1);
+    const uint32_t usb = (uint32_t)sb;
+    const uint64_t rend64 = t0_64 + TILE + usb;
+    const uint32_t R = (rend64 < n ? (uint32_t)rend64 : n) - t0;         /* sorted local indices [0,R) */
+    const uint32_t lt1 = n - t0 < TILE ? n - t0 : TILE;                  /* steps t in [0, lt1) */
+    const uint32_t ta = run * run_len;
+    if (ta >= lt1) return;
+    const uint32_t tb = min(ta + run_len, lt1);
     const uint16_t *rk = ranks + (size_t)reg * 2 * RP;
-    uint32_t *out = (dir ? wb : wf) + (size_t)reg * TILE;                /* indexed by position - t0 */
-    const int32_t isb = sb;
+    uint32_t *of = wf + (size_t)reg * TILE, *ob = wb + (size_t)reg * TILE; /* indexed by t */
 
     for (uint32_t w = 0; w < NW + NS; w++) bm[w * 64u + lane] = 0;
     auto set_bit = [&](uint32_t r) {
         atomicOr(&BM_WORD(r >> 5), 1u << (r & 31));
         atomicOr(&BM_SUMM(r >> 10), 1u << ((r >> 5) & 31));
     };
-    auto clear_bit = [&](uint32_t r) {
-        const uint32_t bit = 1u << (r & 31);
-        const uint32_t old = atomicAnd(&BM_WORD(r >> 5), ~bit);
-        if ((old & ~bit) == 0) atomicAnd(&BM_SUMM(r >> 10), ~(1u << ((r >> 5) & 31)));
-    };
-    auto load8 = [&](int32_t i, uint32_t (&v)[4]) {          /* ranks i..i+7, any alignment */
-        if (i >= 0 && i + 8 <= (int32_t)RP) {
+    auto load8 = [&](uint32_t i, uint32_t (&v)[4]) {          /* ranks i..i+7, any alignment */
+        if (i + 8 <= RP) {
             uint4 t;
             __builtin_memcpy(&t, rk + i, 16);
             v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
         } else {
 #pragma unroll
             for (int j = 0; j < 4; j++) {
-                const int32_t i0 = i + 2 * j, i1 = i0 + 1;
-                const uint32_t lo = (i0 >= 0 && i0 < (int32_t)RP) ? rk[i0] : 0u, hi = (i1 >= 0 && i1 < (int32_t)RP) ? rk[i1] : 0u;
+                const uint32_t i0 = i + 2 * j, i1 = i0 + 1;
+                const uint32_t lo = i0 < RP ? rk[i0] : 0u, hi = i1 < RP ? rk[i1] : 0u;
                 v[j] = lo | (hi << 16);
             }
         }
     };
-    /* window of the first query */
-    {
-        const int32_t lo = dir ? (int32_t)xa - isb : (int32_t)xa + 1;
-        const int32_t hi = dir ? (int32_t)xa - 1 : (int32_t)xa + isb - 1;
-        const int32_t a = lo < 0 ? 0 : lo, b = hi >= (int32_t)R ? (int32_t)R - 1 : hi;
-        int32_t i = a;
-        for (; i + 8 <= b + 1; i += 8) {
-            uint32_t v[4];
-            load8(i, v);
-#pragma unroll
-            for (int j = 0; j < 8; j++) set_bit((v[j >> 1] >> (16 * (j & 1))) & 0xFFFFu);
-        }
-        for (; i <= b; i++) set_bit(rk[i]);
-    }
-    /* one step: neighbours of q in the current window, then slide (enter before leave: with
-     * sb == 1 the entering and the leaving index coincide) */
-    auto step = [&](uint32_t q, uint32_t r_add, uint32_t r_rem) -> uint32_t {
-        const uint32_t w0 = q >> 5, b0 = q & 31;
-        const uint32_t here = BM_WORD(w0);
-        uint32_t succ = WALK_NONE, pred = WALK_NONE;
-        {
-            uint32_t w = w0, m = here & ~((2u << b0) - 1u);
-            if (!m) {
-                uint32_t sw = w >> 5, sm = BM_SUMM(sw) & ~((2u << (w & 31)) - 1u);
-                while (!sm && ++sw < NS) sm = BM_SUMM(sw);
-                if (sm) { w = (sw << 5) + (uint32_t)__builtin_ctz(sm); m = BM_WORD(w); }
-            }
-            if (m) succ = (w << 5) + (uint32_t)__builtin_ctz(m);
-        }
-        {
-            uint32_t w = w0, m = here & ((1u << b0) - 1u);
-            if (!m) {
-                int32_t sw = (int32_t)(w >> 5);
-                uint32_t sm = BM_SUMM(sw) & ((1u << (w & 31)) - 1u);
-                while (!sm && --sw >= 0) sm = BM_SUMM(sw);
-                if (sm) { w = ((uint32_t)sw << 5) + 31u - (uint32_t)__builtin_clz(sm); m = BM_WORD(w); }
-            }
-            if (m) pred = (w << 5) + 31u - (uint32_t)__builtin_clz(m);
-        }
-        if (r_add != WALK_NONE) set_bit(r_add);
-        if (r_rem != WALK_NONE) clear_bit(r_rem);
-        return succ | (pred << 16);
+    /* A query = first set bit strictly above / below rank q.  Level 1: q's own word and its summary
+     * word (both already loaded by the caller); level 2, when the rest of the word is empty: the word
+     * the summary points at.  The two levels are split so that a step can issue the loads of both of
+     * its queries back to back -- the walker is a single wavefront per CU, bound by LDS round trips. */
+    /* branch-free except for the rare case that the summary word has nothing on that side either
+     * (q in the last / first non-empty word of its 1024-rank block) */
+    struct Probe { uint32_t w, m1, sm; };
+    auto up1 = [&](uint32_t w0, uint32_t b0, uint32_t here, uint32_t summ) -> Probe {
+        Probe p;
+        p.m1 = here & ~((2u << b0) - 1u);
+        p.sm = summ & ~((2u << (w0 & 31)) - 1u);
+        uint32_t sw = w0 >> 5;
+        if (!(p.m1 | p.sm))
+            while (!p.sm && ++sw < NS) p.sm = BM_SUMM(sw);
+        p.w = p.sm ? (sw << 5) + (uint32_t)__builtin_ctz(p.sm) : w0;
+        return p;
     };
-    /* index of the position that enters / leaves after the query at x */
-    const int32_t add = dir ? 0 : isb, rem = dir ? -isb : 1;
-    auto valid = [&](int32_t i) { return i >= 0 && i < (int32_t)R; };
-    uint32_t x = xa;
-    /* groups of 8 steps: three 16-byte rank loads, two 16-byte result stores */
-    for (; x + 8 <= xb; x += 8) {
-        uint32_t vq[4], va[4], vr[4], res[8];
-        load8((int32_t)x, vq);
-        load8((int32_t)x + add, va);
-        load8((int32_t)x + rem, vr);
+    auto down1 = [&](uint32_t w0, uint32_t b0, uint32_t here, uint32_t summ) -> Probe {
+        Probe p;
+        p.m1 = here & ((1u << b0) - 1u);
+        p.sm = summ & ((1u << (w0 & 31)) - 1u);
+        int32_t sw = (int32_t)(w0 >> 5);
+        if (!(p.m1 | p.sm))
+            while (!p.sm && --sw >= 0) p.sm = BM_SUMM(sw);
+        p.w = p.sm ? ((uint32_t)sw << 5) + 31u - (uint32_t)__builtin_clz(p.sm) : w0;
+        return p;
+    };
+    /* m2 = the word p.w (level 2), loaded unconditionally by the caller */
+    auto succ_of = [&](const Probe &p, uint32_t w0, uint32_t m2) -> uint32_t {
+        const uint32_t l1 = (w0 << 5) + (uint32_t)__builtin_ctz(p.m1 | 0x80000000u);
+        const uint32_t l2 = (p.w << 5) + (uint32_t)__builtin_ctz(m2 | 0x80000000u);
+        return p.m1 ? l1 : (p.sm ? l2 : WALK_NONE);
+    };
+    auto pred_of = [&](const Probe &p, uint32_t w0, uint32_t m2) -> uint32_t {
+        const uint32_t l1 = (w0 << 5) + 31u - (uint32_t)__builtin_clz(p.m1 | 1u);
+        const uint32_t l2 = (p.w << 5) + 31u - (uint32_t)__builtin_clz(m2 | 1u);
+        return p.m1 ? l1 : (p.sm ? l2 : WALK_NONE);
+    };
+    /* neighbours of rank q in the current bitmap: successor | predecessor << 16 */
+    auto query = [&](uint32_t q) -> uint32_t {
+        const uint32_t w0 = q >> 5, b0 = q & 31;
+        const uint32_t here = BM_WORD(w0), summ = BM_SUMM(w0 >> 5);
+        const Probe up = up1(w0, b0, here, summ), dn = down1(w0, b0, here, summ);
+        const uint32_t mu = BM_WORD(up.w), md = BM_WORD(dn.w);
+        return succ_of(up, w0, mu) | (pred_of(dn, w0, md) << 16);
+    };
+    /* first window minus its last position: [ta, ta+sb-1) */
+    {
+        const uint32_t b = min(ta + usb - 1, R);
+        if (region0 + reg == 0 && run == 0) {
+            /* start of the input: y < sb looks back at [0, y) only -- answer while filling */
+            for (uint32_t i = 0; i < b; i++) {
+                const uint32_t r = rk[i];
+                wb0[i] = query(r);
+                set_bit(r);
+            }
+            if (usb - 1 < R) wb0[usb - 1] = query(rk[usb - 1]);
+        } else {
+            uint32_t i = ta;
+            for (; i + 32 <= b; i += 32) {                   /* four loads in flight: the fill is bound by their latency */
+                uint32_t v[4][4];
+#pragma unroll
+                for (int g4 = 0; g4 < 4; g4++) load8(i + 8 * g4, v[g4]);
+#pragma unroll
+                for (int g4 = 0; g4 < 4; g4++)
+#pragma unroll
+                    for (int j = 0; j < 8; j++) set_bit((v[g4][j >> 1] >> (16 * (j & 1))) & 0xFFFFu);
+            }
+            for (; i + 8 <= b; i += 8) {
+                uint32_t v[4];
+                load8(i, v);
+#pragma unroll
+                for (int j = 0; j < 8; j++) set_bit((v[j >> 1] >> (16 * (j & 1))) & 0xFFFFu);
+            }
+            for (; i < b; i++) set_bit(rk[i]);
+        }
+    }
+    uint32_t r_add = ta + usb - 1 < R ? (uint32_t)rk[ta + usb - 1] : WALK_NONE;
+    /* One step.  The forward query never looks at q's own bit (strict masks), so it may read the
+     * bitmap BEFORE q is cleared, together with the backward query; and since the lane owns its bitmap
+     * the clear is a plain store of the word it has just read. */
+    auto step = [&](uint32_t q, uint32_t ry, uint32_t &resf, uint32_t &resb) {
+        if (r_add != WALK_NONE) set_bit(r_add);
+        const bool hasy = ry != WALK_NONE;
+        const uint32_t wq = q >> 5, bq = q & 31, wy = hasy ? ry >> 5 : wq, by_ = ry & 31;
+        const uint32_t hq = BM_WORD(wq), sq = BM_SUMM(wq >> 5), hy = BM_WORD(wy), sy = BM_SUMM(wy >> 5);
+        const Probe qu = up1(wq, bq, hq, sq), qd = down1(wq, bq, hq, sq);
+        const Probe yu = up1(wy, by_, hy, sy), yd = down1(wy, by_, hy, sy);
+        const uint32_t mqu = BM_WORD(qu.w), mqd = BM_WORD(qd.w), myu = BM_WORD(yu.w), myd = BM_WORD(yd.w);
+        const uint32_t left = hq & ~(1u << bq);
+        BM_WORD(wq) = left;
+        if (!left) atomicAnd(&BM_SUMM(wq >> 5), ~(1u << (wq & 31)));
+        resf = succ_of(qu, wq, mqu) | (pred_of(qd, wq, mqd) << 16);
+        resb = hasy ? succ_of(yu, wy, myu) | (pred_of(yd, wy, myd) << 16) : (WALK_NONE | (WALK_NONE << 16));
+        r_add = ry;                                          /* position t+sb enters at the next step */
+    };
+    uint32_t t = ta;
+    /* groups of 8 steps: two 16-byte rank loads and four 16-byte result stores.  vmcnt counts loads and
+     * stores alike on gfx9, so waiting for ranks also waits for every store in flight: the results of
+     * group k are therefore written at the top of group k+1, together with the loads for group k+2,
+     * and all of them have a whole group of LDS work to complete before anything waits on them. */
+    uint32_t vq[4], vy[4], nq[4] = {0, 0, 0, 0}, ny[4] = {0, 0, 0, 0}, rf[8], rb[8];
+    bool pending = false;
+    uint32_t tprev = 0;
+    auto flush = [&]() {
+        uint4 *o = reinterpret_cast<uint4 *>(of + tprev);
+        o[0] = make_uint4(rf[0], rf[1], rf[2], rf[3]);
+        o[1] = make_uint4(rf[4], rf[5], rf[6], rf[7]);
+        o = reinterpret_cast<uint4 *>(ob + tprev);
+        o[0] = make_uint4(rb[0], rb[1], rb[2], rb[3]);
+        o[1] = make_uint4(rb[4], rb[5], rb[6], rb[7]);
+    };
+    if (t + 8 <= tb) { load8(t, vq); load8(t + usb, vy); }
+    for (; t + 8 <= tb; t += 8) {
+        if (pending) flush();
+        if (t + 16 <= tb) { load8(t + 8, nq); load8(t + 8 + usb, ny); }
 #pragma unroll
         for (int j = 0; j < 8; j++) {
             const uint32_t q = (vq[j >> 1] >> (16 * (j & 1))) & 0xFFFFu;
-            const uint32_t ra = valid((int32_t)x + j + add) ? (va[j >> 1] >> (16 * (j & 1))) & 0xFFFFu : WALK_NONE;
-            const uint32_t rr = valid((int32_t)x + j + rem) ? (vr[j >> 1] >> (16 * (j & 1))) & 0xFFFFu : WALK_NONE;
-            res[j] = step(q, ra, rr);
+            const uint32_t ry = t + j + usb < R ? (vy[j >> 1] >> (16 * (j & 1))) & 0xFFFFu : WALK_NONE;
+            step(q, ry, rf[j], rb[j]);
         }
-        uint4 *o = reinterpret_cast<uint4 *>(out + (x - lt0));
-        o[0] = make_uint4(res[0], res[1], res[2], res[3]);
-        o[1] = make_uint4(res[4], res[5], res[6], res[7]);
+        pending = true;
+        tprev = t;
+#pragma unroll
+        for (int j = 0; j < 4; j++) { vq[j] = nq[j]; vy[j] = ny[j]; }
     }
-    for (; x < xb; x++) {
-        const int32_t ia = (int32_t)x + add, ir = (int32_t)x + rem;
-        out[x - lt0] = step(rk[x], valid(ia) ? (uint32_t)rk[ia] : WALK_NONE, valid(ir) ? (uint32_t)rk[ir] : WALK_NONE);
+    if (pending) flush();
+    for (; t < tb; t++) {
+        uint32_t rf, rb;
+        step(rk[t], t + usb < R ? (uint32_t)rk[t + usb] : WALK_NONE, rf, rb);
+        of[t] = rf;
+        ob[t] = rb;
     }
 #undef BM_WORD
 #undef BM_SUMM
 }
 
 /* ranks -> positions -> the two per-position results of the match stage */
-__global__ __launch_bounds__(256) void k_walk_final(const uint8_t *__restrict__ in, uint32_t n, int sb, int la, uint32_t SBu,
+__global__ __launch_bounds__(256) void k_walk_final(const uint8_t *__restrict__ in, uint32_t n, int sb, int la,
                                                     uint32_t RP, uint32_t TILE, uint32_t region0, uint32_t nregions,
                                                     const uint16_t *__restrict__ ranks, const uint32_t *__restrict__ wf,
-                                                    const uint32_t *__restrict__ wb, uint32_t *__restrict__ ps,
-                                                    uint8_t *__restrict__ maxlen)
+                                                    const uint32_t *__restrict__ wb, const uint32_t *__restrict__ wb0,
+                                                    uint32_t *__restrict__ ps, uint8_t *__restrict__ maxlen)
 {
     const uint64_t rel = (uint64_t)blockIdx.x * 256u + threadIdx.x;      /* position relative to region0*TILE */
     const uint32_t reg = (uint32_t)(rel / TILE);
@@ -848,158 +917,212 @@ __global__ __launch_bounds__(256) void k_walk_final(const uint8_t *__restrict__ 
     if (x64 >= n) return;
     const uint32_t x = (uint32_t)x64;
     const uint32_t t0 = (region0 + reg) * TILE;
-    const uint32_t rstart = t0 >= SBu ? t0 - SBu : 0;
-    const uint32_t lx = x - rstart;
+    const uint32_t lx = x - t0;
     const uint16_t *ix = ranks + (size_t)reg * 2 * RP + RP;
-    const uint32_t f = wf[rel], b = wb[rel];
+    const uint8_t *by = in + t0;
+    const uint32_t f = wf[rel];
     uint32_t P = 0, S = 0;
-    if ((uint64_t)x + (uint32_t)sb < n) {
+    if ((uint64_t)x + (uint32_t)sb < n) {                                /* only evicted positions matter */
         if ((f & 0xFFFFu) != WALK_NONE) S = (uint32_t)ix[f & 0xFFFFu] - lx;
         if ((f >> 16) != WALK_NONE) P = (uint32_t)ix[f >> 16] - lx;
     }
     ps[x] = P | (S << 16);
-    const uint32_t left = n - x;
-    const int cap = (int)(left < (uint32_t)la ? left : (uint32_t)la) - 1;
-    const uint8_t *by = in + rstart;
-    uint32_t best = 0;
-    if ((b & 0xFFFFu) != WALK_NONE) best = (uint32_t)lcp_capped<false>(by, (uint32_t)ix[b & 0xFFFFu], lx, cap);
-    if ((b >> 16) != WALK_NONE) {
-        const uint32_t l2 = (uint32_t)lcp_capped<false>(by, (uint32_t)ix[b >> 16], lx, cap);
-        best = l2 > best ? l2 : best;
-    }
-    maxlen[x] = (uint8_t)best;
+    auto longest = [&](uint32_t b, uint32_t ly) -> uint32_t {            /* max LCP with the two candidates */
+        const uint32_t left = n - (t0 + ly);
+        const int cap = (int)(left < (uint32_t)la ? left : (uint32_t)la) - 1;
+        uint32_t best = 0;
+        if ((b & 0xFFFFu) != WALK_NONE) best = (uint32_t)lcp_capped<false>(by, (uint32_t)ix[b & 0xFFFFu], ly, cap);
+        if ((b >> 16) != WALK_NONE) {
+            const uint32_t l2 = (uint32_t)lcp_capped<false>(by, (uint32_t)ix[b >> 16], ly, cap);
+            best = l2 > best ? l2 : best;
+        }
+        return best;
+    };
+    if ((uint64_t)x + (uint32_t)sb < n) maxlen[x + (uint32_t)sb] = (uint8_t)longest(wb[rel], lx + (uint32_t)sb);
+    if (region0 + reg == 0 && lx < (uint32_t)sb) maxlen[x] = (uint8_t)longest(wb0[lx], lx);
 }
 
 /* ---- large windows (RP > 16384): same walk, bitmap in global memory (L2 resident), 32-bit ranks.
  * The walker converts neighbour ranks to distances itself: forward results go straight to ps[],
- * backward ones (candidates of the longest match) to wb[] for k_walk_final_big. ---- */
-__global__ __launch_bounds__(64) void k_walk_big(const uint32_t *__restrict__ ranks, uint32_t n, int sb, uint32_t SBu, uint32_t RP,
+ * backward ones (candidates of the longest match) to wb[] / wb0[] for k_walk_final_big. ---- */
+__global__ __launch_bounds__(64) void k_walk_big(const uint32_t *__restrict__ ranks, uint32_t n, int sb, uint32_t RP,
                                                  uint32_t TILE, uint32_t region0, uint32_t nregions, uint32_t run_len,
                                                  uint32_t runs_per_tile, uint32_t *__restrict__ bitmaps,
-                                                 uint32_t *__restrict__ ps, uint32_t *__restrict__ wb)
+                                                 uint32_t *__restrict__ ps, uint32_t *__restrict__ wb, uint32_t *__restrict__ wb0)
 {
     const uint32_t NW = RP >> 5, NS = (NW + 31) >> 5;
     const uint32_t id = blockIdx.x * 64u + threadIdx.x;
-    const uint32_t dir = id & 1u;
-    const uint32_t run = (id >> 1) % runs_per_tile;
-    const uint32_t reg = (id >> 1) / runs_per_tile;
-    if (reg >= nregions) return;
+    const uint32_t run = id % runs_per_tile;
+    const uint32_t reg = id / runs_per_tile;
+    const uint32_t usb = (uint32_t)sb;
+    /* lanes without a walker stay for the cooperative fill (every lane reads one rank per round) */
     const uint64_t t0_64 = (uint64_t)(region0 + reg) * TILE;
-    if (t0_64 >= n) return;
-    const uint32_t t0 = (uint32_t)t0_64;
-    const uint32_t rstart = t0 >= SBu ? t0 - SBu : 0;
-    const uint64_t rend64 = (uint64_t)t0 + TILE + (uint32_t)sb - 1;
-    const uint32_t R = (rend64 < n ? (uint32_t)rend64 : n) - rstart;
-    const uint32_t lt0 = t0 - rstart;
-    const uint32_t lt1 = ((uint64_t)t0 + TILE < n ? t0 + TILE : n) - rstart;
-    const uint32_t xa = lt0 + run * run_len;
-    if (xa >= lt1) return;
-    const uint32_t xb = min(xa + run_len, lt1);
-    const uint32_t *rk = ranks + (size_t)reg * (2 * (size_t)RP + 8);
+    bool alive = reg < nregions && t0_64 < n;
+    const uint32_t t0 = alive ? (uint32_t)t0_64 : 0u;
+    const uint64_t rend64 = (uint64_t)t0 + TILE + usb;
+    const uint32_t R = (rend64 < n ? (uint32_t)rend64 : n) - t0;
+    const uint32_t lt1 = n - t0 < TILE ? n - t0 : TILE;
+    const uint32_t ta = run * run_len;
+    alive = alive && ta < lt1;
+    const uint32_t tb = min(ta + run_len, lt1);
+    const uint32_t *rk = ranks + (size_t)(alive ? reg : 0u) * (2 * (size_t)RP + 8);
     const uint32_t *ix = rk + RP + 8;
-    uint32_t *word = bitmaps + (size_t)id * (NW + NS);       /* zeroed by the launcher */
+    uint32_t *word = bitmaps + (size_t)id * (NW + NS);       /* every word is written by the fill below */
     uint32_t *summ = word + NW;
-    const int32_t isb = sb;
     const uint32_t NONE = 0xFFFFFFFFu;
+    const bool first = alive && region0 + reg == 0 && run == 0;
+    const uint32_t lane = threadIdx.x;
 
+    /* The bitmap is private to this wavefront, so WORKGROUP scope is all the coherence it needs: the
+     * accesses are served by this XCD's L2.  Agent scope (coherent across the eight XCDs) sends every
+     * one of them to the memory side of the fabric -- measured 15 us per step instead of ~2. */
+    auto ldw = [&](const uint32_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); };
+    auto stw = [&](uint32_t *p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); };
     auto set_bit = [&](uint32_t r) {
-        atomicOr(&word[r >> 5], 1u << (r & 31));
-        atomicOr(&summ[r >> 10], 1u << ((r >> 5) & 31));
+        __hip_atomic_fetch_or(&word[r >> 5], 1u << (r & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        __hip_atomic_fetch_or(&summ[r >> 10], 1u << ((r >> 5) & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     };
-    auto clear_bit = [&](uint32_t r) {
-        const uint32_t bit = 1u << (r & 31);
-        const uint32_t old = atomicAnd(&word[r >> 5], ~bit);
-        if ((old & ~bit) == 0) atomicAnd(&summ[r >> 10], ~(1u << ((r >> 5) & 31)));
+    /* same two-level probe as the LDS walker: level 1 = own word + its summary word, level 2 = the word
+     * the summary points at, loaded unconditionally so that a step has three batches of loads in all */
+    struct Probe { uint32_t w, m1, sm; };
+    auto up1 = [&](uint32_t w0, uint32_t b0, uint32_t here, uint32_t sm0) -> Probe {
+        Probe p;
+        p.m1 = here & ~((2u << b0) - 1u);
+        p.sm = sm0 & ~((2u << (w0 & 31)) - 1u);
+        uint32_t sw = w0 >> 5;
+        if (!(p.m1 | p.sm))
+            while (!p.sm && ++sw < NS) p.sm = ldw(&summ[sw]);
+        p.w = p.sm ? (sw << 5) + (uint32_t)__builtin_ctz(p.sm) : w0;
+        return p;
     };
-    /* first window: the 64 walkers of the wave are filled one after the other by all 64 lanes
-     * (coalesced rank loads, independent atomics) instead of each lane walking its own SB ranks */
+    auto down1 = [&](uint32_t w0, uint32_t b0, uint32_t here, uint32_t sm0) -> Probe {
+        Probe p;
+        p.m1 = here & ((1u << b0) - 1u);
+        p.sm = sm0 & ((1u << (w0 & 31)) - 1u);
+        int32_t sw = (int32_t)(w0 >> 5);
+        if (!(p.m1 | p.sm))
+            while (!p.sm && --sw >= 0) p.sm = ldw(&summ[sw]);
+        p.w = p.sm ? ((uint32_t)sw << 5) + 31u - (uint32_t)__builtin_clz(p.sm) : w0;
+        return p;
+    };
+    auto succ_of = [&](const Probe &p, uint32_t w0, uint32_t m2) -> uint32_t {
+        const uint32_t l1 = (w0 << 5) + (uint32_t)__builtin_ctz(p.m1 | 0x80000000u);
+        const uint32_t l2 = (p.w << 5) + (uint32_t)__builtin_ctz(m2 | 0x80000000u);
+        return p.m1 ? l1 : (p.sm ? l2 : NONE);
+    };
+    auto pred_of = [&](const Probe &p, uint32_t w0, uint32_t m2) -> uint32_t {
+        const uint32_t l1 = (w0 << 5) + 31u - (uint32_t)__builtin_clz(p.m1 | 1u);
+        const uint32_t l2 = (p.w << 5) + 31u - (uint32_t)__builtin_clz(m2 | 1u);
+        return p.m1 ? l1 : (p.sm ? l2 : NONE);
+    };
+    auto back = [&](uint32_t ly, uint32_t q) -> uint32_t {   /* distances from y to its two candidates */
+        const uint32_t w0 = q >> 5, b0 = q & 31;
+        const uint32_t here = ldw(&word[w0]), sm0 = ldw(&summ[w0 >> 5]);
+        const Probe up = up1(w0, b0, here, sm0), dn = down1(w0, b0, here, sm0);
+        const uint32_t mu = ldw(&word[up.w]), md = ldw(&word[dn.w]);
+        const uint32_t rs = succ_of(up, w0, mu), rp = pred_of(dn, w0, md);
+        return (rs != NONE ? ly - ix[rs] : 0u) | ((rp != NONE ? ly - ix[rp] : 0u) << 16);
+    };
+    /* First window minus its last position, [ta, ta+sb-1).  The wave builds the 64 bitmaps one after the
+     * other straight from the sorted order: 64 lanes read the positions of 64 consecutive ranks (one
+     * coalesced load), test them against the walker's window, and the ballot IS the next two bitmap
+     * words -- plain stores, no atomics, no pre-zeroed memory, and the summary falls out of the same
+     * loop.  (One L2 atomic pair per window position made this fill the most expensive part of a
+     * 65535-position window.)  The first walker of the input starts empty: it answers y < sb as it fills. */
     {
-        const int32_t lo = dir ? (int32_t)xa - isb : (int32_t)xa + 1;
-        const int32_t hi = dir ? (int32_t)xa - 1 : (int32_t)xa + isb - 1;
-        const int32_t a = lo < 0 ? 0 : lo, b = hi >= (int32_t)R ? (int32_t)R - 1 : hi;
-        const uint64_t live = __ballot(1);                    /* lanes without a walker have already left */
-        const int32_t nlive = __popcll(live), mine = __popcll(live & ((1ull << threadIdx.x) - 1ull));
+        const uint32_t a = ta, len = first ? 0u : min(ta + usb - 1, R) - ta;
+        const uint64_t live = __ballot(alive);
         for (uint32_t src = 0; src < 64; src++) {
             if (!((live >> src) & 1ull)) continue;
-            const int32_t wa = __shfl(a, (int)src, 64), wb_ = __shfl(b, (int)src, 64);
-            const uint64_t rkp = (uint64_t)__shfl((unsigned long long)(uintptr_t)rk, (int)src, 64);
+            const uint32_t wa = __shfl(a, (int)src, 64), wlen = __shfl(len, (int)src, 64);
+            const uint64_t ixp = (uint64_t)__shfl((unsigned long long)(uintptr_t)ix, (int)src, 64);
             const uint64_t wdp = (uint64_t)__shfl((unsigned long long)(uintptr_t)word, (int)src, 64);
-            const uint32_t *srk = reinterpret_cast<const uint32_t *>((uintptr_t)rkp);
+            const uint32_t *six = reinterpret_cast<const uint32_t *>((uintptr_t)ixp);
             uint32_t *sword = reinterpret_cast<uint32_t *>((uintptr_t)wdp);
-            for (int32_t i = wa + mine; i <= wb_; i += nlive) {
-                const uint32_t r = srk[i];
-                atomicOr(&sword[r >> 5], 1u << (r & 31));
-                atomicOr(&sword[NW + (r >> 10)], 1u << ((r >> 5) & 31));
+            /* 16 rounds (1024 ranks = one summary word) per iteration, all 16 loads issued before the
+             * first ballot: the fill is bound by load latency, not by instruction count.  RP >= 32768 here. */
+            for (uint32_t r0 = 0; r0 < RP; r0 += 1024) {
+                uint32_t pos[16];
+#pragma unroll
+                for (int u = 0; u < 16; u++) pos[u] = six[r0 + 64 * u + lane];   /* slots >= R hold indices >= R: never inside */
+                uint32_t sacc = 0;
+#pragma unroll
+                for (int u = 0; u < 16; u++) {
+                    const uint64_t mask = __ballot(pos[u] - wa < wlen);
+                    if (lane == 0)
+                        *reinterpret_cast<uint2 *>(sword + (r0 >> 5) + 2 * u) = make_uint2((uint32_t)mask, (uint32_t)(mask >> 32));
+                    sacc |= (((uint32_t)mask != 0u ? 1u : 0u) | ((uint32_t)(mask >> 32) != 0u ? 2u : 0u)) << (2 * u);
+                }
+                if (lane == 0) sword[NW + (r0 >> 10)] = sacc;
             }
         }
     }
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "agent");
-    const int32_t add = dir ? 0 : isb, rem = dir ? -isb : 1;
-    auto fetch = [&](int32_t i) -> uint32_t { return (i >= 0 && i < (int32_t)R) ? rk[i] : NONE; };
-    uint32_t q = rk[xa], r_add = fetch((int32_t)xa + add), r_rem = fetch((int32_t)xa + rem);
-    for (uint32_t x = xa; x < xb; x++) {
-        const uint32_t qn = x + 1 < xb ? rk[x + 1] : 0u;
-        const uint32_t an = fetch((int32_t)x + 1 + add), rn = fetch((int32_t)x + 1 + rem);
-        const uint32_t w0 = q >> 5, b0 = q & 31;
-        const uint32_t here = __hip_atomic_load(&word[w0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        uint32_t succ = NONE, pred = NONE;
-        {
-            uint32_t w = w0, m = here & ~((2u << b0) - 1u);
-            if (!m) {
-                uint32_t sw = w >> 5, sm = __hip_atomic_load(&summ[sw], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & ~((2u << (w & 31)) - 1u);
-                while (!sm && ++sw < NS) sm = __hip_atomic_load(&summ[sw], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (sm) { w = (sw << 5) + (uint32_t)__builtin_ctz(sm); m = __hip_atomic_load(&word[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-            }
-            if (m) succ = (w << 5) + (uint32_t)__builtin_ctz(m);
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    if (!alive) return;
+    if (first) {
+        const uint32_t b = min(usb - 1, R);
+        for (uint32_t i = 0; i < b; i++) {
+            const uint32_t r = rk[i];
+            wb0[i] = back(i, r);
+            set_bit(r);
         }
-        {
-            uint32_t w = w0, m = here & ((1u << b0) - 1u);
-            if (!m) {
-                int32_t sw = (int32_t)(w >> 5);
-                uint32_t sm = __hip_atomic_load(&summ[sw], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & ((1u << (w & 31)) - 1u);
-                while (!sm && --sw >= 0) sm = __hip_atomic_load(&summ[sw], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (sm) { w = ((uint32_t)sw << 5) + 31u - (uint32_t)__builtin_clz(sm); m = __hip_atomic_load(&word[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-            }
-            if (m) pred = (w << 5) + 31u - (uint32_t)__builtin_clz(m);
-        }
-        /* ranks -> distances */
-        const uint32_t ps_ = succ != NONE ? ix[succ] : 0u, pp_ = pred != NONE ? ix[pred] : 0u;
-        const uint32_t xabs = rstart + x;
-        if (dir == 0) {
-            uint32_t P = 0, S = 0;
-            if ((uint64_t)xabs + (uint32_t)sb < n) {
-                if (succ != NONE) S = ps_ - x;
-                if (pred != NONE) P = pp_ - x;
-            }
-            ps[xabs] = P | (S << 16);
-        } else {
-            wb[(size_t)reg * TILE + (x - lt0)] = (succ != NONE ? x - ps_ : 0u) | ((pred != NONE ? x - pp_ : 0u) << 16);
-        }
+        if (usb - 1 < R) wb0[usb - 1] = back(usb - 1, rk[usb - 1]);
+    }
+    auto fetch = [&](uint32_t i) -> uint32_t { return i < R ? rk[i] : NONE; };
+    uint32_t q = rk[ta], ry = fetch(ta + usb), r_add = fetch(ta + usb - 1);
+    for (uint32_t t = ta; t < tb; t++) {
+        const uint32_t qn = t + 1 < tb ? rk[t + 1] : 0u;
+        const uint32_t ryn = fetch(t + 1 + usb);
         if (r_add != NONE) set_bit(r_add);
-        if (r_rem != NONE) clear_bit(r_rem);
-        q = qn; r_add = an; r_rem = rn;
+        /* both queries read the bitmap before q is cleared: the forward one never looks at q's own bit */
+        const bool hasy = ry != NONE;
+        const uint32_t wq = q >> 5, bq = q & 31, wy = hasy ? ry >> 5 : wq, by_ = ry & 31;
+        const uint32_t hq = ldw(&word[wq]), sq = ldw(&summ[wq >> 5]), hy = ldw(&word[wy]), sy = ldw(&summ[wy >> 5]);
+        const Probe qu = up1(wq, bq, hq, sq), qd = down1(wq, bq, hq, sq);
+        const Probe yu = up1(wy, by_, hy, sy), yd = down1(wy, by_, hy, sy);
+        const uint32_t mqu = ldw(&word[qu.w]), mqd = ldw(&word[qd.w]), myu = ldw(&word[yu.w]), myd = ldw(&word[yd.w]);
+        const uint32_t left = hq & ~(1u << bq);
+        stw(&word[wq], left);
+        if (!left) __hip_atomic_fetch_and(&summ[wq >> 5], ~(1u << (wq & 31)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        const uint32_t rs = succ_of(qu, wq, mqu), rp = pred_of(qd, wq, mqd);
+        const uint32_t ys = hasy ? succ_of(yu, wy, myu) : NONE, yp = hasy ? pred_of(yd, wy, myd) : NONE;
+        /* ranks -> local indices -> distances */
+        const uint32_t is = ix[rs != NONE ? rs : 0u], ip = ix[rp != NONE ? rp : 0u];
+        const uint32_t js = ix[ys != NONE ? ys : 0u], jp = ix[yp != NONE ? yp : 0u];
+        const uint32_t xabs = t0 + t, ly = t + usb;
+        uint32_t P = 0, S = 0;
+        if ((uint64_t)xabs + usb < n) {
+            if (rs != NONE) S = is - t;
+            if (rp != NONE) P = ip - t;
+        }
+        ps[xabs] = P | (S << 16);
+        wb[(size_t)reg * TILE + t] = (ys != NONE ? ly - js : 0u) | ((yp != NONE ? ly - jp : 0u) << 16);
+        r_add = ry; q = qn; ry = ryn;
     }
 }
 
-__global__ __launch_bounds__(256) void k_walk_final_big(const uint8_t *__restrict__ in, uint32_t n, int la, uint32_t TILE,
+__global__ __launch_bounds__(256) void k_walk_final_big(const uint8_t *__restrict__ in, uint32_t n, int sb, int la, uint32_t TILE,
                                                         uint32_t region0, uint32_t nregions, const uint32_t *__restrict__ wb,
-                                                        uint8_t *__restrict__ maxlen)
+                                                        const uint32_t *__restrict__ wb0, uint8_t *__restrict__ maxlen)
 {
     const uint64_t rel = (uint64_t)blockIdx.x * 256u + threadIdx.x;
     if (rel >= (uint64_t)nregions * TILE) return;
     const uint64_t x64 = (uint64_t)region0 * TILE + rel;
     if (x64 >= n) return;
-    const uint32_t x = (uint32_t)x64;
-    const uint32_t b = wb[rel];
-    const uint32_t left = n - x;
-    const int cap = (int)(left < (uint32_t)la ? left : (uint32_t)la) - 1;
-    uint32_t best = 0;
-    if (b & 0xFFFFu) best = (uint32_t)lcp_capped<false>(in, x - (b & 0xFFFFu), x, cap);
-    if (b >> 16) {
-        const uint32_t l2 = (uint32_t)lcp_capped<false>(in, x - (b >> 16), x, cap);
-        best = l2 > best ? l2 : best;
-    }
-    maxlen[x] = (uint8_t)best;
+    auto longest = [&](uint32_t b, uint32_t y) -> uint32_t {
+        const uint32_t left = n - y;
+        const int cap = (int)(left < (uint32_t)la ? left : (uint32_t)la) - 1;
+        uint32_t best = 0;
+        if (b & 0xFFFFu) best = (uint32_t)lcp_capped<false>(in, y - (b & 0xFFFFu), y, cap);
+        if (b >> 16) {
+            const uint32_t l2 = (uint32_t)lcp_capped<false>(in, y - (b >> 16), y, cap);
+            best = l2 > best ? l2 : best;
+        }
+        return best;
+    };
+    const uint64_t y64 = x64 + (uint32_t)sb;
+    if (y64 < n) maxlen[y64] = (uint8_t)longest(wb[rel], (uint32_t)y64);
+    if (region0 == 0 && x64 < (uint32_t)sb) maxlen[x64] = (uint8_t)longest(wb0[x64], (uint32_t)x64);
 }
 
 #define WALK_RUN_BIG_DEFAULT 8192u
@@ -1015,11 +1138,11 @@ size_t lz77k_match_lds_bytes(const lz77x_geom &g)
 size_t lz77k_match_scratch_bytes(const lz77x_geom &g, uint32_t nregions)
 {
     /* fast: rank + inverse (uint16 each) per region, then the walkers' fwd/bwd results per position */
-    if (g.fast) return (size_t)nregions * ((size_t)g.RP * 4 + (size_t)g.TILE * 8) + 256;
+    if (g.fast) return (size_t)nregions * ((size_t)g.RP * 4 + (size_t)g.TILE * 8) + (size_t)g.SBu * 4 + 256;
     /* generic: rank + inverse (uint32), one global bitmap per walker, backward results per position */
     const size_t runs = (g.TILE + WALK_RUN_BIG_DEFAULT - 1) / WALK_RUN_BIG_DEFAULT;
     const size_t nws = (g.RP >> 5) + (((g.RP >> 5) + 31) >> 5);
-    return (size_t)nregions * ((2 * (size_t)g.RP + 8) * 4 + runs * 2 * nws * 4 + (size_t)g.TILE * 4) + 256;
+    return (size_t)nregions * ((2 * (size_t)g.RP + 8) * 4 + runs * nws * 4 + (size_t)g.TILE * 4) + (size_t)g.SBu * 4 + 256;
 }
 
 template <bool FAST, int MODE>
@@ -1042,6 +1165,7 @@ hipError_t lz77k_match(const uint8_t *d_in, uint32_t n, const lz77x_geom &g, uin
                        uint32_t *d_ps, uint8_t *d_maxlen, void *d_scratch, int variant, hipStream_t s, hipEvent_t *ev_sort)
 {
     if (nregions == 0) return hipSuccess;
+    if (g.shifted != !(variant == 1 || variant == 3)) return hipErrorInvalidValue;     /* layout of g must match the variant */
     if (ev_sort && !(g.fast && (variant == 0 || variant > 3))) ev_sort = nullptr;
 #define LZ77K_MATCH_ARGS d_in, n, g, region0, nregions, d_ps, d_maxlen, d_scratch, s
     if (g.fast) {
@@ -1057,22 +1181,23 @@ hipError_t lz77k_match(const uint8_t *d_in, uint32_t n, const lz77x_geom &g, uin
         uint16_t *ranks = reinterpret_cast<uint16_t *>(d_scratch);
         uint32_t *wf = reinterpret_cast<uint32_t *>(ranks + (size_t)nregions * 2 * g.RP);
         uint32_t *wb = wf + (size_t)nregions * g.TILE;
+        uint32_t *wb0 = wb + (size_t)nregions * g.TILE;
         const char *rl = getenv("LZ77X_WALK_RUN");
         uint32_t run_len = rl && atoi(rl) > 0 ? (uint32_t)atoi(rl) : WALK_RUN_DEFAULT;
         run_len = (run_len + 7u) & ~7u;
         if (run_len > g.TILE) run_len = g.TILE;
         const uint32_t runs = (g.TILE + run_len - 1) / run_len;
-        const uint64_t walkers = (uint64_t)nregions * runs * 2;
+        const uint64_t walkers = (uint64_t)nregions * runs;
         const size_t lds = ((size_t)(g.RP >> 5) + (((g.RP >> 5) + 31) >> 5)) * 64 * sizeof(uint32_t);
         if (lds > 48 * 1024) {
             e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_walk), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             if (e != hipSuccess) return e;
         }
-        hipLaunchKernelGGL(k_walk, dim3((uint32_t)((walkers + 63) / 64)), dim3(64), lds, s, ranks, n, g.sb, g.SBu, g.RP, g.TILE,
-                           region0, nregions, run_len, runs, wf, wb);
+        hipLaunchKernelGGL(k_walk, dim3((uint32_t)((walkers + 63) / 64)), dim3(64), lds, s, ranks, n, g.sb, g.RP, g.TILE,
+                           region0, nregions, run_len, runs, wf, wb, wb0);
         const uint64_t npos = (uint64_t)nregions * g.TILE;
-        hipLaunchKernelGGL(k_walk_final, dim3((uint32_t)((npos + 255) / 256)), dim3(256), 0, s, d_in, n, g.sb, g.la, g.SBu, g.RP,
-                           g.TILE, region0, nregions, ranks, wf, wb, d_ps, d_maxlen);
+        hipLaunchKernelGGL(k_walk_final, dim3((uint32_t)((npos + 255) / 256)), dim3(256), 0, s, d_in, n, g.sb, g.la, g.RP,
+                           g.TILE, region0, nregions, ranks, wf, wb, wb0, d_ps, d_maxlen);
         return hipGetLastError();
     }
     if (variant == 1) return launch_match<false, 1>(LZ77K_MATCH_ARGS);
@@ -1087,15 +1212,14 @@ hipError_t lz77k_match(const uint8_t *d_in, uint32_t n, const lz77x_geom &g, uin
         const size_t nws = (g.RP >> 5) + (((g.RP >> 5) + 31) >> 5);
         uint32_t *ranks = reinterpret_cast<uint32_t *>(d_scratch);
         uint32_t *bitmaps = ranks + (size_t)nregions * (2 * (size_t)g.RP + 8);
-        const uint64_t walkers = (uint64_t)nregions * runs * 2;
+        const uint64_t walkers = (uint64_t)nregions * runs;
         uint32_t *wb = bitmaps + walkers * nws;
-        e = hipMemsetAsync(bitmaps, 0, walkers * nws * sizeof(uint32_t), s);
-        if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(k_walk_big, dim3((uint32_t)((walkers + 63) / 64)), dim3(64), 0, s, ranks, n, g.sb, g.SBu, g.RP, g.TILE,
-                           region0, nregions, run_len, runs, bitmaps, d_ps, wb);
+        uint32_t *wb0 = wb + (size_t)nregions * g.TILE;
+        hipLaunchKernelGGL(k_walk_big, dim3((uint32_t)((walkers + 63) / 64)), dim3(64), 0, s, ranks, n, g.sb, g.RP, g.TILE,
+                           region0, nregions, run_len, runs, bitmaps, d_ps, wb, wb0);
         const uint64_t npos = (uint64_t)nregions * g.TILE;
-        hipLaunchKernelGGL(k_walk_final_big, dim3((uint32_t)((npos + 255) / 256)), dim3(256), 0, s, d_in, n, g.la, g.TILE, region0,
-                           nregions, wb, d_maxlen);
+        hipLaunchKernelGGL(k_walk_final_big, dim3((uint32_t)((npos + 255) / 256)), dim3(256), 0, s, d_in, n, g.sb, g.la, g.TILE,
+                           region0, nregions, wb, wb0, d_maxlen);
         return hipGetLastError();
     }
 #undef LZ77K_MATCH_ARGS

@@ -17,13 +17,23 @@
 extern "C" {
 #endif
 
-/* Geometry of one call: token widths and the region decomposition of the match kernel.
+/* Geometry of one call: token widths and the region decomposition of the match stage.
  *
- * A region is the unit one workgroup owns: the TILE positions [t0, t0+TILE) whose
- * results it writes, plus the read-only halo it needs: SBu >= SB positions to the left
- * (backward window of the longest-match search) and SB-1 to the right
- * (forward window of the in-order neighbour search, A.5 stage A).  RP is the padded
- * (power of two) number of positions sorted per region.
+ * A region is the unit one workgroup sorts: the positions [t0, t0+TILE+SB) of the input, TILE =
+ * RP - SBu, RP a power of two >= 4*SBu (so TILE+SB <= RP slots are sorted per TILE positions: 4/3
+ * redundancy).  One window W_t = [t, t+SB) slides over it for t in [t0, t0+TILE) and answers BOTH
+ * neighbour queries of the match stage at every step:
+ *     forward  (SURVEY A.5 stage A): in-order neighbours of x = t among W_t \ {t}    -> ps[x]
+ *     backward (A.3, longest match): in-order neighbours of y = t+SB inside W_t      -> maxlen[y]
+ * so region r writes ps[] for [t0, t0+TILE) and maxlen[] for [t0+SB, t0+TILE+SB) -- the backward
+ * results are shifted by SB against the forward ones, which is what lets one sorted set and one
+ * window walk serve both (region 0 also answers y < SB while its first window fills).  A launch
+ * of regions [r0, r1) therefore needs maxlen[r0*TILE .. r0*TILE+SB) from the launch before it;
+ * whoever starts at r0 > 0 without one (a shard) launches region r0-1 as well.
+ *
+ * `shifted == 0` is the layout of the exhaustive pair-scan cross-checks (LZ77X_MATCH_VARIANT 1/3):
+ * TILE = RP - SBu - SB positions [t0, t0+TILE) with halos of SBu to the left and SB-1 to the right,
+ * both results on the same TILE.
  */
 typedef struct lz77x_geom {
     int sb, la;            /* search buffer, lookahead */
@@ -31,11 +41,13 @@ typedef struct lz77x_geom {
     uint32_t SBu;          /* sb rounded up to a multiple of 8 */
     uint32_t RP;           /* padded region size (power of two) */
     uint32_t TILE;         /* positions produced per region (multiple of 8) */
-    int fast;              /* 1: ranks are 16-bit and live in LDS (RP <= 32768) */
+    int fast;              /* 1: ranks are 16-bit and live in LDS (RP <= 16384) */
+    int shifted;           /* 1: production layout (above); 0: pair-scan layout */
 } lz77x_geom;
 
 int  lz77x_bitof(int n);                                   /* bitio.c:41-43, integer form */
 void lz77x_make_geom(lz77x_geom *g, int sb, int la);
+void lz77x_geom_legacy(lz77x_geom *g);                     /* switch g to the pair-scan layout */
 
 /* ---- sequential host stage (hoststage.c) -------------------------------------------- */
 

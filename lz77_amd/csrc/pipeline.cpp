@@ -214,6 +214,15 @@ int shard_contexts(int want, std::vector<Ctx *> &cs)
     return LZ77X_OK;
 }
 
+/* geometry of an encode: the production layout unless a pair-scan cross-check is selected */
+static void make_encode_geom(lz77x_geom *g, int sb, int la)
+{
+    lz77x_make_geom(g, sb, la);
+    const char *vs = getenv("LZ77X_MATCH_VARIANT");
+    const int variant = vs ? atoi(vs) : 0;
+    if (variant == 1 || variant == 3) lz77x_geom_legacy(g);
+}
+
 /* src is a device pointer on cs[0]'s device (src_on_device, single shard only) or a host pointer.
  * On success the stream is in cs[0]->out (device) and *zn holds its size.
  *
@@ -254,11 +263,11 @@ int encode_core(std::vector<Ctx *> &cs, const void *src, bool src_on_device, siz
         const size_t nx = n > (size_t)g.sb ? n - (size_t)g.sb : 0;     /* evicted positions */
         const uint32_t ring_mask = lz77x_prio_mask(g.sb);
         const uint32_t nregions = (uint32_t)((n + g.TILE - 1) / g.TILE);
-        /* host chunk: >= 512 regions (~4M positions on the LDS path); match launch: a group of chunks
-         * (4096 LDS-path regions so that the walkers fill the chip; 512 large-window regions are one
-         * full round of resident workgroups already) */
-        uint32_t per_chunk = (uint32_t)(((size_t)4 << 20) / g.TILE);
-        if (per_chunk < 512) per_chunk = 512;
+        /* host chunk: ~4M positions on the LDS path, >= 512 regions for large windows; match launch: a
+         * group of chunks (8 on the LDS path so that the walkers fill the chip; 512 large-window regions
+         * are one full round of resident workgroups already) */
+        uint32_t per_chunk = (uint32_t)((((size_t)4 << 20) + g.TILE - 1) / g.TILE);
+        if (!g.fast && per_chunk < 512) per_chunk = 512;
         const char *cs_env = getenv("LZ77X_CHUNK_REGIONS");
         if (cs_env && atoi(cs_env) > 0) per_chunk = (uint32_t)atoi(cs_env);
         uint32_t group = g.fast ? 8u : 1u;
@@ -330,7 +339,7 @@ int encode_core(std::vector<Ctx *> &cs, const void *src, bool src_on_device, siz
             Ctx &c = *cs[d];
             HIPCHK(hipSetDevice(c.device));
             const uint64_t most = (uint64_t)per_chunk * group < nregions ? (uint64_t)per_chunk * group : nregions;
-            if ((rc = c.scratch.need(lz77k_match_scratch_bytes(g, (uint32_t)most)))) return rc;
+            if ((rc = c.scratch.need(lz77k_match_scratch_bytes(g, (uint32_t)most + (d > 0 ? 1u : 0u))))) return rc;
             if ((rc = c.ps.need((n + 8) * 4))) return rc;
             if ((rc = c.cells.need((n + 8) * 4))) return rc;
             if ((rc = c.maxlen.need(n + 8))) return rc;
@@ -381,9 +390,14 @@ int encode_core(std::vector<Ctx *> &cs, const void *src, bool src_on_device, siz
         auto enqueue_group = [&](const Group &G) -> int {
             Ctx &c = *cs[G.d];
             HIPCHK(hipSetDevice(c.device));
-            const uint32_t r0 = G.ci * per_chunk;
+            uint32_t r0 = G.ci * per_chunk;
             uint32_t nr = G.nchunks * per_chunk;
             if (nr > nregions - r0) nr = nregions - r0;
+            if (g.shifted && G.d > 0 && G.ci == first_chunk[G.d] && r0 > 0) {
+                /* first launch of a shard: maxlen[] of its first sb positions comes from the region before */
+                r0--;
+                nr++;
+            }
             if (G.d == 0) HIPCHK(hipEventRecord(c.match_ev[2 * launches0], kstream(G.d)));
             HIPCHK(lz77k_match(c.in.as<uint8_t>(), n32, g, r0, nr, c.ps.as<uint32_t>(), c.maxlen.as<uint8_t>(),
                                c.scratch.p, variant, kstream(G.d), G.d == 0 ? &c.sort_ev[2 * launches0] : nullptr));
@@ -812,7 +826,7 @@ int lz77x_encode(const uint8_t *in, size_t n, int sb, int la, uint8_t **out, siz
     if ((rc = shard_contexts(shards < 1 ? 1 : shards, cs))) return rc;
     TRACE("runtime + context init", t0);
     lz77x_geom g;
-    lz77x_make_geom(&g, sb, la);
+    make_encode_geom(&g, sb, la);
     size_t zn = 0;
     const double t1 = now_ms();
     if ((rc = encode_core(cs, in, false, n, g, g_ctx.stream, &zn))) return rc;
@@ -836,7 +850,7 @@ int lz77x_encode_device(const void *d_in, size_t n, int sb, int la, void *d_out,
     std::vector<Ctx *> cs;
     if ((rc = shard_contexts(1, cs))) return rc;      /* device-resident buffers: the caller's device only */
     lz77x_geom g;
-    lz77x_make_geom(&g, sb, la);
+    make_encode_geom(&g, sb, la);
     hipStream_t s = (hipStream_t)stream;
     size_t zn = 0;
     if ((rc = encode_core(cs, d_in, true, n, g, s, &zn))) return rc;
@@ -973,7 +987,7 @@ static int run_match_only(const uint8_t *in, size_t n, int sb, int la, lz77x_geo
     if (rc) return rc;
     if ((rc = primary_context())) return rc;
     if (n > LZ77X_MAX_N) return LZ77X_E_TOOBIG;
-    lz77x_make_geom(g, sb, la);
+    make_encode_geom(g, sb, la);
     Ctx &c = g_ctx;
     hipStream_t s = c.stream;
     if ((rc = c.in.need(n + LZ77X_PAD + 16))) return rc;

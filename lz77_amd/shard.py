@@ -29,7 +29,7 @@ def geometry(sb: int, la: int) -> dict:
     while rp < 4 * sbu:
         rp <<= 1
     return {"sb": sb, "la": la, "ob": bitof(sb), "lb": bitof(la), "T": bitof(sb) + bitof(la) + 8,
-            "SBu": sbu, "RP": rp, "TILE": (rp - sbu - sb) & ~7, "fast": rp <= 16384}
+            "SBu": sbu, "RP": rp, "TILE": rp - sbu, "fast": rp <= 16384}
 
 
 def stream_seed(base_seed: int, rank: int) -> int:
@@ -57,7 +57,8 @@ def plan_positions(n: int, world: int, sb: int, la: int) -> list:
         r0 = nreg * r // world
         r1 = nreg * (r + 1) // world
         b, e = min(r0 * tile, n), min(r1 * tile, n)
-        out.append(Shard(r, r0, r1 - r0, b, e, max(0, b - g["SBu"]) if e > b else b,
+        # a shard that does not start at 0 also runs the region before its first one (lz77x_internal.h)
+        out.append(Shard(r, r0, r1 - r0, b, e, max(0, b - tile) if e > b else b,
                          min(n, e + sb + la) if e > b else b))
     return out
 
@@ -72,3 +73,34 @@ def aggregate_time(dt: float, dist=None) -> float:
         t = t.cuda()
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
+
+
+def _parse_cpulist(text):
+    cpus = set()
+    for part in text.strip().split(","):
+        if not part:
+            continue
+        lo, _, hi = part.partition("-")
+        cpus.update(range(int(lo), int(hi or lo) + 1))
+    return cpus
+
+
+def bind_to_device_numa(pci_bus_id: str):
+    """Pin this process (and the threads it creates later: the library's recurrence thread, the pages
+    it first-touches for the pinned rings) to the CPUs local to the GPU with the given PCI address
+    ("0000:c1:00.0"), the per-rank equivalent of `numactl --cpunodebind`.  The host recurrence streams
+    5 B per position out of pinned memory the GPU writes, so a rank whose threads sit on the other
+    socket pays the inter-socket hop on its critical path.  Best effort: returns the CPU count it
+    bound to, or 0 when the topology is not exposed / the node has one socket / nothing would change."""
+    import os
+    try:
+        with open("/sys/bus/pci/devices/%s/local_cpulist" % pci_bus_id.lower()) as f:
+            local = _parse_cpulist(f.read())
+        allowed = os.sched_getaffinity(0)
+        want = local & allowed
+        if not want or want == allowed:
+            return 0
+        os.sched_setaffinity(0, want)
+        return len(want)
+    except (OSError, ValueError, AttributeError):
+        return 0

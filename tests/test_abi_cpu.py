@@ -77,9 +77,9 @@ def test_geometry_mirror():
     for sb, la in ((4095, 15), (65535, 255), (1, 2), (5, 3), (1000, 10), (4096, 16), (8191, 15), (8192, 16)):
         g = shard.geometry(sb, la)
         assert g["T"] == O.token_bits(sb, la)
-        assert g["TILE"] % 8 == 0 and g["TILE"] >= 8 and g["TILE"] + g["SBu"] + sb <= g["RP"]
+        assert g["TILE"] % 8 == 0 and g["TILE"] >= 3 * g["SBu"] and g["TILE"] + sb <= g["RP"]
         assert g["RP"] & (g["RP"] - 1) == 0
-    assert shard.geometry(4095, 15)["TILE"] == 8192 and shard.geometry(4095, 15)["fast"]
+    assert shard.geometry(4095, 15)["TILE"] == 12288 and shard.geometry(4095, 15)["fast"]
     assert not shard.geometry(65535, 255)["fast"]
 
 
@@ -146,7 +146,7 @@ assert sum(int(s[1]) for s in allsz) == (n + g["TILE"] - 1) // g["TILE"]
 for a, b in zip(plan, plan[1:]):
     assert a.end == b.begin and a.region0 + a.nregions == b.region0
 assert mine.halo_begin <= mine.begin and mine.halo_end >= mine.end
-assert mine.begin - mine.halo_begin in (0, g["SBu"]) and mine.halo_end - mine.end <= sb + la
+assert mine.begin - mine.halo_begin in (0, g["TILE"]) and mine.halo_end - mine.end <= sb + la
 seeds = [shard.stream_seed(0x5EED0001, r) for r in range(world)]
 assert len(set(seeds)) == world
 t = shard.aggregate_time(1.0 + rank, dist)
@@ -166,3 +166,10 @@ def test_two_rank_plan_gloo(tmp_path):
                        capture_output=True, text=True, env=env, timeout=240)
     assert r.returncode == 0, r.stdout + r.stderr
     assert r.stdout.count("ok") == 2
+
+
+def test_numa_binding_helper_is_best_effort():
+    from lz77_amd.shard import _parse_cpulist, bind_to_device_numa
+    assert _parse_cpulist("0-3,8,10-11\n") == {0, 1, 2, 3, 8, 10, 11}
+    assert _parse_cpulist("") == set()
+    assert bind_to_device_numa("ffff:ff:1f.0") == 0          # no such device: nothing changes, no exception
