@@ -719,6 +719,11 @@ __global__ __launch_bounds__(MATCH_BLOCK, (FAST && MODE == 3) ? 8 : 1) void k_ma
  */
 #define WALK_NONE 0xFFFFu
 
+typedef __attribute__((address_space(1))) uint32_t g_u32;
+typedef __attribute__((address_space(1))) uint64_t g_u64;
+struct u32x2 { uint32_t x, y; };
+typedef __attribute__((address_space(1))) u32x2 g_uint2;
+
 __global__ __launch_bounds__(64) void k_walk(const uint16_t *__restrict__ ranks, uint32_t n, int sb, uint32_t RP,
                                              uint32_t TILE, uint32_t region0, uint32_t nregions, uint32_t run_len,
                                              uint32_t runs_per_tile, uint32_t *__restrict__ wf, uint32_t *__restrict__ wb,
@@ -948,7 +953,7 @@ __global__ __launch_bounds__(256) void k_walk_final(const uint8_t *__restrict__ 
 __global__ __launch_bounds__(64) void k_walk_big(const uint32_t *__restrict__ ranks, uint32_t n, int sb, uint32_t RP,
                                                  uint32_t TILE, uint32_t region0, uint32_t nregions, uint32_t run_len,
                                                  uint32_t runs_per_tile, uint32_t *__restrict__ bitmaps,
-                                                 uint32_t *__restrict__ ps, uint32_t *__restrict__ wb, uint32_t *__restrict__ wb0)
+                                                 uint2 *__restrict__ wf, uint2 *__restrict__ wb, uint2 *__restrict__ wb0, int dbg)
 {
     const uint32_t NW = RP >> 5, NS = (NW + 31) >> 5;
     const uint32_t id = blockIdx.x * 64u + threadIdx.x;
@@ -965,10 +970,12 @@ __global__ __launch_bounds__(64) void k_walk_big(const uint32_t *__restrict__ ra
     const uint32_t ta = run * run_len;
     alive = alive && ta < lt1;
     const uint32_t tb = min(ta + run_len, lt1);
-    const uint32_t *rk = ranks + (size_t)(alive ? reg : 0u) * (2 * (size_t)RP + 8);
-    const uint32_t *ix = rk + RP + 8;
-    uint32_t *word = bitmaps + (size_t)id * (NW + NS);       /* every word is written by the fill below */
-    uint32_t *summ = word + NW;
+    /* explicit global address space: pointers that are selected or rebuilt per lane would otherwise
+     * decay to FLAT accesses, which count in lgkmcnt -- every cross-lane shuffle of the fill would then
+     * wait for all stores in flight */
+    const g_u32 *rk = (const g_u32 *)ranks + (size_t)(alive ? reg : 0u) * (2 * (size_t)RP + 8);
+    g_u32 *word = (g_u32 *)bitmaps + (size_t)id * (NW + NS);   /* every word is written by the fill below */
+    g_u32 *summ = word + NW;
     const uint32_t NONE = 0xFFFFFFFFu;
     const bool first = alive && region0 + reg == 0 && run == 0;
     const uint32_t lane = threadIdx.x;
@@ -976,52 +983,50 @@ __global__ __launch_bounds__(64) void k_walk_big(const uint32_t *__restrict__ ra
     /* The bitmap is private to this wavefront, so WORKGROUP scope is all the coherence it needs: the
      * accesses are served by this XCD's L2.  Agent scope (coherent across the eight XCDs) sends every
      * one of them to the memory side of the fabric -- measured 15 us per step instead of ~2. */
-    auto ldw = [&](const uint32_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); };
-    auto stw = [&](uint32_t *p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); };
+    auto ldw = [&](const g_u32 *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); };
+    auto stw = [&](g_u32 *p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); };
     auto set_bit = [&](uint32_t r) {
         __hip_atomic_fetch_or(&word[r >> 5], 1u << (r & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         __hip_atomic_fetch_or(&summ[r >> 10], 1u << ((r >> 5) & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     };
-    /* same two-level probe as the LDS walker: level 1 = own word + its summary word, level 2 = the word
-     * the summary points at, loaded unconditionally so that a step has three batches of loads in all */
-    struct Probe { uint32_t w, m1, sm; };
-    auto up1 = [&](uint32_t w0, uint32_t b0, uint32_t here, uint32_t sm0) -> Probe {
-        Probe p;
-        p.m1 = here & ~((2u << b0) - 1u);
-        p.sm = sm0 & ~((2u << (w0 & 31)) - 1u);
-        uint32_t sw = w0 >> 5;
-        if (!(p.m1 | p.sm))
-            while (!p.sm && ++sw < NS) p.sm = ldw(&summ[sw]);
-        p.w = p.sm ? (sw << 5) + (uint32_t)__builtin_ctz(p.sm) : w0;
-        return p;
+    /* These bitmaps live in HBM (34 KB per walker, hundreds of MB per launch): every access is a random
+     * 64-byte line and the walk is bound by how many of them a step needs.  So a query looks at its own
+     * word, then at the ADJACENT word (same line 15 times out of 16; at 25 % fill a word is empty one
+     * time in 10^4), and only then at the summary -- which is still maintained, so that the nearly empty
+     * windows at the start of the input cost O(1) per query too.  Results leave as ranks; the lookups
+     * rank -> position are k_walk_final_big's (there they are independent and massively parallel). */
+    auto up_slow = [&](uint32_t w) -> uint32_t {             /* first set rank in words > w, or NONE */
+        uint32_t sw = w >> 5, sm = ldw(&summ[sw]) & ~((2u << (w & 31)) - 1u);
+        while (!sm && ++sw < NS) sm = ldw(&summ[sw]);
+        if (!sm) return NONE;
+        const uint32_t w2 = (sw << 5) + (uint32_t)__builtin_ctz(sm);
+        return (w2 << 5) + (uint32_t)__builtin_ctz(ldw(&word[w2]));
     };
-    auto down1 = [&](uint32_t w0, uint32_t b0, uint32_t here, uint32_t sm0) -> Probe {
-        Probe p;
-        p.m1 = here & ((1u << b0) - 1u);
-        p.sm = sm0 & ((1u << (w0 & 31)) - 1u);
-        int32_t sw = (int32_t)(w0 >> 5);
-        if (!(p.m1 | p.sm))
-            while (!p.sm && --sw >= 0) p.sm = ldw(&summ[sw]);
-        p.w = p.sm ? ((uint32_t)sw << 5) + 31u - (uint32_t)__builtin_clz(p.sm) : w0;
-        return p;
+    auto down_slow = [&](uint32_t w) -> uint32_t {           /* last set rank in words < w, or NONE */
+        int32_t sw = (int32_t)(w >> 5);
+        uint32_t sm = ldw(&summ[sw]) & ((1u << (w & 31)) - 1u);
+        while (!sm && --sw >= 0) sm = ldw(&summ[sw]);
+        if (!sm) return NONE;
+        const uint32_t w2 = ((uint32_t)sw << 5) + 31u - (uint32_t)__builtin_clz(sm);
+        return (w2 << 5) + 31u - (uint32_t)__builtin_clz(ldw(&word[w2]));
     };
-    auto succ_of = [&](const Probe &p, uint32_t w0, uint32_t m2) -> uint32_t {
-        const uint32_t l1 = (w0 << 5) + (uint32_t)__builtin_ctz(p.m1 | 0x80000000u);
-        const uint32_t l2 = (p.w << 5) + (uint32_t)__builtin_ctz(m2 | 0x80000000u);
-        return p.m1 ? l1 : (p.sm ? l2 : NONE);
+    /* successor / predecessor of bit b0 of word w0, given that word and its two neighbours */
+    auto succ_of = [&](uint32_t w0, uint32_t b0, uint32_t here, uint32_t next) -> uint32_t {
+        const uint32_t m1 = here & ~((2u << b0) - 1u);
+        if (m1) return (w0 << 5) + (uint32_t)__builtin_ctz(m1);
+        if (w0 + 1 < NW && next) return ((w0 + 1) << 5) + (uint32_t)__builtin_ctz(next);
+        return w0 + 1 < NW ? up_slow(w0 + 1) : NONE;
     };
-    auto pred_of = [&](const Probe &p, uint32_t w0, uint32_t m2) -> uint32_t {
-        const uint32_t l1 = (w0 << 5) + 31u - (uint32_t)__builtin_clz(p.m1 | 1u);
-        const uint32_t l2 = (p.w << 5) + 31u - (uint32_t)__builtin_clz(m2 | 1u);
-        return p.m1 ? l1 : (p.sm ? l2 : NONE);
+    auto pred_of = [&](uint32_t w0, uint32_t b0, uint32_t here, uint32_t prev) -> uint32_t {
+        const uint32_t m1 = here & ((1u << b0) - 1u);
+        if (m1) return (w0 << 5) + 31u - (uint32_t)__builtin_clz(m1);
+        if (w0 > 0 && prev) return ((w0 - 1) << 5) + 31u - (uint32_t)__builtin_clz(prev);
+        return w0 > 0 ? down_slow(w0 - 1) : NONE;
     };
-    auto back = [&](uint32_t ly, uint32_t q) -> uint32_t {   /* distances from y to its two candidates */
+    auto back = [&](uint32_t q) -> uint2 {                   /* ranks of q's two neighbours */
         const uint32_t w0 = q >> 5, b0 = q & 31;
-        const uint32_t here = ldw(&word[w0]), sm0 = ldw(&summ[w0 >> 5]);
-        const Probe up = up1(w0, b0, here, sm0), dn = down1(w0, b0, here, sm0);
-        const uint32_t mu = ldw(&word[up.w]), md = ldw(&word[dn.w]);
-        const uint32_t rs = succ_of(up, w0, mu), rp = pred_of(dn, w0, md);
-        return (rs != NONE ? ly - ix[rs] : 0u) | ((rp != NONE ? ly - ix[rp] : 0u) << 16);
+        const uint32_t here = ldw(&word[w0]), next = ldw(&word[min(w0 + 1, NW - 1)]), prev = ldw(&word[w0 ? w0 - 1 : 0]);
+        return make_uint2(succ_of(w0, b0, here, next), pred_of(w0, b0, here, prev));
     };
     /* First window minus its last position, [ta, ta+sb-1).  The wave builds the 64 bitmaps one after the
      * other straight from the sorted order: 64 lanes read the positions of 64 consecutive ranks (one
@@ -1031,43 +1036,51 @@ __global__ __launch_bounds__(64) void k_walk_big(const uint32_t *__restrict__ ra
      * 65535-position window.)  The first walker of the input starts empty: it answers y < sb as it fills. */
     {
         const uint32_t a = ta, len = first ? 0u : min(ta + usb - 1, R) - ta;
-        const uint64_t live = __ballot(alive);
-        for (uint32_t src = 0; src < 64; src++) {
-            if (!((live >> src) & 1ull)) continue;
-            const uint32_t wa = __shfl(a, (int)src, 64), wlen = __shfl(len, (int)src, 64);
-            const uint64_t ixp = (uint64_t)__shfl((unsigned long long)(uintptr_t)ix, (int)src, 64);
-            const uint64_t wdp = (uint64_t)__shfl((unsigned long long)(uintptr_t)word, (int)src, 64);
-            const uint32_t *six = reinterpret_cast<const uint32_t *>((uintptr_t)ixp);
-            uint32_t *sword = reinterpret_cast<uint32_t *>((uintptr_t)wdp);
+        uint64_t todo = (dbg & 1) ? 0ull : __ballot(alive);
+        while (todo) {
+            /* the walkers of one region share its sorted order: load it once per 1024 ranks, test it
+             * against each of their windows */
+            const int src = __builtin_ctzll(todo);
+            const uint32_t sreg = __shfl(reg, src, 64);
+            const uint64_t group = __ballot(alive && reg == sreg);
+            todo &= ~group;
+            const g_u32 *six = (const g_u32 *)ranks + (size_t)sreg * (2 * (size_t)RP + 8) + RP + 8;
             /* 16 rounds (1024 ranks = one summary word) per iteration, all 16 loads issued before the
              * first ballot: the fill is bound by load latency, not by instruction count.  RP >= 32768 here. */
             for (uint32_t r0 = 0; r0 < RP; r0 += 1024) {
                 uint32_t pos[16];
 #pragma unroll
                 for (int u = 0; u < 16; u++) pos[u] = six[r0 + 64 * u + lane];   /* slots >= R hold indices >= R: never inside */
-                uint32_t sacc = 0;
+                for (uint64_t mem = group; mem; mem &= mem - 1) {
+                    const int m = __builtin_ctzll(mem);
+                    const uint32_t wa = __shfl(a, m, 64), wlen = __shfl(len, m, 64);
+                    g_u32 *sword = (g_u32 *)bitmaps + ((size_t)blockIdx.x * 64u + (uint32_t)m) * (NW + NS);
+                    uint32_t sacc = 0;
 #pragma unroll
-                for (int u = 0; u < 16; u++) {
-                    const uint64_t mask = __ballot(pos[u] - wa < wlen);
-                    if (lane == 0)
-                        *reinterpret_cast<uint2 *>(sword + (r0 >> 5) + 2 * u) = make_uint2((uint32_t)mask, (uint32_t)(mask >> 32));
-                    sacc |= (((uint32_t)mask != 0u ? 1u : 0u) | ((uint32_t)(mask >> 32) != 0u ? 2u : 0u)) << (2 * u);
+                    for (int u = 0; u < 16; u++) {
+                        const uint64_t mask = __ballot(pos[u] - wa < wlen);
+                        if (lane == 0) *(g_u64 *)(sword + (r0 >> 5) + 2 * u) = mask;     /* two words, little endian */
+                        sacc |= (((uint32_t)mask != 0u ? 1u : 0u) | ((uint32_t)(mask >> 32) != 0u ? 2u : 0u)) << (2 * u);
+                    }
+                    if (lane == 0) sword[NW + (r0 >> 10)] = sacc;
                 }
-                if (lane == 0) sword[NW + (r0 >> 10)] = sacc;
             }
         }
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-    if (!alive) return;
+    if (!alive || (dbg & 2)) return;
+    g_uint2 *out0 = (g_uint2 *)wb0;
     if (first) {
         const uint32_t b = min(usb - 1, R);
         for (uint32_t i = 0; i < b; i++) {
             const uint32_t r = rk[i];
-            wb0[i] = back(i, r);
+            const uint2 v = back(r);
+            out0[i].x = v.x; out0[i].y = v.y;
             set_bit(r);
         }
-        if (usb - 1 < R) wb0[usb - 1] = back(usb - 1, rk[usb - 1]);
+        if (usb - 1 < R) { const uint2 v = back(rk[usb - 1]); out0[usb - 1].x = v.x; out0[usb - 1].y = v.y; }
     }
+    g_uint2 *of = (g_uint2 *)wf + (size_t)reg * TILE, *ob = (g_uint2 *)wb + (size_t)reg * TILE;
     auto fetch = [&](uint32_t i) -> uint32_t { return i < R ? rk[i] : NONE; };
     uint32_t q = rk[ta], ry = fetch(ta + usb), r_add = fetch(ta + usb - 1);
     for (uint32_t t = ta; t < tb; t++) {
@@ -1077,57 +1090,71 @@ __global__ __launch_bounds__(64) void k_walk_big(const uint32_t *__restrict__ ra
         /* both queries read the bitmap before q is cleared: the forward one never looks at q's own bit */
         const bool hasy = ry != NONE;
         const uint32_t wq = q >> 5, bq = q & 31, wy = hasy ? ry >> 5 : wq, by_ = ry & 31;
-        const uint32_t hq = ldw(&word[wq]), sq = ldw(&summ[wq >> 5]), hy = ldw(&word[wy]), sy = ldw(&summ[wy >> 5]);
-        const Probe qu = up1(wq, bq, hq, sq), qd = down1(wq, bq, hq, sq);
-        const Probe yu = up1(wy, by_, hy, sy), yd = down1(wy, by_, hy, sy);
-        const uint32_t mqu = ldw(&word[qu.w]), mqd = ldw(&word[qd.w]), myu = ldw(&word[yu.w]), myd = ldw(&word[yd.w]);
+        const uint32_t hq = ldw(&word[wq]), hy = ldw(&word[wy]);
+        const uint32_t nq = ldw(&word[min(wq + 1, NW - 1)]), pq = ldw(&word[wq ? wq - 1 : 0]);
+        const uint32_t ny = ldw(&word[min(wy + 1, NW - 1)]), py = ldw(&word[wy ? wy - 1 : 0]);
         const uint32_t left = hq & ~(1u << bq);
         stw(&word[wq], left);
         if (!left) __hip_atomic_fetch_and(&summ[wq >> 5], ~(1u << (wq & 31)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        const uint32_t rs = succ_of(qu, wq, mqu), rp = pred_of(qd, wq, mqd);
-        const uint32_t ys = hasy ? succ_of(yu, wy, myu) : NONE, yp = hasy ? pred_of(yd, wy, myd) : NONE;
-        /* ranks -> local indices -> distances */
-        const uint32_t is = ix[rs != NONE ? rs : 0u], ip = ix[rp != NONE ? rp : 0u];
-        const uint32_t js = ix[ys != NONE ? ys : 0u], jp = ix[yp != NONE ? yp : 0u];
-        const uint32_t xabs = t0 + t, ly = t + usb;
-        uint32_t P = 0, S = 0;
-        if ((uint64_t)xabs + usb < n) {
-            if (rs != NONE) S = is - t;
-            if (rp != NONE) P = ip - t;
-        }
-        ps[xabs] = P | (S << 16);
-        wb[(size_t)reg * TILE + t] = (ys != NONE ? ly - js : 0u) | ((yp != NONE ? ly - jp : 0u) << 16);
+        const uint32_t rs = succ_of(wq, bq, hq, nq), rp = pred_of(wq, bq, hq, pq);
+        const uint32_t ys = hasy ? succ_of(wy, by_, hy, ny) : NONE, yp = hasy ? pred_of(wy, by_, hy, py) : NONE;
+        of[t].x = rs; of[t].y = rp;
+        ob[t].x = ys; ob[t].y = yp;
         r_add = ry; q = qn; ry = ryn;
     }
 }
 
-__global__ __launch_bounds__(256) void k_walk_final_big(const uint8_t *__restrict__ in, uint32_t n, int sb, int la, uint32_t TILE,
-                                                        uint32_t region0, uint32_t nregions, const uint32_t *__restrict__ wb,
-                                                        const uint32_t *__restrict__ wb0, uint8_t *__restrict__ maxlen)
+__global__ __launch_bounds__(256) void k_walk_final_big(const uint8_t *__restrict__ in, uint32_t n, int sb, int la, uint32_t RP,
+                                                        uint32_t TILE, uint32_t region0, uint32_t nregions,
+                                                        const uint32_t *__restrict__ ranks, const uint2 *__restrict__ wf,
+                                                        const uint2 *__restrict__ wb, const uint2 *__restrict__ wb0,
+                                                        uint32_t *__restrict__ ps, uint8_t *__restrict__ maxlen)
 {
     const uint64_t rel = (uint64_t)blockIdx.x * 256u + threadIdx.x;
     if (rel >= (uint64_t)nregions * TILE) return;
     const uint64_t x64 = (uint64_t)region0 * TILE + rel;
     if (x64 >= n) return;
-    auto longest = [&](uint32_t b, uint32_t y) -> uint32_t {
-        const uint32_t left = n - y;
+    const uint32_t reg = (uint32_t)(rel / TILE);
+    const uint32_t t0 = (region0 + reg) * TILE, lx = (uint32_t)x64 - t0;
+    const uint32_t *ix = ranks + (size_t)reg * (2 * (size_t)RP + 8) + RP + 8;
+    const uint32_t NONE = 0xFFFFFFFFu;
+    const uint8_t *by = in + t0;
+    {
+        const uint2 f = wf[rel];
+        uint32_t P = 0, S = 0;
+        if (x64 + (uint32_t)sb < n) {                                    /* only evicted positions matter */
+            if (f.x != NONE) S = ix[f.x] - lx;
+            if (f.y != NONE) P = ix[f.y] - lx;
+        }
+        ps[x64] = P | (S << 16);
+    }
+    auto longest = [&](uint2 b, uint32_t ly) -> uint32_t {               /* max LCP with the two candidates */
+        const uint32_t left = n - (t0 + ly);
         const int cap = (int)(left < (uint32_t)la ? left : (uint32_t)la) - 1;
         uint32_t best = 0;
-        if (b & 0xFFFFu) best = (uint32_t)lcp_capped<false>(in, y - (b & 0xFFFFu), y, cap);
-        if (b >> 16) {
-            const uint32_t l2 = (uint32_t)lcp_capped<false>(in, y - (b >> 16), y, cap);
+        if (b.x != NONE) best = (uint32_t)lcp_capped<false>(by, ix[b.x], ly, cap);
+        if (b.y != NONE) {
+            const uint32_t l2 = (uint32_t)lcp_capped<false>(by, ix[b.y], ly, cap);
             best = l2 > best ? l2 : best;
         }
         return best;
     };
     const uint64_t y64 = x64 + (uint32_t)sb;
-    if (y64 < n) maxlen[y64] = (uint8_t)longest(wb[rel], (uint32_t)y64);
-    if (region0 == 0 && x64 < (uint32_t)sb) maxlen[x64] = (uint8_t)longest(wb0[x64], (uint32_t)x64);
+    if (y64 < n) maxlen[y64] = (uint8_t)longest(wb[rel], lx + (uint32_t)sb);
+    if (region0 + reg == 0 && lx < (uint32_t)sb) maxlen[x64] = (uint8_t)longest(wb0[lx], lx);
 }
 
-#define WALK_RUN_BIG_DEFAULT 8192u
+#define WALK_RUN_BIG_DEFAULT 4096u
 
 #define WALK_RUN_DEFAULT 2048u
+
+/* steps per walker on the large-window path (LZ77X_WALK_RUN_BIG overrides) */
+static uint32_t walk_run_big(const lz77x_geom &g)
+{
+    const char *rl = getenv("LZ77X_WALK_RUN_BIG");
+    uint32_t run_len = rl && atoi(rl) > 0 ? (uint32_t)atoi(rl) : WALK_RUN_BIG_DEFAULT;
+    return run_len < g.TILE ? run_len : g.TILE;
+}
 
 size_t lz77k_match_lds_bytes(const lz77x_geom &g)
 {
@@ -1140,9 +1167,10 @@ size_t lz77k_match_scratch_bytes(const lz77x_geom &g, uint32_t nregions)
     /* fast: rank + inverse (uint16 each) per region, then the walkers' fwd/bwd results per position */
     if (g.fast) return (size_t)nregions * ((size_t)g.RP * 4 + (size_t)g.TILE * 8) + (size_t)g.SBu * 4 + 256;
     /* generic: rank + inverse (uint32), one global bitmap per walker, backward results per position */
-    const size_t runs = (g.TILE + WALK_RUN_BIG_DEFAULT - 1) / WALK_RUN_BIG_DEFAULT;
+    const size_t run_len = walk_run_big(g);
+    const size_t runs = (g.TILE + run_len - 1) / run_len;
     const size_t nws = (g.RP >> 5) + (((g.RP >> 5) + 31) >> 5);
-    return (size_t)nregions * ((2 * (size_t)g.RP + 8) * 4 + runs * nws * 4 + (size_t)g.TILE * 4) + (size_t)g.SBu * 4 + 256;
+    return (size_t)nregions * ((2 * (size_t)g.RP + 8) * 4 + runs * nws * 4 + (size_t)g.TILE * 16) + (size_t)g.SBu * 8 + 256;
 }
 
 template <bool FAST, int MODE>
@@ -1207,19 +1235,20 @@ hipError_t lz77k_match(const uint8_t *d_in, uint32_t n, const lz77x_geom &g, uin
         /* production for large windows: sort (ranks stay in scratch) -> global-bitmap walkers -> finalize */
         hipError_t e = launch_match<false, 3>(LZ77K_MATCH_ARGS);
         if (e != hipSuccess) return e;
-        const uint32_t run_len = WALK_RUN_BIG_DEFAULT < g.TILE ? WALK_RUN_BIG_DEFAULT : g.TILE;
+        const uint32_t run_len = walk_run_big(g);
         const uint32_t runs = (g.TILE + run_len - 1) / run_len;
         const size_t nws = (g.RP >> 5) + (((g.RP >> 5) + 31) >> 5);
         uint32_t *ranks = reinterpret_cast<uint32_t *>(d_scratch);
         uint32_t *bitmaps = ranks + (size_t)nregions * (2 * (size_t)g.RP + 8);
         const uint64_t walkers = (uint64_t)nregions * runs;
-        uint32_t *wb = bitmaps + walkers * nws;
-        uint32_t *wb0 = wb + (size_t)nregions * g.TILE;
+        uint2 *wf = reinterpret_cast<uint2 *>(bitmaps + walkers * nws);      /* (2RP+8)*4 and nws*4 are multiples of 8 */
+        uint2 *wb = wf + (size_t)nregions * g.TILE;
+        uint2 *wb0 = wb + (size_t)nregions * g.TILE;
         hipLaunchKernelGGL(k_walk_big, dim3((uint32_t)((walkers + 63) / 64)), dim3(64), 0, s, ranks, n, g.sb, g.RP, g.TILE,
-                           region0, nregions, run_len, runs, bitmaps, d_ps, wb, wb0);
+                           region0, nregions, run_len, runs, bitmaps, wf, wb, wb0, getenv("LZ77X_WALK_DEBUG") ? atoi(getenv("LZ77X_WALK_DEBUG")) : 0);
         const uint64_t npos = (uint64_t)nregions * g.TILE;
-        hipLaunchKernelGGL(k_walk_final_big, dim3((uint32_t)((npos + 255) / 256)), dim3(256), 0, s, d_in, n, g.sb, g.la, g.TILE,
-                           region0, nregions, wb, wb0, d_maxlen);
+        hipLaunchKernelGGL(k_walk_final_big, dim3((uint32_t)((npos + 255) / 256)), dim3(256), 0, s, d_in, n, g.sb, g.la, g.RP, g.TILE,
+                           region0, nregions, ranks, wf, wb, wb0, d_ps, d_maxlen);
         return hipGetLastError();
     }
 #undef LZ77K_MATCH_ARGS
