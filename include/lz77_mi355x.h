@@ -107,6 +107,10 @@ typedef struct lz77x_stats {
     uint64_t transfers;       /* stage-B priority hand-overs */
     uint32_t match_launches;  /* launches of the region kernel in the call */
     uint32_t decode_rounds;   /* pointer-jumping rounds */
+    double k_walk_ms;         /* of k_match_ms: the window-walker kernel alone (0 if that path was not taken) */
+    double k_tiebreak_ms;     /* of k_token_ms: the tie-break kernel alone (k_tokens_tile / k_tokens_big) */
+    uint32_t token_launches;  /* launches of the tie-break kernel in the call */
+    uint32_t reserved;
 } lz77x_stats;
 int lz77x_last_stats(lz77x_stats *st);
 

@@ -42,7 +42,8 @@ class Stats(ctypes.Structure):
                 ("host_stageb_ms", ctypes.c_double), ("copy_ms", ctypes.c_double),
                 ("n", ctypes.c_uint64), ("zn", ctypes.c_uint64), ("ntok", ctypes.c_uint64),
                 ("transfers", ctypes.c_uint64), ("match_launches", ctypes.c_uint32),
-                ("decode_rounds", ctypes.c_uint32)]
+                ("decode_rounds", ctypes.c_uint32), ("k_walk_ms", ctypes.c_double), ("k_tiebreak_ms", ctypes.c_double),
+                ("token_launches", ctypes.c_uint32), ("reserved", ctypes.c_uint32)]
 
     def as_dict(self) -> dict:
         return {k: getattr(self, k) for k, _ in self._fields_}

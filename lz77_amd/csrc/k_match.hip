@@ -501,12 +501,22 @@ __global__ __launch_bounds__(MATCH_BLOCK, (FAST && MODE == 3) ? 8 : 1) void k_ma
             constexpr uint32_t CH = 16 * MATCH_BLOCK;
             uint32_t *lix = reinterpret_cast<uint32_t *>(smem);          /* CH words */
             uint32_t *src = reinterpret_cast<uint32_t *>(ix), *dst = reinterpret_cast<uint32_t *>(rk);
+            /* a chunk is CH CONSECUTIVE positions: its CH + la key bytes fit LDS even though the region's
+             * do not, so the chunk sorts compare out of LDS exactly like the small-window path */
+            uint8_t *lby = smem + CH * sizeof(uint32_t);
             for (uint32_t c = 0; c < RP / CH; c++) {
-                for (uint32_t i = tid; i < CH; i += MATCH_BLOCK) lix[i] = c * CH + i;
+                const uint32_t cb = c * CH;
+                const uint32_t Rl = R > cb ? (R - cb < CH ? R - cb : CH) : 0u;       /* valid slots of this chunk */
+                const uint32_t nb = Rl ? (Rl + (uint32_t)la + 24 + 3) & ~3u : 0u;
+                for (uint32_t i = tid * 4; i < nb; i += MATCH_BLOCK * 4)
+                    *reinterpret_cast<uint32_t *>(lby + i) = ld32u(by + cb + i);
+                for (uint32_t i = tid; i < CH; i += MATCH_BLOCK) lix[i] = i;
                 __syncthreads();
-                region_sort_merge<uint32_t, false>(lix, by, R, la, tid);
-                for (uint32_t i = tid * 4; i < CH; i += MATCH_BLOCK * 4)
-                    *reinterpret_cast<uint4 *>(src + c * CH + i) = *reinterpret_cast<const uint4 *>(lix + i);
+                if (Rl) region_sort_merge<uint32_t, true>(lix, lby, Rl, la, tid);
+                for (uint32_t i = tid * 4; i < CH; i += MATCH_BLOCK * 4) {                /* slots >= Rl stay >= R */
+                    const uint4 v = *reinterpret_cast<const uint4 *>(lix + i);
+                    *reinterpret_cast<uint4 *>(src + cb + i) = make_uint4(v.x + cb, v.y + cb, v.z + cb, v.w + cb);
+                }
                 __syncthreads();
             }
             for (uint32_t L = CH; L < RP; L <<= 1) {
@@ -1158,7 +1168,8 @@ static uint32_t walk_run_big(const lz77x_geom &g)
 
 size_t lz77k_match_lds_bytes(const lz77x_geom &g)
 {
-    if (!g.fast) return g.RP > 16u * MATCH_BLOCK ? (size_t)16 * MATCH_BLOCK * sizeof(uint32_t) : 0;
+    /* large windows: one chunk of the index (uint32) + that chunk's key bytes (CH + la + slack) */
+    if (!g.fast) return g.RP > 16u * MATCH_BLOCK ? (size_t)16 * MATCH_BLOCK * (sizeof(uint32_t) + 1) + 512 : 0;
     return (size_t)g.RP * 2 + (size_t)(g.RP + 8) * 2;      /* ix + union{bytes, rk}: RP >= 4096 > la + 11 */
 }
 
@@ -1194,7 +1205,7 @@ hipError_t lz77k_match(const uint8_t *d_in, uint32_t n, const lz77x_geom &g, uin
 {
     if (nregions == 0) return hipSuccess;
     if (g.shifted != !(variant == 1 || variant == 3)) return hipErrorInvalidValue;     /* layout of g must match the variant */
-    if (ev_sort && !(g.fast && (variant == 0 || variant > 3))) ev_sort = nullptr;
+    if (ev_sort && !(variant == 0 || variant > 3)) ev_sort = nullptr;
 #define LZ77K_MATCH_ARGS d_in, n, g, region0, nregions, d_ps, d_maxlen, d_scratch, s
     if (g.fast) {
         if (variant == 1) return launch_match<true, 1>(LZ77K_MATCH_ARGS);
@@ -1223,6 +1234,7 @@ hipError_t lz77k_match(const uint8_t *d_in, uint32_t n, const lz77x_geom &g, uin
         }
         hipLaunchKernelGGL(k_walk, dim3((uint32_t)((walkers + 63) / 64)), dim3(64), lds, s, ranks, n, g.sb, g.RP, g.TILE,
                            region0, nregions, run_len, runs, wf, wb, wb0);
+        if (ev_sort && (e = hipEventRecord(ev_sort[2], s)) != hipSuccess) return e;
         const uint64_t npos = (uint64_t)nregions * g.TILE;
         hipLaunchKernelGGL(k_walk_final, dim3((uint32_t)((npos + 255) / 256)), dim3(256), 0, s, d_in, n, g.sb, g.la, g.RP,
                            g.TILE, region0, nregions, ranks, wf, wb, wb0, d_ps, d_maxlen);
@@ -1233,8 +1245,11 @@ hipError_t lz77k_match(const uint8_t *d_in, uint32_t n, const lz77x_geom &g, uin
     if (variant == 3) return launch_match<false, 0>(LZ77K_MATCH_ARGS);         /* exhaustive pair scan */
     {
         /* production for large windows: sort (ranks stay in scratch) -> global-bitmap walkers -> finalize */
-        hipError_t e = launch_match<false, 3>(LZ77K_MATCH_ARGS);
+        hipError_t e = ev_sort ? hipEventRecord(ev_sort[0], s) : hipSuccess;
         if (e != hipSuccess) return e;
+        e = launch_match<false, 3>(LZ77K_MATCH_ARGS);
+        if (e != hipSuccess) return e;
+        if (ev_sort && (e = hipEventRecord(ev_sort[1], s)) != hipSuccess) return e;
         const uint32_t run_len = walk_run_big(g);
         const uint32_t runs = (g.TILE + run_len - 1) / run_len;
         const size_t nws = (g.RP >> 5) + (((g.RP >> 5) + 31) >> 5);
@@ -1246,6 +1261,7 @@ hipError_t lz77k_match(const uint8_t *d_in, uint32_t n, const lz77x_geom &g, uin
         uint2 *wb0 = wb + (size_t)nregions * g.TILE;
         hipLaunchKernelGGL(k_walk_big, dim3((uint32_t)((walkers + 63) / 64)), dim3(64), 0, s, ranks, n, g.sb, g.RP, g.TILE,
                            region0, nregions, run_len, runs, bitmaps, wf, wb, wb0, getenv("LZ77X_WALK_DEBUG") ? atoi(getenv("LZ77X_WALK_DEBUG")) : 0);
+        if (ev_sort && (e = hipEventRecord(ev_sort[2], s)) != hipSuccess) return e;
         const uint64_t npos = (uint64_t)nregions * g.TILE;
         hipLaunchKernelGGL(k_walk_final_big, dim3((uint32_t)((npos + 255) / 256)), dim3(256), 0, s, d_in, n, g.sb, g.la, g.RP, g.TILE,
                            region0, nregions, ranks, wf, wb, wb0, d_ps, d_maxlen);

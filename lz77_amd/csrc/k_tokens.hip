@@ -436,9 +436,10 @@ size_t lz77k_tokens_tmp_bytes(uint32_t n) { return ((size_t)(n / TOK_TILE) + 8) 
 hipError_t lz77k_tokens(const uint8_t *d_in, uint32_t n, const lz77x_geom &g, const uint32_t *d_chain, uint32_t ntok,
                         const uint8_t *d_maxlen, const uint32_t *d_ofs, const uint2 *d_ent, uint32_t dbase,
                         uint32_t pos0, uint32_t pos1, uint32_t *d_tokval, uint32_t *d_tstart, void *d_index, int variant,
-                        hipStream_t s)
+                        hipStream_t s, hipEvent_t *ev_tie)
 {
     if (ntok == 0) return hipSuccess;
+#define TIE_EV(i) do { if (ev_tie) { hipError_t ee_ = hipEventRecord(ev_tie[i], s); if (ee_ != hipSuccess) return ee_; } } while (0)
     if (variant == 0 && g.sb > 8192 && d_index) {
         const uint32_t ntiles = (pos1 - pos0 + BIG_TT - 1) / BIG_TT;
         const uint32_t span = BIG_TT + (uint32_t)g.sb + 8;
@@ -450,8 +451,10 @@ hipError_t lz77k_tokens(const uint8_t *d_in, uint32_t n, const lz77x_geom &g, co
         hipLaunchKernelGGL(k_bidx_count, grid, dim3(256), 0, s, d_in, g.sb, pos0, pos1, bs);
         hipLaunchKernelGGL(k_bidx_scan, dim3(ntiles), dim3(1024), 0, s, bs);
         hipLaunchKernelGGL(k_bidx_fill, grid, dim3(256), 0, s, d_in, g.sb, pos0, pos1, bs, blist, span);
+        TIE_EV(0);
         hipLaunchKernelGGL(k_tokens_big, dim3((ntok + 3) / 4), dim3(256), 0, s, d_in, n, g.sb, g.ob, g.lb, d_chain, ntok, d_maxlen,
                            d_ofs, d_ent, dbase, pos0, bs, blist, span, d_tokval);
+        TIE_EV(1);
         return hipGetLastError();
     }
     if ((variant == 0 || variant == 2) && g.sb <= 8192 && d_tstart) {
@@ -471,14 +474,19 @@ hipError_t lz77k_tokens(const uint8_t *d_in, uint32_t n, const lz77x_geom &g, co
             if (e != hipSuccess) return e;
         }
         hipLaunchKernelGGL(k_tok_bounds, dim3((ntok + 256) / 256), dim3(256), 0, s, d_chain, ntok, pos0, ntiles, d_tstart);
+        TIE_EV(0);
         hipLaunchKernelGGL(fn, dim3(ntiles), dim3(TOK_BLOCK), lds, s, d_in, n, g.sb, g.la, g.ob, g.lb, d_chain,
                            d_tstart, d_maxlen, d_ofs, d_ent, dbase, pos0, pos1, d_tokval, ent_cap, lofs_off, lent_off, bkt_off);
+        TIE_EV(1);
         return hipGetLastError();
     }
     const uint32_t blocks = (ntok + 3) / 4;
+    TIE_EV(0);
     hipLaunchKernelGGL(k_tokens, dim3(blocks), dim3(256), 0, s, d_in, n, g.sb, g.ob, g.lb, d_chain, ntok, d_maxlen, d_ofs, d_ent,
                        dbase, d_tokval);
+    TIE_EV(1);
     return hipGetLastError();
+#undef TIE_EV
 }
 
 /* ------------------------------------------------------------------ k_pack ----------- */

@@ -87,7 +87,7 @@ size_t lz77k_match_lds_bytes(const lz77x_geom &g);
 hipError_t lz77k_match(const uint8_t *d_in, uint32_t n, const lz77x_geom &g,
                        uint32_t region0, uint32_t nregions,
                        uint32_t *d_ps, uint8_t *d_maxlen, void *d_scratch, int variant, hipStream_t s,
-                       hipEvent_t *ev_sort = nullptr /* [2]: recorded around the region-sort kernel */);
+                       hipEvent_t *ev_sort = nullptr /* [3]: before the region sort, between sort and walkers, after the walkers */);
 
 hipError_t lz77k_fill_pad(uint8_t *d_in, uint32_t n, hipStream_t s);
 
@@ -116,7 +116,8 @@ hipError_t lz77k_tokens(const uint8_t *d_in, uint32_t n, const lz77x_geom &g,
                         const uint32_t *d_chain, uint32_t ntok, const uint8_t *d_maxlen,
                         const uint32_t *d_ofs, const uint2 *d_ent, uint32_t dbase,
                         uint32_t pos0, uint32_t pos1, uint32_t *d_tokval,
-                        uint32_t *d_tstart, void *d_index, int variant, hipStream_t s);
+                        uint32_t *d_tstart, void *d_index, int variant, hipStream_t s,
+                        hipEvent_t *ev_tie = nullptr /* [2]: recorded around the tie-break kernel */);
 
 /* words [w0, w0+nw) of the output stream (word 0 = header) from tokval[0..ntok) */
 hipError_t lz77k_pack(const uint32_t *d_tokval, uint64_t ntok, const lz77x_geom &g,

@@ -131,7 +131,7 @@ struct Ctx {
                                                 still waits for a later match launch) */
     hipStream_t tok = nullptr;               /* per-chunk index + tie-break + pack kernels */
     hipEvent_t ev[6] = {};
-    std::vector<hipEvent_t> chunk_ev, tok_ev, sort_ev, match_ev;
+    std::vector<hipEvent_t> chunk_ev, tok_ev, sort_ev, match_ev, tie_ev;
     DevBuf in, ps, maxlen, scratch, xval, chain, ofs, ent, tokval, out, scantmp;
     DevBuf z, len1, dst, ptr, flag, tstart, bidx, cells;
     PinBuf h_ps, h_maxlen, h_xval, h_chain, h_small, h_tok, h_stage;
@@ -259,6 +259,7 @@ int encode_core(std::vector<Ctx *> &cs, const void *src, bool src_on_device, siz
     uint64_t transfers = 0;
     bool sort_timed = false;
     std::vector<uint32_t> owner;
+    std::vector<char> tie_timed;
     if (n) {
         const size_t nx = n > (size_t)g.sb ? n - (size_t)g.sb : 0;     /* evicted positions */
         const uint32_t ring_mask = lz77x_prio_mask(g.sb);
@@ -359,12 +360,17 @@ int encode_core(std::vector<Ctx *> &cs, const void *src, bool src_on_device, siz
                 HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming | hipEventBlockingSync));
                 c.chunk_ev.push_back(e);
             }
+            while (c.sort_ev.size() < 3 * (size_t)nchunks) {
+                hipEvent_t e;
+                HIPCHK(hipEventCreate(&e));                                    /* region sort | walkers */
+                c.sort_ev.push_back(e);
+            }
             while (c.tok_ev.size() < 2 * (size_t)nchunks) {
                 hipEvent_t e;
                 HIPCHK(hipEventCreate(&e));                                    /* token-stream kernel time */
                 c.tok_ev.push_back(e);
-                HIPCHK(hipEventCreate(&e));                                    /* region-sort kernel time */
-                c.sort_ev.push_back(e);
+                HIPCHK(hipEventCreate(&e));                                    /* tie-break kernel time */
+                c.tie_ev.push_back(e);
                 HIPCHK(hipEventCreate(&e));                                    /* whole match group time */
                 c.match_ev.push_back(e);
             }
@@ -400,7 +406,7 @@ int encode_core(std::vector<Ctx *> &cs, const void *src, bool src_on_device, siz
             }
             if (G.d == 0) HIPCHK(hipEventRecord(c.match_ev[2 * launches0], kstream(G.d)));
             HIPCHK(lz77k_match(c.in.as<uint8_t>(), n32, g, r0, nr, c.ps.as<uint32_t>(), c.maxlen.as<uint8_t>(),
-                               c.scratch.p, variant, kstream(G.d), G.d == 0 ? &c.sort_ev[2 * launches0] : nullptr));
+                               c.scratch.p, variant, kstream(G.d), G.d == 0 ? &c.sort_ev[3 * launches0] : nullptr));
             g_stats.match_launches++;
             {
                 const size_t gb = (size_t)r0 * g.TILE;
@@ -410,7 +416,7 @@ int encode_core(std::vector<Ctx *> &cs, const void *src, bool src_on_device, siz
             }
             if (G.d == 0) {
                 HIPCHK(hipEventRecord(c.match_ev[2 * launches0 + 1], kstream(G.d)));
-                sort_timed = g.fast && variant == 0;
+                sort_timed = variant == 0 || variant > 3;
                 launches0++;
             }
             HIPCHK(hipEventRecord(c.chunk_ev[3 * G.ci], kstream(G.d)));
@@ -469,6 +475,7 @@ int encode_core(std::vector<Ctx *> &cs, const void *src, bool src_on_device, siz
         size_t ntok_sz = 0, chain_p = 0, gi = 0;
         std::vector<size_t> tok_sent(D, 0), x_sent(D, 0), toks_at(nchunks + 1, 0);   /* tokens before chunk ci */
         std::vector<uint32_t> lookback;
+        tie_timed.assign(nchunks, 0);
         double t_chain = 0;
         int err = LZ77X_OK;
         HIPCHK(hipEventRecord(c0.ev[0], kstream(0)));
@@ -562,7 +569,9 @@ int encode_core(std::vector<Ctx *> &cs, const void *src, bool src_on_device, siz
                                           (uint32_t)x_new, c.flag.as<unsigned long long>() + 1)) != hipSuccess) return q;
                 if ((q = lz77k_tokens(c.in.as<uint8_t>(), n32, g, c.chain.as<uint32_t>() + tok_sent[d], (uint32_t)(ntok_sz - tok_sent[d]),
                                       c.maxlen.as<uint8_t>(), c.ofs.as<uint32_t>(), c.ent.as<uint2>(), dbase, (uint32_t)b, (uint32_t)e,
-                                      c.tokval.as<uint32_t>() + tok_sent[d], c.tstart.as<uint32_t>(), c.bidx.p, tvariant, tstream(d))) != hipSuccess) return q;
+                                      c.tokval.as<uint32_t>() + tok_sent[d], c.tstart.as<uint32_t>(), c.bidx.p, tvariant, tstream(d),
+                                      &c.tie_ev[2 * ci])) != hipSuccess) return q;
+                tie_timed[ci] = ntok_sz > tok_sent[d];
                 if ((q = hipEventRecord(c.tok_ev[2 * ci + 1], tstream(d))) != hipSuccess) return q;
                 return tstream(d) == c.tok ? hipSuccess : hipStreamWaitEvent(c.tok, c.tok_ev[2 * ci + 1], 0);
             };
@@ -655,13 +664,27 @@ int encode_core(std::vector<Ctx *> &cs, const void *src, bool src_on_device, siz
         tok_ms += ms;
     }
     g_stats.k_token_ms = tok_ms;
+    {
+        double tie_ms = 0;
+        for (uint32_t ci = 0; ci < nchunks_done && ci < tie_timed.size(); ci++) {
+            if (!tie_timed[ci]) continue;
+            Ctx &c = *cs[owner[ci]];
+            HIPCHK(hipEventElapsedTime(&ms, c.tie_ev[2 * ci], c.tie_ev[2 * ci + 1]));
+            tie_ms += ms;
+            g_stats.token_launches++;
+        }
+        g_stats.k_tiebreak_ms = tie_ms;
+    }
     if (sort_timed && D == 1) {
-        double sort_ms = 0;
+        double sort_ms = 0, walk_ms = 0;
         for (uint32_t i = 0; i < launches0_total; i++) {
-            HIPCHK(hipEventElapsedTime(&ms, c0.sort_ev[2 * i], c0.sort_ev[2 * i + 1]));
+            HIPCHK(hipEventElapsedTime(&ms, c0.sort_ev[3 * i], c0.sort_ev[3 * i + 1]));
             sort_ms += ms;
+            HIPCHK(hipEventElapsedTime(&ms, c0.sort_ev[3 * i + 1], c0.sort_ev[3 * i + 2]));
+            walk_ms += ms;
         }
         g_stats.k_sort_ms = sort_ms;
+        g_stats.k_walk_ms = walk_ms;
     }
     g_stats.n = n;
     g_stats.zn = *zn;
@@ -945,7 +968,7 @@ void ctx_release(Ctx &c)
         b->cap = 0;
     }
     for (PinBuf *b : {&c.h_ps, &c.h_maxlen, &c.h_xval, &c.h_chain, &c.h_small, &c.h_tok, &c.h_stage}) b->release();
-    for (auto *v : {&c.chunk_ev, &c.tok_ev, &c.sort_ev, &c.match_ev}) {
+    for (auto *v : {&c.chunk_ev, &c.tok_ev, &c.sort_ev, &c.match_ev, &c.tie_ev}) {
         for (hipEvent_t ev : *v) e = hipEventDestroy(ev);
         v->clear();
     }
