@@ -42,20 +42,57 @@ __global__ void k_dec_expand(const uint32_t *__restrict__ tokval, const uint32_t
 
 /* pointer jumping, two hops per pass: ptr[j] <- ptr[ptr[ptr[j]]] until every byte points at a literal.
  * A chain of depth d shrinks to ~d/3 per pass (5 passes for the depth-136 chains of text); concurrent
- * updates of other entries only ever move them further along the same chain, so any interleaving is safe. */
-__global__ void k_dec_jump(uint32_t *__restrict__ ptr, uint32_t n, uint32_t *__restrict__ changed)
+ * updates of other entries only ever move them further along the same chain, so any interleaving is safe.
+ * The first pass visits every byte and appends the ones that moved to a work list; later passes visit
+ * only the list of the pass before (most bytes resolve at once: passes 2.. touch a fraction of ptr[]).
+ * An entry leaves the list one pass after it has reached its literal. */
+#define JUMP_ITEMS 8
+__global__ __launch_bounds__(256) void k_dec_jump(uint32_t *__restrict__ ptr, uint32_t total, const uint32_t *__restrict__ in_list,
+                                                  uint32_t *__restrict__ out_list, uint32_t *__restrict__ out_count)
 {
-    bool any = false;
-    for (uint32_t j = blockIdx.x * blockDim.x + threadIdx.x; j < n; j += gridDim.x * blockDim.x) {
-        const uint32_t p = ptr[j];
-        if (p == j) continue;
-        const uint32_t q = ptr[p];
-        if (q == p) continue;
-        const uint32_t r = ptr[q];
-        ptr[j] = r;
-        any = true;
+    __shared__ uint32_t wtot[4], bbase;
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const uint64_t below = (1ull << lane) - 1ull;
+    for (uint32_t base = blockIdx.x * (256u * JUMP_ITEMS); base < total; base += gridDim.x * (256u * JUMP_ITEMS)) {
+        uint32_t j[JUMP_ITEMS];
+        uint64_t m[JUMP_ITEMS];
+        uint32_t mine = 0;
+#pragma unroll
+        for (int u = 0; u < JUMP_ITEMS; u++) {
+            const uint32_t idx = base + 256u * u + threadIdx.x;
+            bool keep = false;
+            j[u] = 0;
+            if (idx < total) {
+                j[u] = in_list ? in_list[idx] : idx;
+                const uint32_t p = ptr[j[u]];
+                if (p != j[u]) {
+                    const uint32_t q = ptr[p];
+                    if (q != p) {
+                        ptr[j[u]] = ptr[q];
+                        keep = true;
+                    }
+                }
+            }
+            m[u] = __ballot(keep);
+            mine += (uint32_t)__popcll(m[u]);
+        }
+        /* one atomic per 2048 entries: a single counter cannot take one per wavefront (1.5 M of them) */
+        if (lane == 0) wtot[wave] = mine;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const uint32_t t = wtot[0] + wtot[1] + wtot[2] + wtot[3];
+            bbase = t ? atomicAdd(out_count, t) : 0u;
+        }
+        __syncthreads();
+        uint32_t slot = bbase;
+        for (uint32_t w = 0; w < wave; w++) slot += wtot[w];
+#pragma unroll
+        for (int u = 0; u < JUMP_ITEMS; u++) {
+            if ((m[u] >> lane) & 1ull) out_list[slot + (uint32_t)__popcll(m[u] & below)] = j[u];
+            slot += (uint32_t)__popcll(m[u]);
+        }
+        __syncthreads();                                      /* wtot / bbase are reused by the next round */
     }
-    if (any) *changed = 1;
 }
 
 __global__ void k_dec_gather(uint8_t *__restrict__ out, const uint32_t *__restrict__ ptr, uint32_t n)
@@ -80,11 +117,13 @@ hipError_t lz77k_dec_expand(const uint32_t *d_tokval, const uint32_t *d_dst, uin
     return hipGetLastError();
 }
 
-hipError_t lz77k_dec_jump(uint32_t *d_ptr, uint32_t n, uint32_t *d_changed, hipStream_t s)
+hipError_t lz77k_dec_jump(uint32_t *d_ptr, uint32_t total, const uint32_t *d_in_list, uint32_t *d_out_list, uint32_t *d_out_count,
+                          hipStream_t s)
 {
-    if (n == 0) return hipSuccess;
-    const uint32_t blocks = min((n + 255u) / 256u, 256u * 32u);
-    hipLaunchKernelGGL(k_dec_jump, dim3(blocks), dim3(256), 0, s, d_ptr, n, d_changed);
+    if (total == 0) return hipSuccess;
+    const uint32_t per = 256u * JUMP_ITEMS;
+    const uint32_t blocks = min((total + per - 1) / per, 256u * 16u);
+    hipLaunchKernelGGL(k_dec_jump, dim3(blocks), dim3(256), 0, s, d_ptr, total, d_in_list, d_out_list, d_out_count);
     return hipGetLastError();
 }
 

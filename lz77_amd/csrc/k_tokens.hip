@@ -233,17 +233,32 @@ __global__ __launch_bounds__(TOK_BLOCK) void k_tokens_tile(const uint8_t *__rest
         for (uint32_t j = 0; j < 64; j++) {
             const uint32_t k = kb + j * (TOK_BLOCK / 64);
             if (k >= k1) break;
-            const uint32_t p = __shfl(p_l, j, 64), len = __shfl(len_l, j, 64);
+            /* j is wave-uniform: v_readlane, not a ds_bpermute round trip */
+            const uint32_t p = (uint32_t)__builtin_amdgcn_readlane((int)p_l, (int)j);
+            const uint32_t len = (uint32_t)__builtin_amdgcn_readlane((int)len_l, (int)j);
             const uint32_t qo = p - wbase;
             const uint32_t next = by[qo + len];
             uint32_t off = 0;
             if (len > 0) {
                 const uint32_t cmin = p > usb ? p - usb : 0u;
                 uint64_t best = ~0ull;
+                /* the token's own first 16 bytes, once per token (every lane compares against them) */
+                uint32_t qw[4];
+#pragma unroll
+                for (int i = 0; i < 4; i++) qw[i] = ld32_at<true>(by, qo + 4 * i);
                 /* candidate c shares len bytes with p?  then its priority at time p */
                 auto consider = [&](uint32_t c) {
                     const uint32_t co = c - wbase;
-                    for (uint32_t i = 0; i < len; i += 4) {
+#pragma unroll
+                    for (int i = 0; i < 4; i++) {
+                        if ((uint32_t)(4 * i) < len) {
+                            uint32_t x = ld32_at<true>(by, co + 4 * i) ^ qw[i];
+                            const uint32_t rem = len - 4 * i;
+                            if (rem < 4) x &= (1u << (8 * rem)) - 1u;
+                            if (x) return;
+                        }
+                    }
+                    for (uint32_t i = 16; i < len; i += 4) {
                         uint32_t x = ld32_at<true>(by, co + i) ^ ld32_at<true>(by, qo + i);
                         const uint32_t rem = len - i;
                         if (rem < 4) x &= (1u << (8 * rem)) - 1u;
@@ -266,14 +281,14 @@ __global__ __launch_bounds__(TOK_BLOCK) void k_tokens_tile(const uint8_t *__rest
                     best = key < best ? key : best;
                 };
                 if (BUCKET && len >= 2) {
-                    const uint32_t h = tok_hash(by[qo], by[qo + 1]);
+                    const uint32_t h = tok_hash(qw[0] & 0xFFu, (qw[0] >> 8) & 0xFFu);
                     const uint32_t e1 = bstart[h + 1];
                     for (uint32_t i = bstart[h] + lane; i < e1; i += 64) {
                         const uint32_t c = wbase + blist[i];
                         if (c >= cmin && c < p) consider(c);
                     }
                 } else {
-                    const uint32_t head = ld32_at<true>(by, qo);
+                    const uint32_t head = qw[0];
                     const uint32_t hmask = len >= 4 ? 0xFFFFFFFFu : (1u << (8 * len)) - 1u;
                     for (uint32_t cg = (cmin & ~3u) + lane * 4; cg < p; cg += 256) {
                         const uint8_t *r = by + (cg - wbase);
@@ -287,10 +302,24 @@ __global__ __launch_bounds__(TOK_BLOCK) void k_tokens_tile(const uint8_t *__rest
                         }
                     }
                 }
+                /* wave minimum of (priority, position).  Usually a handful of lanes hold a candidate:
+                 * read those lanes directly; the xor butterfly (12 bpermute round trips) only when many do */
+                uint64_t have = __ballot(best != ~0ull);
+                if (__popcll(have) <= 8) {
+                    uint64_t m = ~0ull;
+                    for (; have; have &= have - 1) {
+                        const int l = __builtin_ctzll(have);
+                        const uint64_t v = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(best >> 32), l) << 32) |
+                                           (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)best, l);
+                        m = v < m ? v : m;
+                    }
+                    best = m;
+                } else {
 #pragma unroll
-                for (int d = 32; d > 0; d >>= 1) {
-                    const uint64_t o = (uint64_t)__shfl_xor((unsigned long long)best, d, 64);
-                    best = o < best ? o : best;
+                    for (int d = 32; d > 0; d >>= 1) {
+                        const uint64_t o = (uint64_t)__shfl_xor((unsigned long long)best, d, 64);
+                        best = o < best ? o : best;
+                    }
                 }
                 off = p - (uint32_t)(best & 0xFFFFFFFFu);
             }

@@ -127,7 +127,10 @@ hipError_t lz77k_dec_parse(const uint8_t *d_z, uint32_t ntok, const lz77x_geom &
                            uint32_t *d_tokval, uint32_t *d_len1, hipStream_t s);
 hipError_t lz77k_dec_expand(const uint32_t *d_tokval, const uint32_t *d_dst, uint32_t ntok,
                             const lz77x_geom &g, uint8_t *d_out, uint32_t *d_ptr, uint32_t n, hipStream_t s);
-hipError_t lz77k_dec_jump(uint32_t *d_ptr, uint32_t n, uint32_t *d_changed, hipStream_t s);
+/* one pass over in_list[0..total) (or over every j < total when in_list is null); entries that moved are
+ * appended to out_list, *out_count += their number */
+hipError_t lz77k_dec_jump(uint32_t *d_ptr, uint32_t total, const uint32_t *d_in_list, uint32_t *d_out_list, uint32_t *d_out_count,
+                          hipStream_t s);
 hipError_t lz77k_dec_gather(uint8_t *d_out, const uint32_t *d_ptr, uint32_t n, hipStream_t s);
 #endif
 

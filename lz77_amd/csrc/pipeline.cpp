@@ -754,14 +754,22 @@ int decode_core(Ctx &c, size_t zn, hipStream_t s, bool want_data, size_t *n_out)
         if ((rc = c.flag.need(64))) return rc;
         HIPCHK(lz77k_dec_expand(c.tokval.as<uint32_t>(), c.dst.as<uint32_t>(), ntok, g, c.out.as<uint8_t>(),
                                 c.ptr.as<uint32_t>(), n32, s));
-        uint32_t *hflag = reinterpret_cast<uint32_t *>(hdr + 32);
+        /* work lists of the pointer-jumping passes (encode's ps/cells buffers are idle during a decode) */
+        if ((rc = c.ps.need((n + 8) * 4))) return rc;
+        if ((rc = c.cells.need((n + 8) * 4))) return rc;
+        uint32_t *lists[2] = {c.ps.as<uint32_t>(), c.cells.as<uint32_t>()};
+        uint32_t *hcount = reinterpret_cast<uint32_t *>(hdr + 32);
+        uint32_t total = n32;
+        const uint32_t *in_list = nullptr;
         for (;;) {
             HIPCHK(hipMemsetAsync(c.flag.p, 0, 4, s));
-            HIPCHK(lz77k_dec_jump(c.ptr.as<uint32_t>(), n32, c.flag.as<uint32_t>(), s));
-            rounds += 1;
-            HIPCHK(hipMemcpyAsync(hflag, c.flag.p, 4, hipMemcpyDeviceToHost, s));
+            HIPCHK(lz77k_dec_jump(c.ptr.as<uint32_t>(), total, in_list, lists[rounds & 1], c.flag.as<uint32_t>(), s));
+            HIPCHK(hipMemcpyAsync(hcount, c.flag.p, 4, hipMemcpyDeviceToHost, s));
             HIPCHK(hipStreamSynchronize(s));
-            if (!*hflag || rounds > 80) break;
+            in_list = lists[rounds & 1];
+            total = *hcount;
+            rounds += 1;
+            if (!total || rounds > 80) break;
         }
         HIPCHK(lz77k_dec_gather(c.out.as<uint8_t>(), c.ptr.as<uint32_t>(), n32, s));
     }
