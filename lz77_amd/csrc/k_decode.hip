@@ -40,12 +40,12 @@ __global__ void k_dec_expand(const uint32_t *__restrict__ tokval, const uint32_t
     ptr[j0 + len] = j0 + len;
 }
 
-/* pointer jumping, two hops per pass: ptr[j] <- ptr[ptr[ptr[j]]] until every byte points at a literal.
- * A chain of depth d shrinks to ~d/3 per pass (5 passes for the depth-136 chains of text); concurrent
- * updates of other entries only ever move them further along the same chain, so any interleaving is safe.
- * The first pass visits every byte and appends the ones that moved to a work list; later passes visit
- * only the list of the pass before (most bytes resolve at once: passes 2.. touch a fraction of ptr[]).
- * An entry leaves the list one pass after it has reached its literal. */
+/* pointer jumping, up to four hops per pass: ptr[j] <- ptr^4[j], stopping at the first literal, until
+ * every byte points at a literal.  A chain of depth d shrinks to ~d/4 per pass; concurrent updates of
+ * other entries only ever move them further along the same chain, so any interleaving is safe.
+ * The first pass visits every byte and appends the ones that are still short of a literal to a work
+ * list; later passes visit only the list of the pass before (most bytes resolve at once: passes 2..
+ * touch a small fraction of ptr[]). */
 #define JUMP_ITEMS 8
 __global__ __launch_bounds__(256) void k_dec_jump(uint32_t *__restrict__ ptr, uint32_t total, const uint32_t *__restrict__ in_list,
                                                   uint32_t *__restrict__ out_list, uint32_t *__restrict__ out_count)
@@ -67,9 +67,15 @@ __global__ __launch_bounds__(256) void k_dec_jump(uint32_t *__restrict__ ptr, ui
                 const uint32_t p = ptr[j[u]];
                 if (p != j[u]) {
                     const uint32_t q = ptr[p];
-                    if (q != p) {
-                        ptr[j[u]] = ptr[q];
-                        keep = true;
+                    if (q != p) {                             /* p is not a literal yet */
+                        const uint32_t r = ptr[q];
+                        if (r == q) {
+                            ptr[j[u]] = q;                    /* q is: done, and it never enters a list */
+                        } else {
+                            const uint32_t t = ptr[r];
+                            ptr[j[u]] = t;                    /* four hops */
+                            keep = t != r;                    /* r was a literal <=> t == r <=> done */
+                        }
                     }
                 }
             }

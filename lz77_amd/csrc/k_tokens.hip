@@ -142,8 +142,11 @@ __global__ void k_tok_bounds(const uint32_t *__restrict__ chain, uint32_t ntok, 
     for (uint32_t t = first; t <= last; t++) tstart[t] = k;
 }
 
-#define TOK_HASH 1024u
-__device__ __forceinline__ uint32_t tok_hash(uint32_t b0, uint32_t b1) { return (b0 * 251u + b1 * 7u) & (TOK_HASH - 1u); }
+/* Bucket of a candidate = its first byte (major) and three mixed bits of its second byte: a token of
+ * length >= 2 visits one bucket, a token of length 1 the eight adjacent buckets of its first byte --
+ * on incompressible input 94 % of the tokens have length 1 and used to scan the whole window. */
+#define TOK_HASH 2048u
+__device__ __forceinline__ uint32_t tok_hash(uint32_t b0, uint32_t b1) { return (b0 << 3) | ((b1 ^ (b1 >> 3)) & 7u); }
 
 /*
  * One workgroup per tile of TOK_TILE positions.  Staged in LDS: the window bytes, the hand-over
@@ -165,8 +168,8 @@ __global__ __launch_bounds__(TOK_BLOCK) void k_tokens_tile(const uint8_t *__rest
     uint16_t *lofs = reinterpret_cast<uint16_t *>(smem + lofs_off);
     uint2 *lent = reinterpret_cast<uint2 *>(smem + lent_off);
     uint32_t *bstart = reinterpret_cast<uint32_t *>(smem + bkt_off);          /* TOK_HASH + 1 (+pad) */
-    uint32_t *bcur = bstart + TOK_HASH + 8;                                    /* TOK_HASH */
-    uint16_t *blist = reinterpret_cast<uint16_t *>(bcur + TOK_HASH);           /* one entry per candidate */
+    uint16_t *blist = reinterpret_cast<uint16_t *>(bstart + TOK_HASH + 8);     /* one entry per candidate */
+    uint32_t *bcur = reinterpret_cast<uint32_t *>(lent);                       /* TOK_HASH words, dead before lent is staged */
     __shared__ uint32_t wsum[TOK_BLOCK / 64];
 
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -183,24 +186,18 @@ __global__ __launch_bounds__(TOK_BLOCK) void k_tokens_tile(const uint8_t *__rest
     const uint32_t ebase = LIST_START(wbase);
     const uint32_t ecount = LIST_END(t1 - 1) - ebase;
     const bool staged = ecount <= ent_cap && ecount < 65536u;
-    if (staged) {
-        for (uint32_t i = tid; i <= NO; i += TOK_BLOCK) {
-            const uint32_t c = wbase + i;
-            lofs[i] = (uint16_t)(LIST_START(c) - ebase);
-        }
-        for (uint32_t e = tid; e < ecount; e += TOK_BLOCK) lent[e] = ent[ebase + e];
-    }
     if (BUCKET)
         for (uint32_t i = tid; i < TOK_HASH; i += TOK_BLOCK) bcur[i] = 0;
     __syncthreads();
     if (BUCKET) {
-        /* counting sort of the candidate positions by hash(first two bytes) */
+        /* counting sort of the candidate positions by bucket */
         for (uint32_t i = tid; i < NO; i += TOK_BLOCK) atomicAdd(&bcur[tok_hash(by[i], by[i + 1])], 1u);
         __syncthreads();
         {
-            static_assert(TOK_HASH == 2 * TOK_BLOCK, "two buckets per thread");
-            const uint32_t c0 = bcur[2 * tid], c1 = bcur[2 * tid + 1];
-            uint32_t incl = c0 + c1;
+            static_assert(TOK_HASH == 4 * TOK_BLOCK, "four buckets per thread");
+            const uint4 c = *reinterpret_cast<const uint4 *>(bcur + 4 * tid);
+            const uint32_t mine = c.x + c.y + c.z + c.w;
+            uint32_t incl = mine;
 #pragma unroll
             for (int d = 1; d < 64; d <<= 1) {
                 const uint32_t t = __shfl_up(incl, d, 64);
@@ -210,17 +207,24 @@ __global__ __launch_bounds__(TOK_BLOCK) void k_tokens_tile(const uint8_t *__rest
             __syncthreads();
             uint32_t woff = 0;
             for (uint32_t w = 0; w < wave; w++) woff += wsum[w];
-            const uint32_t excl = woff + incl - (c0 + c1);
-            bstart[2 * tid] = excl;
-            bstart[2 * tid + 1] = excl + c0;
-            if (tid == TOK_BLOCK - 1) bstart[TOK_HASH] = excl + c0 + c1;
+            const uint32_t excl = woff + incl - mine;
+            *reinterpret_cast<uint4 *>(bstart + 4 * tid) = make_uint4(excl, excl + c.x, excl + c.x + c.y, excl + c.x + c.y + c.z);
+            if (tid == TOK_BLOCK - 1) bstart[TOK_HASH] = excl + mine;
         }
         __syncthreads();
         for (uint32_t i = tid; i < TOK_HASH; i += TOK_BLOCK) bcur[i] = bstart[i];
         __syncthreads();
         for (uint32_t i = tid; i < NO; i += TOK_BLOCK) blist[atomicAdd(&bcur[tok_hash(by[i], by[i + 1])], 1u)] = (uint16_t)i;
-        __syncthreads();
+        __syncthreads();                                      /* bcur is dead: its space becomes the hand-over lists */
     }
+    if (staged) {
+        for (uint32_t i = tid; i <= NO; i += TOK_BLOCK) {
+            const uint32_t c = wbase + i;
+            lofs[i] = (uint16_t)(LIST_START(c) - ebase);
+        }
+        for (uint32_t e = tid; e < ecount; e += TOK_BLOCK) lent[e] = ent[ebase + e];
+    }
+    __syncthreads();
 
     const uint32_t omask = ob >= 32 ? 0xFFFFFFFFu : (1u << ob) - 1u;
     const uint32_t k0 = tstart[blockIdx.x], k1 = tstart[blockIdx.x + 1];
@@ -280,9 +284,9 @@ __global__ __launch_bounds__(TOK_BLOCK) void k_tokens_tile(const uint8_t *__rest
                     const uint64_t key = ((uint64_t)prio << 32) | c;
                     best = key < best ? key : best;
                 };
-                if (BUCKET && len >= 2) {
-                    const uint32_t h = tok_hash(qw[0] & 0xFFu, (qw[0] >> 8) & 0xFFu);
-                    const uint32_t e1 = bstart[h + 1];
+                if (BUCKET) {
+                    const uint32_t h = len >= 2 ? tok_hash(qw[0] & 0xFFu, (qw[0] >> 8) & 0xFFu) : (qw[0] & 0xFFu) << 3;
+                    const uint32_t e1 = bstart[h + (len >= 2 ? 1u : 8u)];
                     for (uint32_t i = bstart[h] + lane; i < e1; i += 64) {
                         const uint32_t c = wbase + blist[i];
                         if (c >= cmin && c < p) consider(c);
@@ -492,10 +496,11 @@ hipError_t lz77k_tokens(const uint8_t *d_in, uint32_t n, const lz77x_geom &g, co
         const uint32_t span = TOK_TILE + (uint32_t)g.sb + 16;
         const uint32_t lofs_off = (span + (uint32_t)g.la + 16 + 15) & ~15u;
         const uint32_t bkt_off = (lofs_off + 2 * (span + 2) + 15) & ~15u;
-        const uint32_t bkt_bytes = bucket ? ((TOK_HASH + 8) * 4 + TOK_HASH * 4 + 2 * span + 15) & ~15u : 0u;
+        const uint32_t bkt_bytes = bucket ? ((TOK_HASH + 8) * 4 + 2 * span + 15) & ~15u : 0u;
         const uint32_t lent_off = bkt_off + bkt_bytes;
         const uint32_t budget = 78u * 1024u;                         /* two workgroups per CU */
         uint32_t ent_cap = lent_off + 5 * span < budget ? (budget - lent_off) / 8 : span;
+        if (bucket && ent_cap < TOK_HASH / 2) ent_cap = TOK_HASH / 2; /* the lent area doubles as bcur (TOK_HASH words) */
         const size_t lds = (size_t)lent_off + (size_t)ent_cap * 8;
         auto fn = bucket ? k_tokens_tile<true> : k_tokens_tile<false>;
         if (lds > 48 * 1024) {
