@@ -1,11 +1,11 @@
 /*
- * fileio.c -- FILE*-level drop-ins for the two functions main() of the reference calls:
- *     encode(FILE*, struct bitFILE*, int la, int sb)   lz77.h:14, called at main.c:150
- *     decode(struct bitFILE*, FILE*)                   lz77.h:15, called at main.c:161
- * The reference streams through a 3*SB+LA window (lz77.c:113-129) and a 4 KiB bit buffer
- * (bitio.c:20); here the whole file crosses the host/device boundary once per direction.
+ * fileio.c -- whole-file-in-host-memory form of the FILE*-level entry points (plain C).  The public
+ * lz77x_encode_file / lz77x_decode_file (pipeline.cpp) stream the file through two pinned staging
+ * slots instead and only come here when one stream is cut into several shards (LZ77X_SHARDS > 1: the
+ * other devices need a host copy of the input).
  */
 #include "../../include/lz77_mi355x.h"
+#include "lz77x_internal.h"
 #include <stdlib.h>
 #include <string.h>
 
@@ -41,7 +41,7 @@ static int spill(FILE *f, const uint8_t *data, size_t n)
     return LZ77X_OK;
 }
 
-int lz77x_encode_file(FILE *in, FILE *out, int la, int sb)
+int lz77x_encode_file_buffered(FILE *in, FILE *out, int la, int sb)
 {
     if (!in || !out) return LZ77X_E_ARG;
     uint8_t *data = NULL, *z = NULL;
@@ -56,7 +56,7 @@ int lz77x_encode_file(FILE *in, FILE *out, int la, int sb)
     return rc;
 }
 
-int lz77x_decode_file(FILE *in, FILE *out)
+int lz77x_decode_file_buffered(FILE *in, FILE *out)
 {
     if (!in || !out) return LZ77X_E_ARG;
     uint8_t *z = NULL, *data = NULL;

@@ -15,6 +15,7 @@
 
 #include <hip/hip_runtime_api.h>
 #include <sys/mman.h>
+#include <sys/stat.h>
 #ifndef MADV_HUGEPAGE
 #define MADV_HUGEPAGE 14          /* Linux; not exposed in every compilation pass of hipcc */
 #endif
@@ -250,7 +251,8 @@ int encode_core(std::vector<Ctx *> &cs, const void *src, bool src_on_device, siz
         Ctx &c = *cs[d];
         HIPCHK(hipSetDevice(c.device));
         if ((rc = c.in.need(n + LZ77X_PAD + 16))) return rc;
-        if (n) HIPCHK(hipMemcpyAsync(c.in.p, src, n, src_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, kstream(d)));
+        if (n && src != c.in.p)                                /* the file path streams straight into c.in */
+            HIPCHK(hipMemcpyAsync(c.in.p, src, n, src_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, kstream(d)));
         HIPCHK(lz77k_fill_pad(c.in.as<uint8_t>(), n32, kstream(d)));
     }
     HIPCHK(hipSetDevice(c0.device));
@@ -830,6 +832,86 @@ int fetch_result(Ctx &c, uint8_t *dst, const void *d_src, size_t bytes)
     return LZ77X_OK;
 }
 
+/* FILE* -> device buffer `dst` (grown as needed, `slack` spare bytes kept behind the data), streamed
+ * through the two pinned staging slots: the fread of piece k+1 overlaps the DMA of piece k.  Host
+ * memory stays at two pieces whatever the file size (the reference streams through a
+ * 3*SB+LA window, lz77.c:113-129). */
+int stream_in(Ctx &c, FILE *f, DevBuf &dst, size_t slack, size_t *n_out)
+{
+    const size_t piece = (size_t)16 << 20;
+    int rc;
+    if ((rc = c.h_stage.need(2 * piece))) return rc;
+    uint8_t *slot[2] = {c.h_stage.as<uint8_t>(), c.h_stage.as<uint8_t>() + piece};
+    size_t hint = 0;
+    {
+        struct stat st;
+        const long at = ftell(f);
+        if (at >= 0 && fstat(fileno(f), &st) == 0 && S_ISREG(st.st_mode) && (size_t)st.st_size > (size_t)at)
+            hint = (size_t)st.st_size - (size_t)at;
+    }
+    if ((rc = dst.need((hint ? hint : piece) + slack))) return rc;
+    size_t len = 0;
+    bool used[2] = {false, false};
+    for (int k = 0;; k++) {
+        const int sl = k & 1;
+        if (used[sl]) HIPCHK(hipEventSynchronize(c.ev[4 + sl]));          /* its previous DMA has drained */
+        const size_t got = fread(slot[sl], 1, piece, f);
+        if (got == 0) {
+            if (ferror(f)) return LZ77X_E_IO;
+            break;
+        }
+        if (len + got > LZ77X_MAX_N) return LZ77X_E_TOOBIG;
+        if (len + got + slack > dst.cap) {                               /* pipe or growing file: double, keep the data */
+            DevBuf bigger;
+            if ((rc = bigger.need(2 * (len + got) + slack))) return rc;
+            HIPCHK(hipStreamSynchronize(c.up));
+            if (len) HIPCHK(hipMemcpyAsync(bigger.p, dst.p, len, hipMemcpyDeviceToDevice, c.up));
+            HIPCHK(hipStreamSynchronize(c.up));
+            hipError_t e0 = hipFree(dst.p); (void)e0;
+            dst = bigger;
+        }
+        HIPCHK(hipMemcpyAsync(dst.as<uint8_t>() + len, slot[sl], got, hipMemcpyHostToDevice, c.up));
+        HIPCHK(hipEventRecord(c.ev[4 + sl], c.up));
+        used[sl] = true;
+        len += got;
+    }
+    HIPCHK(hipStreamSynchronize(c.up));
+    *n_out = len;
+    return LZ77X_OK;
+}
+
+/* device -> FILE*, the DMA of piece k+1 overlapping the fwrite of piece k */
+int stream_out(Ctx &c, FILE *f, const void *d_src, size_t bytes)
+{
+    const size_t piece = (size_t)16 << 20;
+    int rc;
+    if ((rc = c.h_stage.need(2 * piece))) return rc;
+    uint8_t *slot[2] = {c.h_stage.as<uint8_t>(), c.h_stage.as<uint8_t>() + piece};
+    const uint8_t *src = reinterpret_cast<const uint8_t *>(d_src);
+    size_t issued = 0, done = 0;
+    int k = 0;
+    if (bytes) {
+        const size_t m = bytes < piece ? bytes : piece;
+        HIPCHK(hipMemcpyAsync(slot[0], src, m, hipMemcpyDeviceToHost, c.copy));
+        HIPCHK(hipEventRecord(c.ev[4], c.copy));
+        issued = m;
+    }
+    while (done < bytes) {
+        const size_t cur = issued - done;
+        HIPCHK(hipEventSynchronize(c.ev[4 + (k & 1)]));
+        if (issued < bytes) {
+            const size_t m = bytes - issued < piece ? bytes - issued : piece;
+            HIPCHK(hipMemcpyAsync(slot[(k + 1) & 1], src + issued, m, hipMemcpyDeviceToHost, c.copy));
+            HIPCHK(hipEventRecord(c.ev[4 + ((k + 1) & 1)], c.copy));
+            issued += m;
+        }
+        if (fwrite(slot[k & 1], 1, cur, f) != cur) { hipError_t e0 = hipStreamSynchronize(c.copy); (void)e0; return LZ77X_E_IO; }
+        done += cur;
+        k++;
+    }
+    return fflush(f) == 0 ? LZ77X_OK : LZ77X_E_IO;
+}
+
 }  // namespace
 
 /* ==================================================================== C ABI ========= */
@@ -927,6 +1009,54 @@ int lz77x_decode_device(const void *d_z, size_t zn, void *d_out, size_t out_cap,
     if (n) HIPCHK(hipMemcpyAsync(d_out, g_ctx.out.p, n, hipMemcpyDeviceToDevice, s));
     HIPCHK(hipStreamSynchronize(s));
     return LZ77X_OK;
+}
+
+/* lz77.h:14 encode(file, out, la, sb) as called at main.c:150 */
+int lz77x_encode_file(FILE *in, FILE *out, int la, int sb)
+{
+    if (!in || !out) return LZ77X_E_ARG;
+    int rc = check_geom(sb, la);
+    if (rc) return rc;
+    int shards = g_shards;
+    if (shards <= 0) { const char *e = getenv("LZ77X_SHARDS"); shards = e ? atoi(e) : 1; }
+    if (shards > 1) return lz77x_encode_file_buffered(in, out, la, sb);
+    std::lock_guard<std::mutex> lk(g_mu);
+    const double t0 = now_ms();
+    std::vector<Ctx *> cs;
+    if ((rc = shard_contexts(1, cs))) return rc;
+    TRACE("runtime + context init", t0);
+    Ctx &c = g_ctx;
+    size_t n = 0;
+    const double t1 = now_ms();
+    if ((rc = stream_in(c, in, c.in, LZ77X_PAD + 16, &n))) return rc;
+    TRACE("file -> device", t1);
+    lz77x_geom g;
+    make_encode_geom(&g, sb == -1 ? LZ77X_DEFAULT_SB : sb, la == -1 ? LZ77X_DEFAULT_LA : la);
+    size_t zn = 0;
+    const double t2 = now_ms();
+    if ((rc = encode_core(cs, c.in.p, true, n, g, c.stream, &zn))) return rc;
+    TRACE("encode_core (incl. allocs)", t2);
+    const double t3 = now_ms();
+    rc = stream_out(c, out, c.out.p, zn);
+    TRACE("device -> file", t3);
+    return rc;
+}
+
+/* lz77.h:15 decode(file, out) as called at main.c:161 */
+int lz77x_decode_file(FILE *in, FILE *out)
+{
+    if (!in || !out) return LZ77X_E_ARG;
+    std::lock_guard<std::mutex> lk(g_mu);
+    int rc;
+    if ((rc = primary_context())) return rc;
+    Ctx &c = g_ctx;
+    size_t zn = 0;
+    if ((rc = stream_in(c, in, c.z, 32, &zn))) return rc;
+    if (zn < 4) return LZ77X_E_FORMAT;
+    HIPCHK(hipMemsetAsync(c.z.as<uint8_t>() + zn, 0, 32, c.stream));
+    size_t n = 0;
+    if ((rc = decode_core(c, zn, c.stream, true, &n))) return rc;
+    return stream_out(c, out, c.out.p, n);
 }
 
 void lz77x_free(void *p) { free(p); }

@@ -279,6 +279,33 @@ def test_cli_roundtrip(tmp_path, golden_dir):
     assert open(lz, "rb").read() == O.encode_bst(np.fromfile(src, dtype=np.uint8), 1000, 10)
 
 
+def test_cli_streams_large_files_and_pipes(tmp_path):
+    """the FILE* entry points stream through two 16 MiB pinned slots: several pieces each way, a pipe
+    as input (size unknown up front: the device buffer grows), empty input, and the sharded fallback"""
+    data = synth.mixed(40_000_000, 91)
+    want = L.encode(data)
+    src, lz, out = str(tmp_path / "b.bin"), str(tmp_path / "b.lz"), str(tmp_path / "b.out")
+    data.tofile(src)
+    r = subprocess.run([L.CLI_PATH, "-c", "-i", src, "-o", lz], capture_output=True)
+    assert r.returncode == 0 and r.stderr == b""
+    assert open(lz, "rb").read() == want
+    r = subprocess.run([L.CLI_PATH, "-d", "-i", lz, "-o", out], capture_output=True)
+    assert r.returncode == 0 and r.stderr == b""
+    assert open(out, "rb").read() == data.tobytes()
+    r = subprocess.run([L.CLI_PATH, "-c", "-i", "/dev/stdin", "-o", lz], input=data.tobytes(), capture_output=True)
+    assert r.returncode == 0 and r.stderr == b""
+    assert open(lz, "rb").read() == want
+    r = subprocess.run([L.CLI_PATH, "-d", "-i", "/dev/stdin", "-o", out], input=want, capture_output=True)
+    assert r.returncode == 0 and open(out, "rb").read() == data.tobytes()
+    open(src, "wb").close()
+    r = subprocess.run([L.CLI_PATH, "-c", "-i", src, "-o", lz], capture_output=True)
+    assert r.returncode == 0 and open(lz, "rb").read() == bytes([0xFF, 0x0F, 0x0F, 0x00])
+    data[:3_000_000].tofile(src)
+    r = subprocess.run([L.CLI_PATH, "-c", "-i", src, "-o", lz], capture_output=True,
+                       env=dict(os.environ, LZ77X_SHARDS="2", LZ77X_FAKE_DEVICES="2"))
+    assert r.returncode == 0 and open(lz, "rb").read() == L.encode(data[:3_000_000])
+
+
 def test_device_api_with_torch():
     import torch
     data = synth.text(3 << 20, 77)
