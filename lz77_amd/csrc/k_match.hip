@@ -446,7 +446,7 @@ template <bool FAST, int MODE>
 __global__ __launch_bounds__(MATCH_BLOCK, (FAST && MODE == 3) ? 8 : 1) void k_match(const uint8_t *__restrict__ in, uint32_t n, int sb, int la,
                                                        uint32_t SBu, uint32_t RP, uint32_t TILE, uint32_t region0,
                                                        uint32_t *__restrict__ ps, uint8_t *__restrict__ maxlen,
-                                                       uint32_t *__restrict__ scratch, int sort_variant)
+                                                       uint32_t *__restrict__ scratch, int sort_variant, uint32_t walk_run)
 {
     typedef typename rank_traits<FAST>::rank_t rank_t;
     constexpr uint32_t HALF = rank_traits<FAST>::HALF;
@@ -594,6 +594,54 @@ __global__ __launch_bounds__(MATCH_BLOCK, (FAST && MODE == 3) ? 8 : 1) void k_ma
             }
         }
     }
+    if constexpr (FAST && MODE == 3) {
+        /* Hand the order to the window walkers, run by run.  A walker only ever touches the
+         * walk_run + sb consecutive positions [lo, lo+span) of its run, so it gets their ranks AMONG
+         * THEMSELVES ("sub-ranks": a prefix count over the sorted order) and the inverse: its bitmap
+         * shrinks from RP bits to walk_run+SBu bits (three wavefronts of walkers per CU instead of
+         * one) and is two-thirds full, so it needs no summary level.  Staged in the LDS the key bytes
+         * occupied, copied out 16 bytes at a time. */
+        __shared__ uint32_t wsum[MATCH_BLOCK / 64];
+        const uint32_t K = RP / MATCH_BLOCK;                 /* sorted slots per thread: 4, 8 or 16 */
+        const uint32_t lane = tid & 63, wave = tid >> 6;
+        const uint32_t steps = n - t0 < TILE ? n - t0 : TILE;
+        const uint32_t NR = (TILE + walk_run - 1) / walk_run, SUB = walk_run + SBu;
+        uint16_t *st_rk = reinterpret_cast<uint16_t *>(rk), *st_ix = st_rk + SUB;      /* 2*SUB <= RP */
+        uint16_t *gout = reinterpret_cast<uint16_t *>(scratch) + (size_t)blockIdx.x * NR * 2 * SUB;
+        uint32_t mine[16];
+#pragma unroll
+        for (int q = 0; q < 16; q++) mine[q] = (uint32_t)q < K ? (uint32_t)ix[tid * K + q] : 0xFFFFFFFFu;
+        __syncthreads();                                     /* the sort's last readers of the byte area are done */
+        for (uint32_t j = 0; j < NR; j++) {
+            const uint32_t lo = j * walk_run;
+            if (lo >= steps) break;
+            const uint32_t span = R - lo < SUB ? R - lo : SUB;
+            uint32_t cnt = 0;
+#pragma unroll
+            for (int q = 0; q < 16; q++) cnt += (mine[q] - lo < span) ? 1u : 0u;
+            uint32_t incl = cnt;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const uint32_t t = __shfl_up(incl, d, 64);
+                if (lane >= (uint32_t)d) incl += t;
+            }
+            if (lane == 63) wsum[wave] = incl;
+            __syncthreads();
+            uint32_t run = incl - cnt;
+            for (uint32_t w = 0; w < wave; w++) run += wsum[w];
+#pragma unroll
+            for (int q = 0; q < 16; q++) {
+                const uint32_t i = mine[q] - lo;
+                if (i < span) { st_rk[i] = (uint16_t)run; st_ix[run] = (uint16_t)i; run++; }
+            }
+            __syncthreads();
+            uint16_t *g = gout + (size_t)j * 2 * SUB;
+            for (uint32_t e = tid * 8; e < 2 * SUB; e += MATCH_BLOCK * 8)
+                *reinterpret_cast<uint4 *>(g + e) = *reinterpret_cast<const uint4 *>(st_rk + e);
+            __syncthreads();
+        }
+        return;
+    }
     /* FAST: the staged bytes are dead from here on, their space becomes the ranks (the few remaining
      * byte reads -- LCPs -- go to L1/L2); generic: the rank array was the sort's second buffer */
     for (uint32_t i = tid; i < RP + 8; i += MATCH_BLOCK) rk[i] = 0;
@@ -605,16 +653,6 @@ __global__ __launch_bounds__(MATCH_BLOCK, (FAST && MODE == 3) ? 8 : 1) void k_ma
     }
     __syncthreads();
     if (MODE == 2 || (!FAST && MODE == 3)) return;           /* sort + ranks only (generic path: they live in scratch) */
-    if constexpr (FAST && MODE == 3) {
-        /* hand the order to the window walkers: rank[] and its inverse, 16-bit, per region */
-        uint16_t *grk = reinterpret_cast<uint16_t *>(scratch) + (size_t)blockIdx.x * 2 * RP;
-        uint16_t *gix = grk + RP;
-        for (uint32_t i = tid * 8; i < RP; i += MATCH_BLOCK * 8) {
-            *reinterpret_cast<uint4 *>(grk + i) = *reinterpret_cast<const uint4 *>(rk + i);
-            *reinterpret_cast<uint4 *>(gix + i) = *reinterpret_cast<const uint4 *>(ix + i);
-        }
-        return;
-    }
 
     /* ---- pair scan: one octet of positions per thread, window streamed in octets ---- */
     const uint32_t usb = (uint32_t)sb;
@@ -734,16 +772,15 @@ typedef __attribute__((address_space(1))) uint64_t g_u64;
 struct u32x2 { uint32_t x, y; };
 typedef __attribute__((address_space(1))) u32x2 g_uint2;
 
-__global__ __launch_bounds__(64) void k_walk(const uint16_t *__restrict__ ranks, uint32_t n, int sb, uint32_t RP,
+__global__ __launch_bounds__(64) void k_walk(const uint16_t *__restrict__ subs, uint32_t n, int sb, uint32_t SBu,
                                              uint32_t TILE, uint32_t region0, uint32_t nregions, uint32_t run_len,
                                              uint32_t runs_per_tile, uint32_t *__restrict__ wf, uint32_t *__restrict__ wb,
                                              uint32_t *__restrict__ wb0)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t bm[];
     const uint32_t lane = threadIdx.x;
-    const uint32_t NW = RP >> 5, NS = (NW + 31) >> 5;
+    const uint32_t SUB = run_len + SBu, NW = (SUB + 31) >> 5;
 #define BM_WORD(w) bm[(w) * 64u + lane]
-#define BM_SUMM(w) bm[(NW + (w)) * 64u + lane]
     const uint32_t id = blockIdx.x * 64u + lane;
     const uint32_t run = id % runs_per_tile;
     const uint32_t reg = id / runs_per_tile;
@@ -753,21 +790,19 @@ __global__ __launch_bounds__(64) void k_walk(const uint16_t *__restrict__ ranks,
     const uint32_t t0 = (uint32_t)t0_64;
     const uint32_t usb = (uint32_t)sb;
     const uint64_t rend64 = t0_64 + TILE + usb;
-    const uint32_t R = (rend64 < n ? (uint32_t)rend64 : n) - t0;         /* sorted local indices [0,R) */
-    const uint32_t lt1 = n - t0 < TILE ? n - t0 : TILE;                  /* steps t in [0, lt1) */
-    const uint32_t ta = run * run_len;
-    if (ta >= lt1) return;
-    const uint32_t tb = min(ta + run_len, lt1);
-    const uint16_t *rk = ranks + (size_t)reg * 2 * RP;
-    uint32_t *of = wf + (size_t)reg * TILE, *ob = wb + (size_t)reg * TILE; /* indexed by t */
+    const uint32_t Rreg = (rend64 < n ? (uint32_t)rend64 : n) - t0;      /* sorted local indices of the region */
+    const uint32_t lt1 = n - t0 < TILE ? n - t0 : TILE;                  /* steps of the region */
+    const uint32_t lo = run * run_len;
+    if (lo >= lt1) return;
+    const uint32_t tb = min(run_len, lt1 - lo);                          /* steps t in [0, tb), relative to lo */
+    const uint32_t R = min(SUB, Rreg - lo);                              /* sub-ranked positions [0, R) of this run */
+    const uint16_t *rk = subs + ((size_t)reg * runs_per_tile + run) * 2 * SUB;
+    uint32_t *of = wf + (size_t)reg * TILE + lo, *ob = wb + (size_t)reg * TILE + lo;   /* indexed by t */
 
-    for (uint32_t w = 0; w < NW + NS; w++) bm[w * 64u + lane] = 0;
-    auto set_bit = [&](uint32_t r) {
-        atomicOr(&BM_WORD(r >> 5), 1u << (r & 31));
-        atomicOr(&BM_SUMM(r >> 10), 1u << ((r >> 5) & 31));
-    };
-    auto load8 = [&](uint32_t i, uint32_t (&v)[4]) {          /* ranks i..i+7, any alignment */
-        if (i + 8 <= RP) {
+    for (uint32_t w = 0; w < NW; w++) bm[w * 64u + lane] = 0;
+    auto set_bit = [&](uint32_t r) { atomicOr(&BM_WORD(r >> 5), 1u << (r & 31)); };
+    auto load8 = [&](uint32_t i, uint32_t (&v)[4]) {          /* sub-ranks i..i+7, any alignment */
+        if (i + 8 <= SUB) {
             uint4 t;
             __builtin_memcpy(&t, rk + i, 16);
             v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
@@ -775,60 +810,35 @@ __global__ __launch_bounds__(64) void k_walk(const uint16_t *__restrict__ ranks,
 #pragma unroll
             for (int j = 0; j < 4; j++) {
                 const uint32_t i0 = i + 2 * j, i1 = i0 + 1;
-                const uint32_t lo = i0 < RP ? rk[i0] : 0u, hi = i1 < RP ? rk[i1] : 0u;
-                v[j] = lo | (hi << 16);
+                const uint32_t l = i0 < SUB ? rk[i0] : 0u, h = i1 < SUB ? rk[i1] : 0u;
+                v[j] = l | (h << 16);
             }
         }
     };
-    /* A query = first set bit strictly above / below rank q.  Level 1: q's own word and its summary
-     * word (both already loaded by the caller); level 2, when the rest of the word is empty: the word
-     * the summary points at.  The two levels are split so that a step can issue the loads of both of
-     * its queries back to back -- the walker is a single wavefront per CU, bound by LDS round trips. */
-    /* branch-free except for the rare case that the summary word has nothing on that side either
-     * (q in the last / first non-empty word of its 1024-rank block) */
-    struct Probe { uint32_t w, m1, sm; };
-    auto up1 = [&](uint32_t w0, uint32_t b0, uint32_t here, uint32_t summ) -> Probe {
-        Probe p;
-        p.m1 = here & ~((2u << b0) - 1u);
-        p.sm = summ & ~((2u << (w0 & 31)) - 1u);
-        uint32_t sw = w0 >> 5;
-        if (!(p.m1 | p.sm))
-            while (!p.sm && ++sw < NS) p.sm = BM_SUMM(sw);
-        p.w = p.sm ? (sw << 5) + (uint32_t)__builtin_ctz(p.sm) : w0;
-        return p;
+    /* first set bit strictly above / below bit b0 of word w0, given that word and its two neighbours;
+     * the bitmap is dense, the loops over further words only run in nearly empty windows */
+    auto succ_of = [&](uint32_t w0, uint32_t b0, uint32_t here, uint32_t next) -> uint32_t {
+        uint32_t m = here & ~((2u << b0) - 1u), w = w0;
+        if (!m && w0 + 1 < NW) { m = next; w = w0 + 1; }
+        if (!m)
+            for (w = w0 + 2; w < NW; w++) if ((m = BM_WORD(w))) break;
+        return m ? (w << 5) + (uint32_t)__builtin_ctz(m) : WALK_NONE;
     };
-    auto down1 = [&](uint32_t w0, uint32_t b0, uint32_t here, uint32_t summ) -> Probe {
-        Probe p;
-        p.m1 = here & ((1u << b0) - 1u);
-        p.sm = summ & ((1u << (w0 & 31)) - 1u);
-        int32_t sw = (int32_t)(w0 >> 5);
-        if (!(p.m1 | p.sm))
-            while (!p.sm && --sw >= 0) p.sm = BM_SUMM(sw);
-        p.w = p.sm ? ((uint32_t)sw << 5) + 31u - (uint32_t)__builtin_clz(p.sm) : w0;
-        return p;
+    auto pred_of = [&](uint32_t w0, uint32_t b0, uint32_t here, uint32_t prev) -> uint32_t {
+        uint32_t m = here & ((1u << b0) - 1u), w = w0;
+        if (!m && w0 > 0) { m = prev; w = w0 - 1; }
+        if (!m && w0 > 1)
+            for (w = w0 - 2;; w--) { if ((m = BM_WORD(w)) || w == 0) break; }
+        return m ? (w << 5) + 31u - (uint32_t)__builtin_clz(m) : WALK_NONE;
     };
-    /* m2 = the word p.w (level 2), loaded unconditionally by the caller */
-    auto succ_of = [&](const Probe &p, uint32_t w0, uint32_t m2) -> uint32_t {
-        const uint32_t l1 = (w0 << 5) + (uint32_t)__builtin_ctz(p.m1 | 0x80000000u);
-        const uint32_t l2 = (p.w << 5) + (uint32_t)__builtin_ctz(m2 | 0x80000000u);
-        return p.m1 ? l1 : (p.sm ? l2 : WALK_NONE);
-    };
-    auto pred_of = [&](const Probe &p, uint32_t w0, uint32_t m2) -> uint32_t {
-        const uint32_t l1 = (w0 << 5) + 31u - (uint32_t)__builtin_clz(p.m1 | 1u);
-        const uint32_t l2 = (p.w << 5) + 31u - (uint32_t)__builtin_clz(m2 | 1u);
-        return p.m1 ? l1 : (p.sm ? l2 : WALK_NONE);
-    };
-    /* neighbours of rank q in the current bitmap: successor | predecessor << 16 */
-    auto query = [&](uint32_t q) -> uint32_t {
+    auto query = [&](uint32_t q) -> uint32_t {                /* successor | predecessor << 16 */
         const uint32_t w0 = q >> 5, b0 = q & 31;
-        const uint32_t here = BM_WORD(w0), summ = BM_SUMM(w0 >> 5);
-        const Probe up = up1(w0, b0, here, summ), dn = down1(w0, b0, here, summ);
-        const uint32_t mu = BM_WORD(up.w), md = BM_WORD(dn.w);
-        return succ_of(up, w0, mu) | (pred_of(dn, w0, md) << 16);
+        const uint32_t here = BM_WORD(w0), next = BM_WORD(min(w0 + 1, NW - 1)), prev = BM_WORD(w0 ? w0 - 1 : 0);
+        return succ_of(w0, b0, here, next) | (pred_of(w0, b0, here, prev) << 16);
     };
-    /* first window minus its last position: [ta, ta+sb-1) */
+    /* first window minus its last position: [0, sb-1) */
     {
-        const uint32_t b = min(ta + usb - 1, R);
+        const uint32_t b = min(usb - 1, R);
         if (region0 + reg == 0 && run == 0) {
             /* start of the input: y < sb looks back at [0, y) only -- answer while filling */
             for (uint32_t i = 0; i < b; i++) {
@@ -838,7 +848,7 @@ __global__ __launch_bounds__(64) void k_walk(const uint16_t *__restrict__ ranks,
             }
             if (usb - 1 < R) wb0[usb - 1] = query(rk[usb - 1]);
         } else {
-            uint32_t i = ta;
+            uint32_t i = 0;
             for (; i + 32 <= b; i += 32) {                   /* four loads in flight: the fill is bound by their latency */
                 uint32_t v[4][4];
 #pragma unroll
@@ -857,7 +867,7 @@ __global__ __launch_bounds__(64) void k_walk(const uint16_t *__restrict__ ranks,
             for (; i < b; i++) set_bit(rk[i]);
         }
     }
-    uint32_t r_add = ta + usb - 1 < R ? (uint32_t)rk[ta + usb - 1] : WALK_NONE;
+    uint32_t r_add = usb - 1 < R ? (uint32_t)rk[usb - 1] : WALK_NONE;
     /* One step.  The forward query never looks at q's own bit (strict masks), so it may read the
      * bitmap BEFORE q is cleared, together with the backward query; and since the lane owns its bitmap
      * the clear is a plain store of the word it has just read. */
@@ -865,65 +875,50 @@ __global__ __launch_bounds__(64) void k_walk(const uint16_t *__restrict__ ranks,
         if (r_add != WALK_NONE) set_bit(r_add);
         const bool hasy = ry != WALK_NONE;
         const uint32_t wq = q >> 5, bq = q & 31, wy = hasy ? ry >> 5 : wq, by_ = ry & 31;
-        const uint32_t hq = BM_WORD(wq), sq = BM_SUMM(wq >> 5), hy = BM_WORD(wy), sy = BM_SUMM(wy >> 5);
-        const Probe qu = up1(wq, bq, hq, sq), qd = down1(wq, bq, hq, sq);
-        const Probe yu = up1(wy, by_, hy, sy), yd = down1(wy, by_, hy, sy);
-        const uint32_t mqu = BM_WORD(qu.w), mqd = BM_WORD(qd.w), myu = BM_WORD(yu.w), myd = BM_WORD(yd.w);
-        const uint32_t left = hq & ~(1u << bq);
-        BM_WORD(wq) = left;
-        if (!left) atomicAnd(&BM_SUMM(wq >> 5), ~(1u << (wq & 31)));
-        resf = succ_of(qu, wq, mqu) | (pred_of(qd, wq, mqd) << 16);
-        resb = hasy ? succ_of(yu, wy, myu) | (pred_of(yd, wy, myd) << 16) : (WALK_NONE | (WALK_NONE << 16));
+        const uint32_t hq = BM_WORD(wq), nq = BM_WORD(min(wq + 1, NW - 1)), pq = BM_WORD(wq ? wq - 1 : 0);
+        const uint32_t hy = BM_WORD(wy), ny = BM_WORD(min(wy + 1, NW - 1)), py = BM_WORD(wy ? wy - 1 : 0);
+        resf = succ_of(wq, bq, hq, nq) | (pred_of(wq, bq, hq, pq) << 16);
+        resb = hasy ? succ_of(wy, by_, hy, ny) | (pred_of(wy, by_, hy, py) << 16) : (WALK_NONE | (WALK_NONE << 16));
+        BM_WORD(wq) = hq & ~(1u << bq);
         r_add = ry;                                          /* position t+sb enters at the next step */
     };
-    uint32_t t = ta;
-    /* groups of 8 steps: two 16-byte rank loads and four 16-byte result stores.  vmcnt counts loads and
-     * stores alike on gfx9, so waiting for ranks also waits for every store in flight: the results of
-     * group k are therefore written at the top of group k+1, together with the loads for group k+2,
-     * and all of them have a whole group of LDS work to complete before anything waits on them. */
-    uint32_t vq[4], vy[4], nq[4] = {0, 0, 0, 0}, ny[4] = {0, 0, 0, 0}, rf[8], rb[8];
-    bool pending = false;
-    uint32_t tprev = 0;
-    auto flush = [&]() {
-        uint4 *o = reinterpret_cast<uint4 *>(of + tprev);
-        o[0] = make_uint4(rf[0], rf[1], rf[2], rf[3]);
-        o[1] = make_uint4(rf[4], rf[5], rf[6], rf[7]);
-        o = reinterpret_cast<uint4 *>(ob + tprev);
-        o[0] = make_uint4(rb[0], rb[1], rb[2], rb[3]);
-        o[1] = make_uint4(rb[4], rb[5], rb[6], rb[7]);
-    };
+    uint32_t t = 0;
+    /* groups of 8 steps: two 16-byte sub-rank loads (fetched a group ahead), four 16-byte result stores */
+    uint32_t vq[4], vy[4], nq8[4] = {0, 0, 0, 0}, ny8[4] = {0, 0, 0, 0}, rf[8], rb[8];
     if (t + 8 <= tb) { load8(t, vq); load8(t + usb, vy); }
     for (; t + 8 <= tb; t += 8) {
-        if (pending) flush();
-        if (t + 16 <= tb) { load8(t + 8, nq); load8(t + 8 + usb, ny); }
+        if (t + 16 <= tb) { load8(t + 8, nq8); load8(t + 8 + usb, ny8); }
 #pragma unroll
         for (int j = 0; j < 8; j++) {
             const uint32_t q = (vq[j >> 1] >> (16 * (j & 1))) & 0xFFFFu;
             const uint32_t ry = t + j + usb < R ? (vy[j >> 1] >> (16 * (j & 1))) & 0xFFFFu : WALK_NONE;
             step(q, ry, rf[j], rb[j]);
         }
-        pending = true;
-        tprev = t;
+        uint4 *o = reinterpret_cast<uint4 *>(of + t);
+        o[0] = make_uint4(rf[0], rf[1], rf[2], rf[3]);
+        o[1] = make_uint4(rf[4], rf[5], rf[6], rf[7]);
+        o = reinterpret_cast<uint4 *>(ob + t);
+        o[0] = make_uint4(rb[0], rb[1], rb[2], rb[3]);
+        o[1] = make_uint4(rb[4], rb[5], rb[6], rb[7]);
 #pragma unroll
-        for (int j = 0; j < 4; j++) { vq[j] = nq[j]; vy[j] = ny[j]; }
+        for (int j = 0; j < 4; j++) { vq[j] = nq8[j]; vy[j] = ny8[j]; }
     }
-    if (pending) flush();
     for (; t < tb; t++) {
-        uint32_t rf, rb;
-        step(rk[t], t + usb < R ? (uint32_t)rk[t + usb] : WALK_NONE, rf, rb);
-        of[t] = rf;
-        ob[t] = rb;
+        uint32_t f1, b1;
+        step(rk[t], t + usb < R ? (uint32_t)rk[t + usb] : WALK_NONE, f1, b1);
+        of[t] = f1;
+        ob[t] = b1;
     }
 #undef BM_WORD
-#undef BM_SUMM
 }
 
-/* ranks -> positions -> the two per-position results of the match stage */
-__global__ __launch_bounds__(256) void k_walk_final(const uint8_t *__restrict__ in, uint32_t n, int sb, int la,
-                                                    uint32_t RP, uint32_t TILE, uint32_t region0, uint32_t nregions,
-                                                    const uint16_t *__restrict__ ranks, const uint32_t *__restrict__ wf,
-                                                    const uint32_t *__restrict__ wb, const uint32_t *__restrict__ wb0,
-                                                    uint32_t *__restrict__ ps, uint8_t *__restrict__ maxlen)
+/* sub-ranks -> positions -> the two per-position results of the match stage */
+__global__ __launch_bounds__(256) void k_walk_final(const uint8_t *__restrict__ in, uint32_t n, int sb, int la, uint32_t SBu,
+                                                    uint32_t TILE, uint32_t region0, uint32_t nregions, uint32_t run_len,
+                                                    uint32_t runs_per_tile, const uint16_t *__restrict__ subs,
+                                                    const uint32_t *__restrict__ wf, const uint32_t *__restrict__ wb,
+                                                    const uint32_t *__restrict__ wb0, uint32_t *__restrict__ ps,
+                                                    uint8_t *__restrict__ maxlen)
 {
     const uint64_t rel = (uint64_t)blockIdx.x * 256u + threadIdx.x;      /* position relative to region0*TILE */
     const uint32_t reg = (uint32_t)(rel / TILE);
@@ -933,28 +928,29 @@ __global__ __launch_bounds__(256) void k_walk_final(const uint8_t *__restrict__ 
     const uint32_t x = (uint32_t)x64;
     const uint32_t t0 = (region0 + reg) * TILE;
     const uint32_t lx = x - t0;
-    const uint16_t *ix = ranks + (size_t)reg * 2 * RP + RP;
+    const uint32_t run = lx / run_len, lo = run * run_len, SUB = run_len + SBu;
+    const uint16_t *ix = subs + ((size_t)reg * runs_per_tile + run) * 2 * SUB + SUB;    /* sub-rank -> position - lo */
     const uint8_t *by = in + t0;
     const uint32_t f = wf[rel];
     uint32_t P = 0, S = 0;
     if ((uint64_t)x + (uint32_t)sb < n) {                                /* only evicted positions matter */
-        if ((f & 0xFFFFu) != WALK_NONE) S = (uint32_t)ix[f & 0xFFFFu] - lx;
-        if ((f >> 16) != WALK_NONE) P = (uint32_t)ix[f >> 16] - lx;
+        if ((f & 0xFFFFu) != WALK_NONE) S = lo + (uint32_t)ix[f & 0xFFFFu] - lx;
+        if ((f >> 16) != WALK_NONE) P = lo + (uint32_t)ix[f >> 16] - lx;
     }
     ps[x] = P | (S << 16);
-    auto longest = [&](uint32_t b, uint32_t ly) -> uint32_t {            /* max LCP with the two candidates */
+    auto longest = [&](uint32_t b, uint32_t ly, const uint16_t *inv, uint32_t base) -> uint32_t {   /* max LCP with the two candidates */
         const uint32_t left = n - (t0 + ly);
         const int cap = (int)(left < (uint32_t)la ? left : (uint32_t)la) - 1;
         uint32_t best = 0;
-        if ((b & 0xFFFFu) != WALK_NONE) best = (uint32_t)lcp_capped<false>(by, (uint32_t)ix[b & 0xFFFFu], ly, cap);
+        if ((b & 0xFFFFu) != WALK_NONE) best = (uint32_t)lcp_capped<false>(by, base + (uint32_t)inv[b & 0xFFFFu], ly, cap);
         if ((b >> 16) != WALK_NONE) {
-            const uint32_t l2 = (uint32_t)lcp_capped<false>(by, (uint32_t)ix[b >> 16], ly, cap);
+            const uint32_t l2 = (uint32_t)lcp_capped<false>(by, base + (uint32_t)inv[b >> 16], ly, cap);
             best = l2 > best ? l2 : best;
         }
         return best;
     };
-    if ((uint64_t)x + (uint32_t)sb < n) maxlen[x + (uint32_t)sb] = (uint8_t)longest(wb[rel], lx + (uint32_t)sb);
-    if (region0 + reg == 0 && lx < (uint32_t)sb) maxlen[x] = (uint8_t)longest(wb0[lx], lx);
+    if ((uint64_t)x + (uint32_t)sb < n) maxlen[x + (uint32_t)sb] = (uint8_t)longest(wb[rel], lx + (uint32_t)sb, ix, lo);
+    if (region0 + reg == 0 && lx < (uint32_t)sb) maxlen[x] = (uint8_t)longest(wb0[lx], lx, subs + SUB, 0u);
 }
 
 /* ---- large windows (RP > 16384): same walk, bitmap in global memory (L2 resident), 32-bit ranks.
@@ -1156,7 +1152,21 @@ __global__ __launch_bounds__(256) void k_walk_final_big(const uint8_t *__restric
 
 #define WALK_RUN_BIG_DEFAULT 4096u
 
-#define WALK_RUN_DEFAULT 2048u
+#define WALK_RUN_DEFAULT 1024u
+
+/* steps per walker on the LDS path (LZ77X_WALK_RUN overrides): a multiple of 8 in [256, RP/2 - SBu] --
+ * the two sub-rank arrays of a run (2 * (run + SBu) uint16) are staged in the RP*2 bytes of LDS the key
+ * bytes occupied, and a short run means many arrays per region */
+static uint32_t walk_run_lds(const lz77x_geom &g)
+{
+    const char *rl = getenv("LZ77X_WALK_RUN");
+    uint32_t run_len = rl && atoi(rl) > 0 ? (uint32_t)atoi(rl) : WALK_RUN_DEFAULT;
+    const uint32_t hi = (g.RP / 2 - g.SBu) & ~7u;
+    if (run_len > hi) run_len = hi;
+    if (run_len < 256) run_len = 256 < hi ? 256 : hi;
+    if (run_len > g.TILE) run_len = g.TILE;
+    return (run_len + 7u) & ~7u;
+}
 
 /* steps per walker on the large-window path (LZ77X_WALK_RUN_BIG overrides) */
 static uint32_t walk_run_big(const lz77x_geom &g)
@@ -1175,8 +1185,11 @@ size_t lz77k_match_lds_bytes(const lz77x_geom &g)
 
 size_t lz77k_match_scratch_bytes(const lz77x_geom &g, uint32_t nregions)
 {
-    /* fast: rank + inverse (uint16 each) per region, then the walkers' fwd/bwd results per position */
-    if (g.fast) return (size_t)nregions * ((size_t)g.RP * 4 + (size_t)g.TILE * 8) + (size_t)g.SBu * 4 + 256;
+    /* fast: sub-rank + inverse (uint16 each) per run, then the walkers' fwd/bwd results per position */
+    if (g.fast) {
+        const size_t rl = walk_run_lds(g), runs = (g.TILE + rl - 1) / rl;
+        return (size_t)nregions * (runs * 2 * (rl + g.SBu) * 2 + (size_t)g.TILE * 8) + (size_t)g.SBu * 4 + 256;
+    }
     /* generic: rank + inverse (uint32), one global bitmap per walker, backward results per position */
     const size_t run_len = walk_run_big(g);
     const size_t runs = (g.TILE + run_len - 1) / run_len;
@@ -1196,7 +1209,7 @@ static hipError_t launch_match(const uint8_t *d_in, uint32_t n, const lz77x_geom
     }
     const char *sv = getenv("LZ77X_SORT_VARIANT");
     hipLaunchKernelGGL(fn, dim3(nregions), dim3(MATCH_BLOCK), lds, s, d_in, n, g.sb, g.la, g.SBu, g.RP, g.TILE, region0,
-                       d_ps, d_maxlen, reinterpret_cast<uint32_t *>(d_scratch), sv ? atoi(sv) : 0);
+                       d_ps, d_maxlen, reinterpret_cast<uint32_t *>(d_scratch), sv ? atoi(sv) : 0, g.fast ? walk_run_lds(g) : 0u);
     return hipGetLastError();
 }
 
@@ -1217,27 +1230,24 @@ hipError_t lz77k_match(const uint8_t *d_in, uint32_t n, const lz77x_geom &g, uin
         e = launch_match<true, 3>(LZ77K_MATCH_ARGS);
         if (e != hipSuccess) return e;
         if (ev_sort && (e = hipEventRecord(ev_sort[1], s)) != hipSuccess) return e;
-        uint16_t *ranks = reinterpret_cast<uint16_t *>(d_scratch);
-        uint32_t *wf = reinterpret_cast<uint32_t *>(ranks + (size_t)nregions * 2 * g.RP);
+        const uint32_t run_len = walk_run_lds(g);
+        const uint32_t runs = (g.TILE + run_len - 1) / run_len, SUB = run_len + g.SBu;
+        uint16_t *subs = reinterpret_cast<uint16_t *>(d_scratch);
+        uint32_t *wf = reinterpret_cast<uint32_t *>(subs + (size_t)nregions * runs * 2 * SUB);
         uint32_t *wb = wf + (size_t)nregions * g.TILE;
         uint32_t *wb0 = wb + (size_t)nregions * g.TILE;
-        const char *rl = getenv("LZ77X_WALK_RUN");
-        uint32_t run_len = rl && atoi(rl) > 0 ? (uint32_t)atoi(rl) : WALK_RUN_DEFAULT;
-        run_len = (run_len + 7u) & ~7u;
-        if (run_len > g.TILE) run_len = g.TILE;
-        const uint32_t runs = (g.TILE + run_len - 1) / run_len;
         const uint64_t walkers = (uint64_t)nregions * runs;
-        const size_t lds = ((size_t)(g.RP >> 5) + (((g.RP >> 5) + 31) >> 5)) * 64 * sizeof(uint32_t);
+        const size_t lds = (size_t)((SUB + 31) >> 5) * 64 * sizeof(uint32_t);
         if (lds > 48 * 1024) {
             e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_walk), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             if (e != hipSuccess) return e;
         }
-        hipLaunchKernelGGL(k_walk, dim3((uint32_t)((walkers + 63) / 64)), dim3(64), lds, s, ranks, n, g.sb, g.RP, g.TILE,
+        hipLaunchKernelGGL(k_walk, dim3((uint32_t)((walkers + 63) / 64)), dim3(64), lds, s, subs, n, g.sb, g.SBu, g.TILE,
                            region0, nregions, run_len, runs, wf, wb, wb0);
         if (ev_sort && (e = hipEventRecord(ev_sort[2], s)) != hipSuccess) return e;
         const uint64_t npos = (uint64_t)nregions * g.TILE;
-        hipLaunchKernelGGL(k_walk_final, dim3((uint32_t)((npos + 255) / 256)), dim3(256), 0, s, d_in, n, g.sb, g.la, g.RP,
-                           g.TILE, region0, nregions, ranks, wf, wb, wb0, d_ps, d_maxlen);
+        hipLaunchKernelGGL(k_walk_final, dim3((uint32_t)((npos + 255) / 256)), dim3(256), 0, s, d_in, n, g.sb, g.la, g.SBu,
+                           g.TILE, region0, nregions, run_len, runs, subs, wf, wb, wb0, d_ps, d_maxlen);
         return hipGetLastError();
     }
     if (variant == 1) return launch_match<false, 1>(LZ77K_MATCH_ARGS);
