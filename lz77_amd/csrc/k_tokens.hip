@@ -128,8 +128,12 @@ __global__ __launch_bounds__(256) void k_tokens(const uint8_t *__restrict__ in, 
 
 /* ---- tiled variant: window bytes and the hand-over lists of a tile staged in LDS ---- */
 
+#ifndef TOK_TILE
 #define TOK_TILE 2048u
+#endif
+#ifndef TOK_BLOCK
 #define TOK_BLOCK 512
+#endif
 
 __global__ void k_tok_bounds(const uint32_t *__restrict__ chain, uint32_t ntok, uint32_t pos0, uint32_t ntiles,
                              uint32_t *__restrict__ tstart)
@@ -194,9 +198,11 @@ __global__ __launch_bounds__(TOK_BLOCK) void k_tokens_tile(const uint8_t *__rest
         for (uint32_t i = tid; i < NO; i += TOK_BLOCK) atomicAdd(&bcur[tok_hash(by[i], by[i + 1])], 1u);
         __syncthreads();
         {
-            static_assert(TOK_HASH == 4 * TOK_BLOCK, "four buckets per thread");
-            const uint4 c = *reinterpret_cast<const uint4 *>(bcur + 4 * tid);
-            const uint32_t mine = c.x + c.y + c.z + c.w;
+            constexpr int BPT = TOK_HASH / TOK_BLOCK;         /* buckets per thread */
+            static_assert(BPT * TOK_BLOCK == TOK_HASH && BPT >= 1, "whole buckets per thread");
+            uint32_t c[BPT], mine = 0;
+#pragma unroll
+            for (int q = 0; q < BPT; q++) { c[q] = bcur[BPT * tid + q]; mine += c[q]; }
             uint32_t incl = mine;
 #pragma unroll
             for (int d = 1; d < 64; d <<= 1) {
@@ -207,8 +213,10 @@ __global__ __launch_bounds__(TOK_BLOCK) void k_tokens_tile(const uint8_t *__rest
             __syncthreads();
             uint32_t woff = 0;
             for (uint32_t w = 0; w < wave; w++) woff += wsum[w];
-            const uint32_t excl = woff + incl - mine;
-            *reinterpret_cast<uint4 *>(bstart + 4 * tid) = make_uint4(excl, excl + c.x, excl + c.x + c.y, excl + c.x + c.y + c.z);
+            uint32_t excl = woff + incl - mine;
+#pragma unroll
+            for (int q = 0; q < BPT; q++) { bstart[BPT * tid + q] = excl; excl += c[q]; }
+            excl -= mine;
             if (tid == TOK_BLOCK - 1) bstart[TOK_HASH] = excl + mine;
         }
         __syncthreads();
@@ -498,7 +506,10 @@ hipError_t lz77k_tokens(const uint8_t *d_in, uint32_t n, const lz77x_geom &g, co
         const uint32_t bkt_off = (lofs_off + 2 * (span + 2) + 15) & ~15u;
         const uint32_t bkt_bytes = bucket ? ((TOK_HASH + 8) * 4 + 2 * span + 15) & ~15u : 0u;
         const uint32_t lent_off = bkt_off + bkt_bytes;
-        const uint32_t budget = 78u * 1024u;                         /* two workgroups per CU */
+#ifndef TOK_LDS_KB
+#define TOK_LDS_KB 78u                                               /* two workgroups per CU */
+#endif
+        const uint32_t budget = TOK_LDS_KB * 1024u;
         uint32_t ent_cap = lent_off + 5 * span < budget ? (budget - lent_off) / 8 : span;
         if (bucket && ent_cap < TOK_HASH / 2) ent_cap = TOK_HASH / 2; /* the lent area doubles as bcur (TOK_HASH words) */
         const size_t lds = (size_t)lent_off + (size_t)ent_cap * 8;
