@@ -112,3 +112,22 @@ hipError_t lz77k_scan_u32(const uint32_t *d_in, uint32_t *d_out, uint32_t m, voi
     return hipGetLastError();
 }
 
+
+/* 64-bit sum of m uint32 (the decoded size of a stream before anything trusts 32-bit offsets) */
+__global__ __launch_bounds__(256) void k_sum64(const uint32_t *__restrict__ in, uint32_t m, unsigned long long *__restrict__ out)
+{
+    unsigned long long acc = 0;
+    for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < m; i += gridDim.x * 256u) acc += in[i];
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) acc += __shfl_xor(acc, d, 64);
+    if ((threadIdx.x & 63u) == 0 && acc) atomicAdd(out, acc);
+}
+
+hipError_t lz77k_sum_u32(const uint32_t *d_in, uint32_t m, unsigned long long *d_out, hipStream_t s)
+{
+    hipError_t e = hipMemsetAsync(d_out, 0, sizeof(unsigned long long), s);
+    if (e != hipSuccess || m == 0) return e;
+    const uint32_t blocks = min((m + 255u) / 256u, 2048u);
+    hipLaunchKernelGGL(k_sum64, dim3(blocks), dim3(256), 0, s, d_in, m, d_out);
+    return hipGetLastError();
+}

@@ -103,6 +103,9 @@ hipError_t lz77k_ps_cells(const uint32_t *d_ps, uint32_t *d_cells, uint32_t x0, 
 size_t lz77k_scan_tmp_bytes(uint32_t m);
 hipError_t lz77k_scan_u32(const uint32_t *d_in, uint32_t *d_out, uint32_t m, void *d_tmp, hipStream_t s);
 
+/* *d_out = 64-bit sum of m uint32 */
+hipError_t lz77k_sum_u32(const uint32_t *d_in, uint32_t m, unsigned long long *d_out, hipStream_t s);
+
 /* hand-over index of evictions x in [xa, xb) into destinations [dbase, dend):
  * list(c) = ent[ (c > dbase ? ofs[c-dbase-1] : 0) .. ofs[c-dbase] ).  d_ofs: dend-dbase+1 words */
 hipError_t lz77k_xfer_index(const uint32_t *d_ps, const uint32_t *d_xval, uint32_t xa, uint32_t xb,

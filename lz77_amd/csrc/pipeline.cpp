@@ -728,18 +728,15 @@ int decode_core(Ctx &c, size_t zn, hipStream_t s, bool want_data, size_t *n_out)
         if ((rc = c.scantmp.need(lz77k_scan_tmp_bytes(ntok + 1)))) return rc;
         HIPCHK(lz77k_dec_parse(c.z.as<uint8_t>(), ntok, g, c.tokval.as<uint32_t>(), c.len1.as<uint32_t>(), s));
         HIPCHK(hipMemsetAsync(c.len1.as<uint32_t>() + ntok, 0, 4, s));
-        /* decoded size can exceed 32 bits for hostile streams: bound it before trusting the scan */
+        /* decoded size can exceed 32 bits for hostile streams: bound it (64-bit sum on the device)
+         * before trusting the 32-bit scan */
         if ((uint64_t)ntok * ((1u << g.lb)) > LZ77X_MAX_N) {
-            /* exact check with a 64-bit host sum of a strided sample is not sound; do it fully */
-            PinBuf tmp;
-            if ((rc = tmp.need((size_t)ntok * 4))) return rc;
-            HIPCHK(hipMemcpyAsync(tmp.p, c.len1.p, (size_t)ntok * 4, hipMemcpyDeviceToHost, s));
+            if ((rc = c.flag.need(64))) return rc;
+            unsigned long long *htot = reinterpret_cast<unsigned long long *>(hdr + 48);
+            HIPCHK(lz77k_sum_u32(c.len1.as<uint32_t>(), ntok, c.flag.as<unsigned long long>() + 2, s));
+            HIPCHK(hipMemcpyAsync(htot, c.flag.as<unsigned long long>() + 2, 8, hipMemcpyDeviceToHost, s));
             HIPCHK(hipStreamSynchronize(s));
-            uint64_t tot = 0;
-            const uint32_t *l = tmp.as<uint32_t>();
-            for (uint32_t k = 0; k < ntok; k++) tot += l[k];
-            tmp.release();
-            if (tot > LZ77X_MAX_N) return LZ77X_E_TOOBIG;
+            if (*htot > LZ77X_MAX_N) return LZ77X_E_TOOBIG;
         }
         HIPCHK(lz77k_scan_u32(c.len1.as<uint32_t>(), c.dst.as<uint32_t>(), ntok + 1, c.scantmp.p, s));
         uint32_t *tot = reinterpret_cast<uint32_t *>(hdr + 16);
