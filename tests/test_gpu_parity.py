@@ -279,6 +279,18 @@ def test_cli_roundtrip(tmp_path, golden_dir):
     assert open(lz, "rb").read() == O.encode_bst(np.fromfile(src, dtype=np.uint8), 1000, 10)
 
 
+def test_decode_refuses_streams_that_expand_past_4gib():
+    """hostile stream: 17 M maximal copy tokens (60 MB) would decode to 4.3 GB; the size is summed in
+    64 bits on the device before any 32-bit offset is trusted, and the call fails with LZ77X_E_TOOBIG"""
+    v = 1 | (254 << 12)                                     # off=1, len=254, next=0 at s=4095 l=255 (T=28)
+    pair = (v | (v << 28)).to_bytes(7, "little")
+    z = bytes([0xFF, 0x0F, 0xFF, 0x00]) + pair * 8_500_000
+    with pytest.raises(L.Lz77Error) as e:
+        L.decode(z)
+    assert e.value.code == -8
+    assert L.decode(z[:4 + 7 * 1000]) == bytes(2000 * 255)   # the same tokens in a sane quantity decode (to zeros)
+
+
 def test_cli_streams_large_files_and_pipes(tmp_path):
     """the FILE* entry points stream through two 16 MiB pinned slots: several pieces each way, a pipe
     as input (size unknown up front: the device buffer grows), empty input, and the sharded fallback"""
