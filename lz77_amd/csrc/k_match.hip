@@ -1214,7 +1214,8 @@ static hipError_t launch_match(const uint8_t *d_in, uint32_t n, const lz77x_geom
 }
 
 hipError_t lz77k_match(const uint8_t *d_in, uint32_t n, const lz77x_geom &g, uint32_t region0, uint32_t nregions,
-                       uint32_t *d_ps, uint8_t *d_maxlen, void *d_scratch, int variant, hipStream_t s, hipEvent_t *ev_sort)
+                       uint32_t *d_ps, uint8_t *d_maxlen, void *d_scratch, int variant, hipStream_t s, hipEvent_t *ev_sort,
+                       uint32_t *d_ranks_all)
 {
     if (nregions == 0) return hipSuccess;
     if (g.shifted != !(variant == 1 || variant == 3)) return hipErrorInvalidValue;     /* layout of g must match the variant */
@@ -1257,14 +1258,17 @@ hipError_t lz77k_match(const uint8_t *d_in, uint32_t n, const lz77x_geom &g, uin
         /* production for large windows: sort (ranks stay in scratch) -> global-bitmap walkers -> finalize */
         hipError_t e = ev_sort ? hipEventRecord(ev_sort[0], s) : hipSuccess;
         if (e != hipSuccess) return e;
-        e = launch_match<false, 3>(LZ77K_MATCH_ARGS);
+        /* rank + inverse of every region: in the caller's persistent array (the rank-order tie-break
+         * reads them again once the host stage is through the chunk) or at the head of the scratch */
+        const size_t stride = 2 * (size_t)g.RP + 8;
+        uint32_t *ranks = d_ranks_all ? d_ranks_all + (size_t)region0 * stride : reinterpret_cast<uint32_t *>(d_scratch);
+        uint32_t *bitmaps = d_ranks_all ? reinterpret_cast<uint32_t *>(d_scratch) : ranks + (size_t)nregions * stride;
+        e = launch_match<false, 3>(d_in, n, g, region0, nregions, d_ps, d_maxlen, ranks, s);
         if (e != hipSuccess) return e;
         if (ev_sort && (e = hipEventRecord(ev_sort[1], s)) != hipSuccess) return e;
         const uint32_t run_len = walk_run_big(g);
         const uint32_t runs = (g.TILE + run_len - 1) / run_len;
         const size_t nws = (g.RP >> 5) + (((g.RP >> 5) + 31) >> 5);
-        uint32_t *ranks = reinterpret_cast<uint32_t *>(d_scratch);
-        uint32_t *bitmaps = ranks + (size_t)nregions * (2 * (size_t)g.RP + 8);
         const uint64_t walkers = (uint64_t)nregions * runs;
         uint2 *wf = reinterpret_cast<uint2 *>(bitmaps + walkers * nws);      /* (2RP+8)*4 and nws*4 are multiples of 8 */
         uint2 *wb = wf + (size_t)nregions * g.TILE;

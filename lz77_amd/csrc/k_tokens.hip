@@ -463,6 +463,88 @@ __global__ __launch_bounds__(256) void k_tokens_big(const uint8_t *__restrict__ 
     }
 }
 
+/* ---- large windows, production: candidates in RANK order -----------------------------------------
+ * The candidates whose match with p has the full length `len` are, with every other position of the
+ * region that shares those len bytes, one contiguous run around p in the region's sorted order
+ *  -- which the match stage has already computed.  A wave walks outward from rank[p], 32
+ * lanes down and 32 up: a lane fetches the position at its rank offset, checks the len bytes, and the
+ * run ends at the first failure in each direction; run members inside the window [p-sb, p) are the
+ * candidates.  No candidate index to build, and a token costs (run length)/32 rounds instead of a scan
+ * of every window position that starts with its two bytes (tens of thousands for "\0\0" at sb 65535). */
+__global__ __launch_bounds__(256) void k_tokens_rank(const uint8_t *__restrict__ in, uint32_t n, int sb, int ob, int lb,
+                                                     uint32_t RP, uint32_t TILE, const uint32_t *__restrict__ ranks_all,
+                                                     const uint32_t *__restrict__ chain, uint32_t ntok,
+                                                     const uint8_t *__restrict__ maxlen, const uint32_t *__restrict__ ofs,
+                                                     const uint2 *__restrict__ ent, uint32_t dbase, uint32_t *__restrict__ tokval)
+{
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t k = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (k >= ntok) return;
+    const uint32_t p = chain[k];
+    const uint32_t len = maxlen[p];
+    const uint32_t next = in[p + len];
+    const uint32_t usb = (uint32_t)sb;
+    uint32_t off = 0;
+    if (len > 0) {
+        const uint32_t reg = p >= usb ? (p - usb) / TILE : 0u;          /* the region whose walk answered p */
+        const uint32_t t0 = reg * TILE, ly = p - t0;
+        const uint64_t rend = (uint64_t)t0 + TILE + usb;
+        const uint32_t R = (rend < n ? (uint32_t)rend : n) - t0;
+        const uint32_t *rk = ranks_all + (size_t)reg * (2 * (size_t)RP + 8), *ix = rk + RP + 8;
+        const uint8_t *by = in + t0, *q = in + p;
+        const uint32_t ry = rk[ly];
+        const bool up = lane >= 32;
+        const uint32_t sub = lane & 31;
+        bool open_dn = true, open_up = true;                             /* wave-uniform */
+        uint64_t best = ~0ull;
+        for (uint32_t base = 1; open_dn || open_up; base += 32) {
+            const uint32_t d = base + sub;
+            const bool live = up ? (open_up && ry + d < R) : (open_dn && d <= ry);
+            uint32_t e = 0;
+            bool same = false;
+            if (live) {
+                e = ix[up ? ry + d : ry - d];
+                const uint8_t *r = by + e;
+                same = true;
+                for (uint32_t j = 0; j < len; j += 8) {
+                    uint64_t x = ld64u(r + j) ^ ld64u(q + j);
+                    const uint32_t rem = len - j;
+                    if (rem < 8) x &= (1ull << (8 * rem)) - 1ull;
+                    if (x) { same = false; break; }
+                }
+            }
+            const uint64_t okm = __ballot(same);
+            const uint32_t ok_dn = (uint32_t)okm, ok_up = (uint32_t)(okm >> 32);
+            const uint32_t n_dn = ok_dn == 0xFFFFFFFFu ? 32u : (uint32_t)__builtin_ctz(~ok_dn);   /* leading successes */
+            const uint32_t n_up = ok_up == 0xFFFFFFFFu ? 32u : (uint32_t)__builtin_ctz(~ok_up);
+            if (same && sub < (up ? n_up : n_dn) && e < ly && ly - e <= usb) {
+                const uint32_t c = t0 + e;
+                uint32_t prio = c, latest = 0;
+                bool any = false;
+                const uint32_t lo = c > dbase ? ofs[c - dbase - 1] : 0, hi = c >= dbase ? ofs[c - dbase] : 0;
+                for (uint32_t i = lo; i < hi; i++) {
+                    const uint2 t = ent[i];
+                    if ((uint64_t)t.x + usb < p && (!any || t.x > latest)) { any = true; latest = t.x; prio = t.y; }
+                }
+                const uint64_t key = ((uint64_t)prio << 32) | c;
+                best = key < best ? key : best;
+            }
+            open_dn = open_dn && n_dn == 32u;
+            open_up = open_up && n_up == 32u;
+        }
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) {
+            const uint64_t o = (uint64_t)__shfl_xor((unsigned long long)best, d, 64);
+            best = o < best ? o : best;
+        }
+        off = p - (uint32_t)(best & 0xFFFFFFFFu);
+    }
+    if (lane == 0) {
+        const uint32_t omask = ob >= 32 ? 0xFFFFFFFFu : (1u << ob) - 1u;
+        tokval[k] = (off & omask) | (len << ob) | (next << (ob + lb));
+    }
+}
+
 /* bytes of the global candidate index for token positions spanning npos (0 when the LDS tile kernel applies) */
 size_t lz77k_tokens_index_bytes(const lz77x_geom &g, size_t npos)
 {
@@ -477,11 +559,18 @@ size_t lz77k_tokens_tmp_bytes(uint32_t n) { return ((size_t)(n / TOK_TILE) + 8) 
 hipError_t lz77k_tokens(const uint8_t *d_in, uint32_t n, const lz77x_geom &g, const uint32_t *d_chain, uint32_t ntok,
                         const uint8_t *d_maxlen, const uint32_t *d_ofs, const uint2 *d_ent, uint32_t dbase,
                         uint32_t pos0, uint32_t pos1, uint32_t *d_tokval, uint32_t *d_tstart, void *d_index, int variant,
-                        hipStream_t s, hipEvent_t *ev_tie)
+                        hipStream_t s, hipEvent_t *ev_tie, const uint32_t *d_ranks_all)
 {
     if (ntok == 0) return hipSuccess;
 #define TIE_EV(i) do { if (ev_tie) { hipError_t ee_ = hipEventRecord(ev_tie[i], s); if (ee_ != hipSuccess) return ee_; } } while (0)
-    if (variant == 0 && g.sb > 8192 && d_index) {
+    if (variant == 0 && !g.fast && d_ranks_all) {
+        TIE_EV(0);
+        hipLaunchKernelGGL(k_tokens_rank, dim3((ntok + 3) / 4), dim3(256), 0, s, d_in, n, g.sb, g.ob, g.lb, g.RP, g.TILE, d_ranks_all,
+                           d_chain, ntok, d_maxlen, d_ofs, d_ent, dbase, d_tokval);
+        TIE_EV(1);
+        return hipGetLastError();
+    }
+    if ((variant == 0 || variant == 3) && g.sb > 8192 && d_index) {
         const uint32_t ntiles = (pos1 - pos0 + BIG_TT - 1) / BIG_TT;
         const uint32_t span = BIG_TT + (uint32_t)g.sb + 8;
         uint32_t *bs = reinterpret_cast<uint32_t *>(d_index);

@@ -92,7 +92,8 @@ size_t lz77k_match_lds_bytes(const lz77x_geom &g);
 hipError_t lz77k_match(const uint8_t *d_in, uint32_t n, const lz77x_geom &g,
                        uint32_t region0, uint32_t nregions,
                        uint32_t *d_ps, uint8_t *d_maxlen, void *d_scratch, int variant, hipStream_t s,
-                       hipEvent_t *ev_sort = nullptr /* [3]: before the region sort, between sort and walkers, after the walkers */);
+                       hipEvent_t *ev_sort = nullptr /* [3]: before the region sort, between sort and walkers, after the walkers */,
+                       uint32_t *d_ranks_all = nullptr /* large windows: (2RP+8) words per region of the WHOLE input, kept for lz77k_tokens */);
 
 hipError_t lz77k_fill_pad(uint8_t *d_in, uint32_t n, hipStream_t s);
 
@@ -114,8 +115,9 @@ hipError_t lz77k_xfer_index(const uint32_t *d_ps, const uint32_t *d_xval, uint32
                             uint32_t x_new = 0, unsigned long long *d_total = nullptr /* += hand-overs with x >= x_new */);
 
 /* tokens d_chain[0..ntok) lie in [pos0, pos1).  variant 0: tiled kernel (window, hand-over lists and a
- * two-byte candidate index in LDS) when sb <= 8192; variant 2: same without the index (every
- * candidate visited); else / variant 1: one wave per token straight from global memory.
+ * two-byte candidate index in LDS) when sb <= 8192, rank-order enumeration (d_ranks_all) above; variant 2:
+ * tiled without the index (every candidate visited); variant 3: large windows through the global two-byte
+ * index; else / variant 1: one wave per token straight from global memory.
  * d_tstart: lz77k_tokens_tmp_bytes(pos1-pos0). */
 size_t lz77k_tokens_tmp_bytes(uint32_t n);
 /* large windows (sb > 8192): bytes of the global two-byte candidate index for npos token positions */
@@ -125,7 +127,8 @@ hipError_t lz77k_tokens(const uint8_t *d_in, uint32_t n, const lz77x_geom &g,
                         const uint32_t *d_ofs, const uint2 *d_ent, uint32_t dbase,
                         uint32_t pos0, uint32_t pos1, uint32_t *d_tokval,
                         uint32_t *d_tstart, void *d_index, int variant, hipStream_t s,
-                        hipEvent_t *ev_tie = nullptr /* [2]: recorded around the tie-break kernel */);
+                        hipEvent_t *ev_tie = nullptr /* [2]: recorded around the tie-break kernel */,
+                        const uint32_t *d_ranks_all = nullptr /* large windows: the regions' rank + inverse arrays */);
 
 /* words [w0, w0+nw) of the output stream (word 0 = header) from tokval[0..ntok) */
 hipError_t lz77k_pack(const uint32_t *d_tokval, uint64_t ntok, const lz77x_geom &g,

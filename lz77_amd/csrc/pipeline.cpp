@@ -134,7 +134,7 @@ struct Ctx {
     hipEvent_t ev[6] = {};
     std::vector<hipEvent_t> chunk_ev, tok_ev, sort_ev, match_ev, tie_ev;
     DevBuf in, ps, maxlen, scratch, xval, chain, ofs, ent, tokval, out, scantmp;
-    DevBuf z, len1, dst, ptr, flag, tstart, bidx, cells;
+    DevBuf z, len1, dst, ptr, flag, tstart, bidx, cells, ranks_all;
     PinBuf h_ps, h_maxlen, h_xval, h_chain, h_small, h_tok, h_stage;
 };
 
@@ -300,6 +300,7 @@ int encode_core(std::vector<Ctx *> &cs, const void *src, bool src_on_device, siz
         const int variant = vs ? atoi(vs) : 0;
         const char *tv = getenv("LZ77X_TOKEN_VARIANT");
         const int tvariant = tv ? atoi(tv) : 0;
+        const bool keep_ranks = !g.fast && tvariant == 0 && (variant == 0 || variant > 3);
         const char *sv = getenv("LZ77X_SERIAL");               /* profiling aid: token kernels queue behind */
         const bool serial = sv && atoi(sv);                    /* the match launches, no overlap */
         auto tstream = [&](uint32_t d) { return serial ? kstream(d) : cs[d]->tok; };
@@ -355,7 +356,10 @@ int encode_core(std::vector<Ctx *> &cs, const void *src, bool src_on_device, siz
             if ((rc = c.tstart.need(lz77k_tokens_tmp_bytes((uint32_t)idx_span)))) return rc;
             if ((rc = c.flag.need(64))) return rc;
             HIPCHK(hipMemsetAsync(c.flag.p, 0, 64, kstream(d)));
-            if ((rc = c.bidx.need(lz77k_tokens_index_bytes(g, chunk_pos < n ? chunk_pos : n)))) return rc;
+            if (keep_ranks) {
+                /* large windows: the regions' rank + inverse arrays stay resident for the rank-order tie-break */
+                if ((rc = c.ranks_all.need((size_t)nregions * (2 * (size_t)g.RP + 8) * sizeof(uint32_t)))) return rc;
+            } else if ((rc = c.bidx.need(lz77k_tokens_index_bytes(g, chunk_pos < n ? chunk_pos : n)))) return rc;
             while (c.chunk_ev.size() < 3 * (size_t)nchunks) {
                 hipEvent_t e;
                 /* ordering only; host waiters sleep instead of spinning next to the recurrence thread */
@@ -408,7 +412,8 @@ int encode_core(std::vector<Ctx *> &cs, const void *src, bool src_on_device, siz
             }
             if (G.d == 0) HIPCHK(hipEventRecord(c.match_ev[2 * launches0], kstream(G.d)));
             HIPCHK(lz77k_match(c.in.as<uint8_t>(), n32, g, r0, nr, c.ps.as<uint32_t>(), c.maxlen.as<uint8_t>(),
-                               c.scratch.p, variant, kstream(G.d), G.d == 0 ? &c.sort_ev[3 * launches0] : nullptr));
+                               c.scratch.p, variant, kstream(G.d), G.d == 0 ? &c.sort_ev[3 * launches0] : nullptr,
+                               keep_ranks ? c.ranks_all.as<uint32_t>() : nullptr));
             g_stats.match_launches++;
             {
                 const size_t gb = (size_t)r0 * g.TILE;
@@ -572,7 +577,7 @@ int encode_core(std::vector<Ctx *> &cs, const void *src, bool src_on_device, siz
                 if ((q = lz77k_tokens(c.in.as<uint8_t>(), n32, g, c.chain.as<uint32_t>() + tok_sent[d], (uint32_t)(ntok_sz - tok_sent[d]),
                                       c.maxlen.as<uint8_t>(), c.ofs.as<uint32_t>(), c.ent.as<uint2>(), dbase, (uint32_t)b, (uint32_t)e,
                                       c.tokval.as<uint32_t>() + tok_sent[d], c.tstart.as<uint32_t>(), c.bidx.p, tvariant, tstream(d),
-                                      &c.tie_ev[2 * ci])) != hipSuccess) return q;
+                                      &c.tie_ev[2 * ci], keep_ranks ? c.ranks_all.as<uint32_t>() : nullptr)) != hipSuccess) return q;
                 tie_timed[ci] = ntok_sz > tok_sent[d];
                 if ((q = hipEventRecord(c.tok_ev[2 * ci + 1], tstream(d))) != hipSuccess) return q;
                 return tstream(d) == c.tok ? hipSuccess : hipStreamWaitEvent(c.tok, c.tok_ev[2 * ci + 1], 0);

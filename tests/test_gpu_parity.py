@@ -224,6 +224,17 @@ def test_large_window_sort_variants_agree(sortv, sb, la, monkeypatch):
     assert L.encode(data, la, sb) == want
 
 
+@pytest.mark.parametrize("tokv", ["0", "1", "3"])
+@pytest.mark.parametrize("sb,la,kind", [(65535, 255, "mixed"), (8192, 16, "text"), (20000, 40, "lowent")])
+def test_large_window_token_variants_agree(tokv, sb, la, kind, monkeypatch):
+    """large windows: rank-order candidate enumeration (production) vs the global two-byte index vs the
+    plain one-wave-per-token scan"""
+    data = synth.make(kind, 900_000, 88)
+    want = O.encode_bst(data, sb, la)
+    monkeypatch.setenv("LZ77X_TOKEN_VARIANT", tokv)
+    assert L.encode(data, la, sb) == want
+
+
 def test_roundtrip_incompressible_large():
     """S2-like: 256 MiB of splitmix64 bytes (the match-miss path): size formulas and round trip"""
     n = 256 << 20
