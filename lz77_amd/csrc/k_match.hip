@@ -494,7 +494,7 @@ __global__ __launch_bounds__(MATCH_BLOCK, (FAST && MODE == 3) ? 8 : 1) void k_ma
         if constexpr (FAST) region_sort_merge<uint16_t, true>(reinterpret_cast<uint16_t *>(ix), by, R, la, tid);
     } else if (FAST && RP == 16 * MATCH_BLOCK && sort_variant == 2) {
         if constexpr (FAST) region_sort_blocked<uint16_t, true>(reinterpret_cast<uint16_t *>(ix), by, R, la, tid, false, true);
-    } else if (!FAST && RP > 16 * MATCH_BLOCK && sort_variant == 0) {
+    } else if (!FAST && RP > 16 * MATCH_BLOCK && (sort_variant & 15) == 0) {
         if constexpr (!FAST) {
             /* large region: merge-sort RP/CH chunks in LDS, then merge levels L = CH, 2CH, ... between
              * the two global index arrays of the region (the rank array is free until the sort ends) */
@@ -512,14 +512,14 @@ __global__ __launch_bounds__(MATCH_BLOCK, (FAST && MODE == 3) ? 8 : 1) void k_ma
                     *reinterpret_cast<uint32_t *>(lby + i) = ld32u(by + cb + i);
                 for (uint32_t i = tid; i < CH; i += MATCH_BLOCK) lix[i] = i;
                 __syncthreads();
-                if (Rl) region_sort_merge<uint32_t, true>(lix, lby, Rl, la, tid);
+                if (Rl && !(sort_variant & 32)) region_sort_merge<uint32_t, true>(lix, lby, Rl, la, tid);   /* bit 5: timing ablation */
                 for (uint32_t i = tid * 4; i < CH; i += MATCH_BLOCK * 4) {                /* slots >= Rl stay >= R */
                     const uint4 v = *reinterpret_cast<const uint4 *>(lix + i);
                     *reinterpret_cast<uint4 *>(src + cb + i) = make_uint4(v.x + cb, v.y + cb, v.z + cb, v.w + cb);
                 }
                 __syncthreads();
             }
-            for (uint32_t L = CH; L < RP; L <<= 1) {
+            for (uint32_t L = CH; L < RP && !(sort_variant & 16); L <<= 1) {                 /* bit 4: timing ablation */
                 for (uint32_t o0 = 16 * tid; o0 < RP; o0 += 16 * MATCH_BLOCK) {
                     const uint32_t base = o0 & ~(2 * L - 1);
                     uint32_t v[16];
