@@ -81,7 +81,7 @@ def main():
     ap.add_argument("--sb", type=int, default=4095)
     ap.add_argument("--la", type=int, default=15)
     ap.add_argument("--kind", default="text")
-    ap.add_argument("--cpu-sample", type=int, default=32_000_000)
+    ap.add_argument("--cpu-sample", type=int, default=64_000_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     a = ap.parse_args()
 

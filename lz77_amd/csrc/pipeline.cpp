@@ -452,7 +452,7 @@ int encode_core(std::vector<Ctx *> &cs, const void *src, bool src_on_device, siz
         uint32_t h2d_done = 0;                         /* chunks whose host->device copy has landed  (guarded by pm) */
         bool abort_all = false;
         std::atomic<int> prio_err{0};
-        double t_prio = 0;
+        double t_prio = 0, t_prio_first = 0, t_prio_last = 0;     /* recurrence: start of chunk 0, end of the last chunk */
         std::thread prio_thread([&]() {
             for (uint32_t ci = 0; ci < nchunks; ci++) {
                 const size_t b = chunk_b(ci), e = chunk_e(ci);
@@ -470,6 +470,8 @@ int encode_core(std::vector<Ctx *> &cs, const void *src, bool src_on_device, siz
                 }
                 lz77x_prio_run(&st, rebase32(ps_slot(ci), ci), g.sb, e, rebase32(xv_slot(ci), ci));
                 t_prio += now_ms() - t0;
+                if (ci == 0) t_prio_first = t0;
+                t_prio_last = now_ms();
                 { std::lock_guard<std::mutex> lk(pm); prio_chunks = ci + 1; }
                 pcv.notify_all();
             }
@@ -611,6 +613,9 @@ int encode_core(std::vector<Ctx *> &cs, const void *src, bool src_on_device, siz
         }
         g_stats.host_chain_ms = t_chain;
         g_stats.host_stageb_ms = t_prio;
+        if (trace_on())
+            fprintf(stderr, "[lz77x] recurrence starts %.2f ms into the call, ends at %.2f; chunk loop done at %.2f\n",
+                    t_prio_first - t_begin, t_prio_last - t_begin, now_ms() - t_begin);
 
         /* hand-overs were counted by the index kernels (each eviction once, by the shard that first saw it) */
         for (uint32_t d = 0; d < D; d++) {
@@ -698,6 +703,7 @@ int encode_core(std::vector<Ctx *> &cs, const void *src, bool src_on_device, siz
     g_stats.ntok = ntok;
     g_stats.transfers = transfers;
     g_stats.total_ms = now_ms() - t_begin;
+    TRACE("encode_core total", t_begin);
     g_stats.copy_ms = waited;               /* host time blocked on the device (not overlapped) */
     return LZ77X_OK;
 }
