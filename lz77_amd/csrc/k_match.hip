@@ -800,7 +800,15 @@ __global__ __launch_bounds__(64) void k_walk(const uint16_t *__restrict__ subs, 
     uint32_t *of = wf + (size_t)reg * TILE + lo, *ob = wb + (size_t)reg * TILE + lo;   /* indexed by t */
 
     for (uint32_t w = 0; w < NW; w++) bm[w * 64u + lane] = 0;
-    auto set_bit = [&](uint32_t r) { atomicOr(&BM_WORD(r >> 5), 1u << (r & 31)); };
+    /* no set bit lies in a word below lo_w or above hi_w: what keeps a query that HAS no neighbour on
+     * one side (every step of a run of equal bytes: the window is the top or the bottom of the order)
+     * from scanning the whole bitmap.  Sets widen the bounds, a scan that finds nothing tightens them. */
+    uint32_t lo_w = NW, hi_w = 0;
+    auto set_bit = [&](uint32_t r) {
+        atomicOr(&BM_WORD(r >> 5), 1u << (r & 31));
+        lo_w = min(lo_w, r >> 5);
+        hi_w = max(hi_w, r >> 5);
+    };
     auto load8 = [&](uint32_t i, uint32_t (&v)[4]) {          /* sub-ranks i..i+7, any alignment */
         if (i + 8 <= SUB) {
             uint4 t;
@@ -820,15 +828,20 @@ __global__ __launch_bounds__(64) void k_walk(const uint16_t *__restrict__ subs, 
     auto succ_of = [&](uint32_t w0, uint32_t b0, uint32_t here, uint32_t next) -> uint32_t {
         uint32_t m = here & ~((2u << b0) - 1u), w = w0;
         if (!m && w0 + 1 < NW) { m = next; w = w0 + 1; }
-        if (!m)
-            for (w = w0 + 2; w < NW; w++) if ((m = BM_WORD(w))) break;
+        if (!m) {
+            for (w = w0 + 2; w <= hi_w; w++) if ((m = BM_WORD(w))) break;
+            if (!m) hi_w = min(hi_w, w0);
+        }
         return m ? (w << 5) + (uint32_t)__builtin_ctz(m) : WALK_NONE;
     };
     auto pred_of = [&](uint32_t w0, uint32_t b0, uint32_t here, uint32_t prev) -> uint32_t {
         uint32_t m = here & ((1u << b0) - 1u), w = w0;
         if (!m && w0 > 0) { m = prev; w = w0 - 1; }
-        if (!m && w0 > 1)
-            for (w = w0 - 2;; w--) { if ((m = BM_WORD(w)) || w == 0) break; }
+        if (!m) {
+            if (w0 > 1 && w0 - 2 >= lo_w)
+                for (w = w0 - 2;; w--) { if ((m = BM_WORD(w)) || w == lo_w) break; }
+            if (!m) lo_w = max(lo_w, w0);
+        }
         return m ? (w << 5) + 31u - (uint32_t)__builtin_clz(m) : WALK_NONE;
     };
     auto query = [&](uint32_t q) -> uint32_t {                /* successor | predecessor << 16 */
@@ -991,9 +1004,14 @@ __global__ __launch_bounds__(64) void k_walk_big(const uint32_t *__restrict__ ra
      * one of them to the memory side of the fabric -- measured 15 us per step instead of ~2. */
     auto ldw = [&](const g_u32 *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); };
     auto stw = [&](g_u32 *p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); };
+    /* no set bit lies in a word below lo_w or above hi_w (see k_walk): loose after the ballot fill, widened
+     * by sets, tightened by every scan that finds nothing */
+    uint32_t lo_w = 0, hi_w = NW - 1;
     auto set_bit = [&](uint32_t r) {
         __hip_atomic_fetch_or(&word[r >> 5], 1u << (r & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         __hip_atomic_fetch_or(&summ[r >> 10], 1u << ((r >> 5) & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        lo_w = min(lo_w, r >> 5);
+        hi_w = max(hi_w, r >> 5);
     };
     /* These bitmaps live in HBM (34 KB per walker, hundreds of MB per launch): every access is a random
      * 64-byte line and the walk is bound by how many of them a step needs.  So a query looks at its own
@@ -1002,17 +1020,19 @@ __global__ __launch_bounds__(64) void k_walk_big(const uint32_t *__restrict__ ra
      * windows at the start of the input cost O(1) per query too.  Results leave as ranks; the lookups
      * rank -> position are k_walk_final_big's (there they are independent and massively parallel). */
     auto up_slow = [&](uint32_t w) -> uint32_t {             /* first set rank in words > w, or NONE */
+        if (w >= hi_w) return NONE;
         uint32_t sw = w >> 5, sm = ldw(&summ[sw]) & ~((2u << (w & 31)) - 1u);
-        while (!sm && ++sw < NS) sm = ldw(&summ[sw]);
-        if (!sm) return NONE;
+        while (!sm && ++sw <= (hi_w >> 5)) sm = ldw(&summ[sw]);
+        if (!sm) { hi_w = w; return NONE; }
         const uint32_t w2 = (sw << 5) + (uint32_t)__builtin_ctz(sm);
         return (w2 << 5) + (uint32_t)__builtin_ctz(ldw(&word[w2]));
     };
     auto down_slow = [&](uint32_t w) -> uint32_t {           /* last set rank in words < w, or NONE */
+        if (w <= lo_w) return NONE;
         int32_t sw = (int32_t)(w >> 5);
         uint32_t sm = ldw(&summ[sw]) & ((1u << (w & 31)) - 1u);
-        while (!sm && --sw >= 0) sm = ldw(&summ[sw]);
-        if (!sm) return NONE;
+        while (!sm && --sw >= (int32_t)(lo_w >> 5)) sm = ldw(&summ[sw]);
+        if (!sm) { lo_w = w; return NONE; }
         const uint32_t w2 = ((uint32_t)sw << 5) + 31u - (uint32_t)__builtin_clz(sm);
         return (w2 << 5) + 31u - (uint32_t)__builtin_clz(ldw(&word[w2]));
     };

@@ -497,40 +497,92 @@ __global__ __launch_bounds__(256) void k_tokens_rank(const uint8_t *__restrict__
         const uint32_t sub = lane & 31;
         bool open_dn = true, open_up = true;                             /* wave-uniform */
         uint64_t best = ~0ull;
+        auto shares = [&](uint32_t pos) -> bool {                        /* len bytes at pos == len bytes at p ? */
+            const uint8_t *r = by + pos;
+            for (uint32_t j = 0; j < len; j += 8) {
+                uint64_t x = ld64u(r + j) ^ ld64u(q + j);
+                const uint32_t rem = len - j;
+                if (rem < 8) x &= (1ull << (8 * rem)) - 1ull;
+                if (x) return false;
+            }
+            return true;
+        };
+        auto consider = [&](uint32_t e) {                                /* candidate at local index e: its priority at time p */
+            const uint32_t c = t0 + e;
+            uint32_t prio = c, latest = 0;
+            bool any = false;
+            const uint32_t lo = c > dbase ? ofs[c - dbase - 1] : 0, hi = c >= dbase ? ofs[c - dbase] : 0;
+            for (uint32_t i = lo; i < hi; i++) {
+                const uint2 t = ent[i];
+                if ((uint64_t)t.x + usb < p && (!any || t.x > latest)) { any = true; latest = t.x; prio = t.y; }
+            }
+            const uint64_t key = ((uint64_t)prio << 32) | c;
+            best = key < best ? key : best;
+        };
+        bool long_run = false;
         for (uint32_t base = 1; open_dn || open_up; base += 32) {
+            if (base > 4 * 32) { long_run = true; break; }
             const uint32_t d = base + sub;
             const bool live = up ? (open_up && ry + d < R) : (open_dn && d <= ry);
             uint32_t e = 0;
             bool same = false;
-            if (live) {
-                e = ix[up ? ry + d : ry - d];
-                const uint8_t *r = by + e;
-                same = true;
-                for (uint32_t j = 0; j < len; j += 8) {
-                    uint64_t x = ld64u(r + j) ^ ld64u(q + j);
-                    const uint32_t rem = len - j;
-                    if (rem < 8) x &= (1ull << (8 * rem)) - 1ull;
-                    if (x) { same = false; break; }
-                }
-            }
+            if (live) e = ix[up ? ry + d : ry - d];
+            /* The order is sorted: if the FARTHEST element of a round still shares the len bytes, so do the
+             * 31 before it; only the round that contains the end of the run compares on every lane. */
+            const bool probe = live && sub == 31;
+            if (probe) same = shares(e);
+            const uint64_t far = __ballot(same);
+            const bool whole = (far >> (up ? 63 : 31)) & 1ull;
+            if (live && !probe) same = whole || shares(e);
             const uint64_t okm = __ballot(same);
             const uint32_t ok_dn = (uint32_t)okm, ok_up = (uint32_t)(okm >> 32);
             const uint32_t n_dn = ok_dn == 0xFFFFFFFFu ? 32u : (uint32_t)__builtin_ctz(~ok_dn);   /* leading successes */
             const uint32_t n_up = ok_up == 0xFFFFFFFFu ? 32u : (uint32_t)__builtin_ctz(~ok_up);
-            if (same && sub < (up ? n_up : n_dn) && e < ly && ly - e <= usb) {
-                const uint32_t c = t0 + e;
-                uint32_t prio = c, latest = 0;
-                bool any = false;
-                const uint32_t lo = c > dbase ? ofs[c - dbase - 1] : 0, hi = c >= dbase ? ofs[c - dbase] : 0;
-                for (uint32_t i = lo; i < hi; i++) {
-                    const uint2 t = ent[i];
-                    if ((uint64_t)t.x + usb < p && (!any || t.x > latest)) { any = true; latest = t.x; prio = t.y; }
-                }
-                const uint64_t key = ((uint64_t)prio << 32) | c;
-                best = key < best ? key : best;
-            }
+            if (same && sub < (up ? n_up : n_dn) && e < ly && ly - e <= usb) consider(e);
             open_dn = open_dn && n_dn == 32u;
             open_up = open_up && n_up == 32u;
+        }
+        if (long_run) {
+            /* The run goes on (short matches share their bytes with thousands of positions; a stretch of
+             * equal bytes makes the WHOLE region one run, four times the window).  Find where it ends in
+             * each direction -- "shares" is monotone along the order, a 64-ary search needs three or four
+             * rounds -- then either finish the walk without comparing bytes, or, if the run is longer than
+             * half the window, sweep the window itself (sb coalesced rank loads) and keep the positions
+             * whose rank falls inside the run. */
+            auto extent = [&](bool updir) -> uint32_t {                  /* largest rank offset still in the run */
+                uint32_t lo = 0, hi = (updir ? R - 1 - ry : ry) + 1;     /* true at lo, false (out of range) at hi */
+                while (hi - lo > 1) {
+                    const uint64_t span = hi - lo;
+                    const uint32_t d = lo + (uint32_t)(span * (lane + 1) / 65);          /* lo <= d < hi, increasing in lane */
+                    const bool ok = d == lo || shares(ix[updir ? ry + d : ry - d]);
+                    const uint64_t m = __ballot(ok);
+                    const uint32_t top = m == ~0ull ? 64u : (uint32_t)__builtin_ctzll(~m);   /* lanes 0..top-1 are in */
+                    const uint32_t nlo = top ? lo + (uint32_t)(span * top / 65) : lo;
+                    const uint32_t nhi = top < 64 ? lo + (uint32_t)(span * (top + 1) / 65) : hi;
+                    lo = nlo;
+                    hi = nhi;
+                }
+                return lo;
+            };
+            const uint32_t d_dn = open_dn ? extent(false) : 0u, d_up = open_up ? extent(true) : 0u;
+            if (max(d_dn, d_up) > usb / 2) {
+                /* sweeping the window (sb/64 rounds) is cheaper than walking the run (max(d)/32 rounds) */
+                const uint32_t r_lo = ry - d_dn, r_hi = ry + d_up;
+                for (uint32_t c0 = ly > usb ? ly - usb : 0u; c0 < ly; c0 += 64) {
+                    const uint32_t e = c0 + lane;
+                    if (e < ly) {
+                        const uint32_t rc = rk[e];
+                        if (rc >= r_lo && rc <= r_hi) consider(e);
+                    }
+                }
+            } else {
+                /* the rest of the run, now without comparing bytes */
+                const uint32_t lim = up ? d_up : d_dn;
+                for (uint32_t d = 4 * 32 + 1 + sub; d <= lim; d += 32) {
+                    const uint32_t e = ix[up ? ry + d : ry - d];
+                    if (e < ly && ly - e <= usb) consider(e);
+                }
+            }
         }
 #pragma unroll
         for (int d = 32; d > 0; d >>= 1) {
