@@ -235,6 +235,23 @@ def test_large_window_token_variants_agree(tokv, sb, la, kind, monkeypatch):
     assert L.encode(data, la, sb) == want
 
 
+@pytest.mark.parametrize("sb,la", [(4095, 15), (65535, 255), (20000, 40)])
+@pytest.mark.parametrize("period", [1, 2, 7, 300, 5000])
+def test_periodic_inputs(sb, la, period):
+    """stretches of equal / periodic bytes: every window position is a full-length candidate, the window
+    sits at one end of the key order (walker queries with no neighbour on one side) and the run of the
+    rank-order tie-break spans the whole region (measured by search, replaced by a window sweep)"""
+    n = 60_000 if sb > 8192 else 150_000
+    if period <= 2:
+        n //= 2                                                # the oracle's tree degenerates to a list there
+    base = np.frombuffer(bytes((i * 37 + 11) % 251 for i in range(period)), dtype=np.uint8)
+    data = np.tile(base, n // period + 1)[:n].copy()
+    data[n // 2] ^= 0x55                                       # one irregularity in the middle
+    z = L.encode(data, la, sb)
+    assert z == O.encode_bst(data, sb, la)
+    assert L.decode(z) == data.tobytes()
+
+
 def test_roundtrip_incompressible_large():
     """S2-like: 256 MiB of splitmix64 bytes (the match-miss path): size formulas and round trip"""
     n = 256 << 20
