@@ -1170,7 +1170,7 @@ __global__ __launch_bounds__(256) void k_walk_final_big(const uint8_t *__restric
     if (region0 + reg == 0 && lx < (uint32_t)sb) maxlen[x64] = (uint8_t)longest(wb0[lx], lx);
 }
 
-#define WALK_RUN_BIG_DEFAULT 4096u
+#define WALK_RUN_BIG_DEFAULT 2048u
 
 #define WALK_RUN_DEFAULT 1024u
 
