@@ -13,7 +13,8 @@
  * matches (A.5) -- are reproduced bit for bit.
  *
  * Plain C, plain pointers and sizes.  No global state is required between calls;
- * a lazily created per-process context caches device scratch buffers.
+ * lazily created per-process contexts cache device scratch buffers.  Thread safe: concurrent
+ * callers each lease a context of their own (up to LZ77X_MAX_CONTEXTS, default 4; others wait).
  * All functions return 0 on success or a negative LZ77X_E_* code and never print.
  */
 #ifndef LZ77_MI355X_H

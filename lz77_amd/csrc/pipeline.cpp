@@ -138,9 +138,51 @@ struct Ctx {
     PinBuf h_ps, h_maxlen, h_xval, h_chain, h_small, h_tok, h_stage;
 };
 
-Ctx g_ctx;                                   /* context on the caller's current device */
-std::vector<Ctx *> g_more;                   /* contexts of the other shards (other devices) */
+/* One CtxSet serves one call at a time: `primary` lives on the caller's current device (pinned host
+ * buffers, final stream), `more` are the contexts of the other shards.  Concurrent callers (threads
+ * compressing different files) each lease their own set, up to LZ77X_MAX_CONTEXTS (default 4), so that
+ * the host recurrence of one stream overlaps the GPU work and the recurrences of the others -- one
+ * stream keeps the GPU busy for only a third of its own wall time. */
+struct CtxSet {
+    Ctx primary;
+    std::vector<Ctx *> more;
+    bool busy = false;
+};
+std::vector<CtxSet *> g_pool;
 std::mutex g_mu;
+std::condition_variable g_cv;
+
+struct Lease {
+    CtxSet *set = nullptr;
+    Lease()
+    {
+        int cur = -1;
+        if (hipGetDevice(&cur) != hipSuccess) cur = -1;
+        static int cap = 0;
+        std::unique_lock<std::mutex> lk(g_mu);
+        if (!cap) { const char *e = getenv("LZ77X_MAX_CONTEXTS"); cap = e && atoi(e) > 0 ? atoi(e) : 4; }
+        for (;;) {
+            CtxSet *elsewhere = nullptr;
+            for (CtxSet *s : g_pool) {
+                if (s->busy) continue;
+                if (!s->primary.ready || s->primary.device == cur) { set = s; break; }
+                elsewhere = s;
+            }
+            if (set) break;
+            if ((int)g_pool.size() < cap) { set = new CtxSet(); g_pool.push_back(set); break; }
+            if (elsewhere) { set = elsewhere; break; }       /* primary_context(*lease.set) moves it to this device */
+            g_cv.wait(lk);
+        }
+        set->busy = true;
+    }
+    ~Lease()
+    {
+        { std::lock_guard<std::mutex> lk(g_mu); set->busy = false; }
+        g_cv.notify_one();
+    }
+    Lease(const Lease &) = delete;
+    Lease &operator=(const Lease &) = delete;
+};
 
 int ctx_init(Ctx &c, int device = -1)
 {
@@ -183,22 +225,25 @@ void ctx_release(Ctx &c);
 
 /* The primary context lives on whatever device is current when the library is entered; if the
  * caller has switched devices since the last call, the cached contexts are rebuilt there. */
-int primary_context()
+int primary_context(CtxSet &S)
 {
+    Ctx &g_ctx = S.primary;
     int cur = -1;
     if (g_ctx.ready && hipGetDevice(&cur) == hipSuccess && cur != g_ctx.device) {
-        for (Ctx *c : g_more) { ctx_release(*c); delete c; }
-        g_more.clear();
+        for (Ctx *c : S.more) { ctx_release(*c); delete c; }
+        S.more.clear();
         ctx_release(g_ctx);
         HIPCHK(hipSetDevice(cur));
     }
     return ctx_init(g_ctx);
 }
 
-int shard_contexts(int want, std::vector<Ctx *> &cs)
+int shard_contexts(CtxSet &S, int want, std::vector<Ctx *> &cs)
 {
-    int rc = primary_context();
+    int rc = primary_context(S);
     if (rc) return rc;
+    Ctx &g_ctx = S.primary;
+    std::vector<Ctx *> &g_more = S.more;
     cs.clear();
     cs.push_back(&g_ctx);
     int logical = g_ctx.ndev;
@@ -939,12 +984,14 @@ int lz77x_encode(const uint8_t *in, size_t n, int sb, int la, uint8_t **out, siz
     if (!out || !out_n || (!in && n)) return LZ77X_E_ARG;
     int rc = check_geom(sb, la);
     if (rc) return rc;
-    std::lock_guard<std::mutex> lk(g_mu);
+    Lease lease;
+    Ctx &g_ctx = lease.set->primary;
+    (void)g_ctx;
     const double t0 = now_ms();
     std::vector<Ctx *> cs;
     int shards = g_shards;
     if (shards <= 0) { const char *e = getenv("LZ77X_SHARDS"); shards = e ? atoi(e) : 1; }
-    if ((rc = shard_contexts(shards < 1 ? 1 : shards, cs))) return rc;
+    if ((rc = shard_contexts(*lease.set, shards < 1 ? 1 : shards, cs))) return rc;
     TRACE("runtime + context init", t0);
     lz77x_geom g;
     make_encode_geom(&g, sb, la);
@@ -967,9 +1014,11 @@ int lz77x_encode_device(const void *d_in, size_t n, int sb, int la, void *d_out,
     if (!out_n || (!d_in && n) || !d_out) return LZ77X_E_ARG;
     int rc = check_geom(sb, la);
     if (rc) return rc;
-    std::lock_guard<std::mutex> lk(g_mu);
+    Lease lease;
+    Ctx &g_ctx = lease.set->primary;
+    (void)g_ctx;
     std::vector<Ctx *> cs;
-    if ((rc = shard_contexts(1, cs))) return rc;      /* device-resident buffers: the caller's device only */
+    if ((rc = shard_contexts(*lease.set, 1, cs))) return rc;      /* device-resident buffers: the caller's device only */
     lz77x_geom g;
     make_encode_geom(&g, sb, la);
     hipStream_t s = (hipStream_t)stream;
@@ -985,9 +1034,11 @@ int lz77x_encode_device(const void *d_in, size_t n, int sb, int la, void *d_out,
 int lz77x_decode(const uint8_t *z, size_t zn, uint8_t **out, size_t *out_n)
 {
     if (!out || !out_n || (!z && zn)) return LZ77X_E_ARG;
-    std::lock_guard<std::mutex> lk(g_mu);
+    Lease lease;
+    Ctx &g_ctx = lease.set->primary;
+    (void)g_ctx;
     int rc;
-    if ((rc = primary_context())) return rc;
+    if ((rc = primary_context(*lease.set))) return rc;
     if (zn < 4) return LZ77X_E_FORMAT;
     if ((rc = load_stream(g_ctx, z, false, zn, g_ctx.stream))) return rc;
     size_t n = 0;
@@ -1003,9 +1054,11 @@ int lz77x_decode(const uint8_t *z, size_t zn, uint8_t **out, size_t *out_n)
 int lz77x_decode_device(const void *d_z, size_t zn, void *d_out, size_t out_cap, size_t *out_n, void *stream)
 {
     if (!out_n || (!d_z && zn)) return LZ77X_E_ARG;
-    std::lock_guard<std::mutex> lk(g_mu);
+    Lease lease;
+    Ctx &g_ctx = lease.set->primary;
+    (void)g_ctx;
     int rc;
-    if ((rc = primary_context())) return rc;
+    if ((rc = primary_context(*lease.set))) return rc;
     if (zn < 4) return LZ77X_E_FORMAT;
     hipStream_t s = (hipStream_t)stream;
     if ((rc = load_stream(g_ctx, d_z, true, zn, s))) return rc;
@@ -1028,10 +1081,12 @@ int lz77x_encode_file(FILE *in, FILE *out, int la, int sb)
     int shards = g_shards;
     if (shards <= 0) { const char *e = getenv("LZ77X_SHARDS"); shards = e ? atoi(e) : 1; }
     if (shards > 1) return lz77x_encode_file_buffered(in, out, la, sb);
-    std::lock_guard<std::mutex> lk(g_mu);
+    Lease lease;
+    Ctx &g_ctx = lease.set->primary;
+    (void)g_ctx;
     const double t0 = now_ms();
     std::vector<Ctx *> cs;
-    if ((rc = shard_contexts(1, cs))) return rc;
+    if ((rc = shard_contexts(*lease.set, 1, cs))) return rc;
     TRACE("runtime + context init", t0);
     Ctx &c = g_ctx;
     size_t n = 0;
@@ -1054,9 +1109,11 @@ int lz77x_encode_file(FILE *in, FILE *out, int la, int sb)
 int lz77x_decode_file(FILE *in, FILE *out)
 {
     if (!in || !out) return LZ77X_E_ARG;
-    std::lock_guard<std::mutex> lk(g_mu);
+    Lease lease;
+    Ctx &g_ctx = lease.set->primary;
+    (void)g_ctx;
     int rc;
-    if ((rc = primary_context())) return rc;
+    if ((rc = primary_context(*lease.set))) return rc;
     Ctx &c = g_ctx;
     size_t zn = 0;
     if ((rc = stream_in(c, in, c.z, 32, &zn))) return rc;
@@ -1133,9 +1190,14 @@ extern "C" {
 void lz77x_shutdown(void)
 {
     std::lock_guard<std::mutex> lk(g_mu);
-    for (Ctx *c : g_more) { ctx_release(*c); delete c; }
-    g_more.clear();
-    ctx_release(g_ctx);
+    for (size_t i = 0; i < g_pool.size();) {
+        CtxSet *s = g_pool[i];
+        if (s->busy) { i++; continue; }                      /* another thread is inside the library with it */
+        for (Ctx *c : s->more) { ctx_release(*c); delete c; }
+        ctx_release(s->primary);
+        delete s;
+        g_pool.erase(g_pool.begin() + (long)i);
+    }
 }
 
 const char *lz77x_last_error(void) { return g_err; }
@@ -1150,14 +1212,14 @@ int lz77x_last_stats(lz77x_stats *st)
 
 /* ---- stage-level entry points ---- */
 
-static int run_match_only(const uint8_t *in, size_t n, int sb, int la, lz77x_geom *g)
+static int run_match_only(CtxSet &S, const uint8_t *in, size_t n, int sb, int la, lz77x_geom *g)
 {
     int rc = check_geom(sb, la);
     if (rc) return rc;
-    if ((rc = primary_context())) return rc;
+    if ((rc = primary_context(S))) return rc;
     if (n > LZ77X_MAX_N) return LZ77X_E_TOOBIG;
     make_encode_geom(g, sb, la);
-    Ctx &c = g_ctx;
+    Ctx &c = S.primary;
     hipStream_t s = c.stream;
     if ((rc = c.in.need(n + LZ77X_PAD + 16))) return rc;
     if ((rc = c.ps.need((n + 8) * 4))) return rc;
@@ -1188,9 +1250,11 @@ static int run_match_only(const uint8_t *in, size_t n, int sb, int la, lz77x_geo
 int lz77x_stage_maxlen(const uint8_t *in, size_t n, int sb, int la, uint8_t *maxlen)
 {
     if ((!in || !maxlen) && n) return LZ77X_E_ARG;
-    std::lock_guard<std::mutex> lk(g_mu);
+    Lease lease;
+    Ctx &g_ctx = lease.set->primary;
+    (void)g_ctx;
     lz77x_geom g;
-    int rc = run_match_only(in, n, sb, la, &g);
+    int rc = run_match_only(*lease.set, in, n, sb, la, &g);
     if (rc) return rc;
     if (n) HIPCHK(hipMemcpy(maxlen, g_ctx.maxlen.p, n, hipMemcpyDeviceToHost));
     return LZ77X_OK;
@@ -1199,9 +1263,11 @@ int lz77x_stage_maxlen(const uint8_t *in, size_t n, int sb, int la, uint8_t *max
 int lz77x_stage_neighbours(const uint8_t *in, size_t n, int sb, int la, uint16_t *P, uint16_t *S)
 {
     if ((!in || !P || !S) && n) return LZ77X_E_ARG;
-    std::lock_guard<std::mutex> lk(g_mu);
+    Lease lease;
+    Ctx &g_ctx = lease.set->primary;
+    (void)g_ctx;
     lz77x_geom g;
-    int rc = run_match_only(in, n, sb, la, &g);
+    int rc = run_match_only(*lease.set, in, n, sb, la, &g);
     if (rc) return rc;
     if (!n) return LZ77X_OK;
     uint32_t *tmp = (uint32_t *)malloc(n * 4);

@@ -307,6 +307,30 @@ def test_cli_roundtrip(tmp_path, golden_dir):
     assert open(lz, "rb").read() == O.encode_bst(np.fromfile(src, dtype=np.uint8), 1000, 10)
 
 
+def test_concurrent_calls_from_threads():
+    """callers on different threads lease their own device contexts: results are unaffected, and a
+    fifth caller simply waits for a free one (LZ77X_MAX_CONTEXTS defaults to 4)"""
+    import threading
+    inputs = [synth.make(k, 2_000_000 + 123_457 * i, 60 + i) for i, k in enumerate(["text", "mixed", "random", "code", "lowent", "records"])]
+    want = [O.encode_bst(d) for d in inputs]
+    got = [None] * len(inputs)
+    back = [None] * len(inputs)
+
+    def work(i):
+        for _ in range(2):
+            got[i] = L.encode(inputs[i])
+            back[i] = L.decode(got[i])
+
+    ts = [threading.Thread(target=work, args=(i,)) for i in range(len(inputs))]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    for i in range(len(inputs)):
+        assert got[i] == want[i], i
+        assert back[i] == inputs[i].tobytes(), i
+
+
 def test_decode_refuses_streams_that_expand_past_4gib():
     """hostile stream: 17 M maximal copy tokens (60 MB) would decode to 4.3 GB; the size is summed in
     64 bits on the device before any 32-bit offset is trusted, and the call fails with LZ77X_E_TOOBIG"""
