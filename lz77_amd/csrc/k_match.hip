@@ -235,6 +235,48 @@ __device__ __forceinline__ void merge16(const IdxT *A, uint32_t L, uint32_t d, c
     }
 }
 
+/* Global-memory merge levels of the large regions: out[0..nout) = outputs d .. d+nout-1 of the merge of
+ * A[0..L) and A[L..2L).  Every access is an L2 / HBM round trip and a workgroup has a CU to itself, so
+ * the merge-path search (log2 L dependent round trips) is amortised over 64 outputs instead of 16. */
+__device__ __forceinline__ void merge_run_global(const uint32_t *A, uint32_t L, uint32_t d, const uint8_t *by, uint32_t R, int la,
+                                                 uint32_t *out, uint32_t nout)
+{
+    uint32_t m[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const int rem = la - 4 * i;
+        m[i] = rem >= 4 ? 0xFFFFFFFFu : rem <= 0 ? 0u : 0xFFFFFFFFu << (8 * (4 - rem));
+    }
+    const uint32_t *B = A + L;
+    uint32_t lo = d > L ? d - L : 0, hi = d < L ? d : L;
+    while (lo < hi) {
+        const uint32_t mid = (lo + hi) >> 1;
+        const uint32_t a = A[mid], b = B[d - 1 - mid];
+        const key16 ka = load_key16<false>(by, a, a < R, m), kb = load_key16<false>(by, b, b < R, m);
+        if (sort_less16<false>(by, a, ka, b, kb, R, la)) lo = mid + 1; else hi = mid;
+    }
+    uint32_t ia = lo, ib = d - lo;
+    bool va = ia < L, vb = ib < L;
+    uint32_t a = va ? A[ia] : 0xFFFFFFFFu, b = vb ? B[ib] : 0xFFFFFFFFu;
+    key16 ka = load_key16<false>(by, a, a < R, m), kb = load_key16<false>(by, b, b < R, m);
+    for (uint32_t g = 0; g < nout; g += 4) {
+        uint32_t o[4];
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const bool take_a = !vb || (va && sort_less16<false>(by, a, ka, b, kb, R, la));
+            o[r] = take_a ? a : b;
+            ia += take_a ? 1u : 0u;
+            ib += take_a ? 0u : 1u;
+            const uint32_t pos = take_a ? ia : L + ib;
+            const bool valid = (take_a ? ia : ib) < L;
+            const uint32_t nv = valid ? A[pos] : 0xFFFFFFFFu;
+            const key16 nk = load_key16<false>(by, nv, nv < R, m);
+            if (take_a) { a = nv; ka = nk; va = valid; } else { b = nv; kb = nk; vb = valid; }
+        }
+        *reinterpret_cast<uint4 *>(out + g) = make_uint4(o[0], o[1], o[2], o[3]);
+    }
+}
+
 /*
  * Merge sort of CH = 16*1024 slots in LDS (the production sort): a thread sorts its 16 consecutive
  * slots in registers, then log2(CH/16) = 10 merge levels.  In a level every thread produces 16
@@ -520,13 +562,9 @@ __global__ __launch_bounds__(MATCH_BLOCK, (FAST && MODE == 3) ? 8 : 1) void k_ma
                 __syncthreads();
             }
             for (uint32_t L = CH; L < RP && !(sort_variant & 16); L <<= 1) {                 /* bit 4: timing ablation */
-                for (uint32_t o0 = 16 * tid; o0 < RP; o0 += 16 * MATCH_BLOCK) {
+                for (uint32_t o0 = 64 * tid; o0 < RP; o0 += 64 * MATCH_BLOCK) {
                     const uint32_t base = o0 & ~(2 * L - 1);
-                    uint32_t v[16];
-                    merge16<uint32_t, false>(src + base, L, o0 - base, by, R, la, v);
-#pragma unroll
-                    for (int r = 0; r < 16; r += 4)
-                        *reinterpret_cast<uint4 *>(dst + o0 + r) = make_uint4(v[r], v[r + 1], v[r + 2], v[r + 3]);
+                    merge_run_global(src + base, L, o0 - base, by, R, la, dst + o0, 64);
                 }
                 __syncthreads();
                 uint32_t *t = src; src = dst; dst = t;
