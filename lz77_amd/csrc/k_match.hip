@@ -20,12 +20,14 @@ typedef unsigned short us2 __attribute__((ext_vector_type(2)));
  *   stride < 1024  : both live in the 1024-slot segment ONE wave owns: LDS, no workgroup barrier
  *   stride >= 1024 : across waves: LDS + __syncthreads (10 of the 105 steps)
  */
+template <bool BYTES_LDS> __device__ __forceinline__ bool key_tail_less(const uint8_t *by, uint32_t a, uint32_t b, int la, int from);
+
 template <bool BYTES_LDS>
 __device__ __forceinline__ bool sort_less(const uint8_t *by, uint32_t a, uint32_t pa, uint32_t b, uint32_t pb, uint32_t R, int la)
 {
     if (pa != pb) return pa < pb;
     if (a >= R || b >= R) return a < b;
-    return key_less<BYTES_LDS>(by, a, b, la);
+    return la > 16 ? key_tail_less<BYTES_LDS>(by, a, b, la, 0) : key_less<BYTES_LDS>(by, a, b, la);
 }
 
 template <int J, bool STATIC_DIR, bool BYTES_LDS>
@@ -187,13 +189,32 @@ __device__ __forceinline__ key16 load_key16(const uint8_t *by, uint32_t a, bool 
     return r;
 }
 
+/* bytes from .. la-1 of two keys that agree before `from`, 16 at a time (la = 255 and repetitive
+ * data: most late compares get here, and every round trip is paid by the whole wavefront) */
+template <bool BYTES_LDS>
+__device__ __forceinline__ bool key_tail_less(const uint8_t *by, uint32_t a, uint32_t b, int la, int from)
+{
+    for (int w = from; w < la; w += 16) {
+        uint32_t m[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const int rem = la - w - 4 * i;
+            m[i] = rem >= 4 ? 0xFFFFFFFFu : rem <= 0 ? 0u : 0xFFFFFFFFu << (8 * (4 - rem));
+        }
+        const key16 ka = load_key16<BYTES_LDS>(by, a + (uint32_t)w, true, m), kb = load_key16<BYTES_LDS>(by, b + (uint32_t)w, true, m);
+        if (ka.hi != kb.hi) return ka.hi < kb.hi;
+        if (ka.lo != kb.lo) return ka.lo < kb.lo;
+    }
+    return a < b;
+}
+
 template <bool BYTES_LDS>
 __device__ __forceinline__ bool sort_less16(const uint8_t *by, uint32_t a, const key16 &ka, uint32_t b, const key16 &kb, uint32_t R, int la)
 {
     if (ka.hi != kb.hi) return ka.hi < kb.hi;
     if (ka.lo != kb.lo) return ka.lo < kb.lo;
     if (a >= R || b >= R) return a < b;
-    if (la > 16) return key_less<BYTES_LDS>(by, a, b, la);
+    if (la > 16) return key_tail_less<BYTES_LDS>(by, a, b, la, 16);
     return a < b;
 }
 
