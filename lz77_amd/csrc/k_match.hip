@@ -1078,22 +1078,32 @@ __global__ __launch_bounds__(64) void k_walk_big(const uint32_t *__restrict__ ra
      * time in 10^4), and only then at the summary -- which is still maintained, so that the nearly empty
      * windows at the start of the input cost O(1) per query too.  Results leave as ranks; the lookups
      * rank -> position are k_walk_final_big's (there they are independent and massively parallel). */
+    /* robust against a summary bit whose word is empty: such a word is skipped */
     auto up_slow = [&](uint32_t w) -> uint32_t {             /* first set rank in words > w, or NONE */
         if (w >= hi_w) return NONE;
         uint32_t sw = w >> 5, sm = ldw(&summ[sw]) & ~((2u << (w & 31)) - 1u);
-        while (!sm && ++sw <= (hi_w >> 5)) sm = ldw(&summ[sw]);
-        if (!sm) { hi_w = w; return NONE; }
-        const uint32_t w2 = (sw << 5) + (uint32_t)__builtin_ctz(sm);
-        return (w2 << 5) + (uint32_t)__builtin_ctz(ldw(&word[w2]));
+        for (;;) {
+            while (!sm && ++sw <= (hi_w >> 5)) sm = ldw(&summ[sw]);
+            if (!sm) { hi_w = w; return NONE; }
+            const uint32_t w2 = (sw << 5) + (uint32_t)__builtin_ctz(sm);
+            const uint32_t m = ldw(&word[w2]);
+            if (m) return (w2 << 5) + (uint32_t)__builtin_ctz(m);
+            sm &= sm - 1;
+        }
     };
     auto down_slow = [&](uint32_t w) -> uint32_t {           /* last set rank in words < w, or NONE */
         if (w <= lo_w) return NONE;
         int32_t sw = (int32_t)(w >> 5);
         uint32_t sm = ldw(&summ[sw]) & ((1u << (w & 31)) - 1u);
-        while (!sm && --sw >= (int32_t)(lo_w >> 5)) sm = ldw(&summ[sw]);
-        if (!sm) { lo_w = w; return NONE; }
-        const uint32_t w2 = ((uint32_t)sw << 5) + 31u - (uint32_t)__builtin_clz(sm);
-        return (w2 << 5) + 31u - (uint32_t)__builtin_clz(ldw(&word[w2]));
+        for (;;) {
+            while (!sm && --sw >= (int32_t)(lo_w >> 5)) sm = ldw(&summ[sw]);
+            if (!sm) { lo_w = w; return NONE; }
+            const uint32_t top = 31u - (uint32_t)__builtin_clz(sm);
+            const uint32_t w2 = ((uint32_t)sw << 5) + top;
+            const uint32_t m = ldw(&word[w2]);
+            if (m) return (w2 << 5) + 31u - (uint32_t)__builtin_clz(m);
+            sm &= ~(1u << top);
+        }
     };
     /* successor / predecessor of bit b0 of word w0, given that word and its two neighbours */
     auto succ_of = [&](uint32_t w0, uint32_t b0, uint32_t here, uint32_t next) -> uint32_t {
@@ -1113,42 +1123,101 @@ __global__ __launch_bounds__(64) void k_walk_big(const uint32_t *__restrict__ ra
         const uint32_t here = ldw(&word[w0]), next = ldw(&word[min(w0 + 1, NW - 1)]), prev = ldw(&word[w0 ? w0 - 1 : 0]);
         return make_uint2(succ_of(w0, b0, here, next), pred_of(w0, b0, here, prev));
     };
-    /* First window minus its last position, [ta, ta+sb-1).  The wave builds the 64 bitmaps one after the
-     * other straight from the sorted order: 64 lanes read the positions of 64 consecutive ranks (one
-     * coalesced load), test them against the walker's window, and the ballot IS the next two bitmap
-     * words -- plain stores, no atomics, no pre-zeroed memory, and the summary falls out of the same
-     * loop.  (One L2 atomic pair per window position made this fill the most expensive part of a
-     * 65535-position window.)  The first walker of the input starts empty: it answers y < sb as it fills. */
+    /* First window minus its last position, [ta, ta+sb-1).  The wave builds its 64 bitmaps one after the
+     * other.  The first walker of a region in the wave gets its bitmap straight from the sorted order:
+     * 64 lanes read the positions of 64 consecutive ranks (one coalesced load), test them against the
+     * window, and the ballot IS the next two bitmap words -- plain stores, no atomics, no pre-zeroed
+     * memory, and the summary falls out of the same loop.  Every further walker of that region starts
+     * run_len positions later, i.e. from the SAME window minus run_len positions plus run_len others:
+     * it copies its predecessor's bitmap and applies the difference (33 KB copied and 2*run_len bit
+     * updates instead of a pass over the region's 262144 ranks).  The first walker of the input starts
+     * empty: it answers y < sb as it fills, and its successor is built from the order. */
     {
         const uint32_t a = ta, len = first ? 0u : min(ta + usb - 1, R) - ta;
         uint64_t todo = (dbg & 1) ? 0ull : __ballot(alive);
         while (todo) {
-            /* the walkers of one region share its sorted order: load it once per 1024 ranks, test it
-             * against each of their windows */
             const int src = __builtin_ctzll(todo);
             const uint32_t sreg = __shfl(reg, src, 64);
             const uint64_t group = __ballot(alive && reg == sreg);
             todo &= ~group;
-            const g_u32 *six = (const g_u32 *)ranks + (size_t)sreg * (2 * (size_t)RP + 8) + RP + 8;
-            /* 16 rounds (1024 ranks = one summary word) per iteration, all 16 loads issued before the
-             * first ballot: the fill is bound by load latency, not by instruction count.  RP >= 32768 here. */
-            for (uint32_t r0 = 0; r0 < RP; r0 += 1024) {
-                uint32_t pos[16];
+            const g_u32 *srk = (const g_u32 *)ranks + (size_t)sreg * (2 * (size_t)RP + 8);
+            const g_u32 *six = srk + RP + 8;
+            int prev = -1;
+            for (uint64_t mem = group; mem; mem &= mem - 1) {
+                const int m = __builtin_ctzll(mem);
+                const uint32_t wa = __shfl(a, m, 64), wlen = __shfl(len, m, 64);
+                g_u32 *sword = (g_u32 *)bitmaps + ((size_t)blockIdx.x * 64u + (uint32_t)m) * (NW + NS);
+                const bool m_first = __shfl((int)first, m, 64) != 0;
+                if (prev < 0) {
+                    /* from the order: 16 rounds (1024 ranks = one summary word) per iteration, all 16 loads
+                     * issued before the first ballot.  RP >= 32768 here. */
+                    for (uint32_t r0 = 0; r0 < RP; r0 += 1024) {
+                        uint32_t pos[16];
 #pragma unroll
-                for (int u = 0; u < 16; u++) pos[u] = six[r0 + 64 * u + lane];   /* slots >= R hold indices >= R: never inside */
-                for (uint64_t mem = group; mem; mem &= mem - 1) {
-                    const int m = __builtin_ctzll(mem);
-                    const uint32_t wa = __shfl(a, m, 64), wlen = __shfl(len, m, 64);
-                    g_u32 *sword = (g_u32 *)bitmaps + ((size_t)blockIdx.x * 64u + (uint32_t)m) * (NW + NS);
-                    uint32_t sacc = 0;
+                        for (int u = 0; u < 16; u++) pos[u] = six[r0 + 64 * u + lane];   /* slots >= R hold indices >= R: never inside */
+                        uint32_t sacc = 0;
 #pragma unroll
-                    for (int u = 0; u < 16; u++) {
-                        const uint64_t mask = __ballot(pos[u] - wa < wlen);
-                        if (lane == 0) *(g_u64 *)(sword + (r0 >> 5) + 2 * u) = mask;     /* two words, little endian */
-                        sacc |= (((uint32_t)mask != 0u ? 1u : 0u) | ((uint32_t)(mask >> 32) != 0u ? 2u : 0u)) << (2 * u);
+                        for (int u = 0; u < 16; u++) {
+                            const uint64_t mask = __ballot(pos[u] - wa < wlen);
+                            if (lane == 0) *(g_u64 *)(sword + (r0 >> 5) + 2 * u) = mask;     /* two words, little endian */
+                            sacc |= (((uint32_t)mask != 0u ? 1u : 0u) | ((uint32_t)(mask >> 32) != 0u ? 2u : 0u)) << (2 * u);
+                        }
+                        if (lane == 0) sword[NW + (r0 >> 10)] = sacc;
                     }
-                    if (lane == 0) sword[NW + (r0 >> 10)] = sacc;
+                } else {
+                    const uint32_t pa = __shfl(a, prev, 64), plen = __shfl(len, prev, 64);
+                    const g_u32 *pword = (const g_u32 *)bitmaps + ((size_t)blockIdx.x * 64u + (uint32_t)prev) * (NW + NS);
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+                    /* eight loads in flight per lane: this copy and the two loops below are round trips */
+                    for (uint32_t w = lane; w < NW + NS; w += 64 * 8) {
+                        uint32_t t[8];
+#pragma unroll
+                        for (int u = 0; u < 8; u++) t[u] = w + 64 * u < NW + NS ? ldw(&pword[w + 64 * u]) : 0u;
+#pragma unroll
+                        for (int u = 0; u < 8; u++) if (w + 64 * u < NW + NS) stw(&sword[w + 64 * u], t[u]);
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+                    /* leave: [pa, min(wa, pa+plen))   enter: [max(pa+plen, wa), wa+wlen).  The clears do not
+                     * wait for their result */
+                    const uint32_t le = min(wa, pa + plen);
+                    for (uint32_t i = pa + lane; i < le; i += 64 * 4) {
+                        uint32_t r[4];
+#pragma unroll
+                        for (int u = 0; u < 4; u++) r[u] = i + 64 * u < le ? srk[i + 64 * u] : 0xFFFFFFFFu;
+#pragma unroll
+                        for (int u = 0; u < 4; u++)
+                            if (r[u] != 0xFFFFFFFFu)
+                                __hip_atomic_fetch_and(&sword[r[u] >> 5], ~(1u << (r[u] & 31)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+                    /* second pass over the leavers: words they emptied lose their summary bit (runs of equal
+                     * bytes empty whole words at a time, and a query would step through every stale bit) */
+                    for (uint32_t i = pa + lane; i < le; i += 64 * 4) {
+                        uint32_t r[4], wv[4];
+#pragma unroll
+                        for (int u = 0; u < 4; u++) r[u] = i + 64 * u < le ? srk[i + 64 * u] : 0xFFFFFFFFu;
+#pragma unroll
+                        for (int u = 0; u < 4; u++) wv[u] = r[u] != 0xFFFFFFFFu ? ldw(&sword[r[u] >> 5]) : 1u;
+#pragma unroll
+                        for (int u = 0; u < 4; u++)
+                            if (!wv[u])
+                                __hip_atomic_fetch_and(&sword[NW + (r[u] >> 10)], ~(1u << ((r[u] >> 5) & 31)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+                    const uint32_t eb = max(pa + plen, wa), ee = wa + wlen;
+                    for (uint32_t i = eb + lane; i < ee; i += 64 * 4) {
+                        uint32_t r[4];
+#pragma unroll
+                        for (int u = 0; u < 4; u++) r[u] = i + 64 * u < ee ? srk[i + 64 * u] : 0xFFFFFFFFu;
+#pragma unroll
+                        for (int u = 0; u < 4; u++)
+                            if (r[u] != 0xFFFFFFFFu) {
+                                __hip_atomic_fetch_or(&sword[r[u] >> 5], 1u << (r[u] & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                                __hip_atomic_fetch_or(&sword[NW + (r[u] >> 10)], 1u << ((r[u] >> 5) & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                            }
+                    }
                 }
+                prev = m_first ? -1 : m;
             }
         }
     }
@@ -1229,7 +1298,7 @@ __global__ __launch_bounds__(256) void k_walk_final_big(const uint8_t *__restric
     if (region0 + reg == 0 && lx < (uint32_t)sb) maxlen[x64] = (uint8_t)longest(wb0[lx], lx);
 }
 
-#define WALK_RUN_BIG_DEFAULT 2048u
+#define WALK_RUN_BIG_DEFAULT 1024u
 
 #define WALK_RUN_DEFAULT 1024u
 
