@@ -173,3 +173,34 @@ def test_numa_binding_helper_is_best_effort():
     assert _parse_cpulist("0-3,8,10-11\n") == {0, 1, 2, 3, 8, 10, 11}
     assert _parse_cpulist("") == set()
     assert bind_to_device_numa("ffff:ff:1f.0") == 0          # no such device: nothing changes, no exception
+
+
+def test_header_is_plain_c_and_links(tmp_path):
+    """include/lz77_mi355x.h compiles as C11 with -Wall -Werror -pedantic and a caller links against the library"""
+    src = tmp_path / "caller.c"
+    src.write_text(r'''
+#include "lz77_mi355x.h"
+#include <stdio.h>
+int main(void)
+{
+    uint8_t *z = NULL; size_t zn = 0;
+    lz77x_stats st;
+    (void)st;
+    if (lz77x_encode_bound(100, 4095, 15) != 4 + 300) return 2;
+    int rc = lz77x_encode((const uint8_t *)"", 0, LZ77X_DEFAULT_SB, LZ77X_DEFAULT_LA, &z, &zn);
+    printf("%s %s %d\n", lz77x_version(), lz77x_strerror(rc), lz77x_device_count());
+    lz77x_free(z);
+    lz77x_shutdown();
+    return 0;
+}
+''')
+    exe = tmp_path / "caller"
+    libdir = os.path.dirname(L.LIB_PATH)
+    r = subprocess.run(["gcc", "-std=c11", "-Wall", "-Wextra", "-Werror", "-pedantic", "-I", os.path.join(ROOT, "include"), str(src),
+                        "-L", libdir, "-llz77_mi355x", "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib", "-o", str(exe)],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    r = subprocess.run([str(exe)], capture_output=True, text=True)
+    # without a GPU the encode call reports LZ77X_E_NODEV (-4) and the program still exits normally
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "lz77-mi355x" in r.stdout
