@@ -14,6 +14,7 @@ rm -rf $out && mkdir -p $out
 python bench.py > $out/${tag}_bench.json 2> $out/bench.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -o t -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline > $out/trace.log 2>&1
 cp $out/trace/t_kernel_stats.csv $out/${tag}_bench_kernel_stats.csv
+grep -o '{"metric.*' $out/trace.log > $out/${tag}_bench_under_rocprof.json      # bench.py's own hipEvent timing in the profiled run
 for pass in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_WAIT_ANY" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR"; do
   name=$(echo $pass | cut -d' ' -f1)
   rocprofv3 --kernel-trace --pmc $pass --output-format csv -d $out/pmc_$name -o p -- python bench.py --steps 1 --warmup 0 --no-cpu-baseline > $out/pmc_$name.log 2>&1
