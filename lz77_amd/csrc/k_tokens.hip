@@ -132,7 +132,7 @@ __global__ __launch_bounds__(256) void k_tokens(const uint8_t *__restrict__ in, 
 #define TOK_TILE 2048u
 #endif
 #ifndef TOK_BLOCK
-#define TOK_BLOCK 512
+#define TOK_BLOCK 1024
 #endif
 
 __global__ void k_tok_bounds(const uint32_t *__restrict__ chain, uint32_t ntok, uint32_t pos0, uint32_t ntiles,
