@@ -62,6 +62,40 @@ def cpu_baseline(data, sb, la, budget_bytes):
             "host": _cpu_model()}
 
 
+def concurrent_streams(L, synth, torch, a, n, k):
+    """Aggregate encode+decode rate of k independent streams sharing the GPU (threads of this process,
+    each leasing its own context from the library).  One stream keeps the GPU busy for a third of its
+    wall time -- the rest is the sequential host recurrence -- so this is what a multi-file job sees."""
+    import threading
+    os.environ.setdefault("LZ77X_MAX_CONTEXTS", str(k))
+    cap = L.encode_bound(n, a.la, a.sb)
+    ins = [torch.from_numpy(synth.make(a.kind, n, synth.SEED_S1 + 100 + i)).cuda() for i in range(k)]
+    zs = [torch.empty(cap, dtype=torch.uint8, device="cuda") for _ in range(k)]
+    backs = [torch.empty(n, dtype=torch.uint8, device="cuda") for _ in range(k)]
+
+    def work(i, reps):
+        st = torch.cuda.Stream()
+        for _ in range(reps):
+            zn = L.encode_device(ins[i].data_ptr(), n, zs[i].data_ptr(), cap, a.la, a.sb, st.cuda_stream)
+            L.decode_device(zs[i].data_ptr(), zn, backs[i].data_ptr(), n, st.cuda_stream)
+
+    dt = 0.0
+    reps = 3
+    for r in (1, reps):                                           # the first round creates the k contexts
+        ts = [threading.Thread(target=work, args=(i, r)) for i in range(k)]
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for t in ts:
+            t.start()
+        for t in ts:
+            t.join()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+    ok = all(bool(torch.equal(backs[i], ins[i])) for i in range(k))
+    return {"streams": k, "value": round(k * reps * n / dt / 1e6, 3), "unit": "MB/s", "ms_per_step_per_stream": round(dt / reps * 1e3, 3),
+            "roundtrip_ok": ok, "note": "not the benchmark value: k independent %d-byte streams on one GPU" % n}
+
+
 def _cpu_model():
     try:
         for line in open("/proc/cpuinfo"):
@@ -83,6 +117,7 @@ def main():
     ap.add_argument("--kind", default="text")
     ap.add_argument("--cpu-sample", type=int, default=64_000_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--streams", type=int, default=4, help="also report k concurrent streams on one GPU (informational; 1 = skip)")
     a = ap.parse_args()
 
     import torch
@@ -220,6 +255,12 @@ def main():
                                      "host_stageb_ms", "copy_ms")},
             "decode_breakdown_ms": {k: round(mean(dec_stats, k), 2) for k in ("total_ms", "k_decode_ms")},
         }
+        if world == 1 and a.streams > 1:
+            # informational, never `value`: k independent streams on the one GPU, one thread each
+            try:
+                out["concurrent_streams"] = concurrent_streams(L, synth, torch, a, n, a.streams)
+            except Exception as e:                                # pragma: no cover - must never break the line
+                out["concurrent_streams"] = {"error": str(e)[:200]}
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(data, a.sb, a.la, min(a.cpu_sample, n))
         print(json.dumps(out), flush=True)
