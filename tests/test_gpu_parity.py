@@ -4,6 +4,7 @@ Bit-exact everywhere (integer/byte work).  Run on the GPU box:  pytest -m gpu
 """
 import hashlib
 import os
+import ctypes
 import subprocess
 
 import numpy as np
@@ -289,6 +290,29 @@ def test_arg_errors():
         with pytest.raises(L.Lz77Error) as e:
             L.encode(b"hello", la, sb)
         assert e.value.code == -1
+
+
+def test_device_api_error_paths():
+    """LZ77X_E_CAP reports the needed size, LZ77X_E_FORMAT for short / zero-geometry headers, the size
+    query of decode_device needs no output buffer"""
+    import torch
+    data = synth.text(500_000, 9)
+    d_in = torch.from_numpy(data).cuda()
+    z = L.encode(data)
+    small = torch.empty(100, dtype=torch.uint8, device="cuda")
+    zn = ctypes.c_size_t(0)
+    rc = L.lib().lz77x_encode_device(d_in.data_ptr(), data.size, -1, -1, small.data_ptr(), 100, ctypes.byref(zn), None)
+    assert rc == -6 and zn.value == len(z)                     # LZ77X_E_CAP, *out_n = bytes needed
+    d_z = torch.from_numpy(np.frombuffer(z, dtype=np.uint8).copy()).cuda()
+    assert L.decoded_size_device(d_z.data_ptr(), len(z)) == data.size
+    n = ctypes.c_size_t(0)
+    rc = L.lib().lz77x_decode_device(d_z.data_ptr(), len(z), small.data_ptr(), 100, ctypes.byref(n), None)
+    assert rc == -6 and n.value == data.size
+    for bad in (b"", b"\xff\x0f", b"\x00\x00\x0f\x00", b"\xff\x0f\x00\x00"):
+        with pytest.raises(L.Lz77Error) as e:
+            L.decode(bad)
+        assert e.value.code == -5, bad                         # LZ77X_E_FORMAT
+    assert L.decode(bytes([0xFF, 0x0F, 0x0F, 0x00])) == b""     # header only: the empty file
 
 
 def test_cli_roundtrip(tmp_path, golden_dir):
