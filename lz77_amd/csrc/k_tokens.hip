@@ -238,6 +238,9 @@ __global__ __launch_bounds__(TOK_BLOCK) void k_tokens_tile(const uint8_t *__rest
     const uint32_t k0 = tstart[blockIdx.x], k1 = tstart[blockIdx.x + 1];
     /* each wave takes tokens k0+wave, k0+wave+8, ...; their (position, length) are fetched 64 at a
      * time, one per lane, so that the per-token loop never waits on global memory */
+#ifdef TOK_SETUP_ONLY                                         /* timing ablation: staging + index build, no tokens */
+    if (k1 != 0xFFFFFFFFu) return;
+#endif
     for (uint32_t kb = k0 + wave; kb < k1; kb += 64 * (TOK_BLOCK / 64)) {
         const uint32_t kmine = kb + lane * (TOK_BLOCK / 64);
         uint32_t p_l = 0, len_l = 0;
