@@ -356,7 +356,7 @@ int encode_core(std::vector<Ctx *> &cs, const void *src, bool src_on_device, siz
          * from the devices, K2 slots carry {xval, chain} back.  A slot is recycled once the chunk
          * AFTER it has been consumed (both recurrences look sb positions back into the previous chunk;
          * chunk_pos >= 2*sb by construction of TILE). */
-        uint32_t K = 32, K2 = 4;
+        uint32_t K = 16, K2 = 4;               /* 12..32 slots measure the same: the host paces the pipeline */
         const char *rs = getenv("LZ77X_RING_SLOTS");
         if (rs && atoi(rs) > 0) K = (uint32_t)atoi(rs);
         if (K < group + 2) K = group + 2;                      /* the group being filled + the two chunks in use */
