@@ -96,6 +96,39 @@ def concurrent_streams(L, synth, torch, a, n, k):
             "roundtrip_ok": ok, "note": "not the benchmark value: k independent %d-byte streams on one GPU" % n}
 
 
+def golden_full(kind, n, seed, sb, la):
+    """Reference digest of the full-size stream (tests/golden/golden_full.json, made by the compiled reference)."""
+    try:
+        recs = json.load(open(os.path.join(ROOT, "tests", "golden", "golden_full.json")))["full"]
+    except (OSError, ValueError, KeyError):
+        return None
+    for r in recs:
+        if (r["kind"], r["n"], r["seed"], r["sb"], r["la"]) == (kind, n, seed, sb, la):
+            return r
+    return None
+
+
+def stream_sha(torch, d_z, zn):
+    import hashlib
+    return hashlib.sha256(d_z[:zn].cpu().numpy().tobytes()).hexdigest()
+
+
+def load_input(a, synth, rank):
+    """The step's input: the synthetic S1 stream, or -- when LZ77_CORPUS_DIR holds a file named like the
+    workload (enwik8 by default, LZ77_CORPUS_FILE overrides) -- that file.  -> (array, label, seed)"""
+    import numpy as np
+    cdir = os.environ.get("LZ77_CORPUS_DIR")
+    if cdir:
+        path = os.path.join(cdir, os.environ.get("LZ77_CORPUS_FILE", "enwik8"))
+        if os.path.isfile(path):
+            data = np.fromfile(path, dtype=np.uint8)
+            if a.bytes and a.bytes < data.size and "--bytes" in sys.argv:
+                data = data[:a.bytes]
+            return data, "corpus file %s (%d bytes)" % (path, data.size), None
+    seed = synth.SEED_S1 + rank
+    return synth.make(a.kind, a.bytes, seed), None, seed
+
+
 def _cpu_model():
     try:
         for line in open("/proc/cpuinfo"):
@@ -151,8 +184,8 @@ def main():
     import lz77_amd as L
     from lz77_amd import synth
 
-    n = a.bytes
-    data = synth.make(a.kind, n, synth.SEED_S1 + rank)
+    data, corpus_label, seed = load_input(a, synth, rank)
+    n = int(data.size)
     d_in = torch.from_numpy(data).cuda()
     cap = L.encode_bound(n, a.la, a.sb)
     d_z = torch.empty(cap, dtype=torch.uint8, device="cuda")
@@ -186,14 +219,21 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     ok = bool(torch.equal(d_back, d_in))                 # round trip checked outside the timed region
+    # bit-exactness at the headline size: sha256 of the device stream against the reference's (a round
+    # trip cannot see a wrong tie-break offset)
+    gold = golden_full(a.kind, n, seed, a.sb, a.la) if seed is not None else None
+    sha_ok = None
+    if gold is not None:
+        sha_ok = zn == gold["zn"] and stream_sha(torch, d_z, zn) == gold["sha256_lz"]
     if world > 1:
         red_dev = "cuda" if backend == "nccl" else "cpu"
         t = torch.tensor([dt], dtype=torch.float64, device=red_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-        okt = torch.tensor([1 if ok else 0], device=red_dev)
+        okt = torch.tensor([1 if ok else 0, 2 if sha_ok is None else (1 if sha_ok else 0)], device=red_dev)
         dist.all_reduce(okt, op=dist.ReduceOp.MIN)
-        ok = bool(okt.item())
+        ok = bool(okt[0].item())
+        sha_ok = None if int(okt[1].item()) == 2 else bool(okt[1].item())
 
     if rank == 0:
         K = max(a.steps, 1)
@@ -203,10 +243,12 @@ def main():
         k_match_ms = mean(enc_stats, "k_match_ms")               # sort + window walkers + finalize
         alg_bytes = n + zn                                        # encode reads n, writes zn
         # the three big kernels of an encode, each timed by its own hipEvent pair on the stream it runs on
+        iters = max(int(round(mean(enc_stats, "prio_iters"))), 1)
         cands = {
             "k_tokens_tile<true> (offset tie-break among equal-length matches)": (mean(enc_stats, "k_tiebreak_ms"), tlaunches, "k_tokens_tile"),
             "k_walk (bitmap window walkers: in-order neighbours of every position)": (mean(enc_stats, "k_walk_ms"), launches, "k_walk"),
             "k_match<true,3> (region key sort + rank export)": (mean(enc_stats, "k_sort_ms"), launches, "k_match"),
+            "k_prio_fwd (priority recurrence: forward sweep of one gate iteration)": (mean(enc_stats, "k_prio_fwd_ms"), iters, "k_prio_fwd"),
         }
         dom_name = max(cands, key=lambda k: cands[k][0])
         dom_ms, dom_launches, dom_key = cands[dom_name]
@@ -221,7 +263,7 @@ def main():
             except Exception:
                 traffic = None
         out = {
-            "metric": "encode+decode MB/s on enwik8-like synthetic text, s=%d l=%d" % (a.sb, a.la),
+            "metric": "encode+decode MB/s on %s, s=%d l=%d" % ("enwik8-like synthetic text" if corpus_label is None else "a supplied corpus file", a.sb, a.la),
             "value": round(world * n * K / dt / 1e6, 3),
             "unit": "MB/s",
             "n_gpus": world,
@@ -232,27 +274,37 @@ def main():
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": "u8",
-            "data": "synthetic",
-            "config": {"workload": "S1 enwik8-like text (lz77_amd.synth.text, seed 0x5EED0001+rank), %d bytes per GPU, "
-                                   "s=%d l=%d; step = encode then decode, buffers resident in HBM" % (n, a.sb, a.la),
+            "data": "synthetic" if corpus_label is None else "file",
+            "config": {"workload": ("S1 enwik8-like text (lz77_amd.synth.text, seed 0x5EED0001+rank)" if corpus_label is None else corpus_label) +
+                                   ", %d bytes per GPU, s=%d l=%d; step = encode then decode, buffers resident in HBM" % (n, a.sb, a.la),
                        "bytes_per_gpu": n, "sb": a.sb, "la": a.la, "parallelism": "independent stream per GPU",
                        "numa_bound_cpus": numa_cpus},
             "roofline": {"bound": "hbm", "kernel": dom_name + " -- the largest GPU kernel of the step",
                          "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic,
+                         "traffic_source": "profiles/traffic.json (PMC passes of the committed rocprofv3 run, per launch; not measured in this run)",
                          "launches_per_step": dom_launches,
                          "algorithmic_bytes_per_launch": alg_bytes // dom_launches,
                          "kernel_ms_per_launch": round(dom_ms / dom_launches, 3),
                          "kernels_ms_per_step": {v[2]: round(v[0], 3) for v in cands.values()},
                          "match_stage_ms": round(k_match_ms, 3),
                          "match_stage_GBps": round(alg_bytes / (k_match_ms * 1e-3) / 1e9, 3) if k_match_ms > 0 else 0.0},
+            "roofline_decode": {"bound": "hbm", "kernel": "all decode kernels (parse, scan, expand, pointer jumping, gather)",
+                                "achieved": round(alg_bytes / (mean(dec_stats, "k_decode_ms") * 1e-3) / 1e9, 3) if mean(dec_stats, "k_decode_ms") > 0 else 0.0,
+                                "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                "frac": round(alg_bytes / (mean(dec_stats, "k_decode_ms") * 1e-3) / 1e9 / HBM_PEAK_GBS, 6) if mean(dec_stats, "k_decode_ms") > 0 else 0.0,
+                                "algorithmic_bytes": alg_bytes, "kernels_ms": round(mean(dec_stats, "k_decode_ms"), 3)},
             "roundtrip_ok": ok,
+            "stream_sha_ok": sha_ok,
+            "stream_sha_source": "tests/golden/golden_full.json (sha256 of the compiled reference's stream for this input)" if gold else None,
             "ratio": round(zn / n, 4),
             "encode_MBps": round(n / (mean(enc_stats, "total_ms") * 1e-3) / 1e6, 2),
             "decode_MBps": round(n / (mean(dec_stats, "total_ms") * 1e-3) / 1e6, 2),
             "encode_breakdown_ms": {k: round(mean(enc_stats, k), 2) for k in
-                                    ("total_ms", "k_match_ms", "k_sort_ms", "k_walk_ms", "k_token_ms", "k_tiebreak_ms", "host_chain_ms",
+                                    ("total_ms", "k_match_ms", "k_sort_ms", "k_walk_ms", "k_token_ms", "k_tiebreak_ms", "k_prio_ms",
+                                     "k_prio_fwd_ms", "k_prio_back_ms", "k_prio_scan_ms", "k_chain_ms", "host_chain_ms",
                                      "host_stageb_ms", "copy_ms")},
+            "prio_iters": iters,
             "decode_breakdown_ms": {k: round(mean(dec_stats, k), 2) for k in ("total_ms", "k_decode_ms")},
         }
         if world == 1 and a.streams > 1:

@@ -111,7 +111,12 @@ typedef struct lz77x_stats {
     double k_walk_ms;         /* of k_match_ms: the window-walker kernel alone (0 if that path was not taken) */
     double k_tiebreak_ms;     /* of k_token_ms: the tie-break kernel alone (k_tokens_tile / k_tokens_big) */
     uint32_t token_launches;  /* launches of the tie-break kernel in the call */
-    uint32_t reserved;
+    uint32_t prio_iters;      /* gate iterations of the device priority recurrence (0: it ran on the host) */
+    double k_prio_ms;         /* device priority recurrence (replaces host_stageb_ms when it runs) */
+    double k_chain_ms;        /* device parse chain (replaces host_chain_ms when it runs) */
+    double k_prio_fwd_ms;     /* of k_prio_ms: the forward sweeps (k_prio_fwd), summed over the iterations */
+    double k_prio_back_ms;    /* of k_prio_ms: the backward sweeps (k_prio_back) */
+    double k_prio_scan_ms;    /* of k_prio_ms: the block-boundary scans (k_prio_scan_*) */
 } lz77x_stats;
 int lz77x_last_stats(lz77x_stats *st);
 
@@ -123,6 +128,12 @@ int lz77x_stage_maxlen(const uint8_t *in, size_t n, int sb, int la, uint8_t *max
 int lz77x_stage_neighbours(const uint8_t *in, size_t n, int sb, int la, uint16_t *P, uint16_t *S);
 /* host sequential stage (A.5 stage B) on caller-provided P/S: xval[x] or 0xFFFFFFFF */
 int lz77x_stage_priorities(const uint16_t *P, const uint16_t *S, size_t n, int sb, uint32_t *xval);
+/* the same recurrence on the device (k_prio: gate iteration over block sweeps), sb <= 4096; *iters
+ * receives the number of iterations it took (may be NULL) */
+int lz77x_stage_priorities_device(const uint16_t *P, const uint16_t *S, size_t n, int sb, uint32_t *xval, int *iters);
+/* the greedy parse chain (lz77.c:89-98) on the device from a caller-provided maxlen[]: chain[] must hold
+ * n entries; *ntok receives the number of tokens */
+int lz77x_stage_chain_device(const uint8_t *maxlen, size_t n, int la, uint32_t *chain, size_t *ntok);
 
 #ifdef __cplusplus
 }

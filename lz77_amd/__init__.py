@@ -43,7 +43,9 @@ class Stats(ctypes.Structure):
                 ("n", ctypes.c_uint64), ("zn", ctypes.c_uint64), ("ntok", ctypes.c_uint64),
                 ("transfers", ctypes.c_uint64), ("match_launches", ctypes.c_uint32),
                 ("decode_rounds", ctypes.c_uint32), ("k_walk_ms", ctypes.c_double), ("k_tiebreak_ms", ctypes.c_double),
-                ("token_launches", ctypes.c_uint32), ("reserved", ctypes.c_uint32)]
+                ("token_launches", ctypes.c_uint32), ("prio_iters", ctypes.c_uint32),
+                ("k_prio_ms", ctypes.c_double), ("k_chain_ms", ctypes.c_double), ("k_prio_fwd_ms", ctypes.c_double),
+                ("k_prio_back_ms", ctypes.c_double), ("k_prio_scan_ms", ctypes.c_double)]
 
     def as_dict(self) -> dict:
         return {k: getattr(self, k) for k, _ in self._fields_}
@@ -84,6 +86,8 @@ SYMBOLS = {
     "lz77x_stage_maxlen": (ctypes.c_int, [_vp, _sz, ctypes.c_int, ctypes.c_int, _vp]),
     "lz77x_stage_neighbours": (ctypes.c_int, [_vp, _sz, ctypes.c_int, ctypes.c_int, _vp, _vp]),
     "lz77x_stage_priorities": (ctypes.c_int, [_vp, _vp, _sz, ctypes.c_int, _vp]),
+    "lz77x_stage_priorities_device": (ctypes.c_int, [_vp, _vp, _sz, ctypes.c_int, _vp, ctypes.POINTER(ctypes.c_int)]),
+    "lz77x_stage_chain_device": (ctypes.c_int, [_vp, _sz, ctypes.c_int, _vp, ctypes.POINTER(_sz)]),
 }
 
 
@@ -200,3 +204,22 @@ def stage_priorities(P: np.ndarray, S: np.ndarray, sb: int) -> np.ndarray:
     xval = np.empty(max(P.size, 1), dtype=np.uint32)
     _check(lib().lz77x_stage_priorities(P.ctypes.data, S.ctypes.data, P.size, int(sb), xval.ctypes.data))
     return xval[:P.size]
+
+
+def stage_priorities_device(P: np.ndarray, S: np.ndarray, sb: int):
+    """-> (xval, iterations) from the device form of the recurrence (k_prio.hip)"""
+    P = np.ascontiguousarray(P, dtype=np.uint16)
+    S = np.ascontiguousarray(S, dtype=np.uint16)
+    xval = np.empty(max(P.size, 1), dtype=np.uint32)
+    it = ctypes.c_int(0)
+    _check(lib().lz77x_stage_priorities_device(P.ctypes.data, S.ctypes.data, P.size, int(sb), xval.ctypes.data, ctypes.byref(it)))
+    return xval[:P.size], it.value
+
+
+def stage_chain_device(maxlen: np.ndarray, la: int) -> np.ndarray:
+    """-> chain positions from the device parse chain (k_chain.hip)"""
+    m = np.ascontiguousarray(maxlen, dtype=np.uint8)
+    chain = np.empty(max(m.size, 1), dtype=np.uint32)
+    nt = _sz(0)
+    _check(lib().lz77x_stage_chain_device(m.ctypes.data, m.size, int(la), chain.ctypes.data, ctypes.byref(nt)))
+    return chain[:nt.value]

@@ -1,0 +1,536 @@
+/*
+ * k_prio.hip -- the priority recurrence of the offset tie-break, on the device.
+ *
+ * What it replaces: which node a tree.c:182-243 delete() promotes.  Evicting the oldest position x
+ * (lz77.c:101-103) with two children puts its in-order successor S in x's place (tree.c:202-231); in
+ * the treap restatement (SURVEY A.5 stage B) that is, for x = 0, 1, 2, ... in order,
+ *
+ *     if P[x], S[x] exist and pi[x] < pi[P[x]] and pi[x] < pi[S[x]]:  pi[S[x]] <- pi[x]       (1)
+ *
+ * with pi[c] = c when c is inserted.  Round 1 ran (1) on one host core (0.76 ns per position, 95 % of
+ * an encode).  Read as data flow it parallelises:
+ *
+ *   - a cell only ever DEcreases, and a write that fails its S-side test would not have lowered the
+ *     cell, so (1) is   pi[S[x]] <- min(pi[S[x]], pi[x])   guarded by the P-side test alone: the GATE
+ *     g[x] = "P, S exist and pi_x[x] < pi_x[P[x]]"  (pi_x = cells just before step x);
+ *   - with the gates FIXED the cell values are a min over a forest (x -> S[x] for open gates): for a
+ *     block of B consecutive steps that is a map  in -> out  on the sb cells that are live at the
+ *     block boundary,  out[d] = min(loc[d], min{ in[c] : dest[c] = d }),  which composes, so the
+ *     values at every block boundary are a scan over blocks;
+ *   - the gates follow from the values, and gate x only depends on gates of earlier steps: iterating
+ *     gates -> values -> gates from "every gate open" reaches the unique fixed point.  Measured: wrong
+ *     gates shrink ~5x per iteration on text and random bytes (13-15 iterations for any size),
+ *     record-structured data adds a thin tail; the gates before the first flip of an iteration are
+ *     final, so later iterations only run the blocks from there on.
+ *
+ * One iteration = k_prio_back (per block: where does each entry cell's chain leave the block, and
+ * what arrives at the exit cells from inside) -> k_prio_scan_* (values at every block boundary) ->
+ * k_prio_fwd (per block: the sequential sweep with exact incoming values: new gates, and xval[] --
+ * the priority handed over at each eviction, what k_tokens consumes).  One WAVEFRONT owns a block; its
+ * 64 lanes take 64 consecutive steps, split into "rounds" wherever a step reads a cell an earlier
+ * step of the same 64 writes (a static property of P/S: k_prio_prep computes the round masks once).
+ * The sb + 64 live cells of a sweep are a ring in LDS (16.6 KB at sb 4095: nine wavefronts per CU).
+ */
+#include "kernels_common.h"
+
+#define PRIO_NONE 0xFFFFFFFFu
+#define PRIO_DEAD 0xFFFFu
+#define PRIO_SG 8u                       /* groups of 64 steps fetched per round trip to global memory */
+#define PRIO_SCAN_BLOCK 1024
+
+__device__ __forceinline__ void wave_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
+__device__ __forceinline__ uint64_t readlane64(uint64_t v, int l)
+{
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, l);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), l);
+    return ((uint64_t)hi << 32) | lo;
+}
+
+/* ------------------------------------------------------------------ prep ------------- */
+
+/* Per group of 64 consecutive steps: the initial gates (every step that has both neighbours) and the
+ * round mask -- bit i set <=> lane i must start a new round because some lane j of the current round
+ * (j < i) writes a cell lane i reads: its own (S[j] = x_i), its predecessor's (gate test) or its
+ * successor's (the "did the hand-over happen" test).  tag[c] = lowest lane of the current round that
+ * writes cell c. */
+__global__ __launch_bounds__(256) void k_prio_prep(const uint32_t *__restrict__ ps, uint32_t nx, uint32_t tagn,
+                                                   uint64_t *__restrict__ rmask, uint64_t *__restrict__ gate0)
+{
+    extern __shared__ uint32_t prep_tags[];
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    uint32_t *tag = prep_tags + wave * tagn;
+    const uint32_t ngroups = (nx + 63u) / 64u;
+    for (uint32_t i = lane; i < tagn; i += 64) tag[i] = PRIO_NONE;
+    wave_sync();
+    for (uint32_t g = blockIdx.x * 4u + wave; g < ngroups; g += gridDim.x * 4u) {
+        const uint32_t x = g * 64u + lane;
+        const uint32_t v = x < nx ? ps[x] : 0u;
+        const uint32_t p = v & 0xFFFFu, s = v >> 16;
+        const bool has = p && s;
+        const uint32_t cp = lane + p, cs = lane + s;
+        uint64_t mask = 1;
+        uint32_t start = 0;
+        for (;;) {
+            if (has && lane >= start) atomicMin(&tag[cs], lane);
+            wave_sync();
+            bool blocked = false;
+            if (has && lane > start) blocked = tag[lane] < lane || tag[cp] < lane || tag[cs] < lane;
+            wave_sync();
+            if (has && lane >= start) tag[cs] = PRIO_NONE;
+            wave_sync();
+            const uint64_t bm = __ballot(blocked);
+            if (!bm) break;
+            start = (uint32_t)__builtin_ctzll(bm);
+            mask |= 1ull << start;
+        }
+        const uint64_t hm = __ballot(has);
+        if (lane == 0) { rmask[g] = mask; gate0[g] = hm; }
+    }
+}
+
+/* in[0] = identity: at the start of the input every cell holds its own position */
+__global__ void k_prio_in0(uint32_t *__restrict__ in0, uint32_t sb)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < sb) in0[i] = i;
+}
+
+/* ------------------------------------------------------------------ forward sweep ---- */
+
+/* Block b = steps [b*B, min((b+1)*B, nx)).  in[b][i] = value of cell b*B+i before the block's first
+ * step (cells beyond b*B+sb have not been written yet: they hold their own position). */
+__global__ __launch_bounds__(64) void k_prio_fwd(const uint32_t *__restrict__ ps, uint32_t nx, uint32_t sb, uint32_t B,
+                                                 uint32_t ring_n, uint32_t b_first, const uint64_t *__restrict__ rmask,
+                                                 const uint64_t *__restrict__ gold, uint64_t *__restrict__ gnew,
+                                                 const uint32_t *__restrict__ in, uint32_t *__restrict__ xval,
+                                                 uint32_t *__restrict__ summary /* [0] += flips, [1] = min block with a flip */)
+{
+    extern __shared__ uint32_t ring[];
+    const uint32_t lane = threadIdx.x;
+    const uint32_t b = b_first + blockIdx.x;
+    const uint32_t x0 = b * B;
+    const uint32_t x1 = nx - x0 < B ? nx : x0 + B;
+    for (uint32_t r = lane; r < ring_n; r += 64) ring[r] = r < sb ? in[(size_t)b * sb + r] : x0 + r;
+    wave_sync();
+
+    uint32_t off = 0;                                  /* ring slot of cell xg */
+    uint32_t nflip = 0;
+    uint32_t v[PRIO_SG], vn[PRIO_SG];
+    uint64_t rm_l = 0, go_l = 0, rm_n = 0, go_n = 0;
+    auto fetch = [&](uint32_t xs, uint32_t (&vv)[PRIO_SG], uint64_t &rml, uint64_t &gol) {
+#pragma unroll
+        for (uint32_t k = 0; k < PRIO_SG; k++) {
+            const uint32_t x = xs + 64u * k + lane;
+            vv[k] = (xs < x1 && x < x1) ? ps[x] : 0u;
+        }
+        const uint32_t xq = xs + 64u * lane;
+        rml = 0;
+        gol = 0;
+        if (lane < PRIO_SG && xs < x1 && xq < x1) { rml = rmask[xq >> 6]; gol = gold[xq >> 6]; }
+    };
+    fetch(x0, v, rm_l, go_l);
+    for (uint32_t xs = x0; xs < x1; xs += 64u * PRIO_SG) {
+        fetch(xs + 64u * PRIO_SG, vn, rm_n, go_n);     /* next super-group in flight while this one runs */
+        uint64_t gn_l = 0;
+#pragma unroll
+        for (uint32_t k = 0; k < PRIO_SG; k++) {
+            const uint32_t xg = xs + 64u * k;
+            if (xg < x1) {
+                const uint64_t rm = readlane64(rm_l, (int)k), go = readlane64(go_l, (int)k);
+                const uint32_t p = v[k] & 0xFFFFu, s = v[k] >> 16;
+                const bool has = p && s;
+                const uint32_t x = xg + lane;
+                uint32_t ix = off + lane;
+                ix -= ix >= ring_n ? ring_n : 0u;
+                uint32_t ip = ix + p;
+                ip -= ip >= ring_n ? ring_n : 0u;
+                uint32_t is = ix + s;
+                is -= is >= ring_n ? ring_n : 0u;
+                const bool gate_o = (go >> lane) & 1ull;
+                bool ng = false;
+                uint32_t out = PRIO_NONE;
+                uint64_t r = rm;
+                do {
+                    const uint32_t start = (uint32_t)__builtin_ctzll(r);
+                    r &= r - 1;
+                    const uint32_t end = r ? (uint32_t)__builtin_ctzll(r) : 64u;
+                    if (has && lane >= start && lane < end) {
+                        const uint32_t a = ring[ix], w = ring[ip], sv = ring[is];
+                        ng = a < w;                                   /* the gate: x's predecessor hangs below x */
+                        if (gate_o && a < sv) { ring[is] = a; out = a; }   /* tree.c:202-231: S takes x's place */
+                    }
+                    wave_sync();
+                } while (r);
+                const uint64_t gnb = __ballot(ng);
+                nflip += (uint32_t)__popcll(gnb ^ go);
+                if (lane == k) gn_l = gnb;
+                if (x < x1) xval[x] = out;
+                /* cell xg+64+sb+lane becomes live with the next group; its slot held cell xg+lane */
+                uint32_t fi = off + lane;                             /* (off + 64 + sb_r + lane) mod ring_n, ring_n = sb_r + 64 */
+                fi -= fi >= ring_n ? ring_n : 0u;
+                ring[fi] = xg + ring_n + lane;
+                off += 64u;
+                off -= off >= ring_n ? ring_n : 0u;
+                wave_sync();
+            }
+        }
+        {
+            const uint32_t xq = xs + 64u * lane;
+            if (lane < PRIO_SG && xq < x1) gnew[xq >> 6] = gn_l;
+        }
+#pragma unroll
+        for (uint32_t k = 0; k < PRIO_SG; k++) v[k] = vn[k];
+        rm_l = rm_n;
+        go_l = go_n;
+    }
+    if (lane == 0 && nflip) {
+        atomicAdd(&summary[0], nflip);
+        atomicMin(&summary[1], b);
+    }
+}
+
+/* ------------------------------------------------------------------ backward sweep --- */
+
+/* dest[b][i]: the exit cell (relative to the block's end x1) that the chain of open gates starting at
+ * entry cell b*B+i reaches, or DEAD when it ends inside the block; loc[b][d]: the lowest position of
+ * the block whose chain reaches exit cell d (what arrives there when nothing older comes in). */
+__global__ __launch_bounds__(64) void k_prio_back(const uint32_t *__restrict__ ps, uint32_t nx, uint32_t sb, uint32_t B,
+                                                  uint32_t ring_n, uint32_t b_first, const uint64_t *__restrict__ gates,
+                                                  uint16_t *__restrict__ dest, uint32_t *__restrict__ loc)
+{
+    extern __shared__ uint32_t back_lds[];
+    uint32_t *lloc = back_lds;                                         /* sb_r words */
+    uint16_t *dr = reinterpret_cast<uint16_t *>(back_lds + (ring_n - 64u));   /* ring_n entries */
+    const uint32_t lane = threadIdx.x;
+    const uint32_t b = b_first + blockIdx.x;
+    const uint32_t x0 = b * B;
+    const uint32_t x1 = nx - x0 < B ? nx : x0 + B;
+    for (uint32_t i = lane; i < sb; i += 64) lloc[i] = x1 + i;
+    for (uint32_t i = lane; i < ring_n; i += 64) dr[i] = PRIO_DEAD;
+    wave_sync();
+    const uint32_t nsg = (x1 - x0 + 64u * PRIO_SG - 1u) / (64u * PRIO_SG);
+    uint32_t v[PRIO_SG], vn[PRIO_SG];
+    uint64_t g_l = 0, g_n = 0;
+    auto fetch = [&](int32_t sgi, uint32_t (&vv)[PRIO_SG], uint64_t &gl) {
+        const uint32_t xs = x0 + 64u * PRIO_SG * (uint32_t)(sgi < 0 ? 0 : sgi);
+#pragma unroll
+        for (uint32_t k = 0; k < PRIO_SG; k++) {
+            const uint32_t x = xs + 64u * k + lane;
+            vv[k] = (sgi >= 0 && x < x1) ? ps[x] : 0u;
+        }
+        const uint32_t xq = xs + 64u * lane;
+        gl = (sgi >= 0 && lane < PRIO_SG && xq < x1) ? gates[xq >> 6] : 0ull;
+    };
+    fetch((int32_t)nsg - 1, v, g_l);
+    for (int32_t sgi = (int32_t)nsg - 1; sgi >= 0; sgi--) {
+        fetch(sgi - 1, vn, g_n);
+        const uint32_t xs = x0 + 64u * PRIO_SG * (uint32_t)sgi;
+#pragma unroll
+        for (int k = (int)PRIO_SG - 1; k >= 0; k--) {
+            const uint32_t xg = xs + 64u * (uint32_t)k;
+            if (xg < x1) {
+                const uint64_t gm = readlane64(g_l, k);
+                const uint32_t s = v[k] >> 16;
+                const uint32_t x = xg + lane;
+                const bool valid = x < x1;
+                const bool gate = valid && ((gm >> lane) & 1ull);
+                const uint32_t off = (xg - x0) % ring_n;              /* ring slot of cell xg */
+                uint32_t d = PRIO_DEAD;
+                int ptr = -1;
+                if (gate) {
+                    const uint32_t t = x + s;
+                    if (t >= x1) d = t - x1;                          /* < sb */
+                    else if (t < xg + 64u) ptr = (int)(t - xg);       /* a later lane of this group */
+                    else {
+                        uint32_t it = off + lane + s;
+                        it -= it >= ring_n ? ring_n : 0u;
+                        d = dr[it];
+                    }
+                }
+                while (__ballot(ptr >= 0)) {                          /* chains inside the group: pointer jumping */
+                    const int src = ptr >= 0 ? ptr : (int)lane;
+                    const uint32_t dn = (uint32_t)__shfl((int)d, src, 64);
+                    const int pn = __shfl(ptr, src, 64);
+                    if (ptr >= 0) {
+                        if (pn < 0) { d = dn; ptr = -1; }
+                        else ptr = pn;
+                    }
+                }
+                if (valid) {
+                    uint32_t ix = off + lane;
+                    ix -= ix >= ring_n ? ring_n : 0u;
+                    dr[ix] = (uint16_t)d;
+                    if (d != PRIO_DEAD) atomicMin(&lloc[d], x);
+                }
+                wave_sync();
+            }
+        }
+#pragma unroll
+        for (uint32_t k = 0; k < PRIO_SG; k++) v[k] = vn[k];
+        g_l = g_n;
+    }
+    for (uint32_t i = lane; i < sb; i += 64) {
+        dest[(size_t)b * sb + i] = x0 + i < x1 ? dr[i] : (uint16_t)PRIO_DEAD;
+        loc[(size_t)b * sb + i] = lloc[i];
+    }
+}
+
+/* ------------------------------------------------------------------ scan over blocks -- */
+
+/* in[j+1] = F_j(in[j]),  F_j(v)[d] = min(loc_j[d], min{ v[c] : dest_j[c] = d }),  for the maps
+ * j = b_first .. NB-2 in groups of G: compose each group's maps, run the group maps in sequence,
+ * then replay every group from its now known input.  The per-step cost is two workgroup barriers and a
+ * few LDS operations per cell; the next map's rows are fetched while the current one is applied. */
+#define SCAN_CPT 4                                   /* cells per thread: sb <= 4096 on this path */
+
+struct scan_regs { uint32_t d[SCAN_CPT], l[SCAN_CPT]; };
+
+__device__ __forceinline__ void scan_fetch(scan_regs &r, const uint16_t *dest, const uint32_t *loc, size_t j, uint32_t sb, bool on)
+{
+#pragma unroll
+    for (int q = 0; q < SCAN_CPT; q++) {
+        const uint32_t i = threadIdx.x + PRIO_SCAN_BLOCK * q;
+        const bool ok = on && i < sb;
+        r.d[q] = ok ? (uint32_t)dest[j * sb + i] : PRIO_DEAD;
+        r.l[q] = ok ? loc[j * sb + i] : PRIO_NONE;
+    }
+}
+
+/* one step on LDS vectors: cur (values at the map's entry cells) -> nxt */
+__device__ __forceinline__ void scan_apply(const scan_regs &r, const uint32_t *cur, uint32_t *nxt, uint32_t sb)
+{
+#pragma unroll
+    for (int q = 0; q < SCAN_CPT; q++) {
+        const uint32_t i = threadIdx.x + PRIO_SCAN_BLOCK * q;
+        if (i < sb) nxt[i] = r.l[q];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < SCAN_CPT; q++) {
+        const uint32_t i = threadIdx.x + PRIO_SCAN_BLOCK * q;
+        if (i < sb && r.d[q] != PRIO_DEAD) {
+            const uint32_t val = cur[i];
+            if (val != PRIO_NONE) atomicMin(&nxt[r.d[q]], val);
+        }
+    }
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(PRIO_SCAN_BLOCK) void k_prio_scan_compose(const uint16_t *__restrict__ dest, const uint32_t *__restrict__ loc,
+                                                                       uint32_t sb, uint32_t sb_r, uint32_t b_first, uint32_t nmaps, uint32_t G,
+                                                                       uint16_t *__restrict__ gdest, uint32_t *__restrict__ gloc)
+{
+    extern __shared__ uint32_t scan_lds[];
+    uint32_t *cl[2] = {scan_lds, scan_lds + sb_r};
+    uint16_t *cd = reinterpret_cast<uint16_t *>(scan_lds + 2 * sb_r);       /* composed dest */
+    uint16_t *dj = cd + sb_r;                                                /* the current map's dest row */
+    const uint32_t gi = blockIdx.x;
+    const uint32_t m0 = gi * G, m1 = min(m0 + G, nmaps);
+    for (uint32_t i = threadIdx.x; i < sb; i += PRIO_SCAN_BLOCK) { cl[0][i] = PRIO_NONE; cd[i] = (uint16_t)i; }
+    scan_regs cur, nxt;
+    scan_fetch(cur, dest, loc, (size_t)b_first + m0, sb, true);
+    int w = 0;
+    __syncthreads();
+    for (uint32_t m = m0; m < m1; m++) {
+        scan_fetch(nxt, dest, loc, (size_t)b_first + m + 1, sb, m + 1 < m1);
+#pragma unroll
+        for (int q = 0; q < SCAN_CPT; q++) {
+            const uint32_t i = threadIdx.x + PRIO_SCAN_BLOCK * q;
+            if (i < sb) dj[i] = (uint16_t)cur.d[q];
+        }
+        scan_apply(cur, cl[w], cl[w ^ 1], sb);          /* its first barrier also publishes dj */
+#pragma unroll
+        for (int q = 0; q < SCAN_CPT; q++) {
+            const uint32_t i = threadIdx.x + PRIO_SCAN_BLOCK * q;
+            if (i < sb) { const uint32_t c = cd[i]; cd[i] = c == PRIO_DEAD ? (uint16_t)PRIO_DEAD : dj[c]; }
+        }
+        __syncthreads();
+        w ^= 1;
+        cur = nxt;
+    }
+    for (uint32_t i = threadIdx.x; i < sb; i += PRIO_SCAN_BLOCK) {
+        gdest[(size_t)gi * sb + i] = cd[i];
+        gloc[(size_t)gi * sb + i] = cl[w][i];
+    }
+}
+
+/* replay `count` maps starting at map index m0 (rows of dest/loc start at row0) from the input vector
+ * vin; out[m+1-th row] receives the vector after map m.  Used twice: over the group maps (one
+ * workgroup) and inside every group (one workgroup per group). */
+__global__ __launch_bounds__(PRIO_SCAN_BLOCK) void k_prio_scan_replay(const uint16_t *__restrict__ dest, const uint32_t *__restrict__ loc,
+                                                                      uint32_t sb, uint32_t sb_r, size_t row0, uint32_t nmaps, uint32_t G,
+                                                                      const uint32_t *__restrict__ vin, size_t vin_stride,
+                                                                      uint32_t *__restrict__ vout, size_t vout_row0, uint32_t store_first)
+{
+    extern __shared__ uint32_t scan_lds[];
+    uint32_t *cl[2] = {scan_lds, scan_lds + sb_r};
+    const uint32_t gi = blockIdx.x;
+    const uint32_t m0 = gi * G, m1 = min(m0 + G, nmaps);
+    if (m0 >= m1) return;
+    const uint32_t *src = vin + (size_t)gi * vin_stride;
+    for (uint32_t i = threadIdx.x; i < sb; i += PRIO_SCAN_BLOCK) {
+        const uint32_t val = src[i];
+        cl[0][i] = val;
+        if (store_first) vout[(vout_row0 + m0) * sb + i] = val;
+    }
+    scan_regs cur, nxt;
+    scan_fetch(cur, dest, loc, row0 + m0, sb, true);
+    int w = 0;
+    __syncthreads();
+    for (uint32_t m = m0; m < m1; m++) {
+        scan_fetch(nxt, dest, loc, row0 + m + 1, sb, m + 1 < m1);
+        scan_apply(cur, cl[w], cl[w ^ 1], sb);
+        w ^= 1;
+        for (uint32_t i = threadIdx.x; i < sb; i += PRIO_SCAN_BLOCK) vout[(vout_row0 + m + 1) * sb + i] = cl[w][i];
+        cur = nxt;
+    }
+}
+
+__global__ void k_prio_reset(uint32_t *summary)
+{
+    summary[0] = 0;
+    summary[1] = PRIO_NONE;
+}
+
+/* ------------------------------------------------------------------ host driver ------- */
+
+static uint32_t prio_block_steps(uint32_t sb)
+{
+    const char *e = getenv("LZ77X_PRIO_BLOCK");
+    uint32_t B = e && atoi(e) > 0 ? (uint32_t)atoi(e) : 16384u;
+    const uint32_t unit = 64u * PRIO_SG;
+    if (B < sb) B = sb;                                   /* every entry cell must be evicted inside its block */
+    return (B + unit - 1u) / unit * unit;
+}
+
+struct prio_layout {
+    uint32_t B, NB, ngroups, sb_r, ring_n, G, NG;
+    size_t o_gate[2], o_rmask, o_dest, o_loc, o_in, o_gdest, o_gloc, o_gin, o_gout, o_sum, total;
+};
+
+static prio_layout prio_make_layout(uint32_t nx, uint32_t sb)
+{
+    prio_layout L;
+    L.B = prio_block_steps(sb);
+    L.NB = nx ? (nx + L.B - 1u) / L.B : 0u;
+    L.ngroups = (nx + 63u) / 64u;
+    L.sb_r = (sb + 63u) & ~63u;
+    L.ring_n = L.sb_r + 64u;
+    uint32_t G = 1;
+    while ((uint64_t)G * G < L.NB) G++;
+    const char *e = getenv("LZ77X_PRIO_SCAN_GROUP");
+    if (e && atoi(e) > 0) G = (uint32_t)atoi(e);
+    L.G = G;
+    L.NG = L.NB ? (L.NB + G - 1u) / G : 0u;
+    size_t o = 0;
+    auto take = [&](size_t bytes) { const size_t at = o; o += (bytes + 255) & ~(size_t)255; return at; };
+    L.o_gate[0] = take((size_t)L.ngroups * 8 + 64);
+    L.o_gate[1] = take((size_t)L.ngroups * 8 + 64);
+    L.o_rmask = take((size_t)L.ngroups * 8 + 64);
+    L.o_dest = take(((size_t)L.NB + 1) * sb * 2);
+    L.o_loc = take(((size_t)L.NB + 1) * sb * 4);
+    L.o_in = take(((size_t)L.NB + 1) * sb * 4);
+    L.o_gdest = take(((size_t)L.NG + 1) * sb * 2);
+    L.o_gloc = take(((size_t)L.NG + 1) * sb * 4);
+    L.o_gin = take(((size_t)L.NG + 2) * sb * 4);
+    L.o_sum = take(256);
+    L.total = o;
+    return L;
+}
+
+size_t lz77k_prio_tmp_bytes(uint32_t nx, int sb) { return prio_make_layout(nx, (uint32_t)sb).total + 256; }
+
+int lz77k_prio_supported(int sb) { return sb >= 1 && sb <= 4096; }
+
+/* xval[x] for x < nx from ps[] (distances P | S << 16).  h_flag: 8 bytes of pinned host memory.  Returns
+ * hipSuccess with *converged = 0 when max_iters did not suffice (the caller then takes the host path). */
+hipError_t lz77k_prio(const uint32_t *d_ps, uint32_t nx, int sb_i, uint32_t *d_xval, void *d_tmp, hipStream_t s,
+                      uint32_t *h_flag, int max_iters, int *iters, int *converged, hipEvent_t *ev4, float *ms3)
+{
+    *iters = 0;
+    *converged = 1;
+    if (nx == 0) return hipSuccess;
+    const uint32_t sb = (uint32_t)sb_i;
+    const prio_layout L = prio_make_layout(nx, sb);
+    uint8_t *base = reinterpret_cast<uint8_t *>(d_tmp);
+    uint64_t *gate[2] = {reinterpret_cast<uint64_t *>(base + L.o_gate[0]), reinterpret_cast<uint64_t *>(base + L.o_gate[1])};
+    uint64_t *rmask = reinterpret_cast<uint64_t *>(base + L.o_rmask);
+    uint16_t *dest = reinterpret_cast<uint16_t *>(base + L.o_dest);
+    uint32_t *loc = reinterpret_cast<uint32_t *>(base + L.o_loc);
+    uint32_t *in = reinterpret_cast<uint32_t *>(base + L.o_in);
+    uint16_t *gdest = reinterpret_cast<uint16_t *>(base + L.o_gdest);
+    uint32_t *gloc = reinterpret_cast<uint32_t *>(base + L.o_gloc);
+    uint32_t *gin = reinterpret_cast<uint32_t *>(base + L.o_gin);
+    uint32_t *summary = reinterpret_cast<uint32_t *>(base + L.o_sum);
+    hipError_t e;
+
+    {
+        const uint32_t tagn = L.ring_n + 64u;
+        const size_t lds = (size_t)4 * tagn * sizeof(uint32_t);
+        if (lds > 48 * 1024 &&
+            (e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_prio_prep), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)) != hipSuccess)
+            return e;
+        const uint32_t blocks = min((L.ngroups + 3u) / 4u, 256u * 8u);
+        hipLaunchKernelGGL(k_prio_prep, dim3(blocks), dim3(256), lds, s, d_ps, nx, tagn, rmask, gate[0]);
+        hipLaunchKernelGGL(k_prio_in0, dim3((sb + 255u) / 256u), dim3(256), 0, s, in, sb);
+    }
+    const size_t lds_fwd = (size_t)L.ring_n * 4;
+    const size_t lds_back = (size_t)L.sb_r * 4 + (size_t)L.ring_n * 2;
+    const size_t lds_scan = (size_t)L.sb_r * (4 + 4 + 2 + 2);
+    int cur = 0;
+    uint32_t first = 0;
+    for (int it = 0;; it++) {
+        if (it >= max_iters) { *converged = 0; break; }
+        const uint32_t nb = L.NB - first;
+        hipLaunchKernelGGL(k_prio_reset, dim3(1), dim3(1), 0, s, summary);
+        if (ev4 && (e = hipEventRecord(ev4[0], s)) != hipSuccess) return e;
+        hipLaunchKernelGGL(k_prio_back, dim3(nb), dim3(64), lds_back, s, d_ps, nx, sb, L.B, L.ring_n, first, gate[cur], dest, loc);
+        if (ev4 && (e = hipEventRecord(ev4[1], s)) != hipSuccess) return e;
+        if (nb > 1) {
+            /* maps first .. NB-2; in[first] is final (it = 0: identity) */
+            const uint32_t nmaps = nb - 1;
+            uint32_t G = L.G;
+            const uint32_t NG = (nmaps + G - 1u) / G;
+            if (NG > 1) {
+                hipLaunchKernelGGL(k_prio_scan_compose, dim3(NG), dim3(PRIO_SCAN_BLOCK), lds_scan, s, dest, loc, sb, L.sb_r, first, nmaps, G,
+                                   gdest, gloc);
+                /* gin[g] = input of group g: replay the group maps from in[first] */
+                hipLaunchKernelGGL(k_prio_scan_replay, dim3(1), dim3(PRIO_SCAN_BLOCK), lds_scan, s, gdest, gloc, sb, L.sb_r, (size_t)0, NG - 1u,
+                                   NG, in + (size_t)first * sb, (size_t)0, gin, (size_t)0, 1u);
+                hipLaunchKernelGGL(k_prio_scan_replay, dim3(NG), dim3(PRIO_SCAN_BLOCK), lds_scan, s, dest, loc, sb, L.sb_r, (size_t)first, nmaps, G,
+                                   gin, (size_t)sb, in, (size_t)first, 0u);
+            } else {
+                hipLaunchKernelGGL(k_prio_scan_replay, dim3(1), dim3(PRIO_SCAN_BLOCK), lds_scan, s, dest, loc, sb, L.sb_r, (size_t)first, nmaps,
+                                   nmaps, in + (size_t)first * sb, (size_t)0, in, (size_t)first, 0u);
+            }
+        }
+        if (ev4 && (e = hipEventRecord(ev4[2], s)) != hipSuccess) return e;
+        hipLaunchKernelGGL(k_prio_fwd, dim3(nb), dim3(64), lds_fwd, s, d_ps, nx, sb, L.B, L.ring_n, first, rmask, gate[cur], gate[cur ^ 1], in,
+                           d_xval, summary);
+        if (ev4 && (e = hipEventRecord(ev4[3], s)) != hipSuccess) return e;
+        if ((e = hipMemcpyAsync(h_flag, summary, 8, hipMemcpyDeviceToHost, s)) != hipSuccess) return e;
+        if ((e = hipStreamSynchronize(s)) != hipSuccess) return e;
+        *iters = it + 1;
+        if (ev4 && ms3) {
+            float t = 0;
+            if ((e = hipEventElapsedTime(&t, ev4[2], ev4[3])) != hipSuccess) return e;
+            ms3[0] += t;
+            if ((e = hipEventElapsedTime(&t, ev4[0], ev4[1])) != hipSuccess) return e;
+            ms3[1] += t;
+            if ((e = hipEventElapsedTime(&t, ev4[1], ev4[2])) != hipSuccess) return e;
+            ms3[2] += t;
+        }
+        if (h_flag[0] == 0) break;
+        /* Gates before the first flip are final (gate x only depends on gates of earlier steps), so the
+         * blocks before it keep their xval and in[] and are not visited again -- which is also why the stale
+         * prefix of the other gate buffer never matters. */
+        first = h_flag[1];
+        cur ^= 1;
+    }
+    return hipGetLastError();
+}

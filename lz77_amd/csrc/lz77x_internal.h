@@ -104,6 +104,27 @@ hipError_t lz77k_ps_cells(const uint32_t *d_ps, uint32_t *d_cells, uint32_t x0, 
 size_t lz77k_scan_tmp_bytes(uint32_t m);
 hipError_t lz77k_scan_u32(const uint32_t *d_in, uint32_t *d_out, uint32_t m, void *d_tmp, hipStream_t s);
 
+/* ---- device-resident sequential stages (k_prio.hip, k_chain.hip) ---- */
+
+/* The priority recurrence (SURVEY A.5 stage B, tree.c:202-231) on the device: xval[x] for x < nx from
+ * ps[] (distances P | S << 16).  Supported for sb <= 4096 (the live cells of a sweep are an LDS ring).
+ * h_flag: 8 bytes of pinned host memory.  Synchronises the stream once per iteration; *converged = 0
+ * when max_iters did not suffice (the caller then runs the host recurrence instead). */
+size_t lz77k_prio_tmp_bytes(uint32_t nx, int sb);
+int lz77k_prio_supported(int sb);
+hipError_t lz77k_prio(const uint32_t *d_ps, uint32_t nx, int sb, uint32_t *d_xval, void *d_tmp, hipStream_t s,
+                      uint32_t *h_flag, int max_iters, int *iters, int *converged,
+                      hipEvent_t *ev4 = nullptr /* four events: per-kernel times are added to ms3 */,
+                      float *ms3 = nullptr /* += forward sweeps, backward sweeps, boundary scans */);
+
+/* The greedy parse chain (lz77.c:89-98) on the device: chain[k] = position of token k.  *d_tbase points
+ * (inside d_tmp) at the index of the first token of every lz77k_chain_sub()-position sub-block, nsub + 1
+ * words, the last one = ntok.  Enqueues only. */
+size_t lz77k_chain_tmp_bytes(uint32_t n, int la);
+uint32_t lz77k_chain_sub(void);
+hipError_t lz77k_chain(const uint8_t *d_maxlen, uint32_t n, int la, uint32_t *d_chain, void *d_tmp, hipStream_t s,
+                       const uint32_t **d_tbase, uint32_t *nsub);
+
 /* *d_out = 64-bit sum of m uint32 */
 hipError_t lz77k_sum_u32(const uint32_t *d_in, uint32_t m, unsigned long long *d_out, hipStream_t s);
 

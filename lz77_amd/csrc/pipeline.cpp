@@ -134,8 +134,15 @@ struct Ctx {
     hipEvent_t ev[6] = {};
     std::vector<hipEvent_t> chunk_ev, tok_ev, sort_ev, match_ev, tie_ev;
     DevBuf in, ps, maxlen, scratch, xval, chain, ofs, ent, tokval, out, scantmp;
-    DevBuf z, len1, dst, ptr, flag, tstart, bidx, cells, ranks_all;
-    PinBuf h_ps, h_maxlen, h_xval, h_chain, h_small, h_tok, h_stage;
+    DevBuf z, len1, dst, ptr, flag, tstart, bidx, cells, ranks_all, prio_tmp, chain_tmp;
+    PinBuf h_ps, h_maxlen, h_xval, h_chain, h_small, h_tok, h_stage, h_tbase;
+    /* every cached buffer, so that no release path can forget one */
+    std::vector<DevBuf *> dev_bufs()
+    {
+        return {&in, &ps, &maxlen, &scratch, &xval, &chain, &ofs, &ent, &tokval, &out, &scantmp, &z, &len1, &dst, &ptr,
+                &flag, &tstart, &bidx, &cells, &ranks_all, &prio_tmp, &chain_tmp};
+    }
+    std::vector<PinBuf *> pin_bufs() { return {&h_ps, &h_maxlen, &h_xval, &h_chain, &h_small, &h_tok, &h_stage, &h_tbase}; }
 };
 
 /* One CtxSet serves one call at a time: `primary` lives on the caller's current device (pinned host
@@ -278,7 +285,7 @@ static void make_encode_geom(lz77x_geom *g, int sb, int la)
  * copied to the host as soon as its launch retires, and the host's sequential stage consumes chunk
  * i while the GPUs are already working on later chunks.  The host's products (xval, chain) go back
  * to the chunk's owner, whose token stream resolves and emits that chunk's tokens at once. */
-int encode_core(std::vector<Ctx *> &cs, const void *src, bool src_on_device, size_t n, const lz77x_geom &g, hipStream_t s, size_t *zn)
+int encode_core_host(std::vector<Ctx *> &cs, const void *src, bool src_on_device, size_t n, const lz77x_geom &g, hipStream_t s, size_t *zn)
 {
     const double t_begin = now_ms();
     memset(&g_stats, 0, sizeof g_stats);
@@ -754,6 +761,229 @@ int encode_core(std::vector<Ctx *> &cs, const void *src, bool src_on_device, siz
     return LZ77X_OK;
 }
 
+/* The device-resident encode: nothing but the stream leaves the GPU.
+ *     match (all regions) -> parse chain (k_chain) | priority recurrence (k_prio: gate iteration)
+ *           -> per token chunk: hand-over index + tie-break -> pack
+ * One device, sb <= 4096.  The host only launches, and reads back one 8-byte convergence word per gate
+ * iteration and the sub-blocks' first-token indices (to cut the token work into chunks).  When the
+ * gate iteration does not converge within its budget *fallback is set and nothing has been emitted:
+ * the caller runs the host-stage pipeline (encode_core_host) instead. */
+int encode_core_device(Ctx &c, const void *src, bool src_on_device, size_t n, const lz77x_geom &g, hipStream_t s, size_t *zn,
+                       bool *fallback)
+{
+    const double t_begin = now_ms();
+    memset(&g_stats, 0, sizeof g_stats);
+    *fallback = false;
+    if (n > LZ77X_MAX_N) return LZ77X_E_TOOBIG;
+    const uint32_t n32 = (uint32_t)n;
+    int rc;
+    double waited = 0;
+    HIPCHK(hipSetDevice(c.device));
+    if ((rc = c.in.need(n + LZ77X_PAD + 16))) return rc;
+    if (n && src != c.in.p)
+        HIPCHK(hipMemcpyAsync(c.in.p, src, n, src_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, s));
+    HIPCHK(lz77k_fill_pad(c.in.as<uint8_t>(), n32, s));
+    uint32_t ntok = 0;
+    uint64_t transfers = 0;
+    uint32_t launches = 0, nchunks = 0;
+    std::vector<char> tie_timed;
+    if (n) {
+        const size_t usb = (size_t)g.sb;
+        const size_t nx = n > usb ? n - usb : 0;
+        const uint32_t nregions = (uint32_t)((n + g.TILE - 1) / g.TILE);
+        /* match launches: as many regions as the scratch budget allows */
+        uint32_t batch = nregions;
+        {
+            const size_t per = lz77k_match_scratch_bytes(g, 1);
+            const uint32_t fit = (uint32_t)(((size_t)2 << 30) / per);
+            if (batch > fit) batch = fit ? fit : 1;
+            const char *gs = getenv("LZ77X_MATCH_BATCH");
+            if (gs && atoi(gs) > 0 && (uint32_t)atoi(gs) < batch) batch = (uint32_t)atoi(gs);
+        }
+        /* token chunks: ~4M positions, a multiple of the chain sub-block */
+        const uint32_t csub = lz77k_chain_sub();
+        size_t chunk_pos = (size_t)4 << 20;
+        {
+            const char *ce = getenv("LZ77X_TOKEN_CHUNK");
+            if (ce && atoi(ce) > 0) chunk_pos = (size_t)atoi(ce);
+            chunk_pos = (chunk_pos + csub - 1) / csub * csub;
+        }
+        nchunks = (uint32_t)((n + chunk_pos - 1) / chunk_pos);
+        const size_t idx_span = (chunk_pos < n ? chunk_pos : n) + 2 * usb + 16;
+        const char *tv = getenv("LZ77X_TOKEN_VARIANT");
+        const int tvariant = tv ? atoi(tv) : 0;
+
+        if ((rc = c.scratch.need(lz77k_match_scratch_bytes(g, batch)))) return rc;
+        if ((rc = c.ps.need((n + 8) * 4))) return rc;
+        if ((rc = c.maxlen.need(n + 64))) return rc;
+        if ((rc = c.xval.need((n + 8) * 4))) return rc;
+        if ((rc = c.chain.need((n + 8) * 4))) return rc;
+        if ((rc = c.tokval.need((n + 8) * 4))) return rc;
+        if ((rc = c.ofs.need((idx_span + 8) * 4))) return rc;
+        if ((rc = c.ent.need((idx_span + 8) * 8))) return rc;
+        if ((rc = c.scantmp.need(lz77k_scan_tmp_bytes((uint32_t)idx_span + 1)))) return rc;
+        if ((rc = c.tstart.need(lz77k_tokens_tmp_bytes((uint32_t)idx_span)))) return rc;
+        if ((rc = c.flag.need(64))) return rc;
+        if ((rc = c.prio_tmp.need(lz77k_prio_tmp_bytes((uint32_t)nx, g.sb)))) return rc;
+        if ((rc = c.chain_tmp.need(lz77k_chain_tmp_bytes(n32, g.la)))) return rc;
+        if ((rc = c.h_small.need(64))) return rc;
+        const uint32_t nsub_max = (uint32_t)((n + csub - 1) / csub);
+        if ((rc = c.h_tbase.need(((size_t)nsub_max + 2) * 4))) return rc;
+        HIPCHK(hipMemsetAsync(c.flag.p, 0, 64, s));
+        const uint32_t nlaunch = (nregions + batch - 1) / batch;
+        while (c.sort_ev.size() < 3 * (size_t)nlaunch) {
+            hipEvent_t e;
+            HIPCHK(hipEventCreate(&e));
+            c.sort_ev.push_back(e);
+        }
+        while (c.tie_ev.size() < 2 * (size_t)nchunks + 8) {
+            hipEvent_t e;
+            HIPCHK(hipEventCreate(&e));
+            c.tie_ev.push_back(e);
+        }
+        while (c.match_ev.size() < 8) {
+            hipEvent_t e;
+            HIPCHK(hipEventCreate(&e));
+            c.match_ev.push_back(e);
+        }
+
+        /* -- match stage (replaces tree.c insert/delete/find): ps[], maxlen[] for every position -- */
+        HIPCHK(hipEventRecord(c.ev[0], s));
+        for (uint32_t r0 = 0; r0 < nregions; r0 += batch) {
+            const uint32_t nr = nregions - r0 < batch ? nregions - r0 : batch;
+            HIPCHK(lz77k_match(c.in.as<uint8_t>(), n32, g, r0, nr, c.ps.as<uint32_t>(), c.maxlen.as<uint8_t>(), c.scratch.p, 0, s,
+                               &c.sort_ev[3 * launches], nullptr));
+            launches++;
+        }
+        HIPCHK(hipEventRecord(c.ev[1], s));
+        g_stats.match_launches = launches;
+
+        /* -- parse chain (lz77.c:98) -- */
+        const uint32_t *d_tbase = nullptr;
+        uint32_t nsub = 0;
+        HIPCHK(hipEventRecord(c.match_ev[0], s));
+        HIPCHK(lz77k_chain(c.maxlen.as<uint8_t>(), n32, g.la, c.chain.as<uint32_t>(), c.chain_tmp.p, s, &d_tbase, &nsub));
+        HIPCHK(hipEventRecord(c.match_ev[1], s));
+        uint32_t *h_tbase = c.h_tbase.as<uint32_t>();
+        HIPCHK(hipMemcpyAsync(h_tbase, d_tbase, ((size_t)nsub + 1) * 4, hipMemcpyDeviceToHost, s));
+
+        /* -- priority recurrence (tree.c:202-231) -- */
+        int iters = 0, converged = 1;
+        int max_iters = 96;
+        {
+            const char *me = getenv("LZ77X_PRIO_MAX_ITERS");
+            if (me && atoi(me) > 0) max_iters = atoi(me);
+        }
+        HIPCHK(hipEventRecord(c.match_ev[2], s));
+        const double tw0 = now_ms();
+        float prio_ms3[3] = {0, 0, 0};
+        HIPCHK(lz77k_prio(c.ps.as<uint32_t>(), (uint32_t)nx, g.sb, c.xval.as<uint32_t>(), c.prio_tmp.p, s, c.h_small.as<uint32_t>() + 8,
+                          max_iters, &iters, &converged, &c.match_ev[4], prio_ms3));
+        HIPCHK(hipEventRecord(c.match_ev[3], s));
+        g_stats.k_prio_fwd_ms = prio_ms3[0];
+        g_stats.k_prio_back_ms = prio_ms3[1];
+        g_stats.k_prio_scan_ms = prio_ms3[2];
+        HIPCHK(hipStreamSynchronize(s));                       /* tbase has landed (nx == 0: the recurrence did not sync) */
+        waited += now_ms() - tw0;
+        g_stats.prio_iters = (uint32_t)iters;
+        if (!converged) {
+            *fallback = true;
+            return LZ77X_OK;
+        }
+        ntok = h_tbase[nsub];
+        TRACE("match + chain + recurrence", t_begin);
+
+        /* -- tokens: per chunk, the hand-over index of the evictions that can matter and the tie-break -- */
+        tie_timed.assign(nchunks, 0);
+        HIPCHK(hipEventRecord(c.ev[2], s));
+        for (uint32_t ci = 0; ci < nchunks; ci++) {
+            const size_t b = (size_t)ci * chunk_pos, e = b + chunk_pos < n ? b + chunk_pos : n;
+            const uint32_t ta = h_tbase[b / csub], tb = e == n ? ntok : h_tbase[e / csub];
+            const size_t x_done = e > usb ? e - usb : 0;
+            const uint32_t dbase = b > usb ? (uint32_t)(b - usb) : 0u;
+            const uint32_t xa = dbase > (uint32_t)g.sb ? dbase - (uint32_t)g.sb : 0u;
+            const size_t x_new = b > usb ? b - usb : 0;
+            HIPCHK(lz77k_xfer_index(c.ps.as<uint32_t>(), c.xval.as<uint32_t>(), xa, (uint32_t)x_done, dbase, (uint32_t)e, c.ofs.as<uint32_t>(),
+                                    c.ent.as<uint2>(), c.scantmp.p, s, (uint32_t)x_new, c.flag.as<unsigned long long>() + 1));
+            HIPCHK(lz77k_tokens(c.in.as<uint8_t>(), n32, g, c.chain.as<uint32_t>() + ta, tb - ta, c.maxlen.as<uint8_t>(), c.ofs.as<uint32_t>(),
+                                c.ent.as<uint2>(), dbase, (uint32_t)b, (uint32_t)e, c.tokval.as<uint32_t>() + ta, c.tstart.as<uint32_t>(), nullptr,
+                                tvariant, s, &c.tie_ev[2 * ci], nullptr));
+            tie_timed[ci] = tb > ta;
+        }
+        HIPCHK(hipMemcpyAsync(c.h_small.as<unsigned long long>() + 2, c.flag.as<unsigned long long>() + 1, 8, hipMemcpyDeviceToHost, s));
+    } else {
+        if ((rc = c.tokval.need(64))) return rc;
+        HIPCHK(hipEventRecord(c.ev[0], s));
+        HIPCHK(hipEventRecord(c.ev[1], s));
+        HIPCHK(hipEventRecord(c.ev[2], s));
+    }
+    *zn = stream_bytes(ntok, g.T);
+    const uint64_t nwords = (*zn + 3) / 4;
+    if ((rc = c.out.need(nwords * 4 + 16))) return rc;
+    HIPCHK(lz77k_pack(c.tokval.as<uint32_t>(), ntok, g, c.out.as<uint32_t>(), nwords, s));
+    HIPCHK(hipEventRecord(c.ev[3], s));
+    const double tw = now_ms();
+    HIPCHK(hipStreamSynchronize(s));
+    waited += now_ms() - tw;
+    if (n) transfers = c.h_small.as<unsigned long long>()[2];
+
+    float ms = 0;
+    HIPCHK(hipEventElapsedTime(&ms, c.ev[0], c.ev[1]));
+    g_stats.k_match_ms = ms;
+    HIPCHK(hipEventElapsedTime(&ms, c.ev[2], c.ev[3]));
+    g_stats.k_token_ms = ms;
+    if (n) {
+        HIPCHK(hipEventElapsedTime(&ms, c.match_ev[0], c.match_ev[1]));
+        g_stats.k_chain_ms = ms;
+        HIPCHK(hipEventElapsedTime(&ms, c.match_ev[2], c.match_ev[3]));
+        g_stats.k_prio_ms = ms;
+        double sort_ms = 0, walk_ms = 0, tie_ms = 0;
+        for (uint32_t i = 0; i < launches; i++) {
+            HIPCHK(hipEventElapsedTime(&ms, c.sort_ev[3 * i], c.sort_ev[3 * i + 1]));
+            sort_ms += ms;
+            HIPCHK(hipEventElapsedTime(&ms, c.sort_ev[3 * i + 1], c.sort_ev[3 * i + 2]));
+            walk_ms += ms;
+        }
+        for (uint32_t ci = 0; ci < nchunks; ci++) {
+            if (!tie_timed[ci]) continue;
+            HIPCHK(hipEventElapsedTime(&ms, c.tie_ev[2 * ci], c.tie_ev[2 * ci + 1]));
+            tie_ms += ms;
+            g_stats.token_launches++;
+        }
+        g_stats.k_sort_ms = sort_ms;
+        g_stats.k_walk_ms = walk_ms;
+        g_stats.k_tiebreak_ms = tie_ms;
+    }
+    g_stats.n = n;
+    g_stats.zn = *zn;
+    g_stats.ntok = ntok;
+    g_stats.transfers = transfers;
+    g_stats.total_ms = now_ms() - t_begin;
+    g_stats.copy_ms = waited;
+    TRACE("encode_core_device total", t_begin);
+    return LZ77X_OK;
+}
+
+/* Which pipeline an encode takes: everything on the device when the geometry allows it (one device,
+ * sb <= 4096, production kernels), the round-1 pipeline with the two recurrences on host cores
+ * otherwise (LZ77X_HOST_STAGEB=1 forces it) or when the gate iteration gives up. */
+int encode_core(std::vector<Ctx *> &cs, const void *src, bool src_on_device, size_t n, const lz77x_geom &g, hipStream_t s, size_t *zn)
+{
+    const char *hs = getenv("LZ77X_HOST_STAGEB"), *vs = getenv("LZ77X_MATCH_VARIANT");
+    const bool device_ok = cs.size() == 1 && g.fast && g.shifted && lz77k_prio_supported(g.sb) && !(hs && atoi(hs)) && !(vs && atoi(vs)) &&
+                           !getenv("LZ77X_SERIAL");
+    if (device_ok) {
+        bool fallback = false;
+        const int rc = encode_core_device(*cs[0], src, src_on_device, n, g, s, zn, &fallback);
+        if (rc != LZ77X_OK || !fallback) return rc;
+        const uint32_t iters = g_stats.prio_iters;
+        const int rc2 = encode_core_host(cs, cs[0]->in.p, true, n, g, s, zn);     /* the input is already in c.in */
+        g_stats.prio_iters = iters;
+        return rc2;
+    }
+    return encode_core_host(cs, src, src_on_device, n, g, s, zn);
+}
+
 /* ---------------------------------------------------------------- decode ------------ */
 
 /* Stream must already be in c.z (device, padded).  Computes geometry and decoded size;
@@ -1165,13 +1395,12 @@ void ctx_release(Ctx &c)
     if (!c.ready) return;
     hipError_t e = hipSetDevice(c.device);
     e = hipDeviceSynchronize();
-    for (DevBuf *b : {&c.in, &c.ps, &c.maxlen, &c.scratch, &c.xval, &c.chain, &c.ofs, &c.ent, &c.tokval, &c.out, &c.scantmp,
-                      &c.z, &c.len1, &c.dst, &c.ptr, &c.flag, &c.tstart, &c.bidx, &c.cells}) {
+    for (DevBuf *b : c.dev_bufs()) {
         if (b->p) e = hipFree(b->p);
         b->p = nullptr;
         b->cap = 0;
     }
-    for (PinBuf *b : {&c.h_ps, &c.h_maxlen, &c.h_xval, &c.h_chain, &c.h_small, &c.h_tok, &c.h_stage}) b->release();
+    for (PinBuf *b : c.pin_bufs()) b->release();
     for (auto *v : {&c.chunk_ev, &c.tok_ev, &c.sort_ev, &c.match_ev, &c.tie_ev}) {
         for (hipEvent_t ev : *v) e = hipEventDestroy(ev);
         v->clear();
@@ -1296,6 +1525,70 @@ int lz77x_stage_priorities(const uint16_t *P, const uint16_t *S, size_t n, int s
     lz77x_prio_run(&st, ps, sb, n, xval);
     lz77x_prio_free(&st);
     free(ps);
+    return LZ77X_OK;
+}
+
+int lz77x_stage_priorities_device(const uint16_t *P, const uint16_t *S, size_t n, int sb, uint32_t *xval, int *iters_out)
+{
+    if ((!P || !S || !xval) && n) return LZ77X_E_ARG;
+    if (!lz77k_prio_supported(sb) || n > LZ77X_MAX_N) return LZ77X_E_ARG;
+    Lease lease;
+    int rc;
+    if ((rc = primary_context(*lease.set))) return rc;
+    Ctx &c = lease.set->primary;
+    if (iters_out) *iters_out = 0;
+    if (!n) return LZ77X_OK;
+    uint32_t *ps = (uint32_t *)malloc(n * 4);
+    if (!ps) return LZ77X_E_NOMEM;
+    for (size_t i = 0; i < n; i++) ps[i] = (uint32_t)P[i] | ((uint32_t)S[i] << 16);
+    rc = LZ77X_OK;
+    int iters = 0, converged = 1;
+    do {
+        if ((rc = c.ps.need((n + 8) * 4))) break;
+        if ((rc = c.xval.need((n + 8) * 4))) break;
+        if ((rc = c.prio_tmp.need(lz77k_prio_tmp_bytes((uint32_t)n, sb)))) break;
+        if ((rc = c.h_small.need(64))) break;
+        hipError_t e = hipMemcpyAsync(c.ps.p, ps, n * 4, hipMemcpyHostToDevice, c.stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(c.stream);              /* pageable source */
+        const char *me = getenv("LZ77X_PRIO_MAX_ITERS");
+        /* like lz77x_stage_priorities: only x < n - sb is ever evicted (lz77.c:101-103), the rest stays NONE */
+        const size_t nx = n > (size_t)sb ? n - (size_t)sb : 0;
+        for (size_t i = nx; i < n; i++) xval[i] = LZ77X_NONE32;
+        if (e == hipSuccess)
+            e = lz77k_prio(c.ps.as<uint32_t>(), (uint32_t)nx, sb, c.xval.as<uint32_t>(), c.prio_tmp.p, c.stream, c.h_small.as<uint32_t>() + 8,
+                           me && atoi(me) > 0 ? atoi(me) : 1 << 20, &iters, &converged);
+        if (e == hipSuccess && nx) e = hipMemcpy(xval, c.xval.p, nx * 4, hipMemcpyDeviceToHost);
+        if (e != hipSuccess) {
+            snprintf(g_err, sizeof g_err, "stage_priorities_device: %s", hipGetErrorString(e));
+            rc = LZ77X_E_HIP;
+        }
+    } while (0);
+    free(ps);
+    if (iters_out) *iters_out = converged ? iters : -iters;
+    return rc;
+}
+
+int lz77x_stage_chain_device(const uint8_t *maxlen, size_t n, int la, uint32_t *chain, size_t *ntok)
+{
+    if ((!maxlen || !chain) && n) return LZ77X_E_ARG;
+    if (!ntok || la < 2 || la > 255 || n > LZ77X_MAX_N) return LZ77X_E_ARG;
+    Lease lease;
+    int rc;
+    if ((rc = primary_context(*lease.set))) return rc;
+    Ctx &c = lease.set->primary;
+    *ntok = 0;
+    if (!n) return LZ77X_OK;
+    if ((rc = c.maxlen.need(n + 64))) return rc;
+    if ((rc = c.chain.need((n + 8) * 4))) return rc;
+    if ((rc = c.chain_tmp.need(lz77k_chain_tmp_bytes((uint32_t)n, la)))) return rc;
+    HIPCHK(hipMemcpy(c.maxlen.p, maxlen, n, hipMemcpyHostToDevice));
+    const uint32_t *d_tbase = nullptr;
+    uint32_t nsub = 0, total = 0;
+    HIPCHK(lz77k_chain(c.maxlen.as<uint8_t>(), (uint32_t)n, la, c.chain.as<uint32_t>(), c.chain_tmp.p, c.stream, &d_tbase, &nsub));
+    HIPCHK(hipStreamSynchronize(c.stream));
+    HIPCHK(hipMemcpy(&total, d_tbase + nsub, 4, hipMemcpyDeviceToHost));
+    if (total) HIPCHK(hipMemcpy(chain, c.chain.p, (size_t)total * 4, hipMemcpyDeviceToHost));
+    *ntok = total;
     return LZ77X_OK;
 }
 
