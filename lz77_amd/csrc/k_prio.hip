@@ -8,28 +8,29 @@
  *     if P[x], S[x] exist and pi[x] < pi[P[x]] and pi[x] < pi[S[x]]:  pi[S[x]] <- pi[x]       (1)
  *
  * with pi[c] = c when c is inserted.  Round 1 ran (1) on one host core (0.76 ns per position, 95 % of
- * an encode).  Read as data flow it parallelises:
+ * an encode).  Cut into blocks of B consecutive steps it parallelises:
  *
+ *   - a block only needs the values of the sb cells that are live at its first step ("in"); given them,
+ *     one wavefront runs (1) over the block exactly (k_prio_fwd) -- every block at once;
  *   - a cell only ever DEcreases, and a write that fails its S-side test would not have lowered the
  *     cell, so (1) is   pi[S[x]] <- min(pi[S[x]], pi[x])   guarded by the P-side test alone: the GATE
- *     g[x] = "P, S exist and pi_x[x] < pi_x[P[x]]"  (pi_x = cells just before step x);
- *   - with the gates FIXED the cell values are a min over a forest (x -> S[x] for open gates): for a
- *     block of B consecutive steps that is a map  in -> out  on the sb cells that are live at the
- *     block boundary,  out[d] = min(loc[d], min{ in[c] : dest[c] = d }),  which composes, so the
- *     values at every block boundary are a scan over blocks;
- *   - the gates follow from the values, and gate x only depends on gates of earlier steps: iterating
- *     gates -> values -> gates from "every gate open" reaches the unique fixed point.  Measured: wrong
- *     gates shrink ~5x per iteration on text and random bytes (13-15 iterations for any size),
- *     record-structured data adds a thin tail; the gates before the first flip of an iteration are
- *     final, so later iterations only run the blocks from there on.
+ *     g[x] = "P, S exist and pi_x[x] < pi_x[P[x]]"  (pi_x = cells just before step x).  With the gates
+ *     fixed the cell values are a min over a forest (x -> S[x] for open gates), and a block is a map on
+ *     boundary values,  out[d] = min(loc[d], min{ in[c] : dest[c] = d })  (k_prio_back), which
+ *     composes: the values at every block boundary are a scan over the blocks' maps (k_prio_scan_*);
+ *   - so iterate: gates -> maps -> boundary values -> exact block sweeps -> gates.  Block 0 is exact
+ *     after the first sweep, and by induction every block before the first block whose gates changed in
+ *     an iteration is final (later iterations start there); a sweep that reproduces the gates its
+ *     boundary values were computed from is the fixed point = the sequential result.  Measured: 5-7
+ *     iterations on text, random bytes, low-entropy runs and record-structured data alike at B = 16K-64K
+ *     (wrong gates shrink 30-100x per iteration: a gate mostly depends on recent history, which the
+ *     exact sweep inside a block resolves at once).
  *
- * One iteration = k_prio_back (per block: where does each entry cell's chain leave the block, and
- * what arrives at the exit cells from inside) -> k_prio_scan_* (values at every block boundary) ->
- * k_prio_fwd (per block: the sequential sweep with exact incoming values: new gates, and xval[] --
- * the priority handed over at each eviction, what k_tokens consumes).  One WAVEFRONT owns a block; its
- * 64 lanes take 64 consecutive steps, split into "rounds" wherever a step reads a cell an earlier
- * step of the same 64 writes (a static property of P/S: k_prio_prep computes the round masks once).
- * The sb + 64 live cells of a sweep are a ring in LDS (16.6 KB at sb 4095: nine wavefronts per CU).
+ * One WAVEFRONT owns a block; its 64 lanes take 64 consecutive steps, split into "rounds" wherever a
+ * step reads a cell an earlier step of the same 64 writes (a static property of P/S: k_prio_prep
+ * computes the round masks once).  The sb + 64 live cells of a sweep are a ring in LDS (18.7 KB at
+ * sb 4095: eight wavefronts per CU).  xval[x] -- the priority handed over at the eviction of x, what
+ * k_tokens consumes -- is written by every sweep; the last sweep of a block is the exact one.
  */
 #include "kernels_common.h"
 
@@ -103,7 +104,10 @@ __global__ void k_prio_in0(uint32_t *__restrict__ in0, uint32_t sb)
 /* ------------------------------------------------------------------ forward sweep ---- */
 
 /* Block b = steps [b*B, min((b+1)*B, nx)).  in[b][i] = value of cell b*B+i before the block's first
- * step (cells beyond b*B+sb have not been written yet: they hold their own position). */
+ * step (cells beyond b*B+sb have not been written yet: they hold their own position).  The sweep is
+ * recurrence (1) itself; gold[] (the gates the boundary values came from) is only compared against. */
+/* STORE: write xval[] (every production sweep does; false is a timing probe) */
+template <bool STORE>
 __global__ __launch_bounds__(64) void k_prio_fwd(const uint32_t *__restrict__ ps, uint32_t nx, uint32_t sb, uint32_t B,
                                                  uint32_t ring_n, uint32_t b_first, const uint64_t *__restrict__ rmask,
                                                  const uint64_t *__restrict__ gold, uint64_t *__restrict__ gnew,
@@ -116,22 +120,26 @@ __global__ __launch_bounds__(64) void k_prio_fwd(const uint32_t *__restrict__ ps
     const uint32_t x0 = b * B;
     const uint32_t x1 = nx - x0 < B ? nx : x0 + B;
     for (uint32_t r = lane; r < ring_n; r += 64) ring[r] = r < sb ? in[(size_t)b * sb + r] : x0 + r;
+    uint64_t *gl = reinterpret_cast<uint64_t *>(ring + ring_n);      /* the block's new gates: B/64 words (ring_n is even) */
     wave_sync();
 
     uint32_t off = 0;                                  /* ring slot of cell xg */
     uint32_t nflip = 0;
     uint32_t v[PRIO_SG], vn[PRIO_SG];
     uint64_t rm_l = 0, go_l = 0, rm_n = 0, go_n = 0;
+    /* every load is unconditional (clamped address, value masked afterwards): a load under a branch makes
+     * the compiler wait for ALL outstanding loads at the first use, and the prefetch would overlap nothing */
+    const uint32_t xlast = x1 - 1u;
     auto fetch = [&](uint32_t xs, uint32_t (&vv)[PRIO_SG], uint64_t &rml, uint64_t &gol) {
 #pragma unroll
         for (uint32_t k = 0; k < PRIO_SG; k++) {
             const uint32_t x = xs + 64u * k + lane;
-            vv[k] = (xs < x1 && x < x1) ? ps[x] : 0u;
+            const uint32_t t = ps[min(x, xlast)];
+            vv[k] = x < x1 ? t : 0u;
         }
-        const uint32_t xq = xs + 64u * lane;
-        rml = 0;
-        gol = 0;
-        if (lane < PRIO_SG && xs < x1 && xq < x1) { rml = rmask[xq >> 6]; gol = gold[xq >> 6]; }
+        const uint32_t xq = min(xs + 64u * (lane & (PRIO_SG - 1u)), xlast);
+        rml = rmask[xq >> 6];
+        gol = gold[xq >> 6];
     };
     fetch(x0, v, rm_l, go_l);
     for (uint32_t xs = x0; xs < x1; xs += 64u * PRIO_SG) {
@@ -151,7 +159,6 @@ __global__ __launch_bounds__(64) void k_prio_fwd(const uint32_t *__restrict__ ps
                 ip -= ip >= ring_n ? ring_n : 0u;
                 uint32_t is = ix + s;
                 is -= is >= ring_n ? ring_n : 0u;
-                const bool gate_o = (go >> lane) & 1ull;
                 bool ng = false;
                 uint32_t out = PRIO_NONE;
                 uint64_t r = rm;
@@ -162,14 +169,14 @@ __global__ __launch_bounds__(64) void k_prio_fwd(const uint32_t *__restrict__ ps
                     if (has && lane >= start && lane < end) {
                         const uint32_t a = ring[ix], w = ring[ip], sv = ring[is];
                         ng = a < w;                                   /* the gate: x's predecessor hangs below x */
-                        if (gate_o && a < sv) { ring[is] = a; out = a; }   /* tree.c:202-231: S takes x's place */
+                        if (ng && a < sv) { ring[is] = a; out = a; }  /* tree.c:202-231: S takes x's place */
                     }
                     wave_sync();
                 } while (r);
                 const uint64_t gnb = __ballot(ng);
                 nflip += (uint32_t)__popcll(gnb ^ go);
                 if (lane == k) gn_l = gnb;
-                if (x < x1) xval[x] = out;
+                if (STORE && x < x1) xval[x] = out;
                 /* cell xg+64+sb+lane becomes live with the next group; its slot held cell xg+lane */
                 uint32_t fi = off + lane;                             /* (off + 64 + sb_r + lane) mod ring_n, ring_n = sb_r + 64 */
                 fi -= fi >= ring_n ? ring_n : 0u;
@@ -179,15 +186,14 @@ __global__ __launch_bounds__(64) void k_prio_fwd(const uint32_t *__restrict__ ps
                 wave_sync();
             }
         }
-        {
-            const uint32_t xq = xs + 64u * lane;
-            if (lane < PRIO_SG && xq < x1) gnew[xq >> 6] = gn_l;
-        }
+        if (lane < PRIO_SG) gl[((xs - x0) >> 6) + lane] = gn_l;
 #pragma unroll
         for (uint32_t k = 0; k < PRIO_SG; k++) v[k] = vn[k];
         rm_l = rm_n;
         go_l = go_n;
     }
+    wave_sync();
+    for (uint32_t i = lane; i < (x1 - x0 + 63u) / 64u; i += 64) gnew[(x0 >> 6) + i] = gl[i];
     if (lane == 0 && nflip) {
         atomicAdd(&summary[0], nflip);
         atomicMin(&summary[1], b);
@@ -216,15 +222,17 @@ __global__ __launch_bounds__(64) void k_prio_back(const uint32_t *__restrict__ p
     const uint32_t nsg = (x1 - x0 + 64u * PRIO_SG - 1u) / (64u * PRIO_SG);
     uint32_t v[PRIO_SG], vn[PRIO_SG];
     uint64_t g_l = 0, g_n = 0;
-    auto fetch = [&](int32_t sgi, uint32_t (&vv)[PRIO_SG], uint64_t &gl) {
+    const uint32_t xlast = x1 - 1u;
+    auto fetch = [&](int32_t sgi, uint32_t (&vv)[PRIO_SG], uint64_t &gl) {         /* unconditional loads, see k_prio_fwd */
         const uint32_t xs = x0 + 64u * PRIO_SG * (uint32_t)(sgi < 0 ? 0 : sgi);
 #pragma unroll
         for (uint32_t k = 0; k < PRIO_SG; k++) {
             const uint32_t x = xs + 64u * k + lane;
-            vv[k] = (sgi >= 0 && x < x1) ? ps[x] : 0u;
+            const uint32_t t = ps[min(x, xlast)];
+            vv[k] = x < x1 ? t : 0u;
         }
-        const uint32_t xq = xs + 64u * lane;
-        gl = (sgi >= 0 && lane < PRIO_SG && xq < x1) ? gates[xq >> 6] : 0ull;
+        const uint32_t xq = min(xs + 64u * (lane & (PRIO_SG - 1u)), xlast);
+        gl = gates[xq >> 6];
     };
     fetch((int32_t)nsg - 1, v, g_l);
     for (int32_t sgi = (int32_t)nsg - 1; sgi >= 0; sgi--) {
@@ -290,14 +298,14 @@ __global__ __launch_bounds__(64) void k_prio_back(const uint32_t *__restrict__ p
 
 struct scan_regs { uint32_t d[SCAN_CPT], l[SCAN_CPT]; };
 
-__device__ __forceinline__ void scan_fetch(scan_regs &r, const uint16_t *dest, const uint32_t *loc, size_t j, uint32_t sb, bool on)
+__device__ __forceinline__ void scan_fetch(scan_regs &r, const uint16_t *dest, const uint32_t *loc, size_t j, uint32_t sb)
 {
+    /* unconditional loads (clamped index), so that the compiler can keep them in flight across a step */
 #pragma unroll
     for (int q = 0; q < SCAN_CPT; q++) {
-        const uint32_t i = threadIdx.x + PRIO_SCAN_BLOCK * q;
-        const bool ok = on && i < sb;
-        r.d[q] = ok ? (uint32_t)dest[j * sb + i] : PRIO_DEAD;
-        r.l[q] = ok ? loc[j * sb + i] : PRIO_NONE;
+        const uint32_t i = min(threadIdx.x + PRIO_SCAN_BLOCK * q, sb - 1u);
+        r.d[q] = (uint32_t)dest[j * sb + i];
+        r.l[q] = loc[j * sb + i];
     }
 }
 
@@ -333,11 +341,11 @@ __global__ __launch_bounds__(PRIO_SCAN_BLOCK) void k_prio_scan_compose(const uin
     const uint32_t m0 = gi * G, m1 = min(m0 + G, nmaps);
     for (uint32_t i = threadIdx.x; i < sb; i += PRIO_SCAN_BLOCK) { cl[0][i] = PRIO_NONE; cd[i] = (uint16_t)i; }
     scan_regs cur, nxt;
-    scan_fetch(cur, dest, loc, (size_t)b_first + m0, sb, true);
+    scan_fetch(cur, dest, loc, (size_t)b_first + m0, sb);
     int w = 0;
     __syncthreads();
     for (uint32_t m = m0; m < m1; m++) {
-        scan_fetch(nxt, dest, loc, (size_t)b_first + m + 1, sb, m + 1 < m1);
+        scan_fetch(nxt, dest, loc, (size_t)b_first + min(m + 1, m1 - 1u), sb);
 #pragma unroll
         for (int q = 0; q < SCAN_CPT; q++) {
             const uint32_t i = threadIdx.x + PRIO_SCAN_BLOCK * q;
@@ -379,11 +387,11 @@ __global__ __launch_bounds__(PRIO_SCAN_BLOCK) void k_prio_scan_replay(const uint
         if (store_first) vout[(vout_row0 + m0) * sb + i] = val;
     }
     scan_regs cur, nxt;
-    scan_fetch(cur, dest, loc, row0 + m0, sb, true);
+    scan_fetch(cur, dest, loc, row0 + m0, sb);
     int w = 0;
     __syncthreads();
     for (uint32_t m = m0; m < m1; m++) {
-        scan_fetch(nxt, dest, loc, row0 + m + 1, sb, m + 1 < m1);
+        scan_fetch(nxt, dest, loc, row0 + min(m + 1, m1 - 1u), sb);
         scan_apply(cur, cl[w], cl[w ^ 1], sb);
         w ^= 1;
         for (uint32_t i = threadIdx.x; i < sb; i += PRIO_SCAN_BLOCK) vout[(vout_row0 + m + 1) * sb + i] = cl[w][i];
@@ -399,11 +407,19 @@ __global__ void k_prio_reset(uint32_t *summary)
 
 /* ------------------------------------------------------------------ host driver ------- */
 
-static uint32_t prio_block_steps(uint32_t sb)
+/* Steps per block.  Large blocks converge in fewer iterations (fewer boundaries whose values lag one
+ * iteration behind: 8 iterations at 16K, 5 at 64K on 100 MB of text) and make the boundary scan short;
+ * but a sweep wants >= ~1500 blocks in flight (one wavefront each): nx/1536 clamped to [16K, 64K].
+ * LZ77X_PRIO_BLOCK overrides. */
+static uint32_t prio_block_steps(uint32_t nx, uint32_t sb)
 {
     const char *e = getenv("LZ77X_PRIO_BLOCK");
-    uint32_t B = e && atoi(e) > 0 ? (uint32_t)atoi(e) : 16384u;
+    uint32_t B = e && atoi(e) > 0 ? (uint32_t)atoi(e) : nx / 1536u;
     const uint32_t unit = 64u * PRIO_SG;
+    if (!(e && atoi(e) > 0)) {
+        if (B > 65536u) B = 65536u;
+        if (B < 16384u) B = 16384u;
+    }
     if (B < sb) B = sb;                                   /* every entry cell must be evicted inside its block */
     return (B + unit - 1u) / unit * unit;
 }
@@ -416,7 +432,7 @@ struct prio_layout {
 static prio_layout prio_make_layout(uint32_t nx, uint32_t sb)
 {
     prio_layout L;
-    L.B = prio_block_steps(sb);
+    L.B = prio_block_steps(nx, sb);
     L.NB = nx ? (nx + L.B - 1u) / L.B : 0u;
     L.ngroups = (nx + 63u) / 64u;
     L.sb_r = (sb + 63u) & ~63u;
@@ -479,7 +495,7 @@ hipError_t lz77k_prio(const uint32_t *d_ps, uint32_t nx, int sb_i, uint32_t *d_x
         hipLaunchKernelGGL(k_prio_prep, dim3(blocks), dim3(256), lds, s, d_ps, nx, tagn, rmask, gate[0]);
         hipLaunchKernelGGL(k_prio_in0, dim3((sb + 255u) / 256u), dim3(256), 0, s, in, sb);
     }
-    const size_t lds_fwd = (size_t)L.ring_n * 4;
+    const size_t lds_fwd = (size_t)L.ring_n * 4 + (size_t)(L.B / 64u) * 8;
     const size_t lds_back = (size_t)L.sb_r * 4 + (size_t)L.ring_n * 2;
     const size_t lds_scan = (size_t)L.sb_r * (4 + 4 + 2 + 2);
     int cur = 0;
@@ -510,8 +526,8 @@ hipError_t lz77k_prio(const uint32_t *d_ps, uint32_t nx, int sb_i, uint32_t *d_x
             }
         }
         if (ev4 && (e = hipEventRecord(ev4[2], s)) != hipSuccess) return e;
-        hipLaunchKernelGGL(k_prio_fwd, dim3(nb), dim3(64), lds_fwd, s, d_ps, nx, sb, L.B, L.ring_n, first, rmask, gate[cur], gate[cur ^ 1], in,
-                           d_xval, summary);
+        hipLaunchKernelGGL(k_prio_fwd<true>, dim3(nb), dim3(64), lds_fwd, s, d_ps, nx, sb, L.B, L.ring_n, first, rmask, gate[cur], gate[cur ^ 1],
+                           in, d_xval, summary);
         if (ev4 && (e = hipEventRecord(ev4[3], s)) != hipSuccess) return e;
         if ((e = hipMemcpyAsync(h_flag, summary, 8, hipMemcpyDeviceToHost, s)) != hipSuccess) return e;
         if ((e = hipStreamSynchronize(s)) != hipSuccess) return e;
@@ -526,9 +542,9 @@ hipError_t lz77k_prio(const uint32_t *d_ps, uint32_t nx, int sb_i, uint32_t *d_x
             ms3[2] += t;
         }
         if (h_flag[0] == 0) break;
-        /* Gates before the first flip are final (gate x only depends on gates of earlier steps), so the
-         * blocks before it keep their xval and in[] and are not visited again -- which is also why the stale
-         * prefix of the other gate buffer never matters. */
+        /* Gates before the first flip are final (gate x only depends on gates of earlier steps): the blocks
+         * before it keep their in[] and are not visited again until the closing sweep.  Both gate buffers
+         * agree on that prefix (a block without a flip wrote back what it read). */
         first = h_flag[1];
         cur ^= 1;
     }

@@ -800,9 +800,10 @@ int encode_core_device(Ctx &c, const void *src, bool src_on_device, size_t n, co
             const char *gs = getenv("LZ77X_MATCH_BATCH");
             if (gs && atoi(gs) > 0 && (uint32_t)atoi(gs) < batch) batch = (uint32_t)atoi(gs);
         }
-        /* token chunks: ~4M positions, a multiple of the chain sub-block */
+        /* token chunks: up to 128M positions (one hand-over index and one tie-break launch each; the index
+         * costs 12 bytes of scratch per position), a multiple of the chain sub-block */
         const uint32_t csub = lz77k_chain_sub();
-        size_t chunk_pos = (size_t)4 << 20;
+        size_t chunk_pos = (size_t)128 << 20;
         {
             const char *ce = getenv("LZ77X_TOKEN_CHUNK");
             if (ce && atoi(ce) > 0) chunk_pos = (size_t)atoi(ce);
@@ -1557,6 +1558,7 @@ int lz77x_stage_priorities_device(const uint16_t *P, const uint16_t *S, size_t n
         if (e == hipSuccess)
             e = lz77k_prio(c.ps.as<uint32_t>(), (uint32_t)nx, sb, c.xval.as<uint32_t>(), c.prio_tmp.p, c.stream, c.h_small.as<uint32_t>() + 8,
                            me && atoi(me) > 0 ? atoi(me) : 1 << 20, &iters, &converged);
+        if (e == hipSuccess) e = hipStreamSynchronize(c.stream);              /* the closing sweep is only enqueued */
         if (e == hipSuccess && nx) e = hipMemcpy(xval, c.xval.p, nx * 4, hipMemcpyDeviceToHost);
         if (e != hipSuccess) {
             snprintf(g_err, sizeof g_err, "stage_priorities_device: %s", hipGetErrorString(e));

@@ -47,6 +47,41 @@ def test_stage_neighbours(kind, seed, n, sb, la):
     assert np.array_equal(gS[:nx], S[:nx])
 
 
+PRIO_ENVS = [{}, {"LZ77X_PRIO_BLOCK": "512", "LZ77X_PRIO_SCAN_GROUP": "3"}, {"LZ77X_PRIO_BLOCK": "4096"}]
+
+
+@pytest.mark.parametrize("env", PRIO_ENVS, ids=["default", "b512g3", "b4096"])
+@pytest.mark.parametrize("kind,seed,n,sb,la", [c for c in STAGE_CASES if c[3] <= 4096] +
+                         [("records", 65, 300000, 255, 7), ("mixed", 66, 400000, 1000, 10), ("zeros", 0, 70000, 100, 15),
+                          ("text", 67, 1 << 20, 4095, 15), ("lowent", 68, 300000, 4095, 15)])
+def test_stage_priorities_device(kind, seed, n, sb, la, env, monkeypatch):
+    """k_prio (block sweeps + boundary scan, iterated) == the sequential recurrence of the oracle
+    (tree.c:202-231 delete-by-successor as priority hand-over), for several block / scan-group sizes"""
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    data = synth.make(kind, n, seed)
+    P, S, two = O.stage_a(data, sb, la, tree=True)
+    xv, iters = L.stage_priorities_device(P, S, sb)
+    assert iters >= 0, "the gate iteration gave up"
+    assert np.array_equal(xv, O.stage_b(P, S, sb))
+    nx = max(n - sb, 0)
+    assert np.array_equal(xv[:nx] != 0xFFFFFFFF, two[:nx].astype(bool))
+
+
+@pytest.mark.parametrize("kind,seed,n,sb,la", STAGE_CASES + [("text", 69, 300000, 4095, 2), ("random", 70, 100000, 4095, 255),
+                                                             ("zeros", 0, 50000, 100, 255), ("text", 71, 4097, 10, 4)])
+def test_stage_chain_device(kind, seed, n, sb, la):
+    """k_chain (sub-block maps composed) == the greedy parse p += len + 1 of lz77.c:89-98"""
+    data = synth.make(kind, n, seed)
+    ml = O.maxlen(data, sb, la)
+    p, want = 0, []
+    while p < n:
+        want.append(p)
+        p += int(ml[p]) + 1
+    got = L.stage_chain_device(ml, la)
+    assert np.array_equal(got, np.asarray(want, dtype=np.uint32))
+
+
 @pytest.mark.parametrize("kind,seed,n,sb,la", STAGE_CASES)
 def test_stage_maxlen_on_chain(kind, seed, n, sb, la):
     """k_match backward scan == find()'s length at every parse-chain position (tree.c:118-152)"""
@@ -179,6 +214,7 @@ def test_pinned_rings_wrap(slots, chunk, group, shards, monkeypatch):
     the recurrence thread and the feeding thread must not change a byte"""
     data = synth.mixed(2_600_000, 87)
     want = O.encode_bst(data)
+    monkeypatch.setenv("LZ77X_HOST_STAGEB", "1")           # the pipeline with the recurrences on host cores
     monkeypatch.setenv("LZ77X_RING_SLOTS", slots)
     monkeypatch.setenv("LZ77X_CHUNK_REGIONS", chunk)
     monkeypatch.setenv("LZ77X_MATCH_GROUP", group)
@@ -195,10 +231,35 @@ def test_small_chunks_pipeline(monkeypatch):
     """many tiny host chunks and single-chunk match groups: same bytes as one big chunk"""
     data = synth.text(5_000_000, 85)
     want = O.encode_bst(data)
+    monkeypatch.setenv("LZ77X_HOST_STAGEB", "1")
     for chunk, group in (("1", "1"), ("3", "2"), ("64", "8")):
         monkeypatch.setenv("LZ77X_CHUNK_REGIONS", chunk)
         monkeypatch.setenv("LZ77X_MATCH_GROUP", group)
         assert L.encode(data) == want, (chunk, group)
+
+
+@pytest.mark.parametrize("env", [{}, {"LZ77X_HOST_STAGEB": "1"}, {"LZ77X_PRIO_MAX_ITERS": "1"}, {"LZ77X_PRIO_BLOCK": "4096"},
+                                 {"LZ77X_PRIO_BLOCK": "8192", "LZ77X_PRIO_SCAN_GROUP": "2"}, {"LZ77X_TOKEN_CHUNK": "4096"},
+                                 {"LZ77X_TOKEN_CHUNK": "1000000", "LZ77X_MATCH_BATCH": "3"}],
+                         ids=["device", "host", "fallback", "b4096", "b8192g2", "tok4096", "tok1m-batch3"])
+@pytest.mark.parametrize("kind,seed,n,sb,la", [("mixed", 88, 2_500_000, 4095, 15), ("text", 89, 900_000, 1000, 10),
+                                              ("lowent", 90, 600_000, 255, 7), ("records", 91, 1_200_000, 4096, 16)])
+def test_device_and_host_pipelines_agree(kind, seed, n, sb, la, env, monkeypatch):
+    """the device-resident encode (k_prio + k_chain, any block / chunk decomposition), the pipeline with
+    both recurrences on host cores, and the fallback from one to the other when the gate iteration is cut
+    short all emit the reference's stream"""
+    data = synth.make(kind, n, seed)
+    want = O.encode_bst(data, sb, la)
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    assert L.encode(data, la, sb) == want
+    st = L.last_stats()
+    if env.get("LZ77X_HOST_STAGEB"):
+        assert st["prio_iters"] == 0 and st["host_stageb_ms"] > 0
+    elif env.get("LZ77X_PRIO_MAX_ITERS"):
+        assert st["host_stageb_ms"] > 0                      # gave up after one iteration: host path took over
+    else:
+        assert st["prio_iters"] >= 1 and st["host_stageb_ms"] == 0 and st["host_chain_ms"] == 0
 
 
 @pytest.mark.parametrize("env", [{"LZ77X_MATCH_VARIANT": "1"}, {"LZ77X_MATCH_VARIANT": "3"}, {"LZ77X_SORT_VARIANT": "1"},
