@@ -33,7 +33,8 @@ extern "C" {
 #define LZ77X_E_NOMEM    (-2)   /* host allocation failed */
 #define LZ77X_E_HIP      (-3)   /* a HIP runtime call failed (see lz77x_last_error) */
 #define LZ77X_E_NODEV    (-4)   /* no gfx950 device visible: there is NO CPU fallback */
-#define LZ77X_E_FORMAT   (-5)   /* stream shorter than its 4-byte header / zero sb or la */
+#define LZ77X_E_FORMAT   (-5)   /* stream shorter than its 4-byte header / zero sb or la / a header whose token
+                                   would be wider than 32 bits (la > 255 with a wide sb: main.c:103 never emits it) */
 #define LZ77X_E_CAP      (-6)   /* caller-provided output buffer too small (*out_n holds the need) */
 #define LZ77X_E_IO       (-7)   /* fread/fwrite failed */
 #define LZ77X_E_TOOBIG   (-8)   /* input >= 4 GiB in one call (positions are 32-bit on device) */

@@ -1,8 +1,7 @@
 /*
- * fileio.c -- whole-file-in-host-memory form of the FILE*-level entry points (plain C).  The public
- * lz77x_encode_file / lz77x_decode_file (pipeline.cpp) stream the file through two pinned staging
- * slots instead and only come here when one stream is cut into several shards (LZ77X_SHARDS > 1: the
- * other devices need a host copy of the input).
+ * fileio.c -- whole-file-in-host-memory form of lz77x_encode_file (plain C).  The public entry point
+ * (pipeline.cpp) streams the file through two pinned staging slots instead and only comes here when one
+ * stream is cut into several shards (LZ77X_SHARDS > 1: the other devices need a host copy of the input).
  */
 #include "../../include/lz77_mi355x.h"
 #include "lz77x_internal.h"
@@ -53,20 +52,5 @@ int lz77x_encode_file_buffered(FILE *in, FILE *out, int la, int sb)
     if (rc) return rc;
     rc = spill(out, z, zn);
     lz77x_free(z);
-    return rc;
-}
-
-int lz77x_decode_file_buffered(FILE *in, FILE *out)
-{
-    if (!in || !out) return LZ77X_E_ARG;
-    uint8_t *z = NULL, *data = NULL;
-    size_t zn = 0, n = 0;
-    int rc = slurp(in, &z, &zn);
-    if (rc) return rc;
-    rc = lz77x_decode(z, zn, &data, &n);
-    free(z);
-    if (rc) return rc;
-    rc = spill(out, data, n);
-    lz77x_free(data);
     return rc;
 }

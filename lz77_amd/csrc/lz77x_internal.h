@@ -70,10 +70,9 @@ void lz77x_prio_free(lz77x_prio_state *st);
 uint32_t lz77x_prio_mask(int sb);
 void lz77x_prio_run(lz77x_prio_state *st, const uint32_t *ps, int sb, size_t upto, uint32_t *xval);
 
-/* whole-file-in-memory fallbacks of the FILE* entry points (fileio.c) */
+/* whole-file-in-memory form of lz77x_encode_file for several shards (fileio.c) */
 #include <stdio.h>
 int lz77x_encode_file_buffered(FILE *in, FILE *out, int la, int sb);
-int lz77x_decode_file_buffered(FILE *in, FILE *out);
 
 #ifdef __cplusplus
 }

@@ -493,6 +493,20 @@ int encode_core_host(std::vector<Ctx *> &cs, const void *src, bool src_on_device
 
         lz77x_prio_state st;
         if (!lz77x_prio_init(&st, g.sb)) return LZ77X_E_NOMEM;
+        /* whatever way this scope is left: the recurrence's ring is freed, and on an error exit every
+         * device is drained first -- copies into the pinned rings and kernels on the side streams may
+         * still be in flight, and the cached buffers go back to the pool with the lease */
+        struct StageGuard {
+            lz77x_prio_state &st; std::vector<Ctx *> &cs; bool ok = false;
+            ~StageGuard()
+            {
+                if (!ok) {
+                    for (Ctx *c : cs) { hipError_t q = hipSetDevice(c->device); q = hipDeviceSynchronize(); (void)q; }
+                    hipError_t q = hipSetDevice(cs[0]->device); (void)q;
+                }
+                lz77x_prio_free(&st);
+            }
+        } stage_guard{st, cs};
 
         /* The two host recurrences are independent of each other (SURVEY A.2 vs A.5).  The priority
          * recurrence -- the critical path of the whole encode -- gets a thread of its own that does
@@ -549,9 +563,9 @@ int encode_core_host(std::vector<Ctx *> &cs, const void *src, bool src_on_device
              * chunk K before each of its chunks AND that chunk's successor have been consumed by both
              * host recurrences.  Chunk ci itself must be out before we can wait for it. */
             for (;;) {
-                uint32_t through;
-                { std::lock_guard<std::mutex> lk(pm); through = prio_chunks; }
-                if (through > ci) through = ci;
+                uint32_t snapshot;                              /* chunks the recurrence was through when we looked */
+                { std::lock_guard<std::mutex> lk(pm); snapshot = prio_chunks; }
+                const uint32_t through = snapshot > ci ? ci : snapshot;
                 while (gi < groups.size() &&
                        (!ring_d2h || groups[gi].ci + groups[gi].nchunks + 1 <= (uint64_t)through + K)) {
                     if ((rc = enqueue_group(groups[gi]))) { err = rc; break; }
@@ -564,8 +578,10 @@ int encode_core_host(std::vector<Ctx *> &cs, const void *src, bool src_on_device
                 {
                     std::unique_lock<std::mutex> lk(pm);
                     if (enq_chunks > ci) break;
-                    const uint32_t seen = prio_chunks;          /* ring full: wait for the recurrence to free a slot */
-                    pcv.wait(lk, [&] { return prio_chunks != seen; });
+                    /* ring full: wait until the recurrence has moved past the state the decision above was
+                     * taken on (waiting for a change relative to a LATER reading could sleep through the
+                     * very advance that frees the slot while the recurrence waits for this thread) */
+                    pcv.wait(lk, [&] { return prio_chunks != snapshot; });
                 }
             }
             if (err != LZ77X_OK) break;
@@ -658,12 +674,7 @@ int encode_core_host(std::vector<Ctx *> &cs, const void *src, bool src_on_device
         ntok = (uint32_t)ntok_sz;
         nchunks_done = nchunks;
         launches0_total = launches0;
-        lz77x_prio_free(&st);
-        if (err != LZ77X_OK) {
-            for (Ctx *c : cs) { hipError_t q = hipSetDevice(c->device); q = hipDeviceSynchronize(); (void)q; }
-            hipError_t q = hipSetDevice(c0.device); (void)q;
-            return err;
-        }
+        if (err != LZ77X_OK) return err;                       /* stage_guard drains the devices */
         g_stats.host_chain_ms = t_chain;
         g_stats.host_stageb_ms = t_prio;
         if (trace_on())
@@ -698,6 +709,7 @@ int encode_core_host(std::vector<Ctx *> &cs, const void *src, bool src_on_device
             }
             HIPCHK(hipSetDevice(c0.device));
         }
+        stage_guard.ok = true;
     } else {
         if ((rc = c0.tokval.need(64))) return rc;
         HIPCHK(hipEventRecord(c0.ev[0], s));
@@ -1003,6 +1015,9 @@ int decode_core(Ctx &c, size_t zn, hipStream_t s, bool want_data, size_t *n_out)
     if (sb < 1 || la < 1) return LZ77X_E_FORMAT;
     lz77x_geom g;
     lz77x_make_geom(&g, sb, la);
+    /* the header is 16 bits of la, but main.c:103 never lets la past 255: a token wider than 32 bits
+     * cannot come from the reference's encoder, and the kernels carry tokens in 32-bit words */
+    if (g.T > 32) return LZ77X_E_FORMAT;
     const uint64_t ntok64 = ((uint64_t)zn * 8 - 32) / (uint64_t)g.T;          /* lz77.c:271: short read = EOF */
     if (ntok64 > LZ77X_MAX_N) return LZ77X_E_TOOBIG;
     const uint32_t ntok = (uint32_t)ntok64;
@@ -1134,6 +1149,7 @@ int stream_in(Ctx &c, FILE *f, DevBuf &dst, size_t slack, size_t *n_out)
         if (at >= 0 && fstat(fileno(f), &st) == 0 && S_ISREG(st.st_mode) && (size_t)st.st_size > (size_t)at)
             hint = (size_t)st.st_size - (size_t)at;
     }
+    if (hint > LZ77X_MAX_N) return LZ77X_E_TOOBIG;                       /* before allocating or reading anything */
     if ((rc = dst.need((hint ? hint : piece) + slack))) return rc;
     size_t len = 0;
     bool used[2] = {false, false};

@@ -125,6 +125,36 @@ def test_cli_messages_equal_reference(tmp_path):
         assert (a.returncode, a.stdout, a.stderr) == (b.returncode, b.stdout, b.stderr), args
 
 
+SHIM_BIN = os.path.join(O.ORACLE_DIR, "_ref", "lz77_shimmed")
+SHIM_OBJ = os.path.join(os.path.dirname(L.LIB_PATH), "lz77_shim.o")
+
+
+def test_shim_object_exports_the_reference_symbols():
+    """lz77_shim.o defines encode()/decode() (lz77.h:14-15) and leaves bitIO_write/bitIO_read to the
+    reference's own bitio.o -- nothing of tree.c / lz77.c is needed to link the reference's main.c"""
+    syms = subprocess.check_output(["nm", SHIM_OBJ], text=True).split("\n")
+    defined = {l.split()[-1] for l in syms if " T " in l}
+    undefined = {l.split()[-1] for l in syms if l.strip().startswith("U ")}
+    assert {"encode", "decode"} <= defined
+    assert {"bitIO_write", "bitIO_read", "lz77x_encode", "lz77x_decode"} <= undefined
+    assert not any(u in undefined for u in ("insert", "find", "delete", "createTree", "updateOffset"))
+
+
+@pytest.mark.skipif(not (O.have_ref() and os.path.exists(SHIM_BIN)), reason="reference main.c + shim only in the build container")
+def test_reference_main_through_shim_cli_contract(tmp_path):
+    """the reference's UNMODIFIED main.c linked against the shim: every diagnostic and exit code of the
+    paths that end before the device is touched equals the reference binary's"""
+    f = str(tmp_path / "in")
+    open(f, "wb").write(b"hello")
+    o = str(tmp_path / "out")
+    for args in (["-c", "-o", o], ["-c", "-i", f], ["-i", f, "-o", o], ["-c", "-i", f, "-i", f, "-o", o],
+                 ["-c", "-i", f, "-o", o, "-l", "1"], ["-c", "-i", f, "-o", o, "-s", "70000"], ["-h"],
+                 ["-c", "-i", str(tmp_path / "missing"), "-o", o], ["-d", "-i", str(tmp_path / "missing"), "-o", o]):
+        a = subprocess.run([O.REF_BIN, *args], capture_output=True, text=True)
+        b = subprocess.run([SHIM_BIN, *args], capture_output=True, text=True)
+        assert (a.returncode, a.stdout, a.stderr) == (b.returncode, b.stdout, b.stderr), args
+
+
 # ---- multi-rank plan (gloo, 2 processes) ------------------------------------------------
 
 _WORKER = r"""

@@ -1,0 +1,65 @@
+"""Bit-exactness at the BASELINE.json sizes: sha256 of the device stream == sha256 of the stream the
+compiled reference emitted for the same input (tests/golden/golden_full.json, made by
+tests/golden/make_full.py in the build container).  A round trip cannot see a wrong tie-break offset
+(any valid offset decodes; the reference's choice is lz77.c:89-136 + tree.c:139-141), a digest can."""
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+
+import lz77_amd as L
+from lz77_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+FULL = {r["name"]: r for r in json.load(open(os.path.join(HERE, "golden", "golden_full.json")))["full"]}
+
+
+def _run(name):
+    import torch
+    r = FULL[name]
+    n, sb, la = r["n"], r["sb"], r["la"]
+    data = synth.make(r["kind"], n, r["seed"])
+    assert hashlib.sha256(memoryview(data)).hexdigest() == r["sha256_in"], "generator drifted"
+    d_in = torch.from_numpy(data).cuda()
+    cap = L.encode_bound(n, la, sb)
+    d_z = torch.empty(cap, dtype=torch.uint8, device="cuda")
+    st = torch.cuda.current_stream().cuda_stream
+    zn = L.encode_device(d_in.data_ptr(), n, d_z.data_ptr(), cap, la, sb, st)
+    stats = L.last_stats()
+    assert zn == r["zn"] and stats["ntok"] == r["ntok"]
+    h = hashlib.sha256()
+    step = 1 << 28
+    for at in range(0, zn, step):
+        h.update(d_z[at:min(at + step, zn)].cpu().numpy().tobytes())
+    assert h.hexdigest() == r["sha256_lz"], "stream differs from the reference's"
+    d_back = torch.empty(n, dtype=torch.uint8, device="cuda")
+    assert L.decode_device(d_z.data_ptr(), zn, d_back.data_ptr(), n, st) == n
+    assert bool(torch.equal(d_back, d_in))
+    del d_in, d_z, d_back
+    torch.cuda.empty_cache()
+    return stats
+
+
+def test_s1_enwik8_like_100mb():
+    """BASELINE.json configs[1]: 100 MB text, s=4095 l=15 -- the bench workload; everything on the device"""
+    st = _run("S1")
+    assert st["prio_iters"] >= 1 and st["host_stageb_ms"] == 0
+
+
+def test_s3_silesia_like_212mb_large_window():
+    """configs[3]: 212 MB mixed, s=65535 l=255"""
+    _run("S3")
+
+
+def test_s2_random_1gib():
+    """configs[2]: 1 GiB incompressible (the match-miss path; 521 M tokens)"""
+    _run("S2")
+
+
+def test_s4_enwik9_like_1gb():
+    """configs[4] on one device: 1 GB text, s=4095 l=15"""
+    _run("S4")

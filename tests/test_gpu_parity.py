@@ -346,6 +346,29 @@ def test_shutdown_and_reuse():
     assert L.encode(data) == a and L.decode(a) == data.tobytes()
 
 
+def test_large_window_buffers_survive_shutdown():
+    """the large-window rank arrays are cached per context like every other buffer: after lz77x_shutdown()
+    (or a move to another device) the next large-window encode must allocate them afresh, not reuse a
+    pointer that was freed with the old context"""
+    data = synth.mixed(900_000, 92)
+    want = O.encode_bst(data, 65535, 255)
+    assert L.encode(data, 255, 65535) == want
+    L.lib().lz77x_shutdown()
+    assert L.encode(data, 255, 65535) == want
+    L.lib().lz77x_shutdown()
+    assert L.encode(data[:300_000]) == O.encode_bst(data[:300_000])
+    assert L.encode(data, 255, 65535) == want
+
+
+def test_decode_refuses_tokens_wider_than_32_bits():
+    """a header with la > 255 and a wide sb describes tokens of more than 32 bits; the reference's CLI cannot
+    produce it (main.c:103) and the decode kernels carry tokens in 32-bit words: refused, not mis-decoded"""
+    z = bytes([0xFF, 0xFF, 0x00, 0x02]) + bytes(64)            # sb 65535, la 512 -> T = 16 + 9 + 8
+    with pytest.raises(L.Lz77Error) as e:
+        L.decode(z)
+    assert e.value.code == -5
+
+
 def test_arg_errors():
     for la, sb in ((1, 4095), (256, 4095), (15, 0), (15, 65536)):
         with pytest.raises(L.Lz77Error) as e:
@@ -390,6 +413,28 @@ def test_cli_roundtrip(tmp_path, golden_dir):
     r = subprocess.run([L.CLI_PATH, "-c", "-i", src, "-o", lz, "-s", "1000", "-l", "10"], capture_output=True)
     assert r.returncode == 0
     assert open(lz, "rb").read() == O.encode_bst(np.fromfile(src, dtype=np.uint8), 1000, 10)
+
+
+SHIM_BIN = os.path.join(O.ORACLE_DIR, "_ref", "lz77_shimmed")
+
+
+@pytest.mark.skipif(not os.path.exists(SHIM_BIN), reason="oracle/_ref/lz77_shimmed is built where /root/reference exists")
+@pytest.mark.parametrize("stem", ["small_text_4095_15", "small_random_4095_15", "small_lowent_4095_15", "small_mixed_1000_10",
+                                  "small_text_65535_255", "small_code_255_7"])
+def test_reference_main_through_shim(stem, tmp_path, golden_dir):
+    """INTEGRATION.md option B: cstdvd/lz77's own main.c + bitio.c, unmodified, linked against
+    lz77_shim.o + liblz77_mi355x.so (lz77.c and tree.c left out): -c emits the reference's stream, -d
+    restores the file, both silently with exit status 0 (README.md:25-40)"""
+    _, _, sb, la = stem.split("_")
+    src = os.path.join(golden_dir, stem + ".bin")
+    lz = str(tmp_path / "a.lz")
+    out = str(tmp_path / "a.out")
+    r = subprocess.run([SHIM_BIN, "-c", "-i", src, "-o", lz, "-s", sb, "-l", la], capture_output=True)
+    assert r.returncode == 0 and r.stdout == b"" and r.stderr == b"", r
+    assert open(lz, "rb").read() == open(os.path.join(golden_dir, stem + ".lz"), "rb").read()
+    r = subprocess.run([SHIM_BIN, "-d", "-i", os.path.join(golden_dir, stem + ".lz"), "-o", out], capture_output=True)
+    assert r.returncode == 0 and r.stdout == b"" and r.stderr == b"", r
+    assert open(out, "rb").read() == open(src, "rb").read()
 
 
 def test_concurrent_calls_from_threads():
