@@ -17,11 +17,20 @@
 __device__ __forceinline__ void chain_stage(uint8_t *dst, const uint8_t *__restrict__ maxlen, uint32_t n, uint32_t sub0,
                                             uint32_t nstage, uint32_t nthreads)
 {
-    /* nstage sub-blocks starting at sub0, 16 bytes per thread and step (maxlen has >= 16 bytes of slack) */
+    /* nstage sub-blocks starting at sub0, 16 bytes per thread and step.  maxlen may start at any byte (a
+     * later segment's chain begins wherever its predecessor's last token ended): aligned dwords + funnel
+     * shift; the array has >= 64 bytes of slack behind n */
+    const uint32_t sh = (uint32_t)(reinterpret_cast<uintptr_t>(maxlen) & 3u);
+    const uint32_t *base = reinterpret_cast<const uint32_t *>(maxlen - sh);
     for (uint32_t i = threadIdx.x * 16u; i < nstage * CHAIN_SB; i += nthreads * 16u) {
         const uint64_t pos = (uint64_t)sub0 * CHAIN_SB + i;
         uint4 v = make_uint4(0, 0, 0, 0);
-        if (pos < n) v = *reinterpret_cast<const uint4 *>(maxlen + pos);
+        if (pos < n) {
+            const uint32_t *w = base + (pos >> 2);
+            const uint32_t w0 = w[0], w1 = w[1], w2 = w[2], w3 = w[3], w4 = w[4];
+            v = make_uint4(__builtin_amdgcn_alignbyte(w1, w0, sh), __builtin_amdgcn_alignbyte(w2, w1, sh),
+                           __builtin_amdgcn_alignbyte(w3, w2, sh), __builtin_amdgcn_alignbyte(w4, w3, sh));
+        }
         *reinterpret_cast<uint4 *>(dst + i) = v;
     }
 }
@@ -89,7 +98,7 @@ __global__ void k_chain_top(const uint8_t *__restrict__ gexit, const uint32_t *_
 __global__ __launch_bounds__(256) void k_chain_apply(const uint8_t *__restrict__ exitmap, const uint16_t *__restrict__ cnt,
                                                      uint32_t la, uint32_t nsub, uint32_t GC, const uint32_t *__restrict__ gentry,
                                                      const uint32_t *__restrict__ gbase, uint32_t *__restrict__ entry,
-                                                     uint32_t *__restrict__ tbase)
+                                                     uint32_t *__restrict__ tbase, uint32_t *__restrict__ exit_out)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t chain_rows[];
     const uint32_t g = blockIdx.x, s0 = g * GC, s1 = min(s0 + GC, nsub), rows = s1 - s0;
@@ -108,14 +117,14 @@ __global__ __launch_bounds__(256) void k_chain_apply(const uint8_t *__restrict__
         tot += c_l[r * la + cur];
         cur = e_l[r * la + cur];
     }
-    if (s1 == nsub) tbase[nsub] = tot;
+    if (s1 == nsub) { tbase[nsub] = tot; *exit_out = cur; }   /* cur: how far past the end the last token reaches */
 }
 
 /* 16 sub-blocks per workgroup of 64 (their bytes in LDS): lane l < 16 walks one from its true entry */
 #define CHAIN_EMIT_SUBS 16u
 __global__ __launch_bounds__(64) void k_chain_emit(const uint8_t *__restrict__ maxlen, uint32_t n, uint32_t nsub,
                                                    const uint32_t *__restrict__ entry, const uint32_t *__restrict__ tbase,
-                                                   uint32_t *__restrict__ chain)
+                                                   uint32_t *__restrict__ chain, uint32_t pos_off)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t chain_ml[];
     const uint32_t sub0 = blockIdx.x * CHAIN_EMIT_SUBS;
@@ -128,7 +137,7 @@ __global__ __launch_bounds__(64) void k_chain_emit(const uint8_t *__restrict__ m
     const uint8_t *ml = chain_ml + threadIdx.x * CHAIN_SB;
     uint32_t p = entry[sub], k = tbase[sub];
     while (p < end) {
-        chain[k++] = (uint32_t)base + p;
+        chain[k++] = (uint32_t)base + p + pos_off;
         p += (uint32_t)ml[p] + 1u;
     }
 }
@@ -166,9 +175,12 @@ uint32_t lz77k_chain_sub(void) { return CHAIN_SB; }
 
 /* chain[k] = position of token k; *d_tbase -> first-token index of every CHAIN_SB sub-block (nsub + 1
  * words, the last one = ntok), inside d_tmp.  Enqueues only. */
-hipError_t lz77k_chain(const uint8_t *d_maxlen, uint32_t n, int la_i, uint32_t *d_chain, void *d_tmp, hipStream_t s,
-                       const uint32_t **d_tbase, uint32_t *nsub_out)
+hipError_t lz77k_chain(const uint8_t *d_maxlen_all, uint32_t n_all, int la_i, uint32_t *d_chain, void *d_tmp, hipStream_t s,
+                       const uint32_t **d_tbase, uint32_t *nsub_out, uint32_t start, const uint32_t **d_exit)
 {
+    /* the chain begins at position `start`: sub-blocks are counted from there */
+    const uint8_t *d_maxlen = d_maxlen_all + start;
+    const uint32_t n = n_all > start ? n_all - start : 0u;
     const uint32_t la = (uint32_t)la_i;
     const chain_layout L = chain_make_layout(n, la);
     uint8_t *base = reinterpret_cast<uint8_t *>(d_tmp);
@@ -183,7 +195,11 @@ hipError_t lz77k_chain(const uint8_t *d_maxlen, uint32_t n, int la_i, uint32_t *
     uint32_t *total = reinterpret_cast<uint32_t *>(base + L.o_total);
     *d_tbase = tbase;
     *nsub_out = L.nsub;
-    if (n == 0) return hipMemsetAsync(tbase, 0, 4, s);
+    if (d_exit) *d_exit = total + 1;
+    if (n == 0) {
+        hipError_t e0 = hipMemsetAsync(tbase, 0, 4, s);
+        return e0 == hipSuccess ? hipMemsetAsync(total, 0, 8, s) : e0;
+    }
     uint32_t lps = 2;
     while (lps < la) lps <<= 1;
     const uint32_t spw = 256u / lps < 16u ? 256u / lps : 16u;
@@ -205,14 +221,14 @@ hipError_t lz77k_chain(const uint8_t *d_maxlen, uint32_t n, int la_i, uint32_t *
         }
         hipLaunchKernelGGL(k_chain_compose, dim3(L.ng), dim3(256), lds, s, exitmap, cnt, la, L.nsub, L.GC, gexit, gcnt);
         hipLaunchKernelGGL(k_chain_top, dim3(1), dim3(64), 0, s, gexit, gcnt, la, L.ng, gentry, gbase, total);
-        hipLaunchKernelGGL(k_chain_apply, dim3(L.ng), dim3(256), lds, s, exitmap, cnt, la, L.nsub, L.GC, gentry, gbase, entry, tbase);
+        hipLaunchKernelGGL(k_chain_apply, dim3(L.ng), dim3(256), lds, s, exitmap, cnt, la, L.nsub, L.GC, gentry, gbase, entry, tbase, total + 1);
     }
     {
         const size_t lds = (size_t)CHAIN_EMIT_SUBS * CHAIN_SB;
         if ((e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_chain_emit), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)) != hipSuccess)
             return e;
         hipLaunchKernelGGL(k_chain_emit, dim3((L.nsub + CHAIN_EMIT_SUBS - 1u) / CHAIN_EMIT_SUBS), dim3(64), lds, s, d_maxlen, n, L.nsub, entry,
-                           tbase, d_chain);
+                           tbase, d_chain, start);
     }
     return hipGetLastError();
 }

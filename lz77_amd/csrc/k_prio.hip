@@ -94,11 +94,12 @@ __global__ __launch_bounds__(256) void k_prio_prep(const uint32_t *__restrict__ 
     }
 }
 
-/* in[0] = identity: at the start of the input every cell holds its own position */
-__global__ void k_prio_in0(uint32_t *__restrict__ in0, uint32_t sb)
+/* in[0]: at the start of the input every cell holds its own position (+ voff, the value numbering of a
+ * shard); a later segment of a long input starts from the cells its predecessor left behind (carried) */
+__global__ void k_prio_in0(uint32_t *__restrict__ in0, uint32_t sb, uint32_t voff, const uint32_t *__restrict__ carried)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < sb) in0[i] = i;
+    if (i < sb) in0[i] = carried ? carried[i] : i + voff;
 }
 
 /* ------------------------------------------------------------------ forward sweep ---- */
@@ -112,14 +113,16 @@ __global__ __launch_bounds__(64) void k_prio_fwd(const uint32_t *__restrict__ ps
                                                  uint32_t ring_n, uint32_t b_first, const uint64_t *__restrict__ rmask,
                                                  const uint64_t *__restrict__ gold, uint64_t *__restrict__ gnew,
                                                  const uint32_t *__restrict__ in, uint32_t *__restrict__ xval,
-                                                 uint32_t *__restrict__ summary /* [0] += flips, [1] = min block with a flip */)
+                                                 uint32_t *__restrict__ summary /* [0] += flips, [1] = min block with a flip */,
+                                                 uint32_t voff /* a cell's own priority is its position + voff */,
+                                                 uint32_t *__restrict__ out_state /* last block: the sb cells left live after the last step */)
 {
     extern __shared__ uint32_t ring[];
     const uint32_t lane = threadIdx.x;
     const uint32_t b = b_first + blockIdx.x;
     const uint32_t x0 = b * B;
     const uint32_t x1 = nx - x0 < B ? nx : x0 + B;
-    for (uint32_t r = lane; r < ring_n; r += 64) ring[r] = r < sb ? in[(size_t)b * sb + r] : x0 + r;
+    for (uint32_t r = lane; r < ring_n; r += 64) ring[r] = r < sb ? in[(size_t)b * sb + r] : x0 + r + voff;
     uint64_t *gl = reinterpret_cast<uint64_t *>(ring + ring_n);      /* the block's new gates: B/64 words (ring_n is even) */
     wave_sync();
 
@@ -180,7 +183,7 @@ __global__ __launch_bounds__(64) void k_prio_fwd(const uint32_t *__restrict__ ps
                 /* cell xg+64+sb+lane becomes live with the next group; its slot held cell xg+lane */
                 uint32_t fi = off + lane;                             /* (off + 64 + sb_r + lane) mod ring_n, ring_n = sb_r + 64 */
                 fi -= fi >= ring_n ? ring_n : 0u;
-                ring[fi] = xg + ring_n + lane;
+                if (x < x1) ring[fi] = xg + ring_n + lane + voff;  /* (the lanes past the last step keep their cells: out_state) */
                 off += 64u;
                 off -= off >= ring_n ? ring_n : 0u;
                 wave_sync();
@@ -194,6 +197,11 @@ __global__ __launch_bounds__(64) void k_prio_fwd(const uint32_t *__restrict__ ps
     }
     wave_sync();
     for (uint32_t i = lane; i < (x1 - x0 + 63u) / 64u; i += 64) gnew[(x0 >> 6) + i] = gl[i];
+    if (out_state && x1 == nx) {
+        /* cells nx .. nx+sb-1, what the next segment of a long input starts from: the ring now holds exactly
+         * the cells [x1, x1 + ring_n) */
+        for (uint32_t i = lane; i < sb; i += 64) out_state[i] = ring[(x1 - x0 + i) % ring_n];
+    }
     if (lane == 0 && nflip) {
         atomicAdd(&summary[0], nflip);
         atomicMin(&summary[1], b);
@@ -207,7 +215,8 @@ __global__ __launch_bounds__(64) void k_prio_fwd(const uint32_t *__restrict__ ps
  * the block whose chain reaches exit cell d (what arrives there when nothing older comes in). */
 __global__ __launch_bounds__(64) void k_prio_back(const uint32_t *__restrict__ ps, uint32_t nx, uint32_t sb, uint32_t B,
                                                   uint32_t ring_n, uint32_t b_first, const uint64_t *__restrict__ gates,
-                                                  uint16_t *__restrict__ dest, uint32_t *__restrict__ loc)
+                                                  uint16_t *__restrict__ dest, uint32_t *__restrict__ loc, uint32_t voff,
+                                                  uint32_t ncarried /* cells < ncarried hold carried values, not their own position */)
 {
     extern __shared__ uint32_t back_lds[];
     uint32_t *lloc = back_lds;                                         /* sb_r words */
@@ -216,7 +225,7 @@ __global__ __launch_bounds__(64) void k_prio_back(const uint32_t *__restrict__ p
     const uint32_t b = b_first + blockIdx.x;
     const uint32_t x0 = b * B;
     const uint32_t x1 = nx - x0 < B ? nx : x0 + B;
-    for (uint32_t i = lane; i < sb; i += 64) lloc[i] = x1 + i;
+    for (uint32_t i = lane; i < sb; i += 64) lloc[i] = x1 + i + voff;
     for (uint32_t i = lane; i < ring_n; i += 64) dr[i] = PRIO_DEAD;
     wave_sync();
     const uint32_t nsg = (x1 - x0 + 64u * PRIO_SG - 1u) / (64u * PRIO_SG);
@@ -273,7 +282,9 @@ __global__ __launch_bounds__(64) void k_prio_back(const uint32_t *__restrict__ p
                     uint32_t ix = off + lane;
                     ix -= ix >= ring_n ? ring_n : 0u;
                     dr[ix] = (uint16_t)d;
-                    if (d != PRIO_DEAD) atomicMin(&lloc[d], x);
+                    /* x's own priority reaches d -- unless x is a carried cell of a later segment: its value
+                     * comes in through in[0] (a rank that need not be below its local position) */
+                    if (d != PRIO_DEAD && x >= ncarried) atomicMin(&lloc[d], x + voff);
                 }
                 wave_sync();
             }
@@ -466,12 +477,16 @@ int lz77k_prio_supported(int sb) { return sb >= 1 && sb <= 4096; }
 /* xval[x] for x < nx from ps[] (distances P | S << 16).  h_flag: 8 bytes of pinned host memory.  Returns
  * hipSuccess with *converged = 0 when max_iters did not suffice (the caller then takes the host path). */
 hipError_t lz77k_prio(const uint32_t *d_ps, uint32_t nx, int sb_i, uint32_t *d_xval, void *d_tmp, hipStream_t s,
-                      uint32_t *h_flag, int max_iters, int *iters, int *converged, hipEvent_t *ev4, float *ms3)
+                      uint32_t *h_flag, int max_iters, int *iters, int *converged, hipEvent_t *ev4, float *ms3,
+                      uint32_t voff, const uint32_t *d_carried, uint32_t *d_out_state)
 {
     *iters = 0;
     *converged = 1;
-    if (nx == 0) return hipSuccess;
     const uint32_t sb = (uint32_t)sb_i;
+    if (nx == 0) {
+        if (d_out_state) hipLaunchKernelGGL(k_prio_in0, dim3((sb + 255u) / 256u), dim3(256), 0, s, d_out_state, sb, voff, d_carried);
+        return hipGetLastError();
+    }
     const prio_layout L = prio_make_layout(nx, sb);
     uint8_t *base = reinterpret_cast<uint8_t *>(d_tmp);
     uint64_t *gate[2] = {reinterpret_cast<uint64_t *>(base + L.o_gate[0]), reinterpret_cast<uint64_t *>(base + L.o_gate[1])};
@@ -493,7 +508,7 @@ hipError_t lz77k_prio(const uint32_t *d_ps, uint32_t nx, int sb_i, uint32_t *d_x
             return e;
         const uint32_t blocks = min((L.ngroups + 3u) / 4u, 256u * 8u);
         hipLaunchKernelGGL(k_prio_prep, dim3(blocks), dim3(256), lds, s, d_ps, nx, tagn, rmask, gate[0]);
-        hipLaunchKernelGGL(k_prio_in0, dim3((sb + 255u) / 256u), dim3(256), 0, s, in, sb);
+        hipLaunchKernelGGL(k_prio_in0, dim3((sb + 255u) / 256u), dim3(256), 0, s, in, sb, voff, d_carried);
     }
     const size_t lds_fwd = (size_t)L.ring_n * 4 + (size_t)(L.B / 64u) * 8;
     const size_t lds_back = (size_t)L.sb_r * 4 + (size_t)L.ring_n * 2;
@@ -505,7 +520,7 @@ hipError_t lz77k_prio(const uint32_t *d_ps, uint32_t nx, int sb_i, uint32_t *d_x
         const uint32_t nb = L.NB - first;
         hipLaunchKernelGGL(k_prio_reset, dim3(1), dim3(1), 0, s, summary);
         if (ev4 && (e = hipEventRecord(ev4[0], s)) != hipSuccess) return e;
-        hipLaunchKernelGGL(k_prio_back, dim3(nb), dim3(64), lds_back, s, d_ps, nx, sb, L.B, L.ring_n, first, gate[cur], dest, loc);
+        hipLaunchKernelGGL(k_prio_back, dim3(nb), dim3(64), lds_back, s, d_ps, nx, sb, L.B, L.ring_n, first, gate[cur], dest, loc, voff, d_carried ? sb : 0u);
         if (ev4 && (e = hipEventRecord(ev4[1], s)) != hipSuccess) return e;
         if (nb > 1) {
             /* maps first .. NB-2; in[first] is final (it = 0: identity) */
@@ -527,7 +542,7 @@ hipError_t lz77k_prio(const uint32_t *d_ps, uint32_t nx, int sb_i, uint32_t *d_x
         }
         if (ev4 && (e = hipEventRecord(ev4[2], s)) != hipSuccess) return e;
         hipLaunchKernelGGL(k_prio_fwd<true>, dim3(nb), dim3(64), lds_fwd, s, d_ps, nx, sb, L.B, L.ring_n, first, rmask, gate[cur], gate[cur ^ 1],
-                           in, d_xval, summary);
+                           in, d_xval, summary, voff, d_out_state);
         if (ev4 && (e = hipEventRecord(ev4[3], s)) != hipSuccess) return e;
         if ((e = hipMemcpyAsync(h_flag, summary, 8, hipMemcpyDeviceToHost, s)) != hipSuccess) return e;
         if ((e = hipStreamSynchronize(s)) != hipSuccess) return e;

@@ -75,7 +75,8 @@ __global__ __launch_bounds__(256) void k_tokens(const uint8_t *__restrict__ in, 
                                                 const uint32_t *__restrict__ chain, uint32_t ntok,
                                                 const uint8_t *__restrict__ maxlen,
                                                 const uint32_t *__restrict__ ofs, const uint2 *__restrict__ ent, uint32_t dbase,
-                                                uint32_t *__restrict__ tokval)
+                                                uint32_t *__restrict__ tokval, const uint32_t *__restrict__ look, uint32_t nlook,
+                                                uint32_t voff)
 {
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t k = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
@@ -101,7 +102,7 @@ __global__ __launch_bounds__(256) void k_tokens(const uint8_t *__restrict__ in, 
                 if (x) { same = false; break; }
             }
             if (!same) continue;
-            uint32_t prio = c;
+            uint32_t prio = c < nlook ? look[c] : c + voff;         /* a cell's own priority, or what it held when this segment began */
             const uint32_t lo = c > dbase ? ofs[c - dbase - 1] : 0, hi = c >= dbase ? ofs[c - dbase] : 0;
             uint32_t latest = 0;
             bool any = false;
@@ -165,7 +166,8 @@ __global__ __launch_bounds__(TOK_BLOCK) void k_tokens_tile(const uint8_t *__rest
                                                            const uint32_t *__restrict__ ofs, const uint2 *__restrict__ ent,
                                                            uint32_t dbase, uint32_t pos0, uint32_t pos1,
                                                            uint32_t *__restrict__ tokval, uint32_t ent_cap, uint32_t lofs_off,
-                                                           uint32_t lent_off, uint32_t bkt_off)
+                                                           uint32_t lent_off, uint32_t bkt_off, const uint32_t *__restrict__ look,
+                                                           uint32_t nlook, uint32_t voff)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     uint8_t *by = smem;
@@ -279,7 +281,7 @@ __global__ __launch_bounds__(TOK_BLOCK) void k_tokens_tile(const uint8_t *__rest
                         if (rem < 4) x &= (1u << (8 * rem)) - 1u;
                         if (x) return;
                     }
-                    uint32_t prio = c, latest = 0;
+                    uint32_t prio = c < nlook ? look[c] : c + voff, latest = 0;
                     bool any = false;
                     if (staged) {
                         for (uint32_t e = lofs[co]; e < lofs[co + 1]; e++) {
@@ -412,7 +414,8 @@ __global__ __launch_bounds__(256) void k_tokens_big(const uint8_t *__restrict__ 
                                                     const uint8_t *__restrict__ maxlen,
                                                     const uint32_t *__restrict__ ofs, const uint2 *__restrict__ ent, uint32_t dbase,
                                                     uint32_t pos0, const uint32_t *__restrict__ bs, const uint32_t *__restrict__ blist,
-                                                    uint32_t span, uint32_t *__restrict__ tokval)
+                                                    uint32_t span, uint32_t *__restrict__ tokval, const uint32_t *__restrict__ look,
+                                                    uint32_t nlook, uint32_t voff)
 {
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t k = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
@@ -443,7 +446,7 @@ __global__ __launch_bounds__(256) void k_tokens_big(const uint8_t *__restrict__ 
                 if (x) { same = false; break; }
             }
             if (!same) continue;
-            uint32_t prio = c, latest = 0;
+            uint32_t prio = c < nlook ? look[c] : c + voff, latest = 0;
             bool any = false;
             const uint32_t lo = c > dbase ? ofs[c - dbase - 1] : 0, hi = c >= dbase ? ofs[c - dbase] : 0;
             for (uint32_t e = lo; e < hi; e++) {
@@ -478,7 +481,8 @@ __global__ __launch_bounds__(256) void k_tokens_rank(const uint8_t *__restrict__
                                                      uint32_t RP, uint32_t TILE, const uint32_t *__restrict__ ranks_all,
                                                      const uint32_t *__restrict__ chain, uint32_t ntok,
                                                      const uint8_t *__restrict__ maxlen, const uint32_t *__restrict__ ofs,
-                                                     const uint2 *__restrict__ ent, uint32_t dbase, uint32_t *__restrict__ tokval)
+                                                     const uint2 *__restrict__ ent, uint32_t dbase, uint32_t *__restrict__ tokval,
+                                                     const uint32_t *__restrict__ look, uint32_t nlook, uint32_t voff)
 {
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t k = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
@@ -512,7 +516,7 @@ __global__ __launch_bounds__(256) void k_tokens_rank(const uint8_t *__restrict__
         };
         auto consider = [&](uint32_t e) {                                /* candidate at local index e: its priority at time p */
             const uint32_t c = t0 + e;
-            uint32_t prio = c, latest = 0;
+            uint32_t prio = c < nlook ? look[c] : c + voff, latest = 0;
             bool any = false;
             const uint32_t lo = c > dbase ? ofs[c - dbase - 1] : 0, hi = c >= dbase ? ofs[c - dbase] : 0;
             for (uint32_t i = lo; i < hi; i++) {
@@ -614,14 +618,14 @@ size_t lz77k_tokens_tmp_bytes(uint32_t n) { return ((size_t)(n / TOK_TILE) + 8) 
 hipError_t lz77k_tokens(const uint8_t *d_in, uint32_t n, const lz77x_geom &g, const uint32_t *d_chain, uint32_t ntok,
                         const uint8_t *d_maxlen, const uint32_t *d_ofs, const uint2 *d_ent, uint32_t dbase,
                         uint32_t pos0, uint32_t pos1, uint32_t *d_tokval, uint32_t *d_tstart, void *d_index, int variant,
-                        hipStream_t s, hipEvent_t *ev_tie, const uint32_t *d_ranks_all)
+                        hipStream_t s, hipEvent_t *ev_tie, const uint32_t *d_ranks_all, const uint32_t *d_look, uint32_t nlook, uint32_t voff)
 {
     if (ntok == 0) return hipSuccess;
 #define TIE_EV(i) do { if (ev_tie) { hipError_t ee_ = hipEventRecord(ev_tie[i], s); if (ee_ != hipSuccess) return ee_; } } while (0)
     if (variant == 0 && !g.fast && d_ranks_all) {
         TIE_EV(0);
         hipLaunchKernelGGL(k_tokens_rank, dim3((ntok + 3) / 4), dim3(256), 0, s, d_in, n, g.sb, g.ob, g.lb, g.RP, g.TILE, d_ranks_all,
-                           d_chain, ntok, d_maxlen, d_ofs, d_ent, dbase, d_tokval);
+                           d_chain, ntok, d_maxlen, d_ofs, d_ent, dbase, d_tokval, d_look, nlook, voff);
         TIE_EV(1);
         return hipGetLastError();
     }
@@ -638,7 +642,7 @@ hipError_t lz77k_tokens(const uint8_t *d_in, uint32_t n, const lz77x_geom &g, co
         hipLaunchKernelGGL(k_bidx_fill, grid, dim3(256), 0, s, d_in, g.sb, pos0, pos1, bs, blist, span);
         TIE_EV(0);
         hipLaunchKernelGGL(k_tokens_big, dim3((ntok + 3) / 4), dim3(256), 0, s, d_in, n, g.sb, g.ob, g.lb, d_chain, ntok, d_maxlen,
-                           d_ofs, d_ent, dbase, pos0, bs, blist, span, d_tokval);
+                           d_ofs, d_ent, dbase, pos0, bs, blist, span, d_tokval, d_look, nlook, voff);
         TIE_EV(1);
         return hipGetLastError();
     }
@@ -665,14 +669,14 @@ hipError_t lz77k_tokens(const uint8_t *d_in, uint32_t n, const lz77x_geom &g, co
         hipLaunchKernelGGL(k_tok_bounds, dim3((ntok + 256) / 256), dim3(256), 0, s, d_chain, ntok, pos0, ntiles, d_tstart);
         TIE_EV(0);
         hipLaunchKernelGGL(fn, dim3(ntiles), dim3(TOK_BLOCK), lds, s, d_in, n, g.sb, g.la, g.ob, g.lb, d_chain,
-                           d_tstart, d_maxlen, d_ofs, d_ent, dbase, pos0, pos1, d_tokval, ent_cap, lofs_off, lent_off, bkt_off);
+                           d_tstart, d_maxlen, d_ofs, d_ent, dbase, pos0, pos1, d_tokval, ent_cap, lofs_off, lent_off, bkt_off, d_look, nlook, voff);
         TIE_EV(1);
         return hipGetLastError();
     }
     const uint32_t blocks = (ntok + 3) / 4;
     TIE_EV(0);
     hipLaunchKernelGGL(k_tokens, dim3(blocks), dim3(256), 0, s, d_in, n, g.sb, g.ob, g.lb, d_chain, ntok, d_maxlen, d_ofs, d_ent,
-                       dbase, d_tokval);
+                       dbase, d_tokval, d_look, nlook, voff);
     TIE_EV(1);
     return hipGetLastError();
 #undef TIE_EV
@@ -681,30 +685,40 @@ hipError_t lz77k_tokens(const uint8_t *d_in, uint32_t n, const lz77x_geom &g, co
 /* ------------------------------------------------------------------ k_pack ----------- */
 
 /* bitio.c:203-239 without the per-bit loop: token k occupies stream bits [32+kT, 32+(k+1)T);
- * stream bit b is bit (b & 31) of little-endian word b >> 5.  One thread assembles one word. */
-__global__ void k_pack(const uint32_t *__restrict__ tokval, uint64_t ntok, int sb, int la, int T,
-                       uint32_t *__restrict__ out, uint64_t nwords)
+ * stream bit b is bit (b & 31) of little-endian word b >> 5.  One thread assembles one word.
+ * General form: the words [w0, w0+nw) of the stream from the tokens [k_first, k_end) (tokval[0] is token
+ * k_first): a segment of a long input packs the words its own tokens START in, and carries up to four
+ * tokens of its predecessor in front of its own so that its first word is complete. */
+__global__ void k_pack(const uint32_t *__restrict__ tokval, uint64_t k_first, uint64_t k_end, int sb, int la, int T,
+                       uint32_t *__restrict__ out, uint64_t w0, uint64_t nw)
 {
-    const uint64_t w = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (w >= nwords) return;
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nw) return;
+    const uint64_t w = w0 + i;
     if (w == 0) { out[0] = (uint32_t)sb | ((uint32_t)la << 16); return; }      /* lz77.c:74-75 */
     const uint64_t b0 = 32 * (w - 1);                     /* first token-area bit of this word */
     uint64_t k = b0 / (uint64_t)T;
+    if (k < k_first) k = k_first;                         /* (never needed when the carried tokens are there) */
     uint32_t word = 0;
-    for (; k < ntok; k++) {
+    for (; k < k_end; k++) {
         const int64_t sh = (int64_t)(k * (uint64_t)T) - (int64_t)b0;
         if (sh >= 32) break;
-        const uint32_t v = tokval[k];
+        const uint32_t v = tokval[k - k_first];
         word |= sh >= 0 ? (v << sh) : (v >> (-sh));
     }
-    out[w] = word;
+    out[i] = word;
+}
+
+hipError_t lz77k_pack_range(const uint32_t *d_tokval, uint64_t k_first, uint64_t k_end, const lz77x_geom &g, uint32_t *d_out_words,
+                            uint64_t w0, uint64_t nw, hipStream_t s)
+{
+    if (nw == 0) return hipSuccess;
+    const uint32_t blocks = (uint32_t)((nw + 255) / 256);
+    hipLaunchKernelGGL(k_pack, dim3(blocks), dim3(256), 0, s, d_tokval, k_first, k_end, g.sb, g.la, g.T, d_out_words, w0, nw);
+    return hipGetLastError();
 }
 
 hipError_t lz77k_pack(const uint32_t *d_tokval, uint64_t ntok, const lz77x_geom &g, uint32_t *d_out_words, uint64_t nwords, hipStream_t s)
 {
-    if (nwords == 0) return hipSuccess;
-    const uint32_t blocks = (uint32_t)((nwords + 255) / 256);
-    hipLaunchKernelGGL(k_pack, dim3(blocks), dim3(256), 0, s, d_tokval, ntok, g.sb, g.la, g.T, d_out_words, nwords);
-    return hipGetLastError();
+    return lz77k_pack_range(d_tokval, 0, ntok, g, d_out_words, 0, nwords, s);
 }
-

@@ -114,7 +114,10 @@ int lz77k_prio_supported(int sb);
 hipError_t lz77k_prio(const uint32_t *d_ps, uint32_t nx, int sb, uint32_t *d_xval, void *d_tmp, hipStream_t s,
                       uint32_t *h_flag, int max_iters, int *iters, int *converged,
                       hipEvent_t *ev4 = nullptr /* four events: per-kernel times are added to ms3 */,
-                      float *ms3 = nullptr /* += forward sweeps, backward sweeps, boundary scans */);
+                      float *ms3 = nullptr /* += forward sweeps, backward sweeps, boundary scans */,
+                      uint32_t voff = 0 /* a cell's own priority = its position + voff */,
+                      const uint32_t *d_carried = nullptr /* sb values of cells 0..sb-1 before step 0 (else: their own) */,
+                      uint32_t *d_out_state = nullptr /* sb values of cells nx..nx+sb-1 after the last step */);
 
 /* The greedy parse chain (lz77.c:89-98) on the device: chain[k] = position of token k.  *d_tbase points
  * (inside d_tmp) at the index of the first token of every lz77k_chain_sub()-position sub-block, nsub + 1
@@ -122,7 +125,9 @@ hipError_t lz77k_prio(const uint32_t *d_ps, uint32_t nx, int sb, uint32_t *d_xva
 size_t lz77k_chain_tmp_bytes(uint32_t n, int la);
 uint32_t lz77k_chain_sub(void);
 hipError_t lz77k_chain(const uint8_t *d_maxlen, uint32_t n, int la, uint32_t *d_chain, void *d_tmp, hipStream_t s,
-                       const uint32_t **d_tbase, uint32_t *nsub);
+                       const uint32_t **d_tbase, uint32_t *nsub,
+                       uint32_t start = 0 /* the chain begins here; sub-blocks are counted from it */,
+                       const uint32_t **d_exit = nullptr /* -> how far past n the last token reaches (device word) */);
 
 /* *d_out = 64-bit sum of m uint32 */
 hipError_t lz77k_sum_u32(const uint32_t *d_in, uint32_t m, unsigned long long *d_out, hipStream_t s);
@@ -148,11 +153,17 @@ hipError_t lz77k_tokens(const uint8_t *d_in, uint32_t n, const lz77x_geom &g,
                         uint32_t pos0, uint32_t pos1, uint32_t *d_tokval,
                         uint32_t *d_tstart, void *d_index, int variant, hipStream_t s,
                         hipEvent_t *ev_tie = nullptr /* [2]: recorded around the tie-break kernel */,
-                        const uint32_t *d_ranks_all = nullptr /* large windows: the regions' rank + inverse arrays */);
+                        const uint32_t *d_ranks_all = nullptr /* large windows: the regions' rank + inverse arrays */,
+                        const uint32_t *d_look = nullptr, uint32_t nlook = 0 /* positions < nlook start with priority d_look[c] (a later
+                                                                                  segment's look-back) */,
+                        uint32_t voff = 0 /* a position's own priority = position + voff */);
 
 /* words [w0, w0+nw) of the output stream (word 0 = header) from tokval[0..ntok) */
 hipError_t lz77k_pack(const uint32_t *d_tokval, uint64_t ntok, const lz77x_geom &g,
                       uint32_t *d_out_words, uint64_t nwords, hipStream_t s);
+/* words [w0, w0+nw) from the tokens [k_first, k_end), d_tokval[0] = token k_first, d_out_words[0] = word w0 */
+hipError_t lz77k_pack_range(const uint32_t *d_tokval, uint64_t k_first, uint64_t k_end, const lz77x_geom &g, uint32_t *d_out_words,
+                            uint64_t w0, uint64_t nw, hipStream_t s);
 
 hipError_t lz77k_dec_parse(const uint8_t *d_z, uint32_t ntok, const lz77x_geom &g,
                            uint32_t *d_tokval, uint32_t *d_len1, hipStream_t s);

@@ -24,6 +24,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <algorithm>
 #include <atomic>
 #include <condition_variable>
 #include <mutex>
@@ -134,13 +135,13 @@ struct Ctx {
     hipEvent_t ev[6] = {};
     std::vector<hipEvent_t> chunk_ev, tok_ev, sort_ev, match_ev, tie_ev;
     DevBuf in, ps, maxlen, scratch, xval, chain, ofs, ent, tokval, out, scantmp;
-    DevBuf z, len1, dst, ptr, flag, tstart, bidx, cells, ranks_all, prio_tmp, chain_tmp;
+    DevBuf z, len1, dst, ptr, flag, tstart, bidx, cells, ranks_all, prio_tmp, chain_tmp, look;
     PinBuf h_ps, h_maxlen, h_xval, h_chain, h_small, h_tok, h_stage, h_tbase;
     /* every cached buffer, so that no release path can forget one */
     std::vector<DevBuf *> dev_bufs()
     {
         return {&in, &ps, &maxlen, &scratch, &xval, &chain, &ofs, &ent, &tokval, &out, &scantmp, &z, &len1, &dst, &ptr,
-                &flag, &tstart, &bidx, &cells, &ranks_all, &prio_tmp, &chain_tmp};
+                &flag, &tstart, &bidx, &cells, &ranks_all, &prio_tmp, &chain_tmp, &look};
     }
     std::vector<PinBuf *> pin_bufs() { return {&h_ps, &h_maxlen, &h_xval, &h_chain, &h_small, &h_tok, &h_stage, &h_tbase}; }
 };
@@ -773,230 +774,6 @@ int encode_core_host(std::vector<Ctx *> &cs, const void *src, bool src_on_device
     return LZ77X_OK;
 }
 
-/* The device-resident encode: nothing but the stream leaves the GPU.
- *     match (all regions) -> parse chain (k_chain) | priority recurrence (k_prio: gate iteration)
- *           -> per token chunk: hand-over index + tie-break -> pack
- * One device, sb <= 4096.  The host only launches, and reads back one 8-byte convergence word per gate
- * iteration and the sub-blocks' first-token indices (to cut the token work into chunks).  When the
- * gate iteration does not converge within its budget *fallback is set and nothing has been emitted:
- * the caller runs the host-stage pipeline (encode_core_host) instead. */
-int encode_core_device(Ctx &c, const void *src, bool src_on_device, size_t n, const lz77x_geom &g, hipStream_t s, size_t *zn,
-                       bool *fallback)
-{
-    const double t_begin = now_ms();
-    memset(&g_stats, 0, sizeof g_stats);
-    *fallback = false;
-    if (n > LZ77X_MAX_N) return LZ77X_E_TOOBIG;
-    const uint32_t n32 = (uint32_t)n;
-    int rc;
-    double waited = 0;
-    HIPCHK(hipSetDevice(c.device));
-    if ((rc = c.in.need(n + LZ77X_PAD + 16))) return rc;
-    if (n && src != c.in.p)
-        HIPCHK(hipMemcpyAsync(c.in.p, src, n, src_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, s));
-    HIPCHK(lz77k_fill_pad(c.in.as<uint8_t>(), n32, s));
-    uint32_t ntok = 0;
-    uint64_t transfers = 0;
-    uint32_t launches = 0, nchunks = 0;
-    std::vector<char> tie_timed;
-    if (n) {
-        const size_t usb = (size_t)g.sb;
-        const size_t nx = n > usb ? n - usb : 0;
-        const uint32_t nregions = (uint32_t)((n + g.TILE - 1) / g.TILE);
-        /* match launches: as many regions as the scratch budget allows */
-        uint32_t batch = nregions;
-        {
-            const size_t per = lz77k_match_scratch_bytes(g, 1);
-            const uint32_t fit = (uint32_t)(((size_t)2 << 30) / per);
-            if (batch > fit) batch = fit ? fit : 1;
-            const char *gs = getenv("LZ77X_MATCH_BATCH");
-            if (gs && atoi(gs) > 0 && (uint32_t)atoi(gs) < batch) batch = (uint32_t)atoi(gs);
-        }
-        /* token chunks: up to 128M positions (one hand-over index and one tie-break launch each; the index
-         * costs 12 bytes of scratch per position), a multiple of the chain sub-block */
-        const uint32_t csub = lz77k_chain_sub();
-        size_t chunk_pos = (size_t)128 << 20;
-        {
-            const char *ce = getenv("LZ77X_TOKEN_CHUNK");
-            if (ce && atoi(ce) > 0) chunk_pos = (size_t)atoi(ce);
-            chunk_pos = (chunk_pos + csub - 1) / csub * csub;
-        }
-        nchunks = (uint32_t)((n + chunk_pos - 1) / chunk_pos);
-        const size_t idx_span = (chunk_pos < n ? chunk_pos : n) + 2 * usb + 16;
-        const char *tv = getenv("LZ77X_TOKEN_VARIANT");
-        const int tvariant = tv ? atoi(tv) : 0;
-
-        if ((rc = c.scratch.need(lz77k_match_scratch_bytes(g, batch)))) return rc;
-        if ((rc = c.ps.need((n + 8) * 4))) return rc;
-        if ((rc = c.maxlen.need(n + 64))) return rc;
-        if ((rc = c.xval.need((n + 8) * 4))) return rc;
-        if ((rc = c.chain.need((n + 8) * 4))) return rc;
-        if ((rc = c.tokval.need((n + 8) * 4))) return rc;
-        if ((rc = c.ofs.need((idx_span + 8) * 4))) return rc;
-        if ((rc = c.ent.need((idx_span + 8) * 8))) return rc;
-        if ((rc = c.scantmp.need(lz77k_scan_tmp_bytes((uint32_t)idx_span + 1)))) return rc;
-        if ((rc = c.tstart.need(lz77k_tokens_tmp_bytes((uint32_t)idx_span)))) return rc;
-        if ((rc = c.flag.need(64))) return rc;
-        if ((rc = c.prio_tmp.need(lz77k_prio_tmp_bytes((uint32_t)nx, g.sb)))) return rc;
-        if ((rc = c.chain_tmp.need(lz77k_chain_tmp_bytes(n32, g.la)))) return rc;
-        if ((rc = c.h_small.need(64))) return rc;
-        const uint32_t nsub_max = (uint32_t)((n + csub - 1) / csub);
-        if ((rc = c.h_tbase.need(((size_t)nsub_max + 2) * 4))) return rc;
-        HIPCHK(hipMemsetAsync(c.flag.p, 0, 64, s));
-        const uint32_t nlaunch = (nregions + batch - 1) / batch;
-        while (c.sort_ev.size() < 3 * (size_t)nlaunch) {
-            hipEvent_t e;
-            HIPCHK(hipEventCreate(&e));
-            c.sort_ev.push_back(e);
-        }
-        while (c.tie_ev.size() < 2 * (size_t)nchunks + 8) {
-            hipEvent_t e;
-            HIPCHK(hipEventCreate(&e));
-            c.tie_ev.push_back(e);
-        }
-        while (c.match_ev.size() < 8) {
-            hipEvent_t e;
-            HIPCHK(hipEventCreate(&e));
-            c.match_ev.push_back(e);
-        }
-
-        /* -- match stage (replaces tree.c insert/delete/find): ps[], maxlen[] for every position -- */
-        HIPCHK(hipEventRecord(c.ev[0], s));
-        for (uint32_t r0 = 0; r0 < nregions; r0 += batch) {
-            const uint32_t nr = nregions - r0 < batch ? nregions - r0 : batch;
-            HIPCHK(lz77k_match(c.in.as<uint8_t>(), n32, g, r0, nr, c.ps.as<uint32_t>(), c.maxlen.as<uint8_t>(), c.scratch.p, 0, s,
-                               &c.sort_ev[3 * launches], nullptr));
-            launches++;
-        }
-        HIPCHK(hipEventRecord(c.ev[1], s));
-        g_stats.match_launches = launches;
-
-        /* -- parse chain (lz77.c:98) -- */
-        const uint32_t *d_tbase = nullptr;
-        uint32_t nsub = 0;
-        HIPCHK(hipEventRecord(c.match_ev[0], s));
-        HIPCHK(lz77k_chain(c.maxlen.as<uint8_t>(), n32, g.la, c.chain.as<uint32_t>(), c.chain_tmp.p, s, &d_tbase, &nsub));
-        HIPCHK(hipEventRecord(c.match_ev[1], s));
-        uint32_t *h_tbase = c.h_tbase.as<uint32_t>();
-        HIPCHK(hipMemcpyAsync(h_tbase, d_tbase, ((size_t)nsub + 1) * 4, hipMemcpyDeviceToHost, s));
-
-        /* -- priority recurrence (tree.c:202-231) -- */
-        int iters = 0, converged = 1;
-        int max_iters = 96;
-        {
-            const char *me = getenv("LZ77X_PRIO_MAX_ITERS");
-            if (me && atoi(me) > 0) max_iters = atoi(me);
-        }
-        HIPCHK(hipEventRecord(c.match_ev[2], s));
-        const double tw0 = now_ms();
-        float prio_ms3[3] = {0, 0, 0};
-        HIPCHK(lz77k_prio(c.ps.as<uint32_t>(), (uint32_t)nx, g.sb, c.xval.as<uint32_t>(), c.prio_tmp.p, s, c.h_small.as<uint32_t>() + 8,
-                          max_iters, &iters, &converged, &c.match_ev[4], prio_ms3));
-        HIPCHK(hipEventRecord(c.match_ev[3], s));
-        g_stats.k_prio_fwd_ms = prio_ms3[0];
-        g_stats.k_prio_back_ms = prio_ms3[1];
-        g_stats.k_prio_scan_ms = prio_ms3[2];
-        HIPCHK(hipStreamSynchronize(s));                       /* tbase has landed (nx == 0: the recurrence did not sync) */
-        waited += now_ms() - tw0;
-        g_stats.prio_iters = (uint32_t)iters;
-        if (!converged) {
-            *fallback = true;
-            return LZ77X_OK;
-        }
-        ntok = h_tbase[nsub];
-        TRACE("match + chain + recurrence", t_begin);
-
-        /* -- tokens: per chunk, the hand-over index of the evictions that can matter and the tie-break -- */
-        tie_timed.assign(nchunks, 0);
-        HIPCHK(hipEventRecord(c.ev[2], s));
-        for (uint32_t ci = 0; ci < nchunks; ci++) {
-            const size_t b = (size_t)ci * chunk_pos, e = b + chunk_pos < n ? b + chunk_pos : n;
-            const uint32_t ta = h_tbase[b / csub], tb = e == n ? ntok : h_tbase[e / csub];
-            const size_t x_done = e > usb ? e - usb : 0;
-            const uint32_t dbase = b > usb ? (uint32_t)(b - usb) : 0u;
-            const uint32_t xa = dbase > (uint32_t)g.sb ? dbase - (uint32_t)g.sb : 0u;
-            const size_t x_new = b > usb ? b - usb : 0;
-            HIPCHK(lz77k_xfer_index(c.ps.as<uint32_t>(), c.xval.as<uint32_t>(), xa, (uint32_t)x_done, dbase, (uint32_t)e, c.ofs.as<uint32_t>(),
-                                    c.ent.as<uint2>(), c.scantmp.p, s, (uint32_t)x_new, c.flag.as<unsigned long long>() + 1));
-            HIPCHK(lz77k_tokens(c.in.as<uint8_t>(), n32, g, c.chain.as<uint32_t>() + ta, tb - ta, c.maxlen.as<uint8_t>(), c.ofs.as<uint32_t>(),
-                                c.ent.as<uint2>(), dbase, (uint32_t)b, (uint32_t)e, c.tokval.as<uint32_t>() + ta, c.tstart.as<uint32_t>(), nullptr,
-                                tvariant, s, &c.tie_ev[2 * ci], nullptr));
-            tie_timed[ci] = tb > ta;
-        }
-        HIPCHK(hipMemcpyAsync(c.h_small.as<unsigned long long>() + 2, c.flag.as<unsigned long long>() + 1, 8, hipMemcpyDeviceToHost, s));
-    } else {
-        if ((rc = c.tokval.need(64))) return rc;
-        HIPCHK(hipEventRecord(c.ev[0], s));
-        HIPCHK(hipEventRecord(c.ev[1], s));
-        HIPCHK(hipEventRecord(c.ev[2], s));
-    }
-    *zn = stream_bytes(ntok, g.T);
-    const uint64_t nwords = (*zn + 3) / 4;
-    if ((rc = c.out.need(nwords * 4 + 16))) return rc;
-    HIPCHK(lz77k_pack(c.tokval.as<uint32_t>(), ntok, g, c.out.as<uint32_t>(), nwords, s));
-    HIPCHK(hipEventRecord(c.ev[3], s));
-    const double tw = now_ms();
-    HIPCHK(hipStreamSynchronize(s));
-    waited += now_ms() - tw;
-    if (n) transfers = c.h_small.as<unsigned long long>()[2];
-
-    float ms = 0;
-    HIPCHK(hipEventElapsedTime(&ms, c.ev[0], c.ev[1]));
-    g_stats.k_match_ms = ms;
-    HIPCHK(hipEventElapsedTime(&ms, c.ev[2], c.ev[3]));
-    g_stats.k_token_ms = ms;
-    if (n) {
-        HIPCHK(hipEventElapsedTime(&ms, c.match_ev[0], c.match_ev[1]));
-        g_stats.k_chain_ms = ms;
-        HIPCHK(hipEventElapsedTime(&ms, c.match_ev[2], c.match_ev[3]));
-        g_stats.k_prio_ms = ms;
-        double sort_ms = 0, walk_ms = 0, tie_ms = 0;
-        for (uint32_t i = 0; i < launches; i++) {
-            HIPCHK(hipEventElapsedTime(&ms, c.sort_ev[3 * i], c.sort_ev[3 * i + 1]));
-            sort_ms += ms;
-            HIPCHK(hipEventElapsedTime(&ms, c.sort_ev[3 * i + 1], c.sort_ev[3 * i + 2]));
-            walk_ms += ms;
-        }
-        for (uint32_t ci = 0; ci < nchunks; ci++) {
-            if (!tie_timed[ci]) continue;
-            HIPCHK(hipEventElapsedTime(&ms, c.tie_ev[2 * ci], c.tie_ev[2 * ci + 1]));
-            tie_ms += ms;
-            g_stats.token_launches++;
-        }
-        g_stats.k_sort_ms = sort_ms;
-        g_stats.k_walk_ms = walk_ms;
-        g_stats.k_tiebreak_ms = tie_ms;
-    }
-    g_stats.n = n;
-    g_stats.zn = *zn;
-    g_stats.ntok = ntok;
-    g_stats.transfers = transfers;
-    g_stats.total_ms = now_ms() - t_begin;
-    g_stats.copy_ms = waited;
-    TRACE("encode_core_device total", t_begin);
-    return LZ77X_OK;
-}
-
-/* Which pipeline an encode takes: everything on the device when the geometry allows it (one device,
- * sb <= 4096, production kernels), the round-1 pipeline with the two recurrences on host cores
- * otherwise (LZ77X_HOST_STAGEB=1 forces it) or when the gate iteration gives up. */
-int encode_core(std::vector<Ctx *> &cs, const void *src, bool src_on_device, size_t n, const lz77x_geom &g, hipStream_t s, size_t *zn)
-{
-    const char *hs = getenv("LZ77X_HOST_STAGEB"), *vs = getenv("LZ77X_MATCH_VARIANT");
-    const bool device_ok = cs.size() == 1 && g.fast && g.shifted && lz77k_prio_supported(g.sb) && !(hs && atoi(hs)) && !(vs && atoi(vs)) &&
-                           !getenv("LZ77X_SERIAL");
-    if (device_ok) {
-        bool fallback = false;
-        const int rc = encode_core_device(*cs[0], src, src_on_device, n, g, s, zn, &fallback);
-        if (rc != LZ77X_OK || !fallback) return rc;
-        const uint32_t iters = g_stats.prio_iters;
-        const int rc2 = encode_core_host(cs, cs[0]->in.p, true, n, g, s, zn);     /* the input is already in c.in */
-        g_stats.prio_iters = iters;
-        return rc2;
-    }
-    return encode_core_host(cs, src, src_on_device, n, g, s, zn);
-}
-
 /* ---------------------------------------------------------------- decode ------------ */
 
 /* Stream must already be in c.z (device, padded).  Computes geometry and decoded size;
@@ -1213,6 +990,445 @@ int stream_out(Ctx &c, FILE *f, const void *d_src, size_t bytes)
     return fflush(f) == 0 ? LZ77X_OK : LZ77X_E_IO;
 }
 
+
+/* ---------------------------------------------------------------- device-resident encode ------------ */
+
+/* Where the input comes from and where the stream goes: device memory, host memory or a FILE*.  Both are
+ * strictly sequential (a pipe works), which is what lets an input of any size run through a bounded
+ * amount of device memory (the reference streams through 3*SB+LA bytes, lz77.c:113-129). */
+struct Source {
+    virtual ~Source() {}
+    /* up to `want` bytes to device address d_dst, enqueued on / ordered with stream s; fewer only at the end */
+    virtual int read(Ctx &c, uint8_t *d_dst, size_t want, hipStream_t s, size_t *got) = 0;
+};
+struct Sink {
+    virtual ~Sink() {}
+    /* the next `bytes` of the stream, resident at d_src and complete in stream order on s */
+    virtual int write(Ctx &c, const uint8_t *d_src, size_t bytes, hipStream_t s) = 0;
+    size_t total = 0;
+};
+
+struct MemSource : Source {
+    const uint8_t *p; size_t n, at = 0; bool on_device;
+    MemSource(const void *src, size_t bytes, bool dev) : p(reinterpret_cast<const uint8_t *>(src)), n(bytes), on_device(dev) {}
+    int read(Ctx &, uint8_t *d_dst, size_t want, hipStream_t s, size_t *got) override
+    {
+        const size_t m = n - at < want ? n - at : want;
+        if (m) HIPCHK(hipMemcpyAsync(d_dst, p + at, m, on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, s));
+        at += m;
+        *got = m;
+        return LZ77X_OK;
+    }
+};
+
+struct FileSource : Source {
+    FILE *f;
+    explicit FileSource(FILE *file) : f(file) {}
+    int read(Ctx &c, uint8_t *d_dst, size_t want, hipStream_t s, size_t *got) override
+    {
+        /* fread of piece k+1 overlaps the DMA of piece k (two pinned staging slots) */
+        const size_t piece = (size_t)16 << 20;
+        int rc;
+        if ((rc = c.h_stage.need(2 * piece))) return rc;
+        uint8_t *slot[2] = {c.h_stage.as<uint8_t>(), c.h_stage.as<uint8_t>() + piece};
+        HIPCHK(hipStreamSynchronize(s));                       /* d_dst may still be read by the previous segment's kernels */
+        size_t len = 0;
+        bool used[2] = {false, false};
+        for (int k = 0; len < want; k++) {
+            const int sl = k & 1;
+            if (used[sl]) HIPCHK(hipEventSynchronize(c.ev[4 + sl]));
+            const size_t ask = want - len < piece ? want - len : piece;
+            const size_t m = fread(slot[sl], 1, ask, f);
+            if (m == 0) {
+                if (ferror(f)) return LZ77X_E_IO;
+                break;
+            }
+            HIPCHK(hipMemcpyAsync(d_dst + len, slot[sl], m, hipMemcpyHostToDevice, c.up));
+            HIPCHK(hipEventRecord(c.ev[4 + sl], c.up));
+            used[sl] = true;
+            len += m;
+            if (m < ask) break;
+        }
+        HIPCHK(hipStreamSynchronize(c.up));
+        *got = len;
+        return LZ77X_OK;
+    }
+};
+
+struct DeviceSink : Sink {
+    uint8_t *d_out; size_t cap;
+    DeviceSink(void *out, size_t capacity) : d_out(reinterpret_cast<uint8_t *>(out)), cap(capacity) {}
+    int write(Ctx &, const uint8_t *d_src, size_t bytes, hipStream_t s) override
+    {
+        if (total + bytes <= cap && bytes) HIPCHK(hipMemcpyAsync(d_out + total, d_src, bytes, hipMemcpyDeviceToDevice, s));
+        total += bytes;                                        /* past cap: keep counting, the caller reports the need */
+        return LZ77X_OK;
+    }
+};
+
+struct HostSink : Sink {
+    uint8_t *buf = nullptr; size_t cap = 0;
+    ~HostSink() override { free(buf); }
+    int write(Ctx &c, const uint8_t *d_src, size_t bytes, hipStream_t s) override
+    {
+        if (total + bytes > cap) {
+            size_t ncap = cap ? cap : (size_t)1 << 20;
+            while (ncap < total + bytes) ncap *= 2;
+            uint8_t *nb = (uint8_t *)realloc(buf, ncap);
+            if (!nb) return LZ77X_E_NOMEM;
+            buf = nb;
+            cap = ncap;
+        }
+        HIPCHK(hipStreamSynchronize(s));
+        const int rc = fetch_result(c, buf + total, d_src, bytes);
+        total += bytes;
+        return rc;
+    }
+    uint8_t *release() { uint8_t *b = buf; buf = nullptr; return b ? b : (uint8_t *)malloc(1); }
+};
+
+struct FileSink : Sink {
+    FILE *f;
+    explicit FileSink(FILE *file) : f(file) {}
+    int write(Ctx &c, const uint8_t *d_src, size_t bytes, hipStream_t s) override
+    {
+        HIPCHK(hipStreamSynchronize(s));
+        total += bytes;
+        return stream_out(c, f, d_src, bytes);
+    }
+};
+
+/* What one segment hands to the next (host side): where the parse chain continues, how many tokens are
+ * out, the last tokens (a stream word can straddle the boundary), and -- on the device, in c.look[] -- the
+ * priorities of the sb cells that are live at the boundary, renumbered 0..sb-1 in order (the tie-break
+ * only ever compares priorities; every position of the next segment is newer than all of them). */
+struct SegCarry {
+    bool first = true;
+    uint64_t chain_pos = 0;        /* global position of the next token */
+    uint64_t ntok = 0;
+    uint32_t tail[4] = {0, 0, 0, 0};
+    uint32_t ntail = 0;
+};
+
+/* One segment: the bytes c.in[0, nloc) are the input from global position gpos0 on; its tokens are the chain
+ * positions in [start, E) (local).  Everything is computed in local 32-bit coordinates:
+ *     match (regions covering [0, E)) -> parse chain from `start` | priority recurrence over steps [0, E-sb)
+ *     from the carried cells -> hand-over index + tie-break -> the stream words this segment's tokens start in.
+ * *fallback: the gate iteration gave up (only possible when allow_fallback), nothing was emitted. */
+int encode_segment(Ctx &c, uint32_t nloc, uint32_t start, uint32_t E, bool last, const lz77x_geom &g, hipStream_t s, SegCarry &carry,
+                   Sink &sink, bool allow_fallback, bool *fallback, double *waited)
+{
+    int rc;
+    *fallback = false;
+    const size_t usb = (size_t)g.sb;
+    const bool first = carry.first;
+    const uint32_t nlook = first ? 0u : (uint32_t)g.sb;
+    const uint32_t nx = E > (uint32_t)g.sb ? E - (uint32_t)g.sb : 0u;
+    HIPCHK(lz77k_fill_pad(c.in.as<uint8_t>(), nloc, s));
+    uint32_t ntok = 0, launches = 0, nchunks = 0;
+    std::vector<char> tie_timed;
+    const uint32_t csub = lz77k_chain_sub();
+    uint32_t exit_off = 0;
+    if (E > start) {
+        uint32_t nregions = (uint32_t)(((size_t)E + g.TILE - 1) / g.TILE);
+        {
+            const uint32_t all = (uint32_t)(((size_t)nloc + g.TILE - 1) / g.TILE);
+            if (nregions > all) nregions = all;
+        }
+        uint32_t batch = nregions;
+        {
+            const size_t per = lz77k_match_scratch_bytes(g, 1);
+            const uint32_t fit = (uint32_t)(((size_t)2 << 30) / per);
+            if (batch > fit) batch = fit ? fit : 1;
+            const char *gs = getenv("LZ77X_MATCH_BATCH");
+            if (gs && atoi(gs) > 0 && (uint32_t)atoi(gs) < batch) batch = (uint32_t)atoi(gs);
+        }
+        /* token chunks: up to 128M positions (one hand-over index and one tie-break launch each; the index
+         * costs 12 bytes of scratch per position), a multiple of the chain sub-block, counted from `start` */
+        size_t chunk_pos = (size_t)128 << 20;
+        {
+            const char *ce = getenv("LZ77X_TOKEN_CHUNK");
+            if (ce && atoi(ce) > 0) chunk_pos = (size_t)atoi(ce);
+            chunk_pos = (chunk_pos + csub - 1) / csub * csub;
+        }
+        const size_t span = (size_t)E - start;
+        nchunks = (uint32_t)((span + chunk_pos - 1) / chunk_pos);
+        const size_t idx_span = (chunk_pos < span ? chunk_pos : span) + 2 * usb + 16;
+        const char *tv = getenv("LZ77X_TOKEN_VARIANT");
+        const int tvariant = tv ? atoi(tv) : 0;
+        const size_t np = (size_t)nloc;
+
+        if ((rc = c.scratch.need(lz77k_match_scratch_bytes(g, batch)))) return rc;
+        if ((rc = c.ps.need((np + 8) * 4))) return rc;
+        if ((rc = c.maxlen.need(np + 64))) return rc;
+        if ((rc = c.xval.need((np + 8) * 4))) return rc;
+        if ((rc = c.chain.need((np + 8) * 4))) return rc;
+        if ((rc = c.tokval.need((np + 16) * 4))) return rc;
+        if ((rc = c.ofs.need((idx_span + 8) * 4))) return rc;
+        if ((rc = c.ent.need((idx_span + 8) * 8))) return rc;
+        if ((rc = c.scantmp.need(lz77k_scan_tmp_bytes((uint32_t)idx_span + 1)))) return rc;
+        if ((rc = c.tstart.need(lz77k_tokens_tmp_bytes((uint32_t)idx_span)))) return rc;
+        if ((rc = c.flag.need(64))) return rc;
+        if ((rc = c.prio_tmp.need(lz77k_prio_tmp_bytes(nx, g.sb)))) return rc;
+        if ((rc = c.chain_tmp.need(lz77k_chain_tmp_bytes(E - start, g.la)))) return rc;
+        if ((rc = c.h_small.need(128))) return rc;
+        if ((rc = c.look.need((size_t)2 * (usb + 8) * 4))) return rc;
+        const uint32_t nsub_max = (uint32_t)((span + csub - 1) / csub);
+        if ((rc = c.h_tbase.need(((size_t)nsub_max + 2) * 4 + (usb + 8) * 4))) return rc;
+        HIPCHK(hipMemsetAsync(c.flag.p, 0, 64, s));
+        const uint32_t nlaunch = (nregions + batch - 1) / batch;
+        while (c.sort_ev.size() < 3 * (size_t)nlaunch) { hipEvent_t e; HIPCHK(hipEventCreate(&e)); c.sort_ev.push_back(e); }
+        while (c.tie_ev.size() < 2 * (size_t)nchunks + 8) { hipEvent_t e; HIPCHK(hipEventCreate(&e)); c.tie_ev.push_back(e); }
+        while (c.match_ev.size() < 8) { hipEvent_t e; HIPCHK(hipEventCreate(&e)); c.match_ev.push_back(e); }
+        /* c.look: [0, sb) the cells this segment starts from, [sb+8, ..) the cells it leaves behind */
+        uint32_t *look_cur = c.look.as<uint32_t>(), *look_next = look_cur + usb + 8;
+
+        /* -- match stage (replaces tree.c insert/delete/find): ps[], maxlen[] -- */
+        HIPCHK(hipEventRecord(c.ev[0], s));
+        for (uint32_t r0 = 0; r0 < nregions; r0 += batch) {
+            const uint32_t nr = nregions - r0 < batch ? nregions - r0 : batch;
+            HIPCHK(lz77k_match(c.in.as<uint8_t>(), nloc, g, r0, nr, c.ps.as<uint32_t>(), c.maxlen.as<uint8_t>(), c.scratch.p, 0, s,
+                               &c.sort_ev[3 * launches], nullptr));
+            launches++;
+        }
+        HIPCHK(hipEventRecord(c.ev[1], s));
+        g_stats.match_launches += launches;
+
+        /* -- parse chain (lz77.c:98) over [start, E) -- */
+        const uint32_t *d_tbase = nullptr, *d_exit = nullptr;
+        uint32_t nsub = 0;
+        HIPCHK(hipEventRecord(c.match_ev[0], s));
+        HIPCHK(lz77k_chain(c.maxlen.as<uint8_t>(), E, g.la, c.chain.as<uint32_t>(), c.chain_tmp.p, s, &d_tbase, &nsub, start, &d_exit));
+        HIPCHK(hipEventRecord(c.match_ev[1], s));
+        uint32_t *h_tbase = c.h_tbase.as<uint32_t>();
+        HIPCHK(hipMemcpyAsync(h_tbase, d_tbase, ((size_t)nsub + 1) * 4, hipMemcpyDeviceToHost, s));
+        HIPCHK(hipMemcpyAsync(c.h_small.as<uint32_t>() + 16, d_exit, 4, hipMemcpyDeviceToHost, s));
+
+        /* -- priority recurrence (tree.c:202-231) over steps [0, nx) from the carried cells -- */
+        int iters = 0, converged = 1;
+        int max_iters = allow_fallback ? 96 : 1 << 30;     /* a sweep finalises at least one more block: it always ends */
+        {
+            const char *me = getenv("LZ77X_PRIO_MAX_ITERS");
+            if (me && atoi(me) > 0 && allow_fallback) max_iters = atoi(me);
+        }
+        HIPCHK(hipEventRecord(c.match_ev[2], s));
+        const double tw0 = now_ms();
+        float prio_ms3[3] = {0, 0, 0};
+        HIPCHK(lz77k_prio(c.ps.as<uint32_t>(), nx, g.sb, c.xval.as<uint32_t>(), c.prio_tmp.p, s, c.h_small.as<uint32_t>() + 8, max_iters,
+                          &iters, &converged, &c.match_ev[4], prio_ms3, 0u, first ? nullptr : look_cur, last ? nullptr : look_next));
+        HIPCHK(hipEventRecord(c.match_ev[3], s));
+        HIPCHK(hipStreamSynchronize(s));                       /* tbase has landed (nx == 0: the recurrence did not sync) */
+        *waited += now_ms() - tw0;
+        g_stats.k_prio_fwd_ms += prio_ms3[0];
+        g_stats.k_prio_back_ms += prio_ms3[1];
+        g_stats.k_prio_scan_ms += prio_ms3[2];
+        g_stats.prio_iters += (uint32_t)iters;
+        if (!converged) {
+            *fallback = true;
+            return LZ77X_OK;
+        }
+        ntok = h_tbase[nsub];
+        exit_off = c.h_small.as<uint32_t>()[16];
+
+        /* -- tokens: per chunk, the hand-over index of the evictions that can matter and the tie-break.  Tokens
+         *    land behind four slots that hold the predecessor's last tokens (for the first stream word) -- */
+        uint32_t *tokbuf = c.tokval.as<uint32_t>();
+        if (carry.ntail) HIPCHK(hipMemcpyAsync(tokbuf + 4 - carry.ntail, carry.tail + 4 - carry.ntail, carry.ntail * 4, hipMemcpyHostToDevice, s));
+        tie_timed.assign(nchunks, 0);
+        HIPCHK(hipEventRecord(c.ev[2], s));
+        for (uint32_t ci = 0; ci < nchunks; ci++) {
+            const size_t b = start + (size_t)ci * chunk_pos, e = b + chunk_pos < E ? b + chunk_pos : E;
+            const uint32_t ta = h_tbase[(b - start) / csub], tb = e == E ? ntok : h_tbase[(e - start) / csub];
+            const size_t x_done = e > usb ? e - usb : 0;
+            const uint32_t dbase = b > usb ? (uint32_t)(b - usb) : 0u;
+            const uint32_t xa = dbase > (uint32_t)g.sb ? dbase - (uint32_t)g.sb : 0u;
+            const size_t x_new = ci == 0 ? 0 : (b > usb ? b - usb : 0);
+            HIPCHK(lz77k_xfer_index(c.ps.as<uint32_t>(), c.xval.as<uint32_t>(), xa, (uint32_t)x_done, dbase, (uint32_t)e, c.ofs.as<uint32_t>(),
+                                    c.ent.as<uint2>(), c.scantmp.p, s, (uint32_t)x_new, c.flag.as<unsigned long long>() + 1));
+            HIPCHK(lz77k_tokens(c.in.as<uint8_t>(), nloc, g, c.chain.as<uint32_t>() + ta, tb - ta, c.maxlen.as<uint8_t>(), c.ofs.as<uint32_t>(),
+                                c.ent.as<uint2>(), dbase, (uint32_t)b, (uint32_t)e, tokbuf + 4 + ta, c.tstart.as<uint32_t>(), nullptr,
+                                tvariant, s, &c.tie_ev[2 * ci], nullptr, first ? nullptr : look_cur, nlook, 0u));
+            tie_timed[ci] = tb > ta;
+        }
+        HIPCHK(hipMemcpyAsync(c.h_small.as<unsigned long long>() + 2, c.flag.as<unsigned long long>() + 1, 8, hipMemcpyDeviceToHost, s));
+        if (!last) {
+            /* the cells left live, renumbered by rank on the host (sb values): what the next segment starts from */
+            uint32_t *h_state = h_tbase + nsub_max + 2;
+            HIPCHK(hipMemcpyAsync(h_state, look_next, usb * 4, hipMemcpyDeviceToHost, s));
+            HIPCHK(hipStreamSynchronize(s));
+            std::vector<std::pair<uint32_t, uint32_t>> order(usb);
+            for (size_t i = 0; i < usb; i++) order[i] = {h_state[i], (uint32_t)i};
+            std::sort(order.begin(), order.end());
+            for (size_t r = 0; r < usb; r++) h_state[order[r].second] = (uint32_t)r;
+            HIPCHK(hipMemcpyAsync(look_cur, h_state, usb * 4, hipMemcpyHostToDevice, s));       /* tokens of this segment are done with it in stream order */
+        }
+    } else {
+        if ((rc = c.tokval.need(64))) return rc;
+        if ((rc = c.h_small.need(128))) return rc;
+        uint32_t *tokbuf = c.tokval.as<uint32_t>();
+        if (carry.ntail) HIPCHK(hipMemcpyAsync(tokbuf + 4 - carry.ntail, carry.tail + 4 - carry.ntail, carry.ntail * 4, hipMemcpyHostToDevice, s));
+        HIPCHK(hipEventRecord(c.ev[0], s));
+        HIPCHK(hipEventRecord(c.ev[1], s));
+        HIPCHK(hipEventRecord(c.ev[2], s));
+    }
+
+    /* -- pack (lz77.c:246-252): the words this segment's tokens start in; the last segment also the rest -- */
+    const uint64_t K0 = carry.ntok, K1 = K0 + ntok;
+    const uint64_t T = (uint64_t)g.T;
+    const uint64_t zn_total = stream_bytes(K1, g.T);
+    const uint64_t wlo = K0 == 0 ? 0 : (32 + K0 * T) / 32;
+    const uint64_t whi = last ? (zn_total + 3) / 4 : (32 + K1 * T) / 32;
+    const uint64_t nw = whi > wlo ? whi - wlo : 0;
+    if ((rc = c.out.need(nw * 4 + 16))) return rc;
+    HIPCHK(lz77k_pack_range(c.tokval.as<uint32_t>() + 4 - carry.ntail, K0 - carry.ntail, K1, g, c.out.as<uint32_t>(), wlo, nw, s));
+    HIPCHK(hipEventRecord(c.ev[3], s));
+    {
+        /* carry: the last four tokens seen so far */
+        const uint32_t have = ntok + carry.ntail < 4 ? ntok + carry.ntail : 4;
+        if (have) HIPCHK(hipMemcpyAsync(c.h_small.as<uint32_t>() + 20, c.tokval.as<uint32_t>() + 4 + ntok - have, have * 4, hipMemcpyDeviceToHost, s));
+        const double tw = now_ms();
+        HIPCHK(hipStreamSynchronize(s));
+        *waited += now_ms() - tw;
+        for (uint32_t i = 0; i < have; i++) carry.tail[4 - have + i] = c.h_small.as<uint32_t>()[20 + i];
+        carry.ntail = have;
+    }
+    const uint64_t bytes = last ? zn_total - 4 * wlo : 4 * nw;
+    if ((rc = sink.write(c, c.out.as<uint8_t>(), (size_t)bytes, s))) return rc;
+    if (E > start) g_stats.transfers += c.h_small.as<unsigned long long>()[2];
+
+    float ms = 0;
+    HIPCHK(hipEventElapsedTime(&ms, c.ev[0], c.ev[1]));
+    g_stats.k_match_ms += ms;
+    HIPCHK(hipEventElapsedTime(&ms, c.ev[2], c.ev[3]));
+    g_stats.k_token_ms += ms;
+    if (E > start) {
+        HIPCHK(hipEventElapsedTime(&ms, c.match_ev[0], c.match_ev[1]));
+        g_stats.k_chain_ms += ms;
+        HIPCHK(hipEventElapsedTime(&ms, c.match_ev[2], c.match_ev[3]));
+        g_stats.k_prio_ms += ms;
+        for (uint32_t i = 0; i < launches; i++) {
+            HIPCHK(hipEventElapsedTime(&ms, c.sort_ev[3 * i], c.sort_ev[3 * i + 1]));
+            g_stats.k_sort_ms += ms;
+            HIPCHK(hipEventElapsedTime(&ms, c.sort_ev[3 * i + 1], c.sort_ev[3 * i + 2]));
+            g_stats.k_walk_ms += ms;
+        }
+        for (uint32_t ci = 0; ci < nchunks; ci++) {
+            if (!tie_timed[ci]) continue;
+            HIPCHK(hipEventElapsedTime(&ms, c.tie_ev[2 * ci], c.tie_ev[2 * ci + 1]));
+            g_stats.k_tiebreak_ms += ms;
+            g_stats.token_launches++;
+        }
+    }
+    carry.first = false;
+    carry.ntok = K1;
+    c.h_small.as<uint32_t>()[24] = exit_off;               /* the caller turns it into the global chain position */
+    return LZ77X_OK;
+}
+
+/* The device-resident encode of an input of any size: the source is cut into segments of up to
+ * LZ77X_SEGMENT positions (default 2^30) that run one after the other through the same device buffers; a
+ * segment starts sb bytes before its first token (the look-back window), so consecutive segments overlap by
+ * sb + the look-ahead, and hands the state of lz77.c's two sequential loops to the next one (SegCarry).
+ * One device, sb <= 4096.  Nothing but the stream (and a few words per segment) leaves the GPU. */
+int encode_stream_device(Ctx &c, Source &src, Sink &sink, const lz77x_geom &g, hipStream_t s, bool *fallback, size_t *n_fallback)
+{
+    const double t_begin = now_ms();
+    memset(&g_stats, 0, sizeof g_stats);
+    *fallback = false;
+    int rc;
+    double waited = 0;
+    HIPCHK(hipSetDevice(c.device));
+    const size_t usb = (size_t)g.sb, halo = (size_t)g.la + 64;
+    size_t seg = (size_t)1 << 30;
+    {
+        const char *se = getenv("LZ77X_SEGMENT");
+        if (se && atoll(se) > 0) seg = (size_t)atoll(se);
+        const size_t lo = 4 * usb + 3 * (size_t)lz77k_chain_sub();
+        if (seg < lo) seg = lo;
+        if (seg > ((size_t)3 << 30)) seg = (size_t)3 << 30;      /* local coordinates are 32-bit */
+    }
+    SegCarry carry;
+    uint64_t gpos0 = 0;                                    /* global position of c.in[0] */
+    size_t have = 0;                                       /* bytes of the input in c.in */
+    uint64_t n_total = 0, a = 0;                           /* a: global position of this segment's first possible token */
+    bool eof = false;
+    for (;;) {
+        /* this segment wants the bytes up to a + seg + halo */
+        const size_t want_local = (size_t)(a + seg + halo - gpos0);
+        if ((rc = c.in.need(want_local + LZ77X_PAD + 64))) return rc;
+        if (!eof && have < want_local) {
+            size_t got = 0;
+            if ((rc = src.read(c, c.in.as<uint8_t>() + have, want_local - have, s, &got))) return rc;
+            if (got < want_local - have) eof = true;
+            have += got;
+            n_total += got;
+        }
+        const bool last = eof;
+        const uint32_t nloc = (uint32_t)have;
+        const uint32_t start = (uint32_t)(carry.chain_pos - gpos0);
+        uint32_t E;
+        if (last) E = nloc;
+        else {
+            const uint32_t lim = (uint32_t)(a + seg - gpos0), csub = lz77k_chain_sub();
+            E = start + (lim - start) / csub * csub;
+        }
+        bool fb = false;
+        if ((rc = encode_segment(c, nloc, start, E, last, g, s, carry, sink, carry.first && last, &fb, &waited))) return rc;
+        if (fb) { *fallback = true; *n_fallback = have; return LZ77X_OK; }
+        if (last) break;
+        carry.chain_pos = gpos0 + E + c.h_small.as<uint32_t>()[24];
+        /* the next segment looks back sb bytes from E: move [E - sb, have) to the front (through a spare
+         * buffer: the ranges overlap) */
+        const size_t keep0 = (size_t)E - usb, keep = have - keep0;
+        if ((rc = c.bidx.need(keep + 64))) return rc;
+        HIPCHK(hipMemcpyAsync(c.bidx.p, c.in.as<uint8_t>() + keep0, keep, hipMemcpyDeviceToDevice, s));
+        HIPCHK(hipMemcpyAsync(c.in.p, c.bidx.p, keep, hipMemcpyDeviceToDevice, s));
+        gpos0 += keep0;
+        have = keep;
+        a = gpos0 + usb;                                   /* = the old E */
+    }
+    g_stats.n = n_total;
+    g_stats.zn = sink.total;
+    g_stats.ntok = carry.ntok;
+    g_stats.total_ms = now_ms() - t_begin;
+    g_stats.copy_ms = waited;
+    TRACE("encode_stream_device total", t_begin);
+    return LZ77X_OK;
+}
+
+/* Which pipeline an encode takes: everything on the device when the geometry allows it (one device,
+ * sb <= 4096, production kernels), the round-1 pipeline with the two recurrences on host cores
+ * otherwise (LZ77X_HOST_STAGEB=1 forces it) or when the gate iteration gives up. */
+bool device_pipeline_ok(size_t ndev, const lz77x_geom &g)
+{
+    const char *hs = getenv("LZ77X_HOST_STAGEB"), *vs = getenv("LZ77X_MATCH_VARIANT");
+    return ndev == 1 && g.fast && g.shifted && lz77k_prio_supported(g.sb) && !(hs && atoi(hs)) && !(vs && atoi(vs)) && !getenv("LZ77X_SERIAL");
+}
+
+/* memory -> sink.  src: host or device pointer of n bytes */
+int encode_any(std::vector<Ctx *> &cs, const void *src, bool src_on_device, size_t n, const lz77x_geom &g, hipStream_t s, Sink &sink)
+{
+    Ctx &c0 = *cs[0];
+    const void *host_src = src;
+    bool host_on_device = src_on_device;
+    uint32_t iters = 0;                                    /* gate iterations spent before giving up */
+    if (device_pipeline_ok(cs.size(), g)) {
+        MemSource ms(src, n, src_on_device);
+        bool fallback = false;
+        size_t nfb = 0;
+        const int rc = encode_stream_device(c0, ms, sink, g, s, &fallback, &nfb);
+        if (rc != LZ77X_OK || !fallback) return rc;
+        host_src = c0.in.p;                                /* single segment: the whole input is in c.in */
+        host_on_device = true;
+        iters = g_stats.prio_iters;
+    }
+    size_t zn = 0;
+    int rc = encode_core_host(cs, host_src, host_on_device, n, g, s, &zn);
+    g_stats.prio_iters = iters;
+    if (rc) return rc;
+    return sink.write(c0, c0.out.as<uint8_t>(), zn, s);
+}
+
 }  // namespace
 
 /* ==================================================================== C ABI ========= */
@@ -1243,18 +1459,13 @@ int lz77x_encode(const uint8_t *in, size_t n, int sb, int la, uint8_t **out, siz
     TRACE("runtime + context init", t0);
     lz77x_geom g;
     make_encode_geom(&g, sb, la);
-    size_t zn = 0;
     const double t1 = now_ms();
-    if ((rc = encode_core(cs, in, false, n, g, g_ctx.stream, &zn))) return rc;
-    TRACE("encode_core (incl. allocs)", t1);
-    const double t2 = now_ms();
-    uint8_t *buf = (uint8_t *)malloc(zn ? zn : 1);
-    if (!buf) return LZ77X_E_NOMEM;
-    if ((rc = fetch_result(g_ctx, buf, g_ctx.out.p, zn))) { free(buf); return rc; }
-    TRACE("fetch result", t2);
-    *out = buf;
-    *out_n = zn;
-    return LZ77X_OK;
+    HostSink sink;
+    if ((rc = encode_any(cs, in, false, n, g, g_ctx.stream, sink))) return rc;
+    TRACE("encode (incl. allocs, result fetch)", t1);
+    *out_n = sink.total;
+    *out = sink.release();
+    return *out ? LZ77X_OK : LZ77X_E_NOMEM;
 }
 
 int lz77x_encode_device(const void *d_in, size_t n, int sb, int la, void *d_out, size_t out_cap, size_t *out_n, void *stream)
@@ -1270,13 +1481,11 @@ int lz77x_encode_device(const void *d_in, size_t n, int sb, int la, void *d_out,
     lz77x_geom g;
     make_encode_geom(&g, sb, la);
     hipStream_t s = (hipStream_t)stream;
-    size_t zn = 0;
-    if ((rc = encode_core(cs, d_in, true, n, g, s, &zn))) return rc;
-    *out_n = zn;
-    if (zn > out_cap) return LZ77X_E_CAP;
-    HIPCHK(hipMemcpyAsync(d_out, g_ctx.out.p, zn, hipMemcpyDeviceToDevice, s));
+    DeviceSink sink(d_out, out_cap);
+    if ((rc = encode_any(cs, d_in, true, n, g, s, sink))) return rc;
+    *out_n = sink.total;
     HIPCHK(hipStreamSynchronize(s));
-    return LZ77X_OK;
+    return sink.total > out_cap ? LZ77X_E_CAP : LZ77X_OK;
 }
 
 int lz77x_decode(const uint8_t *z, size_t zn, uint8_t **out, size_t *out_n)
@@ -1337,16 +1546,27 @@ int lz77x_encode_file(FILE *in, FILE *out, int la, int sb)
     if ((rc = shard_contexts(*lease.set, 1, cs))) return rc;
     TRACE("runtime + context init", t0);
     Ctx &c = g_ctx;
-    size_t n = 0;
-    const double t1 = now_ms();
-    if ((rc = stream_in(c, in, c.in, LZ77X_PAD + 16, &n))) return rc;
-    TRACE("file -> device", t1);
     lz77x_geom g;
     make_encode_geom(&g, sb == -1 ? LZ77X_DEFAULT_SB : sb, la == -1 ? LZ77X_DEFAULT_LA : la);
+    size_t n = 0;
+    if (device_pipeline_ok(1, g)) {
+        /* any size, any kind of file: segment by segment through bounded device memory */
+        FileSource src(in);
+        FileSink sink(out);
+        bool fallback = false;
+        const double t1 = now_ms();
+        rc = encode_stream_device(c, src, sink, g, c.stream, &fallback, &n);
+        TRACE("file -> device -> file", t1);
+        if (rc || !fallback) return rc;                         /* fallback: the whole (single-segment) input sits in c.in */
+    } else {
+        const double t1 = now_ms();
+        if ((rc = stream_in(c, in, c.in, LZ77X_PAD + 16, &n))) return rc;
+        TRACE("file -> device", t1);
+    }
     size_t zn = 0;
     const double t2 = now_ms();
-    if ((rc = encode_core(cs, c.in.p, true, n, g, c.stream, &zn))) return rc;
-    TRACE("encode_core (incl. allocs)", t2);
+    if ((rc = encode_core_host(cs, c.in.p, true, n, g, c.stream, &zn))) return rc;
+    TRACE("encode_core_host (incl. allocs)", t2);
     const double t3 = now_ms();
     rc = stream_out(c, out, c.out.p, zn);
     TRACE("device -> file", t3);

@@ -21,6 +21,8 @@ FULL = {r["name"]: r for r in json.load(open(os.path.join(HERE, "golden", "golde
 def _run(name):
     import torch
     r = FULL[name]
+    if r["n"] >= 1 << 32:
+        return _run_huge(r)
     n, sb, la = r["n"], r["sb"], r["la"]
     data = synth.make(r["kind"], n, r["seed"])
     assert hashlib.sha256(memoryview(data)).hexdigest() == r["sha256_in"], "generator drifted"
@@ -42,6 +44,56 @@ def _run(name):
     del d_in, d_z, d_back
     torch.cuda.empty_cache()
     return stats
+
+
+def _run_huge(r):
+    """>= 4 GiB: the input goes through the FILE* entry point as a pipe would, piece by piece"""
+    import torch                                            # noqa: F401  (maps the HIP runtime first)
+    import ctypes
+    import tempfile
+    n, sb, la = r["n"], r["sb"], r["la"]
+    libc = ctypes.CDLL(None)
+    libc.fdopen.restype = ctypes.c_void_p
+    libc.fdopen.argtypes = [ctypes.c_int, ctypes.c_char_p]
+    libc.fclose.argtypes = [ctypes.c_void_p]
+    with tempfile.TemporaryDirectory(dir="/dev/shm" if os.path.isdir("/dev/shm") else None) as d:
+        fin, fout = os.path.join(d, "in"), os.path.join(d, "out")
+        data = synth.make(r["kind"], n, r["seed"])
+        assert hashlib.sha256(memoryview(data)).hexdigest() == r["sha256_in"], "generator drifted"
+        data.tofile(fin)
+        del data
+        fi = libc.fdopen(os.open(fin, os.O_RDONLY), b"rb")
+        fo = libc.fdopen(os.open(fout, os.O_WRONLY | os.O_CREAT | os.O_TRUNC, 0o600), b"wb")
+        rc = L.lib().lz77x_encode_file(fi, fo, la, sb)
+        libc.fclose(fi)
+        libc.fclose(fo)
+        assert rc == 0, L.lib().lz77x_last_error()
+        stats = L.last_stats()
+        assert os.path.getsize(fout) == r["zn"] and stats["ntok"] == r["ntok"] and stats["n"] == n
+        h = hashlib.sha256()
+        with open(fout, "rb") as f:
+            while True:
+                b = f.read(1 << 26)
+                if not b:
+                    break
+                h.update(b)
+        assert h.hexdigest() == r["sha256_lz"], "stream differs from the reference's"
+    return stats
+
+
+def test_s1_in_five_segments(monkeypatch):
+    """the 100 MB bench stream cut into 20 MB segments (carried parse position, token tail and renumbered
+    priorities): the same digest"""
+    monkeypatch.setenv("LZ77X_SEGMENT", "20000000")
+    st = _run("S1")
+    assert st["host_stageb_ms"] == 0
+
+
+@pytest.mark.skipif(os.environ.get("LZ77_TEST_HUGE") != "1", reason="5 GiB input: ~10 minutes of generation and hashing; set LZ77_TEST_HUGE=1")
+def test_s5_5gib_through_bounded_device_memory():
+    """5 GiB of text through the FILE* entry point -- six segments of 2^30 positions, device
+    memory independent of the input size -- equals the reference's stream (digest made by make_full.py)"""
+    _run("S5")
 
 
 def test_s1_enwik8_like_100mb():

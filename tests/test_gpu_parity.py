@@ -262,6 +262,24 @@ def test_device_and_host_pipelines_agree(kind, seed, n, sb, la, env, monkeypatch
         assert st["prio_iters"] >= 1 and st["host_stageb_ms"] == 0 and st["host_chain_ms"] == 0
 
 
+@pytest.mark.parametrize("seg", ["1", "50000", "300001"])
+@pytest.mark.parametrize("kind,seed,n,sb,la", [("mixed", 93, 1_500_000, 4095, 15), ("text", 94, 700_000, 1000, 10),
+                                              ("lowent", 95, 400_000, 255, 7), ("records", 96, 600_000, 4096, 16),
+                                              ("random", 97, 300_000, 5, 3), ("zeros", 0, 200_000, 4095, 15),
+                                              ("text", 98, 500_000, 100, 200)])
+def test_segments_give_identical_bytes(kind, seed, n, sb, la, seg, monkeypatch):
+    """SURVEY 8f-2 / lz77.c:113-129: an input of any size runs through bounded device memory as a sequence of
+    segments, each handed the parse position, the token count, the last tokens (a stream word may straddle
+    the cut, also for token widths that are not whole bytes) and the live cells' priorities renumbered by
+    rank.  Segment sizes far below the input (the minimum is 4*sb + 12 KiB) must not change a byte."""
+    data = synth.make(kind, n, seed)
+    want = O.encode_bst(data, sb, la)
+    monkeypatch.setenv("LZ77X_SEGMENT", seg)
+    assert L.encode(data, la, sb) == want
+    st = L.last_stats()
+    assert st["host_stageb_ms"] == 0 and st["n"] == n and st["zn"] == len(want)
+
+
 @pytest.mark.parametrize("env", [{"LZ77X_MATCH_VARIANT": "1"}, {"LZ77X_MATCH_VARIANT": "3"}, {"LZ77X_SORT_VARIANT": "1"},
                                  {"LZ77X_SORT_VARIANT": "2"}, {"LZ77X_TOKEN_VARIANT": "1"}, {"LZ77X_TOKEN_VARIANT": "2"}, {"LZ77X_WALK_RUN": "256"}, {"LZ77X_WALK_RUN": "1000"},
                                  {"LZ77X_WALK_RUN": "4096"}])
