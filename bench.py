@@ -139,6 +139,73 @@ def _cpu_model():
     return "unknown"
 
 
+def shard_mode(a):
+    """BASELINE config 5: one stream, position-sharded over N devices (lz77x_set_shards), host buffers in and
+    out (per-GPU outputs are gathered on the host, as north_star describes) -- so this rate includes PCIe.
+    One process (rank 0) drives every device; under torch.distributed.run the other ranks only meet it at the
+    barriers."""
+    import numpy as np
+    import hashlib
+    import torch
+    import torch.distributed as dist
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo")
+    import lz77_amd as L
+    from lz77_amd import synth
+    n = a.bytes if "--bytes" in sys.argv else 1_000_000_000
+    seed = synth.SEED_S4
+    out = None
+    if rank == 0:
+        ndev = L.lib().lz77x_device_count()
+        shards = min(a.gpus, ndev) if not os.environ.get("LZ77X_FAKE_DEVICES") else a.gpus
+        data = synth.make(a.kind, n, seed)
+        assert L.lib().lz77x_set_shards(max(shards, 1)) == 0
+        z = b""
+        for _ in range(a.warmup):
+            z = L.encode(data, a.la, a.sb)
+            L.decode(z[:4 + 3 * 1000])
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    if rank == 0:
+        enc_ms, dec_ms, iters = [], [], 0
+        for _ in range(a.steps):
+            t1 = time.perf_counter()
+            z = L.encode(data, a.la, a.sb)
+            iters = L.last_stats()["prio_iters"]
+            t2 = time.perf_counter()
+            back = L.decode(z)
+            t3 = time.perf_counter()
+            enc_ms.append((t2 - t1) * 1e3)
+            dec_ms.append((t3 - t2) * 1e3)
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if rank == 0:
+        K = max(a.steps, 1)
+        gold = golden_full(a.kind, n, seed, a.sb, a.la)
+        sha_ok = None if gold is None else (len(z) == gold["zn"] and hashlib.sha256(z).hexdigest() == gold["sha256_lz"])
+        plan = [p.__dict__ for p in __import__("lz77_amd.shard", fromlist=["plan"]).plan(n, max(shards, 1), a.sb, a.la)]
+        out = {"metric": "encode+decode MB/s on enwik9-like synthetic text, s=%d l=%d, ONE stream position-sharded" % (a.sb, a.la),
+               "value": round(n * K / dt / 1e6, 3), "unit": "MB/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+               "ms_per_step": round(dt / K * 1e3, 3), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+               "dtype": "u8", "data": "synthetic",
+               "config": {"workload": "S4 enwik9-like text (lz77_amd.synth.text, seed 0x5EED0004), %d bytes, s=%d l=%d, cut into %d shards "
+                                      "on %d device(s); host buffers in and out (PCIe-inclusive); decode on one device" %
+                                      (n, a.sb, a.la, len(plan), min(len(plan), L.lib().lz77x_device_count())),
+                          "mode": "shard", "shards": len(plan), "max_local_bytes": max(p["local_bytes"] for p in plan)},
+               "encode_ms": round(sum(enc_ms) / K, 2), "decode_ms": round(sum(dec_ms) / K, 2), "prio_iters": iters,
+               "roundtrip_ok": bool(back == data.tobytes()), "stream_sha_ok": sha_ok,
+               "serial_terms": "per gate iteration one host exchange of 6 KB per shard (priority cells), one of 1.3 KB per shard for "
+                               "the parse chain, 16 bytes per cut for packing; everything else is shard-local"}
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -151,7 +218,12 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=64_000_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--streams", type=int, default=4, help="also report k concurrent streams on one GPU (informational; 1 = skip)")
+    ap.add_argument("--mode", choices=("files", "shard"), default="files",
+                    help="files: an independent stream per GPU (default; weak scaling).  shard: ONE stream (default the 1 GB "
+                         "S4 'enwik9-like' input, BASELINE config 5) cut by position over --gpus devices, driven by rank 0")
     a = ap.parse_args()
+    if a.mode == "shard":
+        return shard_mode(a)
 
     import torch
     import torch.distributed as dist
@@ -277,7 +349,7 @@ def main():
             "data": "synthetic" if corpus_label is None else "file",
             "config": {"workload": ("S1 enwik8-like text (lz77_amd.synth.text, seed 0x5EED0001+rank)" if corpus_label is None else corpus_label) +
                                    ", %d bytes per GPU, s=%d l=%d; step = encode then decode, buffers resident in HBM" % (n, a.sb, a.la),
-                       "bytes_per_gpu": n, "sb": a.sb, "la": a.la, "parallelism": "independent stream per GPU",
+                       "mode": "files", "bytes_per_gpu": n, "sb": a.sb, "la": a.la, "parallelism": "independent stream per GPU",
                        "numa_bound_cpus": numa_cpus},
             "roofline": {"bound": "hbm", "kernel": dom_name + " -- the largest GPU kernel of the step",
                          "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS,

@@ -92,6 +92,27 @@ const char *lz77x_strerror(int code);
 const char *lz77x_last_error(void);       /* detail of the last LZ77X_E_HIP, thread local */
 const char *lz77x_version(void);
 
+/* ---- one stream on several devices: the host-side plan and exchange (no device needed) ------------
+ * With lz77x_set_shards(D) > 1 lz77x_encode cuts the positions of one stream into D contiguous shards, one per
+ * device; each device only ever holds its shard.  The two sequential loops of lz77.c cross the
+ * cuts as small maps chained on the host; these three functions ARE that host side (the library calls them
+ * itself; exported so that the multi-rank plan can be checked without a GPU). */
+typedef struct lz77x_shard {
+    uint64_t first_token_pos, end_token_pos;   /* the shard emits the tokens whose position lies in [first, end) */
+    uint64_t local0;                            /* global position of the shard's first byte (= first - lookback) */
+    uint64_t local_bytes;                       /* bytes the device holds: look-back + shard + look-ahead */
+    uint64_t steps;                             /* evictions (lz77.c:101-103) it simulates: [local0, end - sb) */
+    uint32_t lookback, reserved;                /* sb, or 0 for the first shard */
+} lz77x_shard;
+int lz77x_shard_plan(size_t n, int sb, int la, int shards, lz77x_shard *out);       /* -> shards used, or < 0 */
+void lz77x_shard_compose_cells(const uint16_t *dest, const uint32_t *loc, int sb, uint32_t *cells);
+void lz77x_shard_compose_chain(const uint8_t *exit_of, const uint32_t *tokens_of, uint32_t *entry, uint64_t *tokens);
+
+/* ---- several files at once (each on a context of its own, up to LZ77X_MAX_CONTEXTS at a time) -------
+ * rc[i] receives the status of file i; returns 0 when all succeeded, else the first failure. */
+int lz77x_encode_files(int n_files, FILE **in, FILE **out, int la, int sb, int *rc);
+int lz77x_decode_files(int n_files, FILE **in, FILE **out, int *rc);
+
 /* Per-call timing of the last encode/decode on this thread, milliseconds.  Kernel
  * times are hipEvent pairs on the call's stream; host_* are wall clock. */
 typedef struct lz77x_stats {

@@ -88,6 +88,11 @@ SYMBOLS = {
     "lz77x_stage_priorities": (ctypes.c_int, [_vp, _vp, _sz, ctypes.c_int, _vp]),
     "lz77x_stage_priorities_device": (ctypes.c_int, [_vp, _vp, _sz, ctypes.c_int, _vp, ctypes.POINTER(ctypes.c_int)]),
     "lz77x_stage_chain_device": (ctypes.c_int, [_vp, _sz, ctypes.c_int, _vp, ctypes.POINTER(_sz)]),
+    "lz77x_shard_plan": (ctypes.c_int, [_sz, ctypes.c_int, ctypes.c_int, ctypes.c_int, _vp]),
+    "lz77x_shard_compose_cells": (None, [_vp, _vp, ctypes.c_int, _vp]),
+    "lz77x_shard_compose_chain": (None, [_vp, _vp, _vp, _vp]),
+    "lz77x_encode_files": (ctypes.c_int, [ctypes.c_int, _vp, _vp, ctypes.c_int, ctypes.c_int, _vp]),
+    "lz77x_decode_files": (ctypes.c_int, [ctypes.c_int, _vp, _vp, _vp]),
 }
 
 

@@ -79,12 +79,28 @@ __global__ __launch_bounds__(256) void k_chain_compose(const uint8_t *__restrict
     gcnt[(size_t)g * la + e] = total;
 }
 
-/* the groups in sequence from the start of the input (entry offset 0): one lane */
+/* all groups composed, one lane per entry offset: the map of the whole range (what a shard of a stream that
+ * is spread over several devices sends to the host, which chains the shards) */
+__global__ void k_chain_whole(const uint8_t *__restrict__ gexit, const uint32_t *__restrict__ gcnt, uint32_t la, uint32_t ng,
+                              uint8_t *__restrict__ wexit, uint32_t *__restrict__ wcnt)
+{
+    const uint32_t e = threadIdx.x;
+    if (e >= la) return;
+    uint32_t cur = e, tot = 0;
+    for (uint32_t g = 0; g < ng; g++) {
+        tot += gcnt[(size_t)g * la + cur];
+        cur = gexit[(size_t)g * la + cur];
+    }
+    wexit[e] = (uint8_t)cur;
+    wcnt[e] = tot;
+}
+
+/* the groups in sequence from the entry offset of the first sub-block (0 at the start of a stream): one lane */
 __global__ void k_chain_top(const uint8_t *__restrict__ gexit, const uint32_t *__restrict__ gcnt, uint32_t la, uint32_t ng,
-                            uint32_t *__restrict__ gentry, uint32_t *__restrict__ gbase, uint32_t *__restrict__ total)
+                            uint32_t *__restrict__ gentry, uint32_t *__restrict__ gbase, uint32_t *__restrict__ total, uint32_t entry0)
 {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    uint32_t e = 0, tot = 0;
+    uint32_t e = entry0, tot = 0;
     for (uint32_t g = 0; g < ng; g++) {
         gentry[g] = e;
         gbase[g] = tot;
@@ -144,7 +160,7 @@ __global__ __launch_bounds__(64) void k_chain_emit(const uint8_t *__restrict__ m
 
 struct chain_layout {
     uint32_t nsub, GC, ng;
-    size_t o_exit, o_cnt, o_gexit, o_gcnt, o_gentry, o_gbase, o_entry, o_tbase, o_total, total;
+    size_t o_exit, o_cnt, o_gexit, o_gcnt, o_gentry, o_gbase, o_entry, o_tbase, o_total, o_wexit, o_wcnt, total;
 };
 
 static chain_layout chain_make_layout(uint32_t n, uint32_t la)
@@ -166,6 +182,8 @@ static chain_layout chain_make_layout(uint32_t n, uint32_t la)
     L.o_entry = take((size_t)L.nsub * 4);
     L.o_tbase = take(((size_t)L.nsub + 1) * 4);
     L.o_total = take(64);
+    L.o_wexit = take(256);
+    L.o_wcnt = take(256 * 4);
     L.total = o;
     return L;
 }
@@ -173,20 +191,58 @@ static chain_layout chain_make_layout(uint32_t n, uint32_t la)
 size_t lz77k_chain_tmp_bytes(uint32_t n, int la) { return chain_make_layout(n, (uint32_t)la).total + 256; }
 uint32_t lz77k_chain_sub(void) { return CHAIN_SB; }
 
-/* chain[k] = position of token k; *d_tbase -> first-token index of every CHAIN_SB sub-block (nsub + 1
- * words, the last one = ntok), inside d_tmp.  Enqueues only. */
-hipError_t lz77k_chain(const uint8_t *d_maxlen_all, uint32_t n_all, int la_i, uint32_t *d_chain, void *d_tmp, hipStream_t s,
-                       const uint32_t **d_tbase, uint32_t *nsub_out, uint32_t start, const uint32_t **d_exit)
+/* Phase 1: the sub-blocks' maps and their composition by groups (and, whole = true, of the whole range: 256
+ * bytes of exit offsets + 256 words of token counts, indexed by entry offset).  The chain covers positions
+ * [start, n_all): sub-blocks are counted from `start`. */
+hipError_t lz77k_chain_maps(const uint8_t *d_maxlen_all, uint32_t n_all, int la_i, void *d_tmp, hipStream_t s, uint32_t start, bool whole,
+                            const uint8_t **d_wexit, const uint32_t **d_wcnt)
 {
-    /* the chain begins at position `start`: sub-blocks are counted from there */
     const uint8_t *d_maxlen = d_maxlen_all + start;
     const uint32_t n = n_all > start ? n_all - start : 0u;
     const uint32_t la = (uint32_t)la_i;
     const chain_layout L = chain_make_layout(n, la);
     uint8_t *base = reinterpret_cast<uint8_t *>(d_tmp);
-    uint8_t *exitmap = base + L.o_exit;
+    uint8_t *exitmap = base + L.o_exit, *gexit = base + L.o_gexit, *wexit = base + L.o_wexit;
     uint16_t *cnt = reinterpret_cast<uint16_t *>(base + L.o_cnt);
-    uint8_t *gexit = base + L.o_gexit;
+    uint32_t *gcnt = reinterpret_cast<uint32_t *>(base + L.o_gcnt), *wcnt = reinterpret_cast<uint32_t *>(base + L.o_wcnt);
+    if (d_wexit) *d_wexit = wexit;
+    if (d_wcnt) *d_wcnt = wcnt;
+    uint32_t lps = 2;
+    while (lps < la) lps <<= 1;
+    const uint32_t spw = 256u / lps < 16u ? 256u / lps : 16u;
+    hipError_t e;
+    if (n) {
+        const size_t lds = (size_t)spw * CHAIN_SB;
+        if (lds > 48 * 1024 &&
+            (e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_chain_map), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)) != hipSuccess)
+            return e;
+        hipLaunchKernelGGL(k_chain_map, dim3((L.nsub + spw - 1u) / spw), dim3(256), lds, s, d_maxlen, n, la, lps, L.nsub, exitmap, cnt);
+        const size_t lds2 = (size_t)L.GC * la * 3 + 16;
+        if (lds2 > 48 * 1024) {
+            if ((e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_chain_compose), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2)) != hipSuccess)
+                return e;
+            if ((e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_chain_apply), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2)) != hipSuccess)
+                return e;
+        }
+        hipLaunchKernelGGL(k_chain_compose, dim3(L.ng), dim3(256), lds2, s, exitmap, cnt, la, L.nsub, L.GC, gexit, gcnt);
+    }
+    if (whole) hipLaunchKernelGGL(k_chain_whole, dim3(1), dim3(256), 0, s, gexit, gcnt, la, n ? L.ng : 0u, wexit, wcnt);
+    return hipGetLastError();
+}
+
+/* Phase 2: from the entry offset of the first sub-block, every sub-block's true entry and first-token
+ * index, then chain[k] = position of token k.  *d_tbase -> first-token index of every CHAIN_SB sub-block
+ * (nsub + 1 words, the last one = ntok), *d_exit -> how far past n_all the last token reaches; both inside d_tmp. */
+hipError_t lz77k_chain_finish(const uint8_t *d_maxlen_all, uint32_t n_all, int la_i, uint32_t *d_chain, void *d_tmp, hipStream_t s,
+                              uint32_t start, uint32_t entry0, const uint32_t **d_tbase, uint32_t *nsub_out, const uint32_t **d_exit)
+{
+    const uint8_t *d_maxlen = d_maxlen_all + start;
+    const uint32_t n = n_all > start ? n_all - start : 0u;
+    const uint32_t la = (uint32_t)la_i;
+    const chain_layout L = chain_make_layout(n, la);
+    uint8_t *base = reinterpret_cast<uint8_t *>(d_tmp);
+    uint8_t *exitmap = base + L.o_exit, *gexit = base + L.o_gexit;
+    uint16_t *cnt = reinterpret_cast<uint16_t *>(base + L.o_cnt);
     uint32_t *gcnt = reinterpret_cast<uint32_t *>(base + L.o_gcnt);
     uint32_t *gentry = reinterpret_cast<uint32_t *>(base + L.o_gentry);
     uint32_t *gbase = reinterpret_cast<uint32_t *>(base + L.o_gbase);
@@ -196,39 +252,28 @@ hipError_t lz77k_chain(const uint8_t *d_maxlen_all, uint32_t n_all, int la_i, ui
     *d_tbase = tbase;
     *nsub_out = L.nsub;
     if (d_exit) *d_exit = total + 1;
-    if (n == 0) {
-        hipError_t e0 = hipMemsetAsync(tbase, 0, 4, s);
-        return e0 == hipSuccess ? hipMemsetAsync(total, 0, 8, s) : e0;
-    }
-    uint32_t lps = 2;
-    while (lps < la) lps <<= 1;
-    const uint32_t spw = 256u / lps < 16u ? 256u / lps : 16u;
     hipError_t e;
-    {
-        const size_t lds = (size_t)spw * CHAIN_SB;
-        if (lds > 48 * 1024 &&
-            (e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_chain_map), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)) != hipSuccess)
-            return e;
-        hipLaunchKernelGGL(k_chain_map, dim3((L.nsub + spw - 1u) / spw), dim3(256), lds, s, d_maxlen, n, la, lps, L.nsub, exitmap, cnt);
+    if (n == 0) {
+        if ((e = hipMemsetAsync(tbase, 0, 4, s)) != hipSuccess) return e;
+        if ((e = hipMemsetAsync(total, 0, 4, s)) != hipSuccess) return e;
+        return hipMemcpyAsync(total + 1, &entry0, 4, hipMemcpyHostToDevice, s);     /* nothing to walk: the entry passes through */
     }
-    {
-        const size_t lds = (size_t)L.GC * la * 3 + 16;
-        if (lds > 48 * 1024) {
-            if ((e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_chain_compose), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)) != hipSuccess)
-                return e;
-            if ((e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_chain_apply), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)) != hipSuccess)
-                return e;
-        }
-        hipLaunchKernelGGL(k_chain_compose, dim3(L.ng), dim3(256), lds, s, exitmap, cnt, la, L.nsub, L.GC, gexit, gcnt);
-        hipLaunchKernelGGL(k_chain_top, dim3(1), dim3(64), 0, s, gexit, gcnt, la, L.ng, gentry, gbase, total);
-        hipLaunchKernelGGL(k_chain_apply, dim3(L.ng), dim3(256), lds, s, exitmap, cnt, la, L.nsub, L.GC, gentry, gbase, entry, tbase, total + 1);
-    }
-    {
-        const size_t lds = (size_t)CHAIN_EMIT_SUBS * CHAIN_SB;
-        if ((e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_chain_emit), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)) != hipSuccess)
-            return e;
-        hipLaunchKernelGGL(k_chain_emit, dim3((L.nsub + CHAIN_EMIT_SUBS - 1u) / CHAIN_EMIT_SUBS), dim3(64), lds, s, d_maxlen, n, L.nsub, entry,
-                           tbase, d_chain, start);
-    }
+    const size_t lds2 = (size_t)L.GC * la * 3 + 16;
+    hipLaunchKernelGGL(k_chain_top, dim3(1), dim3(64), 0, s, gexit, gcnt, la, L.ng, gentry, gbase, total, entry0);
+    hipLaunchKernelGGL(k_chain_apply, dim3(L.ng), dim3(256), lds2, s, exitmap, cnt, la, L.nsub, L.GC, gentry, gbase, entry, tbase, total + 1);
+    const size_t lds = (size_t)CHAIN_EMIT_SUBS * CHAIN_SB;
+    if ((e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_chain_emit), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)) != hipSuccess)
+        return e;
+    hipLaunchKernelGGL(k_chain_emit, dim3((L.nsub + CHAIN_EMIT_SUBS - 1u) / CHAIN_EMIT_SUBS), dim3(64), lds, s, d_maxlen, n, L.nsub, entry, tbase,
+                       d_chain, start);
     return hipGetLastError();
+}
+
+/* both phases for a range whose chain begins exactly at `start` */
+hipError_t lz77k_chain(const uint8_t *d_maxlen_all, uint32_t n_all, int la_i, uint32_t *d_chain, void *d_tmp, hipStream_t s,
+                       const uint32_t **d_tbase, uint32_t *nsub_out, uint32_t start, const uint32_t **d_exit)
+{
+    hipError_t e = lz77k_chain_maps(d_maxlen_all, n_all, la_i, d_tmp, s, start, false, nullptr, nullptr);
+    if (e != hipSuccess) return e;
+    return lz77k_chain_finish(d_maxlen_all, n_all, la_i, d_chain, d_tmp, s, start, 0u, d_tbase, nsub_out, d_exit);
 }

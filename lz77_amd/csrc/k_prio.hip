@@ -225,7 +225,9 @@ __global__ __launch_bounds__(64) void k_prio_back(const uint32_t *__restrict__ p
     const uint32_t b = b_first + blockIdx.x;
     const uint32_t x0 = b * B;
     const uint32_t x1 = nx - x0 < B ? nx : x0 + B;
-    for (uint32_t i = lane; i < sb; i += 64) lloc[i] = x1 + i + voff;
+    /* what reaches exit cell x1+i when nothing older comes in: its own priority -- unless it is a carried
+     * cell (a short first block of a later segment: its value comes in through in[0]) */
+    for (uint32_t i = lane; i < sb; i += 64) lloc[i] = x1 + i >= ncarried ? x1 + i + voff : PRIO_NONE;
     for (uint32_t i = lane; i < ring_n; i += 64) dr[i] = PRIO_DEAD;
     wave_sync();
     const uint32_t nsg = (x1 - x0 + 64u * PRIO_SG - 1u) / (64u * PRIO_SG);
@@ -294,7 +296,8 @@ __global__ __launch_bounds__(64) void k_prio_back(const uint32_t *__restrict__ p
         g_l = g_n;
     }
     for (uint32_t i = lane; i < sb; i += 64) {
-        dest[(size_t)b * sb + i] = x0 + i < x1 ? dr[i] : (uint16_t)PRIO_DEAD;
+        /* an entry cell that is not evicted inside a (short, last) block is still live at its end */
+        dest[(size_t)b * sb + i] = x0 + i < x1 ? dr[i] : (uint16_t)(i - (x1 - x0));
         loc[(size_t)b * sb + i] = lloc[i];
     }
 }
@@ -435,44 +438,159 @@ static uint32_t prio_block_steps(uint32_t nx, uint32_t sb)
     return (B + unit - 1u) / unit * unit;
 }
 
-struct prio_layout {
-    uint32_t B, NB, ngroups, sb_r, ring_n, G, NG;
-    size_t o_gate[2], o_rmask, o_dest, o_loc, o_in, o_gdest, o_gloc, o_gin, o_gout, o_sum, total;
-};
+/* ---- the iteration, as phases (one device drives them in a loop: lz77k_prio; several devices, each with a
+ *      shard of one stream, interleave them with a host exchange of the shards' boundary maps) ---- */
 
-static prio_layout prio_make_layout(uint32_t nx, uint32_t sb)
+static void prio_layout(lz77k_prio_plan &P)
 {
-    prio_layout L;
-    L.B = prio_block_steps(nx, sb);
-    L.NB = nx ? (nx + L.B - 1u) / L.B : 0u;
-    L.ngroups = (nx + 63u) / 64u;
-    L.sb_r = (sb + 63u) & ~63u;
-    L.ring_n = L.sb_r + 64u;
+    const uint32_t sb = P.sb, nx = P.nx;
+    P.B = prio_block_steps(nx, sb);
+    P.NB = nx ? (nx + P.B - 1u) / P.B : 0u;
+    P.ngroups = (nx + 63u) / 64u;
+    P.sb_r = (sb + 63u) & ~63u;
+    P.ring_n = P.sb_r + 64u;
     uint32_t G = 1;
-    while ((uint64_t)G * G < L.NB) G++;
+    while ((uint64_t)G * G < P.NB) G++;
     const char *e = getenv("LZ77X_PRIO_SCAN_GROUP");
     if (e && atoi(e) > 0) G = (uint32_t)atoi(e);
-    L.G = G;
-    L.NG = L.NB ? (L.NB + G - 1u) / G : 0u;
+    P.G = G;
+    P.NG = P.NB ? (P.NB + G - 1u) / G : 0u;
     size_t o = 0;
     auto take = [&](size_t bytes) { const size_t at = o; o += (bytes + 255) & ~(size_t)255; return at; };
-    L.o_gate[0] = take((size_t)L.ngroups * 8 + 64);
-    L.o_gate[1] = take((size_t)L.ngroups * 8 + 64);
-    L.o_rmask = take((size_t)L.ngroups * 8 + 64);
-    L.o_dest = take(((size_t)L.NB + 1) * sb * 2);
-    L.o_loc = take(((size_t)L.NB + 1) * sb * 4);
-    L.o_in = take(((size_t)L.NB + 1) * sb * 4);
-    L.o_gdest = take(((size_t)L.NG + 1) * sb * 2);
-    L.o_gloc = take(((size_t)L.NG + 1) * sb * 4);
-    L.o_gin = take(((size_t)L.NG + 2) * sb * 4);
-    L.o_sum = take(256);
-    L.total = o;
-    return L;
+    P.o_gate[0] = take((size_t)P.ngroups * 8 + 64);
+    P.o_gate[1] = take((size_t)P.ngroups * 8 + 64);
+    P.o_rmask = take((size_t)P.ngroups * 8 + 64);
+    P.o_dest = take(((size_t)P.NB + 1) * sb * 2);
+    P.o_loc = take(((size_t)P.NB + 1) * sb * 4);
+    P.o_in = take(((size_t)P.NB + 2) * sb * 4);
+    P.o_gdest = take(((size_t)P.NG + 2) * sb * 2);
+    P.o_gloc = take(((size_t)P.NG + 2) * sb * 4);
+    P.o_gin = take(((size_t)P.NG + 2) * sb * 4);
+    P.o_sum = take(256);
+    P.total = o;
 }
 
-size_t lz77k_prio_tmp_bytes(uint32_t nx, int sb) { return prio_make_layout(nx, (uint32_t)sb).total + 256; }
+size_t lz77k_prio_tmp_bytes(uint32_t nx, int sb)
+{
+    lz77k_prio_plan P;
+    P.nx = nx;
+    P.sb = (uint32_t)sb;
+    prio_layout(P);
+    return P.total + 256;
+}
 
 int lz77k_prio_supported(int sb) { return sb >= 1 && sb <= 4096; }
+
+#define PRIO_PTR(T, off) reinterpret_cast<T *>(reinterpret_cast<uint8_t *>(P.tmp) + (off))
+
+/* round masks + initial gates (every step with both neighbours), and the cells block 0 starts from */
+hipError_t lz77k_prio_begin(lz77k_prio_plan &P, const uint32_t *d_ps, uint32_t nx, int sb, uint32_t *d_xval, void *d_tmp, uint32_t voff,
+                            const uint32_t *d_carried, hipStream_t s)
+{
+    P.ps = d_ps;
+    P.nx = nx;
+    P.sb = (uint32_t)sb;
+    P.xval = d_xval;
+    P.tmp = d_tmp;
+    P.voff = voff;
+    P.ncarried = d_carried ? (uint32_t)sb : 0u;
+    P.cur = 0;
+    P.first = 0;
+    prio_layout(P);
+    if (nx == 0) return hipSuccess;
+    const uint32_t tagn = P.ring_n + 64u;
+    const size_t lds = (size_t)4 * tagn * sizeof(uint32_t);
+    hipError_t e;
+    if (lds > 48 * 1024 &&
+        (e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_prio_prep), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)) != hipSuccess)
+        return e;
+    const uint32_t blocks = min((P.ngroups + 3u) / 4u, 256u * 8u);
+    hipLaunchKernelGGL(k_prio_prep, dim3(blocks), dim3(256), lds, s, d_ps, nx, tagn, PRIO_PTR(uint64_t, P.o_rmask), PRIO_PTR(uint64_t, P.o_gate[0]));
+    hipLaunchKernelGGL(k_prio_in0, dim3((P.sb + 255u) / 256u), dim3(256), 0, s, PRIO_PTR(uint32_t, P.o_in), P.sb, voff, d_carried);
+    return hipGetLastError();
+}
+
+/* the cells block 0 starts from, when they only become known later (a shard: they follow from the maps of
+ * the shards before it) */
+hipError_t lz77k_prio_set_in0(lz77k_prio_plan &P, const uint32_t *h_or_d_in0, hipMemcpyKind kind, hipStream_t s)
+{
+    if (P.nx == 0) return hipSuccess;
+    return hipMemcpyAsync(PRIO_PTR(uint32_t, P.o_in), h_or_d_in0, (size_t)P.sb * 4, kind, s);
+}
+
+/* the blocks' boundary maps from the current gates (blocks >= P.first); whole = also the composition of
+ * ALL blocks of this plan into one map (row NG+1 of gdest/gloc: what a shard sends to the host) */
+hipError_t lz77k_prio_maps(lz77k_prio_plan &P, hipStream_t s, bool whole, const uint16_t **d_sdest, const uint32_t **d_sloc)
+{
+    if (P.nx == 0) return hipSuccess;
+    const size_t lds_back = (size_t)P.sb_r * 4 + (size_t)P.ring_n * 2;
+    const size_t lds_scan = (size_t)P.sb_r * (4 + 4 + 2 + 2);
+    uint16_t *dest = PRIO_PTR(uint16_t, P.o_dest), *gdest = PRIO_PTR(uint16_t, P.o_gdest);
+    uint32_t *loc = PRIO_PTR(uint32_t, P.o_loc), *gloc = PRIO_PTR(uint32_t, P.o_gloc);
+    const uint32_t nb = P.NB - P.first;
+    hipLaunchKernelGGL(k_prio_back, dim3(nb), dim3(64), lds_back, s, P.ps, P.nx, P.sb, P.B, P.ring_n, P.first, PRIO_PTR(uint64_t, P.o_gate[P.cur]),
+                       dest, loc, P.voff, P.ncarried);
+    if (whole) {
+        /* every block 0 .. NB-1 (the maps of the blocks before P.first are still there and final), in groups,
+         * then the groups */
+        hipLaunchKernelGGL(k_prio_scan_compose, dim3(P.NG), dim3(PRIO_SCAN_BLOCK), lds_scan, s, dest, loc, P.sb, P.sb_r, 0u, P.NB, P.G, gdest, gloc);
+        hipLaunchKernelGGL(k_prio_scan_compose, dim3(1), dim3(PRIO_SCAN_BLOCK), lds_scan, s, gdest, gloc, P.sb, P.sb_r, 0u, P.NG, P.NG,
+                           gdest + (size_t)(P.NG + 1) * P.sb, gloc + (size_t)(P.NG + 1) * P.sb);
+        if (d_sdest) *d_sdest = gdest + (size_t)(P.NG + 1) * P.sb;
+        if (d_sloc) *d_sloc = gloc + (size_t)(P.NG + 1) * P.sb;
+    }
+    return hipGetLastError();
+}
+
+/* boundary values from the maps (in[first] is final), then the exact sweep of every block >= first;
+ * the flip summary lands in h_flag (8 bytes, pinned) once the stream has drained */
+hipError_t lz77k_prio_sweep(lz77k_prio_plan &P, hipStream_t s, uint32_t *h_flag, uint32_t *d_out_state, hipEvent_t *ev3)
+{
+    if (P.nx == 0) { h_flag[0] = 0; h_flag[1] = PRIO_NONE; return hipSuccess; }
+    const size_t lds_fwd = (size_t)P.ring_n * 4 + (size_t)(P.B / 64u) * 8;
+    const size_t lds_scan = (size_t)P.sb_r * (4 + 4 + 2 + 2);
+    uint16_t *dest = PRIO_PTR(uint16_t, P.o_dest), *gdest = PRIO_PTR(uint16_t, P.o_gdest);
+    uint32_t *loc = PRIO_PTR(uint32_t, P.o_loc), *gloc = PRIO_PTR(uint32_t, P.o_gloc);
+    uint32_t *in = PRIO_PTR(uint32_t, P.o_in), *gin = PRIO_PTR(uint32_t, P.o_gin), *summary = PRIO_PTR(uint32_t, P.o_sum);
+    const uint32_t first = P.first, nb = P.NB - first, sb = P.sb;
+    hipError_t e;
+    hipLaunchKernelGGL(k_prio_reset, dim3(1), dim3(1), 0, s, summary);
+    if (ev3 && (e = hipEventRecord(ev3[0], s)) != hipSuccess) return e;
+    if (nb > 1) {
+        /* maps first .. NB-2 */
+        const uint32_t nmaps = nb - 1, G = P.G;
+        const uint32_t NG = (nmaps + G - 1u) / G;
+        if (NG > 1) {
+            hipLaunchKernelGGL(k_prio_scan_compose, dim3(NG), dim3(PRIO_SCAN_BLOCK), lds_scan, s, dest, loc, sb, P.sb_r, first, nmaps, G, gdest, gloc);
+            /* gin[g] = input of group g: replay the group maps from in[first] */
+            hipLaunchKernelGGL(k_prio_scan_replay, dim3(1), dim3(PRIO_SCAN_BLOCK), lds_scan, s, gdest, gloc, sb, P.sb_r, (size_t)0, NG - 1u, NG,
+                               in + (size_t)first * sb, (size_t)0, gin, (size_t)0, 1u);
+            hipLaunchKernelGGL(k_prio_scan_replay, dim3(NG), dim3(PRIO_SCAN_BLOCK), lds_scan, s, dest, loc, sb, P.sb_r, (size_t)first, nmaps, G, gin,
+                               (size_t)sb, in, (size_t)first, 0u);
+        } else {
+            hipLaunchKernelGGL(k_prio_scan_replay, dim3(1), dim3(PRIO_SCAN_BLOCK), lds_scan, s, dest, loc, sb, P.sb_r, (size_t)first, nmaps, nmaps,
+                               in + (size_t)first * sb, (size_t)0, in, (size_t)first, 0u);
+        }
+    }
+    if (ev3 && (e = hipEventRecord(ev3[1], s)) != hipSuccess) return e;
+    hipLaunchKernelGGL(k_prio_fwd<true>, dim3(nb), dim3(64), lds_fwd, s, P.ps, P.nx, sb, P.B, P.ring_n, first, PRIO_PTR(uint64_t, P.o_rmask),
+                       PRIO_PTR(uint64_t, P.o_gate[P.cur]), PRIO_PTR(uint64_t, P.o_gate[P.cur ^ 1]), in, P.xval, summary, P.voff, d_out_state);
+    if (ev3 && (e = hipEventRecord(ev3[2], s)) != hipSuccess) return e;
+    return hipMemcpyAsync(h_flag, summary, 8, hipMemcpyDeviceToHost, s);
+}
+
+/* after the stream has drained: take the sweep's gates as current.  Gates before the first flip are final
+ * (a block's sweep is exact once the blocks before it are): those blocks keep their xval and in[] and are
+ * not visited again; both gate buffers agree on that prefix (a block without a flip wrote back what it read).
+ * restart_at0: the cells this plan starts from may still change (a shard whose predecessors have not
+ * converged): nothing of it is final yet. */
+void lz77k_prio_advance(lz77k_prio_plan &P, const uint32_t *h_flag, bool restart_at0)
+{
+    if (P.nx == 0) return;
+    if (h_flag[0] == 0) { if (restart_at0) P.first = 0; return; }   /* the gate buffers are equal from `first` on: keep cur */
+    P.first = restart_at0 ? 0u : h_flag[1];
+    P.cur ^= 1;
+}
 
 /* xval[x] for x < nx from ps[] (distances P | S << 16).  h_flag: 8 bytes of pinned host memory.  Returns
  * hipSuccess with *converged = 0 when max_iters did not suffice (the caller then takes the host path). */
@@ -487,81 +605,27 @@ hipError_t lz77k_prio(const uint32_t *d_ps, uint32_t nx, int sb_i, uint32_t *d_x
         if (d_out_state) hipLaunchKernelGGL(k_prio_in0, dim3((sb + 255u) / 256u), dim3(256), 0, s, d_out_state, sb, voff, d_carried);
         return hipGetLastError();
     }
-    const prio_layout L = prio_make_layout(nx, sb);
-    uint8_t *base = reinterpret_cast<uint8_t *>(d_tmp);
-    uint64_t *gate[2] = {reinterpret_cast<uint64_t *>(base + L.o_gate[0]), reinterpret_cast<uint64_t *>(base + L.o_gate[1])};
-    uint64_t *rmask = reinterpret_cast<uint64_t *>(base + L.o_rmask);
-    uint16_t *dest = reinterpret_cast<uint16_t *>(base + L.o_dest);
-    uint32_t *loc = reinterpret_cast<uint32_t *>(base + L.o_loc);
-    uint32_t *in = reinterpret_cast<uint32_t *>(base + L.o_in);
-    uint16_t *gdest = reinterpret_cast<uint16_t *>(base + L.o_gdest);
-    uint32_t *gloc = reinterpret_cast<uint32_t *>(base + L.o_gloc);
-    uint32_t *gin = reinterpret_cast<uint32_t *>(base + L.o_gin);
-    uint32_t *summary = reinterpret_cast<uint32_t *>(base + L.o_sum);
+    lz77k_prio_plan P;
     hipError_t e;
-
-    {
-        const uint32_t tagn = L.ring_n + 64u;
-        const size_t lds = (size_t)4 * tagn * sizeof(uint32_t);
-        if (lds > 48 * 1024 &&
-            (e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_prio_prep), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)) != hipSuccess)
-            return e;
-        const uint32_t blocks = min((L.ngroups + 3u) / 4u, 256u * 8u);
-        hipLaunchKernelGGL(k_prio_prep, dim3(blocks), dim3(256), lds, s, d_ps, nx, tagn, rmask, gate[0]);
-        hipLaunchKernelGGL(k_prio_in0, dim3((sb + 255u) / 256u), dim3(256), 0, s, in, sb, voff, d_carried);
-    }
-    const size_t lds_fwd = (size_t)L.ring_n * 4 + (size_t)(L.B / 64u) * 8;
-    const size_t lds_back = (size_t)L.sb_r * 4 + (size_t)L.ring_n * 2;
-    const size_t lds_scan = (size_t)L.sb_r * (4 + 4 + 2 + 2);
-    int cur = 0;
-    uint32_t first = 0;
+    if ((e = lz77k_prio_begin(P, d_ps, nx, sb_i, d_xval, d_tmp, voff, d_carried, s)) != hipSuccess) return e;
     for (int it = 0;; it++) {
         if (it >= max_iters) { *converged = 0; break; }
-        const uint32_t nb = L.NB - first;
-        hipLaunchKernelGGL(k_prio_reset, dim3(1), dim3(1), 0, s, summary);
-        if (ev4 && (e = hipEventRecord(ev4[0], s)) != hipSuccess) return e;
-        hipLaunchKernelGGL(k_prio_back, dim3(nb), dim3(64), lds_back, s, d_ps, nx, sb, L.B, L.ring_n, first, gate[cur], dest, loc, voff, d_carried ? sb : 0u);
-        if (ev4 && (e = hipEventRecord(ev4[1], s)) != hipSuccess) return e;
-        if (nb > 1) {
-            /* maps first .. NB-2; in[first] is final (it = 0: identity) */
-            const uint32_t nmaps = nb - 1;
-            uint32_t G = L.G;
-            const uint32_t NG = (nmaps + G - 1u) / G;
-            if (NG > 1) {
-                hipLaunchKernelGGL(k_prio_scan_compose, dim3(NG), dim3(PRIO_SCAN_BLOCK), lds_scan, s, dest, loc, sb, L.sb_r, first, nmaps, G,
-                                   gdest, gloc);
-                /* gin[g] = input of group g: replay the group maps from in[first] */
-                hipLaunchKernelGGL(k_prio_scan_replay, dim3(1), dim3(PRIO_SCAN_BLOCK), lds_scan, s, gdest, gloc, sb, L.sb_r, (size_t)0, NG - 1u,
-                                   NG, in + (size_t)first * sb, (size_t)0, gin, (size_t)0, 1u);
-                hipLaunchKernelGGL(k_prio_scan_replay, dim3(NG), dim3(PRIO_SCAN_BLOCK), lds_scan, s, dest, loc, sb, L.sb_r, (size_t)first, nmaps, G,
-                                   gin, (size_t)sb, in, (size_t)first, 0u);
-            } else {
-                hipLaunchKernelGGL(k_prio_scan_replay, dim3(1), dim3(PRIO_SCAN_BLOCK), lds_scan, s, dest, loc, sb, L.sb_r, (size_t)first, nmaps,
-                                   nmaps, in + (size_t)first * sb, (size_t)0, in, (size_t)first, 0u);
-            }
-        }
-        if (ev4 && (e = hipEventRecord(ev4[2], s)) != hipSuccess) return e;
-        hipLaunchKernelGGL(k_prio_fwd<true>, dim3(nb), dim3(64), lds_fwd, s, d_ps, nx, sb, L.B, L.ring_n, first, rmask, gate[cur], gate[cur ^ 1],
-                           in, d_xval, summary, voff, d_out_state);
         if (ev4 && (e = hipEventRecord(ev4[3], s)) != hipSuccess) return e;
-        if ((e = hipMemcpyAsync(h_flag, summary, 8, hipMemcpyDeviceToHost, s)) != hipSuccess) return e;
+        if ((e = lz77k_prio_maps(P, s, false, nullptr, nullptr)) != hipSuccess) return e;
+        if ((e = lz77k_prio_sweep(P, s, h_flag, d_out_state, ev4)) != hipSuccess) return e;
         if ((e = hipStreamSynchronize(s)) != hipSuccess) return e;
         *iters = it + 1;
         if (ev4 && ms3) {
             float t = 0;
-            if ((e = hipEventElapsedTime(&t, ev4[2], ev4[3])) != hipSuccess) return e;
-            ms3[0] += t;
-            if ((e = hipEventElapsedTime(&t, ev4[0], ev4[1])) != hipSuccess) return e;
-            ms3[1] += t;
             if ((e = hipEventElapsedTime(&t, ev4[1], ev4[2])) != hipSuccess) return e;
+            ms3[0] += t;
+            if ((e = hipEventElapsedTime(&t, ev4[3], ev4[0])) != hipSuccess) return e;
+            ms3[1] += t;
+            if ((e = hipEventElapsedTime(&t, ev4[0], ev4[1])) != hipSuccess) return e;
             ms3[2] += t;
         }
         if (h_flag[0] == 0) break;
-        /* Gates before the first flip are final (gate x only depends on gates of earlier steps): the blocks
-         * before it keep their in[] and are not visited again until the closing sweep.  Both gate buffers
-         * agree on that prefix (a block without a flip wrote back what it read). */
-        first = h_flag[1];
-        cur ^= 1;
+        lz77k_prio_advance(P, h_flag, false);
     }
     return hipGetLastError();
 }

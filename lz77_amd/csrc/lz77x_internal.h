@@ -119,11 +119,38 @@ hipError_t lz77k_prio(const uint32_t *d_ps, uint32_t nx, int sb, uint32_t *d_xva
                       const uint32_t *d_carried = nullptr /* sb values of cells 0..sb-1 before step 0 (else: their own) */,
                       uint32_t *d_out_state = nullptr /* sb values of cells nx..nx+sb-1 after the last step */);
 
+/* The same iteration as phases, for several devices that each hold a shard of ONE stream: every iteration
+ * the shards' whole-shard maps go to the host, which chains them into the cells each shard starts from.
+ *     begin -> { maps(whole) -> [host: compose, set_in0] -> sweep -> [sync] -> advance } until no shard flips */
+struct lz77k_prio_plan {
+    const uint32_t *ps = nullptr;
+    uint32_t *xval = nullptr;
+    void *tmp = nullptr;
+    uint32_t nx = 0, sb = 0, voff = 0, ncarried = 0;
+    uint32_t B = 0, NB = 0, ngroups = 0, sb_r = 0, ring_n = 0, G = 0, NG = 0;
+    size_t o_gate[2] = {0, 0}, o_rmask = 0, o_dest = 0, o_loc = 0, o_in = 0, o_gdest = 0, o_gloc = 0, o_gin = 0, o_sum = 0, total = 0;
+    int cur = 0;              /* gate buffer the next maps/sweep read */
+    uint32_t first = 0;       /* blocks before it are final */
+};
+hipError_t lz77k_prio_begin(lz77k_prio_plan &P, const uint32_t *d_ps, uint32_t nx, int sb, uint32_t *d_xval, void *d_tmp, uint32_t voff,
+                            const uint32_t *d_carried, hipStream_t s);
+hipError_t lz77k_prio_set_in0(lz77k_prio_plan &P, const uint32_t *h_or_d_in0, hipMemcpyKind kind, hipStream_t s);
+hipError_t lz77k_prio_maps(lz77k_prio_plan &P, hipStream_t s, bool whole, const uint16_t **d_sdest, const uint32_t **d_sloc);
+hipError_t lz77k_prio_sweep(lz77k_prio_plan &P, hipStream_t s, uint32_t *h_flag, uint32_t *d_out_state, hipEvent_t *ev3 = nullptr);
+void lz77k_prio_advance(lz77k_prio_plan &P, const uint32_t *h_flag, bool restart_at0);
+
 /* The greedy parse chain (lz77.c:89-98) on the device: chain[k] = position of token k.  *d_tbase points
  * (inside d_tmp) at the index of the first token of every lz77k_chain_sub()-position sub-block, nsub + 1
  * words, the last one = ntok.  Enqueues only. */
 size_t lz77k_chain_tmp_bytes(uint32_t n, int la);
 uint32_t lz77k_chain_sub(void);
+/* the two phases of lz77k_chain: (1) the maps of the sub-blocks of [start, n), composed by groups and -- whole --
+ * over the whole range (d_wexit[e], d_wcnt[e]: exit offset and token count when the range is entered at start + e);
+ * (2) from the true entry offset, chain[] and the sub-blocks' first-token indices */
+hipError_t lz77k_chain_maps(const uint8_t *d_maxlen, uint32_t n, int la, void *d_tmp, hipStream_t s, uint32_t start, bool whole,
+                            const uint8_t **d_wexit, const uint32_t **d_wcnt);
+hipError_t lz77k_chain_finish(const uint8_t *d_maxlen, uint32_t n, int la, uint32_t *d_chain, void *d_tmp, hipStream_t s,
+                              uint32_t start, uint32_t entry0, const uint32_t **d_tbase, uint32_t *nsub, const uint32_t **d_exit);
 hipError_t lz77k_chain(const uint8_t *d_maxlen, uint32_t n, int la, uint32_t *d_chain, void *d_tmp, hipStream_t s,
                        const uint32_t **d_tbase, uint32_t *nsub,
                        uint32_t start = 0 /* the chain begins here; sub-blocks are counted from it */,

@@ -1396,6 +1396,307 @@ int encode_stream_device(Ctx &c, Source &src, Sink &sink, const lz77x_geom &g, h
     return LZ77X_OK;
 }
 
+/* ONE stream on SEVERAL devices (BASELINE config 5): the positions are cut into D contiguous
+ * shards, device d holds only its shard's bytes (plus sb of look-back and the look-ahead) and only its share
+ * of every intermediate array -- memory per device ~ n/D.  Every stage is local to a shard except the two
+ * sequential loops of lz77.c, which cross the cuts as a few KB through the host:
+ *   - parse chain: each shard's map  entry offset -> (exit offset, tokens)  (la entries), chained on the host;
+ *   - priority recurrence: each gate iteration, each shard's whole map of boundary cells (sb entries), chained
+ *     on the host into the cells every shard starts from;
+ *   - packing: the last four tokens of a shard go to its successor (a stream word can straddle the cut).
+ * No device-to-device traffic, no collective.  Priorities are GLOBAL positions here (local + voff): the shards
+ * iterate together, so nothing can be renumbered; one call therefore handles < 4 GiB (a longer stream goes
+ * through segments on one device, encode_stream_device). */
+}  // namespace
+
+extern "C" {
+
+/* host-only: how one stream of n bytes is cut for `shards` devices.  Returns the number of shards actually
+ * used (a shard is never smaller than 4*sb + 12 KiB) */
+int lz77x_shard_plan(size_t n, int sb, int la, int shards, lz77x_shard *out)
+{
+    if (check_geom(sb, la) != LZ77X_OK || shards < 1) return LZ77X_E_ARG;
+    const size_t usb = (size_t)sb, halo = (size_t)la + 64;
+    size_t D = (size_t)shards;
+    const size_t min_shard = 4 * usb + 3 * (size_t)4096;
+    while (D > 1 && n / D < min_shard) D--;
+    for (size_t d = 0; d < D && out; d++) {
+        lz77x_shard &j = out[d];
+        j.first_token_pos = (uint64_t)n * d / D;
+        j.end_token_pos = (uint64_t)n * (d + 1) / D;
+        j.lookback = d ? (uint32_t)usb : 0u;
+        j.local0 = j.first_token_pos - j.lookback;
+        const uint64_t end = d + 1 == D ? (uint64_t)n : (j.end_token_pos + halo < n ? j.end_token_pos + halo : (uint64_t)n);
+        j.local_bytes = end - j.local0;
+        j.steps = j.end_token_pos - j.local0 > usb ? j.end_token_pos - j.local0 - usb : 0;
+    }
+    return (int)D;
+}
+
+/* host-only: one shard's whole map of boundary cells applied to the cells it starts from (in place):
+ * cells[d] <- min(loc[d], min{ cells[c] : dest[c] = d }) */
+void lz77x_shard_compose_cells(const uint16_t *dest, const uint32_t *loc, int sb, uint32_t *cells)
+{
+    std::vector<uint32_t> vo(loc, loc + sb);
+    for (int i = 0; i < sb; i++)
+        if (dest[i] != 0xFFFFu && cells[i] < vo[dest[i]]) vo[dest[i]] = cells[i];
+    memcpy(cells, vo.data(), (size_t)sb * 4);
+}
+
+/* host-only: one shard's parse-chain map applied to the running (entry offset, token count) */
+void lz77x_shard_compose_chain(const uint8_t *exit_of, const uint32_t *tokens_of, uint32_t *entry, uint64_t *tokens)
+{
+    *tokens += tokens_of[*entry];
+    *entry = exit_of[*entry];
+}
+
+}  // extern "C"
+
+namespace {
+
+struct ShardJob {
+    Ctx *c = nullptr;
+    uint64_t a = 0, b = 0, gpos0 = 0;      /* tokens [a, b) (global), local 0 = gpos0 */
+    uint32_t look = 0, nloc = 0, E = 0, nx = 0, entry = 0, start = 0, ntok = 0, nsub = 0;
+    uint64_t K0 = 0;
+    lz77k_prio_plan P;
+    const uint32_t *d_tbase = nullptr;
+    uint32_t *h = nullptr;                  /* pinned scratch of this shard (c->h_tbase) */
+};
+
+int encode_sharded(std::vector<Ctx *> &cs, const uint8_t *src, size_t n, const lz77x_geom &g, Sink &sink)
+{
+    const double t_begin = now_ms();
+    memset(&g_stats, 0, sizeof g_stats);
+    if (n > LZ77X_MAX_N) return LZ77X_E_TOOBIG;
+    const size_t usb = (size_t)g.sb;
+    const uint32_t csub = lz77k_chain_sub();
+    std::vector<lz77x_shard> plan(cs.size());
+    const int planned = lz77x_shard_plan(n, g.sb, g.la, (int)cs.size(), plan.data());
+    if (planned < 1) return LZ77X_E_ARG;
+    const size_t D = (size_t)planned;
+    std::vector<ShardJob> J(D);
+    int rc;
+    const char *tv = getenv("LZ77X_TOKEN_VARIANT");
+    const int tvariant = tv ? atoi(tv) : 0;
+    auto dev = [&](ShardJob &j) -> int { HIPCHK(hipSetDevice(j.c->device)); return LZ77X_OK; };
+    auto sync_all = [&]() -> int {
+        for (ShardJob &j : J) { HIPCHK(hipSetDevice(j.c->device)); HIPCHK(hipStreamSynchronize(j.c->stream)); }
+        return LZ77X_OK;
+    };
+    const size_t hwords = 4 * usb + 1024;                 /* pinned words per shard beyond the tbase copy */
+
+    /* -- phase A: every shard on its own: input, match stage, the parse chain's maps, round masks -- */
+    for (size_t d = 0; d < D; d++) {
+        ShardJob &j = J[d];
+        j.c = cs[d];
+        Ctx &c = *j.c;
+        j.a = plan[d].first_token_pos;
+        j.b = plan[d].end_token_pos;
+        j.look = plan[d].lookback;
+        j.gpos0 = plan[d].local0;
+        j.nloc = (uint32_t)plan[d].local_bytes;
+        j.E = (uint32_t)(j.b - j.gpos0);
+        j.nx = (uint32_t)plan[d].steps;
+        if ((rc = dev(j))) return rc;
+        hipStream_t s = c.stream;
+        const size_t np = j.nloc;
+        const uint32_t nregions = (uint32_t)(((size_t)j.E + g.TILE - 1) / g.TILE) < (uint32_t)((np + g.TILE - 1) / g.TILE)
+                                      ? (uint32_t)(((size_t)j.E + g.TILE - 1) / g.TILE) : (uint32_t)((np + g.TILE - 1) / g.TILE);
+        uint32_t batch = nregions;
+        {
+            const size_t per = lz77k_match_scratch_bytes(g, 1);
+            const uint32_t fit = (uint32_t)(((size_t)2 << 30) / per);
+            if (batch > fit) batch = fit ? fit : 1;
+        }
+        const size_t span = (size_t)j.E - j.look;
+        const size_t idx_span = span + 3 * usb + 64;
+        if ((rc = c.in.need(np + LZ77X_PAD + 64))) return rc;
+        if ((rc = c.scratch.need(lz77k_match_scratch_bytes(g, batch)))) return rc;
+        if ((rc = c.ps.need((np + 8) * 4))) return rc;
+        if ((rc = c.maxlen.need(np + 64))) return rc;
+        if ((rc = c.xval.need((np + 8) * 4))) return rc;
+        if ((rc = c.chain.need((np + 8) * 4))) return rc;
+        if ((rc = c.tokval.need((np + 16) * 4))) return rc;
+        if ((rc = c.ofs.need((idx_span + 8) * 4))) return rc;
+        if ((rc = c.ent.need((idx_span + 8) * 8))) return rc;
+        if ((rc = c.scantmp.need(lz77k_scan_tmp_bytes((uint32_t)idx_span + 1)))) return rc;
+        if ((rc = c.tstart.need(lz77k_tokens_tmp_bytes((uint32_t)idx_span)))) return rc;
+        if ((rc = c.flag.need(64))) return rc;
+        if ((rc = c.prio_tmp.need(lz77k_prio_tmp_bytes(j.nx, g.sb)))) return rc;
+        if ((rc = c.chain_tmp.need(lz77k_chain_tmp_bytes((uint32_t)span, g.la)))) return rc;
+        if ((rc = c.h_small.need(128))) return rc;
+        const uint32_t nsub_max = (uint32_t)((span + csub - 1) / csub);
+        if ((rc = c.h_tbase.need(((size_t)nsub_max + 2 + hwords) * 4))) return rc;
+        j.h = c.h_tbase.as<uint32_t>() + nsub_max + 2;
+        HIPCHK(hipMemsetAsync(c.flag.p, 0, 64, s));
+        HIPCHK(hipMemcpyAsync(c.in.p, src + j.gpos0, np, hipMemcpyHostToDevice, s));
+        HIPCHK(lz77k_fill_pad(c.in.as<uint8_t>(), j.nloc, s));
+        for (uint32_t r0 = 0; r0 < nregions; r0 += batch) {
+            const uint32_t nr = nregions - r0 < batch ? nregions - r0 : batch;
+            HIPCHK(lz77k_match(c.in.as<uint8_t>(), j.nloc, g, r0, nr, c.ps.as<uint32_t>(), c.maxlen.as<uint8_t>(), c.scratch.p, 0, s, nullptr, nullptr));
+            g_stats.match_launches++;
+        }
+        const uint8_t *d_wexit = nullptr;
+        const uint32_t *d_wcnt = nullptr;
+        HIPCHK(lz77k_chain_maps(c.maxlen.as<uint8_t>(), j.E, g.la, c.chain_tmp.p, s, j.look, true, &d_wexit, &d_wcnt));
+        HIPCHK(hipMemcpyAsync(j.h, d_wcnt, 256 * 4, hipMemcpyDeviceToHost, s));
+        HIPCHK(hipMemcpyAsync(j.h + 256, d_wexit, 256, hipMemcpyDeviceToHost, s));
+        HIPCHK(lz77k_prio_begin(j.P, c.ps.as<uint32_t>(), j.nx, g.sb, c.xval.as<uint32_t>(), c.prio_tmp.p, (uint32_t)j.gpos0, nullptr, s));
+    }
+    if ((rc = sync_all())) return rc;
+
+    /* -- the parse chain across the cuts (lz77.c:98): entry offset and first-token index of every shard -- */
+    {
+        uint32_t e = 0;
+        uint64_t K = 0;
+        for (ShardJob &j : J) {
+            j.entry = e;
+            j.K0 = K;
+            j.ntok = j.h[e];
+            lz77x_shard_compose_chain(reinterpret_cast<const uint8_t *>(j.h + 256), j.h, &e, &K);
+            j.start = j.look + j.entry;
+        }
+    }
+    for (ShardJob &j : J) {
+        Ctx &c = *j.c;
+        if ((rc = dev(j))) return rc;
+        HIPCHK(lz77k_chain_finish(c.maxlen.as<uint8_t>(), j.E, g.la, c.chain.as<uint32_t>(), c.chain_tmp.p, c.stream, j.look, j.entry, &j.d_tbase,
+                                  &j.nsub, nullptr));
+        HIPCHK(hipMemcpyAsync(c.h_tbase.p, j.d_tbase, ((size_t)j.nsub + 1) * 4, hipMemcpyDeviceToHost, c.stream));
+    }
+
+    /* -- the priority recurrence across the cuts (tree.c:202-231): all shards iterate together -- */
+    {
+        std::vector<uint32_t> v(usb);
+        std::vector<char> flipped(D, 0);
+        const uint16_t *d_sdest = nullptr;
+        const uint32_t *d_sloc = nullptr;
+        int max_iters = 1 << 30;
+        uint32_t iters = 0;
+        for (int it = 0; it < max_iters; it++) {
+            for (size_t d = 0; d + 1 < D; d++) {            /* the last shard's whole map is nobody's input */
+                ShardJob &j = J[d];
+                if ((rc = dev(j))) return rc;
+                HIPCHK(lz77k_prio_maps(j.P, j.c->stream, true, &d_sdest, &d_sloc));
+                if (j.nx) {
+                    HIPCHK(hipMemcpyAsync(j.h + 512, d_sloc, usb * 4, hipMemcpyDeviceToHost, j.c->stream));
+                    HIPCHK(hipMemcpyAsync(j.h + 512 + usb, d_sdest, usb * 2, hipMemcpyDeviceToHost, j.c->stream));
+                }
+            }
+            if (D > 0) {
+                ShardJob &j = J[D - 1];
+                if ((rc = dev(j))) return rc;
+                HIPCHK(lz77k_prio_maps(j.P, j.c->stream, false, nullptr, nullptr));
+            }
+            if ((rc = sync_all())) return rc;
+            for (size_t i = 0; i < usb; i++) v[i] = (uint32_t)i;          /* the start of the input: every cell its own position */
+            for (size_t d = 0; d < D; d++) {
+                ShardJob &j = J[d];
+                if ((rc = dev(j))) return rc;
+                if (d > 0) {
+                    uint32_t *pin = j.h + 512 + 2 * usb;                /* pinned copy of the cells this shard starts from */
+                    memcpy(pin, v.data(), usb * 4);
+                    HIPCHK(lz77k_prio_set_in0(j.P, pin, hipMemcpyHostToDevice, j.c->stream));
+                }
+                if (d + 1 < D) {                                       /* v <- this shard's whole map applied to v */
+                    if (j.nx == 0) continue;                           /* no step: the cells pass through */
+                    lz77x_shard_compose_cells(reinterpret_cast<const uint16_t *>(j.h + 512 + usb), j.h + 512, g.sb, v.data());
+                }
+            }
+            for (ShardJob &j : J) {
+                if ((rc = dev(j))) return rc;
+                HIPCHK(lz77k_prio_sweep(j.P, j.c->stream, j.c->h_small.as<uint32_t>() + 8, nullptr));
+            }
+            if ((rc = sync_all())) return rc;
+            iters++;
+            bool any = false, earlier = false;
+            for (size_t d = 0; d < D; d++) {
+                const uint32_t *hf = J[d].c->h_small.as<uint32_t>() + 8;
+                flipped[d] = hf[0] != 0;
+                /* a shard after one that still changes may be handed different cells next time: nothing of it is final */
+                lz77k_prio_advance(J[d].P, hf, earlier);
+                earlier = earlier || flipped[d];
+                any = any || flipped[d];
+            }
+            if (!any) break;
+        }
+        g_stats.prio_iters = iters;
+    }
+
+    /* -- tokens: every shard resolves its own (look-back priorities = the cells it started from) -- */
+    for (ShardJob &j : J) {
+        Ctx &c = *j.c;
+        if ((rc = dev(j))) return rc;
+        hipStream_t s = c.stream;
+        const uint32_t *h_tbase = c.h_tbase.as<uint32_t>();
+        if (h_tbase[j.nsub] != j.ntok) { snprintf(g_err, sizeof g_err, "shard chain mismatch: %u vs %u", h_tbase[j.nsub], j.ntok); return LZ77X_E_HIP; }
+        const uint32_t *look = j.look ? reinterpret_cast<const uint32_t *>(reinterpret_cast<const uint8_t *>(j.P.tmp) + j.P.o_in) : nullptr;
+        const size_t b = j.start, e = j.E;
+        if (e > b) {
+            const size_t x_done = e > usb ? e - usb : 0;
+            const uint32_t dbase = b > usb ? (uint32_t)(b - usb) : 0u;
+            const uint32_t xa = dbase > (uint32_t)g.sb ? dbase - (uint32_t)g.sb : 0u;
+            HIPCHK(lz77k_xfer_index(c.ps.as<uint32_t>(), c.xval.as<uint32_t>(), xa, (uint32_t)x_done, dbase, (uint32_t)e, c.ofs.as<uint32_t>(),
+                                    c.ent.as<uint2>(), c.scantmp.p, s, 0u, c.flag.as<unsigned long long>() + 1));
+            HIPCHK(lz77k_tokens(c.in.as<uint8_t>(), j.nloc, g, c.chain.as<uint32_t>(), j.ntok, c.maxlen.as<uint8_t>(), c.ofs.as<uint32_t>(),
+                                c.ent.as<uint2>(), dbase, (uint32_t)b, (uint32_t)e, c.tokval.as<uint32_t>() + 4, c.tstart.as<uint32_t>(), nullptr,
+                                tvariant, s, nullptr, nullptr, look, j.look, (uint32_t)j.gpos0));
+        }
+        const uint32_t have = j.ntok < 4 ? j.ntok : 4;
+        if (have) HIPCHK(hipMemcpyAsync(j.h, c.tokval.as<uint32_t>() + 4 + j.ntok - have, have * 4, hipMemcpyDeviceToHost, s));
+        j.h[8] = have;
+    }
+    if ((rc = sync_all())) return rc;
+
+    /* -- pack (lz77.c:246-252): each shard the stream words its tokens start in, with its predecessors' last
+     *    tokens in front; then the pieces leave in order -- */
+    const uint64_t T = (uint64_t)g.T;
+    const uint64_t K_all = D ? J[D - 1].K0 + J[D - 1].ntok : 0;
+    const uint64_t zn_total = stream_bytes(K_all, g.T);
+    uint32_t tail[4] = {0, 0, 0, 0};
+    uint32_t ntail = 0;
+    std::vector<uint64_t> piece(D, 0);
+    for (size_t d = 0; d < D; d++) {
+        ShardJob &j = J[d];
+        Ctx &c = *j.c;
+        if ((rc = dev(j))) return rc;
+        const bool last = d + 1 == D;
+        const uint64_t K0 = j.K0, K1 = K0 + j.ntok;
+        const uint64_t wlo = K0 == 0 ? 0 : (32 + K0 * T) / 32;
+        const uint64_t whi = last ? (zn_total + 3) / 4 : (32 + K1 * T) / 32;
+        const uint64_t nw = whi > wlo ? whi - wlo : 0;
+        if ((rc = c.out.need(nw * 4 + 16))) return rc;
+        uint32_t *pin = j.h + 16;
+        memcpy(pin, tail, sizeof tail);
+        if (ntail) HIPCHK(hipMemcpyAsync(c.tokval.as<uint32_t>() + 4 - ntail, pin + 4 - ntail, ntail * 4, hipMemcpyHostToDevice, c.stream));
+        HIPCHK(lz77k_pack_range(c.tokval.as<uint32_t>() + 4 - ntail, K0 - ntail, K1, g, c.out.as<uint32_t>(), wlo, nw, c.stream));
+        piece[d] = last ? zn_total - 4 * wlo : 4 * nw;
+        /* the last four tokens so far */
+        const uint32_t have = j.h[8];
+        uint32_t merged[8], m = 0;
+        for (uint32_t i = 0; i < ntail; i++) merged[m++] = tail[4 - ntail + i];
+        for (uint32_t i = 0; i < have; i++) merged[m++] = j.h[i];
+        ntail = m < 4 ? m : 4;
+        for (uint32_t i = 0; i < ntail; i++) tail[4 - ntail + i] = merged[m - ntail + i];
+    }
+    for (size_t d = 0; d < D; d++) {
+        ShardJob &j = J[d];
+        if ((rc = dev(j))) return rc;
+        if ((rc = sink.write(*j.c, j.c->out.as<uint8_t>(), (size_t)piece[d], j.c->stream))) return rc;
+        unsigned long long cnt = 0;
+        HIPCHK(hipMemcpy(&cnt, j.c->flag.as<unsigned long long>() + 1, 8, hipMemcpyDeviceToHost));
+        g_stats.transfers += cnt;
+    }
+    HIPCHK(hipSetDevice(cs[0]->device));
+    g_stats.n = n;
+    g_stats.zn = sink.total;
+    g_stats.ntok = K_all;
+    g_stats.total_ms = now_ms() - t_begin;
+    TRACE("encode_sharded total", t_begin);
+    return LZ77X_OK;
+}
+
 /* Which pipeline an encode takes: everything on the device when the geometry allows it (one device,
  * sb <= 4096, production kernels), the round-1 pipeline with the two recurrences on host cores
  * otherwise (LZ77X_HOST_STAGEB=1 forces it) or when the gate iteration gives up. */
@@ -1412,6 +1713,8 @@ int encode_any(std::vector<Ctx *> &cs, const void *src, bool src_on_device, size
     const void *host_src = src;
     bool host_on_device = src_on_device;
     uint32_t iters = 0;                                    /* gate iterations spent before giving up */
+    if (cs.size() > 1 && !src_on_device && device_pipeline_ok(1, g))
+        return encode_sharded(cs, reinterpret_cast<const uint8_t *>(src), n, g, sink);
     if (device_pipeline_ok(cs.size(), g)) {
         MemSource ms(src, n, src_on_device);
         bool fallback = false;
@@ -1829,5 +2132,38 @@ int lz77x_stage_chain_device(const uint8_t *maxlen, size_t n, int la, uint32_t *
     *ntok = total;
     return LZ77X_OK;
 }
+
+/* several files at once: a thread per file in flight, each leasing its own device context (the lease blocks
+ * further threads until a context is free), which is what overlaps the kernels of one file with the host
+ * work and the transfers of the others */
+static int run_files(int n_files, FILE **in, FILE **out, int la, int sb, int *rcs, bool enc)
+{
+    if (n_files < 0 || (n_files && (!in || !out))) return LZ77X_E_ARG;
+    int cur = -1;
+    if (hipGetDevice(&cur) != hipSuccess) cur = -1;
+    std::vector<int> rc((size_t)n_files, LZ77X_OK);
+    std::atomic<int> next{0};
+    auto work = [&]() {
+        if (cur >= 0) { hipError_t e = hipSetDevice(cur); (void)e; }
+        for (int i = next.fetch_add(1); i < n_files; i = next.fetch_add(1))
+            rc[(size_t)i] = enc ? lz77x_encode_file(in[i], out[i], la, sb) : lz77x_decode_file(in[i], out[i]);
+    };
+    int lanes = 4;
+    { const char *e = getenv("LZ77X_MAX_CONTEXTS"); if (e && atoi(e) > 0) lanes = atoi(e); }
+    if (lanes > n_files) lanes = n_files;
+    std::vector<std::thread> th;
+    for (int t = 1; t < lanes; t++) th.emplace_back(work);
+    if (n_files) work();
+    for (auto &t : th) t.join();
+    int first = LZ77X_OK;
+    for (int i = 0; i < n_files; i++) {
+        if (rcs) rcs[i] = rc[(size_t)i];
+        if (first == LZ77X_OK && rc[(size_t)i] != LZ77X_OK) first = rc[(size_t)i];
+    }
+    return first;
+}
+
+int lz77x_encode_files(int n_files, FILE **in, FILE **out, int la, int sb, int *rc) { return run_files(n_files, in, out, la, sb, rc, true); }
+int lz77x_decode_files(int n_files, FILE **in, FILE **out, int *rc) { return run_files(n_files, in, out, 0, 0, rc, false); }
 
 }  // extern "C"

@@ -1,16 +1,18 @@
-"""Host-side sharding plan for multi-GPU runs -- pure Python, no GPU needed.
+"""Host side of multi-GPU runs -- bindings of the library's own plan, no GPU needed.
 
 Two ways the path shards, neither needs a data-path collective:
 
-* independent streams (what bench.py measures at N>1): rank r encodes/decodes its own
+* independent streams (what bench.py measures at N>1, `--mode files`): rank r encodes/decodes its own
   stream; `stream_seed` gives each rank a distinct deterministic input.
-* one stream cut by position (`plan_positions`): rank r owns the k_match regions whose tile
-  starts fall in [begin, end); it reads the halo [begin-SBu, end+SB+LA) of the input
-  read-only.  The per-position results (ps, maxlen) are concatenated on the host, which
-  runs the sequential stage once over the whole stream.
+* ONE stream cut by position (`plan`, bench.py `--mode shard`): shard d emits the tokens whose position
+  lies in [first_token_pos, end_token_pos) and holds only its own bytes (sb of look-back, the look-ahead).
+  The two sequential loops of lz77.c cross the cuts as small maps that the host chains:
+  `compose_chain` (parse position / token count) and `compose_cells` (priorities of the sb live cells).
+  These call the exact functions the library uses inside lz77x_encode when lz77x_set_shards(D) > 1.
 """
 from __future__ import annotations
 
+import ctypes
 from dataclasses import dataclass
 
 
@@ -36,31 +38,55 @@ def stream_seed(base_seed: int, rank: int) -> int:
     return (base_seed + rank) & 0xFFFFFFFFFFFFFFFF
 
 
+class _CShard(ctypes.Structure):
+    _fields_ = [("first_token_pos", ctypes.c_uint64), ("end_token_pos", ctypes.c_uint64), ("local0", ctypes.c_uint64),
+                ("local_bytes", ctypes.c_uint64), ("steps", ctypes.c_uint64), ("lookback", ctypes.c_uint32),
+                ("reserved", ctypes.c_uint32)]
+
+
 @dataclass(frozen=True)
 class Shard:
     rank: int
-    region0: int        # first k_match region
-    nregions: int
-    begin: int          # first position produced
-    end: int            # one past the last position produced
-    halo_begin: int     # first input byte read
-    halo_end: int       # one past the last input byte read
+    first_token_pos: int    # the shard emits the tokens whose position lies in [first, end)
+    end_token_pos: int
+    local0: int             # global position of the first byte the device holds
+    local_bytes: int        # look-back + shard + look-ahead
+    steps: int              # evictions it simulates: global [local0, end_token_pos - sb)
+    lookback: int           # sb, 0 for the first shard
 
 
-def plan_positions(n: int, world: int, sb: int, la: int) -> list:
-    """Split the regions of an n-byte stream into `world` contiguous, nearly equal shards."""
-    g = geometry(sb, la)
-    tile = g["TILE"]
-    nreg = (n + tile - 1) // tile
-    out = []
-    for r in range(world):
-        r0 = nreg * r // world
-        r1 = nreg * (r + 1) // world
-        b, e = min(r0 * tile, n), min(r1 * tile, n)
-        # a shard that does not start at 0 also runs the region before its first one (lz77x_internal.h)
-        out.append(Shard(r, r0, r1 - r0, b, e, max(0, b - tile) if e > b else b,
-                         min(n, e + sb + la) if e > b else b))
-    return out
+def plan(n: int, shards: int, sb: int, la: int) -> list:
+    """lz77x_shard_plan: how the library cuts an n-byte stream for `shards` devices (it may use fewer)."""
+    from . import lib
+    arr = (_CShard * max(shards, 1))()
+    d = lib().lz77x_shard_plan(n, sb, la, shards, ctypes.addressof(arr))
+    if d < 1:
+        raise ValueError("lz77x_shard_plan(%d, %d, %d, %d) -> %d" % (n, sb, la, shards, d))
+    return [Shard(r, int(a.first_token_pos), int(a.end_token_pos), int(a.local0), int(a.local_bytes), int(a.steps), int(a.lookback))
+            for r, a in enumerate(arr[:d])]
+
+
+def compose_cells(dest, loc, cells):
+    """lz77x_shard_compose_cells: cells (uint32[sb], in place) <- one shard's boundary map applied to them."""
+    import numpy as np
+    from . import lib
+    dest = np.ascontiguousarray(dest, dtype=np.uint16)
+    loc = np.ascontiguousarray(loc, dtype=np.uint32)
+    assert cells.dtype == np.uint32 and cells.flags.c_contiguous and dest.size == loc.size == cells.size
+    lib().lz77x_shard_compose_cells(dest.ctypes.data, loc.ctypes.data, int(cells.size), cells.ctypes.data)
+    return cells
+
+
+def compose_chain(exit_of, tokens_of, entry: int, tokens: int):
+    """lz77x_shard_compose_chain: (entry offset, tokens so far) after one shard's parse-chain map."""
+    import numpy as np
+    from . import lib
+    ex = np.ascontiguousarray(exit_of, dtype=np.uint8)
+    tk = np.ascontiguousarray(tokens_of, dtype=np.uint32)
+    e = ctypes.c_uint32(entry)
+    t = ctypes.c_uint64(tokens)
+    lib().lz77x_shard_compose_chain(ex.ctypes.data, tk.ctypes.data, ctypes.byref(e), ctypes.byref(t))
+    return int(e.value), int(t.value)
 
 
 def aggregate_time(dt: float, dist=None) -> float:

@@ -158,25 +158,96 @@ def test_reference_main_through_shim_cli_contract(tmp_path):
 # ---- multi-rank plan (gloo, 2 processes) ------------------------------------------------
 
 _WORKER = r"""
+# One stream cut over the ranks: every rank derives ITS shard's two hand-over maps from the oracle's view of
+# its own range, the maps are all-gathered, and the LIBRARY's host functions (the ones lz77x_encode uses when
+# lz77x_set_shards(D) > 1) plan the cut and chain the maps.  Checked against the sequential oracle.
 import os, sys
-sys.path.insert(0, %(root)r)
+sys.path.insert(0, %(root)r); sys.path.insert(0, os.path.join(%(root)r, "tests"))
+import numpy as np
 import torch, torch.distributed as dist
-from lz77_amd import shard
+import oracle_lib as O
+from lz77_amd import shard, synth
 dist.init_process_group("gloo")
 rank, world = dist.get_rank(), dist.get_world_size()
-n, sb, la = 100_000_037, 4095, 15
-plan = shard.plan_positions(n, world, sb, la)
-mine = plan[rank]
-sizes = torch.tensor([mine.end - mine.begin, mine.nregions], dtype=torch.int64)
-allsz = [torch.zeros(2, dtype=torch.int64) for _ in range(world)]
-dist.all_gather(allsz, sizes)
-assert sum(int(s[0]) for s in allsz) == n
-g = shard.geometry(sb, la)
-assert sum(int(s[1]) for s in allsz) == (n + g["TILE"] - 1) // g["TILE"]
+n, sb, la = 90_000, 1000, 10
+data = synth.text(n, 77)
+plan = shard.plan(n, world, sb, la)
+assert len(plan) == world and plan[0].first_token_pos == 0 and plan[-1].end_token_pos == n
 for a, b in zip(plan, plan[1:]):
-    assert a.end == b.begin and a.region0 + a.nregions == b.region0
-assert mine.halo_begin <= mine.begin and mine.halo_end >= mine.end
-assert mine.begin - mine.halo_begin in (0, g["TILE"]) and mine.halo_end - mine.end <= sb + la
+    assert a.end_token_pos == b.first_token_pos and b.local0 == b.first_token_pos - sb and b.lookback == sb
+    assert a.local0 + a.local_bytes >= a.end_token_pos + la             # look-ahead of the last token
+assert plan[-1].local0 + plan[-1].local_bytes == n
+mine = plan[rank]
+
+# ---- the oracle's sequential truth (every rank computes it; inputs are tiny) ----
+P, S, two = O.stage_a(data, sb, la, tree=True)
+P, S = P.astype(np.int64), S.astype(np.int64)
+ml = O.maxlen(data, sb, la).astype(np.int64)
+nx = n - sb
+val = np.arange(n, dtype=np.int64)
+gate = np.zeros(nx, dtype=bool)
+state_at = {}                                   # step -> cells [step, step+sb) before that step
+for x in range(nx):
+    if x in {p.local0 for p in plan}:
+        state_at[x] = val[x:x + sb].copy()
+    if P[x] and S[x]:
+        a = val[x]
+        gate[x] = a < val[x + P[x]]
+        if gate[x] and a < val[x + S[x]]:
+            val[x + S[x]] = a
+chain = []
+p = 0
+while p < n:
+    chain.append(p)
+    p += int(ml[p]) + 1
+chain = np.asarray(chain)
+
+# ---- this rank's maps, from its own range only (definition of k_prio_back / k_chain_map) ----
+x0, x1 = mine.local0, mine.local0 + mine.steps          # its steps
+dest = np.full(sb, 0xFFFF, dtype=np.uint16)
+loc = (x1 + np.arange(sb)).astype(np.uint32)
+dmap = {}
+for x in range(x1 - 1, x0 - 1, -1):
+    d = None
+    if gate[x]:
+        t = x + int(S[x])
+        d = t - x1 if t >= x1 else dmap.get(t)
+    dmap[x] = d
+    if d is not None:
+        loc[d] = min(int(loc[d]), x)
+for i in range(sb):
+    if x0 + i < x1 and dmap.get(x0 + i) is not None:
+        dest[i] = dmap[x0 + i]
+a0, a1 = mine.first_token_pos, mine.end_token_pos
+exit_of = np.zeros(256, dtype=np.uint8)
+tokens_of = np.zeros(256, dtype=np.uint32)
+for e in range(la):
+    q, c = a0 + e, 0
+    while q < a1:
+        q += int(ml[q]) + 1
+        c += 1
+    exit_of[e], tokens_of[e] = q - a1, c
+
+# ---- exchange (gloo), then the library's host functions chain the shards ----
+def gather(t):
+    out = [torch.zeros_like(t) for _ in range(world)]
+    dist.all_gather(out, t)
+    return [o.numpy() for o in out]
+dests = gather(torch.from_numpy(dest.astype(np.int32)))
+locs = gather(torch.from_numpy(loc.astype(np.int64)))
+exits = gather(torch.from_numpy(exit_of.astype(np.int32)))
+counts = gather(torch.from_numpy(tokens_of.astype(np.int64)))
+cells = np.arange(sb, dtype=np.uint32)
+entry, ntok = 0, 0
+for d in range(world):
+    if d == rank:
+        want = state_at[mine.local0]
+        assert np.array_equal(cells.astype(np.int64), want), "cells this shard starts from"
+        first = chain[np.searchsorted(chain, a0)]
+        assert first == a0 + entry and np.searchsorted(chain, a0) == ntok, "parse position / token index at the cut"
+    shard.compose_cells(dests[d].astype(np.uint16), locs[d].astype(np.uint32), cells)
+    entry, ntok = shard.compose_chain(exits[d].astype(np.uint8), counts[d].astype(np.uint32), entry, ntok)
+assert ntok == chain.size and entry == 0
 seeds = [shard.stream_seed(0x5EED0001, r) for r in range(world)]
 assert len(set(seeds)) == world
 t = shard.aggregate_time(1.0 + rank, dist)
@@ -187,15 +258,26 @@ print("rank", rank, "ok")
 """
 
 
-def test_two_rank_plan_gloo(tmp_path):
+def test_two_rank_shard_exchange_gloo(tmp_path):
+    """world_size 2 on CPU: the library's own shard plan and its two host-side compositions (priority cells,
+    parse chain), fed with per-rank maps exchanged over gloo, reproduce the sequential oracle at the cut"""
     script = tmp_path / "w.py"
     script.write_text(_WORKER % {"root": ROOT})
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", LZ77X_NO_TORCH="1")
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
                         "--master-addr", "127.0.0.1", "--master-port", "29541", str(script)],
-                       capture_output=True, text=True, env=env, timeout=240)
+                       capture_output=True, text=True, env=env, timeout=600)
     assert r.returncode == 0, r.stdout + r.stderr
     assert r.stdout.count("ok") == 2
+
+
+def test_shard_plan_properties():
+    for n, sb, la, want in ((1_000_000_000, 4095, 15, 8), (100_000, 4095, 15, 3), (50_000, 4095, 15, 1), (10 << 20, 1000, 10, 8)):
+        plan = shard.plan(n, 8, sb, la)
+        assert len(plan) == want
+        assert plan[0].first_token_pos == 0 and plan[-1].end_token_pos == n and plan[0].lookback == 0
+        assert sum(p.end_token_pos - p.first_token_pos for p in plan) == n
+        assert max(p.local_bytes for p in plan) <= n // len(plan) + sb + la + 65      # memory per device ~ n / D
 
 
 def test_numa_binding_helper_is_best_effort():
