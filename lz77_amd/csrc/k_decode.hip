@@ -8,7 +8,7 @@
 
 /* lz77.c:260-283 + bitio.c:256-298: fixed-width tokens, so token k is simply bits [32+kT, ..) */
 __global__ void k_dec_parse(const uint8_t *__restrict__ z, uint32_t ntok, int ob, int lb, int T,
-                            uint32_t *__restrict__ tokval, uint32_t *__restrict__ len1)
+                            uint32_t *__restrict__ tokval, uint32_t *__restrict__ len1, uint32_t *__restrict__ stale_flag)
 {
     const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= ntok) return;
@@ -16,13 +16,19 @@ __global__ void k_dec_parse(const uint8_t *__restrict__ z, uint32_t ntok, int ob
     uint64_t v = ld64u(z + (bit >> 3)) >> (bit & 7);
     v &= T >= 32 ? 0xFFFFFFFFull : ((1ull << T) - 1);
     tokval[k] = (uint32_t)v;
-    len1[k] = (((uint32_t)v >> ob) & ((1u << lb) - 1u)) + 1u;
+    const uint32_t off = ob ? ((uint32_t)v & ((1u << ob) - 1u)) : 0u, len = ((uint32_t)v >> ob) & ((1u << lb) - 1u);
+    len1[k] = len + 1u;
+    /* a copy from distance 0: the reference's encoder emits it when -s is a power of two (the offset sb does
+     * not fit its field); its decoder then reads whatever its cyclic buffer holds (lz77.c:178-181) */
+    if (off == 0 && len > 0 && stale_flag) *stale_flag = 1u;
 }
 
 /* lz77.c:178-194 as data flow: every copied byte j points at j-off, every literal at itself.
  * Position n is a zero byte that degenerate tokens (off==0 or off>j) point at. */
 __global__ void k_dec_expand(const uint32_t *__restrict__ tokval, const uint32_t *__restrict__ dst, uint32_t ntok,
-                             int ob, int lb, uint8_t *__restrict__ out, uint32_t *__restrict__ ptr, uint32_t n)
+                             int ob, int lb, uint8_t *__restrict__ out, uint32_t *__restrict__ ptr, uint32_t n,
+                             const uint32_t *__restrict__ cyc /* output offsets at which the reference's buffer wraps */,
+                             uint32_t ncyc, uint32_t sb)
 {
     const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k == 0) { out[n] = 0; ptr[n] = n; }
@@ -32,6 +38,29 @@ __global__ void k_dec_expand(const uint32_t *__restrict__ tokval, const uint32_t
     const uint32_t len = (v >> ob) & ((1u << lb) - 1u);
     const uint32_t lit = (v >> (ob + lb)) & 0xFFu;
     const uint32_t j0 = dst[k];
+    if (off == 0 && len > 0 && cyc) {
+        /* lz77.c:178-181 with off == back: buffer[back] = buffer[back], i.e. the byte the reference's
+         * 3*SB+LA staging buffer still holds at that index: the output byte that was stored there the last
+         * time the buffer passed it, or 0 (calloc, lz77.c:162).  cyc[c] = output offset of the first byte
+         * of pass c (pass 0 starts at buffer index 0, every later one at index sb, lz77.c:172-175). */
+        uint32_t lo = 0, hi = ncyc;                           /* last pass that starts at or before j0 */
+        while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (cyc[mid] <= j0) lo = mid; else hi = mid; }
+        const uint32_t c = lo, idx0 = (c ? sb : 0u) + (j0 - cyc[c]);
+        for (uint32_t i = 0; i < len; i++) {
+            const uint32_t idx = idx0 + i;
+            uint32_t src = n;
+            for (uint32_t cc = c; cc-- > 0;) {
+                const uint32_t b0 = cc ? sb : 0u;
+                if (idx < b0) break;                          /* below sb every pass rewrites the index: never read stale */
+                const uint32_t cand = cyc[cc] + (idx - b0);
+                if (cand < cyc[cc + 1]) { src = cand; break; }   /* pass cc got that far */
+            }
+            ptr[j0 + i] = src;
+        }
+        out[j0 + len] = (uint8_t)lit;
+        ptr[j0 + len] = j0 + len;
+        return;
+    }
     for (uint32_t i = 0; i < len; i++) {
         const uint32_t j = j0 + i;
         ptr[j] = (off > 0 && off <= j) ? j - off : n;
@@ -109,17 +138,19 @@ __global__ void k_dec_gather(uint8_t *__restrict__ out, const uint32_t *__restri
     }
 }
 
-hipError_t lz77k_dec_parse(const uint8_t *d_z, uint32_t ntok, const lz77x_geom &g, uint32_t *d_tokval, uint32_t *d_len1, hipStream_t s)
+hipError_t lz77k_dec_parse(const uint8_t *d_z, uint32_t ntok, const lz77x_geom &g, uint32_t *d_tokval, uint32_t *d_len1, hipStream_t s,
+                           uint32_t *d_stale_flag)
 {
     if (ntok == 0) return hipSuccess;
-    hipLaunchKernelGGL(k_dec_parse, dim3((ntok + 255) / 256), dim3(256), 0, s, d_z, ntok, g.ob, g.lb, g.T, d_tokval, d_len1);
+    hipLaunchKernelGGL(k_dec_parse, dim3((ntok + 255) / 256), dim3(256), 0, s, d_z, ntok, g.ob, g.lb, g.T, d_tokval, d_len1, d_stale_flag);
     return hipGetLastError();
 }
 
 hipError_t lz77k_dec_expand(const uint32_t *d_tokval, const uint32_t *d_dst, uint32_t ntok, const lz77x_geom &g,
-                            uint8_t *d_out, uint32_t *d_ptr, uint32_t n, hipStream_t s)
+                            uint8_t *d_out, uint32_t *d_ptr, uint32_t n, hipStream_t s, const uint32_t *d_cyc, uint32_t ncyc)
 {
-    hipLaunchKernelGGL(k_dec_expand, dim3(ntok ? (ntok + 255) / 256 : 1), dim3(256), 0, s, d_tokval, d_dst, ntok, g.ob, g.lb, d_out, d_ptr, n);
+    hipLaunchKernelGGL(k_dec_expand, dim3(ntok ? (ntok + 255) / 256 : 1), dim3(256), 0, s, d_tokval, d_dst, ntok, g.ob, g.lb, d_out, d_ptr, n,
+                       d_cyc, ncyc, (uint32_t)g.sb);
     return hipGetLastError();
 }
 

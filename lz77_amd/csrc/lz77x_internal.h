@@ -192,10 +192,14 @@ hipError_t lz77k_pack(const uint32_t *d_tokval, uint64_t ntok, const lz77x_geom 
 hipError_t lz77k_pack_range(const uint32_t *d_tokval, uint64_t k_first, uint64_t k_end, const lz77x_geom &g, uint32_t *d_out_words,
                             uint64_t w0, uint64_t nw, hipStream_t s);
 
+/* *d_stale_flag (may be null) is set when a token copies from distance 0 (power-of-two -s) */
 hipError_t lz77k_dec_parse(const uint8_t *d_z, uint32_t ntok, const lz77x_geom &g,
-                           uint32_t *d_tokval, uint32_t *d_len1, hipStream_t s);
+                           uint32_t *d_tokval, uint32_t *d_len1, hipStream_t s, uint32_t *d_stale_flag = nullptr);
+/* d_cyc[0..ncyc]: output offsets at which the reference's staging buffer starts a new pass (+ a final n), for
+ * the distance-0 copies; null when the stream has none */
 hipError_t lz77k_dec_expand(const uint32_t *d_tokval, const uint32_t *d_dst, uint32_t ntok,
-                            const lz77x_geom &g, uint8_t *d_out, uint32_t *d_ptr, uint32_t n, hipStream_t s);
+                            const lz77x_geom &g, uint8_t *d_out, uint32_t *d_ptr, uint32_t n, hipStream_t s,
+                            const uint32_t *d_cyc = nullptr, uint32_t ncyc = 0);
 /* one pass over in_list[0..total) (or over every j < total when in_list is null); entries that moved are
  * appended to out_list, *out_count += their number */
 hipError_t lz77k_dec_jump(uint32_t *d_ptr, uint32_t total, const uint32_t *d_in_list, uint32_t *d_out_list, uint32_t *d_out_count,

@@ -800,13 +800,16 @@ int decode_core(Ctx &c, size_t zn, hipStream_t s, bool want_data, size_t *n_out)
     const uint32_t ntok = (uint32_t)ntok64;
 
     uint64_t n = 0;
+    bool stale = false;                       /* the stream copies from distance 0 somewhere (power-of-two -s) */
     HIPCHK(hipEventRecord(c.ev[0], s));
     if (ntok) {
         if ((rc = c.tokval.need(((size_t)ntok + 8) * 4))) return rc;
         if ((rc = c.len1.need(((size_t)ntok + 8) * 4))) return rc;
         if ((rc = c.dst.need(((size_t)ntok + 8) * 4))) return rc;
         if ((rc = c.scantmp.need(lz77k_scan_tmp_bytes(ntok + 1)))) return rc;
-        HIPCHK(lz77k_dec_parse(c.z.as<uint8_t>(), ntok, g, c.tokval.as<uint32_t>(), c.len1.as<uint32_t>(), s));
+        if ((rc = c.flag.need(64))) return rc;
+        HIPCHK(hipMemsetAsync(c.flag.as<uint32_t>() + 8, 0, 4, s));
+        HIPCHK(lz77k_dec_parse(c.z.as<uint8_t>(), ntok, g, c.tokval.as<uint32_t>(), c.len1.as<uint32_t>(), s, c.flag.as<uint32_t>() + 8));
         HIPCHK(hipMemsetAsync(c.len1.as<uint32_t>() + ntok, 0, 4, s));
         /* decoded size can exceed 32 bits for hostile streams: bound it (64-bit sum on the device)
          * before trusting the 32-bit scan */
@@ -821,8 +824,10 @@ int decode_core(Ctx &c, size_t zn, hipStream_t s, bool want_data, size_t *n_out)
         HIPCHK(lz77k_scan_u32(c.len1.as<uint32_t>(), c.dst.as<uint32_t>(), ntok + 1, c.scantmp.p, s));
         uint32_t *tot = reinterpret_cast<uint32_t *>(hdr + 16);
         HIPCHK(hipMemcpyAsync(tot, c.dst.as<uint32_t>() + ntok, 4, hipMemcpyDeviceToHost, s));
+        HIPCHK(hipMemcpyAsync(tot + 1, c.flag.as<uint32_t>() + 8, 4, hipMemcpyDeviceToHost, s));
         HIPCHK(hipStreamSynchronize(s));
         n = *tot;
+        stale = tot[1] != 0;
     }
     *n_out = (size_t)n;
     uint32_t rounds = 0;
@@ -831,8 +836,48 @@ int decode_core(Ctx &c, size_t zn, hipStream_t s, bool want_data, size_t *n_out)
         if ((rc = c.out.need(n + 16))) return rc;
         if ((rc = c.ptr.need((n + 8) * 4))) return rc;
         if ((rc = c.flag.need(64))) return rc;
+        const uint32_t *d_cyc = nullptr;
+        uint32_t ncyc = 0;
+        if (stale) {
+            /* The reference's decoder stages its output in a buffer of W = 3*SB+LA bytes that restarts at index
+             * SB whenever the next token would not fit (lz77.c:172-175); a copy from distance 0 re-reads the byte
+             * an earlier pass left at the same index.  Where the passes begin is a sequential function of the
+             * token lengths -- one step per ~2*SB bytes of output: walked here on the host over dst[] (only
+             * streams from a power-of-two -s ever come this way). */
+            std::vector<uint32_t> hdst((size_t)ntok + 1);
+            HIPCHK(hipMemcpy(hdst.data(), c.dst.p, ((size_t)ntok + 1) * 4, hipMemcpyDeviceToHost));
+            const uint64_t W = 3 * (uint64_t)g.sb + (uint64_t)g.la;
+            const uint32_t lmax = (1u << g.lb) - 1u;
+            std::vector<uint32_t> cyc;
+            cyc.push_back(0);
+            uint32_t ks = 0;
+            for (;;) {
+                const uint64_t back0 = cyc.size() == 1 ? 0 : (uint64_t)g.sb, J = hdst[ks];
+                /* first token k >= ks with back0 + (dst[k] - J) + len_k > W - 1 */
+                uint32_t lo = ks, hi = ntok;                  /* tokens below lo certainly fit */
+                const uint64_t safe = W - 1 > lmax ? W - 1 - lmax : 0;
+                while (lo < hi) {                             /* first k whose start is past the always-safe zone */
+                    const uint32_t mid = lo + (hi - lo) / 2;
+                    if (back0 + (hdst[mid] - J) <= safe) lo = mid + 1; else hi = mid;
+                }
+                uint32_t k = lo > ks ? lo - 1 : ks;
+                for (; k < ntok; k++) {
+                    const uint64_t len = (uint64_t)hdst[k + 1] - hdst[k] - 1;
+                    if (back0 + (hdst[k] - J) + len > W - 1) break;
+                }
+                if (k >= ntok) break;
+                if (k == ks && cyc.size() > 1 && back0 + ((uint64_t)hdst[k + 1] - hdst[k] - 1) > W - 1) break;   /* a token longer than the buffer: malformed */
+                cyc.push_back(hdst[k]);
+                ks = k;
+            }
+            cyc.push_back(n32);
+            ncyc = (uint32_t)cyc.size() - 1;
+            if ((rc = c.scratch.need(cyc.size() * 4 + 64))) return rc;
+            HIPCHK(hipMemcpy(c.scratch.p, cyc.data(), cyc.size() * 4, hipMemcpyHostToDevice));
+            d_cyc = c.scratch.as<uint32_t>();
+        }
         HIPCHK(lz77k_dec_expand(c.tokval.as<uint32_t>(), c.dst.as<uint32_t>(), ntok, g, c.out.as<uint8_t>(),
-                                c.ptr.as<uint32_t>(), n32, s));
+                                c.ptr.as<uint32_t>(), n32, s, d_cyc, ncyc));
         /* work lists of the pointer-jumping passes (encode's ps/cells buffers are idle during a decode) */
         if ((rc = c.ps.need((n + 8) * 4))) return rc;
         if ((rc = c.cells.need((n + 8) * 4))) return rc;
