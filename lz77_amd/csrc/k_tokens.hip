@@ -47,13 +47,111 @@ __global__ void k_xfer_fill(const uint32_t *__restrict__ ps, const uint32_t *__r
     }
 }
 
+/* The same index built destination block by destination block: a workgroup owns XF_DB consecutive
+ * destinations; a hand-over x -> x + S[x] reaches at most sb - 1 positions ahead, so it only has to look at the
+ * evictions of its own range and the sb before it (1.5x the range at sb 4095).  Counting and slot assignment
+ * then happen in LDS; the only global pass over all destinations is the write of ofs[] itself.  (Round 1 used
+ * one global atomic per hand-over, twice, plus a three-kernel scan over every destination: 4.1 ms per 100 MB.) */
+#define XF_DB 8192u
+#define XF_THREADS 1024
+
+__global__ __launch_bounds__(XF_THREADS) void k_xfer_blocksum(const uint32_t *__restrict__ ps, const uint32_t *__restrict__ xval, uint32_t xa,
+                                                             uint32_t xb, uint32_t dbase, uint32_t dend, uint32_t sb,
+                                                             uint32_t *__restrict__ blocksum, uint32_t x_new,
+                                                             unsigned long long *__restrict__ total)
+{
+    __shared__ uint32_t wsum[2 * XF_THREADS / 64];
+    const uint32_t d0 = dbase + blockIdx.x * XF_DB, d1 = min(d0 + XF_DB, dend);
+    const uint32_t xlo = max(xa, d0 >= sb ? d0 - sb + 1u : 0u), xhi = min(xb, d1);
+    uint32_t cnt = 0, fresh = 0;
+    for (uint32_t x = xlo + threadIdx.x; x < xhi; x += XF_THREADS) {
+        if (xval[x] == LZ77X_NONE32) continue;
+        const uint32_t dst = x + (ps[x] >> 16);
+        if (dst >= d0 && dst < d1) { cnt++; fresh += x >= x_new; }
+    }
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) { cnt += __shfl_xor(cnt, d, 64); fresh += __shfl_xor(fresh, d, 64); }
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) { wsum[wave] = cnt; wsum[XF_THREADS / 64 + wave] = fresh; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t c = 0, f = 0;
+        for (int w = 0; w < XF_THREADS / 64; w++) { c += wsum[w]; f += wsum[XF_THREADS / 64 + w]; }
+        blocksum[blockIdx.x] = c;
+        if (total && f) atomicAdd(total, (unsigned long long)f);
+    }
+}
+
+__global__ __launch_bounds__(XF_THREADS) void k_xfer_blockfill(const uint32_t *__restrict__ ps, const uint32_t *__restrict__ xval, uint32_t xa,
+                                                              uint32_t xb, uint32_t dbase, uint32_t dend, uint32_t sb,
+                                                              const uint32_t *__restrict__ blockbase, uint32_t *__restrict__ ofs,
+                                                              uint2 *__restrict__ ent)
+{
+    __shared__ uint32_t cnt[XF_DB];
+    __shared__ uint32_t wsum[XF_THREADS / 64];
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t d0 = dbase + blockIdx.x * XF_DB, d1 = min(d0 + XF_DB, dend);
+    const uint32_t xlo = max(xa, d0 >= sb ? d0 - sb + 1u : 0u), xhi = min(xb, d1);
+    for (uint32_t i = tid; i < XF_DB; i += XF_THREADS) cnt[i] = 0;
+    __syncthreads();
+    for (uint32_t x = xlo + tid; x < xhi; x += XF_THREADS) {
+        if (xval[x] == LZ77X_NONE32) continue;
+        const uint32_t dst = x + (ps[x] >> 16);
+        if (dst >= d0 && dst < d1) atomicAdd(&cnt[dst - d0], 1u);
+    }
+    __syncthreads();
+    {
+        /* exclusive scan of the XF_DB counters (eight per thread), turned into slot cursors; ofs[] gets the END of every list */
+        constexpr int PER = XF_DB / XF_THREADS;
+        uint32_t c[PER], mine = 0;
+#pragma unroll
+        for (int q = 0; q < PER; q++) { c[q] = cnt[PER * tid + q]; mine += c[q]; }
+        uint32_t incl = mine;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t t = __shfl_up(incl, d, 64);
+            if (lane >= (uint32_t)d) incl += t;
+        }
+        if (lane == 63) wsum[wave] = incl;
+        __syncthreads();
+        uint32_t run = blockbase[blockIdx.x] + incl - mine;
+        for (uint32_t w = 0; w < wave; w++) run += wsum[w];
+#pragma unroll
+        for (int q = 0; q < PER; q++) {
+            cnt[PER * tid + q] = run;                          /* cursor: first slot of this destination's list */
+            run += c[q];
+            const uint32_t d = d0 + PER * tid + q;
+            if (d < d1) ofs[d - dbase] = run;
+        }
+    }
+    __syncthreads();
+    for (uint32_t x = xlo + tid; x < xhi; x += XF_THREADS) {
+        const uint32_t v = xval[x];
+        if (v == LZ77X_NONE32) continue;
+        const uint32_t dst = x + (ps[x] >> 16);
+        if (dst >= d0 && dst < d1) ent[atomicAdd(&cnt[dst - d0], 1u)] = make_uint2(x, v);
+    }
+}
+
 /* Index of the hand-overs of evictions x in [xa, xb) into destinations [dbase, dend):
- * afterwards list(c) = ent[ (c > dbase ? ofs[c-dbase-1] : 0) .. ofs[c-dbase] ). */
+ * afterwards list(c) = ent[ (c > dbase ? ofs[c-dbase-1] : 0) .. ofs[c-dbase] ).  sb: a hand-over reaches less
+ * than sb positions ahead (0 = unknown: the round-1 kernels with global atomics). */
 hipError_t lz77k_xfer_index(const uint32_t *d_ps, const uint32_t *d_xval, uint32_t xa, uint32_t xb, uint32_t dbase, uint32_t dend,
                             uint32_t *d_ofs, uint2 *d_ent, void *d_scan_tmp, hipStream_t s, uint32_t x_new,
-                            unsigned long long *d_total)
+                            unsigned long long *d_total, uint32_t sb)
 {
     const uint32_t nd = dend - dbase;
+    if (sb && xb > xa && !getenv("LZ77X_XFER_V1")) {
+        const uint32_t nblocks = (nd + XF_DB - 1u) / XF_DB;
+        uint32_t *sums = reinterpret_cast<uint32_t *>(d_scan_tmp);
+        void *tmp2 = sums + ((nblocks + 64u) & ~63u);
+        hipLaunchKernelGGL(k_xfer_blocksum, dim3(nblocks), dim3(XF_THREADS), 0, s, d_ps, d_xval, xa, xb, dbase, dend, sb, sums, x_new, d_total);
+        hipError_t e = lz77k_scan_u32(sums, sums, nblocks, tmp2, s);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(k_xfer_blockfill, dim3(nblocks), dim3(XF_THREADS), 0, s, d_ps, d_xval, xa, xb, dbase, dend, sb, sums, d_ofs, d_ent);
+        /* ofs[nd] (one past the last destination) = total, as the tile kernel's LIST_END(t1 - 1) may read up to ofs[nd-1] only: not needed */
+        return hipGetLastError();
+    }
     hipError_t e = hipMemsetAsync(d_ofs, 0, ((size_t)nd + 1) * sizeof(uint32_t), s);
     if (e != hipSuccess) return e;
     if (xb <= xa) return hipSuccess;

@@ -164,7 +164,8 @@ hipError_t lz77k_sum_u32(const uint32_t *d_in, uint32_t m, unsigned long long *d
 hipError_t lz77k_xfer_index(const uint32_t *d_ps, const uint32_t *d_xval, uint32_t xa, uint32_t xb,
                             uint32_t dbase, uint32_t dend, uint32_t *d_ofs, uint2 *d_ent,
                             void *d_scan_tmp, hipStream_t s,
-                            uint32_t x_new = 0, unsigned long long *d_total = nullptr /* += hand-overs with x >= x_new */);
+                            uint32_t x_new = 0, unsigned long long *d_total = nullptr /* += hand-overs with x >= x_new */,
+                            uint32_t sb = 0 /* a hand-over reaches < sb positions ahead: lets destination blocks build their lists in LDS */);
 
 /* tokens d_chain[0..ntok) lie in [pos0, pos1).  variant 0: tiled kernel (window, hand-over lists and a
  * two-byte candidate index in LDS) when sb <= 8192, rank-order enumeration (d_ranks_all) above; variant 2:

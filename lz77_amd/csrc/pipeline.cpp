@@ -1289,7 +1289,7 @@ int encode_segment(Ctx &c, uint32_t nloc, uint32_t start, uint32_t E, bool last,
             const uint32_t xa = dbase > (uint32_t)g.sb ? dbase - (uint32_t)g.sb : 0u;
             const size_t x_new = ci == 0 ? 0 : (b > usb ? b - usb : 0);
             HIPCHK(lz77k_xfer_index(c.ps.as<uint32_t>(), c.xval.as<uint32_t>(), xa, (uint32_t)x_done, dbase, (uint32_t)e, c.ofs.as<uint32_t>(),
-                                    c.ent.as<uint2>(), c.scantmp.p, s, (uint32_t)x_new, c.flag.as<unsigned long long>() + 1));
+                                    c.ent.as<uint2>(), c.scantmp.p, s, (uint32_t)x_new, c.flag.as<unsigned long long>() + 1, (uint32_t)g.sb));
             HIPCHK(lz77k_tokens(c.in.as<uint8_t>(), nloc, g, c.chain.as<uint32_t>() + ta, tb - ta, c.maxlen.as<uint8_t>(), c.ofs.as<uint32_t>(),
                                 c.ent.as<uint2>(), dbase, (uint32_t)b, (uint32_t)e, tokbuf + 4 + ta, c.tstart.as<uint32_t>(), nullptr,
                                 tvariant, s, &c.tie_ev[2 * ci], nullptr, first ? nullptr : look_cur, nlook, 0u));
@@ -1683,7 +1683,7 @@ int encode_sharded(std::vector<Ctx *> &cs, const uint8_t *src, size_t n, const l
             const uint32_t dbase = b > usb ? (uint32_t)(b - usb) : 0u;
             const uint32_t xa = dbase > (uint32_t)g.sb ? dbase - (uint32_t)g.sb : 0u;
             HIPCHK(lz77k_xfer_index(c.ps.as<uint32_t>(), c.xval.as<uint32_t>(), xa, (uint32_t)x_done, dbase, (uint32_t)e, c.ofs.as<uint32_t>(),
-                                    c.ent.as<uint2>(), c.scantmp.p, s, 0u, c.flag.as<unsigned long long>() + 1));
+                                    c.ent.as<uint2>(), c.scantmp.p, s, 0u, c.flag.as<unsigned long long>() + 1, (uint32_t)g.sb));
             HIPCHK(lz77k_tokens(c.in.as<uint8_t>(), j.nloc, g, c.chain.as<uint32_t>(), j.ntok, c.maxlen.as<uint8_t>(), c.ofs.as<uint32_t>(),
                                 c.ent.as<uint2>(), dbase, (uint32_t)b, (uint32_t)e, c.tokval.as<uint32_t>() + 4, c.tstart.as<uint32_t>(), nullptr,
                                 tvariant, s, nullptr, nullptr, look, j.look, (uint32_t)j.gpos0));
