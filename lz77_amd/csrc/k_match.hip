@@ -509,7 +509,9 @@ template <bool FAST, int MODE>
 __global__ __launch_bounds__(MATCH_BLOCK, (FAST && MODE == 3) ? 8 : 1) void k_match(const uint8_t *__restrict__ in, uint32_t n, int sb, int la,
                                                        uint32_t SBu, uint32_t RP, uint32_t TILE, uint32_t region0,
                                                        uint32_t *__restrict__ ps, uint8_t *__restrict__ maxlen,
-                                                       uint32_t *__restrict__ scratch, int sort_variant, uint32_t walk_run)
+                                                       uint32_t *__restrict__ scratch, int sort_variant, uint32_t walk_run,
+                                                       uint16_t *__restrict__ order_all /* FAST production: RP uint16 per region of the input
+                                                                                           (sorted order -> position - t0), kept for the tie-break */)
 {
     typedef typename rank_traits<FAST>::rank_t rank_t;
     constexpr uint32_t HALF = rank_traits<FAST>::HALF;
@@ -670,6 +672,13 @@ __global__ __launch_bounds__(MATCH_BLOCK, (FAST && MODE == 3) ? 8 : 1) void k_ma
         uint32_t mine[16];
 #pragma unroll
         for (int q = 0; q < 16; q++) mine[q] = (uint32_t)q < K ? (uint32_t)ix[tid * K + q] : 0xFFFFFFFFu;
+        if (order_all) {
+            /* the region's sorted order itself stays resident: the tie-break enumerates equal-length candidates
+             * as runs of it (k_tokens_sorted) */
+            uint16_t *go = order_all + (size_t)region * RP;
+            for (uint32_t e = tid * 8; e < RP; e += MATCH_BLOCK * 8)
+                *reinterpret_cast<uint4 *>(go + e) = *reinterpret_cast<const uint4 *>(reinterpret_cast<const uint16_t *>(ix) + e);
+        }
         __syncthreads();                                     /* the sort's last readers of the byte area are done */
         for (uint32_t j = 0; j < NR; j++) {
             const uint32_t lo = j * walk_run;
@@ -1347,7 +1356,7 @@ size_t lz77k_match_scratch_bytes(const lz77x_geom &g, uint32_t nregions)
 
 template <bool FAST, int MODE>
 static hipError_t launch_match(const uint8_t *d_in, uint32_t n, const lz77x_geom &g, uint32_t region0, uint32_t nregions,
-                               uint32_t *d_ps, uint8_t *d_maxlen, void *d_scratch, hipStream_t s)
+                               uint32_t *d_ps, uint8_t *d_maxlen, void *d_scratch, hipStream_t s, uint16_t *d_order = nullptr)
 {
     const size_t lds = lz77k_match_lds_bytes(g);
     auto fn = k_match<FAST, MODE>;
@@ -1357,7 +1366,7 @@ static hipError_t launch_match(const uint8_t *d_in, uint32_t n, const lz77x_geom
     }
     const char *sv = getenv("LZ77X_SORT_VARIANT");
     hipLaunchKernelGGL(fn, dim3(nregions), dim3(MATCH_BLOCK), lds, s, d_in, n, g.sb, g.la, g.SBu, g.RP, g.TILE, region0,
-                       d_ps, d_maxlen, reinterpret_cast<uint32_t *>(d_scratch), sv ? atoi(sv) : 0, g.fast ? walk_run_lds(g) : 0u);
+                       d_ps, d_maxlen, reinterpret_cast<uint32_t *>(d_scratch), sv ? atoi(sv) : 0, g.fast ? walk_run_lds(g) : 0u, d_order);
     return hipGetLastError();
 }
 
@@ -1376,7 +1385,7 @@ hipError_t lz77k_match(const uint8_t *d_in, uint32_t n, const lz77x_geom &g, uin
         /* production: sort -> per-lane bitmap walkers -> finalize */
         hipError_t e = ev_sort ? hipEventRecord(ev_sort[0], s) : hipSuccess;
         if (e != hipSuccess) return e;
-        e = launch_match<true, 3>(LZ77K_MATCH_ARGS);
+        e = launch_match<true, 3>(LZ77K_MATCH_ARGS, reinterpret_cast<uint16_t *>(d_ranks_all));
         if (e != hipSuccess) return e;
         if (ev_sort && (e = hipEventRecord(ev_sort[1], s)) != hipSuccess) return e;
         const uint32_t run_len = walk_run_lds(g);

@@ -446,6 +446,328 @@ __global__ __launch_bounds__(TOK_BLOCK) void k_tokens_tile(const uint8_t *__rest
 #undef LIST_START
 #undef LIST_END
 
+/* ---- production for LDS-sized windows: candidates enumerated as RUNS OF THE SORTED ORDER ------------------
+ *
+ * The candidates whose match with p has the full length len are exactly the window positions that share p's
+ * first len bytes, and positions sharing a prefix are contiguous in (key, position) order -- the order the
+ * match stage has already computed for every region (k_match keeps it: `order_all`, RP uint16 per region).
+ * A tile of TS_TT token positions [a, b) lies inside ONE region together with its whole look-back, so the
+ * workgroup filters the region's order down to the cells of [a - sb, b) (a compaction, no sort), and then
+ *   A. per token (two lanes: downwards / upwards from p's own slot) gallops to the ends of the run of cells
+ *      that share its len bytes -- a handful of probes, every lane busy with its own token;
+ *   B. the runs of a batch of tokens are laid end to end and dealt to the 1024 threads in equal contiguous
+ *      pieces: per item one window test and one priority look-up (hand-over lists in LDS), minimum per token
+ *      through a 64-bit LDS atomic;
+ *   C. per token, offset = p - argmin.
+ * Compared with the bucket kernel above (one wave per token, 64 lanes scanning a hash bucket of which a
+ * handful qualify; VALU-bound at ~130 wave instructions per token) every lane does useful work and only
+ * exact candidates are visited (17 per token on text against a bucket of 95).
+ *
+ * Tile grid: region r (positions [r*TILE, r*TILE + TILE + sb) sorted) owns the backward windows of
+ * y in [r*TILE + sb, (r+1)*TILE + sb), cut into ceil(TILE / TS_TT) tiles; region 0 also owns y < sb
+ * ("head" tiles). */
+#define TS_TT 2048u
+#define TS_BLOCK 1024
+#define TS_TB 512u                                   /* tokens per batch (two lanes each in phase A) */
+
+struct ts_grid { uint32_t sb, TILE, head, tpr; };
+
+static inline ts_grid ts_make_grid(const lz77x_geom &g)
+{
+    ts_grid G;
+    G.sb = (uint32_t)g.sb;
+    G.TILE = g.TILE;
+    G.head = (G.sb + TS_TT - 1u) / TS_TT;
+    G.tpr = (g.TILE + TS_TT - 1u) / TS_TT;
+    return G;
+}
+
+__host__ __device__ __forceinline__ uint32_t ts_tile_of(const ts_grid &G, uint32_t pos)
+{
+    if (pos < G.sb) return pos / TS_TT;
+    const uint32_t q = pos - G.sb, r = q / G.TILE;
+    return G.head + r * G.tpr + (q - r * G.TILE) / TS_TT;
+}
+
+__device__ __forceinline__ void ts_tile_range(const ts_grid &G, uint32_t idx, uint32_t &a, uint32_t &b, uint32_t &region)
+{
+    if (idx < G.head) {
+        a = idx * TS_TT;
+        b = min(a + TS_TT, G.sb);
+        region = 0;
+    } else {
+        const uint32_t q = idx - G.head, r = q / G.tpr, i = q - r * G.tpr;
+        a = G.sb + r * G.TILE + i * TS_TT;
+        b = G.sb + r * G.TILE + min((i + 1u) * TS_TT, G.TILE);
+        region = r;
+    }
+}
+
+__global__ void k_tok_bounds_grid(const uint32_t *__restrict__ chain, uint32_t ntok, ts_grid G, uint32_t tile0, uint32_t ntiles,
+                                  uint32_t *__restrict__ tstart)
+{
+    /* tstart[t] = first token that lies in tile tile0 + t or later */
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k > ntok) return;
+    const uint32_t first = k == 0 ? 0u : ts_tile_of(G, chain[k - 1]) - tile0 + 1;
+    const uint32_t last = k == ntok ? ntiles : ts_tile_of(G, chain[k]) - tile0;
+    for (uint32_t t = first; t <= last; t++) tstart[t] = k;
+}
+
+/* exclusive prefix of one value per thread over the workgroup; *total (LDS) = the sum.  Two barriers. */
+__device__ __forceinline__ uint32_t ts_wg_scan(uint32_t v, uint32_t *wsum, uint32_t *total)
+{
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t incl = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t t = __shfl_up(incl, d, 64);
+        if (lane >= (uint32_t)d) incl += t;
+    }
+    __syncthreads();                                      /* the previous use of wsum is over */
+    if (lane == 63) wsum[wave] = incl;
+    __syncthreads();
+    uint32_t run = incl - v, all = 0;
+#pragma unroll
+    for (uint32_t w = 0; w < TS_BLOCK / 64; w++) {
+        const uint32_t t = wsum[w];
+        run += w < wave ? t : 0u;
+        all += t;
+    }
+    if (threadIdx.x == 0) *total = all;
+    return run;
+}
+
+__global__ __launch_bounds__(TS_BLOCK) void k_tokens_sorted(const uint8_t *__restrict__ in, uint32_t n, int sb, int la, int ob, int lb,
+                                                            const uint32_t *__restrict__ chain, const uint32_t *__restrict__ tstart,
+                                                            const uint8_t *__restrict__ maxlen, const uint32_t *__restrict__ ofs,
+                                                            const uint2 *__restrict__ ent, uint32_t dbase, uint32_t pos0, uint32_t pos1,
+                                                            uint32_t *__restrict__ tokval, uint32_t ent_cap, uint32_t off_sorted,
+                                                            uint32_t off_inv, uint32_t off_lofs, uint32_t off_tk, uint32_t off_lent,
+                                                            const uint32_t *__restrict__ look, uint32_t nlook, uint32_t voff,
+                                                            const uint16_t *__restrict__ order_all, uint32_t RP, ts_grid G, uint32_t tile0)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    uint8_t *by = smem;
+    uint16_t *sorted = reinterpret_cast<uint16_t *>(smem + off_sorted);        /* window cells (offsets from wbase) in key order */
+    uint16_t *inv = reinterpret_cast<uint16_t *>(smem + off_inv);              /* slot of every tile position */
+    uint16_t *lofs = reinterpret_cast<uint16_t *>(smem + off_lofs);
+    unsigned long long *tk_best = reinterpret_cast<unsigned long long *>(smem + off_tk);   /* TS_TB */
+    uint32_t *tk_cum = reinterpret_cast<uint32_t *>(tk_best + TS_TB);                      /* TS_TB + 1 */
+    uint32_t *tk_pl = tk_cum + TS_TB + 4;                                                   /* TS_TB: offset | len << 16 */
+    uint16_t *tk_lo = reinterpret_cast<uint16_t *>(tk_pl + TS_TB);                         /* TS_TB */
+    uint16_t *tk_hi = tk_lo + TS_TB;                                                        /* TS_TB */
+    uint2 *lent = reinterpret_cast<uint2 *>(smem + off_lent);
+    __shared__ uint32_t wsum[TS_BLOCK / 64];
+    __shared__ uint32_t s_total;
+
+    const uint32_t tid = threadIdx.x;
+    const uint32_t usb = (uint32_t)sb;
+    uint32_t a, b, region;
+    ts_tile_range(G, tile0 + blockIdx.x, a, b, region);
+    a = max(a, pos0);
+    b = min(b, pos1);
+    if (a >= b) return;
+    const uint32_t t0r = region * G.TILE;
+    const uint32_t wlo = a > usb ? a - usb : 0u;
+    const uint32_t wbase = wlo & ~3u;
+#define LIST_START(c) ((c) > dbase ? ofs[(c) - dbase - 1] : 0u)
+#define LIST_END(c) ((c) >= dbase ? ofs[(c) - dbase] : 0u)
+    {
+        const uint32_t nb = (b + (uint32_t)la + 8 - wbase + 3) & ~3u;
+        for (uint32_t i = tid * 4; i < nb; i += TS_BLOCK * 4)
+            *reinterpret_cast<uint32_t *>(by + i) = *reinterpret_cast<const uint32_t *>(in + wbase + i);
+    }
+    const uint32_t NO = b - wbase;
+    const uint32_t ebase = LIST_START(wbase);
+    const uint32_t ecount = LIST_END(b - 1) - ebase;
+    const bool staged = ecount <= ent_cap && ecount < 65536u;
+    if (staged) {
+        for (uint32_t i = tid; i <= NO; i += TS_BLOCK) lofs[i] = (uint16_t)(LIST_START(wbase + i) - ebase);
+        for (uint32_t e = tid; e < ecount; e += TS_BLOCK) lent[e] = ent[ebase + e];
+    }
+    /* the region's order, filtered down to the cells of [wlo, b) */
+    uint32_t N;
+    {
+        const uint32_t K = RP / TS_BLOCK;                  /* 4, 8 or 16 consecutive slots per thread */
+        const uint16_t *ord = order_all + (size_t)region * RP + (size_t)tid * K;
+        uint32_t mine[16];
+        if (K == 16) {
+            const uint4 v0 = *reinterpret_cast<const uint4 *>(ord), v1 = *reinterpret_cast<const uint4 *>(ord + 8);
+            const uint32_t w[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+#pragma unroll
+            for (int q = 0; q < 8; q++) { mine[2 * q] = w[q] & 0xFFFFu; mine[2 * q + 1] = w[q] >> 16; }
+        } else if (K == 8) {
+            const uint4 v0 = *reinterpret_cast<const uint4 *>(ord);
+            const uint32_t w[4] = {v0.x, v0.y, v0.z, v0.w};
+#pragma unroll
+            for (int q = 0; q < 4; q++) { mine[2 * q] = w[q] & 0xFFFFu; mine[2 * q + 1] = w[q] >> 16; }
+#pragma unroll
+            for (int q = 8; q < 16; q++) mine[q] = 0xFFFFFFFFu;
+        } else {
+            const uint2 v0 = *reinterpret_cast<const uint2 *>(ord);
+            mine[0] = v0.x & 0xFFFFu; mine[1] = v0.x >> 16; mine[2] = v0.y & 0xFFFFu; mine[3] = v0.y >> 16;
+#pragma unroll
+            for (int q = 4; q < 16; q++) mine[q] = 0xFFFFFFFFu;
+        }
+        const uint32_t wl = wlo - t0r, wn = b - wlo;        /* region-local window */
+        uint32_t cnt = 0;
+#pragma unroll
+        for (int q = 0; q < 16; q++) cnt += (mine[q] - wl < wn) ? 1u : 0u;
+        uint32_t run = ts_wg_scan(cnt, wsum, &s_total);
+        const uint32_t shift = t0r - wbase, ta = a - wbase;
+#pragma unroll
+        for (int q = 0; q < 16; q++) {
+            if (mine[q] - wl < wn) {
+                const uint32_t co = mine[q] + shift;
+                sorted[run] = (uint16_t)co;
+                if (co >= ta) inv[co - ta] = (uint16_t)run;
+                run++;
+            }
+        }
+        __syncthreads();
+        N = s_total;                                        /* = b - wlo: every cell of the window is in the region */
+    }
+
+    const uint32_t omask = ob >= 32 ? 0xFFFFFFFFu : (1u << ob) - 1u;
+    const uint32_t k0 = tstart[blockIdx.x], k1 = tstart[blockIdx.x + 1];
+    for (uint32_t kb = k0; kb < k1; kb += TS_TB) {
+        const uint32_t nt = min(TS_TB, k1 - kb);
+        /* ---- A: the run of cells sharing the token's len bytes; lane pair = (down, up) ---- */
+        {
+            const uint32_t ti = tid >> 1, up = tid & 1u;
+            if (ti < nt) {
+                const uint32_t p = chain[kb + ti];
+                const uint32_t len = maxlen[p];
+                const uint32_t qo = p - wbase;
+                int edge = 0;
+                if (len > 0) {
+                    uint32_t qw[4];
+#pragma unroll
+                    for (int w = 0; w < 4; w++) qw[w] = (uint32_t)(4 * w) < len ? ld32_at<true>(by, qo + 4 * w) : 0u;
+                    auto shares = [&](int i) -> bool {
+                        const uint32_t co = sorted[i];
+#pragma unroll
+                        for (int w = 0; w < 4; w++) {
+                            if ((uint32_t)(4 * w) < len) {
+                                uint32_t x = ld32_at<true>(by, co + 4 * w) ^ qw[w];
+                                const uint32_t rem = len - 4 * w;
+                                if (rem < 4) x &= (1u << (8 * rem)) - 1u;
+                                if (x) return false;
+                            }
+                        }
+                        for (uint32_t i2 = 16; i2 < len; i2 += 4) {
+                            uint32_t x = ld32_at<true>(by, co + i2) ^ ld32_at<true>(by, qo + i2);
+                            const uint32_t rem = len - i2;
+                            if (rem < 4) x &= (1u << (8 * rem)) - 1u;
+                            if (x) return false;
+                        }
+                        return true;
+                    };
+                    const int j = (int)inv[p - a];
+                    if (!up) {
+                        int lo = j, bad = -1, step = 1;           /* every slot of [lo, j) shares; slot `bad` does not */
+                        while (lo > 0) {
+                            const int t = lo > step ? lo - step : 0;
+                            if (shares(t)) { lo = t; step <<= 1; }
+                            else { bad = t; break; }
+                        }
+                        if (bad >= 0)
+                            while (lo - bad > 1) {
+                                const int m = (lo + bad) >> 1;
+                                if (shares(m)) lo = m; else bad = m;
+                            }
+                        edge = lo;
+                    } else {
+                        int hi = j + 1, bad = (int)N, step = 1;   /* every slot of (j, hi) shares; slot `bad` does not */
+                        while (hi < (int)N) {
+                            const int t = min(hi - 1 + step, (int)N - 1);
+                            if (shares(t)) { hi = t + 1; step <<= 1; }
+                            else { bad = t; break; }
+                        }
+                        while (hi < bad) {
+                            const int m = (hi + bad) >> 1;
+                            if (shares(m)) hi = m + 1; else bad = m;
+                        }
+                        edge = hi;
+                    }
+                }
+                if (up) tk_hi[ti] = (uint16_t)edge;
+                else { tk_lo[ti] = (uint16_t)edge; tk_pl[ti] = qo | (len << 16); }
+            }
+        }
+        __syncthreads();
+        /* ---- the runs laid end to end ---- */
+        {
+            uint32_t cnt = 0;
+            if (tid < nt && (tk_pl[tid] >> 16)) cnt = (uint32_t)tk_hi[tid] - (uint32_t)tk_lo[tid];
+            const uint32_t ex = ts_wg_scan(cnt, wsum, &s_total);
+            if (tid < nt) { tk_cum[tid] = ex; tk_best[tid] = ~0ull; }
+            __syncthreads();
+        }
+        const uint32_t W = s_total;
+        if (tid == 0) tk_cum[nt] = W;
+        /* ---- B: every run member: inside the token's window?  then its priority at time p ---- */
+        {
+            const uint32_t per = (W + TS_BLOCK - 1u) / TS_BLOCK;
+            const uint32_t w0 = tid * per, w1 = min(w0 + per, W);
+            __syncthreads();                                /* tk_cum[nt] */
+            if (w0 < w1) {
+                uint32_t lo_i = 0, hi_i = nt;               /* largest ti with cum[ti] <= w0 */
+                while (hi_i - lo_i > 1) {
+                    const uint32_t m = (lo_i + hi_i) >> 1;
+                    if (tk_cum[m] <= w0) lo_i = m; else hi_i = m;
+                }
+                uint32_t ti = lo_i;
+                uint32_t w = w0;
+                while (w < w1) {
+                    /* skip tokens without members (cum[ti + 1] == cum[ti]) */
+                    while (tk_cum[ti + 1] <= w) ti++;
+                    const uint32_t pl = tk_pl[ti], cbase = tk_cum[ti], cend = min(tk_cum[ti + 1], w1);
+                    const uint32_t p = wbase + (pl & 0xFFFFu);
+                    const uint32_t cmin = p > usb ? p - usb : 0u;
+                    const uint32_t slot0 = (uint32_t)tk_lo[ti] - cbase;
+                    unsigned long long best = ~0ull;
+                    for (; w < cend; w++) {
+                        const uint32_t co = sorted[slot0 + w];
+                        const uint32_t c = wbase + co;
+                        if (c < cmin || c >= p) continue;
+                        uint32_t prio = c < nlook ? look[c] : c + voff, latest = 0;
+                        bool any = false;
+                        if (staged) {
+                            const uint32_t e1 = lofs[co + 1];
+                            for (uint32_t e = lofs[co]; e < e1; e++) {
+                                const uint2 t = lent[e];
+                                if ((uint64_t)t.x + usb < p && (!any || t.x > latest)) { any = true; latest = t.x; prio = t.y; }
+                            }
+                        } else {
+                            const uint32_t e1 = LIST_END(c);
+                            for (uint32_t e = LIST_START(c); e < e1; e++) {
+                                const uint2 t = ent[e];
+                                if ((uint64_t)t.x + usb < p && (!any || t.x > latest)) { any = true; latest = t.x; prio = t.y; }
+                            }
+                        }
+                        const unsigned long long key = ((unsigned long long)prio << 32) | c;
+                        best = key < best ? key : best;
+                    }
+                    if (best != ~0ull) atomicMin(&tk_best[ti], best);
+                }
+            }
+        }
+        __syncthreads();
+        /* ---- C: the token ---- */
+        if (tid < nt) {
+            const uint32_t pl = tk_pl[tid], qo = pl & 0xFFFFu, len = pl >> 16;
+            const uint32_t next = by[qo + len];
+            const uint32_t off = len ? wbase + qo - (uint32_t)(tk_best[tid] & 0xFFFFFFFFull) : 0u;
+            tokval[kb + tid] = (off & omask) | (len << ob) | (next << (ob + lb));
+        }
+        __syncthreads();
+    }
+#undef LIST_START
+#undef LIST_END
+}
+
 /* ---- large windows (sb > 8192): the candidate index lives in global memory -------------------
  * Per tile of BIG_TT positions, every candidate position (tile + its SB look-back) is bucketed by
  * its first two bytes (exact 16-bit key, so a length-1 token reads the 256 adjacent buckets of its
@@ -710,7 +1032,8 @@ size_t lz77k_tokens_index_bytes(const lz77x_geom &g, size_t npos)
     return ntiles * ((size_t)BIG_KEYS + BIG_TT + (size_t)g.sb + 8) * sizeof(uint32_t) + 256;
 }
 
-size_t lz77k_tokens_tmp_bytes(uint32_t n) { return ((size_t)(n / TOK_TILE) + 8) * sizeof(uint32_t); }
+/* one word per tile + 1: the sorted-order kernel cuts every region into ceil(TILE / TS_TT) tiles (TILE >= 3064) */
+size_t lz77k_tokens_tmp_bytes(uint32_t n) { return ((size_t)(n / 1024u) + 64) * sizeof(uint32_t); }
 
 /* tokens d_chain[0..ntok) all lie in [pos0, pos1); the hand-over index covers dst >= dbase */
 hipError_t lz77k_tokens(const uint8_t *d_in, uint32_t n, const lz77x_geom &g, const uint32_t *d_chain, uint32_t ntok,
@@ -741,6 +1064,31 @@ hipError_t lz77k_tokens(const uint8_t *d_in, uint32_t n, const lz77x_geom &g, co
         TIE_EV(0);
         hipLaunchKernelGGL(k_tokens_big, dim3((ntok + 3) / 4), dim3(256), 0, s, d_in, n, g.sb, g.ob, g.lb, d_chain, ntok, d_maxlen,
                            d_ofs, d_ent, dbase, pos0, bs, blist, span, d_tokval, d_look, nlook, voff);
+        TIE_EV(1);
+        return hipGetLastError();
+    }
+    if (variant == 0 && g.fast && d_ranks_all && d_tstart) {
+        /* production, LDS-sized windows: runs of the regions' sorted order (d_ranks_all = RP uint16 per region) */
+        const ts_grid G = ts_make_grid(g);
+        const uint32_t tile0 = ts_tile_of(G, pos0), ntiles = ts_tile_of(G, pos1 - 1u) - tile0 + 1u;
+        const uint32_t span = TS_TT + (uint32_t)g.sb + 16;
+        const uint32_t off_sorted = (span + (uint32_t)g.la + 16 + 15) & ~15u;
+        const uint32_t off_inv = (off_sorted + 2 * span + 15) & ~15u;
+        const uint32_t off_lofs = (off_inv + 2 * TS_TT + 15) & ~15u;
+        const uint32_t off_tk = (off_lofs + 2 * (span + 2) + 15) & ~15u;
+        const uint32_t off_lent = (off_tk + TS_TB * 8 + (TS_TB + 4) * 4 + TS_TB * 4 + TS_TB * 2 * 2 + 15) & ~15u;
+        const uint32_t budget = 78u * 1024u;                              /* two workgroups per CU */
+        const uint32_t ent_cap = off_lent + 8 * 512 < budget ? (budget - off_lent) / 8 : 512;
+        const size_t lds = (size_t)off_lent + (size_t)ent_cap * 8;
+        if (lds > 48 * 1024) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_tokens_sorted), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) return e;
+        }
+        hipLaunchKernelGGL(k_tok_bounds_grid, dim3((ntok + 256) / 256), dim3(256), 0, s, d_chain, ntok, G, tile0, ntiles, d_tstart);
+        TIE_EV(0);
+        hipLaunchKernelGGL(k_tokens_sorted, dim3(ntiles), dim3(TS_BLOCK), lds, s, d_in, n, g.sb, g.la, g.ob, g.lb, d_chain, d_tstart, d_maxlen,
+                           d_ofs, d_ent, dbase, pos0, pos1, d_tokval, ent_cap, off_sorted, off_inv, off_lofs, off_tk, off_lent, d_look, nlook, voff,
+                           reinterpret_cast<const uint16_t *>(d_ranks_all), g.RP, G, tile0);
         TIE_EV(1);
         return hipGetLastError();
     }

@@ -1218,6 +1218,10 @@ int encode_segment(Ctx &c, uint32_t nloc, uint32_t start, uint32_t E, bool last,
         if ((rc = c.chain_tmp.need(lz77k_chain_tmp_bytes(E - start, g.la)))) return rc;
         if ((rc = c.h_small.need(128))) return rc;
         if ((rc = c.look.need((size_t)2 * (usb + 8) * 4))) return rc;
+        /* the regions' sorted order stays resident for the tie-break (RP uint16 per region: 2.7 B per input byte) */
+        const bool keep_order = g.fast && tvariant == 0 && !getenv("LZ77X_TOKENS_BUCKET");
+        if (keep_order && (rc = c.ranks_all.need((size_t)nregions * g.RP * 2 + 64))) return rc;
+        uint32_t *d_order = keep_order ? c.ranks_all.as<uint32_t>() : nullptr;
         const uint32_t nsub_max = (uint32_t)((span + csub - 1) / csub);
         if ((rc = c.h_tbase.need(((size_t)nsub_max + 2) * 4 + (usb + 8) * 4))) return rc;
         HIPCHK(hipMemsetAsync(c.flag.p, 0, 64, s));
@@ -1233,7 +1237,7 @@ int encode_segment(Ctx &c, uint32_t nloc, uint32_t start, uint32_t E, bool last,
         for (uint32_t r0 = 0; r0 < nregions; r0 += batch) {
             const uint32_t nr = nregions - r0 < batch ? nregions - r0 : batch;
             HIPCHK(lz77k_match(c.in.as<uint8_t>(), nloc, g, r0, nr, c.ps.as<uint32_t>(), c.maxlen.as<uint8_t>(), c.scratch.p, 0, s,
-                               &c.sort_ev[3 * launches], nullptr));
+                               &c.sort_ev[3 * launches], d_order));
             launches++;
         }
         HIPCHK(hipEventRecord(c.ev[1], s));
@@ -1292,7 +1296,7 @@ int encode_segment(Ctx &c, uint32_t nloc, uint32_t start, uint32_t E, bool last,
                                     c.ent.as<uint2>(), c.scantmp.p, s, (uint32_t)x_new, c.flag.as<unsigned long long>() + 1, (uint32_t)g.sb));
             HIPCHK(lz77k_tokens(c.in.as<uint8_t>(), nloc, g, c.chain.as<uint32_t>() + ta, tb - ta, c.maxlen.as<uint8_t>(), c.ofs.as<uint32_t>(),
                                 c.ent.as<uint2>(), dbase, (uint32_t)b, (uint32_t)e, tokbuf + 4 + ta, c.tstart.as<uint32_t>(), nullptr,
-                                tvariant, s, &c.tie_ev[2 * ci], nullptr, first ? nullptr : look_cur, nlook, 0u));
+                                tvariant, s, &c.tie_ev[2 * ci], d_order, first ? nullptr : look_cur, nlook, 0u));
             tie_timed[ci] = tb > ta;
         }
         HIPCHK(hipMemcpyAsync(c.h_small.as<unsigned long long>() + 2, c.flag.as<unsigned long long>() + 1, 8, hipMemcpyDeviceToHost, s));
