@@ -33,6 +33,7 @@
  * k_tokens consumes -- is written by every sweep; the last sweep of a block is the exact one.
  */
 #include "kernels_common.h"
+#include <stdio.h>
 
 #define PRIO_NONE 0xFFFFFFFFu
 #define PRIO_DEAD 0xFFFFu
@@ -624,6 +625,8 @@ hipError_t lz77k_prio(const uint32_t *d_ps, uint32_t nx, int sb_i, uint32_t *d_x
             if ((e = hipEventElapsedTime(&t, ev4[0], ev4[1])) != hipSuccess) return e;
             ms3[2] += t;
         }
+        if (getenv("LZ77X_PRIO_TRACE"))
+            fprintf(stderr, "prio it %d: B %u NB %u first %u flips %u min flipped block %u\n", it, P.B, P.NB, P.first, h_flag[0], h_flag[1]);
         if (h_flag[0] == 0) break;
         lz77k_prio_advance(P, h_flag, false);
     }

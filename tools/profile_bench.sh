@@ -48,8 +48,8 @@ def hbm(k):
 tr = {"round": tag,
       "command": "rocprofv3 --kernel-trace --pmc FETCH_SIZE | --pmc WRITE_SIZE (separate passes) -- python bench.py --steps 1 --warmup 0 --no-cpu-baseline --streams 1",
       "correction": "gfx950 FETCH_SIZE counts 128-B requests as 64 B (MI355X_MICROARCH.md, HBM): fetch doubled; WRITE_SIZE as reported",
-      "hbm_bytes_per_launch": {"k_tokens_tile": hbm("k_tokens_tile<true>"), "k_walk": hbm("k_walk"), "k_match": hbm("k_match<true, 3>")},
-      "launches": {k: nl[k] for k in ("k_tokens_tile<true>", "k_walk", "k_match<true, 3>")}}
+      "hbm_bytes_per_launch": {k.split("<")[0]: hbm(k) for k in sorted(acc) if k.startswith("k_")},
+      "launches": {k.split("<")[0]: nl[k] for k in sorted(acc) if k.startswith("k_")}}
 json.dump(tr, open(out + "/traffic.json", "w"), indent=1)
 print(json.dumps(tr))
 PY
