@@ -138,6 +138,250 @@ __global__ void k_dec_gather(uint8_t *__restrict__ out, const uint32_t *__restri
     }
 }
 
+/* ------------------------------------------------------------------ tile-local decode ---
+ *
+ * The pointer-jumping decode above keeps a 4-byte pointer for EVERY output byte in HBM and chases it there
+ * (67x the algorithmic bytes).  Most of a copy chain is short-range: this path resolves, per tile
+ * of DT_TB output bytes, everything that stays inside the tile in LDS -- a byte is a literal, a pointer to an
+ * earlier byte of the same tile, or a pointer out of the tile; pointer doubling in LDS leaves only literals
+ * (written straight to out[]) and out-of-tile pointers.  Only those go to HBM (ptr32[], one bit per byte in
+ * unres[]), and only they take part in the global jumping: an unresolved byte hops along unresolved bytes until
+ * it points at a resolved one (whose value the tile pass already wrote and nothing changes any more), then one
+ * gather.  unres[] is immutable after the tile pass, ptr32[j] only ever moves along j's own chain: any
+ * interleaving is safe. */
+#define DT_TB 12288u                                 /* 5 B of LDS per byte: two workgroups per CU */
+#define DT_BLOCK 1024
+#define DT_INT 0u
+#define DT_LIT 1u
+#define DT_EXT 2u
+
+/* tfirst[t] = the token whose bytes contain output offset t * DT_TB */
+__global__ void k_dec_bounds(const uint32_t *__restrict__ dst, uint32_t ntok, uint32_t *__restrict__ tfirst)
+{
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= ntok) return;
+    const uint32_t a = dst[k], b = dst[k + 1];
+    const uint32_t t = (a + DT_TB - 1u) / DT_TB;
+    if ((uint64_t)t * DT_TB < b) tfirst[t] = k;
+}
+
+__global__ __launch_bounds__(DT_BLOCK) void k_dec_tile(const uint32_t *__restrict__ tokval, const uint32_t *__restrict__ dst, uint32_t ntok,
+                                                       int ob, int lb, uint8_t *__restrict__ out, uint32_t *__restrict__ ptr32,
+                                                       unsigned long long *__restrict__ unres, uint32_t n, uint32_t ntiles,
+                                                       const uint32_t *__restrict__ tfirst, const uint32_t *__restrict__ cyc, uint32_t ncyc,
+                                                       uint32_t sb)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t dt_smem[];
+    uint32_t *val = reinterpret_cast<uint32_t *>(dt_smem);           /* local index | byte value | absolute source */
+    uint8_t *tag = dt_smem + (size_t)DT_TB * 4;
+    const uint32_t tid = threadIdx.x;
+    const uint32_t t = blockIdx.x;
+    const uint32_t j0 = t * DT_TB, j1 = n - j0 < DT_TB ? n : j0 + DT_TB, cnt = j1 - j0;
+    const uint32_t k0 = tfirst[t], k1 = t + 1 < ntiles ? tfirst[t + 1] + 1u : ntok;
+
+    /* lz77.c:178-194 as data flow: copied byte j <- byte j - off, then the literal */
+    for (uint32_t k = k0 + tid; k < k1; k += DT_BLOCK) {
+        const uint32_t v = tokval[k];
+        const uint32_t off = ob ? (v & ((1u << ob) - 1u)) : 0;
+        const uint32_t len = (v >> ob) & ((1u << lb) - 1u);
+        const uint32_t lit = (v >> (ob + lb)) & 0xFFu;
+        const uint32_t d = dst[k];
+        const bool stale = off == 0 && len > 0 && cyc;
+        uint32_t c = 0, idx0 = 0;
+        if (stale) {
+            /* a copy from distance 0 (power-of-two -s): the byte the reference's 3*SB+LA staging buffer still
+             * holds at that index (lz77.c:172-181), see k_dec_expand */
+            uint32_t lo = 0, hi = ncyc;
+            while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (cyc[mid] <= d) lo = mid; else hi = mid; }
+            c = lo;
+            idx0 = (c ? sb : 0u) + (d - cyc[c]);
+        }
+        const uint32_t ia = d < j0 ? j0 - d : 0u;                     /* first byte of the token inside the tile */
+        for (uint32_t i = ia; i <= len; i++) {
+            const uint32_t j = d + i;
+            if (j >= j1) break;
+            uint32_t tg = DT_LIT, vv = lit;
+            if (i < len) {
+                uint32_t src = n;                                     /* n = "a zero byte" (degenerate tokens) */
+                if (stale) {
+                    const uint32_t idx = idx0 + i;
+                    for (uint32_t cc = c; cc-- > 0;) {
+                        const uint32_t b0 = cc ? sb : 0u;
+                        if (idx < b0) break;
+                        const uint32_t cand = cyc[cc] + (idx - b0);
+                        if (cand < cyc[cc + 1]) { src = cand; break; }
+                    }
+                } else if (off > 0 && off <= j) {
+                    src = j - off;
+                }
+                if (src == n) { tg = DT_LIT; vv = 0; }
+                else if (src >= j0) { tg = DT_INT; vv = src - j0; }
+                else { tg = DT_EXT; vv = src; }
+            }
+            val[j - j0] = vv;
+            tag[j - j0] = (uint8_t)tg;
+        }
+    }
+    __syncthreads();
+
+    /* pointer doubling inside the tile: read, barrier, write -- (val, tag) change together */
+    constexpr uint32_t PER = DT_TB / DT_BLOCK;
+    for (;;) {
+        uint32_t nv[PER], nt[PER];
+        int any = 0;
+#pragma unroll
+        for (uint32_t q = 0; q < PER; q++) {
+            const uint32_t i = tid + q * DT_BLOCK;
+            nt[q] = 0xFFu;
+            nv[q] = 0;
+            if (i < cnt && tag[i] == DT_INT) {
+                const uint32_t sidx = val[i];
+                nt[q] = tag[sidx];
+                nv[q] = val[sidx];
+                any |= nt[q] == DT_INT;
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (uint32_t q = 0; q < PER; q++) {
+            const uint32_t i = tid + q * DT_BLOCK;
+            if (nt[q] != 0xFFu) { val[i] = nv[q]; tag[i] = (uint8_t)nt[q]; }
+        }
+        if (!__syncthreads_or(any)) break;
+    }
+
+    /* out: resolved bytes (four per thread), pointers that leave the tile, and the bit that says which */
+    for (uint32_t i = tid * 4; i < cnt; i += DT_BLOCK * 4) {
+        uint32_t w = 0;
+#pragma unroll
+        for (uint32_t q = 0; q < 4; q++)
+            if (i + q < cnt && tag[i + q] == DT_LIT) w |= (val[i + q] & 0xFFu) << (8 * q);
+        if (i + 4 <= cnt) *reinterpret_cast<uint32_t *>(out + j0 + i) = w;
+        else for (uint32_t q = 0; i + q < cnt; q++) out[j0 + i + q] = (uint8_t)(w >> (8 * q));
+    }
+    for (uint32_t i0 = (tid & ~63u); i0 < cnt; i0 += DT_BLOCK) {
+        const uint32_t i = i0 + (tid & 63u);
+        const bool ext = i < cnt && tag[i] == DT_EXT;
+        if (ext) ptr32[j0 + i] = val[i];
+        const unsigned long long m = __ballot(ext);
+        if ((tid & 63u) == 0) unres[(j0 + i0) >> 6] = m;
+    }
+}
+
+__device__ __forceinline__ bool dt_unres(const unsigned long long *__restrict__ unres, uint32_t j)
+{
+    return (unres[j >> 6] >> (j & 63u)) & 1ull;
+}
+
+/* one pass of the global jumping: in_list == null visits every unresolved byte (bitmap), later passes the list
+ * of the pass before; up to four hops, stopping at the first resolved byte */
+__global__ __launch_bounds__(256) void k_dec_jump2(uint32_t *__restrict__ ptr, const unsigned long long *__restrict__ unres, uint32_t total,
+                                                   const uint32_t *__restrict__ in_list, uint32_t *__restrict__ out_list,
+                                                   uint32_t *__restrict__ out_count)
+{
+    __shared__ uint32_t wtot[4], bbase;
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const uint64_t below = (1ull << lane) - 1ull;
+    for (uint32_t base = blockIdx.x * (256u * JUMP_ITEMS); base < total; base += gridDim.x * (256u * JUMP_ITEMS)) {
+        uint32_t j[JUMP_ITEMS];
+        uint64_t m[JUMP_ITEMS];
+        uint32_t mine = 0;
+#pragma unroll
+        for (int u = 0; u < JUMP_ITEMS; u++) {
+            const uint32_t idx = base + 256u * u + threadIdx.x;
+            bool keep = false;
+            j[u] = 0;
+            if (idx < total) {
+                j[u] = in_list ? in_list[idx] : idx;
+                if (in_list || dt_unres(unres, j[u])) {
+                    const uint32_t p = ptr[j[u]];
+                    if (dt_unres(unres, p)) {
+                        const uint32_t q = ptr[p];
+                        if (!dt_unres(unres, q)) ptr[j[u]] = q;
+                        else {
+                            const uint32_t r = ptr[q];
+                            if (!dt_unres(unres, r)) ptr[j[u]] = r;
+                            else {
+                                const uint32_t tt = ptr[r];
+                                ptr[j[u]] = tt;
+                                keep = dt_unres(unres, tt);
+                            }
+                        }
+                    }
+                }
+            }
+            m[u] = __ballot(keep);
+            mine += (uint32_t)__popcll(m[u]);
+        }
+        if (lane == 0) wtot[wave] = mine;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const uint32_t tt = wtot[0] + wtot[1] + wtot[2] + wtot[3];
+            bbase = tt ? atomicAdd(out_count, tt) : 0u;
+        }
+        __syncthreads();
+        uint32_t slot = bbase;
+        for (uint32_t w = 0; w < wave; w++) slot += wtot[w];
+#pragma unroll
+        for (int u = 0; u < JUMP_ITEMS; u++) {
+            if ((m[u] >> lane) & 1ull) out_list[slot + (uint32_t)__popcll(m[u] & below)] = j[u];
+            slot += (uint32_t)__popcll(m[u]);
+        }
+        __syncthreads();
+    }
+}
+
+__global__ void k_dec_gather2(uint8_t *__restrict__ out, const uint32_t *__restrict__ ptr, const unsigned long long *__restrict__ unres,
+                              uint32_t n)
+{
+    for (uint32_t j = blockIdx.x * blockDim.x + threadIdx.x; j < n; j += gridDim.x * blockDim.x)
+        if (dt_unres(unres, j)) out[j] = out[ptr[j]];
+}
+
+size_t lz77k_dec_tile_tmp_bytes(uint32_t n)
+{
+    const size_t ntiles = ((size_t)n + DT_TB - 1) / DT_TB;
+    return (ntiles + 8) * 4 + 256 + ((size_t)n / 64 + 8) * 8;
+}
+
+/* tile pass: out[] (resolved bytes), d_ptr[] + bitmap (the others).  d_tmp: lz77k_dec_tile_tmp_bytes(n);
+ * *d_unres receives the bitmap's address inside it. */
+hipError_t lz77k_dec_tiles(const uint32_t *d_tokval, const uint32_t *d_dst, uint32_t ntok, const lz77x_geom &g, uint8_t *d_out,
+                           uint32_t *d_ptr, uint32_t n, void *d_tmp, const unsigned long long **d_unres, hipStream_t s,
+                           const uint32_t *d_cyc, uint32_t ncyc)
+{
+    if (n == 0 || ntok == 0) return hipSuccess;
+    const uint32_t ntiles = (uint32_t)(((size_t)n + DT_TB - 1) / DT_TB);
+    uint32_t *tfirst = reinterpret_cast<uint32_t *>(d_tmp);
+    unsigned long long *unres = reinterpret_cast<unsigned long long *>(reinterpret_cast<uint8_t *>(d_tmp) + (((size_t)ntiles + 8) * 4 + 255) / 256 * 256);
+    *d_unres = unres;
+    const size_t lds = (size_t)DT_TB * 5;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_dec_tile), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k_dec_bounds, dim3((ntok + 255) / 256), dim3(256), 0, s, d_dst, ntok, tfirst);
+    hipLaunchKernelGGL(k_dec_tile, dim3(ntiles), dim3(DT_BLOCK), lds, s, d_tokval, d_dst, ntok, g.ob, g.lb, d_out, d_ptr, unres, n, ntiles,
+                       tfirst, d_cyc, ncyc, (uint32_t)g.sb);
+    return hipGetLastError();
+}
+
+hipError_t lz77k_dec_jump2(uint32_t *d_ptr, const unsigned long long *d_unres, uint32_t total, const uint32_t *d_in_list,
+                           uint32_t *d_out_list, uint32_t *d_out_count, hipStream_t s)
+{
+    if (total == 0) return hipSuccess;
+    const uint32_t per = 256u * JUMP_ITEMS;
+    const uint32_t blocks = min((total + per - 1) / per, 256u * 16u);
+    hipLaunchKernelGGL(k_dec_jump2, dim3(blocks), dim3(256), 0, s, d_ptr, d_unres, total, d_in_list, d_out_list, d_out_count);
+    return hipGetLastError();
+}
+
+hipError_t lz77k_dec_gather2(uint8_t *d_out, const uint32_t *d_ptr, const unsigned long long *d_unres, uint32_t n, hipStream_t s)
+{
+    if (n == 0) return hipSuccess;
+    const uint32_t blocks = min((n + 255u) / 256u, 256u * 32u);
+    hipLaunchKernelGGL(k_dec_gather2, dim3(blocks), dim3(256), 0, s, d_out, d_ptr, d_unres, n);
+    return hipGetLastError();
+}
+
 hipError_t lz77k_dec_parse(const uint8_t *d_z, uint32_t ntok, const lz77x_geom &g, uint32_t *d_tokval, uint32_t *d_len1, hipStream_t s,
                            uint32_t *d_stale_flag)
 {

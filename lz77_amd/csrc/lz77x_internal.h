@@ -206,6 +206,15 @@ hipError_t lz77k_dec_expand(const uint32_t *d_tokval, const uint32_t *d_dst, uin
 hipError_t lz77k_dec_jump(uint32_t *d_ptr, uint32_t total, const uint32_t *d_in_list, uint32_t *d_out_list, uint32_t *d_out_count,
                           hipStream_t s);
 hipError_t lz77k_dec_gather(uint8_t *d_out, const uint32_t *d_ptr, uint32_t n, hipStream_t s);
+/* tile-local decode (production): per tile of the output everything that stays inside the tile is resolved in
+ * LDS; only pointers that leave a tile reach HBM (d_ptr[] + one bit per byte) and take part in the jumping */
+size_t lz77k_dec_tile_tmp_bytes(uint32_t n);
+hipError_t lz77k_dec_tiles(const uint32_t *d_tokval, const uint32_t *d_dst, uint32_t ntok, const lz77x_geom &g, uint8_t *d_out,
+                           uint32_t *d_ptr, uint32_t n, void *d_tmp, const unsigned long long **d_unres, hipStream_t s,
+                           const uint32_t *d_cyc = nullptr, uint32_t ncyc = 0);
+hipError_t lz77k_dec_jump2(uint32_t *d_ptr, const unsigned long long *d_unres, uint32_t total, const uint32_t *d_in_list,
+                           uint32_t *d_out_list, uint32_t *d_out_count, hipStream_t s);
+hipError_t lz77k_dec_gather2(uint8_t *d_out, const uint32_t *d_ptr, const unsigned long long *d_unres, uint32_t n, hipStream_t s);
 #endif
 
 #endif

@@ -876,8 +876,6 @@ int decode_core(Ctx &c, size_t zn, hipStream_t s, bool want_data, size_t *n_out)
             HIPCHK(hipMemcpy(c.scratch.p, cyc.data(), cyc.size() * 4, hipMemcpyHostToDevice));
             d_cyc = c.scratch.as<uint32_t>();
         }
-        HIPCHK(lz77k_dec_expand(c.tokval.as<uint32_t>(), c.dst.as<uint32_t>(), ntok, g, c.out.as<uint8_t>(),
-                                c.ptr.as<uint32_t>(), n32, s, d_cyc, ncyc));
         /* work lists of the pointer-jumping passes (encode's ps/cells buffers are idle during a decode) */
         if ((rc = c.ps.need((n + 8) * 4))) return rc;
         if ((rc = c.cells.need((n + 8) * 4))) return rc;
@@ -885,17 +883,39 @@ int decode_core(Ctx &c, size_t zn, hipStream_t s, bool want_data, size_t *n_out)
         uint32_t *hcount = reinterpret_cast<uint32_t *>(hdr + 32);
         uint32_t total = n32;
         const uint32_t *in_list = nullptr;
-        for (;;) {
-            HIPCHK(hipMemsetAsync(c.flag.p, 0, 4, s));
-            HIPCHK(lz77k_dec_jump(c.ptr.as<uint32_t>(), total, in_list, lists[rounds & 1], c.flag.as<uint32_t>(), s));
-            HIPCHK(hipMemcpyAsync(hcount, c.flag.p, 4, hipMemcpyDeviceToHost, s));
-            HIPCHK(hipStreamSynchronize(s));
-            in_list = lists[rounds & 1];
-            total = *hcount;
-            rounds += 1;
-            if (!total || rounds > 80) break;
+        if (getenv("LZ77X_DECODE_V1")) {
+            /* round 1: a pointer per output byte in HBM, jumped there (kept as a cross-check) */
+            HIPCHK(lz77k_dec_expand(c.tokval.as<uint32_t>(), c.dst.as<uint32_t>(), ntok, g, c.out.as<uint8_t>(),
+                                    c.ptr.as<uint32_t>(), n32, s, d_cyc, ncyc));
+            for (;;) {
+                HIPCHK(hipMemsetAsync(c.flag.p, 0, 4, s));
+                HIPCHK(lz77k_dec_jump(c.ptr.as<uint32_t>(), total, in_list, lists[rounds & 1], c.flag.as<uint32_t>(), s));
+                HIPCHK(hipMemcpyAsync(hcount, c.flag.p, 4, hipMemcpyDeviceToHost, s));
+                HIPCHK(hipStreamSynchronize(s));
+                in_list = lists[rounds & 1];
+                total = *hcount;
+                rounds += 1;
+                if (!total || rounds > 80) break;
+            }
+            HIPCHK(lz77k_dec_gather(c.out.as<uint8_t>(), c.ptr.as<uint32_t>(), n32, s));
+        } else {
+            /* tiles resolve in LDS what stays inside them; only the pointers that leave a tile are jumped in HBM */
+            if ((rc = c.tstart.need(lz77k_dec_tile_tmp_bytes(n32)))) return rc;
+            const unsigned long long *d_unres = nullptr;
+            HIPCHK(lz77k_dec_tiles(c.tokval.as<uint32_t>(), c.dst.as<uint32_t>(), ntok, g, c.out.as<uint8_t>(), c.ptr.as<uint32_t>(), n32,
+                                   c.tstart.p, &d_unres, s, d_cyc, ncyc));
+            for (;;) {
+                HIPCHK(hipMemsetAsync(c.flag.p, 0, 4, s));
+                HIPCHK(lz77k_dec_jump2(c.ptr.as<uint32_t>(), d_unres, total, in_list, lists[rounds & 1], c.flag.as<uint32_t>(), s));
+                HIPCHK(hipMemcpyAsync(hcount, c.flag.p, 4, hipMemcpyDeviceToHost, s));
+                HIPCHK(hipStreamSynchronize(s));
+                in_list = lists[rounds & 1];
+                total = *hcount;
+                rounds += 1;
+                if (!total || rounds > 80) break;
+            }
+            HIPCHK(lz77k_dec_gather2(c.out.as<uint8_t>(), c.ptr.as<uint32_t>(), d_unres, n32, s));
         }
-        HIPCHK(lz77k_dec_gather(c.out.as<uint8_t>(), c.ptr.as<uint32_t>(), n32, s));
     }
     HIPCHK(hipEventRecord(c.ev[1], s));
     HIPCHK(hipStreamSynchronize(s));
