@@ -382,6 +382,322 @@ hipError_t lz77k_dec_gather2(uint8_t *d_out, const uint32_t *d_ptr, const unsign
     return hipGetLastError();
 }
 
+/* ------------------------------------------------------------------ segment decode -----
+ *
+ * Copy chains are long (a byte of English text is on average 6 hops from its literal, one in five more than 12),
+ * so most chains leave a 12 KB tile and the tile pass above still hands 60 % of the bytes to the global jumping.
+ * But a hop reaches at most sb bytes back: a workgroup that walks a SEGMENT of the output front to back, a
+ * DS_TS-byte step at a time, only ever needs the ROOTS (literal value, or "unknown") of the sb bytes before the
+ * step -- a ring in LDS.  Per step: the step's tokens are expanded into the ring (a copy from before the step
+ * takes the root of its source at once, a copy from inside the step becomes a ring pointer), a few rounds of
+ * pointer doubling inside the 4 KB step settle the rest, the bytes go out.  Segments run concurrently: what lies
+ * before a segment is unknown while it runs, so the sb bytes before it are seeded as symbolic references
+ * EXT(i) = "byte i of the previous segment's tail"; the few bytes whose root is such a reference are flagged and
+ * patched afterwards: the segments' tails (sb roots each) are resolved front to back by one workgroup, then one
+ * pass fills the flagged bytes.  HBM traffic: tokens in, bytes out, 2 B per flagged byte -- no per-byte pointers.
+ * For sb <= 8192 and streams without distance-0 copies; others take the tile pass. */
+#define DS_TS 4096u
+#define DS_R 16384u                                  /* ring slots: >= sb + DS_TS */
+#define DS_BLOCK 512
+#define DS_TAG 0xC000u
+#define DS_LIT 0x0000u                               /* | byte value */
+#define DS_INT 0x4000u                               /* | ring slot of the source (inside the current step) */
+#define DS_EXT 0x8000u                               /* | index into the previous segment's tail */
+
+__global__ void k_dec_bounds_ts(const uint32_t *__restrict__ dst, uint32_t ntok, uint32_t *__restrict__ tfirst)
+{
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= ntok) return;
+    const uint32_t a = dst[k], b = dst[k + 1];
+    const uint32_t t = (a + DS_TS - 1u) / DS_TS;
+    if ((uint64_t)t * DS_TS < b) tfirst[t] = k;
+}
+
+#define DS_PF 2                                      /* tokens per thread fetched a step ahead (2 * 512 cover text and random bytes) */
+#define DS_MAX_STEPS 1024u                           /* steps per segment (segment <= 4 MB) */
+
+__global__ __launch_bounds__(DS_BLOCK) void k_dec_seg(const uint32_t *__restrict__ tokval, const uint32_t *__restrict__ dst, uint32_t ntok,
+                                                      int ob, int lb, uint8_t *__restrict__ out, uint16_t *__restrict__ ref16,
+                                                      unsigned long long *__restrict__ flags, uint32_t n, uint32_t seg_bytes, uint32_t nseg,
+                                                      const uint32_t *__restrict__ tfirst, uint32_t sb, uint16_t *__restrict__ tail)
+{
+    __shared__ uint16_t ring[DS_R];
+    __shared__ uint32_t s_tf[DS_MAX_STEPS + 2];
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const uint32_t sg = blockIdx.x;
+    const uint32_t a = sg * seg_bytes;
+    const uint32_t b = sg + 1 == nseg ? n : a + seg_bytes;
+    const uint32_t nsteps = (b - a + DS_TS - 1u) / DS_TS;
+    if (sg > 0)
+        for (uint32_t i = tid; i < sb; i += DS_BLOCK) ring[(a - sb + i) & (DS_R - 1u)] = (uint16_t)(DS_EXT | i);
+    /* first token of every step (and of the step after the last one, when there is one) */
+    for (uint32_t i = tid; i <= nsteps; i += DS_BLOCK) s_tf[i] = (uint64_t)a + (uint64_t)i * DS_TS < n ? tfirst[a / DS_TS + i] : ntok;
+    __syncthreads();
+    const uint32_t omask = ob ? (1u << ob) - 1u : 0u, lmask = (1u << lb) - 1u;
+    auto krange = [&](uint32_t si, uint32_t &k0, uint32_t &k1) {
+        const uint32_t ts = a + si * DS_TS, te = b - ts < DS_TS ? b : ts + DS_TS;
+        k0 = s_tf[si];
+        k1 = te < n ? s_tf[si + 1] + 1u : ntok;
+    };
+    uint32_t cv[DS_PF], cd[DS_PF], nv[DS_PF], nd[DS_PF];
+    {
+        uint32_t k0, k1;
+        krange(0, k0, k1);
+#pragma unroll
+        for (int q = 0; q < DS_PF; q++) { const uint32_t k = min(k0 + tid + q * DS_BLOCK, ntok - 1u); cv[q] = tokval[k]; cd[q] = dst[k]; }
+    }
+    for (uint32_t si = 0; si < nsteps; si++) {
+        const uint32_t ts = a + si * DS_TS;
+        const uint32_t te = b - ts < DS_TS ? b : ts + DS_TS;
+        uint32_t k0, k1;
+        krange(si, k0, k1);
+        {
+            /* the next step's tokens travel while this step runs (unconditional loads, clamped index) */
+            uint32_t f0 = k0, f1 = k1;
+            if (si + 1 < nsteps) krange(si + 1, f0, f1);
+#pragma unroll
+            for (int q = 0; q < DS_PF; q++) { const uint32_t k = min(f0 + tid + q * DS_BLOCK, ntok - 1u); nv[q] = tokval[k]; nd[q] = dst[k]; }
+        }
+        /* lz77.c:178-194 as data flow, one thread per token */
+        auto expand = [&](uint32_t v, uint32_t d) {
+            const uint32_t off = v & omask, len = (v >> ob) & lmask, lit = (v >> (ob + lb)) & 0xFFu;
+            const uint32_t ia = d < ts ? ts - d : 0u;
+            for (uint32_t i = ia; i <= len; i++) {
+                const uint32_t j = d + i;
+                if (j >= te) break;
+                uint32_t st = DS_LIT | lit;
+                if (i < len) {
+                    if (off == 0 || off > j) st = DS_LIT;                          /* degenerate: a zero byte */
+                    else {
+                        const uint32_t src = j - off;
+                        st = src >= ts ? (DS_INT | (src & (DS_R - 1u))) : (uint32_t)ring[src & (DS_R - 1u)];
+                    }
+                }
+                ring[j & (DS_R - 1u)] = (uint16_t)st;
+            }
+        };
+#pragma unroll
+        for (int q = 0; q < DS_PF; q++)
+            if (k0 + tid + q * DS_BLOCK < k1) expand(cv[q], cd[q]);
+        for (uint32_t k = k0 + tid + DS_PF * DS_BLOCK; k < k1; k += DS_BLOCK) expand(tokval[k], dst[k]);
+        __syncthreads();
+        /* pointer doubling inside the step (16-bit states: a racing reader sees a state further along the chain) */
+        uint32_t pending = (1u << (DS_TS / DS_BLOCK)) - 1u;
+        for (;;) {
+            int any = 0;
+#pragma unroll
+            for (uint32_t q = 0; q < DS_TS / DS_BLOCK; q++) {
+                const uint32_t p = ts + tid + q * DS_BLOCK;
+                if ((pending >> q) & 1u) {
+                    const uint32_t st = p < te ? (uint32_t)ring[p & (DS_R - 1u)] : 0u;
+                    if ((st & DS_TAG) == DS_INT) {
+                        const uint32_t s2 = ring[st & (DS_R - 1u)];
+                        ring[p & (DS_R - 1u)] = (uint16_t)s2;
+                        if ((s2 & DS_TAG) == DS_INT) any = 1; else pending &= ~(1u << q);
+                    } else {
+                        pending &= ~(1u << q);
+                    }
+                }
+            }
+            if (!__syncthreads_or(any)) break;
+        }
+#pragma unroll
+        for (uint32_t q = 0; q < DS_TS / DS_BLOCK; q++) {
+            const uint32_t p0 = ts + q * DS_BLOCK + wave * 64u;
+            const uint32_t p = p0 + lane;
+            const bool valid = p < te;
+            const uint32_t st = valid ? ring[p & (DS_R - 1u)] : 0u;
+            const bool ext = valid && (st & DS_TAG) == DS_EXT;
+            if (valid) out[p] = ext ? (uint8_t)0 : (uint8_t)st;
+            if (ext) ref16[p] = (uint16_t)(st & 0x3FFFu);
+            const unsigned long long m = __ballot(ext);
+            if (lane == 0 && p0 < te) flags[p0 >> 6] = m;
+        }
+        /* no barrier: the next step writes the slots of [te, te + DS_TS), which alias positions older than ts - sb */
+#pragma unroll
+        for (int q = 0; q < DS_PF; q++) { cv[q] = nv[q]; cd[q] = nd[q]; }
+    }
+    if (sg + 1 < nseg)
+        for (uint32_t i = tid; i < sb; i += DS_BLOCK) tail[(size_t)sg * sb + i] = ring[(b - sb + i) & (DS_R - 1u)];
+}
+
+/* The segments' tails, front to back: tres[s][i] = value of byte i of the last sb bytes of segment s.
+ * A tail is a map on the tail before it ("byte i = constant, or byte ref of the previous tail") and such maps
+ * compose, so the chain over S segments runs as ~3*sqrt(S) sequential steps instead of S:
+ *   compose: every group of G consecutive tails -> one map           (one workgroup per group, G steps)
+ *   top    : the groups' maps in sequence -> values at every group end (one workgroup, S/G steps)
+ *   replay : every group again, from the now known values before it   (one workgroup per group, G steps) */
+#define DS_TAIL_MAX 8192u
+__device__ __forceinline__ void ds_load_tail(uint16_t (&r)[8], const uint16_t *__restrict__ row, uint32_t sb)
+{
+#pragma unroll
+    for (int q = 0; q < 8; q++) { const uint32_t i = threadIdx.x + 1024u * q; r[q] = row[min(i, sb - 1u)]; }
+}
+
+__global__ __launch_bounds__(1024) void k_dec_tails_compose(const uint16_t *__restrict__ tail, uint16_t *__restrict__ gmap, uint32_t ntails,
+                                                            uint32_t G, uint32_t sb)
+{
+    __shared__ uint16_t cur[2][DS_TAIL_MAX];
+    const uint32_t g = blockIdx.x, s0 = g * G, s1 = min(s0 + G, ntails);
+    uint16_t st[8], nx[8];
+    ds_load_tail(st, tail + (size_t)s0 * sb, sb);
+    int w = 0;
+    for (uint32_t s = s0; s < s1; s++) {
+        ds_load_tail(nx, tail + (size_t)min(s + 1, s1 - 1u) * sb, sb);
+#pragma unroll
+        for (int q = 0; q < 8; q++) {
+            const uint32_t i = threadIdx.x + 1024u * q;
+            if (i < sb) {
+                const uint32_t x = st[q];
+                cur[w][i] = (s > s0 && (x & DS_TAG) == DS_EXT) ? cur[w ^ 1][x & 0x3FFFu] : (uint16_t)x;
+            }
+        }
+        __syncthreads();
+        w ^= 1;
+#pragma unroll
+        for (int q = 0; q < 8; q++) st[q] = nx[q];
+    }
+    for (uint32_t i = threadIdx.x; i < sb; i += 1024u) gmap[(size_t)g * sb + i] = cur[w ^ 1][i];
+}
+
+/* rows[0..count) applied in sequence to the values `before` (null: nothing lies before -- row 0 holds no
+ * reference); vout[r] = the values after row r */
+__global__ __launch_bounds__(1024) void k_dec_tails_replay(const uint16_t *__restrict__ rows, uint32_t nrows, uint32_t G,
+                                                           const uint8_t *__restrict__ before /* row g-1: the values before group g */,
+                                                           uint8_t *__restrict__ vout, uint32_t sb)
+{
+    __shared__ uint8_t cur[2][DS_TAIL_MAX];
+    const uint32_t g = blockIdx.x, r0 = g * G, r1 = min(r0 + G, nrows);
+    if (r0 >= r1) return;
+    if (before != nullptr && g > 0) {
+        const uint8_t *bsrc = before + (size_t)(g - 1u) * sb;
+        for (uint32_t i = threadIdx.x; i < sb; i += 1024u) cur[1][i] = bsrc[i];
+    }
+    uint16_t st[8], nx[8];
+    ds_load_tail(st, rows + (size_t)r0 * sb, sb);
+    int w = 0;
+    __syncthreads();
+    for (uint32_t r = r0; r < r1; r++) {
+        ds_load_tail(nx, rows + (size_t)min(r + 1, r1 - 1u) * sb, sb);
+#pragma unroll
+        for (int q = 0; q < 8; q++) {
+            const uint32_t i = threadIdx.x + 1024u * q;
+            if (i < sb) {
+                const uint32_t x = st[q];
+                const uint8_t v = (x & DS_TAG) == DS_EXT ? cur[w ^ 1][x & 0x3FFFu] : (uint8_t)x;
+                cur[w][i] = v;
+                vout[(size_t)r * sb + i] = v;
+            }
+        }
+        __syncthreads();
+        w ^= 1;
+#pragma unroll
+        for (int q = 0; q < 8; q++) st[q] = nx[q];
+    }
+}
+
+/* flagged bytes take their value from the resolved tail of the segment before theirs.  A lane fetches one
+ * 64-bit flag word; the wave then visits only the words that have a flag (they cluster at segment starts). */
+__global__ __launch_bounds__(256) void k_dec_patch(uint8_t *__restrict__ out, const uint16_t *__restrict__ ref16,
+                                                   const unsigned long long *__restrict__ flags, const uint8_t *__restrict__ tres, uint32_t n,
+                                                   uint32_t seg_bytes, uint32_t sb)
+{
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t nwords = (n + 63u) / 64u;
+    const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = (gridDim.x * blockDim.x) >> 6;
+    for (uint32_t w0 = wave * 64u; w0 < nwords; w0 += nwaves * 64u) {
+        const uint32_t wi = w0 + lane;
+        const unsigned long long m = wi < nwords ? flags[wi] : 0ull;
+        unsigned long long have = __ballot(m != 0ull);
+        while (have) {
+            /* four flagged words per trip: their dependent loads (ref16 -> tres) overlap */
+            uint32_t j[4], r[4];
+            bool on[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                on[u] = false;
+                j[u] = 0;
+                if (have) {
+                    const int l = __builtin_ctzll(have);
+                    have &= have - 1ull;
+                    const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)m, l);
+                    const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(m >> 32), l);
+                    const unsigned long long mm = ((unsigned long long)hi << 32) | lo;
+                    j[u] = (w0 + (uint32_t)l) * 64u + lane;
+                    on[u] = (mm >> lane) & 1ull;
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++) r[u] = ref16[on[u] ? j[u] : 0u];
+            uint8_t v[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) v[u] = tres[on[u] ? (size_t)(j[u] / seg_bytes - 1u) * sb + r[u] : 0u];
+#pragma unroll
+            for (int u = 0; u < 4; u++)
+                if (on[u]) out[j[u]] = v[u];
+        }
+    }
+}
+
+int lz77k_dec_seg_supported(const lz77x_geom &g) { return g.sb <= 8192; }
+
+static void dec_seg_plan(uint32_t n, uint32_t *seg_bytes, uint32_t *nseg)
+{
+    /* about two segments per CU-slot (four 512-thread workgroups fit a CU), at least 64 KB each */
+    const char *e = getenv("LZ77X_DECODE_SEGMENT");
+    uint64_t sbytes = e && atoll(e) > 0 ? (uint64_t)atoll(e) : ((uint64_t)n + 1023u) / 1024u;
+    if (sbytes < 65536u) sbytes = 65536u;
+    if (sbytes > (uint64_t)DS_MAX_STEPS * DS_TS) sbytes = (uint64_t)DS_MAX_STEPS * DS_TS;
+    sbytes = (sbytes + DS_TS - 1u) / DS_TS * DS_TS;
+    *seg_bytes = (uint32_t)sbytes;
+    *nseg = (uint32_t)(((uint64_t)n + sbytes - 1u) / sbytes);
+}
+
+size_t lz77k_dec_seg_tmp_bytes(uint32_t n, const lz77x_geom &g)
+{
+    uint32_t sbytes, nseg;
+    dec_seg_plan(n, &sbytes, &nseg);
+    return ((size_t)n / DS_TS + 8) * 4 + 256 + ((size_t)n / 64 + 8) * 8 + 256 + (size_t)nseg * g.sb * 3 + ((size_t)nseg / 8 + 40) * g.sb * 3 + 2048;
+}
+
+/* the whole copy resolution: d_out[0..n) from the tokens.  d_ref: 2n bytes; d_tmp: lz77k_dec_seg_tmp_bytes */
+hipError_t lz77k_dec_segments(const uint32_t *d_tokval, const uint32_t *d_dst, uint32_t ntok, const lz77x_geom &g, uint8_t *d_out,
+                              void *d_ref, uint32_t n, void *d_tmp, hipStream_t s)
+{
+    if (n == 0 || ntok == 0) return hipSuccess;
+    uint32_t sbytes, nseg;
+    dec_seg_plan(n, &sbytes, &nseg);
+    uint8_t *base = reinterpret_cast<uint8_t *>(d_tmp);
+    size_t o = 0;
+    auto take = [&](size_t bytes) { uint8_t *q = base + o; o += (bytes + 255) & ~(size_t)255; return q; };
+    uint32_t *tfirst = reinterpret_cast<uint32_t *>(take(((size_t)n / DS_TS + 8) * 4));
+    unsigned long long *flags = reinterpret_cast<unsigned long long *>(take(((size_t)n / 64 + 8) * 8));
+    uint16_t *tail = reinterpret_cast<uint16_t *>(take((size_t)nseg * g.sb * 2));
+    uint8_t *tres = take((size_t)nseg * g.sb);
+    uint16_t *gmap = reinterpret_cast<uint16_t *>(take(((size_t)nseg / 8 + 40) * g.sb * 2));     /* sqrt(nseg) + 1 group maps */
+    uint8_t *gres = take(((size_t)nseg / 8 + 40) * g.sb);
+    hipLaunchKernelGGL(k_dec_bounds_ts, dim3((ntok + 255) / 256), dim3(256), 0, s, d_dst, ntok, tfirst);
+    hipLaunchKernelGGL(k_dec_seg, dim3(nseg), dim3(DS_BLOCK), 0, s, d_tokval, d_dst, ntok, g.ob, g.lb, d_out, reinterpret_cast<uint16_t *>(d_ref),
+                       flags, n, sbytes, nseg, tfirst, (uint32_t)g.sb, tail);
+    if (nseg > 1) {
+        const uint32_t ntails = nseg - 1u, usb = (uint32_t)g.sb;
+        uint32_t G = 1;
+        while (G * G < ntails) G++;
+        const uint32_t NG = (ntails + G - 1u) / G;
+        if (NG > 1) {
+            hipLaunchKernelGGL(k_dec_tails_compose, dim3(NG), dim3(1024), 0, s, tail, gmap, ntails, G, usb);
+            hipLaunchKernelGGL(k_dec_tails_replay, dim3(1), dim3(1024), 0, s, gmap, NG, NG, (const uint8_t *)nullptr, gres, usb);
+            hipLaunchKernelGGL(k_dec_tails_replay, dim3(NG), dim3(1024), 0, s, tail, ntails, G, gres, tres, usb);
+        } else {
+            hipLaunchKernelGGL(k_dec_tails_replay, dim3(1), dim3(1024), 0, s, tail, ntails, ntails, (const uint8_t *)nullptr, tres, usb);
+        }
+        const uint32_t blocks = min((n / 64u + 255u) / 256u + 1u, 256u * 8u);
+        hipLaunchKernelGGL(k_dec_patch, dim3(blocks), dim3(256), 0, s, d_out, reinterpret_cast<const uint16_t *>(d_ref), flags, tres, n, sbytes,
+                           (uint32_t)g.sb);
+    }
+    return hipGetLastError();
+}
+
 hipError_t lz77k_dec_parse(const uint8_t *d_z, uint32_t ntok, const lz77x_geom &g, uint32_t *d_tokval, uint32_t *d_len1, hipStream_t s,
                            uint32_t *d_stale_flag)
 {

@@ -214,6 +214,12 @@ hipError_t lz77k_dec_tiles(const uint32_t *d_tokval, const uint32_t *d_dst, uint
                            const uint32_t *d_cyc = nullptr, uint32_t ncyc = 0);
 hipError_t lz77k_dec_jump2(uint32_t *d_ptr, const unsigned long long *d_unres, uint32_t total, const uint32_t *d_in_list,
                            uint32_t *d_out_list, uint32_t *d_out_count, hipStream_t s);
+/* segment decode (production for sb <= 8192, no distance-0 copies): a workgroup walks a segment of the output
+ * front to back with the roots of the last sb bytes in an LDS ring; no per-byte pointers in HBM */
+int lz77k_dec_seg_supported(const lz77x_geom &g);
+size_t lz77k_dec_seg_tmp_bytes(uint32_t n, const lz77x_geom &g);
+hipError_t lz77k_dec_segments(const uint32_t *d_tokval, const uint32_t *d_dst, uint32_t ntok, const lz77x_geom &g, uint8_t *d_out,
+                              void *d_ref, uint32_t n, void *d_tmp, hipStream_t s);
 hipError_t lz77k_dec_gather2(uint8_t *d_out, const uint32_t *d_ptr, const unsigned long long *d_unres, uint32_t n, hipStream_t s);
 #endif
 

@@ -876,6 +876,11 @@ int decode_core(Ctx &c, size_t zn, hipStream_t s, bool want_data, size_t *n_out)
             HIPCHK(hipMemcpy(c.scratch.p, cyc.data(), cyc.size() * 4, hipMemcpyHostToDevice));
             d_cyc = c.scratch.as<uint32_t>();
         }
+        const char *dv = getenv("LZ77X_DECODE_VARIANT");            /* 0 production, 1 tile pass + jumping, (LZ77X_DECODE_V1: round 1) */
+        if (!stale && lz77k_dec_seg_supported(g) && !(dv && atoi(dv)) && !getenv("LZ77X_DECODE_V1")) {
+            if ((rc = c.tstart.need(lz77k_dec_seg_tmp_bytes(n32, g)))) return rc;
+            HIPCHK(lz77k_dec_segments(c.tokval.as<uint32_t>(), c.dst.as<uint32_t>(), ntok, g, c.out.as<uint8_t>(), c.ptr.p, n32, c.tstart.p, s));
+        } else {
         /* work lists of the pointer-jumping passes (encode's ps/cells buffers are idle during a decode) */
         if ((rc = c.ps.need((n + 8) * 4))) return rc;
         if ((rc = c.cells.need((n + 8) * 4))) return rc;
@@ -915,6 +920,7 @@ int decode_core(Ctx &c, size_t zn, hipStream_t s, bool want_data, size_t *n_out)
                 if (!total || rounds > 80) break;
             }
             HIPCHK(lz77k_dec_gather2(c.out.as<uint8_t>(), c.ptr.as<uint32_t>(), d_unres, n32, s));
+        }
         }
     }
     HIPCHK(hipEventRecord(c.ev[1], s));
