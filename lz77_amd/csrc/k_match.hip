@@ -1034,6 +1034,74 @@ __global__ __launch_bounds__(256) void k_walk_final(const uint8_t *__restrict__ 
     if (region0 + reg == 0 && lx < (uint32_t)sb) maxlen[x] = (uint8_t)longest(wb0[lx], lx, subs + SUB, 0u);
 }
 
+/* The same per RUN with the run's inverse array and bytes staged in LDS: the four inverse look-ups and the two
+ * LCPs of a position are gathers (64 lanes, 64 different lines) -- out of L1 they took 1.8 ms per 100 MB, bound by
+ * the texture path; out of LDS they are bank accesses.  One workgroup per walker run; the workgroup of the input's
+ * first run also answers y < sb (wb0). */
+#define WFIN_BLOCK 256
+__global__ __launch_bounds__(WFIN_BLOCK) void k_walk_final_lds(const uint8_t *__restrict__ in, uint32_t n, int sb, int la, uint32_t SBu,
+                                                               uint32_t TILE, uint32_t region0, uint32_t nregions, uint32_t run_len,
+                                                               uint32_t runs_per_tile, const uint16_t *__restrict__ subs,
+                                                               const uint32_t *__restrict__ wf, const uint32_t *__restrict__ wb,
+                                                               const uint32_t *__restrict__ wb0, uint32_t *__restrict__ ps,
+                                                               uint8_t *__restrict__ maxlen)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t wfin_smem[];
+    const uint32_t SUB = run_len + SBu;
+    uint16_t *s_ix = reinterpret_cast<uint16_t *>(wfin_smem);                       /* SUB entries (SUB is a multiple of 8) */
+    uint8_t *s_by = wfin_smem + (size_t)SUB * 2;                                    /* SUB + la + 16 bytes */
+    const uint32_t tid = threadIdx.x;
+    const uint32_t reg = blockIdx.x / runs_per_tile, run = blockIdx.x - reg * runs_per_tile;
+    const uint64_t t0_64 = (uint64_t)(region0 + reg) * TILE;
+    if (t0_64 >= n) return;
+    const uint32_t t0 = (uint32_t)t0_64;
+    const uint32_t lt1 = n - t0 < TILE ? n - t0 : TILE;
+    const uint32_t lo = run * run_len;
+    if (lo >= lt1) return;
+    const uint32_t tb = min(run_len, lt1 - lo);
+    const uint16_t *ixg = subs + ((size_t)reg * runs_per_tile + run) * 2 * SUB + SUB;
+    for (uint32_t e = tid * 8; e < SUB; e += WFIN_BLOCK * 8)
+        *reinterpret_cast<uint4 *>(s_ix + e) = *reinterpret_cast<const uint4 *>(ixg + e);
+    {
+        const uint64_t avail = (uint64_t)n + LZ77X_PAD - ((uint64_t)t0 + lo);       /* bytes that exist from t0 + lo on (0xFF tail included) */
+        const uint32_t want = SUB + (uint32_t)la + 16;
+        const uint32_t nb = (uint32_t)(avail < want ? avail : want) & ~3u;
+        const uint8_t *src = in + t0 + lo;                                          /* t0, lo: multiples of 8 */
+        for (uint32_t i = tid * 4; i < nb; i += WFIN_BLOCK * 4)
+            *reinterpret_cast<uint32_t *>(s_by + i) = *reinterpret_cast<const uint32_t *>(src + i);
+    }
+    __syncthreads();
+    const uint32_t usb = (uint32_t)sb;
+    auto longest = [&](uint32_t b, uint32_t ly /* relative to lo */) -> uint32_t {
+        const uint32_t left = n - (t0 + lo + ly);
+        const int cap = (int)(left < (uint32_t)la ? left : (uint32_t)la) - 1;
+        uint32_t best = 0;
+        if ((b & 0xFFFFu) != WALK_NONE) best = (uint32_t)lcp_capped<true>(s_by, (uint32_t)s_ix[b & 0xFFFFu], ly, cap);
+        if ((b >> 16) != WALK_NONE) {
+            const uint32_t l2 = (uint32_t)lcp_capped<true>(s_by, (uint32_t)s_ix[b >> 16], ly, cap);
+            best = l2 > best ? l2 : best;
+        }
+        return best;
+    };
+    for (uint32_t t = tid; t < tb; t += WFIN_BLOCK) {
+        const uint32_t lx = lo + t, x = t0 + lx;
+        const size_t rel = (size_t)reg * TILE + lx;
+        const bool evicted = (uint64_t)x + usb < n;                                /* only evicted positions matter */
+        const uint32_t f = wf[rel];
+        uint32_t P = 0, S = 0;
+        if (evicted) {
+            if ((f & 0xFFFFu) != WALK_NONE) S = (uint32_t)s_ix[f & 0xFFFFu] - t;
+            if ((f >> 16) != WALK_NONE) P = (uint32_t)s_ix[f >> 16] - t;
+        }
+        ps[x] = P | (S << 16);
+        if (evicted) maxlen[x + usb] = (uint8_t)longest(wb[rel], t + usb);
+    }
+    if (region0 + reg == 0 && run == 0) {
+        const uint32_t lim = min(usb, n);
+        for (uint32_t lx = tid; lx < lim; lx += WFIN_BLOCK) maxlen[lx] = (uint8_t)longest(wb0[lx], lx);
+    }
+}
+
 /* ---- large windows (RP > 16384): same walk, bitmap in global memory (L2 resident), 32-bit ranks.
  * The walker converts neighbour ranks to distances itself: forward results go straight to ps[],
  * backward ones (candidates of the longest match) to wb[] / wb0[] for k_walk_final_big. ---- */
@@ -1403,9 +1471,15 @@ hipError_t lz77k_match(const uint8_t *d_in, uint32_t n, const lz77x_geom &g, uin
         hipLaunchKernelGGL(k_walk, dim3((uint32_t)((walkers + 63) / 64)), dim3(64), lds, s, subs, n, g.sb, g.SBu, g.TILE,
                            region0, nregions, run_len, runs, wf, wb, wb0);
         if (ev_sort && (e = hipEventRecord(ev_sort[2], s)) != hipSuccess) return e;
-        const uint64_t npos = (uint64_t)nregions * g.TILE;
-        hipLaunchKernelGGL(k_walk_final, dim3((uint32_t)((npos + 255) / 256)), dim3(256), 0, s, d_in, n, g.sb, g.la, g.SBu,
-                           g.TILE, region0, nregions, run_len, runs, subs, wf, wb, wb0, d_ps, d_maxlen);
+        if (getenv("LZ77X_WALK_FINAL_V1")) {
+            const uint64_t npos = (uint64_t)nregions * g.TILE;
+            hipLaunchKernelGGL(k_walk_final, dim3((uint32_t)((npos + 255) / 256)), dim3(256), 0, s, d_in, n, g.sb, g.la, g.SBu,
+                               g.TILE, region0, nregions, run_len, runs, subs, wf, wb, wb0, d_ps, d_maxlen);
+        } else {
+            const size_t flds = (size_t)SUB * 3 + (size_t)g.la + 32;
+            hipLaunchKernelGGL(k_walk_final_lds, dim3((uint32_t)walkers), dim3(WFIN_BLOCK), flds, s, d_in, n, g.sb, g.la, g.SBu,
+                               g.TILE, region0, nregions, run_len, runs, subs, wf, wb, wb0, d_ps, d_maxlen);
+        }
         return hipGetLastError();
     }
     if (variant == 1) return launch_match<false, 1>(LZ77K_MATCH_ARGS);
