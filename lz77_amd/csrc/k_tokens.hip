@@ -514,6 +514,13 @@ __global__ void k_tok_bounds_grid(const uint32_t *__restrict__ chain, uint32_t n
     for (uint32_t t = first; t <= last; t++) tstart[t] = k;
 }
 
+/* workgroup barrier that orders LDS traffic only: global loads in flight stay in flight (__syncthreads() drains
+ * them: its fence waits for vmcnt(0)) */
+__device__ __forceinline__ void ts_barrier_lds()
+{
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
 /* exclusive prefix of one value per thread over the workgroup; *total (LDS) = the sum.  Two barriers. */
 __device__ __forceinline__ uint32_t ts_wg_scan(uint32_t v, uint32_t *wsum, uint32_t *total)
 {
@@ -524,9 +531,9 @@ __device__ __forceinline__ uint32_t ts_wg_scan(uint32_t v, uint32_t *wsum, uint3
         const uint32_t t = __shfl_up(incl, d, 64);
         if (lane >= (uint32_t)d) incl += t;
     }
-    __syncthreads();                                      /* the previous use of wsum is over */
+    ts_barrier_lds();                                     /* the previous use of wsum is over */
     if (lane == 63) wsum[wave] = incl;
-    __syncthreads();
+    ts_barrier_lds();
     uint32_t run = incl - v, all = 0;
 #pragma unroll
     for (uint32_t w = 0; w < TS_BLOCK / 64; w++) {
@@ -545,7 +552,7 @@ __global__ __launch_bounds__(TS_BLOCK) void k_tokens_sorted(const uint8_t *__res
                                                             uint32_t *__restrict__ tokval, uint32_t ent_cap, uint32_t off_sorted,
                                                             uint32_t off_inv, uint32_t off_lofs, uint32_t off_tk, uint32_t off_lent,
                                                             const uint32_t *__restrict__ look, uint32_t nlook, uint32_t voff,
-                                                            const uint16_t *__restrict__ order_all, uint32_t RP, ts_grid G, uint32_t tile0)
+                                                            const uint16_t *__restrict__ order_all, uint32_t RP, ts_grid G, uint32_t tile0, uint32_t ntiles, int ablate)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     uint8_t *by = smem;
@@ -560,11 +567,18 @@ __global__ __launch_bounds__(TS_BLOCK) void k_tokens_sorted(const uint8_t *__res
     uint2 *lent = reinterpret_cast<uint2 *>(smem + off_lent);
     __shared__ uint32_t wsum[TS_BLOCK / 64];
     __shared__ uint32_t s_total;
+    __shared__ uint16_t fb_lo[256], fb_hi[256];
 
     const uint32_t tid = threadIdx.x;
     const uint32_t usb = (uint32_t)sb;
+    /* consecutive workgroups go to different XCDs (eight L2s): give each XCD a contiguous stretch of tiles, so that
+     * the tiles that share a region's order array and overlap in their windows meet in the same L2 */
+    const uint32_t per_xcd = gridDim.x >> 3;
+    const uint32_t tl = (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);
+    if (tl >= ntiles) return;
+    if ((ablate & 15) == 15) return;
     uint32_t a, b, region;
-    ts_tile_range(G, tile0 + blockIdx.x, a, b, region);
+    ts_tile_range(G, tile0 + tl, a, b, region);
     a = max(a, pos0);
     b = min(b, pos1);
     if (a >= b) return;
@@ -573,26 +587,18 @@ __global__ __launch_bounds__(TS_BLOCK) void k_tokens_sorted(const uint8_t *__res
     const uint32_t wbase = wlo & ~3u;
 #define LIST_START(c) ((c) > dbase ? ofs[(c) - dbase - 1] : 0u)
 #define LIST_END(c) ((c) >= dbase ? ofs[(c) - dbase] : 0u)
-    {
-        const uint32_t nb = (b + (uint32_t)la + 8 - wbase + 3) & ~3u;
-        for (uint32_t i = tid * 4; i < nb; i += TS_BLOCK * 4)
-            *reinterpret_cast<uint32_t *>(by + i) = *reinterpret_cast<const uint32_t *>(in + wbase + i);
-    }
     const uint32_t NO = b - wbase;
-    const uint32_t ebase = LIST_START(wbase);
-    const uint32_t ecount = LIST_END(b - 1) - ebase;
-    const bool staged = ecount <= ent_cap && ecount < 65536u;
-    if (staged) {
-        for (uint32_t i = tid; i <= NO; i += TS_BLOCK) lofs[i] = (uint16_t)(LIST_START(wbase + i) - ebase);
-        for (uint32_t e = tid; e < ecount; e += TS_BLOCK) lent[e] = ent[ebase + e];
-    }
-    /* the region's order, filtered down to the cells of [wlo, b) */
-    uint32_t N;
+    /* ---- everything the tile needs from HBM is requested at once (one latency, not seven in a row): the region's
+     *      order, the token range, the hand-over offsets, the window bytes; the barriers in between only order
+     *      LDS traffic (ts_barrier_lds does not wait for loads in flight) ---- */
+    uint32_t mine[16];
     {
         const uint32_t K = RP / TS_BLOCK;                  /* 4, 8 or 16 consecutive slots per thread */
         const uint16_t *ord = order_all + (size_t)region * RP + (size_t)tid * K;
-        uint32_t mine[16];
-        if (K == 16) {
+        if (ablate & 16) {
+#pragma unroll
+            for (int q = 0; q < 16; q++) mine[q] = tid * 16 + q;
+        } else if (K == 16) {
             const uint4 v0 = *reinterpret_cast<const uint4 *>(ord), v1 = *reinterpret_cast<const uint4 *>(ord + 8);
             const uint32_t w[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
 #pragma unroll
@@ -610,6 +616,27 @@ __global__ __launch_bounds__(TS_BLOCK) void k_tokens_sorted(const uint8_t *__res
 #pragma unroll
             for (int q = 4; q < 16; q++) mine[q] = 0xFFFFFFFFu;
         }
+    }
+    const uint32_t k0 = tstart[tl], k1 = tstart[tl + 1];
+    const uint32_t ebase = LIST_START(wbase);
+    const uint32_t ecount = LIST_END(b - 1) - ebase;
+    constexpr int LOFS_PER = (TS_TT + 4096 + 8 + TS_BLOCK - 1) / TS_BLOCK;       /* sb <= 4096 on this path */
+    constexpr int BY_PER = (TS_TT + 4096 + 256 + 16 + 4 * TS_BLOCK - 1) / (4 * TS_BLOCK);
+    uint32_t lo_raw[LOFS_PER], by_raw[BY_PER];
+#pragma unroll
+    for (int r = 0; r < LOFS_PER; r++) {
+        const uint32_t i = tid + (uint32_t)r * TS_BLOCK;
+        lo_raw[r] = (i <= NO && !(ablate & 32)) ? LIST_START(wbase + i) : 0u;
+    }
+    const uint32_t nb = (b + (uint32_t)la + 8 - wbase + 3) & ~3u;
+#pragma unroll
+    for (int r = 0; r < BY_PER; r++) {
+        const uint32_t i = (tid + (uint32_t)r * TS_BLOCK) * 4u;
+        by_raw[r] = (i < nb && !(ablate & 64)) ? *reinterpret_cast<const uint32_t *>(in + wbase + i) : 0u;
+    }
+    /* the region's order, filtered down to the cells of [wlo, b) */
+    uint32_t N;
+    {
         const uint32_t wl = wlo - t0r, wn = b - wlo;        /* region-local window */
         uint32_t cnt = 0;
 #pragma unroll
@@ -625,12 +652,39 @@ __global__ __launch_bounds__(TS_BLOCK) void k_tokens_sorted(const uint8_t *__res
                 run++;
             }
         }
-        __syncthreads();
-        N = s_total;                                        /* = b - wlo: every cell of the window is in the region */
     }
+    if ((ablate & 15) == 14) return;
+#pragma unroll
+    for (int r = 0; r < BY_PER; r++) {
+        const uint32_t i = (tid + (uint32_t)r * TS_BLOCK) * 4u;
+        if (i < nb) *reinterpret_cast<uint32_t *>(by + i) = by_raw[r];
+    }
+    const bool staged = ecount <= ent_cap && ecount < 65536u;
+    if (staged) {
+#pragma unroll
+        for (int r = 0; r < LOFS_PER; r++) {
+            const uint32_t i = tid + (uint32_t)r * TS_BLOCK;
+            if (i <= NO) lofs[i] = (uint16_t)(lo_raw[r] - ebase);
+        }
+        if (!(ablate & 128)) for (uint32_t e = tid; e < ecount; e += TS_BLOCK) lent[e] = ent[ebase + e];
+    }
+    if ((ablate & 15) == 13) return;
+    ts_barrier_lds();
+    N = s_total;                                            /* = b - wlo: every cell of the window is in the region */
+    /* cells by first byte: [fb_lo[c], fb_hi[c]) -- the run of a token of length 1, without a search */
+    for (uint32_t i = tid; i < N; i += TS_BLOCK) {
+        const uint32_t c = by[sorted[i]];
+        const uint32_t cp = i ? (uint32_t)by[sorted[i - 1]] : 256u;
+        if (c != cp) {
+            fb_lo[c] = (uint16_t)i;
+            if (i) fb_hi[cp] = (uint16_t)i;
+        }
+        if (i + 1 == N) fb_hi[c] = (uint16_t)N;
+    }
+    __syncthreads();
 
     const uint32_t omask = ob >= 32 ? 0xFFFFFFFFu : (1u << ob) - 1u;
-    const uint32_t k0 = tstart[blockIdx.x], k1 = tstart[blockIdx.x + 1];
+    if ((ablate & 15) == 1) return;                         /* timing ablations (LZ77X_TS_ABLATE): the output is wrong */
     for (uint32_t kb = k0; kb < k1; kb += TS_TB) {
         const uint32_t nt = min(TS_TB, k1 - kb);
         /* ---- A: the run of cells sharing the token's len bytes; lane pair = (down, up) ---- */
@@ -665,7 +719,9 @@ __global__ __launch_bounds__(TS_BLOCK) void k_tokens_sorted(const uint8_t *__res
                         return true;
                     };
                     const int j = (int)inv[p - a];
-                    if (!up) {
+                    if (len == 1) {
+                        edge = up ? (int)fb_hi[qw[0] & 0xFFu] : (int)fb_lo[qw[0] & 0xFFu];
+                    } else if (!up) {
                         int lo = j, bad = -1, step = 1;           /* every slot of [lo, j) shares; slot `bad` does not */
                         while (lo > 0) {
                             const int t = lo > step ? lo - step : 0;
@@ -697,6 +753,7 @@ __global__ __launch_bounds__(TS_BLOCK) void k_tokens_sorted(const uint8_t *__res
             }
         }
         __syncthreads();
+        if ((ablate & 15) == 2) continue;
         /* ---- the runs laid end to end ---- */
         {
             uint32_t cnt = 0;
@@ -705,7 +762,7 @@ __global__ __launch_bounds__(TS_BLOCK) void k_tokens_sorted(const uint8_t *__res
             if (tid < nt) { tk_cum[tid] = ex; tk_best[tid] = ~0ull; }
             __syncthreads();
         }
-        const uint32_t W = s_total;
+        const uint32_t W = (ablate & 15) == 3 ? 0u : s_total;
         if (tid == 0) tk_cum[nt] = W;
         /* ---- B: every run member: inside the token's window?  then its priority at time p ---- */
         {
@@ -1086,9 +1143,10 @@ hipError_t lz77k_tokens(const uint8_t *d_in, uint32_t n, const lz77x_geom &g, co
         }
         hipLaunchKernelGGL(k_tok_bounds_grid, dim3((ntok + 256) / 256), dim3(256), 0, s, d_chain, ntok, G, tile0, ntiles, d_tstart);
         TIE_EV(0);
-        hipLaunchKernelGGL(k_tokens_sorted, dim3(ntiles), dim3(TS_BLOCK), lds, s, d_in, n, g.sb, g.la, g.ob, g.lb, d_chain, d_tstart, d_maxlen,
+        hipLaunchKernelGGL(k_tokens_sorted, dim3((ntiles + 7u) / 8u * 8u), dim3(TS_BLOCK), lds, s, d_in, n, g.sb, g.la, g.ob, g.lb, d_chain, d_tstart, d_maxlen,
                            d_ofs, d_ent, dbase, pos0, pos1, d_tokval, ent_cap, off_sorted, off_inv, off_lofs, off_tk, off_lent, d_look, nlook, voff,
-                           reinterpret_cast<const uint16_t *>(d_ranks_all), g.RP, G, tile0);
+                           reinterpret_cast<const uint16_t *>(d_ranks_all), g.RP, G, tile0, ntiles,
+                           getenv("LZ77X_TS_ABLATE") ? atoi(getenv("LZ77X_TS_ABLATE")) : 0);
         TIE_EV(1);
         return hipGetLastError();
     }
