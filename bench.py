@@ -317,7 +317,7 @@ def main():
         # the three big kernels of an encode, each timed by its own hipEvent pair on the stream it runs on
         iters = max(int(round(mean(enc_stats, "prio_iters"))), 1)
         cands = {
-            "k_tokens_tile<true> (offset tie-break among equal-length matches)": (mean(enc_stats, "k_tiebreak_ms"), tlaunches, "k_tokens_tile"),
+            "k_tokens_sorted (offset tie-break: equal-length candidates as runs of the regions' sorted order)": (mean(enc_stats, "k_tiebreak_ms"), tlaunches, "k_tokens_sorted"),
             "k_walk (bitmap window walkers: in-order neighbours of every position)": (mean(enc_stats, "k_walk_ms"), launches, "k_walk"),
             "k_match<true,3> (region key sort + rank export)": (mean(enc_stats, "k_sort_ms"), launches, "k_match"),
             "k_prio_fwd (priority recurrence: forward sweep of one gate iteration)": (mean(enc_stats, "k_prio_fwd_ms"), iters, "k_prio_fwd"),
@@ -361,7 +361,7 @@ def main():
                          "kernels_ms_per_step": {v[2]: round(v[0], 3) for v in cands.values()},
                          "match_stage_ms": round(k_match_ms, 3),
                          "match_stage_GBps": round(alg_bytes / (k_match_ms * 1e-3) / 1e9, 3) if k_match_ms > 0 else 0.0},
-            "roofline_decode": {"bound": "hbm", "kernel": "all decode kernels (parse, scan, expand, pointer jumping, gather)",
+            "roofline_decode": {"bound": "hbm", "kernel": "all decode kernels (parse, scan, segment walk with an LDS ring, tail chain, patch)",
                                 "achieved": round(alg_bytes / (mean(dec_stats, "k_decode_ms") * 1e-3) / 1e9, 3) if mean(dec_stats, "k_decode_ms") > 0 else 0.0,
                                 "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                 "frac": round(alg_bytes / (mean(dec_stats, "k_decode_ms") * 1e-3) / 1e9 / HBM_PEAK_GBS, 6) if mean(dec_stats, "k_decode_ms") > 0 else 0.0,
