@@ -1335,6 +1335,224 @@ __global__ __launch_bounds__(64) void k_walk_big(const uint32_t *__restrict__ ra
     }
 }
 
+/* ---- large windows, production: ONE WAVEFRONT per run, the bitmap in LDS, 64 steps at a time -------------
+ *
+ * k_walk_big above gives every lane a 34 KB bitmap in HBM: each access of a step is a random 64-byte line and the
+ * stage is bound by how many of those the memory system moves (114 ms on S3).  Here a wavefront owns one bitmap
+ * over the region's rank space in LDS (RP bits + a one-bit-per-word summary: 33 KB at RP 262144, four wavefronts
+ * per CU) and its 64 lanes take 64 CONSECUTIVE steps t = tg + i together.  Lane i's window is [t, t+sb); all 64
+ * windows share the core [tg+64, tg+sb), differ in the fringe: the old positions O_j = tg+j (in lane i's window
+ * for j >= i; for its forward query, j > i) and the new ones N_j = tg+sb+j (for j < i).  So per group:
+ *   1. every lane clears its own O_i: the bitmap is the core;
+ *   2. every lane queries the core for the neighbours of rank[t+sb] (backward) and rank[t] (forward);
+ *   3. all-to-all over the 2 x 64 fringe ranks (broadcast with v_readlane): a fringe rank that is admissible
+ *      for the lane and closer than the core's answer replaces it;
+ *   4. every lane sets its N_i: the bitmap is the window of the next group.
+ * The first run of the input starts sb steps early with an empty bitmap: its steps t < 0 have no forward query
+ * and answer the backward queries of y < sb (wb0).  Results leave as ranks, like k_walk_big's. */
+__device__ __forceinline__ uint32_t wave_min_u32(uint32_t v)
+{
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) v = min(v, (uint32_t)__shfl_xor((int)v, d, 64));
+    return v;
+}
+__device__ __forceinline__ uint32_t wave_max_u32(uint32_t v)
+{
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) v = max(v, (uint32_t)__shfl_xor((int)v, d, 64));
+    return v;
+}
+
+__global__ __launch_bounds__(64) void k_walk_wave(const uint32_t *__restrict__ ranks, uint32_t n, int sb, uint32_t RP,
+                                                  uint32_t TILE, uint32_t region0, uint32_t nregions, uint32_t run_len,
+                                                  uint32_t runs_per_tile, uint2 *__restrict__ wf, uint2 *__restrict__ wb,
+                                                  uint2 *__restrict__ wb0)
+{
+    extern __shared__ uint32_t wv_bm[];
+    const uint32_t NW = RP >> 5, NS = (NW + 31) >> 5;
+    uint32_t *word = wv_bm, *summ = wv_bm + NW;
+    const uint32_t lane = threadIdx.x;
+    const uint32_t run = blockIdx.x % runs_per_tile, reg = blockIdx.x / runs_per_tile;
+    const uint32_t usb = (uint32_t)sb;
+    const uint32_t NONE = 0xFFFFFFFFu;
+    if (reg >= nregions) return;
+    const uint64_t t0_64 = (uint64_t)(region0 + reg) * TILE;
+    if (t0_64 >= n) return;
+    const uint32_t t0 = (uint32_t)t0_64;
+    const uint64_t rend64 = (uint64_t)t0 + TILE + usb;
+    const uint32_t R = (rend64 < n ? (uint32_t)rend64 : n) - t0;
+    const uint32_t lt1 = n - t0 < TILE ? n - t0 : TILE;
+    const uint32_t ta = run * run_len;
+    if (ta >= lt1) return;
+    const uint32_t tb = min(ta + run_len, lt1);
+    const uint32_t *rk = ranks + (size_t)reg * (2 * (size_t)RP + 8);
+    const bool first = region0 + reg == 0 && run == 0;
+    auto wsync = [&]() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); };
+
+    for (uint32_t w = lane; w < NW + NS; w += 64) wv_bm[w] = 0;
+    wsync();
+    /* no set bit lies in a summary word below lo_s or above hi_s (wave-uniform): what keeps a query that has no
+     * neighbour on one side -- every step of a stretch of equal bytes -- from scanning the whole summary */
+    uint32_t lo_s = NS, hi_s = 0;
+    if (!first) {
+        const uint32_t e = min(ta + usb, R);
+        uint32_t mn = NONE, mx = 0;
+        for (uint32_t i0 = ta; i0 < e; i0 += 64 * 4) {
+            uint32_t r[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) { const uint32_t i = i0 + 64 * u + lane; r[u] = i < e ? rk[i] : NONE; }
+#pragma unroll
+            for (int u = 0; u < 4; u++)
+                if (r[u] != NONE) {
+                    atomicOr(&word[r[u] >> 5], 1u << (r[u] & 31));
+                    atomicOr(&summ[r[u] >> 10], 1u << ((r[u] >> 5) & 31));
+                    mn = min(mn, r[u] >> 10);
+                    mx = max(mx, r[u] >> 10);
+                }
+        }
+        lo_s = min(wave_min_u32(mn), NS);
+        hi_s = wave_max_u32(mx);
+        wsync();
+    }
+    /* first set rank in words > w / last set rank in words < w, through the summary (a summary bit whose word is
+     * empty is skipped); *dry: the scan ran out -- nothing lies beyond w on that side */
+    auto up_slow = [&](uint32_t w, bool &dry) -> uint32_t {
+        uint32_t sw = w >> 5;
+        if (sw > hi_s) { dry = true; return NONE; }
+        uint32_t sm = summ[sw] & ~((2u << (w & 31)) - 1u);
+        for (;;) {
+            while (!sm && ++sw <= hi_s) sm = summ[sw];
+            if (!sm) { dry = true; return NONE; }
+            const uint32_t w2 = (sw << 5) + (uint32_t)__builtin_ctz(sm);
+            const uint32_t m = word[w2];
+            if (m) return (w2 << 5) + (uint32_t)__builtin_ctz(m);
+            sm &= sm - 1;
+        }
+    };
+    auto down_slow = [&](uint32_t w, bool &dry) -> uint32_t {
+        int32_t sw = (int32_t)(w >> 5);
+        if (sw < (int32_t)lo_s) { dry = true; return NONE; }
+        uint32_t sm = summ[sw] & ((1u << (w & 31)) - 1u);
+        for (;;) {
+            while (!sm && --sw >= (int32_t)lo_s) sm = summ[sw];
+            if (!sm) { dry = true; return NONE; }
+            const uint32_t top = 31u - (uint32_t)__builtin_clz(sm);
+            const uint32_t w2 = ((uint32_t)sw << 5) + top;
+            const uint32_t m = word[w2];
+            if (m) return (w2 << 5) + 31u - (uint32_t)__builtin_clz(m);
+            sm &= ~(1u << top);
+        }
+    };
+    uint32_t dry_up = NONE, dry_dn = 0;                      /* lowest word an up-scan / highest word a down-scan ran dry from */
+    auto core = [&](uint32_t q, uint32_t &su, uint32_t &pr) {     /* q's own bit is not set */
+        const uint32_t w0 = q >> 5, b0 = q & 31;
+        const uint32_t here = word[w0], next = word[min(w0 + 1, NW - 1)], prev = word[w0 ? w0 - 1 : 0];
+        const uint32_t m1 = here & ~((2u << b0) - 1u), m2 = here & ((1u << b0) - 1u);
+        bool dry = false;
+        if (m1) su = (w0 << 5) + (uint32_t)__builtin_ctz(m1);
+        else if (w0 + 1 < NW && next) su = ((w0 + 1) << 5) + (uint32_t)__builtin_ctz(next);
+        else {
+            su = w0 + 1 < NW ? up_slow(w0 + 1, dry) : NONE;
+            if (dry) dry_up = min(dry_up, w0 >> 5);
+        }
+        dry = false;
+        if (m2) pr = (w0 << 5) + 31u - (uint32_t)__builtin_clz(m2);
+        else if (w0 > 0 && prev) pr = ((w0 - 1) << 5) + 31u - (uint32_t)__builtin_clz(prev);
+        else {
+            pr = w0 > 0 ? down_slow(w0 - 1, dry) : NONE;
+            if (dry) dry_dn = max(dry_dn, w0 >> 5);
+        }
+    };
+
+    uint2 *of = wf + (size_t)reg * TILE, *ob = wb + (size_t)reg * TILE;
+    const int32_t tstart = first ? -(int32_t)usb : (int32_t)ta;
+    auto fetch = [&](int32_t tg, uint32_t &rx, uint32_t &ry) {
+        const int32_t t = tg + (int32_t)lane;
+        const bool act = t < (int32_t)tb;
+        rx = (act && t >= 0) ? rk[t] : NONE;
+        const uint32_t y = (uint32_t)(t + (int32_t)usb);
+        ry = (act && y < R) ? rk[y] : NONE;
+    };
+    uint32_t rx, ry, rxn = NONE, ryn = NONE;
+    fetch(tstart, rx, ry);
+    for (int32_t tg = tstart; tg < (int32_t)tb; tg += 64) {
+        if (tg + 64 < (int32_t)tb) fetch(tg + 64, rxn, ryn);      /* the next group's ranks travel while this one runs */
+        const int32_t t = tg + (int32_t)lane;
+        /* 1. the old positions leave */
+        if (rx != NONE) {
+            const uint32_t bit = 1u << (rx & 31);
+            const uint32_t old = atomicAnd(&word[rx >> 5], ~bit);
+            if ((old & ~bit) == 0u) atomicAnd(&summ[rx >> 10], ~(1u << ((rx >> 5) & 31)));
+        }
+        wsync();
+        /* 2. the core */
+        uint32_t fs = NONE, fp = NONE, bs = NONE, bp = NONE;
+        dry_up = NONE;
+        dry_dn = 0;
+        if (rx != NONE) core(rx, fs, fp);
+        if (ry != NONE) core(ry, bs, bp);
+        /* 3. the fringe: O_j counts for the backward query of lanes i <= j and the forward query of lanes i < j,
+         *    N_j for both queries of lanes i > j.  Ranks are distinct; "closer than the current answer" in unsigned
+         *    arithmetic with NONE = 0xFFFFFFFF as "no successor" and pred stored + 1 (0 = none). */
+        {
+            /* branch-free: which lanes a fringe rank is admissible for is a wave-uniform mask of j, so a candidate
+             * costs compare + mask + select + min/max; a single wavefront per SIMD issues one instruction every
+             * 5-8 cycles, the count is what matters */
+            uint32_t fp1 = fp + 1u, bp1 = bp + 1u;               /* NONE + 1 = 0 */
+            const uint64_t hasx = __ballot(rx != NONE), hasy = __ballot(ry != NONE);
+            for (int j = 0; j < 64; j++) {
+                const uint32_t co = (uint32_t)__builtin_amdgcn_readlane((int)rx, j);
+                const uint32_t cn = (uint32_t)__builtin_amdgcn_readlane((int)ry, j);
+                const uint64_t upto = (2ull << j) - 1ull;          /* lanes i <= j */
+                const uint64_t below = upto >> 1;                  /* lanes i < j */
+                const uint64_t ob_ok = ((hasx >> j) & 1ull) ? (upto & hasy) : 0ull;
+                const uint64_t of_ok = ((hasx >> j) & 1ull) ? (below & hasx) : 0ull;
+                const uint64_t nb_ok = ((hasy >> j) & 1ull) ? (~upto & hasy) : 0ull;
+                const uint64_t nf_ok = ((hasy >> j) & 1ull) ? (~upto & hasx) : 0ull;
+                const bool me_ob = (ob_ok >> lane) & 1ull, me_of = (of_ok >> lane) & 1ull;
+                const bool me_nb = (nb_ok >> lane) & 1ull, me_nf = (nf_ok >> lane) & 1ull;
+                bs = min(bs, (me_ob && co > ry) ? co : NONE);
+                bp1 = max(bp1, (me_ob && co < ry) ? co + 1u : 0u);
+                fs = min(fs, (me_of && co > rx) ? co : NONE);
+                fp1 = max(fp1, (me_of && co < rx) ? co + 1u : 0u);
+                bs = min(bs, (me_nb && cn > ry) ? cn : NONE);
+                bp1 = max(bp1, (me_nb && cn < ry) ? cn + 1u : 0u);
+                fs = min(fs, (me_nf && cn > rx) ? cn : NONE);
+                fp1 = max(fp1, (me_nf && cn < rx) ? cn + 1u : 0u);
+            }
+            fp = fp1 - 1u;
+            bp = bp1 - 1u;
+        }
+        wsync();
+        /* 4. the new positions enter */
+        uint32_t mn = NONE, mx = 0;
+        if (ry != NONE) {
+            atomicOr(&word[ry >> 5], 1u << (ry & 31));
+            atomicOr(&summ[ry >> 10], 1u << ((ry >> 5) & 31));
+            mn = mx = ry >> 10;
+        }
+        /* bounds: sets widen them, a scan that ran dry tightens them (conservative either way) */
+        {
+            const uint32_t du = wave_min_u32(dry_up), dd = wave_max_u32(dry_dn);
+            if (du != NONE) hi_s = min(hi_s, du);
+            if (dd != 0u) lo_s = max(lo_s, dd);
+            const uint32_t smn = wave_min_u32(mn), smx = wave_max_u32(mx);
+            if (smn != NONE) { lo_s = min(lo_s, smn); hi_s = max(hi_s, smx); }
+        }
+        wsync();
+        if (t < (int32_t)tb) {
+            if (t >= 0) {
+                of[t] = make_uint2(fs, fp);
+                ob[t] = make_uint2(bs, bp);
+            } else {
+                wb0[t + (int32_t)usb] = make_uint2(bs, bp);
+            }
+        }
+        rx = rxn;
+        ry = ryn;
+    }
+}
+
 __global__ __launch_bounds__(256) void k_walk_final_big(const uint8_t *__restrict__ in, uint32_t n, int sb, int la, uint32_t RP,
                                                         uint32_t TILE, uint32_t region0, uint32_t nregions,
                                                         const uint32_t *__restrict__ ranks, const uint2 *__restrict__ wf,
@@ -1398,6 +1616,16 @@ static uint32_t walk_run_big(const lz77x_geom &g)
 {
     const char *rl = getenv("LZ77X_WALK_RUN_BIG");
     uint32_t run_len = rl && atoi(rl) > 0 ? (uint32_t)atoi(rl) : WALK_RUN_BIG_DEFAULT;
+    return run_len < g.TILE ? run_len : g.TILE;
+}
+
+/* steps per wavefront of the LDS large-window walker (LZ77X_WALK_RUN_WAVE overrides): its fill costs sb bit sets,
+ * so runs are long */
+static uint32_t walk_run_wave(const lz77x_geom &g)
+{
+    const char *rl = getenv("LZ77X_WALK_RUN_WAVE");
+    uint32_t run_len = rl && atoi(rl) > 0 ? (uint32_t)atoi(rl) : 8192u;
+    run_len = (run_len + 63u) & ~63u;
     return run_len < g.TILE ? run_len : g.TILE;
 }
 
@@ -1497,13 +1725,24 @@ hipError_t lz77k_match(const uint8_t *d_in, uint32_t n, const lz77x_geom &g, uin
         e = launch_match<false, 3>(d_in, n, g, region0, nregions, d_ps, d_maxlen, ranks, s);
         if (e != hipSuccess) return e;
         if (ev_sort && (e = hipEventRecord(ev_sort[1], s)) != hipSuccess) return e;
-        const uint32_t run_len = walk_run_big(g);
-        const uint32_t runs = (g.TILE + run_len - 1) / run_len;
         const size_t nws = (g.RP >> 5) + (((g.RP >> 5) + 31) >> 5);
+        const bool wave_walk = !getenv("LZ77X_WALK_BIG_V1") && nws * 4 <= 64 * 1024;
+        const uint32_t run_len = wave_walk ? walk_run_wave(g) : walk_run_big(g);
+        const uint32_t runs = (g.TILE + run_len - 1) / run_len;
         const uint64_t walkers = (uint64_t)nregions * runs;
-        uint2 *wf = reinterpret_cast<uint2 *>(bitmaps + walkers * nws);      /* (2RP+8)*4 and nws*4 are multiples of 8 */
+        uint2 *wf = reinterpret_cast<uint2 *>(bitmaps + (wave_walk ? 0 : walkers * nws));      /* (2RP+8)*4 and nws*4 are multiples of 8 */
         uint2 *wb = wf + (size_t)nregions * g.TILE;
         uint2 *wb0 = wb + (size_t)nregions * g.TILE;
+        if (wave_walk) {
+            /* one wavefront per run, bitmap in LDS, 64 steps at a time */
+            const size_t wlds = nws * 4;
+            if (wlds > 48 * 1024) {
+                e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_walk_wave), hipFuncAttributeMaxDynamicSharedMemorySize, (int)wlds);
+                if (e != hipSuccess) return e;
+            }
+            hipLaunchKernelGGL(k_walk_wave, dim3((uint32_t)walkers), dim3(64), wlds, s, ranks, n, g.sb, g.RP, g.TILE, region0, nregions, run_len,
+                               runs, wf, wb, wb0);
+        } else
         hipLaunchKernelGGL(k_walk_big, dim3((uint32_t)((walkers + 63) / 64)), dim3(64), 0, s, ranks, n, g.sb, g.RP, g.TILE,
                            region0, nregions, run_len, runs, bitmaps, wf, wb, wb0, getenv("LZ77X_WALK_DEBUG") ? atoi(getenv("LZ77X_WALK_DEBUG")) : 0);
         if (ev_sort && (e = hipEventRecord(ev_sort[2], s)) != hipSuccess) return e;
