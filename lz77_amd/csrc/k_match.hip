@@ -1593,6 +1593,257 @@ __global__ __launch_bounds__(256) void k_walk_final_big(const uint8_t *__restric
     if (region0 + reg == 0 && lx < (uint32_t)sb) maxlen[x64] = (uint8_t)longest(wb0[lx], lx);
 }
 
+/* ------------------------------------------------------------------ large regions: one sort for all of them ----
+ *
+ * k_match<false,3> gives every region of 262144 slots to ONE workgroup: 16 chunk sorts in LDS one after the other,
+ * then merge levels straight out of global memory, sixteen wavefronts on a CU to hide their round trips (S3: 115 ms).
+ * But regions overlap (region r = positions [r*TILE, r*TILE+RP), TILE = 3/4 RP) and (key, position) is ONE total
+ * order: a sorted run of positions is the same run in every region that contains it.  When TILE is a multiple of
+ * 65536 the regions are unions of globally aligned 64 K blocks, so
+ *   k_big_chunks     sorts every 16 K chunk of the input once, in LDS, exactly like a small-window region
+ *                    (uint16 indices + staged key bytes: two workgroups per CU);
+ *   k_big_partition  + k_big_merge: merge levels over the WHOLE launch, a workgroup per 2048 outputs: the merge
+ *                    path of its two diagonals comes from the partition kernel, its slice of both runs is loaded
+ *                    coalesced, the 16-byte key heads of its 2048 elements are fetched in parallel (the only
+ *                    random global reads) and the serial merge steps run on LDS.  16 K -> 32 K -> 64 K once for
+ *                    everybody (indices relative to the block: uint16), 64 K -> 128 K -> 256 K per region (uint32,
+ *                    relative to the region's first position; the rank array doubles as the second buffer);
+ *   k_big_ranks      inverts the order into the rank array.
+ * A region's order then also holds the positions [R, RP) the old kernel pushed to the end as "invalid" (they belong
+ * to the next region's tile); no window ever contains them, the walkers never ask for their ranks, and the rank-order
+ * tie-break bounds its walk by the positions that exist (lz77k_big_sort_shared). */
+#define BIG_CH  (16u * MATCH_BLOCK)
+#define BIG_BLK 65536u
+#define BIG_T   2048u
+#define BIG_MB  256
+
+__global__ __launch_bounds__(MATCH_BLOCK, 8) void k_big_chunks(const uint8_t *__restrict__ in, uint32_t n, int la, uint64_t pos0,
+                                                              uint16_t *__restrict__ out)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    uint16_t *ix = reinterpret_cast<uint16_t *>(smem);
+    uint8_t *lby = smem + BIG_CH * sizeof(uint16_t);
+    const uint32_t tid = threadIdx.x;
+    const uint64_t base = pos0 + (uint64_t)blockIdx.x * BIG_CH;
+    const uint32_t Rl = base >= n ? 0u : (n - (uint32_t)base < BIG_CH ? n - (uint32_t)base : BIG_CH);
+    const uint32_t nb = Rl ? (Rl + (uint32_t)la + 24 + 3) & ~3u : 0u;
+    for (uint32_t i = tid * 4; i < nb; i += MATCH_BLOCK * 4) *reinterpret_cast<uint32_t *>(lby + i) = ld32u(in + base + i);
+    for (uint32_t i = tid; i < BIG_CH; i += MATCH_BLOCK) ix[i] = (uint16_t)i;
+    __syncthreads();
+    if (Rl) region_sort_merge<uint16_t, true>(ix, lby, Rl, la, tid);
+    uint16_t *o = out + (size_t)blockIdx.x * BIG_CH;
+    for (uint32_t e = tid * 8; e < BIG_CH; e += MATCH_BLOCK * 8) *reinterpret_cast<uint4 *>(o + e) = *reinterpret_cast<const uint4 *>(ix + e);
+}
+
+/* One merge level: pair p = (group g = p / ppg, j = p % ppg) merges the runs A | B of L elements each that start at
+ * src + g*src_gstride + j*2L into dst + g*dst_gstride + j*2L; keys are read at in + pos0 + g*kb_gstride + index.
+ * rel: the stored indices are relative to their own run (shared uint16 levels): + j*2L (+ L for B) makes them
+ * relative to the group's key base. */
+struct big_level {
+    const void *src;
+    void *dst;
+    uint64_t src_gstride, dst_gstride, pos0;
+    uint32_t L, ppg, kb_gstride, rel, npairs;
+};
+
+template <class InT> struct big_pair {
+    const InT *A, *B;
+    const uint8_t *by;
+    uint32_t a_add, b_add, R;
+    size_t out_off;
+};
+
+template <class InT>
+__device__ __forceinline__ big_pair<InT> big_pair_of(const big_level &lv, const uint8_t *in, uint32_t n, uint32_t p)
+{
+    big_pair<InT> bp;
+    const uint32_t g = p / lv.ppg, j = p % lv.ppg;
+    bp.A = reinterpret_cast<const InT *>(lv.src) + (size_t)g * lv.src_gstride + (size_t)j * 2 * lv.L;
+    bp.B = bp.A + lv.L;
+    bp.a_add = lv.rel ? j * 2 * lv.L : 0u;
+    bp.b_add = lv.rel ? j * 2 * lv.L + lv.L : 0u;
+    const uint64_t kb = lv.pos0 + (uint64_t)g * lv.kb_gstride;
+    bp.by = kb < n ? in + kb : in;                           /* nothing valid: R = 0 and no key is ever looked at */
+    bp.R = kb < n ? n - (uint32_t)kb : 0u;
+    bp.out_off = (size_t)g * lv.dst_gstride + (size_t)j * 2 * lv.L;
+    return bp;
+}
+
+__device__ __forceinline__ void big_masks(int la, uint32_t (&m)[4])
+{
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const int rem = la - 4 * i;
+        m[i] = rem >= 4 ? 0xFFFFFFFFu : rem <= 0 ? 0u : 0xFFFFFFFFu << (8 * (4 - rem));
+    }
+}
+
+/* split[p*(ntile+1) + k] = how many of the first k*BIG_T outputs of pair p come from A */
+template <class InT>
+__global__ __launch_bounds__(256) void k_big_partition(const uint8_t *__restrict__ in, uint32_t n, int la, big_level lv,
+                                                       uint32_t *__restrict__ split)
+{
+    const uint32_t ntile = 2 * lv.L / BIG_T;
+    const uint64_t gid = (uint64_t)blockIdx.x * 256u + threadIdx.x;
+    const uint32_t p = (uint32_t)(gid / (ntile + 1)), k = (uint32_t)(gid % (ntile + 1));
+    if (p >= lv.npairs) return;
+    const big_pair<InT> bp = big_pair_of<InT>(lv, in, n, p);
+    uint32_t m[4];
+    big_masks(la, m);
+    const uint32_t L = lv.L, d = k * BIG_T;
+    uint32_t lo = d > L ? d - L : 0, hi = d < L ? d : L;
+    while (lo < hi) {
+        const uint32_t mid = (lo + hi) >> 1;
+        const uint32_t a = (uint32_t)bp.A[mid] + bp.a_add, b = (uint32_t)bp.B[d - 1 - mid] + bp.b_add;
+        const key16 ka = load_key16<false>(bp.by, a, a < bp.R, m), kb = load_key16<false>(bp.by, b, b < bp.R, m);
+        if (sort_less16<false>(bp.by, a, ka, b, kb, bp.R, la)) lo = mid + 1; else hi = mid;
+    }
+    split[gid] = lo;
+}
+
+template <class InT, class OutT>
+__global__ __launch_bounds__(BIG_MB) void k_big_merge(const uint8_t *__restrict__ in, uint32_t n, int la, big_level lv,
+                                                     const uint32_t *__restrict__ split)
+{
+    constexpr uint32_t VT = BIG_T / BIG_MB;
+    __shared__ uint32_t lidx[BIG_T];
+    __shared__ __attribute__((aligned(16))) uint64_t lkey[2 * BIG_T];
+    const uint32_t ntile = 2 * lv.L / BIG_T, tid = threadIdx.x;
+    const uint32_t p = blockIdx.x / ntile, k = blockIdx.x % ntile;
+    const big_pair<InT> bp = big_pair_of<InT>(lv, in, n, p);
+    uint32_t m[4];
+    big_masks(la, m);
+    const uint32_t a0 = split[(size_t)p * (ntile + 1) + k], a1 = split[(size_t)p * (ntile + 1) + k + 1];
+    const uint32_t b0 = k * BIG_T - a0, na = a1 - a0, nb = BIG_T - na;
+    const uint32_t R = bp.R;
+    const uint8_t *by = bp.by;
+#pragma unroll
+    for (uint32_t q = 0; q < VT; q++) {
+        const uint32_t i = tid + BIG_MB * q;
+        const uint32_t v = i < na ? (uint32_t)bp.A[a0 + i] + bp.a_add : (uint32_t)bp.B[b0 + (i - na)] + bp.b_add;
+        lidx[i] = v;
+        const key16 kk = load_key16<false>(by, v, v < R, m);
+        lkey[2 * i] = kk.hi;
+        lkey[2 * i + 1] = kk.lo;
+    }
+    __syncthreads();
+    auto less = [&](uint32_t ia, uint32_t ib) -> bool {      /* LDS slots */
+        key16 ka, kb;
+        ka.hi = lkey[2 * ia]; ka.lo = lkey[2 * ia + 1];
+        kb.hi = lkey[2 * ib]; kb.lo = lkey[2 * ib + 1];
+        return sort_less16<false>(by, lidx[ia], ka, lidx[ib], kb, R, la);
+    };
+    const uint32_t d = tid * VT;
+    uint32_t lo = d > nb ? d - nb : 0, hi = d < na ? d : na;
+    while (lo < hi) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (less(mid, na + (d - 1 - mid))) lo = mid + 1; else hi = mid;
+    }
+    uint32_t ia = lo, ib = d - lo, o[VT];
+#pragma unroll
+    for (uint32_t r = 0; r < VT; r++) {
+        const bool va = ia < na, vb = ib < nb;
+        const bool take_a = !vb || (va && less(ia, na + ib));
+        o[r] = lidx[take_a ? ia : na + ib];
+        ia += take_a ? 1u : 0u;
+        ib += take_a ? 0u : 1u;
+    }
+    __syncthreads();
+#pragma unroll
+    for (uint32_t r = 0; r < VT; r++) lidx[d + r] = o[r];
+    __syncthreads();
+    OutT *out = reinterpret_cast<OutT *>(lv.dst) + bp.out_off + (size_t)k * BIG_T;
+#pragma unroll
+    for (uint32_t q = 0; q < VT; q++) out[tid + BIG_MB * q] = (OutT)lidx[tid + BIG_MB * q];
+}
+
+/* rk[ix[r]] = r: the rank array from the order */
+__global__ __launch_bounds__(256) void k_big_ranks(uint32_t *__restrict__ ranks, uint32_t RP)
+{
+    uint32_t *rk = ranks + (size_t)blockIdx.y * (2 * (size_t)RP + 8);
+    const uint32_t *ix = rk + RP + 8;
+    const uint32_t r = blockIdx.x * 256u + threadIdx.x;
+    if (r < RP) rk[ix[r]] = r;
+    if (r < 8) rk[RP + r] = 0;
+}
+
+int lz77k_big_sort_shared(const lz77x_geom &g)
+{
+    return !g.fast && g.shifted && g.RP >= 2 * BIG_BLK && g.TILE % BIG_BLK == 0 && !getenv("LZ77X_BIG_SORT_V1") &&
+           !(getenv("LZ77X_SORT_VARIANT") && atoi(getenv("LZ77X_SORT_VARIANT")));
+}
+
+/* bytes behind the walkers' part of the scratch: two uint16 arrays over the launch's positions + the splits */
+static size_t big_sort_span(const lz77x_geom &g, uint32_t nregions) { return (size_t)(nregions - 1) * g.TILE + g.RP; }
+static size_t big_sort_split_words(const lz77x_geom &g, uint32_t nregions)
+{
+    /* per level: npairs * (2L / T + 1); elements never exceed nregions * RP */
+    return ((size_t)nregions * g.RP) / BIG_T + ((size_t)nregions * g.RP) / (2 * BIG_CH) + 64;
+}
+static size_t big_sort_extra_bytes(const lz77x_geom &g, uint32_t nregions)
+{
+    if (!nregions) return 0;
+    return 2 * ((big_sort_span(g, nregions) * 2 + 255) & ~(size_t)255) + big_sort_split_words(g, nregions) * 4 + 256;
+}
+
+template <class InT, class OutT>
+static hipError_t big_level_run(const uint8_t *d_in, uint32_t n, int la, const big_level &lv, uint32_t *d_split, hipStream_t s)
+{
+    const uint32_t ntile = 2 * lv.L / BIG_T;
+    const uint64_t nsplit = (uint64_t)lv.npairs * (ntile + 1);
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_big_partition<InT>), dim3((uint32_t)((nsplit + 255) / 256)), dim3(256), 0, s, d_in, n, la, lv, d_split);
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_big_merge<InT, OutT>), dim3(lv.npairs * ntile), dim3(BIG_MB), 0, s, d_in, n, la, lv, d_split);
+    return hipGetLastError();
+}
+
+/* order + ranks of regions [region0, region0 + nregions) into ranks[] ((2RP+8) words per region); d_extra:
+ * big_sort_extra_bytes() */
+static hipError_t big_sort(const uint8_t *d_in, uint32_t n, const lz77x_geom &g, uint32_t region0, uint32_t nregions, uint32_t *ranks,
+                           void *d_extra, hipStream_t s)
+{
+    const size_t span = big_sort_span(g, nregions), sbytes = (span * 2 + 255) & ~(size_t)255;
+    uint16_t *S[2] = {reinterpret_cast<uint16_t *>(d_extra), reinterpret_cast<uint16_t *>(reinterpret_cast<uint8_t *>(d_extra) + sbytes)};
+    uint32_t *split = reinterpret_cast<uint32_t *>(reinterpret_cast<uint8_t *>(d_extra) + 2 * sbytes);
+    const uint64_t pos0 = (uint64_t)region0 * g.TILE;
+    const size_t lds = (size_t)BIG_CH * 2 + BIG_CH + 256 + 32;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_big_chunks), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k_big_chunks, dim3((uint32_t)(span / BIG_CH)), dim3(MATCH_BLOCK), lds, s, d_in, n, g.la, pos0, S[0]);
+    int cur = 0;
+    for (uint32_t L = BIG_CH; L < BIG_BLK; L <<= 1) {       /* shared levels */
+        big_level lv;
+        lv.src = S[cur]; lv.dst = S[cur ^ 1];
+        lv.src_gstride = lv.dst_gstride = 2 * (size_t)L;
+        lv.pos0 = pos0; lv.L = L; lv.ppg = 1; lv.kb_gstride = 2 * L; lv.rel = 1;
+        lv.npairs = (uint32_t)(span / (2 * (size_t)L));
+        if ((e = big_level_run<uint16_t, uint16_t>(d_in, n, g.la, lv, split, s)) != hipSuccess) return e;
+        cur ^= 1;
+    }
+    /* region levels: the last one writes the order (ix = ranks + RP + 8), the one before it the rank array's space */
+    const size_t stride = 2 * (size_t)g.RP + 8;
+    int nlev = 0;
+    for (uint32_t L = BIG_BLK; L < g.RP; L <<= 1) nlev++;
+    int lev = 0;
+    for (uint32_t L = BIG_BLK; L < g.RP; L <<= 1, lev++) {
+        const bool to_ix = ((nlev - 1 - lev) & 1) == 0;
+        big_level lv;
+        lv.dst = ranks + (to_ix ? g.RP + 8 : 0);
+        lv.dst_gstride = stride;
+        lv.pos0 = pos0; lv.L = L; lv.ppg = g.RP / (2 * L); lv.kb_gstride = g.TILE;
+        lv.npairs = nregions * lv.ppg;
+        if (lev == 0) {
+            lv.src = S[cur]; lv.src_gstride = g.TILE; lv.rel = 1;
+            e = big_level_run<uint16_t, uint32_t>(d_in, n, g.la, lv, split, s);
+        } else {
+            lv.src = ranks + (to_ix ? 0 : g.RP + 8); lv.src_gstride = stride; lv.rel = 0;
+            e = big_level_run<uint32_t, uint32_t>(d_in, n, g.la, lv, split, s);
+        }
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(k_big_ranks, dim3(g.RP / 256, nregions), dim3(256), 0, s, ranks, g.RP);
+    return hipGetLastError();
+}
+
 #define WALK_RUN_BIG_DEFAULT 1024u
 
 #define WALK_RUN_DEFAULT 1024u
@@ -1636,6 +1887,15 @@ size_t lz77k_match_lds_bytes(const lz77x_geom &g)
     return (size_t)g.RP * 2 + (size_t)(g.RP + 8) * 2;      /* ix + union{bytes, rk}: RP >= 4096 > la + 11 */
 }
 
+/* large windows: rank + inverse (uint32), one global bitmap per walker (v1 walkers), backward results per position */
+static size_t big_walk_scratch_bytes(const lz77x_geom &g, uint32_t nregions)
+{
+    const size_t run_len = walk_run_big(g);
+    const size_t runs = (g.TILE + run_len - 1) / run_len;
+    const size_t nws = (g.RP >> 5) + (((g.RP >> 5) + 31) >> 5);
+    return (((size_t)nregions * ((2 * (size_t)g.RP + 8) * 4 + runs * nws * 4 + (size_t)g.TILE * 16) + (size_t)g.SBu * 8 + 256) + 255) & ~(size_t)255;
+}
+
 size_t lz77k_match_scratch_bytes(const lz77x_geom &g, uint32_t nregions)
 {
     /* fast: sub-rank + inverse (uint16 each) per run, then the walkers' fwd/bwd results per position */
@@ -1643,11 +1903,7 @@ size_t lz77k_match_scratch_bytes(const lz77x_geom &g, uint32_t nregions)
         const size_t rl = walk_run_lds(g), runs = (g.TILE + rl - 1) / rl;
         return (size_t)nregions * (runs * 2 * (rl + g.SBu) * 2 + (size_t)g.TILE * 8) + (size_t)g.SBu * 4 + 256;
     }
-    /* generic: rank + inverse (uint32), one global bitmap per walker, backward results per position */
-    const size_t run_len = walk_run_big(g);
-    const size_t runs = (g.TILE + run_len - 1) / run_len;
-    const size_t nws = (g.RP >> 5) + (((g.RP >> 5) + 31) >> 5);
-    return (size_t)nregions * ((2 * (size_t)g.RP + 8) * 4 + runs * nws * 4 + (size_t)g.TILE * 16) + (size_t)g.SBu * 8 + 256;
+    return big_walk_scratch_bytes(g, nregions) + (lz77k_big_sort_shared(g) ? big_sort_extra_bytes(g, nregions) : 0);
 }
 
 template <bool FAST, int MODE>
@@ -1722,7 +1978,10 @@ hipError_t lz77k_match(const uint8_t *d_in, uint32_t n, const lz77x_geom &g, uin
         const size_t stride = 2 * (size_t)g.RP + 8;
         uint32_t *ranks = d_ranks_all ? d_ranks_all + (size_t)region0 * stride : reinterpret_cast<uint32_t *>(d_scratch);
         uint32_t *bitmaps = d_ranks_all ? reinterpret_cast<uint32_t *>(d_scratch) : ranks + (size_t)nregions * stride;
-        e = launch_match<false, 3>(d_in, n, g, region0, nregions, d_ps, d_maxlen, ranks, s);
+        if (lz77k_big_sort_shared(g))
+            e = big_sort(d_in, n, g, region0, nregions, ranks, reinterpret_cast<uint8_t *>(d_scratch) + big_walk_scratch_bytes(g, nregions), s);
+        else
+            e = launch_match<false, 3>(d_in, n, g, region0, nregions, d_ps, d_maxlen, ranks, s);
         if (e != hipSuccess) return e;
         if (ev_sort && (e = hipEventRecord(ev_sort[1], s)) != hipSuccess) return e;
         const size_t nws = (g.RP >> 5) + (((g.RP >> 5) + 31) >> 5);

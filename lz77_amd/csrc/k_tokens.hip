@@ -959,7 +959,9 @@ __global__ __launch_bounds__(256) void k_tokens_rank(const uint8_t *__restrict__
                                                      const uint32_t *__restrict__ chain, uint32_t ntok,
                                                      const uint8_t *__restrict__ maxlen, const uint32_t *__restrict__ ofs,
                                                      const uint2 *__restrict__ ent, uint32_t dbase, uint32_t *__restrict__ tokval,
-                                                     const uint32_t *__restrict__ look, uint32_t nlook, uint32_t voff)
+                                                     const uint32_t *__restrict__ look, uint32_t nlook, uint32_t voff,
+                                                     uint32_t whole_order /* the order holds every position < n of the region's RP
+                                                                             slots (lz77k_big_sort_shared), not only its first R */)
 {
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t k = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
@@ -972,8 +974,8 @@ __global__ __launch_bounds__(256) void k_tokens_rank(const uint8_t *__restrict__
     if (len > 0) {
         const uint32_t reg = p >= usb ? (p - usb) / TILE : 0u;          /* the region whose walk answered p */
         const uint32_t t0 = reg * TILE, ly = p - t0;
-        const uint64_t rend = (uint64_t)t0 + TILE + usb;
-        const uint32_t R = (rend < n ? (uint32_t)rend : n) - t0;
+        const uint64_t rend = (uint64_t)t0 + (whole_order ? RP : TILE + usb);
+        const uint32_t R = (rend < n ? (uint32_t)rend : n) - t0;            /* ranks [0, R) are sorted positions */
         const uint32_t *rk = ranks_all + (size_t)reg * (2 * (size_t)RP + 8), *ix = rk + RP + 8;
         const uint8_t *by = in + t0, *q = in + p;
         const uint32_t ry = rk[ly];
@@ -1103,7 +1105,7 @@ hipError_t lz77k_tokens(const uint8_t *d_in, uint32_t n, const lz77x_geom &g, co
     if (variant == 0 && !g.fast && d_ranks_all) {
         TIE_EV(0);
         hipLaunchKernelGGL(k_tokens_rank, dim3((ntok + 3) / 4), dim3(256), 0, s, d_in, n, g.sb, g.ob, g.lb, g.RP, g.TILE, d_ranks_all,
-                           d_chain, ntok, d_maxlen, d_ofs, d_ent, dbase, d_tokval, d_look, nlook, voff);
+                           d_chain, ntok, d_maxlen, d_ofs, d_ent, dbase, d_tokval, d_look, nlook, voff, (uint32_t)lz77k_big_sort_shared(g));
         TIE_EV(1);
         return hipGetLastError();
     }

@@ -94,6 +94,10 @@ hipError_t lz77k_match(const uint8_t *d_in, uint32_t n, const lz77x_geom &g,
                        hipEvent_t *ev_sort = nullptr /* [3]: before the region sort, between sort and walkers, after the walkers */,
                        uint32_t *d_ranks_all = nullptr /* large windows: (2RP+8) words per region of the WHOLE input, kept for lz77k_tokens */);
 
+/* large windows: 1 when the regions' orders come from the sort shared between overlapping regions (a region's order
+ * then holds every position < n of its RP slots, not only the TILE + sb it owns) */
+int lz77k_big_sort_shared(const lz77x_geom &g);
+
 hipError_t lz77k_fill_pad(uint8_t *d_in, uint32_t n, hipStream_t s);
 
 /* cells[x] = ((x+P)&mask) | ((x+S)&mask)<<16 for x in [x0, x1): what the host recurrence indexes its ring with */
