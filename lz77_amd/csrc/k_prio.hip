@@ -171,9 +171,11 @@ __global__ __launch_bounds__(64) void k_prio_fwd(const uint32_t *__restrict__ ps
                     r &= r - 1;
                     const uint32_t end = r ? (uint32_t)__builtin_ctzll(r) : 64u;
                     if (has && lane >= start && lane < end) {
+                        /* the three reads leave together (one LDS round trip per round, not two: no short circuit) */
                         const uint32_t a = ring[ix], w = ring[ip], sv = ring[is];
-                        ng = a < w;                                   /* the gate: x's predecessor hangs below x */
-                        if (ng && a < sv) { ring[is] = a; out = a; }  /* tree.c:202-231: S takes x's place */
+                        const bool gate = a < w, lower = a < sv;
+                        ng = gate;                                    /* the gate: x's predecessor hangs below x */
+                        if (gate & lower) { ring[is] = a; out = a; }  /* tree.c:202-231: S takes x's place */
                     }
                     wave_sync();
                 } while (r);
