@@ -1846,7 +1846,10 @@ static hipError_t big_sort(const uint8_t *d_in, uint32_t n, const lz77x_geom &g,
 
 #define WALK_RUN_BIG_DEFAULT 1024u
 
-#define WALK_RUN_DEFAULT 1024u
+/* C1 (TILE 12288): 2048 steps per walker = six runs per region: half the sub-rank exports of the sort kernel and
+ * half the window fills of the walkers against 1024 (match stage 8.1 -> 7.2 ms per 100 MB); 2560+ no longer
+ * divide the tile evenly and lose walker occupancy (48 -> 64 KB of bitmaps per wavefront) */
+#define WALK_RUN_DEFAULT 2048u
 
 /* steps per walker on the LDS path (LZ77X_WALK_RUN overrides): a multiple of 8 in [256, RP/2 - SBu] --
  * the two sub-rank arrays of a run (2 * (run + SBu) uint16) are staged in the RP*2 bytes of LDS the key

@@ -119,6 +119,7 @@ __global__ __launch_bounds__(64) void k_prio_fwd(const uint32_t *__restrict__ ps
                                                  uint32_t *__restrict__ out_state /* last block: the sb cells left live after the last step */)
 {
     extern __shared__ uint32_t ring[];
+    __builtin_amdgcn_s_setprio(3);      /* a chain of dependent instructions: issue ahead of any co-resident throughput kernel */
     const uint32_t lane = threadIdx.x;
     const uint32_t b = b_first + blockIdx.x;
     const uint32_t x0 = b * B;
@@ -222,6 +223,7 @@ __global__ __launch_bounds__(64) void k_prio_back(const uint32_t *__restrict__ p
                                                   uint32_t ncarried /* cells < ncarried hold carried values, not their own position */)
 {
     extern __shared__ uint32_t back_lds[];
+    __builtin_amdgcn_s_setprio(3);      /* a chain of dependent instructions: issue ahead of any co-resident throughput kernel */
     uint32_t *lloc = back_lds;                                         /* sb_r words */
     uint16_t *dr = reinterpret_cast<uint16_t *>(back_lds + (ring_n - 64u));   /* ring_n entries */
     const uint32_t lane = threadIdx.x;
@@ -311,6 +313,7 @@ __global__ __launch_bounds__(64) void k_prio_back(const uint32_t *__restrict__ p
  * j = b_first .. NB-2 in groups of G: compose each group's maps, run the group maps in sequence,
  * then replay every group from its now known input.  The per-step cost is two workgroup barriers and a
  * few LDS operations per cell; the next map's rows are fetched while the current one is applied. */
+#define SCAN_AHEAD 4u                                 /* maps whose rows are in flight */
 #define SCAN_CPT 4                                   /* cells per thread: sb <= 4096 on this path */
 
 struct scan_regs { uint32_t d[SCAN_CPT], l[SCAN_CPT]; };
@@ -351,32 +354,42 @@ __global__ __launch_bounds__(PRIO_SCAN_BLOCK) void k_prio_scan_compose(const uin
                                                                        uint16_t *__restrict__ gdest, uint32_t *__restrict__ gloc)
 {
     extern __shared__ uint32_t scan_lds[];
+    __builtin_amdgcn_s_setprio(3);
     uint32_t *cl[2] = {scan_lds, scan_lds + sb_r};
     uint16_t *cd = reinterpret_cast<uint16_t *>(scan_lds + 2 * sb_r);       /* composed dest */
     uint16_t *dj = cd + sb_r;                                                /* the current map's dest row */
     const uint32_t gi = blockIdx.x;
     const uint32_t m0 = gi * G, m1 = min(m0 + G, nmaps);
     for (uint32_t i = threadIdx.x; i < sb; i += PRIO_SCAN_BLOCK) { cl[0][i] = PRIO_NONE; cd[i] = (uint16_t)i; }
-    scan_regs cur, nxt;
-    scan_fetch(cur, dest, loc, (size_t)b_first + m0, sb);
+    /* the rows of the next SCAN_AHEAD maps are in flight while a map is applied: a step is two barriers and a few
+     * LDS operations, far shorter than a round trip to the rows k_prio_back has just written */
+    scan_regs rr[SCAN_AHEAD];
+#pragma unroll
+    for (uint32_t u = 0; u < SCAN_AHEAD; u++) scan_fetch(rr[u], dest, loc, (size_t)b_first + min(m0 + u, m1 - 1u), sb);
     int w = 0;
     __syncthreads();
-    for (uint32_t m = m0; m < m1; m++) {
-        scan_fetch(nxt, dest, loc, (size_t)b_first + min(m + 1, m1 - 1u), sb);
+    for (uint32_t mb = m0; mb < m1; mb += SCAN_AHEAD) {
 #pragma unroll
-        for (int q = 0; q < SCAN_CPT; q++) {
-            const uint32_t i = threadIdx.x + PRIO_SCAN_BLOCK * q;
-            if (i < sb) dj[i] = (uint16_t)cur.d[q];
-        }
-        scan_apply(cur, cl[w], cl[w ^ 1], sb);          /* its first barrier also publishes dj */
+        for (uint32_t u = 0; u < SCAN_AHEAD; u++) {
+            const uint32_t m = mb + u;
+            if (m < m1) {
+                const scan_regs cur = rr[u];
+                scan_fetch(rr[u], dest, loc, (size_t)b_first + min(m + SCAN_AHEAD, m1 - 1u), sb);
 #pragma unroll
-        for (int q = 0; q < SCAN_CPT; q++) {
-            const uint32_t i = threadIdx.x + PRIO_SCAN_BLOCK * q;
-            if (i < sb) { const uint32_t c = cd[i]; cd[i] = c == PRIO_DEAD ? (uint16_t)PRIO_DEAD : dj[c]; }
+                for (int q = 0; q < SCAN_CPT; q++) {
+                    const uint32_t i = threadIdx.x + PRIO_SCAN_BLOCK * q;
+                    if (i < sb) dj[i] = (uint16_t)cur.d[q];
+                }
+                scan_apply(cur, cl[w], cl[w ^ 1], sb);          /* its first barrier also publishes dj */
+#pragma unroll
+                for (int q = 0; q < SCAN_CPT; q++) {
+                    const uint32_t i = threadIdx.x + PRIO_SCAN_BLOCK * q;
+                    if (i < sb) { const uint32_t c = cd[i]; cd[i] = c == PRIO_DEAD ? (uint16_t)PRIO_DEAD : dj[c]; }
+                }
+                __syncthreads();
+                w ^= 1;
+            }
         }
-        __syncthreads();
-        w ^= 1;
-        cur = nxt;
     }
     for (uint32_t i = threadIdx.x; i < sb; i += PRIO_SCAN_BLOCK) {
         gdest[(size_t)gi * sb + i] = cd[i];
@@ -393,6 +406,7 @@ __global__ __launch_bounds__(PRIO_SCAN_BLOCK) void k_prio_scan_replay(const uint
                                                                       uint32_t *__restrict__ vout, size_t vout_row0, uint32_t store_first)
 {
     extern __shared__ uint32_t scan_lds[];
+    __builtin_amdgcn_s_setprio(3);
     uint32_t *cl[2] = {scan_lds, scan_lds + sb_r};
     const uint32_t gi = blockIdx.x;
     const uint32_t m0 = gi * G, m1 = min(m0 + G, nmaps);
@@ -403,16 +417,23 @@ __global__ __launch_bounds__(PRIO_SCAN_BLOCK) void k_prio_scan_replay(const uint
         cl[0][i] = val;
         if (store_first) vout[(vout_row0 + m0) * sb + i] = val;
     }
-    scan_regs cur, nxt;
-    scan_fetch(cur, dest, loc, row0 + m0, sb);
+    scan_regs rr[SCAN_AHEAD];
+#pragma unroll
+    for (uint32_t u = 0; u < SCAN_AHEAD; u++) scan_fetch(rr[u], dest, loc, row0 + min(m0 + u, m1 - 1u), sb);
     int w = 0;
     __syncthreads();
-    for (uint32_t m = m0; m < m1; m++) {
-        scan_fetch(nxt, dest, loc, row0 + min(m + 1, m1 - 1u), sb);
-        scan_apply(cur, cl[w], cl[w ^ 1], sb);
-        w ^= 1;
-        for (uint32_t i = threadIdx.x; i < sb; i += PRIO_SCAN_BLOCK) vout[(vout_row0 + m + 1) * sb + i] = cl[w][i];
-        cur = nxt;
+    for (uint32_t mb = m0; mb < m1; mb += SCAN_AHEAD) {
+#pragma unroll
+        for (uint32_t u = 0; u < SCAN_AHEAD; u++) {
+            const uint32_t m = mb + u;
+            if (m < m1) {
+                const scan_regs cur = rr[u];
+                scan_fetch(rr[u], dest, loc, row0 + min(m + SCAN_AHEAD, m1 - 1u), sb);
+                scan_apply(cur, cl[w], cl[w ^ 1], sb);
+                w ^= 1;
+                for (uint32_t i = threadIdx.x; i < sb; i += PRIO_SCAN_BLOCK) vout[(vout_row0 + m + 1) * sb + i] = cl[w][i];
+            }
+        }
     }
 }
 

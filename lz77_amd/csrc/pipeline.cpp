@@ -133,6 +133,9 @@ struct Ctx {
                                                 still waits for a later match launch) */
     hipStream_t tok = nullptr;               /* per-chunk index + tie-break + pack kernels */
     hipEvent_t ev[6] = {};
+    hipEvent_t pipe_ev[3] = {};              /* [0] this context's input has arrived, [1] its last segment's result is out,
+                                                [2] the parse chain (runs beside the recurrence on `tok`) is done */
+    Ctx *pipe = nullptr;                     /* second context set on the same device (two segments of one stream in flight) */
     std::vector<hipEvent_t> chunk_ev, tok_ev, sort_ev, match_ev, tie_ev;
     DevBuf in, ps, maxlen, scratch, xval, chain, ofs, ent, tokval, out, scantmp;
     DevBuf z, len1, dst, ptr, flag, tstart, bidx, cells, ranks_all, prio_tmp, chain_tmp, look;
@@ -210,6 +213,7 @@ int ctx_init(Ctx &c, int device = -1)
     HIPCHK(hipStreamCreateWithFlags(&c.up, hipStreamNonBlocking));
     HIPCHK(hipStreamCreateWithFlags(&c.tok, hipStreamNonBlocking));
     for (auto &ev : c.ev) HIPCHK(hipEventCreate(&ev));
+    for (auto &ev : c.pipe_ev) HIPCHK(hipEventCreate(&ev));
     c.ready = true;
     return LZ77X_OK;
 }
@@ -1071,6 +1075,7 @@ struct Source {
     virtual ~Source() {}
     /* up to `want` bytes to device address d_dst, enqueued on / ordered with stream s; fewer only at the end */
     virtual int read(Ctx &c, uint8_t *d_dst, size_t want, hipStream_t s, size_t *got) = 0;
+    virtual size_t size_hint() const { return 0; }            /* bytes still to come, when known */
 };
 struct Sink {
     virtual ~Sink() {}
@@ -1090,6 +1095,7 @@ struct MemSource : Source {
         *got = m;
         return LZ77X_OK;
     }
+    size_t size_hint() const override { return n - at; }
 };
 
 struct FileSource : Source {
@@ -1170,114 +1176,145 @@ struct FileSink : Sink {
 };
 
 /* What one segment hands to the next (host side): where the parse chain continues, how many tokens are
- * out, the last tokens (a stream word can straddle the boundary), and -- on the device, in c.look[] -- the
- * priorities of the sb cells that are live at the boundary, renumbered 0..sb-1 in order (the tie-break
- * only ever compares priorities; every position of the next segment is newer than all of them). */
+ * out, the last tokens (a stream word can straddle the boundary), and the priorities of the sb cells that are
+ * live at the boundary, renumbered 0..sb-1 in order (the tie-break only ever compares priorities; every
+ * position of the next segment is newer than all of them). */
 struct SegCarry {
     bool first = true;
     uint64_t chain_pos = 0;        /* global position of the next token */
     uint64_t ntok = 0;
     uint32_t tail[4] = {0, 0, 0, 0};
     uint32_t ntail = 0;
+    std::vector<uint32_t> cells;   /* sb ranks (after the first segment) */
 };
 
-/* One segment: the bytes c.in[0, nloc) are the input from global position gpos0 on; its tokens are the chain
- * positions in [start, E) (local).  Everything is computed in local 32-bit coordinates:
- *     match (regions covering [0, E)) -> parse chain from `start` | priority recurrence over steps [0, E-sb)
- *     from the carried cells -> hand-over index + tie-break -> the stream words this segment's tokens start in.
- * *fallback: the gate iteration gave up (only possible when allow_fallback), nothing was emitted. */
-int encode_segment(Ctx &c, uint32_t nloc, uint32_t start, uint32_t E, bool last, const lz77x_geom &g, hipStream_t s, SegCarry &carry,
-                   Sink &sink, bool allow_fallback, bool *fallback, double *waited)
+/* One segment in flight.  The bytes c->in[0, nloc) are the input from global position gpos0 on; its tokens are
+ * the chain positions in [start, E) (local).  Everything is computed in local 32-bit coordinates, in four
+ * phases so that two segments can be in flight on two context sets of the same device:
+ *     seg_front   match stage over [0, cover): needs nothing from the segment before
+ *     seg_mid     parse chain from `start` | priority recurrence over steps [0, E-sb) from the carried cells
+ *                 (the host drives the gate iteration) -> the carry of the two sequential loops
+ *     seg_tokens  hand-over index + tie-break + the stream words this segment's tokens start in (enqueue only)
+ *     seg_finish  wait, last tokens to the carry, the words to the sink, timings */
+struct SegJob {
+    Ctx *c = nullptr;
+    hipStream_t s = nullptr;
+    uint64_t gpos0 = 0;
+    uint32_t nloc = 0, cover = 0;
+    bool last = false, first = false;
+    uint32_t start = 0, E = 0;
+    uint32_t nx = 0, nlook = 0, ntok = 0, exit_off = 0;
+    uint32_t nregions = 0, launches = 0, nchunks = 0, nsub = 0;
+    uint32_t *d_order = nullptr;
+    int tvariant = 0;
+    uint64_t K0 = 0;
+    uint32_t have_tail = 0, ntail_in = 0;
+    uint64_t out_bytes = 0;
+    std::vector<char> tie_timed;
+};
+
+int seg_front(SegJob &J, const lz77x_geom &g)
 {
+    Ctx &c = *J.c;
+    hipStream_t s = J.s;
+    int rc;
+    HIPCHK(lz77k_fill_pad(c.in.as<uint8_t>(), J.nloc, s));
+    J.launches = 0;
+    uint32_t nregions = (uint32_t)(((size_t)J.cover + g.TILE - 1) / g.TILE);
+    {
+        const uint32_t all = (uint32_t)(((size_t)J.nloc + g.TILE - 1) / g.TILE);
+        if (nregions > all) nregions = all;
+    }
+    J.nregions = nregions;
+    const char *tv = getenv("LZ77X_TOKEN_VARIANT");
+    J.tvariant = tv ? atoi(tv) : 0;
+    J.d_order = nullptr;
+    if (!nregions) {
+        HIPCHK(hipEventRecord(c.ev[0], s));
+        HIPCHK(hipEventRecord(c.ev[1], s));
+        return LZ77X_OK;
+    }
+    uint32_t batch = nregions;
+    {
+        const size_t per = lz77k_match_scratch_bytes(g, 1);
+        const uint32_t fit = (uint32_t)(((size_t)2 << 30) / per);
+        if (batch > fit) batch = fit ? fit : 1;
+        const char *gs = getenv("LZ77X_MATCH_BATCH");
+        if (gs && atoi(gs) > 0 && (uint32_t)atoi(gs) < batch) batch = (uint32_t)atoi(gs);
+    }
+    const size_t np = (size_t)J.nloc;
+    if ((rc = c.scratch.need(lz77k_match_scratch_bytes(g, batch)))) return rc;
+    if ((rc = c.ps.need((np + 8) * 4))) return rc;
+    if ((rc = c.maxlen.need(np + 64))) return rc;
+    /* the regions' sorted order stays resident for the tie-break (RP uint16 per region: 2.7 B per input byte) */
+    const bool keep_order = g.fast && J.tvariant == 0 && !getenv("LZ77X_TOKENS_BUCKET");
+    if (keep_order && (rc = c.ranks_all.need((size_t)nregions * g.RP * 2 + 64))) return rc;
+    J.d_order = keep_order ? c.ranks_all.as<uint32_t>() : nullptr;
+    const uint32_t nlaunch = (nregions + batch - 1) / batch;
+    while (c.sort_ev.size() < 3 * (size_t)nlaunch) { hipEvent_t e; HIPCHK(hipEventCreate(&e)); c.sort_ev.push_back(e); }
+    while (c.match_ev.size() < 8) { hipEvent_t e; HIPCHK(hipEventCreate(&e)); c.match_ev.push_back(e); }
+    /* -- match stage (replaces tree.c insert/delete/find): ps[], maxlen[] -- */
+    HIPCHK(hipEventRecord(c.ev[0], s));
+    for (uint32_t r0 = 0; r0 < nregions; r0 += batch) {
+        const uint32_t nr = nregions - r0 < batch ? nregions - r0 : batch;
+        HIPCHK(lz77k_match(c.in.as<uint8_t>(), J.nloc, g, r0, nr, c.ps.as<uint32_t>(), c.maxlen.as<uint8_t>(), c.scratch.p, 0, s,
+                           &c.sort_ev[3 * J.launches], J.d_order));
+        J.launches++;
+    }
+    HIPCHK(hipEventRecord(c.ev[1], s));
+    g_stats.match_launches += J.launches;
+    return LZ77X_OK;
+}
+
+/* *fallback: the gate iteration gave up (only possible when allow_fallback), nothing was emitted. */
+int seg_mid(SegJob &J, const lz77x_geom &g, SegCarry &carry, bool allow_fallback, bool *fallback, double *waited)
+{
+    Ctx &c = *J.c;
+    hipStream_t s = J.s;
     int rc;
     *fallback = false;
     const size_t usb = (size_t)g.sb;
-    const bool first = carry.first;
-    const uint32_t nlook = first ? 0u : (uint32_t)g.sb;
-    const uint32_t nx = E > (uint32_t)g.sb ? E - (uint32_t)g.sb : 0u;
-    HIPCHK(lz77k_fill_pad(c.in.as<uint8_t>(), nloc, s));
-    uint32_t ntok = 0, launches = 0, nchunks = 0;
-    std::vector<char> tie_timed;
-    const uint32_t csub = lz77k_chain_sub();
-    uint32_t exit_off = 0;
+    const uint32_t start = J.start, E = J.E;
+    J.first = carry.first;
+    J.nlook = J.first ? 0u : (uint32_t)g.sb;
+    J.nx = E > (uint32_t)g.sb ? E - (uint32_t)g.sb : 0u;
+    J.ntok = 0;
+    J.exit_off = 0;
+    J.K0 = carry.ntok;
+    if ((rc = c.h_small.need(128))) return rc;
     if (E > start) {
-        uint32_t nregions = (uint32_t)(((size_t)E + g.TILE - 1) / g.TILE);
-        {
-            const uint32_t all = (uint32_t)(((size_t)nloc + g.TILE - 1) / g.TILE);
-            if (nregions > all) nregions = all;
-        }
-        uint32_t batch = nregions;
-        {
-            const size_t per = lz77k_match_scratch_bytes(g, 1);
-            const uint32_t fit = (uint32_t)(((size_t)2 << 30) / per);
-            if (batch > fit) batch = fit ? fit : 1;
-            const char *gs = getenv("LZ77X_MATCH_BATCH");
-            if (gs && atoi(gs) > 0 && (uint32_t)atoi(gs) < batch) batch = (uint32_t)atoi(gs);
-        }
-        /* token chunks: up to 128M positions (one hand-over index and one tie-break launch each; the index
-         * costs 12 bytes of scratch per position), a multiple of the chain sub-block, counted from `start` */
-        size_t chunk_pos = (size_t)128 << 20;
-        {
-            const char *ce = getenv("LZ77X_TOKEN_CHUNK");
-            if (ce && atoi(ce) > 0) chunk_pos = (size_t)atoi(ce);
-            chunk_pos = (chunk_pos + csub - 1) / csub * csub;
-        }
-        const size_t span = (size_t)E - start;
-        nchunks = (uint32_t)((span + chunk_pos - 1) / chunk_pos);
-        const size_t idx_span = (chunk_pos < span ? chunk_pos : span) + 2 * usb + 16;
-        const char *tv = getenv("LZ77X_TOKEN_VARIANT");
-        const int tvariant = tv ? atoi(tv) : 0;
-        const size_t np = (size_t)nloc;
-
-        if ((rc = c.scratch.need(lz77k_match_scratch_bytes(g, batch)))) return rc;
-        if ((rc = c.ps.need((np + 8) * 4))) return rc;
-        if ((rc = c.maxlen.need(np + 64))) return rc;
+        const uint32_t csub = lz77k_chain_sub();
+        const size_t np = (size_t)J.nloc, span = (size_t)E - start;
         if ((rc = c.xval.need((np + 8) * 4))) return rc;
         if ((rc = c.chain.need((np + 8) * 4))) return rc;
-        if ((rc = c.tokval.need((np + 16) * 4))) return rc;
-        if ((rc = c.ofs.need((idx_span + 8) * 4))) return rc;
-        if ((rc = c.ent.need((idx_span + 8) * 8))) return rc;
-        if ((rc = c.scantmp.need(lz77k_scan_tmp_bytes((uint32_t)idx_span + 1)))) return rc;
-        if ((rc = c.tstart.need(lz77k_tokens_tmp_bytes((uint32_t)idx_span)))) return rc;
         if ((rc = c.flag.need(64))) return rc;
-        if ((rc = c.prio_tmp.need(lz77k_prio_tmp_bytes(nx, g.sb)))) return rc;
+        if ((rc = c.prio_tmp.need(lz77k_prio_tmp_bytes(J.nx, g.sb)))) return rc;
         if ((rc = c.chain_tmp.need(lz77k_chain_tmp_bytes(E - start, g.la)))) return rc;
-        if ((rc = c.h_small.need(128))) return rc;
         if ((rc = c.look.need((size_t)2 * (usb + 8) * 4))) return rc;
-        /* the regions' sorted order stays resident for the tie-break (RP uint16 per region: 2.7 B per input byte) */
-        const bool keep_order = g.fast && tvariant == 0 && !getenv("LZ77X_TOKENS_BUCKET");
-        if (keep_order && (rc = c.ranks_all.need((size_t)nregions * g.RP * 2 + 64))) return rc;
-        uint32_t *d_order = keep_order ? c.ranks_all.as<uint32_t>() : nullptr;
         const uint32_t nsub_max = (uint32_t)((span + csub - 1) / csub);
         if ((rc = c.h_tbase.need(((size_t)nsub_max + 2) * 4 + (usb + 8) * 4))) return rc;
         HIPCHK(hipMemsetAsync(c.flag.p, 0, 64, s));
-        const uint32_t nlaunch = (nregions + batch - 1) / batch;
-        while (c.sort_ev.size() < 3 * (size_t)nlaunch) { hipEvent_t e; HIPCHK(hipEventCreate(&e)); c.sort_ev.push_back(e); }
-        while (c.tie_ev.size() < 2 * (size_t)nchunks + 8) { hipEvent_t e; HIPCHK(hipEventCreate(&e)); c.tie_ev.push_back(e); }
-        while (c.match_ev.size() < 8) { hipEvent_t e; HIPCHK(hipEventCreate(&e)); c.match_ev.push_back(e); }
         /* c.look: [0, sb) the cells this segment starts from, [sb+8, ..) the cells it leaves behind */
         uint32_t *look_cur = c.look.as<uint32_t>(), *look_next = look_cur + usb + 8;
-
-        /* -- match stage (replaces tree.c insert/delete/find): ps[], maxlen[] -- */
-        HIPCHK(hipEventRecord(c.ev[0], s));
-        for (uint32_t r0 = 0; r0 < nregions; r0 += batch) {
-            const uint32_t nr = nregions - r0 < batch ? nregions - r0 : batch;
-            HIPCHK(lz77k_match(c.in.as<uint8_t>(), nloc, g, r0, nr, c.ps.as<uint32_t>(), c.maxlen.as<uint8_t>(), c.scratch.p, 0, s,
-                               &c.sort_ev[3 * launches], d_order));
-            launches++;
+        uint32_t *h_tbase = c.h_tbase.as<uint32_t>(), *h_state = h_tbase + nsub_max + 2;
+        if (!J.first) {
+            memcpy(h_state, carry.cells.data(), usb * 4);
+            HIPCHK(hipMemcpyAsync(look_cur, h_state, usb * 4, hipMemcpyHostToDevice, s));
         }
-        HIPCHK(hipEventRecord(c.ev[1], s));
-        g_stats.match_launches += launches;
 
-        /* -- parse chain (lz77.c:98) over [start, E) -- */
+        /* -- parse chain (lz77.c:98) over [start, E): needs maxlen[] only, nothing needs it before the tie-break:
+         *    on a stream of its own, beside the recurrence -- */
         const uint32_t *d_tbase = nullptr, *d_exit = nullptr;
         uint32_t nsub = 0;
-        HIPCHK(hipEventRecord(c.match_ev[0], s));
-        HIPCHK(lz77k_chain(c.maxlen.as<uint8_t>(), E, g.la, c.chain.as<uint32_t>(), c.chain_tmp.p, s, &d_tbase, &nsub, start, &d_exit));
-        HIPCHK(hipEventRecord(c.match_ev[1], s));
-        uint32_t *h_tbase = c.h_tbase.as<uint32_t>();
-        HIPCHK(hipMemcpyAsync(h_tbase, d_tbase, ((size_t)nsub + 1) * 4, hipMemcpyDeviceToHost, s));
-        HIPCHK(hipMemcpyAsync(c.h_small.as<uint32_t>() + 16, d_exit, 4, hipMemcpyDeviceToHost, s));
+        hipStream_t sc = getenv("LZ77X_CHAIN_INLINE") ? s : c.tok;
+        if (sc != s) HIPCHK(hipStreamWaitEvent(sc, c.ev[1], 0));               /* the match stage is through */
+        HIPCHK(hipEventRecord(c.match_ev[0], sc));
+        HIPCHK(lz77k_chain(c.maxlen.as<uint8_t>(), E, g.la, c.chain.as<uint32_t>(), c.chain_tmp.p, sc, &d_tbase, &nsub, start, &d_exit));
+        HIPCHK(hipEventRecord(c.match_ev[1], sc));
+        HIPCHK(hipMemcpyAsync(h_tbase, d_tbase, ((size_t)nsub + 1) * 4, hipMemcpyDeviceToHost, sc));
+        HIPCHK(hipMemcpyAsync(c.h_small.as<uint32_t>() + 16, d_exit, 4, hipMemcpyDeviceToHost, sc));
+        HIPCHK(hipEventRecord(c.pipe_ev[2], sc));
+        J.nsub = nsub;
 
         /* -- priority recurrence (tree.c:202-231) over steps [0, nx) from the carried cells -- */
         int iters = 0, converged = 1;
@@ -1289,10 +1326,13 @@ int encode_segment(Ctx &c, uint32_t nloc, uint32_t start, uint32_t E, bool last,
         HIPCHK(hipEventRecord(c.match_ev[2], s));
         const double tw0 = now_ms();
         float prio_ms3[3] = {0, 0, 0};
-        HIPCHK(lz77k_prio(c.ps.as<uint32_t>(), nx, g.sb, c.xval.as<uint32_t>(), c.prio_tmp.p, s, c.h_small.as<uint32_t>() + 8, max_iters,
-                          &iters, &converged, &c.match_ev[4], prio_ms3, 0u, first ? nullptr : look_cur, last ? nullptr : look_next));
+        HIPCHK(lz77k_prio(c.ps.as<uint32_t>(), J.nx, g.sb, c.xval.as<uint32_t>(), c.prio_tmp.p, s, c.h_small.as<uint32_t>() + 8, max_iters,
+                          &iters, &converged, &c.match_ev[4], prio_ms3, 0u, J.first ? nullptr : look_cur, J.last ? nullptr : look_next));
         HIPCHK(hipEventRecord(c.match_ev[3], s));
-        HIPCHK(hipStreamSynchronize(s));                       /* tbase has landed (nx == 0: the recurrence did not sync) */
+        if (!J.last) HIPCHK(hipMemcpyAsync(h_state, look_next, usb * 4, hipMemcpyDeviceToHost, s));
+        HIPCHK(hipStreamSynchronize(s));                       /* (nx == 0: the recurrence did not sync) */
+        HIPCHK(hipEventSynchronize(c.pipe_ev[2]));             /* tbase has landed */
+        HIPCHK(hipStreamWaitEvent(s, c.pipe_ev[2], 0));        /* chain[] is there for the tie-break */
         *waited += now_ms() - tw0;
         g_stats.k_prio_fwd_ms += prio_ms3[0];
         g_stats.k_prio_back_ms += prio_ms3[1];
@@ -1302,14 +1342,60 @@ int encode_segment(Ctx &c, uint32_t nloc, uint32_t start, uint32_t E, bool last,
             *fallback = true;
             return LZ77X_OK;
         }
-        ntok = h_tbase[nsub];
-        exit_off = c.h_small.as<uint32_t>()[16];
+        J.ntok = h_tbase[nsub];
+        J.exit_off = c.h_small.as<uint32_t>()[16];
+        if (!J.last) {
+            /* the cells left live, renumbered by rank (sb values): what the next segment starts from */
+            std::vector<std::pair<uint32_t, uint32_t>> order(usb);
+            for (size_t i = 0; i < usb; i++) order[i] = {h_state[i], (uint32_t)i};
+            std::sort(order.begin(), order.end());
+            carry.cells.resize(usb);
+            for (size_t r = 0; r < usb; r++) carry.cells[order[r].second] = (uint32_t)r;
+        }
+    }
+    carry.first = false;
+    carry.ntok = J.K0 + J.ntok;
+    carry.chain_pos = J.gpos0 + E + J.exit_off;
+    return LZ77X_OK;
+}
 
+/* enqueue only; carry.tail is the predecessor's (its seg_finish has run) */
+int seg_tokens(SegJob &J, const lz77x_geom &g, const SegCarry &carry)
+{
+    Ctx &c = *J.c;
+    hipStream_t s = J.s;
+    int rc;
+    const size_t usb = (size_t)g.sb;
+    const uint32_t start = J.start, E = J.E, ntok = J.ntok;
+    J.ntail_in = carry.ntail;
+    J.nchunks = 0;
+    if (E > start) {
+        const uint32_t csub = lz77k_chain_sub();
+        /* token chunks: up to 128M positions (one hand-over index and one tie-break launch each; the index
+         * costs 12 bytes of scratch per position), a multiple of the chain sub-block, counted from `start` */
+        size_t chunk_pos = (size_t)128 << 20;
+        {
+            const char *ce = getenv("LZ77X_TOKEN_CHUNK");
+            if (ce && atoi(ce) > 0) chunk_pos = (size_t)atoi(ce);
+            chunk_pos = (chunk_pos + csub - 1) / csub * csub;
+        }
+        const size_t span = (size_t)E - start, np = (size_t)J.nloc;
+        const uint32_t nchunks = (uint32_t)((span + chunk_pos - 1) / chunk_pos);
+        J.nchunks = nchunks;
+        const size_t idx_span = (chunk_pos < span ? chunk_pos : span) + 2 * usb + 16;
+        if ((rc = c.tokval.need((np + 16) * 4))) return rc;
+        if ((rc = c.ofs.need((idx_span + 8) * 4))) return rc;
+        if ((rc = c.ent.need((idx_span + 8) * 8))) return rc;
+        if ((rc = c.scantmp.need(lz77k_scan_tmp_bytes((uint32_t)idx_span + 1)))) return rc;
+        if ((rc = c.tstart.need(lz77k_tokens_tmp_bytes((uint32_t)idx_span)))) return rc;
+        while (c.tie_ev.size() < 2 * (size_t)nchunks + 8) { hipEvent_t e; HIPCHK(hipEventCreate(&e)); c.tie_ev.push_back(e); }
+        uint32_t *look_cur = c.look.as<uint32_t>();
+        const uint32_t *h_tbase = c.h_tbase.as<uint32_t>();
         /* -- tokens: per chunk, the hand-over index of the evictions that can matter and the tie-break.  Tokens
          *    land behind four slots that hold the predecessor's last tokens (for the first stream word) -- */
         uint32_t *tokbuf = c.tokval.as<uint32_t>();
         if (carry.ntail) HIPCHK(hipMemcpyAsync(tokbuf + 4 - carry.ntail, carry.tail + 4 - carry.ntail, carry.ntail * 4, hipMemcpyHostToDevice, s));
-        tie_timed.assign(nchunks, 0);
+        J.tie_timed.assign(nchunks, 0);
         HIPCHK(hipEventRecord(c.ev[2], s));
         for (uint32_t ci = 0; ci < nchunks; ci++) {
             const size_t b = start + (size_t)ci * chunk_pos, e = b + chunk_pos < E ? b + chunk_pos : E;
@@ -1320,91 +1406,102 @@ int encode_segment(Ctx &c, uint32_t nloc, uint32_t start, uint32_t E, bool last,
             const size_t x_new = ci == 0 ? 0 : (b > usb ? b - usb : 0);
             HIPCHK(lz77k_xfer_index(c.ps.as<uint32_t>(), c.xval.as<uint32_t>(), xa, (uint32_t)x_done, dbase, (uint32_t)e, c.ofs.as<uint32_t>(),
                                     c.ent.as<uint2>(), c.scantmp.p, s, (uint32_t)x_new, c.flag.as<unsigned long long>() + 1, (uint32_t)g.sb));
-            HIPCHK(lz77k_tokens(c.in.as<uint8_t>(), nloc, g, c.chain.as<uint32_t>() + ta, tb - ta, c.maxlen.as<uint8_t>(), c.ofs.as<uint32_t>(),
+            HIPCHK(lz77k_tokens(c.in.as<uint8_t>(), J.nloc, g, c.chain.as<uint32_t>() + ta, tb - ta, c.maxlen.as<uint8_t>(), c.ofs.as<uint32_t>(),
                                 c.ent.as<uint2>(), dbase, (uint32_t)b, (uint32_t)e, tokbuf + 4 + ta, c.tstart.as<uint32_t>(), nullptr,
-                                tvariant, s, &c.tie_ev[2 * ci], d_order, first ? nullptr : look_cur, nlook, 0u));
-            tie_timed[ci] = tb > ta;
+                                J.tvariant, s, &c.tie_ev[2 * ci], J.d_order, J.first ? nullptr : look_cur, J.nlook, 0u));
+            J.tie_timed[ci] = tb > ta;
         }
         HIPCHK(hipMemcpyAsync(c.h_small.as<unsigned long long>() + 2, c.flag.as<unsigned long long>() + 1, 8, hipMemcpyDeviceToHost, s));
-        if (!last) {
-            /* the cells left live, renumbered by rank on the host (sb values): what the next segment starts from */
-            uint32_t *h_state = h_tbase + nsub_max + 2;
-            HIPCHK(hipMemcpyAsync(h_state, look_next, usb * 4, hipMemcpyDeviceToHost, s));
-            HIPCHK(hipStreamSynchronize(s));
-            std::vector<std::pair<uint32_t, uint32_t>> order(usb);
-            for (size_t i = 0; i < usb; i++) order[i] = {h_state[i], (uint32_t)i};
-            std::sort(order.begin(), order.end());
-            for (size_t r = 0; r < usb; r++) h_state[order[r].second] = (uint32_t)r;
-            HIPCHK(hipMemcpyAsync(look_cur, h_state, usb * 4, hipMemcpyHostToDevice, s));       /* tokens of this segment are done with it in stream order */
-        }
     } else {
         if ((rc = c.tokval.need(64))) return rc;
-        if ((rc = c.h_small.need(128))) return rc;
         uint32_t *tokbuf = c.tokval.as<uint32_t>();
         if (carry.ntail) HIPCHK(hipMemcpyAsync(tokbuf + 4 - carry.ntail, carry.tail + 4 - carry.ntail, carry.ntail * 4, hipMemcpyHostToDevice, s));
-        HIPCHK(hipEventRecord(c.ev[0], s));
-        HIPCHK(hipEventRecord(c.ev[1], s));
         HIPCHK(hipEventRecord(c.ev[2], s));
     }
 
     /* -- pack (lz77.c:246-252): the words this segment's tokens start in; the last segment also the rest -- */
-    const uint64_t K0 = carry.ntok, K1 = K0 + ntok;
+    const uint64_t K0 = J.K0, K1 = K0 + ntok;
     const uint64_t T = (uint64_t)g.T;
     const uint64_t zn_total = stream_bytes(K1, g.T);
     const uint64_t wlo = K0 == 0 ? 0 : (32 + K0 * T) / 32;
-    const uint64_t whi = last ? (zn_total + 3) / 4 : (32 + K1 * T) / 32;
+    const uint64_t whi = J.last ? (zn_total + 3) / 4 : (32 + K1 * T) / 32;
     const uint64_t nw = whi > wlo ? whi - wlo : 0;
     if ((rc = c.out.need(nw * 4 + 16))) return rc;
     HIPCHK(lz77k_pack_range(c.tokval.as<uint32_t>() + 4 - carry.ntail, K0 - carry.ntail, K1, g, c.out.as<uint32_t>(), wlo, nw, s));
     HIPCHK(hipEventRecord(c.ev[3], s));
+    /* carry: the last four tokens seen so far */
+    J.have_tail = ntok + carry.ntail < 4 ? ntok + carry.ntail : 4;
+    if (J.have_tail)
+        HIPCHK(hipMemcpyAsync(c.h_small.as<uint32_t>() + 20, c.tokval.as<uint32_t>() + 4 + ntok - J.have_tail, J.have_tail * 4, hipMemcpyDeviceToHost, s));
+    J.out_bytes = J.last ? zn_total - 4 * wlo : 4 * nw;
+    return LZ77X_OK;
+}
+
+int seg_finish(SegJob &J, SegCarry &carry, Sink &sink, double *waited)
+{
+    Ctx &c = *J.c;
+    hipStream_t s = J.s;
+    int rc;
     {
-        /* carry: the last four tokens seen so far */
-        const uint32_t have = ntok + carry.ntail < 4 ? ntok + carry.ntail : 4;
-        if (have) HIPCHK(hipMemcpyAsync(c.h_small.as<uint32_t>() + 20, c.tokval.as<uint32_t>() + 4 + ntok - have, have * 4, hipMemcpyDeviceToHost, s));
         const double tw = now_ms();
         HIPCHK(hipStreamSynchronize(s));
         *waited += now_ms() - tw;
-        for (uint32_t i = 0; i < have; i++) carry.tail[4 - have + i] = c.h_small.as<uint32_t>()[20 + i];
-        carry.ntail = have;
+        for (uint32_t i = 0; i < J.have_tail; i++) carry.tail[4 - J.have_tail + i] = c.h_small.as<uint32_t>()[20 + i];
+        carry.ntail = J.have_tail;
     }
-    const uint64_t bytes = last ? zn_total - 4 * wlo : 4 * nw;
-    if ((rc = sink.write(c, c.out.as<uint8_t>(), (size_t)bytes, s))) return rc;
-    if (E > start) g_stats.transfers += c.h_small.as<unsigned long long>()[2];
+    if ((rc = sink.write(c, c.out.as<uint8_t>(), (size_t)J.out_bytes, s))) return rc;
+    if (J.E > J.start) g_stats.transfers += c.h_small.as<unsigned long long>()[2];
 
     float ms = 0;
     HIPCHK(hipEventElapsedTime(&ms, c.ev[0], c.ev[1]));
     g_stats.k_match_ms += ms;
     HIPCHK(hipEventElapsedTime(&ms, c.ev[2], c.ev[3]));
     g_stats.k_token_ms += ms;
-    if (E > start) {
+    for (uint32_t i = 0; i < J.launches; i++) {
+        HIPCHK(hipEventElapsedTime(&ms, c.sort_ev[3 * i], c.sort_ev[3 * i + 1]));
+        g_stats.k_sort_ms += ms;
+        HIPCHK(hipEventElapsedTime(&ms, c.sort_ev[3 * i + 1], c.sort_ev[3 * i + 2]));
+        g_stats.k_walk_ms += ms;
+    }
+    if (J.E > J.start) {
         HIPCHK(hipEventElapsedTime(&ms, c.match_ev[0], c.match_ev[1]));
         g_stats.k_chain_ms += ms;
         HIPCHK(hipEventElapsedTime(&ms, c.match_ev[2], c.match_ev[3]));
         g_stats.k_prio_ms += ms;
-        for (uint32_t i = 0; i < launches; i++) {
-            HIPCHK(hipEventElapsedTime(&ms, c.sort_ev[3 * i], c.sort_ev[3 * i + 1]));
-            g_stats.k_sort_ms += ms;
-            HIPCHK(hipEventElapsedTime(&ms, c.sort_ev[3 * i + 1], c.sort_ev[3 * i + 2]));
-            g_stats.k_walk_ms += ms;
-        }
-        for (uint32_t ci = 0; ci < nchunks; ci++) {
-            if (!tie_timed[ci]) continue;
+        for (uint32_t ci = 0; ci < J.nchunks; ci++) {
+            if (!J.tie_timed[ci]) continue;
             HIPCHK(hipEventElapsedTime(&ms, c.tie_ev[2 * ci], c.tie_ev[2 * ci + 1]));
             g_stats.k_tiebreak_ms += ms;
             g_stats.token_launches++;
         }
     }
-    carry.first = false;
-    carry.ntok = K1;
-    c.h_small.as<uint32_t>()[24] = exit_off;               /* the caller turns it into the global chain position */
+    return LZ77X_OK;
+}
+
+/* the second context set of a device (same device as c): lets two segments of one stream be in flight */
+int ctx_sibling(Ctx &c, Ctx **out)
+{
+    if (!c.pipe) c.pipe = new Ctx();
+    int rc = ctx_init(*c.pipe, c.device);
+    if (rc) return rc;
+    *out = c.pipe;
     return LZ77X_OK;
 }
 
 /* The device-resident encode of an input of any size: the source is cut into segments of up to
- * LZ77X_SEGMENT positions (default 2^30) that run one after the other through the same device buffers; a
- * segment starts sb bytes before its first token (the look-back window), so consecutive segments overlap by
- * sb + the look-ahead, and hands the state of lz77.c's two sequential loops to the next one (SegCarry).
- * One device, sb <= 4096.  Nothing but the stream (and a few words per segment) leaves the GPU. */
+ * LZ77X_SEGMENT positions (default 2^30); a segment
+ * starts sb bytes before its first token (the look-back window), so consecutive segments overlap by sb + the
+ * look-ahead, and hands the state of lz77.c's two sequential loops to the next one (SegCarry).
+ *
+ * Two segments are in flight, on two context sets and two streams of the device: the gate iteration of the
+ * priority recurrence is a chain of latency-bound launches (one wavefront per block, a host round trip per
+ * iteration) that leaves the CUs' issue slots idle, and the only thing segment k+1's match stage or segment
+ * k-1's tie-break need from it is nothing -- so while the host drives the recurrence of segment k on one
+ * stream, the other stream runs the tie-break of k-1 and then the match stage of k+1:
+ *     stream A:  match 0 | chain, recurrence 0 | tie-break, pack 0 |  match 2 (after match 1)  | ...
+ *     stream B:           (after match 0) match 1 | chain, recurrence 1 | tie-break, pack 1 | ...
+ * LZ77X_PIPELINE=0: one context, one segment at a time.  One device, sb <= 4096.  Nothing but the stream
+ * (and a few words per segment) leaves the GPU. */
 int encode_stream_device(Ctx &c, Source &src, Sink &sink, const lz77x_geom &g, hipStream_t s, bool *fallback, size_t *n_fallback)
 {
     const double t_begin = now_ms();
@@ -1414,53 +1511,123 @@ int encode_stream_device(Ctx &c, Source &src, Sink &sink, const lz77x_geom &g, h
     double waited = 0;
     HIPCHK(hipSetDevice(c.device));
     const size_t usb = (size_t)g.sb, halo = (size_t)g.la + 64;
+    const uint32_t csub = lz77k_chain_sub();
     size_t seg = (size_t)1 << 30;
+    bool pipelined = !(getenv("LZ77X_PIPELINE") && atoi(getenv("LZ77X_PIPELINE")) == 0);
     {
+        const size_t lo = 4 * usb + 3 * (size_t)csub;
         const char *se = getenv("LZ77X_SEGMENT");
         if (se && atoll(se) > 0) seg = (size_t)atoll(se);
-        const size_t lo = 4 * usb + 3 * (size_t)lz77k_chain_sub();
+        else {
+            /* LZ77X_SPLIT=1: cut an input of known size above 32 MB in two so that the halves overlap.  Off by
+             * default: the recurrence of a half takes as long as that of the whole (it is latency bound: 6.8 ms
+             * per 50 MB half against 6.0 for 100 MB, co-running kernels included), so S1 ends at 23.1 ms against
+             * 20.8 in one segment */
+            const size_t hint = src.size_hint();
+            const char *sp = getenv("LZ77X_SPLIT");
+            if (sp && atoi(sp) && pipelined && hint >= ((size_t)32 << 20) && hint / 2 + csub < seg) seg = (hint / 2 + csub) / csub * csub;
+        }
         if (seg < lo) seg = lo;
         if (seg > ((size_t)3 << 30)) seg = (size_t)3 << 30;      /* local coordinates are 32-bit */
     }
+    Ctx *cx[2] = {&c, &c};
+    hipStream_t sx[2] = {s, s};
+    if (pipelined) {
+        if ((rc = ctx_sibling(c, &cx[1]))) return rc;
+        sx[1] = cx[1]->stream;
+    }
     SegCarry carry;
-    uint64_t gpos0 = 0;                                    /* global position of c.in[0] */
-    size_t have = 0;                                       /* bytes of the input in c.in */
-    uint64_t n_total = 0, a = 0;                           /* a: global position of this segment's first possible token */
+    SegJob J[2];
+    uint64_t n_total = 0;
     bool eof = false;
-    for (;;) {
-        /* this segment wants the bytes up to a + seg + halo */
-        const size_t want_local = (size_t)(a + seg + halo - gpos0);
-        if ((rc = c.in.need(want_local + LZ77X_PAD + 64))) return rc;
+
+    /* input of segment k into context k & 1: the tail of its predecessor's buffer, then the source */
+    auto load = [&](int k, const SegJob *prev) -> int {
+        SegJob &N = J[k & 1];
+        N = SegJob();
+        N.c = cx[k & 1];
+        N.s = sx[k & 1];
+        Ctx &cn = *N.c;
+        const size_t want_local = (k ? usb : 0) + seg + halo;
+        int r;
+        size_t have = 0;
+        /* sized for every segment at once: the buffer must not move once a predecessor's tail sits in it */
+        if ((r = cn.in.need(usb + seg + halo + LZ77X_PAD + 64))) return r;
+        if (prev) {
+            const size_t keep0 = (size_t)prev->E - usb, keep = (size_t)prev->nloc - keep0;
+            N.gpos0 = prev->gpos0 + keep0;
+            if (prev->c != N.c) {
+                HIPCHK(hipStreamWaitEvent(N.s, prev->c->pipe_ev[0], 0));        /* its input has arrived */
+                HIPCHK(hipMemcpyAsync(cn.in.p, prev->c->in.as<uint8_t>() + keep0, keep, hipMemcpyDeviceToDevice, N.s));
+            } else {
+                /* same buffer: move [E - sb, have) to the front (through a spare buffer: the ranges overlap) */
+                if ((r = cn.bidx.need(keep + 64))) return r;
+                HIPCHK(hipMemcpyAsync(cn.bidx.p, cn.in.as<uint8_t>() + keep0, keep, hipMemcpyDeviceToDevice, N.s));
+                HIPCHK(hipMemcpyAsync(cn.in.p, cn.bidx.p, keep, hipMemcpyDeviceToDevice, N.s));
+            }
+            have = keep;
+        }
         if (!eof && have < want_local) {
             size_t got = 0;
-            if ((rc = src.read(c, c.in.as<uint8_t>() + have, want_local - have, s, &got))) return rc;
+            if ((r = src.read(cn, cn.in.as<uint8_t>() + have, want_local - have, N.s, &got))) return r;
             if (got < want_local - have) eof = true;
             have += got;
             n_total += got;
         }
-        const bool last = eof;
-        const uint32_t nloc = (uint32_t)have;
-        const uint32_t start = (uint32_t)(carry.chain_pos - gpos0);
-        uint32_t E;
-        if (last) E = nloc;
-        else {
-            const uint32_t lim = (uint32_t)(a + seg - gpos0), csub = lz77k_chain_sub();
-            E = start + (lim - start) / csub * csub;
+        HIPCHK(hipEventRecord(cn.pipe_ev[0], N.s));
+        N.last = eof;
+        N.nloc = (uint32_t)have;
+        N.cover = N.last ? N.nloc : (uint32_t)((k ? usb : 0) + seg);
+        return LZ77X_OK;
+    };
+    /* where segment k's tokens start and end (needs the carry of k - 1) */
+    auto place = [&](SegJob &K) {
+        K.start = (uint32_t)(carry.chain_pos - K.gpos0);
+        if (K.last) K.E = K.nloc;
+        else K.E = K.start + (K.cover - K.start) / csub * csub;
+    };
+
+    if ((rc = load(0, nullptr))) return rc;
+    if ((rc = seg_front(J[0], g))) return rc;
+    int prev_unfinished = -1;
+    for (int k = 0;; k++) {
+        SegJob &K = J[k & 1];
+        place(K);
+        const bool single = carry.first && K.last;
+        if (pipelined && !K.last) {
+            /* the next segment's input and match stage, behind this one's match stage on the other stream */
+            if (prev_unfinished >= 0) {
+                /* its context is the one segment k-1 still occupies: its last tokens and its words are taken first */
+                if ((rc = seg_finish(J[prev_unfinished & 1], carry, sink, &waited))) return rc;
+                prev_unfinished = -1;
+            }
+            if ((rc = load(k + 1, &K))) return rc;
+            HIPCHK(hipStreamWaitEvent(J[(k + 1) & 1].s, K.c->ev[1], 0));
+            if ((rc = seg_front(J[(k + 1) & 1], g))) return rc;
         }
         bool fb = false;
-        if ((rc = encode_segment(c, nloc, start, E, last, g, s, carry, sink, carry.first && last, &fb, &waited))) return rc;
-        if (fb) { *fallback = true; *n_fallback = have; return LZ77X_OK; }
-        if (last) break;
-        carry.chain_pos = gpos0 + E + c.h_small.as<uint32_t>()[24];
-        /* the next segment looks back sb bytes from E: move [E - sb, have) to the front (through a spare
-         * buffer: the ranges overlap) */
-        const size_t keep0 = (size_t)E - usb, keep = have - keep0;
-        if ((rc = c.bidx.need(keep + 64))) return rc;
-        HIPCHK(hipMemcpyAsync(c.bidx.p, c.in.as<uint8_t>() + keep0, keep, hipMemcpyDeviceToDevice, s));
-        HIPCHK(hipMemcpyAsync(c.in.p, c.bidx.p, keep, hipMemcpyDeviceToDevice, s));
-        gpos0 += keep0;
-        have = keep;
-        a = gpos0 + usb;                                   /* = the old E */
+        if ((rc = seg_mid(K, g, carry, single, &fb, &waited))) return rc;
+        if (fb) { *fallback = true; *n_fallback = K.nloc; return LZ77X_OK; }
+        if (prev_unfinished >= 0) {
+            if ((rc = seg_finish(J[prev_unfinished & 1], carry, sink, &waited))) return rc;
+            prev_unfinished = -1;
+        }
+        if ((rc = seg_tokens(K, g, carry))) return rc;
+        if (K.last) {
+            if ((rc = seg_finish(K, carry, sink, &waited))) return rc;
+            if (K.s != s) {
+                /* the caller's stream sees the whole result */
+                HIPCHK(hipEventRecord(K.c->pipe_ev[1], K.s));
+                HIPCHK(hipStreamWaitEvent(s, K.c->pipe_ev[1], 0));
+            }
+            break;
+        }
+        if (pipelined) prev_unfinished = k;
+        else {
+            if ((rc = seg_finish(K, carry, sink, &waited))) return rc;
+            if ((rc = load(k + 1, &K))) return rc;
+            if ((rc = seg_front(J[(k + 1) & 1], g))) return rc;
+        }
     }
     g_stats.n = n_total;
     g_stats.zn = sink.total;
@@ -2007,6 +2174,7 @@ const char *lz77x_strerror(int code)
 namespace {
 void ctx_release(Ctx &c)
 {
+    if (c.pipe) { ctx_release(*c.pipe); delete c.pipe; c.pipe = nullptr; }
     if (!c.ready) return;
     hipError_t e = hipSetDevice(c.device);
     e = hipDeviceSynchronize();
@@ -2021,6 +2189,7 @@ void ctx_release(Ctx &c)
         v->clear();
     }
     for (auto &ev : c.ev) e = hipEventDestroy(ev);
+    for (auto &ev : c.pipe_ev) e = hipEventDestroy(ev);
     e = hipStreamDestroy(c.stream);
     e = hipStreamDestroy(c.copy);
     e = hipStreamDestroy(c.up);
