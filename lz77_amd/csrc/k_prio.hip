@@ -38,6 +38,8 @@
 #define PRIO_NONE 0xFFFFFFFFu
 #define PRIO_DEAD 0xFFFFu
 #define PRIO_SG 8u                       /* groups of 64 steps fetched per round trip to global memory */
+/* 1024 threads x 4 cells per map step; 256 x 16 is twice as slow (measured): a step is bound by the LDS work per
+ * thread, not by its two barriers */
 #define PRIO_SCAN_BLOCK 1024
 
 __device__ __forceinline__ void wave_sync()
@@ -314,7 +316,7 @@ __global__ __launch_bounds__(64) void k_prio_back(const uint32_t *__restrict__ p
  * then replay every group from its now known input.  The per-step cost is two workgroup barriers and a
  * few LDS operations per cell; the next map's rows are fetched while the current one is applied. */
 #define SCAN_AHEAD 4u                                 /* maps whose rows are in flight */
-#define SCAN_CPT 4                                   /* cells per thread: sb <= 4096 on this path */
+#define SCAN_CPT (4096 / PRIO_SCAN_BLOCK)             /* cells per thread: sb <= 4096 on this path */
 
 struct scan_regs { uint32_t d[SCAN_CPT], l[SCAN_CPT]; };
 

@@ -1302,11 +1302,11 @@ int seg_mid(SegJob &J, const lz77x_geom &g, SegCarry &carry, bool allow_fallback
             HIPCHK(hipMemcpyAsync(look_cur, h_state, usb * 4, hipMemcpyHostToDevice, s));
         }
 
-        /* -- parse chain (lz77.c:98) over [start, E): needs maxlen[] only, nothing needs it before the tie-break:
-         *    on a stream of its own, beside the recurrence -- */
+        /* -- parse chain (lz77.c:98) over [start, E): needs maxlen[] only and nothing needs it before the tie-break;
+         *    LZ77X_CHAIN_STREAM=1 runs it on a stream of its own beside the recurrence -- */
         const uint32_t *d_tbase = nullptr, *d_exit = nullptr;
         uint32_t nsub = 0;
-        hipStream_t sc = getenv("LZ77X_CHAIN_INLINE") ? s : c.tok;
+        hipStream_t sc = getenv("LZ77X_CHAIN_STREAM") ? c.tok : s;   /* measured: beside the recurrence it costs the recurrence more (6.0 -> 6.5 ms) than it hides (0.4) */
         if (sc != s) HIPCHK(hipStreamWaitEvent(sc, c.ev[1], 0));               /* the match stage is through */
         HIPCHK(hipEventRecord(c.match_ev[0], sc));
         HIPCHK(lz77k_chain(c.maxlen.as<uint8_t>(), E, g.la, c.chain.as<uint32_t>(), c.chain_tmp.p, sc, &d_tbase, &nsub, start, &d_exit));
