@@ -328,7 +328,11 @@ int encode_core_host(std::vector<Ctx *> &cs, const void *src, bool src_on_device
          * are one full round of resident workgroups already, and finer chunks pipeline better with the
          * host stage: 512 -> 256 regions took 40 ms off a 350 ms encode of S3) */
         uint32_t per_chunk = (uint32_t)((((size_t)4 << 20) + g.TILE - 1) / g.TILE);
-        if (!g.fast && per_chunk < 256) per_chunk = 256;         /* one workgroup per CU in the sort: a full round */
+        /* large windows.  Per-region sort kernel: one workgroup per CU, a full round of 256 regions.  Shared
+         * hierarchical sort (grid-wide launches): 128 -- the host recurrence is the critical path (S3: 183 of a
+         * 210 ms encode) and smaller chunks shorten what runs before its first and after its last position
+         * (228 -> 210 ms), while 64 starts to cost the walkers their occupancy */
+        if (!g.fast && per_chunk < 256) per_chunk = lz77k_big_sort_shared(g) ? 128 : 256;
         const char *cs_env = getenv("LZ77X_CHUNK_REGIONS");
         if (cs_env && atoi(cs_env) > 0) per_chunk = (uint32_t)atoi(cs_env);
         uint32_t group = g.fast ? 8u : 1u;
