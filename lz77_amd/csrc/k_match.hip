@@ -891,31 +891,37 @@ __global__ __launch_bounds__(64) void k_walk(const uint16_t *__restrict__ subs, 
             }
         }
     };
-    /* first set bit strictly above / below bit b0 of word w0, given that word and its two neighbours;
-     * the bitmap is dense, the loops over further words only run in nearly empty windows */
-    auto succ_of = [&](uint32_t w0, uint32_t b0, uint32_t here, uint32_t next) -> uint32_t {
-        uint32_t m = here & ~((2u << b0) - 1u), w = w0;
-        if (!m && w0 + 1 < NW) { m = next; w = w0 + 1; }
-        if (!m) {
-            for (w = w0 + 2; w <= hi_w; w++) if ((m = BM_WORD(w))) break;
-            if (!m) hi_w = min(hi_w, w0);
-        }
+    /* first set bit strictly above / below bit b0 of word w0, given that word and its two neighbours.  The bitmap is
+     * dense (two thirds full), so the answer nearly always lies in those three words: that case is branch-free 64-bit
+     * arithmetic (the walk is bound by the instructions and branches a lone wavefront per SIMD can issue: 2.4 ms ->
+     * see DESIGN.md); the loops over further words only run in nearly empty windows */
+    auto succ_far = [&](uint32_t w0) -> uint32_t {
+        uint32_t m = 0, w;
+        for (w = w0 + 2; w <= hi_w; w++) if ((m = BM_WORD(w))) break;
+        if (!m) hi_w = min(hi_w, w0);
         return m ? (w << 5) + (uint32_t)__builtin_ctz(m) : WALK_NONE;
     };
-    auto pred_of = [&](uint32_t w0, uint32_t b0, uint32_t here, uint32_t prev) -> uint32_t {
-        uint32_t m = here & ((1u << b0) - 1u), w = w0;
-        if (!m && w0 > 0) { m = prev; w = w0 - 1; }
-        if (!m) {
-            if (w0 > 1 && w0 - 2 >= lo_w)
-                for (w = w0 - 2;; w--) { if ((m = BM_WORD(w)) || w == lo_w) break; }
-            if (!m) lo_w = max(lo_w, w0);
-        }
+    auto pred_far = [&](uint32_t w0) -> uint32_t {
+        uint32_t m = 0, w = w0;
+        if (w0 > 1 && w0 - 2 >= lo_w)
+            for (w = w0 - 2;; w--) { if ((m = BM_WORD(w)) || w == lo_w) break; }
+        if (!m) lo_w = max(lo_w, w0);
         return m ? (w << 5) + 31u - (uint32_t)__builtin_clz(m) : WALK_NONE;
+    };
+    auto neighbours = [&](uint32_t w0, uint32_t b0, uint32_t here, uint32_t next, uint32_t prev) -> uint32_t {   /* successor | predecessor << 16 */
+        const uint32_t nx = w0 + 1 < NW ? next : 0u, pv = w0 ? prev : 0u;
+        const uint64_t up = ((((uint64_t)nx << 32) | here) >> 1) >> b0;                       /* bits above b0, then word w0+1 */
+        const uint64_t dn = (((uint64_t)here << 32) | pv) & ((1ull << (32u + b0)) - 1ull);     /* word w0-1, then bits below b0 */
+        uint32_t su = (w0 << 5) + b0 + 1u + (uint32_t)__builtin_ctzll(up | (1ull << 63));
+        uint32_t pr = (w0 << 5) + 31u - (uint32_t)__builtin_clzll(dn | 1ull);                  /* ((w0-1) << 5) + 63 - clz */
+        if (!up) su = succ_far(w0);
+        if (!dn) pr = pred_far(w0);
+        return su | (pr << 16);
     };
     auto query = [&](uint32_t q) -> uint32_t {                /* successor | predecessor << 16 */
         const uint32_t w0 = q >> 5, b0 = q & 31;
         const uint32_t here = BM_WORD(w0), next = BM_WORD(min(w0 + 1, NW - 1)), prev = BM_WORD(w0 ? w0 - 1 : 0);
-        return succ_of(w0, b0, here, next) | (pred_of(w0, b0, here, prev) << 16);
+        return neighbours(w0, b0, here, next, prev);
     };
     /* first window minus its last position: [0, sb-1) */
     {
@@ -958,8 +964,8 @@ __global__ __launch_bounds__(64) void k_walk(const uint16_t *__restrict__ subs, 
         const uint32_t wq = q >> 5, bq = q & 31, wy = hasy ? ry >> 5 : wq, by_ = ry & 31;
         const uint32_t hq = BM_WORD(wq), nq = BM_WORD(min(wq + 1, NW - 1)), pq = BM_WORD(wq ? wq - 1 : 0);
         const uint32_t hy = BM_WORD(wy), ny = BM_WORD(min(wy + 1, NW - 1)), py = BM_WORD(wy ? wy - 1 : 0);
-        resf = succ_of(wq, bq, hq, nq) | (pred_of(wq, bq, hq, pq) << 16);
-        resb = hasy ? succ_of(wy, by_, hy, ny) | (pred_of(wy, by_, hy, py) << 16) : (WALK_NONE | (WALK_NONE << 16));
+        resf = neighbours(wq, bq, hq, nq, pq);
+        resb = hasy ? neighbours(wy, by_, hy, ny, py) : (WALK_NONE | (WALK_NONE << 16));
         BM_WORD(wq) = hq & ~(1u << bq);
         r_add = ry;                                          /* position t+sb enters at the next step */
     };
