@@ -843,13 +843,18 @@ typedef __attribute__((address_space(1))) u32x2 g_uint2;
 __global__ __launch_bounds__(64) void k_walk(const uint16_t *__restrict__ subs, uint32_t n, int sb, uint32_t SBu,
                                              uint32_t TILE, uint32_t region0, uint32_t nregions, uint32_t run_len,
                                              uint32_t runs_per_tile, uint32_t *__restrict__ wf, uint32_t *__restrict__ wb,
-                                             uint32_t *__restrict__ wb0)
+                                             uint32_t *__restrict__ wb0, int head_block)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t bm[];
     const uint32_t lane = threadIdx.x;
     const uint32_t SUB = run_len + SBu, NW = (SUB + 31) >> 5;
 #define BM_WORD(w) bm[(w) * 64u + lane]
-    const uint32_t id = blockIdx.x * 64u + lane;
+    /* head block (the last one of a launch that starts at region 0): its 64 lanes share the backward queries of the
+     * first sb positions of the input, which look back at [0, y) only.  The first walker used to answer them while it
+     * filled its first window -- 4095 query + store steps on ONE lane that every other wavefront of the launch
+     * finished long before (1.5 of the kernel's 2.1 ms per 100 MB) */
+    const bool head = head_block && blockIdx.x == gridDim.x - 1;
+    const uint32_t id = head ? 0u : blockIdx.x * 64u + lane;
     const uint32_t run = id % runs_per_tile;
     const uint32_t reg = id / runs_per_tile;
     if (reg >= nregions) return;
@@ -877,19 +882,14 @@ __global__ __launch_bounds__(64) void k_walk(const uint16_t *__restrict__ subs, 
         lo_w = min(lo_w, r >> 5);
         hi_w = max(hi_w, r >> 5);
     };
-    auto load8 = [&](uint32_t i, uint32_t (&v)[4]) {          /* sub-ranks i..i+7, any alignment */
-        if (i + 8 <= SUB) {
-            uint4 t;
-            __builtin_memcpy(&t, rk + i, 16);
-            v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
-        } else {
-#pragma unroll
-            for (int j = 0; j < 4; j++) {
-                const uint32_t i0 = i + 2 * j, i1 = i0 + 1;
-                const uint32_t l = i0 < SUB ? rk[i0] : 0u, h = i1 < SUB ? rk[i1] : 0u;
-                v[j] = l | (h << 16);
-            }
-        }
+    /* sub-ranks i..i+7, any alignment.  ONE unconditional 16-byte load: entries past SUB are never used (every use is
+     * guarded by R <= SUB) and the run's inverse array follows its sub-ranks, so the bytes exist.  A load under a
+     * branch makes the compiler drain vmcnt right behind it -- the "prefetch" then waits for its own round trip AND
+     * for the scattered result stores of the group before (that was half of this kernel's time). */
+    auto load8 = [&](uint32_t i, uint32_t (&v)[4]) {
+        uint4 t;
+        __builtin_memcpy(&t, rk + i, 16);
+        v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
     };
     /* first set bit strictly above / below bit b0 of word w0, given that word and its two neighbours.  The bitmap is
      * dense (two thirds full), so the answer nearly always lies in those three words: that case is branch-free 64-bit
@@ -923,37 +923,38 @@ __global__ __launch_bounds__(64) void k_walk(const uint16_t *__restrict__ subs, 
         const uint32_t here = BM_WORD(w0), next = BM_WORD(min(w0 + 1, NW - 1)), prev = BM_WORD(w0 ? w0 - 1 : 0);
         return neighbours(w0, b0, here, next, prev);
     };
-    /* first window minus its last position: [0, sb-1) */
-    {
-        const uint32_t b = min(usb - 1, R);
-        if (region0 + reg == 0 && run == 0) {
-            /* start of the input: y < sb looks back at [0, y) only -- answer while filling */
-            for (uint32_t i = 0; i < b; i++) {
-                const uint32_t r = rk[i];
-                wb0[i] = query(r);
-                set_bit(r);
-            }
-            if (usb - 1 < R) wb0[usb - 1] = query(rk[usb - 1]);
-        } else {
-            uint32_t i = 0;
-            for (; i + 32 <= b; i += 32) {                   /* four loads in flight: the fill is bound by their latency */
-                uint32_t v[4][4];
+    auto fill = [&](uint32_t b) {                            /* set the bits of positions [0, b) */
+        uint32_t i = 0;
+        for (; i + 32 <= b; i += 32) {                       /* four loads in flight: the fill is bound by their latency */
+            uint32_t v[4][4];
 #pragma unroll
-                for (int g4 = 0; g4 < 4; g4++) load8(i + 8 * g4, v[g4]);
+            for (int g4 = 0; g4 < 4; g4++) load8(i + 8 * g4, v[g4]);
 #pragma unroll
-                for (int g4 = 0; g4 < 4; g4++)
+            for (int g4 = 0; g4 < 4; g4++)
 #pragma unroll
-                    for (int j = 0; j < 8; j++) set_bit((v[g4][j >> 1] >> (16 * (j & 1))) & 0xFFFFu);
-            }
-            for (; i + 8 <= b; i += 8) {
-                uint32_t v[4];
-                load8(i, v);
-#pragma unroll
-                for (int j = 0; j < 8; j++) set_bit((v[j >> 1] >> (16 * (j & 1))) & 0xFFFFu);
-            }
-            for (; i < b; i++) set_bit(rk[i]);
+                for (int j = 0; j < 8; j++) set_bit((v[g4][j >> 1] >> (16 * (j & 1))) & 0xFFFFu);
         }
+        for (; i + 8 <= b; i += 8) {
+            uint32_t v[4];
+            load8(i, v);
+#pragma unroll
+            for (int j = 0; j < 8; j++) set_bit((v[j >> 1] >> (16 * (j & 1))) & 0xFFFFu);
+        }
+        for (; i < b; i++) set_bit(rk[i]);
+    };
+    if (head) {
+        /* start of the input: y < sb looks back at [0, y) only; lane l takes y in [l*C, (l+1)*C) after setting [0, l*C) */
+        const uint32_t ymax = min(usb, R), C = (usb + 63u) / 64u;
+        const uint32_t y0 = min(lane * C, ymax), y1 = min(y0 + C, ymax);
+        fill(y0);
+        for (uint32_t y = y0; y < y1; y++) {
+            const uint32_t r = rk[y];
+            wb0[y] = query(r);
+            set_bit(r);
+        }
+        return;
     }
+    fill(min(usb - 1, R));                                   /* first window minus its last position: [0, sb-1) */
     uint32_t r_add = usb - 1 < R ? (uint32_t)rk[usb - 1] : WALK_NONE;
     /* One step.  The forward query never looks at q's own bit (strict masks), so it may read the
      * bitmap BEFORE q is cleared, together with the backward query; and since the lane owns its bitmap
@@ -970,11 +971,22 @@ __global__ __launch_bounds__(64) void k_walk(const uint16_t *__restrict__ subs, 
         r_add = ry;                                          /* position t+sb enters at the next step */
     };
     uint32_t t = 0;
-    /* groups of 8 steps: two 16-byte sub-rank loads (fetched a group ahead), four 16-byte result stores */
-    uint32_t vq[4], vy[4], nq8[4] = {0, 0, 0, 0}, ny8[4] = {0, 0, 0, 0}, rf[8], rb[8];
-    if (t + 8 <= tb) { load8(t, vq); load8(t + usb, vy); }
+    /* groups of 8 steps: two 16-byte sub-rank loads, four 16-byte result stores.  The loads run TWO groups ahead and
+     * are unconditional (always inside the run's two arrays): the wait for a group's sub-ranks then leaves the result
+     * stores of the two groups before it in flight -- they are scattered 16-byte writes, one line per lane, and with
+     * the loads one group ahead (or under a branch) every group waited for their completion: half of the kernel */
+    uint32_t vq[4], vy[4], aq[4], ay[4], bq[4], by8[4], rf[8], rb[8];
+    load8(t, vq);
+    load8(t + usb, vy);
+    load8(t + 8, aq);
+    load8(t + 8 + usb, ay);
+    /* the four loads land here, once (an empty asm that consumes them): otherwise the compiler's wait at the top of
+     * the loop body must also cover the first pass, where vq / vy are still load destinations, and ends up draining
+     * the previous group's stores on every pass */
+    asm volatile("" ::"v"(vq[0] ^ vq[3]), "v"(vy[0] ^ vy[3]), "v"(aq[0] ^ aq[3]), "v"(ay[0] ^ ay[3]));
     for (; t + 8 <= tb; t += 8) {
-        if (t + 16 <= tb) { load8(t + 8, nq8); load8(t + 8 + usb, ny8); }
+        load8(t + 16, bq);                                   /* t + 16 + usb + 8 <= SUB + 16 < 2 * SUB */
+        load8(t + 16 + usb, by8);
 #pragma unroll
         for (int j = 0; j < 8; j++) {
             const uint32_t q = (vq[j >> 1] >> (16 * (j & 1))) & 0xFFFFu;
@@ -988,7 +1000,7 @@ __global__ __launch_bounds__(64) void k_walk(const uint16_t *__restrict__ subs, 
         o[0] = make_uint4(rb[0], rb[1], rb[2], rb[3]);
         o[1] = make_uint4(rb[4], rb[5], rb[6], rb[7]);
 #pragma unroll
-        for (int j = 0; j < 4; j++) { vq[j] = nq8[j]; vy[j] = ny8[j]; }
+        for (int j = 0; j < 4; j++) { vq[j] = aq[j]; vy[j] = ay[j]; aq[j] = bq[j]; ay[j] = by8[j]; }
     }
     for (; t < tb; t++) {
         uint32_t f1, b1;
@@ -1961,8 +1973,8 @@ hipError_t lz77k_match(const uint8_t *d_in, uint32_t n, const lz77x_geom &g, uin
             e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_walk), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             if (e != hipSuccess) return e;
         }
-        hipLaunchKernelGGL(k_walk, dim3((uint32_t)((walkers + 63) / 64)), dim3(64), lds, s, subs, n, g.sb, g.SBu, g.TILE,
-                           region0, nregions, run_len, runs, wf, wb, wb0);
+        hipLaunchKernelGGL(k_walk, dim3((uint32_t)((walkers + 63) / 64) + (region0 == 0 ? 1u : 0u)), dim3(64), lds, s, subs, n, g.sb, g.SBu, g.TILE,
+                           region0, nregions, run_len, runs, wf, wb, wb0, region0 == 0 ? 1 : 0);
         if (ev_sort && (e = hipEventRecord(ev_sort[2], s)) != hipSuccess) return e;
         if (getenv("LZ77X_WALK_FINAL_V1")) {
             const uint64_t npos = (uint64_t)nregions * g.TILE;
