@@ -81,6 +81,14 @@ def _run_huge(r):
     return stats
 
 
+def test_s1_split_in_two_overlapping_halves(monkeypatch):
+    """LZ77X_SPLIT=1: the 100 MB stream as two segments in flight on two context sets (match stage of the second half
+    beside the recurrence of the first, tie-break of the first beside the recurrence of the second): the same digest"""
+    monkeypatch.setenv("LZ77X_SPLIT", "1")
+    st = _run("S1")
+    assert st["host_stageb_ms"] == 0
+
+
 def test_s1_in_five_segments(monkeypatch):
     """the 100 MB bench stream cut into 20 MB segments (carried parse position, token tail and renumbered
     priorities): the same digest"""

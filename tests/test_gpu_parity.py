@@ -320,6 +320,39 @@ def test_large_window_sort_variants_agree(sortv, sb, la, monkeypatch):
     assert L.encode(data, la, sb) == want
 
 
+@pytest.mark.parametrize("env", [{}, {"LZ77X_BIG_SORT_V1": "1"}, {"LZ77X_WALK_BIG_V1": "1"}, {"LZ77X_WALK_RUN_WAVE": "1024"},
+                                 {"LZ77X_WALK_RUN_WAVE": "65536"}, {"LZ77X_CHUNK_REGIONS": "1"}, {"LZ77X_CHUNK_REGIONS": "3"}])
+@pytest.mark.parametrize("sb,la,kind,n", [(65535, 255, "mixed", 1_300_000), (65530, 100, "text", 900_000), (65535, 16, "lowent", 700_000),
+                                          (65535, 255, "records", 600_000)])
+def test_large_window_shared_sort_and_wave_walkers(env, sb, la, kind, n, monkeypatch):
+    """large windows whose tile is a multiple of 64 K positions (sb 65529..65535): the hierarchical sort shared by the
+    overlapping regions (16 K chunks in LDS once, grid-wide merge levels; a region's order then also holds the
+    positions past its own TILE + sb) and the wavefront-per-run walkers with the rank bitmap in LDS, against the
+    per-region sort kernel / the per-lane global-bitmap walkers, for several launch shapes (one region per launch:
+    every region is the first and the last of its launch) -- all equal to the reference stream"""
+    data = synth.make(kind, n, 89)
+    want = O.encode_bst(data, sb, la)
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    assert L.encode(data, la, sb) == want
+
+
+@pytest.mark.parametrize("env", [{"LZ77X_PIPELINE": "0"}, {"LZ77X_PIPELINE": "1"}, {"LZ77X_SPLIT": "1"}, {"LZ77X_CHAIN_STREAM": "1"}])
+@pytest.mark.parametrize("seg", ["", "60000", "400000"])
+def test_two_segments_in_flight(env, seg, monkeypatch):
+    """the device pipeline's phases (match | chain + recurrence | tie-break + pack | finish) with two segments in flight
+    on two context sets and streams, against one segment at a time on one context; LZ77X_SPLIT cuts a
+    single-segment input in two (only above 32 MB: a no-op here, covered by test_gpu_full)"""
+    data = synth.text(2_500_000, 90)
+    want = O.encode_bst(data)
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    if seg:
+        monkeypatch.setenv("LZ77X_SEGMENT", seg)
+    assert L.encode(data) == want
+    assert L.encode(data) == want                  # both context sets warm
+
+
 @pytest.mark.parametrize("tokv", ["0", "1", "3"])
 @pytest.mark.parametrize("sb,la,kind", [(65535, 255, "mixed"), (8192, 16, "text"), (20000, 40, "lowent")])
 def test_large_window_token_variants_agree(tokv, sb, la, kind, monkeypatch):
