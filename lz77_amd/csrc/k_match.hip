@@ -309,16 +309,17 @@ __device__ __forceinline__ void merge_run_global(const uint32_t *A, uint32_t L, 
  * (key, index) is a strict total order, so the merge path is unique.  O(CH log CH) key compares
  * instead of the bitonic network's O(CH log^2 CH): ~3.5x fewer random LDS reads per region.
  */
-template <class IdxT, bool BYTES_LDS>
-__device__ __forceinline__ void region_sort_merge(IdxT *ix, const uint8_t *by, uint32_t R, int la, uint32_t tid)
+template <class IdxT, bool BYTES_LDS, uint32_t NT = MATCH_BLOCK>
+__device__ __forceinline__ void region_sort_merge(IdxT *ix, const uint8_t *by, uint32_t R, int la, uint32_t tid,
+                                                  uint32_t L_first = 0 /* > 0: ix[] already holds sorted runs of L_first slots */)
 {
-    constexpr uint32_t CH = 16 * MATCH_BLOCK;
+    constexpr uint32_t CH = 16 * NT;
     const uint32_t pmask = la >= 4 ? 0xFFFFFFFFu : 0xFFFFFFFFu << (8 * (4 - la));
     auto prefix = [&](uint32_t a) -> uint32_t {
         return a < R ? (__builtin_bswap32(ld32_at<BYTES_LDS>(by, a)) & pmask) : 0xFFFFFFFFu;
     };
     uint32_t v[16];
-    {
+    if (!L_first) {
         uint32_t pf[16];
         if constexpr (sizeof(IdxT) == 2) {
             const uint4 a = *reinterpret_cast<const uint4 *>(ix + 16 * tid), b = *reinterpret_cast<const uint4 *>(ix + 16 * tid + 8);
@@ -362,8 +363,8 @@ __device__ __forceinline__ void region_sort_merge(IdxT *ix, const uint8_t *by, u
         if (wide) __syncthreads();
         else { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); }
     };
-    store_mine();
-    for (uint32_t L = 16; L < CH; L <<= 1) {
+    if (!L_first) store_mine();
+    for (uint32_t L = L_first ? L_first : 16; L < CH; L <<= 1) {
         const bool wide = 2 * L > 1024;
         barrier(wide);
         const uint32_t o0 = 16 * tid, base = o0 & ~(2 * L - 1);
@@ -375,6 +376,37 @@ __device__ __forceinline__ void region_sort_merge(IdxT *ix, const uint8_t *by, u
 }
 
 /* ------------------------------------------------------------------ k_match ---------- */
+
+/* Small windows whose tile is three quarters of the region (sb 4089..4096: RP 16384 = 4 x 4096, TILE = 3 x 4096): the
+ * regions are unions of globally aligned 4 K chunks and overlap by one, and (key, position) is one total order -- so
+ * every chunk is sorted ONCE (a 256-thread workgroup: the same register sort + merge levels as a region, eight levels
+ * instead of ten) and a region only runs the last two merge levels over its four chunks: 12 of the 14 levels on 1x
+ * instead of 4/3x the data. */
+#define C1_CH 4096u
+#define C1_BLOCK 256
+
+__global__ __launch_bounds__(C1_BLOCK) void k_c1_chunks(const uint8_t *__restrict__ in, uint32_t n, int la, uint64_t pos0,
+                                                       uint16_t *__restrict__ out)
+{
+    __shared__ __attribute__((aligned(16))) uint16_t ix[C1_CH];
+    __shared__ __attribute__((aligned(16))) uint8_t lby[C1_CH + 256 + 32];
+    const uint32_t tid = threadIdx.x;
+    const uint64_t base = pos0 + (uint64_t)blockIdx.x * C1_CH;
+    const uint32_t Rl = base >= n ? 0u : (n - (uint32_t)base < C1_CH ? n - (uint32_t)base : C1_CH);
+    const uint32_t nb = Rl ? (Rl + (uint32_t)la + 24 + 3) & ~3u : 0u;
+    for (uint32_t i = tid * 4; i < nb; i += C1_BLOCK * 4) *reinterpret_cast<uint32_t *>(lby + i) = ld32u(in + base + i);
+    for (uint32_t i = tid; i < C1_CH; i += C1_BLOCK) ix[i] = (uint16_t)i;
+    __syncthreads();
+    if (Rl) region_sort_merge<uint16_t, true, C1_BLOCK>(ix, lby, Rl, la, tid);
+    uint16_t *o = out + (size_t)blockIdx.x * C1_CH;
+    for (uint32_t e = tid * 8; e < C1_CH; e += C1_BLOCK * 8) *reinterpret_cast<uint4 *>(o + e) = *reinterpret_cast<const uint4 *>(ix + e);
+}
+
+static bool c1_shared_sort(const lz77x_geom &g)
+{
+    return g.fast && g.shifted && g.RP == 16u * MATCH_BLOCK && g.SBu * 4u == g.RP && !getenv("LZ77X_C1_SORT_V1") &&
+           !(getenv("LZ77X_SORT_VARIANT") && atoi(getenv("LZ77X_SORT_VARIANT")));
+}
 
 template <bool FAST> struct rank_traits;
 template <> struct rank_traits<true>  { typedef uint16_t rank_t; static constexpr uint32_t HALF = 0x8000u; static constexpr uint32_t MASK = 0xFFFFu; };
@@ -511,7 +543,9 @@ __global__ __launch_bounds__(MATCH_BLOCK, (FAST && MODE == 3) ? 8 : 1) void k_ma
                                                        uint32_t *__restrict__ ps, uint8_t *__restrict__ maxlen,
                                                        uint32_t *__restrict__ scratch, int sort_variant, uint32_t walk_run,
                                                        uint16_t *__restrict__ order_all /* FAST production: RP uint16 per region of the input
-                                                                                           (sorted order -> position - t0), kept for the tie-break */)
+                                                                                           (sorted order -> position - t0), kept for the tie-break */,
+                                                       const uint16_t *__restrict__ chunks /* FAST production, tile = 3/4 region: the sorted orders of
+                                                                                              the launch's 4 K chunks (k_c1_chunks), else null */)
 {
     typedef typename rank_traits<FAST>::rank_t rank_t;
     constexpr uint32_t HALF = rank_traits<FAST>::HALF;
@@ -542,7 +576,10 @@ __global__ __launch_bounds__(MATCH_BLOCK, (FAST && MODE == 3) ? 8 : 1) void k_ma
         ix = reinterpret_cast<rank_t *>(smem);             /* RP */
         rk = ix + RP;                                      /* RP + 8, written after the sort */
         uint8_t *stage = reinterpret_cast<uint8_t *>(rk);  /* R + la + 11 <= 2*RP + 16 bytes */
-        const uint32_t nb = (R + (uint32_t)la + 8 + 3) & ~3u;
+        /* shared chunks: the order holds every position < n of the RP slots (the one past TILE + sb is sorted in its
+         * chunk like any other), so the merge levels must see its key too */
+        const uint32_t Rs = chunks ? (n - rstart < RP ? n - rstart : RP) : R;
+        const uint32_t nb = (Rs + (uint32_t)la + 8 + 3) & ~3u;
         for (uint32_t i = tid * 4; i < nb; i += MATCH_BLOCK * 4)
             *reinterpret_cast<uint32_t *>(stage + i) = *reinterpret_cast<const uint32_t *>(in + rstart + i);
         by = stage;
@@ -551,11 +588,28 @@ __global__ __launch_bounds__(MATCH_BLOCK, (FAST && MODE == 3) ? 8 : 1) void k_ma
         ix = rk + RP + 8;
         by = in + rstart;
     }
+    if (FAST && chunks) {
+        if constexpr (FAST) {
+            /* the region = four consecutive 4 K chunks of the launch, each already in key order (k_c1_chunks): the last
+             * two merge levels are all that is left */
+            const uint16_t *src = chunks + (size_t)blockIdx.x * 3u * C1_CH;
+            for (uint32_t e = tid * 8; e < RP; e += MATCH_BLOCK * 8) {
+                const uint4 v = *reinterpret_cast<const uint4 *>(src + e);
+                const uint32_t add = (e / C1_CH) * C1_CH * 0x10001u;
+                *reinterpret_cast<uint4 *>(reinterpret_cast<uint16_t *>(ix) + e) = make_uint4(v.x + add, v.y + add, v.z + add, v.w + add);
+            }
+        }
+    } else
     for (uint32_t i = tid; i < RP; i += MATCH_BLOCK) ix[i] = (rank_t)i;
     __syncthreads();
 
     /* ---- bitonic sort of local indices by (key, index); indices >= R sort last ---- */
-    if (FAST && RP == 16 * MATCH_BLOCK && sort_variant == 0) {
+    if (FAST && chunks) {
+        if constexpr (FAST) {
+            const uint32_t Rs = n - rstart < RP ? n - rstart : RP;
+            region_sort_merge<uint16_t, true>(reinterpret_cast<uint16_t *>(ix), by, Rs, la, tid, C1_CH);
+        }
+    } else if (FAST && RP == 16 * MATCH_BLOCK && sort_variant == 0) {
         if constexpr (FAST) region_sort_merge<uint16_t, true>(reinterpret_cast<uint16_t *>(ix), by, R, la, tid);
     } else if (FAST && RP == 16 * MATCH_BLOCK && sort_variant == 2) {
         if constexpr (FAST) region_sort_blocked<uint16_t, true>(reinterpret_cast<uint16_t *>(ix), by, R, la, tid, false, true);
@@ -1917,19 +1971,25 @@ static size_t big_walk_scratch_bytes(const lz77x_geom &g, uint32_t nregions)
     return (((size_t)nregions * ((2 * (size_t)g.RP + 8) * 4 + runs * nws * 4 + (size_t)g.TILE * 16) + (size_t)g.SBu * 8 + 256) + 255) & ~(size_t)255;
 }
 
+/* small windows: sub-rank + inverse (uint16 each) per run, then the walkers' fwd/bwd results per position */
+static size_t c1_walk_scratch_bytes(const lz77x_geom &g, uint32_t nregions)
+{
+    const size_t rl = walk_run_lds(g), runs = (g.TILE + rl - 1) / rl;
+    return (((size_t)nregions * (runs * 2 * (rl + g.SBu) * 2 + (size_t)g.TILE * 8) + (size_t)g.SBu * 4 + 256) + 255) & ~(size_t)255;
+}
+
 size_t lz77k_match_scratch_bytes(const lz77x_geom &g, uint32_t nregions)
 {
-    /* fast: sub-rank + inverse (uint16 each) per run, then the walkers' fwd/bwd results per position */
     if (g.fast) {
-        const size_t rl = walk_run_lds(g), runs = (g.TILE + rl - 1) / rl;
-        return (size_t)nregions * (runs * 2 * (rl + g.SBu) * 2 + (size_t)g.TILE * 8) + (size_t)g.SBu * 4 + 256;
+        return c1_walk_scratch_bytes(g, nregions) + (c1_shared_sort(g) ? ((size_t)nregions * 3 + 1) * C1_CH * 2 + 256 : 0);
     }
     return big_walk_scratch_bytes(g, nregions) + (lz77k_big_sort_shared(g) ? big_sort_extra_bytes(g, nregions) : 0);
 }
 
 template <bool FAST, int MODE>
 static hipError_t launch_match(const uint8_t *d_in, uint32_t n, const lz77x_geom &g, uint32_t region0, uint32_t nregions,
-                               uint32_t *d_ps, uint8_t *d_maxlen, void *d_scratch, hipStream_t s, uint16_t *d_order = nullptr)
+                               uint32_t *d_ps, uint8_t *d_maxlen, void *d_scratch, hipStream_t s, uint16_t *d_order = nullptr,
+                               const uint16_t *d_chunks = nullptr)
 {
     const size_t lds = lz77k_match_lds_bytes(g);
     auto fn = k_match<FAST, MODE>;
@@ -1939,7 +1999,7 @@ static hipError_t launch_match(const uint8_t *d_in, uint32_t n, const lz77x_geom
     }
     const char *sv = getenv("LZ77X_SORT_VARIANT");
     hipLaunchKernelGGL(fn, dim3(nregions), dim3(MATCH_BLOCK), lds, s, d_in, n, g.sb, g.la, g.SBu, g.RP, g.TILE, region0,
-                       d_ps, d_maxlen, reinterpret_cast<uint32_t *>(d_scratch), sv ? atoi(sv) : 0, g.fast ? walk_run_lds(g) : 0u, d_order);
+                       d_ps, d_maxlen, reinterpret_cast<uint32_t *>(d_scratch), sv ? atoi(sv) : 0, g.fast ? walk_run_lds(g) : 0u, d_order, d_chunks);
     return hipGetLastError();
 }
 
@@ -1958,7 +2018,13 @@ hipError_t lz77k_match(const uint8_t *d_in, uint32_t n, const lz77x_geom &g, uin
         /* production: sort -> per-lane bitmap walkers -> finalize */
         hipError_t e = ev_sort ? hipEventRecord(ev_sort[0], s) : hipSuccess;
         if (e != hipSuccess) return e;
-        e = launch_match<true, 3>(LZ77K_MATCH_ARGS, reinterpret_cast<uint16_t *>(d_ranks_all));
+        const uint16_t *d_chunks = nullptr;
+        if (c1_shared_sort(g)) {
+            uint16_t *ch = reinterpret_cast<uint16_t *>(reinterpret_cast<uint8_t *>(d_scratch) + c1_walk_scratch_bytes(g, nregions));
+            hipLaunchKernelGGL(k_c1_chunks, dim3(nregions * 3u + 1u), dim3(C1_BLOCK), 0, s, d_in, n, g.la, (uint64_t)region0 * g.TILE, ch);
+            d_chunks = ch;
+        }
+        e = launch_match<true, 3>(LZ77K_MATCH_ARGS, reinterpret_cast<uint16_t *>(d_ranks_all), d_chunks);
         if (e != hipSuccess) return e;
         if (ev_sort && (e = hipEventRecord(ev_sort[1], s)) != hipSuccess) return e;
         const uint32_t run_len = walk_run_lds(g);

@@ -1240,8 +1240,10 @@ int seg_front(SegJob &J, const lz77x_geom &g)
     }
     uint32_t batch = nregions;
     {
+        /* 3 GB of scratch: 100 MB at C1 (8138 regions of 287 KB) in ONE launch -- the walkers are latency bound (a
+         * launch takes its fill + 2048 steps whatever its size), a second launch is a second 0.75 ms */
         const size_t per = lz77k_match_scratch_bytes(g, 1);
-        const uint32_t fit = (uint32_t)(((size_t)2 << 30) / per);
+        const uint32_t fit = (uint32_t)(((size_t)3 << 30) / per);
         if (batch > fit) batch = fit ? fit : 1;
         const char *gs = getenv("LZ77X_MATCH_BATCH");
         if (gs && atoi(gs) > 0 && (uint32_t)atoi(gs) < batch) batch = (uint32_t)atoi(gs);

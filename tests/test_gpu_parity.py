@@ -298,7 +298,7 @@ def test_segments_give_identical_bytes(kind, seed, n, sb, la, seg, monkeypatch):
 
 @pytest.mark.parametrize("env", [{"LZ77X_MATCH_VARIANT": "1"}, {"LZ77X_MATCH_VARIANT": "3"}, {"LZ77X_SORT_VARIANT": "1"},
                                  {"LZ77X_SORT_VARIANT": "2"}, {"LZ77X_TOKEN_VARIANT": "1"}, {"LZ77X_TOKEN_VARIANT": "2"}, {"LZ77X_WALK_RUN": "256"}, {"LZ77X_WALK_RUN": "1000"},
-                                 {"LZ77X_WALK_RUN": "4096"}])
+                                 {"LZ77X_WALK_RUN": "4096"}, {"LZ77X_C1_SORT_V1": "1"}, {"LZ77X_MATCH_BATCH": "7"}])
 def test_kernel_variants_agree(env, monkeypatch):
     """independent formulations of the same stage (exhaustive pair scan vs bitmap walkers, merge sort vs
     plain / blocked bitonic sort, three token kernels) all reproduce the reference stream"""
