@@ -1025,36 +1025,45 @@ __global__ __launch_bounds__(64) void k_walk(const uint16_t *__restrict__ subs, 
         r_add = ry;                                          /* position t+sb enters at the next step */
     };
     uint32_t t = 0;
-    /* groups of 8 steps: two 16-byte sub-rank loads, four 16-byte result stores.  The loads run TWO groups ahead and
-     * are unconditional (always inside the run's two arrays): the wait for a group's sub-ranks then leaves the result
-     * stores of the two groups before it in flight -- they are scattered 16-byte writes, one line per lane, and with
-     * the loads one group ahead (or under a branch) every group waited for their completion: half of the kernel */
-    uint32_t vq[4], vy[4], aq[4], ay[4], bq[4], by8[4], rf[8], rb[8];
-    load8(t, vq);
-    load8(t + usb, vy);
-    load8(t + 8, aq);
-    load8(t + 8 + usb, ay);
+    /* groups of 16 steps: four 16-byte sub-rank loads, eight 16-byte result stores = one whole 64-byte line per lane
+     * and result array (a lane's results are its own stream: 32-byte half lines made the L2 fetch the rest of every
+     * line: 4.1 GB of HBM traffic per 100 MB for 0.8 GB of results).  The loads run TWO groups ahead and are
+     * unconditional (always inside the run's two arrays): the wait for a group's sub-ranks then leaves the result
+     * stores of the two groups before it in flight; with the loads one group ahead (or under a branch) every group
+     * waited for its predecessor's scattered stores to complete */
+    uint32_t vq[8], vy[8], aq[8], ay[8], bq[8], by8[8], rf[16], rb[16];
+    auto load16 = [&](uint32_t i, uint32_t (&v)[8]) {
+        uint4 t0, t1;
+        __builtin_memcpy(&t0, rk + i, 16);
+        __builtin_memcpy(&t1, rk + i + 8, 16);
+        v[0] = t0.x; v[1] = t0.y; v[2] = t0.z; v[3] = t0.w;
+        v[4] = t1.x; v[5] = t1.y; v[6] = t1.z; v[7] = t1.w;
+    };
+    load16(t, vq);
+    load16(t + usb, vy);
+    load16(t + 16, aq);
+    load16(t + 16 + usb, ay);
     /* the four loads land here, once (an empty asm that consumes them): otherwise the compiler's wait at the top of
      * the loop body must also cover the first pass, where vq / vy are still load destinations, and ends up draining
      * the previous group's stores on every pass */
-    asm volatile("" ::"v"(vq[0] ^ vq[3]), "v"(vy[0] ^ vy[3]), "v"(aq[0] ^ aq[3]), "v"(ay[0] ^ ay[3]));
-    for (; t + 8 <= tb; t += 8) {
-        load8(t + 16, bq);                                   /* t + 16 + usb + 8 <= SUB + 16 < 2 * SUB */
-        load8(t + 16 + usb, by8);
+    asm volatile("" ::"v"(vq[0] ^ vq[7]), "v"(vy[0] ^ vy[7]), "v"(aq[0] ^ aq[7]), "v"(ay[0] ^ ay[7]));
+    for (; t + 16 <= tb; t += 16) {
+        load16(t + 32, bq);                                  /* t + 32 + usb + 16 <= SUB + 32 < 2 * SUB */
+        load16(t + 32 + usb, by8);
 #pragma unroll
-        for (int j = 0; j < 8; j++) {
+        for (int j = 0; j < 16; j++) {
             const uint32_t q = (vq[j >> 1] >> (16 * (j & 1))) & 0xFFFFu;
             const uint32_t ry = t + j + usb < R ? (vy[j >> 1] >> (16 * (j & 1))) & 0xFFFFu : WALK_NONE;
             step(q, ry, rf[j], rb[j]);
         }
         uint4 *o = reinterpret_cast<uint4 *>(of + t);
-        o[0] = make_uint4(rf[0], rf[1], rf[2], rf[3]);
-        o[1] = make_uint4(rf[4], rf[5], rf[6], rf[7]);
-        o = reinterpret_cast<uint4 *>(ob + t);
-        o[0] = make_uint4(rb[0], rb[1], rb[2], rb[3]);
-        o[1] = make_uint4(rb[4], rb[5], rb[6], rb[7]);
 #pragma unroll
-        for (int j = 0; j < 4; j++) { vq[j] = aq[j]; vy[j] = ay[j]; aq[j] = bq[j]; ay[j] = by8[j]; }
+        for (int j = 0; j < 4; j++) o[j] = make_uint4(rf[4 * j], rf[4 * j + 1], rf[4 * j + 2], rf[4 * j + 3]);
+        o = reinterpret_cast<uint4 *>(ob + t);
+#pragma unroll
+        for (int j = 0; j < 4; j++) o[j] = make_uint4(rb[4 * j], rb[4 * j + 1], rb[4 * j + 2], rb[4 * j + 3]);
+#pragma unroll
+        for (int j = 0; j < 8; j++) { vq[j] = aq[j]; vy[j] = ay[j]; aq[j] = bq[j]; ay[j] = by8[j]; }
     }
     for (; t < tb; t++) {
         uint32_t f1, b1;
