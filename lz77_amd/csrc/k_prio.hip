@@ -331,9 +331,13 @@ __device__ __forceinline__ void scan_fetch(scan_regs &r, const uint16_t *dest, c
     }
 }
 
-/* one step on LDS vectors: cur (values at the map's entry cells) -> nxt */
-__device__ __forceinline__ void scan_apply(const scan_regs &r, const uint32_t *cur, uint32_t *nxt, uint32_t sb)
+/* one step on LDS vectors: cur (values at the map's entry cells) -> nxt.  The two vectors are addressed as offsets into
+ * the kernel's LDS array: selected through an array of pointers they were GENERIC pointers, every access a flat
+ * operation behind s_waitcnt vmcnt(0) lgkmcnt(0) -- each step drained the prefetched rows (2 us per step) */
+__device__ __forceinline__ void scan_apply(const scan_regs &r, uint32_t *lds, uint32_t cur_off, uint32_t nxt_off, uint32_t sb)
 {
+    const uint32_t *cur = lds + cur_off;
+    uint32_t *nxt = lds + nxt_off;
 #pragma unroll
     for (int q = 0; q < SCAN_CPT; q++) {
         const uint32_t i = threadIdx.x + PRIO_SCAN_BLOCK * q;
@@ -357,12 +361,11 @@ __global__ __launch_bounds__(PRIO_SCAN_BLOCK) void k_prio_scan_compose(const uin
 {
     extern __shared__ uint32_t scan_lds[];
     __builtin_amdgcn_s_setprio(3);
-    uint32_t *cl[2] = {scan_lds, scan_lds + sb_r};
     uint16_t *cd = reinterpret_cast<uint16_t *>(scan_lds + 2 * sb_r);       /* composed dest */
     uint16_t *dj = cd + sb_r;                                                /* the current map's dest row */
     const uint32_t gi = blockIdx.x;
     const uint32_t m0 = gi * G, m1 = min(m0 + G, nmaps);
-    for (uint32_t i = threadIdx.x; i < sb; i += PRIO_SCAN_BLOCK) { cl[0][i] = PRIO_NONE; cd[i] = (uint16_t)i; }
+    for (uint32_t i = threadIdx.x; i < sb; i += PRIO_SCAN_BLOCK) { scan_lds[i] = PRIO_NONE; cd[i] = (uint16_t)i; }
     /* the rows of the next SCAN_AHEAD maps are in flight while a map is applied: a step is two barriers and a few
      * LDS operations, far shorter than a round trip to the rows k_prio_back has just written */
     scan_regs rr[SCAN_AHEAD];
@@ -382,7 +385,7 @@ __global__ __launch_bounds__(PRIO_SCAN_BLOCK) void k_prio_scan_compose(const uin
                     const uint32_t i = threadIdx.x + PRIO_SCAN_BLOCK * q;
                     if (i < sb) dj[i] = (uint16_t)cur.d[q];
                 }
-                scan_apply(cur, cl[w], cl[w ^ 1], sb);          /* its first barrier also publishes dj */
+                scan_apply(cur, scan_lds, w ? sb_r : 0u, w ? 0u : sb_r, sb);          /* its first barrier also publishes dj */
 #pragma unroll
                 for (int q = 0; q < SCAN_CPT; q++) {
                     const uint32_t i = threadIdx.x + PRIO_SCAN_BLOCK * q;
@@ -395,7 +398,7 @@ __global__ __launch_bounds__(PRIO_SCAN_BLOCK) void k_prio_scan_compose(const uin
     }
     for (uint32_t i = threadIdx.x; i < sb; i += PRIO_SCAN_BLOCK) {
         gdest[(size_t)gi * sb + i] = cd[i];
-        gloc[(size_t)gi * sb + i] = cl[w][i];
+        gloc[(size_t)gi * sb + i] = scan_lds[(w ? sb_r : 0u) + i];
     }
 }
 
@@ -409,14 +412,13 @@ __global__ __launch_bounds__(PRIO_SCAN_BLOCK) void k_prio_scan_replay(const uint
 {
     extern __shared__ uint32_t scan_lds[];
     __builtin_amdgcn_s_setprio(3);
-    uint32_t *cl[2] = {scan_lds, scan_lds + sb_r};
     const uint32_t gi = blockIdx.x;
     const uint32_t m0 = gi * G, m1 = min(m0 + G, nmaps);
     if (m0 >= m1) return;
     const uint32_t *src = vin + (size_t)gi * vin_stride;
     for (uint32_t i = threadIdx.x; i < sb; i += PRIO_SCAN_BLOCK) {
         const uint32_t val = src[i];
-        cl[0][i] = val;
+        scan_lds[i] = val;
         if (store_first) vout[(vout_row0 + m0) * sb + i] = val;
     }
     scan_regs rr[SCAN_AHEAD];
@@ -431,9 +433,9 @@ __global__ __launch_bounds__(PRIO_SCAN_BLOCK) void k_prio_scan_replay(const uint
             if (m < m1) {
                 const scan_regs cur = rr[u];
                 scan_fetch(rr[u], dest, loc, row0 + min(m + SCAN_AHEAD, m1 - 1u), sb);
-                scan_apply(cur, cl[w], cl[w ^ 1], sb);
+                scan_apply(cur, scan_lds, w ? sb_r : 0u, w ? 0u : sb_r, sb);
                 w ^= 1;
-                for (uint32_t i = threadIdx.x; i < sb; i += PRIO_SCAN_BLOCK) vout[(vout_row0 + m + 1) * sb + i] = cl[w][i];
+                for (uint32_t i = threadIdx.x; i < sb; i += PRIO_SCAN_BLOCK) vout[(vout_row0 + m + 1) * sb + i] = scan_lds[(w ? sb_r : 0u) + i];
             }
         }
     }
