@@ -618,8 +618,26 @@ __global__ __launch_bounds__(TS_BLOCK) void k_tokens_sorted(const uint8_t *__res
         }
     }
     const uint32_t k0 = tstart[tl], k1 = tstart[tl + 1];
+    /* the first batch's token positions (and, once they are here, their lengths) travel with the tile's other requests:
+     * under the batch loop they were two exposed round trips, one behind the other */
+    const uint32_t p_pre = chain[min(k0 + (tid >> 1), max(k1, 1u) - 1u)];
     const uint32_t ebase = LIST_START(wbase);
     const uint32_t ecount = LIST_END(b - 1) - ebase;
+    /* the hand-over entries of the window go straight to LDS (LDS-DMA: global_load_lds, 16 bytes = two entries per
+     * lane, wave-uniform LDS base + lane * 16): no staging registers, and all of them are in flight with the rest of
+     * the tile's requests instead of one round trip per 1024 entries behind the filter */
+    const bool staged = ecount <= ent_cap && ecount < 65536u;
+    if (staged && !(ablate & 128)) {
+        const uint32_t npieces = (ecount + 1u) >> 1;
+        const uint8_t *src = reinterpret_cast<const uint8_t *>(ent + ebase);
+        for (uint32_t p0 = 0; p0 < npieces; p0 += TS_BLOCK) {
+            const uint32_t piece = p0 + tid;
+            if (piece < npieces)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + (size_t)piece * 16u),
+                                                 (__attribute__((address_space(3))) void *)(reinterpret_cast<uint8_t *>(lent) + (size_t)(p0 + (tid & ~63u)) * 16u),
+                                                 16, 0, 0);
+        }
+    }
     constexpr int LOFS_PER = (TS_TT + 4096 + 8 + TS_BLOCK - 1) / TS_BLOCK;       /* sb <= 4096 on this path */
     constexpr int BY_PER = (TS_TT + 4096 + 256 + 16 + 4 * TS_BLOCK - 1) / (4 * TS_BLOCK);
     uint32_t lo_raw[LOFS_PER], by_raw[BY_PER];
@@ -654,20 +672,20 @@ __global__ __launch_bounds__(TS_BLOCK) void k_tokens_sorted(const uint8_t *__res
         }
     }
     if ((ablate & 15) == 14) return;
+    const uint32_t len_pre = maxlen[p_pre];
 #pragma unroll
     for (int r = 0; r < BY_PER; r++) {
         const uint32_t i = (tid + (uint32_t)r * TS_BLOCK) * 4u;
         if (i < nb) *reinterpret_cast<uint32_t *>(by + i) = by_raw[r];
     }
-    const bool staged = ecount <= ent_cap && ecount < 65536u;
     if (staged) {
 #pragma unroll
         for (int r = 0; r < LOFS_PER; r++) {
             const uint32_t i = tid + (uint32_t)r * TS_BLOCK;
             if (i <= NO) lofs[i] = (uint16_t)(lo_raw[r] - ebase);
         }
-        if (!(ablate & 128)) for (uint32_t e = tid; e < ecount; e += TS_BLOCK) lent[e] = ent[ebase + e];
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         /* the LDS-DMA pieces have landed (the compiler does not track them) */
     if ((ablate & 15) == 13) return;
     ts_barrier_lds();
     N = s_total;                                            /* = b - wlo: every cell of the window is in the region */
@@ -691,8 +709,8 @@ __global__ __launch_bounds__(TS_BLOCK) void k_tokens_sorted(const uint8_t *__res
         {
             const uint32_t ti = tid >> 1, up = tid & 1u;
             if (ti < nt) {
-                const uint32_t p = chain[kb + ti];
-                const uint32_t len = maxlen[p];
+                const uint32_t p = kb == k0 ? p_pre : chain[kb + ti];
+                const uint32_t len = kb == k0 ? len_pre : (uint32_t)maxlen[p];
                 const uint32_t qo = p - wbase;
                 int edge = 0;
                 if (len > 0) {
@@ -1138,7 +1156,7 @@ hipError_t lz77k_tokens(const uint8_t *d_in, uint32_t n, const lz77x_geom &g, co
         const uint32_t off_lent = (off_tk + TS_TB * 8 + (TS_TB + 4) * 4 + TS_TB * 4 + TS_TB * 2 * 2 + 15) & ~15u;
         const uint32_t budget = 78u * 1024u;                              /* two workgroups per CU */
         const uint32_t ent_cap = off_lent + 8 * 512 < budget ? (budget - off_lent) / 8 : 512;
-        const size_t lds = (size_t)off_lent + (size_t)ent_cap * 8;
+        const size_t lds = (size_t)off_lent + (size_t)ent_cap * 8 + 16;      /* + the odd half of the last LDS-DMA piece */
         if (lds > 48 * 1024) {
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_tokens_sorted), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             if (e != hipSuccess) return e;
