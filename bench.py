@@ -194,13 +194,15 @@ def shard_mode(a):
                "ms_per_step": round(dt / K * 1e3, 3), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
                "dtype": "u8", "data": "synthetic",
                "config": {"workload": "S4 enwik9-like text (lz77_amd.synth.text, seed 0x5EED0004), %d bytes, s=%d l=%d, cut into %d shards "
-                                      "on %d device(s); host buffers in and out (PCIe-inclusive); decode on one device" %
+                                      "on %d device(s); host buffers in and out (PCIe-inclusive); decode sharded by token ranges "
+                                      "(sb-byte maps chained on the host)" %
                                       (n, a.sb, a.la, len(plan), min(len(plan), L.lib().lz77x_device_count())),
                           "mode": "shard", "shards": len(plan), "max_local_bytes": max(p["local_bytes"] for p in plan)},
                "encode_ms": round(sum(enc_ms) / K, 2), "decode_ms": round(sum(dec_ms) / K, 2), "prio_iters": iters,
                "roundtrip_ok": bool(back == data.tobytes()), "stream_sha_ok": sha_ok,
                "serial_terms": "per gate iteration one host exchange of 6 KB per shard (priority cells), one of 1.3 KB per shard for "
-                               "the parse chain, 16 bytes per cut for packing; everything else is shard-local"}
+                               "the parse chain, 16 bytes per cut for packing; decode: one map of sb 16-bit states per shard, chained "
+                               "on the host; everything else is shard-local"}
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()

@@ -82,7 +82,10 @@ int lz77x_decode_file(FILE *in, FILE *out);
 
 /* Number of logical shards the positions of one input are split into (default 1, or
  * env LZ77X_SHARDS).  Shards are spread round-robin over the visible devices; output
- * bytes are identical for every shard count. */
+ * bytes are identical for every shard count.  lz77x_encode cuts the input by
+ * positions, lz77x_decode cuts the stream by token ranges (the sb bytes before a range reach it
+ * as a map chained on the host; lz77.c:172-192 across the cuts); streams it cannot cut that way
+ * (distance-0 copies of a power-of-two -s, windows above 8192) decode on one device. */
 int lz77x_set_shards(int shards);
 int lz77x_device_count(void);
 /* Release every cached device/pinned buffer, stream and event (they are otherwise kept for the

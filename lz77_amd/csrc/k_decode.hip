@@ -419,7 +419,10 @@ __global__ void k_dec_bounds_ts(const uint32_t *__restrict__ dst, uint32_t ntok,
 __global__ __launch_bounds__(DS_BLOCK) void k_dec_seg(const uint32_t *__restrict__ tokval, const uint32_t *__restrict__ dst, uint32_t ntok,
                                                       int ob, int lb, uint8_t *__restrict__ out, uint16_t *__restrict__ ref16,
                                                       unsigned long long *__restrict__ flags, uint32_t n, uint32_t seg_bytes, uint32_t nseg,
-                                                      const uint32_t *__restrict__ tfirst, uint32_t sb, uint16_t *__restrict__ tail)
+                                                      const uint32_t *__restrict__ tfirst, uint32_t sb, uint16_t *__restrict__ tail,
+                                                      uint32_t ext0 /* a shard of a stream cut by token ranges: the sb bytes before output byte 0
+                                                                       exist elsewhere (EXT references like any segment's), and the last
+                                                                       segment's tail is wanted too */)
 {
     __shared__ uint16_t ring[DS_R];
     __shared__ uint32_t s_tf[DS_MAX_STEPS + 2];
@@ -428,7 +431,7 @@ __global__ __launch_bounds__(DS_BLOCK) void k_dec_seg(const uint32_t *__restrict
     const uint32_t a = sg * seg_bytes;
     const uint32_t b = sg + 1 == nseg ? n : a + seg_bytes;
     const uint32_t nsteps = (b - a + DS_TS - 1u) / DS_TS;
-    if (sg > 0)
+    if (sg > 0 || ext0)
         for (uint32_t i = tid; i < sb; i += DS_BLOCK) ring[(a - sb + i) & (DS_R - 1u)] = (uint16_t)(DS_EXT | i);
     /* first token of every step (and of the step after the last one, when there is one) */
     for (uint32_t i = tid; i <= nsteps; i += DS_BLOCK) s_tf[i] = (uint64_t)a + (uint64_t)i * DS_TS < n ? tfirst[a / DS_TS + i] : ntok;
@@ -467,7 +470,8 @@ __global__ __launch_bounds__(DS_BLOCK) void k_dec_seg(const uint32_t *__restrict
                 if (j >= te) break;
                 uint32_t st = DS_LIT | lit;
                 if (i < len) {
-                    if (off == 0 || off > j) st = DS_LIT;                          /* degenerate: a zero byte */
+                    if (off == 0 || (off > j && !(ext0 && off - j <= sb))) st = DS_LIT;   /* degenerate: a zero byte */
+                    else if (off > j) st = (uint32_t)ring[(j - off) & (DS_R - 1u)];      /* a shard: from the bytes before it */
                     else {
                         const uint32_t src = j - off;
                         st = src >= ts ? (DS_INT | (src & (DS_R - 1u))) : (uint32_t)ring[src & (DS_R - 1u)];
@@ -517,7 +521,7 @@ __global__ __launch_bounds__(DS_BLOCK) void k_dec_seg(const uint32_t *__restrict
 #pragma unroll
         for (int q = 0; q < DS_PF; q++) { cv[q] = nv[q]; cd[q] = nd[q]; }
     }
-    if (sg + 1 < nseg)
+    if (sg + 1 < nseg || ext0)
         for (uint32_t i = tid; i < sb; i += DS_BLOCK) tail[(size_t)sg * sb + i] = ring[(b - sb + i) & (DS_R - 1u)];
 }
 
@@ -564,13 +568,14 @@ __global__ __launch_bounds__(1024) void k_dec_tails_compose(const uint16_t *__re
  * reference); vout[r] = the values after row r */
 __global__ __launch_bounds__(1024) void k_dec_tails_replay(const uint16_t *__restrict__ rows, uint32_t nrows, uint32_t G,
                                                            const uint8_t *__restrict__ before /* row g-1: the values before group g */,
-                                                           uint8_t *__restrict__ vout, uint32_t sb)
+                                                           uint8_t *__restrict__ vout, uint32_t sb,
+                                                           const uint8_t *__restrict__ before0 /* a shard: the values before row 0, else null */)
 {
     __shared__ uint8_t cur[2][DS_TAIL_MAX];
     const uint32_t g = blockIdx.x, r0 = g * G, r1 = min(r0 + G, nrows);
     if (r0 >= r1) return;
-    if (before != nullptr && g > 0) {
-        const uint8_t *bsrc = before + (size_t)(g - 1u) * sb;
+    if ((before != nullptr && g > 0) || (g == 0 && before0 != nullptr)) {
+        const uint8_t *bsrc = g > 0 ? before + (size_t)(g - 1u) * sb : before0;
         for (uint32_t i = threadIdx.x; i < sb; i += 1024u) cur[1][i] = bsrc[i];
     }
     uint16_t st[8], nx[8];
@@ -599,8 +604,10 @@ __global__ __launch_bounds__(1024) void k_dec_tails_replay(const uint16_t *__res
 /* flagged bytes take their value from the resolved tail of the segment before theirs.  A lane fetches one
  * 64-bit flag word; the wave then visits only the words that have a flag (they cluster at segment starts). */
 __global__ __launch_bounds__(256) void k_dec_patch(uint8_t *__restrict__ out, const uint16_t *__restrict__ ref16,
-                                                   const unsigned long long *__restrict__ flags, const uint8_t *__restrict__ tres, uint32_t n,
-                                                   uint32_t seg_bytes, uint32_t sb)
+                                                   const unsigned long long *__restrict__ flags,
+                                                   const uint8_t *__restrict__ tres0 /* row s = the resolved sb bytes BEFORE segment s (row 0: a shard's
+                                                                                        incoming bytes; never read otherwise) */,
+                                                   uint32_t n, uint32_t seg_bytes, uint32_t sb)
 {
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t nwords = (n + 63u) / 64u;
@@ -631,7 +638,7 @@ __global__ __launch_bounds__(256) void k_dec_patch(uint8_t *__restrict__ out, co
             for (int u = 0; u < 4; u++) r[u] = ref16[on[u] ? j[u] : 0u];
             uint8_t v[4];
 #pragma unroll
-            for (int u = 0; u < 4; u++) v[u] = tres[on[u] ? (size_t)(j[u] / seg_bytes - 1u) * sb + r[u] : 0u];
+            for (int u = 0; u < 4; u++) v[u] = tres0[on[u] ? (size_t)(j[u] / seg_bytes) * sb + r[u] : (size_t)sb];
 #pragma unroll
             for (int u = 0; u < 4; u++)
                 if (on[u]) out[j[u]] = v[u];
@@ -657,45 +664,82 @@ size_t lz77k_dec_seg_tmp_bytes(uint32_t n, const lz77x_geom &g)
 {
     uint32_t sbytes, nseg;
     dec_seg_plan(n, &sbytes, &nseg);
-    return ((size_t)n / DS_TS + 8) * 4 + 256 + ((size_t)n / 64 + 8) * 8 + 256 + (size_t)nseg * g.sb * 3 + ((size_t)nseg / 8 + 40) * g.sb * 3 + 2048;
+    return ((size_t)n / DS_TS + 8) * 4 + ((size_t)n / 64 + 8) * 8 + (size_t)nseg * g.sb * 2 + ((size_t)nseg + 1) * g.sb +
+           ((size_t)nseg / 8 + 40) * g.sb * 3 + (size_t)g.sb * 2 + 8 * 256;
+}
+
+/* The copy resolution in two phases, so that a stream cut by token ranges over several devices can exchange the sb bytes
+ * between its shards in the middle:
+ *   front: segment walk (flagged bytes + every segment's tail) and the composition of the tails by groups; ext0: the
+ *          bytes before output byte 0 exist (another shard's): segment 0 starts from references too, the last tail is
+ *          kept, and *d_smap receives the whole shard as ONE map (sb states: a byte value, or EXT | index into the
+ *          incoming sb bytes) -- what the host chains from shard to shard;
+ *   back : tails resolved front to back (ext0: from the incoming bytes the caller has put into P.tres0[0..sb)), flagged
+ *          bytes patched. */
+hipError_t lz77k_dec_segments_front(const uint32_t *d_tokval, const uint32_t *d_dst, uint32_t ntok, const lz77x_geom &g, uint8_t *d_out,
+                                    void *d_ref, uint32_t n, void *d_tmp, hipStream_t s, bool ext0, lz77k_dec_seg_state &P,
+                                    const uint16_t **d_smap)
+{
+    P = lz77k_dec_seg_state();
+    if (n == 0 || ntok == 0) return hipSuccess;
+    dec_seg_plan(n, &P.sbytes, &P.nseg);
+    const uint32_t nseg = P.nseg, usb = (uint32_t)g.sb;
+    uint8_t *base = reinterpret_cast<uint8_t *>(d_tmp);
+    size_t o = 0;
+    auto take = [&](size_t bytes) { uint8_t *q = base + o; o += (bytes + 255) & ~(size_t)255; return q; };
+    P.tfirst = reinterpret_cast<uint32_t *>(take(((size_t)n / DS_TS + 8) * 4));
+    P.flags = reinterpret_cast<unsigned long long *>(take(((size_t)n / 64 + 8) * 8));
+    P.tail = reinterpret_cast<uint16_t *>(take((size_t)nseg * g.sb * 2));
+    P.tres0 = take(((size_t)nseg + 1) * g.sb);              /* row s: the bytes before segment s */
+    P.gmap = reinterpret_cast<uint16_t *>(take(((size_t)nseg / 8 + 40) * g.sb * 2));     /* sqrt(nseg) + 1 group maps */
+    P.gres = take(((size_t)nseg / 8 + 40) * g.sb);
+    P.smap = reinterpret_cast<uint16_t *>(take((size_t)g.sb * 2));
+    P.ext0 = ext0;
+    hipLaunchKernelGGL(k_dec_bounds_ts, dim3((ntok + 255) / 256), dim3(256), 0, s, d_dst, ntok, P.tfirst);
+    hipLaunchKernelGGL(k_dec_seg, dim3(nseg), dim3(DS_BLOCK), 0, s, d_tokval, d_dst, ntok, g.ob, g.lb, d_out, reinterpret_cast<uint16_t *>(d_ref),
+                       P.flags, n, P.sbytes, nseg, P.tfirst, usb, P.tail, ext0 ? 1u : 0u);
+    P.ntails = ext0 ? nseg : nseg - 1u;
+    if (P.ntails) {
+        uint32_t G = 1;
+        while (G * G < P.ntails) G++;
+        P.G = G;
+        P.NG = (P.ntails + G - 1u) / G;
+        if (P.NG > 1) hipLaunchKernelGGL(k_dec_tails_compose, dim3(P.NG), dim3(1024), 0, s, P.tail, P.gmap, P.ntails, G, usb);
+        if (ext0) {
+            if (P.NG > 1) hipLaunchKernelGGL(k_dec_tails_compose, dim3(1), dim3(1024), 0, s, P.gmap, P.smap, P.NG, P.NG, usb);
+            else hipLaunchKernelGGL(k_dec_tails_compose, dim3(1), dim3(1024), 0, s, P.tail, P.smap, P.ntails, P.ntails, usb);
+        }
+    }
+    if (d_smap) *d_smap = P.smap;
+    return hipGetLastError();
+}
+
+hipError_t lz77k_dec_segments_back(const lz77x_geom &g, uint8_t *d_out, void *d_ref, uint32_t n, const lz77k_dec_seg_state &P, hipStream_t s)
+{
+    if (n == 0 || P.nseg == 0 || P.ntails == 0) return hipSuccess;
+    const uint32_t usb = (uint32_t)g.sb;
+    const uint8_t *before0 = P.ext0 ? P.tres0 : nullptr;
+    uint8_t *tres = P.tres0 + usb;                           /* row s + 1: the tail of segment s, resolved */
+    if (P.NG > 1) {
+        hipLaunchKernelGGL(k_dec_tails_replay, dim3(1), dim3(1024), 0, s, P.gmap, P.NG, P.NG, (const uint8_t *)nullptr, P.gres, usb, before0);
+        hipLaunchKernelGGL(k_dec_tails_replay, dim3(P.NG), dim3(1024), 0, s, P.tail, P.ntails, P.G, P.gres, tres, usb, before0);
+    } else {
+        hipLaunchKernelGGL(k_dec_tails_replay, dim3(1), dim3(1024), 0, s, P.tail, P.ntails, P.ntails, (const uint8_t *)nullptr, tres, usb, before0);
+    }
+    const uint32_t blocks = min((n / 64u + 255u) / 256u + 1u, 256u * 8u);
+    hipLaunchKernelGGL(k_dec_patch, dim3(blocks), dim3(256), 0, s, d_out, reinterpret_cast<const uint16_t *>(d_ref), P.flags, P.tres0, n, P.sbytes,
+                       usb);
+    return hipGetLastError();
 }
 
 /* the whole copy resolution: d_out[0..n) from the tokens.  d_ref: 2n bytes; d_tmp: lz77k_dec_seg_tmp_bytes */
 hipError_t lz77k_dec_segments(const uint32_t *d_tokval, const uint32_t *d_dst, uint32_t ntok, const lz77x_geom &g, uint8_t *d_out,
                               void *d_ref, uint32_t n, void *d_tmp, hipStream_t s)
 {
-    if (n == 0 || ntok == 0) return hipSuccess;
-    uint32_t sbytes, nseg;
-    dec_seg_plan(n, &sbytes, &nseg);
-    uint8_t *base = reinterpret_cast<uint8_t *>(d_tmp);
-    size_t o = 0;
-    auto take = [&](size_t bytes) { uint8_t *q = base + o; o += (bytes + 255) & ~(size_t)255; return q; };
-    uint32_t *tfirst = reinterpret_cast<uint32_t *>(take(((size_t)n / DS_TS + 8) * 4));
-    unsigned long long *flags = reinterpret_cast<unsigned long long *>(take(((size_t)n / 64 + 8) * 8));
-    uint16_t *tail = reinterpret_cast<uint16_t *>(take((size_t)nseg * g.sb * 2));
-    uint8_t *tres = take((size_t)nseg * g.sb);
-    uint16_t *gmap = reinterpret_cast<uint16_t *>(take(((size_t)nseg / 8 + 40) * g.sb * 2));     /* sqrt(nseg) + 1 group maps */
-    uint8_t *gres = take(((size_t)nseg / 8 + 40) * g.sb);
-    hipLaunchKernelGGL(k_dec_bounds_ts, dim3((ntok + 255) / 256), dim3(256), 0, s, d_dst, ntok, tfirst);
-    hipLaunchKernelGGL(k_dec_seg, dim3(nseg), dim3(DS_BLOCK), 0, s, d_tokval, d_dst, ntok, g.ob, g.lb, d_out, reinterpret_cast<uint16_t *>(d_ref),
-                       flags, n, sbytes, nseg, tfirst, (uint32_t)g.sb, tail);
-    if (nseg > 1) {
-        const uint32_t ntails = nseg - 1u, usb = (uint32_t)g.sb;
-        uint32_t G = 1;
-        while (G * G < ntails) G++;
-        const uint32_t NG = (ntails + G - 1u) / G;
-        if (NG > 1) {
-            hipLaunchKernelGGL(k_dec_tails_compose, dim3(NG), dim3(1024), 0, s, tail, gmap, ntails, G, usb);
-            hipLaunchKernelGGL(k_dec_tails_replay, dim3(1), dim3(1024), 0, s, gmap, NG, NG, (const uint8_t *)nullptr, gres, usb);
-            hipLaunchKernelGGL(k_dec_tails_replay, dim3(NG), dim3(1024), 0, s, tail, ntails, G, gres, tres, usb);
-        } else {
-            hipLaunchKernelGGL(k_dec_tails_replay, dim3(1), dim3(1024), 0, s, tail, ntails, ntails, (const uint8_t *)nullptr, tres, usb);
-        }
-        const uint32_t blocks = min((n / 64u + 255u) / 256u + 1u, 256u * 8u);
-        hipLaunchKernelGGL(k_dec_patch, dim3(blocks), dim3(256), 0, s, d_out, reinterpret_cast<const uint16_t *>(d_ref), flags, tres, n, sbytes,
-                           (uint32_t)g.sb);
-    }
-    return hipGetLastError();
+    lz77k_dec_seg_state P;
+    hipError_t e = lz77k_dec_segments_front(d_tokval, d_dst, ntok, g, d_out, d_ref, n, d_tmp, s, false, P, nullptr);
+    if (e != hipSuccess) return e;
+    return lz77k_dec_segments_back(g, d_out, d_ref, n, P, s);
 }
 
 hipError_t lz77k_dec_parse(const uint8_t *d_z, uint32_t ntok, const lz77x_geom &g, uint32_t *d_tokval, uint32_t *d_len1, hipStream_t s,

@@ -224,6 +224,19 @@ int lz77k_dec_seg_supported(const lz77x_geom &g);
 size_t lz77k_dec_seg_tmp_bytes(uint32_t n, const lz77x_geom &g);
 hipError_t lz77k_dec_segments(const uint32_t *d_tokval, const uint32_t *d_dst, uint32_t ntok, const lz77x_geom &g, uint8_t *d_out,
                               void *d_ref, uint32_t n, void *d_tmp, hipStream_t s);
+/* the two phases of lz77k_dec_segments (k_decode.hip), for a stream whose token ranges are decoded on several devices */
+struct lz77k_dec_seg_state {
+    uint32_t sbytes = 0, nseg = 0, ntails = 0, G = 0, NG = 0;
+    bool ext0 = false;
+    uint32_t *tfirst = nullptr;
+    unsigned long long *flags = nullptr;
+    uint16_t *tail = nullptr, *gmap = nullptr, *smap = nullptr;
+    uint8_t *tres0 = nullptr, *gres = nullptr;      /* tres0[0..sb): the bytes before output byte 0 (ext0: filled by the caller before _back) */
+};
+hipError_t lz77k_dec_segments_front(const uint32_t *d_tokval, const uint32_t *d_dst, uint32_t ntok, const lz77x_geom &g, uint8_t *d_out,
+                                    void *d_ref, uint32_t n, void *d_tmp, hipStream_t s, bool ext0, lz77k_dec_seg_state &P,
+                                    const uint16_t **d_smap);
+hipError_t lz77k_dec_segments_back(const lz77x_geom &g, uint8_t *d_out, void *d_ref, uint32_t n, const lz77k_dec_seg_state &P, hipStream_t s);
 hipError_t lz77k_dec_gather2(uint8_t *d_out, const uint32_t *d_ptr, const unsigned long long *d_unres, uint32_t n, hipStream_t s);
 #endif
 

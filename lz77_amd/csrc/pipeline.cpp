@@ -945,6 +945,137 @@ int decode_core(Ctx &c, size_t zn, hipStream_t s, bool want_data, size_t *n_out)
     return LZ77X_OK;
 }
 
+int fetch_result(Ctx &c, uint8_t *dst, const void *d_src, size_t bytes);
+
+/* ONE stream decoded on SEVERAL devices: the tokens are cut into D contiguous ranges at multiples of
+ * eight tokens (every range then starts on a byte of the stream); device d parses and scans its range and walks
+ * its segments with the sb bytes before its first output byte as symbolic references, like any segment's
+ * (k_dec_seg ext0) -- nothing it does depends on another shard.  What crosses the cuts is, per shard, ONE map of sb
+ * states (a byte value, or "byte i of the bytes before me": the composition of all its segments' tails), chained on
+ * the host front to back (D steps of sb table look-ups), after which every shard is handed its sb incoming bytes,
+ * resolves its tails and patches its flagged bytes.  No device-to-device traffic, no collective; device memory per
+ * shard ~ its share of the tokens and of the output.  *handled = 0: not a case for this path (distance-0 copies,
+ * windows above 8192, a shard shorter than the window, too few tokens) -- the caller decodes on one device. */
+int decode_sharded(std::vector<Ctx *> &cs, const uint8_t *z, size_t zn, uint8_t **out, size_t *out_n, int *handled)
+{
+    const double t_begin = now_ms();
+    *handled = 0;
+    int rc;
+    if (zn < 4) return LZ77X_E_FORMAT;
+    const int sb = z[0] | (z[1] << 8), la = z[2] | (z[3] << 8);               /* lz77.c:157-158 */
+    if (sb < 1 || la < 1) return LZ77X_E_FORMAT;
+    lz77x_geom g;
+    lz77x_make_geom(&g, sb, la);
+    if (g.T > 32) return LZ77X_E_FORMAT;
+    const uint64_t ntok64 = ((uint64_t)zn * 8 - 32) / (uint64_t)g.T;
+    if (ntok64 > LZ77X_MAX_N) return LZ77X_E_TOOBIG;
+    const uint32_t ntok = (uint32_t)ntok64;
+    const size_t D = cs.size();
+    if (!lz77k_dec_seg_supported(g) || getenv("LZ77X_DECODE_VARIANT") || getenv("LZ77X_DECODE_V1") || ntok < 64 * D) return LZ77X_OK;
+    const size_t usb = (size_t)sb;
+    std::vector<uint32_t> k0(D + 1);
+    for (size_t d = 0; d <= D; d++) k0[d] = d == D ? ntok : (uint32_t)((uint64_t)ntok * d / D) & ~7u;
+    struct Sh { uint32_t ntok = 0, n = 0; lz77k_dec_seg_state P; const uint16_t *d_smap = nullptr; };
+    std::vector<Sh> sh(D);
+    /* 1. every shard: its bytes of the stream behind a header of its own, parse, scan */
+    for (size_t d = 0; d < D; d++) {
+        Ctx &c = *cs[d];
+        HIPCHK(hipSetDevice(c.device));
+        hipStream_t s = c.stream;
+        Sh &S = sh[d];
+        S.ntok = k0[d + 1] - k0[d];
+        const size_t b0 = 4 + (size_t)k0[d] * g.T / 8, b1 = 4 + ((size_t)k0[d + 1] * g.T + 7) / 8;      /* k0 is a multiple of 8: b0 exact */
+        const size_t zb = 4 + (b1 - b0);
+        if ((rc = c.z.need(zb + 32))) return rc;
+        if ((rc = c.h_small.need(128))) return rc;
+        HIPCHK(hipMemsetAsync(c.z.as<uint8_t>() + zb, 0, 32, s));
+        HIPCHK(hipMemcpyAsync(c.z.p, z, 4, hipMemcpyHostToDevice, s));
+        HIPCHK(hipMemcpyAsync(c.z.as<uint8_t>() + 4, z + b0, b1 - b0, hipMemcpyHostToDevice, s));
+        if ((rc = c.tokval.need(((size_t)S.ntok + 8) * 4))) return rc;
+        if ((rc = c.len1.need(((size_t)S.ntok + 8) * 4))) return rc;
+        if ((rc = c.dst.need(((size_t)S.ntok + 8) * 4))) return rc;
+        if ((rc = c.scantmp.need(lz77k_scan_tmp_bytes(S.ntok + 1)))) return rc;
+        if ((rc = c.flag.need(64))) return rc;
+        HIPCHK(hipMemsetAsync(c.flag.as<uint32_t>() + 8, 0, 4, s));
+        HIPCHK(lz77k_dec_parse(c.z.as<uint8_t>(), S.ntok, g, c.tokval.as<uint32_t>(), c.len1.as<uint32_t>(), s, c.flag.as<uint32_t>() + 8));
+        HIPCHK(hipMemsetAsync(c.len1.as<uint32_t>() + S.ntok, 0, 4, s));
+        HIPCHK(lz77k_sum_u32(c.len1.as<uint32_t>(), S.ntok, c.flag.as<unsigned long long>() + 2, s));
+        HIPCHK(lz77k_scan_u32(c.len1.as<uint32_t>(), c.dst.as<uint32_t>(), S.ntok + 1, c.scantmp.p, s));
+        uint32_t *h = c.h_small.as<uint32_t>();
+        HIPCHK(hipMemcpyAsync(h + 4, c.flag.as<unsigned long long>() + 2, 8, hipMemcpyDeviceToHost, s));
+        HIPCHK(hipMemcpyAsync(h + 8, c.flag.as<uint32_t>() + 8, 4, hipMemcpyDeviceToHost, s));
+    }
+    uint64_t n = 0;
+    bool fits = true;
+    std::vector<uint64_t> o0(D + 1, 0);
+    for (size_t d = 0; d < D; d++) {
+        Ctx &c = *cs[d];
+        HIPCHK(hipSetDevice(c.device));
+        HIPCHK(hipStreamSynchronize(c.stream));
+        const uint32_t *h = c.h_small.as<uint32_t>();
+        const uint64_t nd = *reinterpret_cast<const unsigned long long *>(h + 4);
+        if (h[8] != 0 || nd < usb || nd > LZ77X_MAX_N) fits = false;        /* distance-0 copies / a shard inside one window */
+        sh[d].n = (uint32_t)nd;
+        o0[d + 1] = o0[d] + nd;
+    }
+    n = o0[D];
+    if (!fits || n > LZ77X_MAX_N) { HIPCHK(hipSetDevice(cs[0]->device)); return LZ77X_OK; }
+    /* 2. every shard: segment walk, tails composed into the shard's map */
+    std::vector<std::vector<uint16_t>> smap(D, std::vector<uint16_t>(usb));
+    for (size_t d = 0; d < D; d++) {
+        Ctx &c = *cs[d];
+        HIPCHK(hipSetDevice(c.device));
+        Sh &S = sh[d];
+        if ((rc = c.out.need((size_t)S.n + 16))) return rc;
+        if ((rc = c.ptr.need(((size_t)S.n + 8) * 4))) return rc;
+        if ((rc = c.tstart.need(lz77k_dec_seg_tmp_bytes(S.n, g)))) return rc;
+        HIPCHK(lz77k_dec_segments_front(c.tokval.as<uint32_t>(), c.dst.as<uint32_t>(), S.ntok, g, c.out.as<uint8_t>(), c.ptr.p, S.n, c.tstart.p,
+                                        c.stream, true, S.P, &S.d_smap));
+        HIPCHK(hipMemcpyAsync(smap[d].data(), S.d_smap, usb * 2, hipMemcpyDeviceToHost, c.stream));
+    }
+    /* 3. the host chains the maps: incoming bytes of every shard (nothing lies before the first: zero bytes, what a
+     *    copy from before the start of the output reads in the single-device decoder too) */
+    std::vector<std::vector<uint8_t>> incoming(D, std::vector<uint8_t>(usb, 0));
+    for (size_t d = 0; d + 1 < D; d++) {
+        Ctx &c = *cs[d];
+        HIPCHK(hipSetDevice(c.device));
+        HIPCHK(hipStreamSynchronize(c.stream));
+        const std::vector<uint8_t> &in_d = incoming[d];
+        std::vector<uint8_t> &out_d = incoming[d + 1];
+        for (size_t i = 0; i < usb; i++) {
+            const uint16_t x = smap[d][i];
+            out_d[i] = (x & 0xC000u) == 0x8000u ? in_d[x & 0x3FFFu] : (uint8_t)x;
+        }
+    }
+    /* 4. every shard: incoming bytes in, tails resolved, flagged bytes patched, output to the host */
+    uint8_t *buf = (uint8_t *)malloc(n ? (size_t)n : 1);
+    if (!buf) return LZ77X_E_NOMEM;
+    for (size_t d = 0; d < D; d++) {
+        Ctx &c = *cs[d];
+        hipError_t e = hipSetDevice(c.device);
+        if (e == hipSuccess) e = hipMemcpyAsync(sh[d].P.tres0, incoming[d].data(), usb, hipMemcpyHostToDevice, c.stream);
+        if (e == hipSuccess) e = lz77k_dec_segments_back(g, c.out.as<uint8_t>(), c.ptr.p, sh[d].n, sh[d].P, c.stream);
+        if (e != hipSuccess) { free(buf); snprintf(g_err, sizeof g_err, "HIP: %s", hipGetErrorString(e)); return LZ77X_E_HIP; }
+    }
+    for (size_t d = 0; d < D; d++) {
+        Ctx &c = *cs[d];
+        hipError_t e = hipSetDevice(c.device);
+        if (e == hipSuccess) e = hipStreamSynchronize(c.stream);
+        if (e != hipSuccess) { free(buf); snprintf(g_err, sizeof g_err, "HIP: %s", hipGetErrorString(e)); return LZ77X_E_HIP; }
+        if ((rc = fetch_result(c, buf + o0[d], c.out.p, sh[d].n))) { free(buf); return rc; }
+    }
+    HIPCHK(hipSetDevice(cs[0]->device));
+    memset(&g_stats, 0, sizeof g_stats);
+    g_stats.n = n;
+    g_stats.zn = zn;
+    g_stats.ntok = ntok;
+    g_stats.total_ms = now_ms() - t_begin;
+    *out = buf;
+    *out_n = (size_t)n;
+    *handled = 1;
+    return LZ77X_OK;
+}
+
 int load_stream(Ctx &c, const void *src, bool on_device, size_t zn, hipStream_t s)
 {
     int rc;
@@ -2046,6 +2177,18 @@ int lz77x_decode(const uint8_t *z, size_t zn, uint8_t **out, size_t *out_n)
     Ctx &g_ctx = lease.set->primary;
     (void)g_ctx;
     int rc;
+    int shards = g_shards;
+    if (shards <= 0) { const char *e = getenv("LZ77X_SHARDS"); shards = e ? atoi(e) : 1; }
+    if (shards > 1) {
+        /* one stream on several devices: token ranges with a chained sb-byte hand-off (decode_sharded) */
+        std::vector<Ctx *> cs;
+        if ((rc = shard_contexts(*lease.set, shards, cs))) return rc;
+        if (cs.size() > 1) {
+            int handled = 0;
+            if ((rc = decode_sharded(cs, z, zn, out, out_n, &handled))) return rc;
+            if (handled) return LZ77X_OK;
+        }
+    }
     if ((rc = primary_context(*lease.set))) return rc;
     if (zn < 4) return LZ77X_E_FORMAT;
     if ((rc = load_stream(g_ctx, z, false, zn, g_ctx.stream))) return rc;

@@ -222,6 +222,40 @@ def test_shards_give_identical_bytes(kind, seed, n, sb, la, monkeypatch):
         L.lib().lz77x_set_shards(1)
 
 
+@pytest.mark.parametrize("kind,seed,n,sb,la", [("text", 91, 3_000_000, 4095, 15), ("random", 92, 1_200_000, 4095, 15),
+                                              ("mixed", 93, 2_000_000, 1000, 10), ("lowent", 94, 1_500_000, 8191, 16),
+                                              ("zeros", 0, 700_000, 4095, 15), ("records", 95, 900_000, 255, 7)])
+def test_sharded_decode_gives_identical_bytes(kind, seed, n, sb, la, monkeypatch):
+    """SURVEY 8e, decode side: the tokens cut into 2/3/4/8 ranges (one device context each, sharing the test box's GPU),
+    every range decoded with the sb bytes before it as symbolic references, the shards' maps chained on the host
+    (lz77.c:172-192 across the cuts): the same bytes as the reference's decoder; small decode segments so that a
+    shard holds several"""
+    data = synth.make(kind, n, seed)
+    z = O.encode_bst(data, sb, la)
+    monkeypatch.setenv("LZ77X_FAKE_DEVICES", "8")
+    monkeypatch.setenv("LZ77X_DECODE_SEGMENT", "65536")
+    try:
+        for shards in (2, 3, 4, 8):
+            assert L.lib().lz77x_set_shards(shards) == 0
+            assert L.decode(z) == data.tobytes(), shards
+            assert L.last_stats()["k_decode_ms"] == 0, "the single-device decoder ran"
+    finally:
+        L.lib().lz77x_set_shards(1)
+
+
+def test_sharded_decode_falls_back(monkeypatch):
+    """streams the sharded decoder does not take (a power-of-two -s with distance-0 copies; fewer tokens than 64 per
+    shard; a shard shorter than the window) decode on one device, same bytes"""
+    monkeypatch.setenv("LZ77X_FAKE_DEVICES", "8")
+    try:
+        assert L.lib().lz77x_set_shards(4) == 0
+        for data, sb, la in ((synth.text(400_000, 96), 4096, 15), (synth.text(150, 97), 4095, 15), (synth.zeros(9000), 4095, 15)):
+            z = O.encode_bst(data, sb, la)
+            assert L.decode(z) == O.decode(z)
+    finally:
+        L.lib().lz77x_set_shards(1)
+
+
 @pytest.mark.parametrize("slots,chunk,group,shards", [("3", "1", "1", 1), ("4", "2", "2", 1), ("5", "1", "3", 1),
                                                        ("6", "4", "4", 1), ("4", "1", "2", 3)])
 def test_pinned_rings_wrap(slots, chunk, group, shards, monkeypatch):
