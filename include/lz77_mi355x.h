@@ -110,6 +110,11 @@ typedef struct lz77x_shard {
 int lz77x_shard_plan(size_t n, int sb, int la, int shards, lz77x_shard *out);       /* -> shards used, or < 0 */
 void lz77x_shard_compose_cells(const uint16_t *dest, const uint32_t *loc, int sb, uint32_t *cells);
 void lz77x_shard_compose_chain(const uint8_t *exit_of, const uint32_t *tokens_of, uint32_t *entry, uint64_t *tokens);
+/* decode side (lz77.c:172-192 across the cuts): first token of shard d of `shards` over a stream of ntok tokens (a
+ * multiple of eight: every shard starts on a byte of the stream), and one shard's map applied to the sb bytes before
+ * it: map[i] = a byte value, or 0x8000 | index into `incoming`; outgoing = the last sb bytes of the shard's output */
+uint64_t lz77x_shard_token_cut(uint64_t ntok, int shards, int d);
+void lz77x_shard_compose_tail(const uint16_t *map, int sb, const uint8_t *incoming, uint8_t *outgoing);
 
 /* ---- several files at once (each on a context of its own, up to LZ77X_MAX_CONTEXTS at a time) -------
  * rc[i] receives the status of file i; returns 0 when all succeeded, else the first failure. */

@@ -946,6 +946,8 @@ int decode_core(Ctx &c, size_t zn, hipStream_t s, bool want_data, size_t *n_out)
 }
 
 int fetch_result(Ctx &c, uint8_t *dst, const void *d_src, size_t bytes);
+extern "C" uint64_t lz77x_shard_token_cut(uint64_t ntok, int shards, int d);
+extern "C" void lz77x_shard_compose_tail(const uint16_t *map, int sb, const uint8_t *incoming, uint8_t *outgoing);
 
 /* ONE stream decoded on SEVERAL devices: the tokens are cut into D contiguous ranges at multiples of
  * eight tokens (every range then starts on a byte of the stream); device d parses and scans its range and walks
@@ -974,7 +976,7 @@ int decode_sharded(std::vector<Ctx *> &cs, const uint8_t *z, size_t zn, uint8_t 
     if (!lz77k_dec_seg_supported(g) || getenv("LZ77X_DECODE_VARIANT") || getenv("LZ77X_DECODE_V1") || ntok < 64 * D) return LZ77X_OK;
     const size_t usb = (size_t)sb;
     std::vector<uint32_t> k0(D + 1);
-    for (size_t d = 0; d <= D; d++) k0[d] = d == D ? ntok : (uint32_t)((uint64_t)ntok * d / D) & ~7u;
+    for (size_t d = 0; d <= D; d++) k0[d] = (uint32_t)lz77x_shard_token_cut(ntok, (int)D, (int)d);
     struct Sh { uint32_t ntok = 0, n = 0; lz77k_dec_seg_state P; const uint16_t *d_smap = nullptr; };
     std::vector<Sh> sh(D);
     /* 1. every shard: its bytes of the stream behind a header of its own, parse, scan */
@@ -1040,12 +1042,7 @@ int decode_sharded(std::vector<Ctx *> &cs, const uint8_t *z, size_t zn, uint8_t 
         Ctx &c = *cs[d];
         HIPCHK(hipSetDevice(c.device));
         HIPCHK(hipStreamSynchronize(c.stream));
-        const std::vector<uint8_t> &in_d = incoming[d];
-        std::vector<uint8_t> &out_d = incoming[d + 1];
-        for (size_t i = 0; i < usb; i++) {
-            const uint16_t x = smap[d][i];
-            out_d[i] = (x & 0xC000u) == 0x8000u ? in_d[x & 0x3FFFu] : (uint8_t)x;
-        }
+        lz77x_shard_compose_tail(smap[d].data(), sb, incoming[d].data(), incoming[d + 1].data());
     }
     /* 4. every shard: incoming bytes in, tails resolved, flagged bytes patched, output to the host */
     uint8_t *buf = (uint8_t *)malloc(n ? (size_t)n : 1);
@@ -1827,6 +1824,23 @@ void lz77x_shard_compose_chain(const uint8_t *exit_of, const uint32_t *tokens_of
 {
     *tokens += tokens_of[*entry];
     *entry = exit_of[*entry];
+}
+
+/* host-only, decode: where shard d's tokens begin */
+uint64_t lz77x_shard_token_cut(uint64_t ntok, int shards, int d)
+{
+    if (shards < 1 || d <= 0) return 0;
+    if (d >= shards) return ntok;
+    return (ntok * (uint64_t)d / (uint64_t)shards) & ~(uint64_t)7;
+}
+
+/* host-only, decode: one shard's map (the composition of its segments' tails) applied to the sb bytes before it */
+void lz77x_shard_compose_tail(const uint16_t *map, int sb, const uint8_t *incoming, uint8_t *outgoing)
+{
+    for (int i = 0; i < sb; i++) {
+        const uint16_t x = map[i];
+        outgoing[i] = (x & 0xC000u) == 0x8000u ? incoming[x & 0x3FFFu] : (uint8_t)x;
+    }
 }
 
 }  // extern "C"

@@ -89,6 +89,24 @@ def compose_chain(exit_of, tokens_of, entry: int, tokens: int):
     return int(e.value), int(t.value)
 
 
+def token_cut(ntok: int, shards: int, d: int) -> int:
+    """decode side: first token of shard d (a multiple of eight tokens: a byte boundary of the stream)"""
+    from . import lib
+    return int(lib().lz77x_shard_token_cut(int(ntok), int(shards), int(d)))
+
+
+def compose_tail(smap, incoming):
+    """decode side: one shard's map (sb 16-bit states: a byte, or 0x8000 | index into the incoming bytes) applied
+    to the sb bytes before the shard -> the last sb bytes of its output (what the next shard starts from)"""
+    import numpy as np
+    from . import lib
+    m = np.ascontiguousarray(smap, dtype=np.uint16)
+    i = np.ascontiguousarray(incoming, dtype=np.uint8)
+    o = np.empty(m.size, dtype=np.uint8)
+    lib().lz77x_shard_compose_tail(m.ctypes.data, int(m.size), i.ctypes.data, o.ctypes.data)
+    return o
+
+
 def aggregate_time(dt: float, dist=None) -> float:
     """MAX over ranks of a wall time (the bench contract); identity without a process group."""
     if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:

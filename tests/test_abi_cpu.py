@@ -248,6 +248,36 @@ for d in range(world):
     shard.compose_cells(dests[d].astype(np.uint16), locs[d].astype(np.uint32), cells)
     entry, ntok = shard.compose_chain(exits[d].astype(np.uint8), counts[d].astype(np.uint32), entry, ntok)
 assert ntok == chain.size and entry == 0
+# ---- decode side: the stream cut by token ranges; every rank decodes ITS range with the sb bytes before it as
+#      symbols (256 + i = "byte i of what lies before me"), its map = the last sb states; the maps are all-gathered
+#      and the library chains them: each rank's incoming bytes must be the true sb bytes before its output ----
+z = O.encode_bst(data, sb, la)
+_sb, _la, toff, tlen, tnext = O.tokens(z)
+ntok_all = len(toff)
+k0, k1 = shard.token_cut(ntok_all, world, rank), shard.token_cut(ntok_all, world, rank + 1)
+assert k0 %% 8 == 0 and (rank + 1 < world or k1 == ntok_all)
+hist = list(range(256, 256 + sb))                # the sb states before my first output byte
+outv = []
+for k in range(k0, k1):
+    for i in range(int(tlen[k])):
+        src = len(outv) - int(toff[k])
+        outv.append(outv[src] if src >= 0 else hist[sb + src])
+    outv.append(int(tnext[k]) & 0xFF)
+lastsb = (hist + outv)[-sb:]
+mymap = np.array([0x8000 | (v - 256) if v >= 256 else v for v in lastsb], dtype=np.uint16)
+maps = gather(torch.from_numpy(mymap.astype(np.int32)))
+lens = gather(torch.tensor([len(outv)], dtype=torch.int64))
+incoming = np.zeros(sb, dtype=np.uint8)
+start = 0
+for d in range(world):
+    if d == rank:
+        truth = np.concatenate((np.zeros(sb, dtype=np.uint8), data))[start:start + sb]      # the sb bytes before output byte `start`
+        assert np.array_equal(incoming, truth), "bytes this decode shard starts from"
+        mine_out = np.array([incoming[v - 256] if v >= 256 else v for v in outv], dtype=np.uint8)
+        assert np.array_equal(mine_out, data[start:start + len(outv)]), "this shard's bytes"
+    incoming = shard.compose_tail(maps[d].astype(np.uint16), incoming)
+    start += int(lens[d][0])
+assert start == n
 seeds = [shard.stream_seed(0x5EED0001, r) for r in range(world)]
 assert len(set(seeds)) == world
 t = shard.aggregate_time(1.0 + rank, dist)
@@ -259,8 +289,9 @@ print("rank", rank, "ok")
 
 
 def test_two_rank_shard_exchange_gloo(tmp_path):
-    """world_size 2 on CPU: the library's own shard plan and its two host-side compositions (priority cells,
-    parse chain), fed with per-rank maps exchanged over gloo, reproduce the sequential oracle at the cut"""
+    """world_size 2 on CPU: the library's own shard plan and its host-side compositions (priority cells, parse
+    chain; decode: token cuts and the sb-byte tail map), fed with per-rank maps exchanged over gloo, reproduce the
+    sequential oracle at the cut"""
     script = tmp_path / "w.py"
     script.write_text(_WORKER % {"root": ROOT})
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", LZ77X_NO_TORCH="1")
