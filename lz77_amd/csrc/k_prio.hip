@@ -127,7 +127,6 @@ __global__ __launch_bounds__(64) void k_prio_fwd(const uint32_t *__restrict__ ps
     const uint32_t x0 = b * B;
     const uint32_t x1 = nx - x0 < B ? nx : x0 + B;
     for (uint32_t r = lane; r < ring_n; r += 64) ring[r] = r < sb ? in[(size_t)b * sb + r] : x0 + r + voff;
-    uint64_t *gl = reinterpret_cast<uint64_t *>(ring + ring_n);      /* the block's new gates: B/64 words (ring_n is even) */
     wave_sync();
 
     uint32_t off = 0;                                  /* ring slot of cell xg */
@@ -195,14 +194,15 @@ __global__ __launch_bounds__(64) void k_prio_fwd(const uint32_t *__restrict__ ps
                 wave_sync();
             }
         }
-        if (lane < PRIO_SG) gl[((xs - x0) >> 6) + lane] = gn_l;
+        /* the super-group's new gates straight to HBM (eight consecutive words): kept in LDS until the end of the block
+         * they cost 8 KB of a wavefront's 25 KB and with them a third of the sweeps in flight on large inputs */
+        if (lane < PRIO_SG && xs + 64u * lane < x1) gnew[(xs >> 6) + lane] = gn_l;
 #pragma unroll
         for (uint32_t k = 0; k < PRIO_SG; k++) v[k] = vn[k];
         rm_l = rm_n;
         go_l = go_n;
     }
     wave_sync();
-    for (uint32_t i = lane; i < (x1 - x0 + 63u) / 64u; i += 64) gnew[(x0 >> 6) + i] = gl[i];
     if (out_state && x1 == nx) {
         /* cells nx .. nx+sb-1, what the next segment of a long input starts from: the ring now holds exactly
          * the cells [x1, x1 + ring_n) */
@@ -575,7 +575,7 @@ hipError_t lz77k_prio_maps(lz77k_prio_plan &P, hipStream_t s, bool whole, const 
 hipError_t lz77k_prio_sweep(lz77k_prio_plan &P, hipStream_t s, uint32_t *h_flag, uint32_t *d_out_state, hipEvent_t *ev3)
 {
     if (P.nx == 0) { h_flag[0] = 0; h_flag[1] = PRIO_NONE; return hipSuccess; }
-    const size_t lds_fwd = (size_t)P.ring_n * 4 + (size_t)(P.B / 64u) * 8;
+    const size_t lds_fwd = (size_t)P.ring_n * 4;
     const size_t lds_scan = (size_t)P.sb_r * (4 + 4 + 2 + 2);
     uint16_t *dest = PRIO_PTR(uint16_t, P.o_dest), *gdest = PRIO_PTR(uint16_t, P.o_gdest);
     uint32_t *loc = PRIO_PTR(uint32_t, P.o_loc), *gloc = PRIO_PTR(uint32_t, P.o_gloc);
