@@ -118,7 +118,9 @@ __global__ __launch_bounds__(64) void k_prio_fwd(const uint32_t *__restrict__ ps
                                                  const uint32_t *__restrict__ in, uint32_t *__restrict__ xval,
                                                  uint32_t *__restrict__ summary /* [0] += flips, [1] = min block with a flip */,
                                                  uint32_t voff /* a cell's own priority is its position + voff */,
-                                                 uint32_t *__restrict__ out_state /* last block: the sb cells left live after the last step */)
+                                                 uint32_t *__restrict__ out_state /* last block: the sb cells left live after the last step */,
+                                                 uint32_t *__restrict__ gates_changed /* [b] = this sweep flipped a gate of block b */,
+                                                 const uint32_t *__restrict__ in_changed /* [b] = 0: the block's entry cells are those of its last sweep */)
 {
     extern __shared__ uint32_t ring[];
     __builtin_amdgcn_s_setprio(3);      /* a chain of dependent instructions: issue ahead of any co-resident throughput kernel */
@@ -126,6 +128,14 @@ __global__ __launch_bounds__(64) void k_prio_fwd(const uint32_t *__restrict__ ps
     const uint32_t b = b_first + blockIdx.x;
     const uint32_t x0 = b * B;
     const uint32_t x1 = nx - x0 < B ? nx : x0 + B;
+    if (in_changed && !in_changed[b] && !(out_state && x1 == nx)) {
+        /* the sweep is a function of the entry cells alone: the same cells as last time give the same xval[] and the
+         * gates the maps of this iteration were built from -- no flip.  (On inputs of many rounds of blocks the tail
+         * iterations touch a few per cent of them.) */
+        for (uint32_t i = lane; i < (x1 - x0 + 63u) / 64u; i += 64) gnew[(x0 >> 6) + i] = gold[(x0 >> 6) + i];
+        if (lane == 0) gates_changed[b] = 0;
+        return;
+    }
     for (uint32_t r = lane; r < ring_n; r += 64) ring[r] = r < sb ? in[(size_t)b * sb + r] : x0 + r + voff;
     wave_sync();
 
@@ -212,6 +222,7 @@ __global__ __launch_bounds__(64) void k_prio_fwd(const uint32_t *__restrict__ ps
         atomicAdd(&summary[0], nflip);
         atomicMin(&summary[1], b);
     }
+    if (lane == 0 && gates_changed) gates_changed[b] = nflip ? 1u : 0u;
 }
 
 /* ------------------------------------------------------------------ backward sweep --- */
@@ -222,9 +233,11 @@ __global__ __launch_bounds__(64) void k_prio_fwd(const uint32_t *__restrict__ ps
 __global__ __launch_bounds__(64) void k_prio_back(const uint32_t *__restrict__ ps, uint32_t nx, uint32_t sb, uint32_t B,
                                                   uint32_t ring_n, uint32_t b_first, const uint64_t *__restrict__ gates,
                                                   uint16_t *__restrict__ dest, uint32_t *__restrict__ loc, uint32_t voff,
-                                                  uint32_t ncarried /* cells < ncarried hold carried values, not their own position */)
+                                                  uint32_t ncarried /* cells < ncarried hold carried values, not their own position */,
+                                                  const uint32_t *__restrict__ gates_changed /* [b] = 0: the block's map of the last iteration still holds */)
 {
     extern __shared__ uint32_t back_lds[];
+    if (gates_changed && !gates_changed[b_first + blockIdx.x]) return;
     __builtin_amdgcn_s_setprio(3);      /* a chain of dependent instructions: issue ahead of any co-resident throughput kernel */
     uint32_t *lloc = back_lds;                                         /* sb_r words */
     uint16_t *dr = reinterpret_cast<uint16_t *>(back_lds + (ring_n - 64u));   /* ring_n entries */
@@ -405,10 +418,13 @@ __global__ __launch_bounds__(PRIO_SCAN_BLOCK) void k_prio_scan_compose(const uin
 /* replay `count` maps starting at map index m0 (rows of dest/loc start at row0) from the input vector
  * vin; out[m+1-th row] receives the vector after map m.  Used twice: over the group maps (one
  * workgroup) and inside every group (one workgroup per group). */
+template <bool TRACK>      /* TRACK: compare what is written to vout with what was there (a load per value: not for free) */
 __global__ __launch_bounds__(PRIO_SCAN_BLOCK) void k_prio_scan_replay(const uint16_t *__restrict__ dest, const uint32_t *__restrict__ loc,
                                                                       uint32_t sb, uint32_t sb_r, size_t row0, uint32_t nmaps, uint32_t G,
                                                                       const uint32_t *__restrict__ vin, size_t vin_stride,
-                                                                      uint32_t *__restrict__ vout, size_t vout_row0, uint32_t store_first)
+                                                                      uint32_t *__restrict__ vout, size_t vout_row0, uint32_t store_first,
+                                                                      uint32_t *__restrict__ changed /* [row] = 1 when a value written to that row of vout
+                                                                                                        differs from what was there (null: not tracked) */)
 {
     extern __shared__ uint32_t scan_lds[];
     __builtin_amdgcn_s_setprio(3);
@@ -435,7 +451,14 @@ __global__ __launch_bounds__(PRIO_SCAN_BLOCK) void k_prio_scan_replay(const uint
                 scan_fetch(rr[u], dest, loc, row0 + min(m + SCAN_AHEAD, m1 - 1u), sb);
                 scan_apply(cur, scan_lds, w ? sb_r : 0u, w ? 0u : sb_r, sb);
                 w ^= 1;
-                for (uint32_t i = threadIdx.x; i < sb; i += PRIO_SCAN_BLOCK) vout[(vout_row0 + m + 1) * sb + i] = scan_lds[(w ? sb_r : 0u) + i];
+                bool diff = false;
+                for (uint32_t i = threadIdx.x; i < sb; i += PRIO_SCAN_BLOCK) {
+                    const uint32_t val = scan_lds[(w ? sb_r : 0u) + i];
+                    uint32_t *q = vout + (vout_row0 + m + 1) * sb + i;
+                    if constexpr (TRACK) diff |= *q != val;
+                    *q = val;
+                }
+                if constexpr (TRACK) { if (diff) changed[vout_row0 + m + 1] = 1u; }
             }
         }
     }
@@ -495,6 +518,7 @@ static void prio_layout(lz77k_prio_plan &P)
     P.o_gloc = take(((size_t)P.NG + 2) * sb * 4);
     P.o_gin = take(((size_t)P.NG + 2) * sb * 4);
     P.o_sum = take(256);
+    P.o_dirty = take(((size_t)P.NB + 2) * 2 * 4);            /* per block: [0, NB+2) its gates changed in the last sweep, then its entry cells changed in the last scan */
     P.total = o;
 }
 
@@ -535,7 +559,10 @@ hipError_t lz77k_prio_begin(lz77k_prio_plan &P, const uint32_t *d_ps, uint32_t n
     const uint32_t blocks = min((P.ngroups + 3u) / 4u, 256u * 8u);
     hipLaunchKernelGGL(k_prio_prep, dim3(blocks), dim3(256), lds, s, d_ps, nx, tagn, PRIO_PTR(uint64_t, P.o_rmask), PRIO_PTR(uint64_t, P.o_gate[0]));
     hipLaunchKernelGGL(k_prio_in0, dim3((P.sb + 255u) / 256u), dim3(256), 0, s, PRIO_PTR(uint32_t, P.o_in), P.sb, voff, d_carried);
-    return hipGetLastError();
+    /* every block's map has to be built and every block swept once */
+    P.in0_dirty = false;
+    P.sweeps = 0;
+    return hipMemsetAsync(PRIO_PTR(uint8_t, P.o_dirty), 1, ((size_t)P.NB + 2) * 2 * 4, s);
 }
 
 /* the cells block 0 starts from, when they only become known later (a shard: they follow from the maps of
@@ -543,6 +570,7 @@ hipError_t lz77k_prio_begin(lz77k_prio_plan &P, const uint32_t *d_ps, uint32_t n
 hipError_t lz77k_prio_set_in0(lz77k_prio_plan &P, const uint32_t *h_or_d_in0, hipMemcpyKind kind, hipStream_t s)
 {
     if (P.nx == 0) return hipSuccess;
+    P.in0_dirty = true;
     return hipMemcpyAsync(PRIO_PTR(uint32_t, P.o_in), h_or_d_in0, (size_t)P.sb * 4, kind, s);
 }
 
@@ -557,7 +585,7 @@ hipError_t lz77k_prio_maps(lz77k_prio_plan &P, hipStream_t s, bool whole, const 
     uint32_t *loc = PRIO_PTR(uint32_t, P.o_loc), *gloc = PRIO_PTR(uint32_t, P.o_gloc);
     const uint32_t nb = P.NB - P.first;
     hipLaunchKernelGGL(k_prio_back, dim3(nb), dim3(64), lds_back, s, P.ps, P.nx, P.sb, P.B, P.ring_n, P.first, PRIO_PTR(uint64_t, P.o_gate[P.cur]),
-                       dest, loc, P.voff, P.ncarried);
+                       dest, loc, P.voff, P.ncarried, PRIO_PTR(uint32_t, P.o_dirty));
     if (whole) {
         /* every block 0 .. NB-1 (the maps of the blocks before P.first are still there and final), in groups,
          * then the groups */
@@ -584,6 +612,24 @@ hipError_t lz77k_prio_sweep(lz77k_prio_plan &P, hipStream_t s, uint32_t *h_flag,
     hipError_t e;
     hipLaunchKernelGGL(k_prio_reset, dim3(1), dim3(1), 0, s, summary);
     if (ev3 && (e = hipEventRecord(ev3[0], s)) != hipSuccess) return e;
+    /* which blocks' entry cells does this scan change?  A block whose cells stay what its last sweep started from is not
+     * swept again (k_prio_fwd), one whose gates that sweep did not flip keeps its map (k_prio_back).  Nothing on S1 (one
+     * round of blocks: a sweep is one wavefront's latency whatever their number); on 1 GiB the tail iterations touch a
+     * few per cent of the 16 K blocks. */
+    uint32_t *gates_changed = PRIO_PTR(uint32_t, P.o_dirty), *in_changed = gates_changed + P.NB + 2;
+    /* only where it pays: with at most one round of blocks in flight (9 wavefronts per CU) a sweep is one wavefront's
+     * latency whatever the number of blocks, and comparing the rows costs the scans 0.4 ms per 100 MB */
+    const char *sk = getenv("LZ77X_PRIO_SKIP");
+    const bool track = P.sweeps > 0 && (sk ? atoi(sk) != 0 : P.NB > 2304u);
+    if (track) {
+        if ((e = hipMemsetAsync(in_changed + first, 0, (size_t)nb * 4, s)) != hipSuccess) return e;
+        if (P.in0_dirty && first == 0 && (e = hipMemsetAsync(in_changed, 1, 4, s)) != hipSuccess) return e;
+    } else if (P.sweeps > 0) {
+        if ((e = hipMemsetAsync(gates_changed, 1, ((size_t)P.NB + 2) * 2 * 4, s)) != hipSuccess) return e;
+    }
+    P.in0_dirty = false;
+    P.sweeps++;
+    uint32_t *changed = track ? in_changed : nullptr;
     if (nb > 1) {
         /* maps first .. NB-2 */
         const uint32_t nmaps = nb - 1, G = P.G;
@@ -591,18 +637,27 @@ hipError_t lz77k_prio_sweep(lz77k_prio_plan &P, hipStream_t s, uint32_t *h_flag,
         if (NG > 1) {
             hipLaunchKernelGGL(k_prio_scan_compose, dim3(NG), dim3(PRIO_SCAN_BLOCK), lds_scan, s, dest, loc, sb, P.sb_r, first, nmaps, G, gdest, gloc);
             /* gin[g] = input of group g: replay the group maps from in[first] */
-            hipLaunchKernelGGL(k_prio_scan_replay, dim3(1), dim3(PRIO_SCAN_BLOCK), lds_scan, s, gdest, gloc, sb, P.sb_r, (size_t)0, NG - 1u, NG,
-                               in + (size_t)first * sb, (size_t)0, gin, (size_t)0, 1u);
-            hipLaunchKernelGGL(k_prio_scan_replay, dim3(NG), dim3(PRIO_SCAN_BLOCK), lds_scan, s, dest, loc, sb, P.sb_r, (size_t)first, nmaps, G, gin,
-                               (size_t)sb, in, (size_t)first, 0u);
+            hipLaunchKernelGGL(k_prio_scan_replay<false>, dim3(1), dim3(PRIO_SCAN_BLOCK), lds_scan, s, gdest, gloc, sb, P.sb_r, (size_t)0, NG - 1u, NG,
+                               in + (size_t)first * sb, (size_t)0, gin, (size_t)0, 1u, (uint32_t *)nullptr);
+            if (changed)
+                hipLaunchKernelGGL(k_prio_scan_replay<true>, dim3(NG), dim3(PRIO_SCAN_BLOCK), lds_scan, s, dest, loc, sb, P.sb_r, (size_t)first, nmaps, G, gin,
+                                   (size_t)sb, in, (size_t)first, 0u, changed);
+            else
+                hipLaunchKernelGGL(k_prio_scan_replay<false>, dim3(NG), dim3(PRIO_SCAN_BLOCK), lds_scan, s, dest, loc, sb, P.sb_r, (size_t)first, nmaps, G, gin,
+                                   (size_t)sb, in, (size_t)first, 0u, changed);
         } else {
-            hipLaunchKernelGGL(k_prio_scan_replay, dim3(1), dim3(PRIO_SCAN_BLOCK), lds_scan, s, dest, loc, sb, P.sb_r, (size_t)first, nmaps, nmaps,
-                               in + (size_t)first * sb, (size_t)0, in, (size_t)first, 0u);
+            if (changed)
+                hipLaunchKernelGGL(k_prio_scan_replay<true>, dim3(1), dim3(PRIO_SCAN_BLOCK), lds_scan, s, dest, loc, sb, P.sb_r, (size_t)first, nmaps, nmaps,
+                                   in + (size_t)first * sb, (size_t)0, in, (size_t)first, 0u, changed);
+            else
+                hipLaunchKernelGGL(k_prio_scan_replay<false>, dim3(1), dim3(PRIO_SCAN_BLOCK), lds_scan, s, dest, loc, sb, P.sb_r, (size_t)first, nmaps, nmaps,
+                                   in + (size_t)first * sb, (size_t)0, in, (size_t)first, 0u, changed);
         }
     }
     if (ev3 && (e = hipEventRecord(ev3[1], s)) != hipSuccess) return e;
     hipLaunchKernelGGL(k_prio_fwd<true>, dim3(nb), dim3(64), lds_fwd, s, P.ps, P.nx, sb, P.B, P.ring_n, first, PRIO_PTR(uint64_t, P.o_rmask),
-                       PRIO_PTR(uint64_t, P.o_gate[P.cur]), PRIO_PTR(uint64_t, P.o_gate[P.cur ^ 1]), in, P.xval, summary, P.voff, d_out_state);
+                       PRIO_PTR(uint64_t, P.o_gate[P.cur]), PRIO_PTR(uint64_t, P.o_gate[P.cur ^ 1]), in, P.xval, summary, P.voff, d_out_state,
+                       gates_changed, (const uint32_t *)in_changed);
     if (ev3 && (e = hipEventRecord(ev3[2], s)) != hipSuccess) return e;
     return hipMemcpyAsync(h_flag, summary, 8, hipMemcpyDeviceToHost, s);
 }

@@ -132,8 +132,10 @@ struct lz77k_prio_plan {
     void *tmp = nullptr;
     uint32_t nx = 0, sb = 0, voff = 0, ncarried = 0;
     uint32_t B = 0, NB = 0, ngroups = 0, sb_r = 0, ring_n = 0, G = 0, NG = 0;
-    size_t o_gate[2] = {0, 0}, o_rmask = 0, o_dest = 0, o_loc = 0, o_in = 0, o_gdest = 0, o_gloc = 0, o_gin = 0, o_sum = 0, total = 0;
+    size_t o_gate[2] = {0, 0}, o_rmask = 0, o_dest = 0, o_loc = 0, o_in = 0, o_gdest = 0, o_gloc = 0, o_gin = 0, o_sum = 0, o_dirty = 0, total = 0;
     int cur = 0;              /* gate buffer the next maps/sweep read */
+    uint32_t sweeps = 0;      /* sweeps so far (the first one visits every block) */
+    bool in0_dirty = false;   /* the cells block 0 starts from were replaced (lz77k_prio_set_in0) since its last sweep */
     uint32_t first = 0;       /* blocks before it are final */
 };
 hipError_t lz77k_prio_begin(lz77k_prio_plan &P, const uint32_t *d_ps, uint32_t nx, int sb, uint32_t *d_xval, void *d_tmp, uint32_t voff,

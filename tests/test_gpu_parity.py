@@ -256,6 +256,25 @@ def test_sharded_decode_falls_back(monkeypatch):
         L.lib().lz77x_set_shards(1)
 
 
+@pytest.mark.parametrize("kind,seed,n", [("text", 98, 2_500_000), ("lowent", 99, 1_500_000), ("records", 100, 2_000_000)])
+def test_recurrence_skips_unchanged_blocks(kind, seed, n, monkeypatch):
+    """gate iteration with per-block change tracking (what inputs of many rounds of blocks use): a block whose entry
+    cells are those of its last sweep is not swept again, one whose gates that sweep did not flip keeps its map --
+    small blocks so that there are hundreds of them; one device, then three shards iterating jointly (the cells a
+    shard starts from are replaced every iteration)"""
+    data = synth.make(kind, n, seed)
+    want = O.encode_bst(data)
+    monkeypatch.setenv("LZ77X_PRIO_SKIP", "1")
+    monkeypatch.setenv("LZ77X_PRIO_BLOCK", "8192")
+    assert L.encode(data) == want
+    monkeypatch.setenv("LZ77X_FAKE_DEVICES", "4")
+    try:
+        assert L.lib().lz77x_set_shards(3) == 0
+        assert L.encode(data) == want
+    finally:
+        L.lib().lz77x_set_shards(1)
+
+
 @pytest.mark.parametrize("slots,chunk,group,shards", [("3", "1", "1", 1), ("4", "2", "2", 1), ("5", "1", "3", 1),
                                                        ("6", "4", "4", 1), ("4", "1", "2", 3)])
 def test_pinned_rings_wrap(slots, chunk, group, shards, monkeypatch):
@@ -332,7 +351,8 @@ def test_segments_give_identical_bytes(kind, seed, n, sb, la, seg, monkeypatch):
 
 @pytest.mark.parametrize("env", [{"LZ77X_MATCH_VARIANT": "1"}, {"LZ77X_MATCH_VARIANT": "3"}, {"LZ77X_SORT_VARIANT": "1"},
                                  {"LZ77X_SORT_VARIANT": "2"}, {"LZ77X_TOKEN_VARIANT": "1"}, {"LZ77X_TOKEN_VARIANT": "2"}, {"LZ77X_WALK_RUN": "256"}, {"LZ77X_WALK_RUN": "1000"},
-                                 {"LZ77X_WALK_RUN": "4096"}, {"LZ77X_C1_SORT_V1": "1"}, {"LZ77X_MATCH_BATCH": "7"}])
+                                 {"LZ77X_WALK_RUN": "4096"}, {"LZ77X_C1_SORT_V1": "1"}, {"LZ77X_MATCH_BATCH": "7"}, {"LZ77X_PRIO_SKIP": "1"},
+                                 {"LZ77X_PRIO_SKIP": "1", "LZ77X_PRIO_BLOCK": "16384"}, {"LZ77X_PRIO_SKIP": "0", "LZ77X_PRIO_BLOCK": "16384"}])
 def test_kernel_variants_agree(env, monkeypatch):
     """independent formulations of the same stage (exhaustive pair scan vs bitmap walkers, merge sort vs
     plain / blocked bitonic sort, three token kernels) all reproduce the reference stream"""
