@@ -10,6 +10,13 @@
 
 #define MATCH_BLOCK 1024
 
+/* workgroup barrier that orders LDS traffic only: global stores and loads in flight stay in flight (__syncthreads()
+ * drains them: its fence waits for vmcnt(0)) */
+__device__ __forceinline__ void lds_barrier()
+{
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
 typedef unsigned short us2 __attribute__((ext_vector_type(2)));
 
 /*
@@ -715,7 +722,9 @@ __global__ __launch_bounds__(MATCH_BLOCK, (FAST && MODE == 3) ? 8 : 1) void k_ma
          * THEMSELVES ("sub-ranks": a prefix count over the sorted order) and the inverse: its bitmap
          * shrinks from RP bits to walk_run+SBu bits (three wavefronts of walkers per CU instead of
          * one) and is two-thirds full, so it needs no summary level.  Staged in the LDS the key bytes
-         * occupied, copied out 16 bytes at a time. */
+         * occupied, copied out 16 bytes at a time.  The barriers order LDS traffic only (lds_barrier): a
+         * __syncthreads() would also wait for the previous run's 24 KB of global stores to complete, 18 times
+         * per region. */
         __shared__ uint32_t wsum[MATCH_BLOCK / 64];
         const uint32_t K = RP / MATCH_BLOCK;                 /* sorted slots per thread: 4, 8 or 16 */
         const uint32_t lane = tid & 63, wave = tid >> 6;
@@ -733,7 +742,7 @@ __global__ __launch_bounds__(MATCH_BLOCK, (FAST && MODE == 3) ? 8 : 1) void k_ma
             for (uint32_t e = tid * 8; e < RP; e += MATCH_BLOCK * 8)
                 *reinterpret_cast<uint4 *>(go + e) = *reinterpret_cast<const uint4 *>(reinterpret_cast<const uint16_t *>(ix) + e);
         }
-        __syncthreads();                                     /* the sort's last readers of the byte area are done */
+        lds_barrier();                                       /* the sort's last readers of the byte area are done */
         for (uint32_t j = 0; j < NR; j++) {
             const uint32_t lo = j * walk_run;
             if (lo >= steps) break;
@@ -748,7 +757,7 @@ __global__ __launch_bounds__(MATCH_BLOCK, (FAST && MODE == 3) ? 8 : 1) void k_ma
                 if (lane >= (uint32_t)d) incl += t;
             }
             if (lane == 63) wsum[wave] = incl;
-            __syncthreads();
+            lds_barrier();
             uint32_t run = incl - cnt;
             for (uint32_t w = 0; w < wave; w++) run += wsum[w];
 #pragma unroll
@@ -756,11 +765,11 @@ __global__ __launch_bounds__(MATCH_BLOCK, (FAST && MODE == 3) ? 8 : 1) void k_ma
                 const uint32_t i = mine[q] - lo;
                 if (i < span) { st_rk[i] = (uint16_t)run; st_ix[run] = (uint16_t)i; run++; }
             }
-            __syncthreads();
+            lds_barrier();
             uint16_t *g = gout + (size_t)j * 2 * SUB;
             for (uint32_t e = tid * 8; e < 2 * SUB; e += MATCH_BLOCK * 8)
                 *reinterpret_cast<uint4 *>(g + e) = *reinterpret_cast<const uint4 *>(st_rk + e);
-            __syncthreads();
+            lds_barrier();
         }
         return;
     }
