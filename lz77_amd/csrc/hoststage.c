@@ -42,6 +42,11 @@ void lz77x_make_geom(lz77x_geom *g, int sb, int la)
     while (rp < 4u * g->SBu) rp <<= 1;
     g->RP = rp;
     g->TILE = rp - g->SBu;
+    /* large windows (sb > 32768): tiles of whole 64 K blocks (three of the region's four), so that the regions are
+     * unions of globally aligned blocks and share one hierarchical sort (k_big_*): up to 13 % more regions against
+     * half the sort.  (At RP 131072 the tile would shrink from ~100 K to 64 K: measured at sb 32768, the walkers
+     * lose more, 24 -> 35 ms per 100 MB, than the sort gains, 33 -> 28.) */
+    if (rp >= 262144u) g->TILE = (rp - g->SBu) / 65536u * 65536u;
     g->shifted = 1;
     g->fast = rp <= 16384u;
 }

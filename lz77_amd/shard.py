@@ -30,8 +30,11 @@ def geometry(sb: int, la: int) -> dict:
     rp = 4096
     while rp < 4 * sbu:
         rp <<= 1
+    tile = rp - sbu
+    if rp >= 262144:                     # large windows: tiles of whole 64 K blocks (shared hierarchical sort)
+        tile = tile // 65536 * 65536
     return {"sb": sb, "la": la, "ob": bitof(sb), "lb": bitof(la), "T": bitof(sb) + bitof(la) + 8,
-            "SBu": sbu, "RP": rp, "TILE": rp - sbu, "fast": rp <= 16384}
+            "SBu": sbu, "RP": rp, "TILE": tile, "fast": rp <= 16384}
 
 
 def stream_seed(base_seed: int, rank: int) -> int:

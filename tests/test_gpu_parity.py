@@ -377,9 +377,10 @@ def test_large_window_sort_variants_agree(sortv, sb, la, monkeypatch):
 @pytest.mark.parametrize("env", [{}, {"LZ77X_BIG_SORT_V1": "1"}, {"LZ77X_WALK_BIG_V1": "1"}, {"LZ77X_WALK_RUN_WAVE": "1024"},
                                  {"LZ77X_WALK_RUN_WAVE": "65536"}, {"LZ77X_CHUNK_REGIONS": "1"}, {"LZ77X_CHUNK_REGIONS": "3"}])
 @pytest.mark.parametrize("sb,la,kind,n", [(65535, 255, "mixed", 1_300_000), (65530, 100, "text", 900_000), (65535, 16, "lowent", 700_000),
-                                          (65535, 255, "records", 600_000)])
+                                          (65535, 255, "records", 600_000), (20000, 40, "mixed", 800_000), (32768, 255, "text", 700_000),
+                                          (16385, 15, "lowent", 500_000), (49999, 200, "mixed", 900_000)])
 def test_large_window_shared_sort_and_wave_walkers(env, sb, la, kind, n, monkeypatch):
-    """large windows whose tile is a multiple of 64 K positions (sb 65529..65535): the hierarchical sort shared by the
+    """large windows (sb > 32768: tiles of whole 64 K blocks; the smaller ones keep the per-region kernel): the hierarchical sort shared by the
     overlapping regions (16 K chunks in LDS once, grid-wide merge levels; a region's order then also holds the
     positions past its own TILE + sb) and the wavefront-per-run walkers with the rank bitmap in LDS, against the
     per-region sort kernel / the per-lane global-bitmap walkers, for several launch shapes (one region per launch:
