@@ -730,8 +730,8 @@ __global__ __launch_bounds__(MATCH_BLOCK, (FAST && MODE == 3) ? 8 : 1) void k_ma
         const uint32_t lane = tid & 63, wave = tid >> 6;
         const uint32_t steps = n - t0 < TILE ? n - t0 : TILE;
         const uint32_t NR = (TILE + walk_run - 1) / walk_run, SUB = walk_run + SBu;
-        uint16_t *st_rk = reinterpret_cast<uint16_t *>(rk), *st_ix = st_rk + SUB;      /* 2*SUB <= RP */
-        uint16_t *gout = reinterpret_cast<uint16_t *>(scratch) + (size_t)blockIdx.x * NR * 2 * SUB;
+        uint16_t *st_rk = reinterpret_cast<uint16_t *>(rk);                              /* SUB <= RP */
+        uint16_t *gout = reinterpret_cast<uint16_t *>(scratch) + (size_t)blockIdx.x * NR * SUB;
         uint32_t mine[16];
 #pragma unroll
         for (int q = 0; q < 16; q++) mine[q] = (uint32_t)q < K ? (uint32_t)ix[tid * K + q] : 0xFFFFFFFFu;
@@ -763,11 +763,11 @@ __global__ __launch_bounds__(MATCH_BLOCK, (FAST && MODE == 3) ? 8 : 1) void k_ma
 #pragma unroll
             for (int q = 0; q < 16; q++) {
                 const uint32_t i = mine[q] - lo;
-                if (i < span) { st_rk[i] = (uint16_t)run; st_ix[run] = (uint16_t)i; run++; }
+                if (i < span) { st_rk[i] = (uint16_t)run; run++; }     /* (the inverse is a scatter of this array: k_walk_final_lds) */
             }
             lds_barrier();
-            uint16_t *g = gout + (size_t)j * 2 * SUB;
-            for (uint32_t e = tid * 8; e < 2 * SUB; e += MATCH_BLOCK * 8)
+            uint16_t *g = gout + (size_t)j * SUB;
+            for (uint32_t e = tid * 8; e < SUB; e += MATCH_BLOCK * 8)
                 *reinterpret_cast<uint4 *>(g + e) = *reinterpret_cast<const uint4 *>(st_rk + e);
             lds_barrier();
         }
@@ -932,7 +932,7 @@ __global__ __launch_bounds__(64) void k_walk(const uint16_t *__restrict__ subs, 
     if (lo >= lt1) return;
     const uint32_t tb = min(run_len, lt1 - lo);                          /* steps t in [0, tb), relative to lo */
     const uint32_t R = min(SUB, Rreg - lo);                              /* sub-ranked positions [0, R) of this run */
-    const uint16_t *rk = subs + ((size_t)reg * runs_per_tile + run) * 2 * SUB;
+    const uint16_t *rk = subs + ((size_t)reg * runs_per_tile + run) * SUB;
     uint32_t *of = wf + (size_t)reg * TILE + lo, *ob = wb + (size_t)reg * TILE + lo;   /* indexed by t */
 
     for (uint32_t w = 0; w < NW; w++) bm[w * 64u + lane] = 0;
@@ -1057,7 +1057,7 @@ __global__ __launch_bounds__(64) void k_walk(const uint16_t *__restrict__ subs, 
      * the previous group's stores on every pass */
     asm volatile("" ::"v"(vq[0] ^ vq[7]), "v"(vy[0] ^ vy[7]), "v"(aq[0] ^ aq[7]), "v"(ay[0] ^ ay[7]));
     for (; t + 16 <= tb; t += 16) {
-        load16(t + 32, bq);                                  /* t + 32 + usb + 16 <= SUB + 32 < 2 * SUB */
+        load16(t + 32, bq);                                  /* t + 32 + usb + 16 <= SUB + 32: at most into the next run's array / the results behind the last one */
         load16(t + 32 + usb, by8);
 #pragma unroll
         for (int j = 0; j < 16; j++) {
@@ -1083,51 +1083,11 @@ __global__ __launch_bounds__(64) void k_walk(const uint16_t *__restrict__ subs, 
 #undef BM_WORD
 }
 
-/* sub-ranks -> positions -> the two per-position results of the match stage */
-__global__ __launch_bounds__(256) void k_walk_final(const uint8_t *__restrict__ in, uint32_t n, int sb, int la, uint32_t SBu,
-                                                    uint32_t TILE, uint32_t region0, uint32_t nregions, uint32_t run_len,
-                                                    uint32_t runs_per_tile, const uint16_t *__restrict__ subs,
-                                                    const uint32_t *__restrict__ wf, const uint32_t *__restrict__ wb,
-                                                    const uint32_t *__restrict__ wb0, uint32_t *__restrict__ ps,
-                                                    uint8_t *__restrict__ maxlen)
-{
-    const uint64_t rel = (uint64_t)blockIdx.x * 256u + threadIdx.x;      /* position relative to region0*TILE */
-    const uint32_t reg = (uint32_t)(rel / TILE);
-    if (reg >= nregions) return;
-    const uint64_t x64 = (uint64_t)region0 * TILE + rel;
-    if (x64 >= n) return;
-    const uint32_t x = (uint32_t)x64;
-    const uint32_t t0 = (region0 + reg) * TILE;
-    const uint32_t lx = x - t0;
-    const uint32_t run = lx / run_len, lo = run * run_len, SUB = run_len + SBu;
-    const uint16_t *ix = subs + ((size_t)reg * runs_per_tile + run) * 2 * SUB + SUB;    /* sub-rank -> position - lo */
-    const uint8_t *by = in + t0;
-    const uint32_t f = wf[rel];
-    uint32_t P = 0, S = 0;
-    if ((uint64_t)x + (uint32_t)sb < n) {                                /* only evicted positions matter */
-        if ((f & 0xFFFFu) != WALK_NONE) S = lo + (uint32_t)ix[f & 0xFFFFu] - lx;
-        if ((f >> 16) != WALK_NONE) P = lo + (uint32_t)ix[f >> 16] - lx;
-    }
-    ps[x] = P | (S << 16);
-    auto longest = [&](uint32_t b, uint32_t ly, const uint16_t *inv, uint32_t base) -> uint32_t {   /* max LCP with the two candidates */
-        const uint32_t left = n - (t0 + ly);
-        const int cap = (int)(left < (uint32_t)la ? left : (uint32_t)la) - 1;
-        uint32_t best = 0;
-        if ((b & 0xFFFFu) != WALK_NONE) best = (uint32_t)lcp_capped<false>(by, base + (uint32_t)inv[b & 0xFFFFu], ly, cap);
-        if ((b >> 16) != WALK_NONE) {
-            const uint32_t l2 = (uint32_t)lcp_capped<false>(by, base + (uint32_t)inv[b >> 16], ly, cap);
-            best = l2 > best ? l2 : best;
-        }
-        return best;
-    };
-    if ((uint64_t)x + (uint32_t)sb < n) maxlen[x + (uint32_t)sb] = (uint8_t)longest(wb[rel], lx + (uint32_t)sb, ix, lo);
-    if (region0 + reg == 0 && lx < (uint32_t)sb) maxlen[x] = (uint8_t)longest(wb0[lx], lx, subs + SUB, 0u);
-}
-
-/* The same per RUN with the run's inverse array and bytes staged in LDS: the four inverse look-ups and the two
- * LCPs of a position are gathers (64 lanes, 64 different lines) -- out of L1 they took 1.8 ms per 100 MB, bound by
- * the texture path; out of LDS they are bank accesses.  One workgroup per walker run; the workgroup of the input's
- * first run also answers y < sb (wb0). */
+/* sub-ranks -> positions -> the two per-position results of the match stage, per RUN with the run's inverse array
+ * (scattered from its sub-ranks) and bytes in LDS: the four inverse look-ups and the two LCPs of a position are
+ * gathers (64 lanes, 64 different lines) -- one thread per position straight out of L1 they took 1.8 ms per 100 MB,
+ * bound by the texture path (round 1); out of LDS they are bank accesses.  One workgroup per walker run; the
+ * workgroup of the input's first run also answers y < sb (wb0). */
 #define WFIN_BLOCK 256
 __global__ __launch_bounds__(WFIN_BLOCK) void k_walk_final_lds(const uint8_t *__restrict__ in, uint32_t n, int sb, int la, uint32_t SBu,
                                                                uint32_t TILE, uint32_t region0, uint32_t nregions, uint32_t run_len,
@@ -1149,9 +1109,21 @@ __global__ __launch_bounds__(WFIN_BLOCK) void k_walk_final_lds(const uint8_t *__
     const uint32_t lo = run * run_len;
     if (lo >= lt1) return;
     const uint32_t tb = min(run_len, lt1 - lo);
-    const uint16_t *ixg = subs + ((size_t)reg * runs_per_tile + run) * 2 * SUB + SUB;
-    for (uint32_t e = tid * 8; e < SUB; e += WFIN_BLOCK * 8)
-        *reinterpret_cast<uint4 *>(s_ix + e) = *reinterpret_cast<const uint4 *>(ixg + e);
+    {
+        /* the inverse (sub-rank -> position - lo) is a scatter of the run's sub-ranks: the sort kernel used to export it
+         * as a second array (1.2 GB written and read again per 100 MB) */
+        const uint16_t *rkg = subs + ((size_t)reg * runs_per_tile + run) * SUB;
+        const uint64_t rend64 = t0_64 + TILE + (uint32_t)sb;
+        const uint32_t Rreg = (rend64 < n ? (uint32_t)rend64 : n) - t0;
+        const uint32_t R = min(SUB, Rreg - lo);                                      /* sub-ranked positions [0, R) of this run */
+        for (uint32_t e = tid * 8; e < R; e += WFIN_BLOCK * 8) {
+            const uint4 v = *reinterpret_cast<const uint4 *>(rkg + e);
+            const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int q = 0; q < 8; q++)
+                if (e + q < R) s_ix[(w[q >> 1] >> (16 * (q & 1))) & 0xFFFFu] = (uint16_t)(e + q);
+        }
+    }
     {
         const uint64_t avail = (uint64_t)n + LZ77X_PAD - ((uint64_t)t0 + lo);       /* bytes that exist from t0 + lo on (0xFF tail included) */
         const uint32_t want = SUB + (uint32_t)la + 16;
@@ -1993,7 +1965,7 @@ static size_t big_walk_scratch_bytes(const lz77x_geom &g, uint32_t nregions)
 static size_t c1_walk_scratch_bytes(const lz77x_geom &g, uint32_t nregions)
 {
     const size_t rl = walk_run_lds(g), runs = (g.TILE + rl - 1) / rl;
-    return (((size_t)nregions * (runs * 2 * (rl + g.SBu) * 2 + (size_t)g.TILE * 8) + (size_t)g.SBu * 4 + 256) + 255) & ~(size_t)255;
+    return (((size_t)nregions * (runs * (rl + g.SBu) * 2 + (size_t)g.TILE * 8) + (size_t)g.SBu * 4 + 256) + 255) & ~(size_t)255;
 }
 
 size_t lz77k_match_scratch_bytes(const lz77x_geom &g, uint32_t nregions)
@@ -2048,7 +2020,7 @@ hipError_t lz77k_match(const uint8_t *d_in, uint32_t n, const lz77x_geom &g, uin
         const uint32_t run_len = walk_run_lds(g);
         const uint32_t runs = (g.TILE + run_len - 1) / run_len, SUB = run_len + g.SBu;
         uint16_t *subs = reinterpret_cast<uint16_t *>(d_scratch);
-        uint32_t *wf = reinterpret_cast<uint32_t *>(subs + (size_t)nregions * runs * 2 * SUB);
+        uint32_t *wf = reinterpret_cast<uint32_t *>(subs + (size_t)nregions * runs * SUB);
         uint32_t *wb = wf + (size_t)nregions * g.TILE;
         uint32_t *wb0 = wb + (size_t)nregions * g.TILE;
         const uint64_t walkers = (uint64_t)nregions * runs;
@@ -2060,15 +2032,9 @@ hipError_t lz77k_match(const uint8_t *d_in, uint32_t n, const lz77x_geom &g, uin
         hipLaunchKernelGGL(k_walk, dim3((uint32_t)((walkers + 63) / 64) + (region0 == 0 ? 1u : 0u)), dim3(64), lds, s, subs, n, g.sb, g.SBu, g.TILE,
                            region0, nregions, run_len, runs, wf, wb, wb0, region0 == 0 ? 1 : 0);
         if (ev_sort && (e = hipEventRecord(ev_sort[2], s)) != hipSuccess) return e;
-        if (getenv("LZ77X_WALK_FINAL_V1")) {
-            const uint64_t npos = (uint64_t)nregions * g.TILE;
-            hipLaunchKernelGGL(k_walk_final, dim3((uint32_t)((npos + 255) / 256)), dim3(256), 0, s, d_in, n, g.sb, g.la, g.SBu,
-                               g.TILE, region0, nregions, run_len, runs, subs, wf, wb, wb0, d_ps, d_maxlen);
-        } else {
-            const size_t flds = (size_t)SUB * 3 + (size_t)g.la + 32;
-            hipLaunchKernelGGL(k_walk_final_lds, dim3((uint32_t)walkers), dim3(WFIN_BLOCK), flds, s, d_in, n, g.sb, g.la, g.SBu,
-                               g.TILE, region0, nregions, run_len, runs, subs, wf, wb, wb0, d_ps, d_maxlen);
-        }
+        const size_t flds = (size_t)SUB * 3 + (size_t)g.la + 32;
+        hipLaunchKernelGGL(k_walk_final_lds, dim3((uint32_t)walkers), dim3(WFIN_BLOCK), flds, s, d_in, n, g.sb, g.la, g.SBu,
+                           g.TILE, region0, nregions, run_len, runs, subs, wf, wb, wb0, d_ps, d_maxlen);
         return hipGetLastError();
     }
     if (variant == 1) return launch_match<false, 1>(LZ77K_MATCH_ARGS);
