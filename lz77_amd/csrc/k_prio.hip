@@ -175,7 +175,8 @@ __global__ __launch_bounds__(64) void k_prio_fwd(const uint32_t *__restrict__ ps
                 ip -= ip >= ring_n ? ring_n : 0u;
                 uint32_t is = ix + s;
                 is -= is >= ring_n ? ring_n : 0u;
-                bool ng = false;
+                uint32_t ng = 0;                                      /* a VGPR flag, not a bool: as a lane mask the compiler merges it
+                                                                         through three levels of exec masks, 20 scalar instructions a round */
                 uint32_t out = PRIO_NONE;
                 uint64_t r = rm;
                 do {
@@ -186,12 +187,12 @@ __global__ __launch_bounds__(64) void k_prio_fwd(const uint32_t *__restrict__ ps
                         /* the three reads leave together (one LDS round trip per round, not two: no short circuit) */
                         const uint32_t a = ring[ix], w = ring[ip], sv = ring[is];
                         const bool gate = a < w, lower = a < sv;
-                        ng = gate;                                    /* the gate: x's predecessor hangs below x */
+                        ng = gate ? 1u : 0u;                          /* the gate: x's predecessor hangs below x */
                         if (gate & lower) { ring[is] = a; out = a; }  /* tree.c:202-231: S takes x's place */
                     }
                     wave_sync();
                 } while (r);
-                const uint64_t gnb = __ballot(ng);
+                const uint64_t gnb = __ballot(ng != 0u);
                 nflip += (uint32_t)__popcll(gnb ^ go);
                 if (lane == k) gn_l = gnb;
                 if (STORE && x < x1) xval[x] = out;
