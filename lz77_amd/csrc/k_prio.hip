@@ -267,19 +267,22 @@ __global__ __launch_bounds__(64) void k_prio_back(const uint32_t *__restrict__ p
         gl = gates[xq >> 6];
     };
     fetch((int32_t)nsg - 1, v, g_l);
+    /* ring slot of cell xg, stepped down with the groups (64 < ring_n): a % per group is ten scalar instructions */
+    uint32_t off_run = (64u * PRIO_SG * nsg) % ring_n;
     for (int32_t sgi = (int32_t)nsg - 1; sgi >= 0; sgi--) {
         fetch(sgi - 1, vn, g_n);
         const uint32_t xs = x0 + 64u * PRIO_SG * (uint32_t)sgi;
 #pragma unroll
         for (int k = (int)PRIO_SG - 1; k >= 0; k--) {
             const uint32_t xg = xs + 64u * (uint32_t)k;
+            off_run = off_run >= 64u ? off_run - 64u : off_run + ring_n - 64u;
             if (xg < x1) {
                 const uint64_t gm = readlane64(g_l, k);
                 const uint32_t s = v[k] >> 16;
                 const uint32_t x = xg + lane;
                 const bool valid = x < x1;
                 const bool gate = valid && ((gm >> lane) & 1ull);
-                const uint32_t off = (xg - x0) % ring_n;              /* ring slot of cell xg */
+                const uint32_t off = off_run;                         /* = (xg - x0) % ring_n */
                 uint32_t d = PRIO_DEAD;
                 int ptr = -1;
                 if (gate) {
