@@ -60,8 +60,9 @@ __device__ __forceinline__ uint64_t readlane64(uint64_t v, int l)
 /* Per group of 64 consecutive steps: the initial gates (every step that has both neighbours) and the
  * round mask -- bit i set <=> lane i must start a new round because some lane j of the current round
  * (j < i) writes a cell lane i reads: its own (S[j] = x_i), its predecessor's (gate test) or its
- * successor's (the "did the hand-over happen" test).  tag[c] = lowest lane of the current round that
- * writes cell c. */
+ * successor's (the "did the hand-over happen" test).  tag[c] = (version, 63 - lowest lane of the current round that
+ * writes cell c), kept with atomicMax: every round of every group has a version of its own, so stale tags are simply
+ * older and nothing is ever reset (a round is two wavefront barriers instead of three and no clearing stores). */
 __global__ __launch_bounds__(256) void k_prio_prep(const uint32_t *__restrict__ ps, uint32_t nx, uint32_t tagn,
                                                    uint64_t *__restrict__ rmask, uint64_t *__restrict__ gate0)
 {
@@ -69,8 +70,9 @@ __global__ __launch_bounds__(256) void k_prio_prep(const uint32_t *__restrict__ 
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     uint32_t *tag = prep_tags + wave * tagn;
     const uint32_t ngroups = (nx + 63u) / 64u;
-    for (uint32_t i = lane; i < tagn; i += 64) tag[i] = PRIO_NONE;
+    for (uint32_t i = lane; i < tagn; i += 64) tag[i] = 0u;
     wave_sync();
+    uint32_t ver = 1;                                     /* < 2^26: a wavefront sees at most ngroups / 8192 groups of <= 64 rounds */
     for (uint32_t g = blockIdx.x * 4u + wave; g < ngroups; g += gridDim.x * 4u) {
         const uint32_t x = g * 64u + lane;
         const uint32_t v = x < nx ? ps[x] : 0u;
@@ -80,14 +82,19 @@ __global__ __launch_bounds__(256) void k_prio_prep(const uint32_t *__restrict__ 
         uint64_t mask = 1;
         uint32_t start = 0;
         for (;;) {
-            if (has && lane >= start) atomicMin(&tag[cs], lane);
+            if (has && lane >= start) atomicMax(&tag[cs], (ver << 6) | (63u - lane));
             wave_sync();
-            bool blocked = false;
-            if (has && lane > start) blocked = tag[lane] < lane || tag[cp] < lane || tag[cs] < lane;
+            uint32_t blocked = 0;
+            if (has && lane > start) {
+                const uint32_t t0 = tag[lane], t1 = tag[cp], t2 = tag[cs];
+                const uint32_t b0 = (t0 >> 6) == ver && 63u - (t0 & 63u) < lane;
+                const uint32_t b1 = (t1 >> 6) == ver && 63u - (t1 & 63u) < lane;
+                const uint32_t b2 = (t2 >> 6) == ver && 63u - (t2 & 63u) < lane;
+                blocked = b0 | b1 | b2;
+            }
             wave_sync();
-            if (has && lane >= start) tag[cs] = PRIO_NONE;
-            wave_sync();
-            const uint64_t bm = __ballot(blocked);
+            ver++;
+            const uint64_t bm = __ballot(blocked != 0u);
             if (!bm) break;
             start = (uint32_t)__builtin_ctzll(bm);
             mask |= 1ull << start;
