@@ -971,14 +971,20 @@ __global__ __launch_bounds__(64) void k_walk(const uint16_t *__restrict__ subs, 
         if (!m) lo_w = max(lo_w, w0);
         return m ? (w << 5) + 31u - (uint32_t)__builtin_clz(m) : WALK_NONE;
     };
-    auto neighbours = [&](uint32_t w0, uint32_t b0, uint32_t here, uint32_t next, uint32_t prev) -> uint32_t {   /* successor | predecessor << 16 */
+    /* the three-word case; returns bit 0: nothing above in them, bit 1: nothing below (the far scans are then due) */
+    auto near3 = [&](uint32_t w0, uint32_t b0, uint32_t here, uint32_t next, uint32_t prev, uint32_t &su, uint32_t &pr) -> uint32_t {
         const uint32_t nx = w0 + 1 < NW ? next : 0u, pv = w0 ? prev : 0u;
         const uint64_t up = ((((uint64_t)nx << 32) | here) >> 1) >> b0;                       /* bits above b0, then word w0+1 */
         const uint64_t dn = (((uint64_t)here << 32) | pv) & ((1ull << (32u + b0)) - 1ull);     /* word w0-1, then bits below b0 */
-        uint32_t su = (w0 << 5) + b0 + 1u + (uint32_t)__builtin_ctzll(up | (1ull << 63));
-        uint32_t pr = (w0 << 5) + 31u - (uint32_t)__builtin_clzll(dn | 1ull);                  /* ((w0-1) << 5) + 63 - clz */
-        if (!up) su = succ_far(w0);
-        if (!dn) pr = pred_far(w0);
+        su = (w0 << 5) + b0 + 1u + (uint32_t)__builtin_ctzll(up | (1ull << 63));
+        pr = (w0 << 5) + 31u - (uint32_t)__builtin_clzll(dn | 1ull);                           /* ((w0-1) << 5) + 63 - clz */
+        return (up ? 0u : 1u) | (dn ? 0u : 2u);
+    };
+    auto neighbours = [&](uint32_t w0, uint32_t b0, uint32_t here, uint32_t next, uint32_t prev) -> uint32_t {   /* successor | predecessor << 16 */
+        uint32_t su, pr;
+        const uint32_t miss = near3(w0, b0, here, next, prev, su, pr);
+        if (miss & 1u) su = succ_far(w0);
+        if (miss & 2u) pr = pred_far(w0);
         return su | (pr << 16);
     };
     auto query = [&](uint32_t q) -> uint32_t {                /* successor | predecessor << 16 */
@@ -1028,8 +1034,18 @@ __global__ __launch_bounds__(64) void k_walk(const uint16_t *__restrict__ subs, 
         const uint32_t wq = q >> 5, bq = q & 31, wy = hasy ? ry >> 5 : wq, by_ = ry & 31;
         const uint32_t hq = BM_WORD(wq), nq = BM_WORD(min(wq + 1, NW - 1)), pq = BM_WORD(wq ? wq - 1 : 0);
         const uint32_t hy = BM_WORD(wy), ny = BM_WORD(min(wy + 1, NW - 1)), py = BM_WORD(wy ? wy - 1 : 0);
-        resf = neighbours(wq, bq, hq, nq, pq);
-        resb = hasy ? neighbours(wy, by_, hy, ny, py) : (WALK_NONE | (WALK_NONE << 16));
+        /* both queries out of the words at hand; ONE wave-uniform branch for the far scans of either (rare) */
+        uint32_t suq, prq, suy, pry;
+        const uint32_t mq = near3(wq, bq, hq, nq, pq, suq, prq);
+        const uint32_t my = hasy ? near3(wy, by_, hy, ny, py, suy, pry) : 0u;
+        if (__ballot((mq | my) != 0u)) {
+            if (mq & 1u) suq = succ_far(wq);
+            if (mq & 2u) prq = pred_far(wq);
+            if (my & 1u) suy = succ_far(wy);
+            if (my & 2u) pry = pred_far(wy);
+        }
+        resf = suq | (prq << 16);
+        resb = hasy ? suy | (pry << 16) : (WALK_NONE | (WALK_NONE << 16));
         BM_WORD(wq) = hq & ~(1u << bq);
         r_add = ry;                                          /* position t+sb enters at the next step */
     };
