@@ -290,26 +290,23 @@ __global__ __launch_bounds__(64) void k_prio_back(const uint32_t *__restrict__ p
                 const bool valid = x < x1;
                 const bool gate = valid && ((gm >> lane) & 1ull);
                 const uint32_t off = off_run;                         /* = (xg - x0) % ring_n */
-                uint32_t d = PRIO_DEAD;
-                int ptr = -1;
-                if (gate) {
-                    const uint32_t t = x + s;
-                    if (t >= x1) d = t - x1;                          /* < sb */
-                    else if (t < xg + 64u) ptr = (int)(t - xg);       /* a later lane of this group */
-                    else {
-                        uint32_t it = off + lane + s;
-                        it -= it >= ring_n ? ring_n : 0u;
-                        d = dr[it];
-                    }
-                }
+                /* three cases by where x + s lies -- beyond the block (an exit cell), in a later lane of this group (a
+                 * pointer, jumped below), or in between (the ring) -- as selects on ONE unconditional ring read: nested
+                 * branches cost a lone wavefront more in exec-mask bookkeeping than the read they save */
+                const uint32_t t = x + s;
+                uint32_t it = off + lane + (gate ? s : 0u);
+                it -= it >= ring_n ? ring_n : 0u;
+                const uint32_t dring = dr[it];
+                const bool past = t >= x1, near = t < xg + 64u;
+                uint32_t d = !gate ? (uint32_t)PRIO_DEAD : past ? t - x1 : near ? (uint32_t)PRIO_DEAD : dring;
+                int ptr = gate && !past && near ? (int)(t - xg) : -1;
                 while (__ballot(ptr >= 0)) {                          /* chains inside the group: pointer jumping */
                     const int src = ptr >= 0 ? ptr : (int)lane;
                     const uint32_t dn = (uint32_t)__shfl((int)d, src, 64);
                     const int pn = __shfl(ptr, src, 64);
-                    if (ptr >= 0) {
-                        if (pn < 0) { d = dn; ptr = -1; }
-                        else ptr = pn;
-                    }
+                    const bool on = ptr >= 0, done = pn < 0;
+                    d = on && done ? dn : d;
+                    ptr = on ? (done ? -1 : pn) : -1;
                 }
                 if (valid) {
                     uint32_t ix = off + lane;
