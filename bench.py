@@ -57,7 +57,10 @@ def cpu_baseline(data, sb, la, budget_bytes):
         O.decode(z)
         t2 = time.perf_counter()
     return {"value": round(n / (t2 - t0) / 1e6, 3), "unit": "MB/s", "cores": 1, "kind": kind,
-            "sample": "first %d bytes of the same S1 stream, encode then decode, single thread" % n,
+            "sample": ("first %d bytes of the same S1 stream, encode then decode, single thread; WHOLE-PROCESS wall time of the "
+                       "reference CLI (process start + file I/O on tmpfs included) -- like for like with `file_to_file`, not with "
+                       "`value` (HBM-resident kernels on the full 100 MB)" if kind == "reference" else
+                       "first %d bytes of the same S1 stream, encode then decode, single thread, in-memory port") % n,
             "encode_MBps": round(n / (t1 - t0) / 1e6, 3), "decode_MBps": round(n / (t2 - t1) / 1e6, 3),
             "host": _cpu_model()}
 
@@ -94,6 +97,77 @@ def concurrent_streams(L, synth, torch, a, n, k):
     ok = all(bool(torch.equal(backs[i], ins[i])) for i in range(k))
     return {"streams": k, "value": round(k * reps * n / dt / 1e6, 3), "unit": "MB/s", "ms_per_step_per_stream": round(dt / reps * 1e3, 3),
             "roundtrip_ok": ok, "note": "not the benchmark value: k independent %d-byte streams on one GPU" % n}
+
+
+def file_to_file(L, data, sb, la):
+    """what a CLI user sees -- `lz77 -c` then `lz77 -d` as separate processes on a tmpfs file: process
+    start, HIP runtime + code-object load, file -> pinned slots -> device -> file.  Run twice: the first pair pays
+    whatever the box has not cached yet ("cold"), the second is "warm"; `process_start_ms` is an encode of an EMPTY
+    file (everything but the data)."""
+    import numpy as np
+    tmp = "/dev/shm" if os.path.isdir("/dev/shm") else "/tmp"
+    fin, flz, fout, fempty = (os.path.join(tmp, "lz77f2f_%d.%s" % (os.getpid(), e)) for e in ("in", "lz", "out", "empty"))
+    n = int(data.size)
+    data.tofile(fin)
+    open(fempty, "wb").close()
+    geo = ["-s", str(sb), "-l", str(la)]
+    res = {}
+    try:
+        for label in ("cold", "warm"):
+            t0 = time.perf_counter()
+            subprocess.check_call([L.CLI_PATH, "-c", "-i", fin, "-o", flz] + geo)
+            t1 = time.perf_counter()
+            subprocess.check_call([L.CLI_PATH, "-d", "-i", flz, "-o", fout])
+            t2 = time.perf_counter()
+            res[label] = {"encode_ms": round((t1 - t0) * 1e3, 1), "decode_ms": round((t2 - t1) * 1e3, 1)}
+        t0 = time.perf_counter()
+        subprocess.check_call([L.CLI_PATH, "-c", "-i", fempty, "-o", flz + ".e"] + geo)
+        start_ms = (time.perf_counter() - t0) * 1e3
+        ok = bool(np.array_equal(np.fromfile(fout, dtype=np.uint8), data))
+    finally:
+        for p in (fin, flz, fout, fempty, flz + ".e"):
+            if os.path.exists(p):
+                os.unlink(p)
+    w = res["warm"]
+    return {"encode_MBps": round(n / w["encode_ms"] / 1e3, 1), "decode_MBps": round(n / w["decode_ms"] / 1e3, 1),
+            "encode_plus_decode_MBps": round(n / (w["encode_ms"] + w["decode_ms"]) / 1e3, 1),
+            "cold_start_ms": round(res["cold"]["encode_ms"] - w["encode_ms"], 1), "process_start_ms": round(start_ms, 1),
+            "cold": res["cold"], "warm": w, "roundtrip_ok": ok, "bytes": n,
+            "note": "whole-process wall time of lz77_amd/lz77 on a tmpfs file (PCIe, process start and runtime init included); never `value`"}
+
+
+def shard_record(L, synth, a, shards):
+    """BASELINE config 5 inside the default N > 1 run: the 1 GB S4 stream position-sharded over the N devices by ONE
+    process (rank 0), host buffers in and out.  No physical scaling is claimed unless the devices are distinct."""
+    import hashlib
+    n, seed = 1_000_000_000, synth.SEED_S4
+    data = synth.make("text", n, seed)
+    ndev = L.lib().lz77x_device_count()
+    assert L.lib().lz77x_set_shards(max(shards, 1)) == 0
+    try:
+        L.decode(L.encode(data[:64_000_000], a.la, a.sb))                # contexts, buffers, code objects on every device
+        t0 = time.perf_counter()
+        z = L.encode(data, a.la, a.sb)
+        st = L.last_stats()
+        t1 = time.perf_counter()
+        back = L.decode(z)
+        t2 = time.perf_counter()
+    finally:
+        L.lib().lz77x_set_shards(1)
+    gold = golden_full("text", n, seed, a.sb, a.la)
+    enc_ms, dec_ms = (t1 - t0) * 1e3, (t2 - t1) * 1e3
+    return {"workload": "S4 enwik9-like text, %d bytes, s=%d l=%d, ONE stream cut into %d position shards on %d physical device(s); "
+                        "host buffers in and out (PCIe-inclusive)" % (n, a.sb, a.la, shards, min(shards, ndev)),
+            "shards": shards, "physical_devices": min(shards, ndev),
+            "encode_ms": round(enc_ms, 1), "decode_ms": round(dec_ms, 1),
+            "encode_plus_decode_MBps": round(n / (enc_ms + dec_ms) / 1e3, 1),
+            "host_serial_ms": round(st["copy_ms"], 2), "host_serial_frac_of_encode": round(st["copy_ms"] / enc_ms, 4) if enc_ms else None,
+            "prio_iters": st["prio_iters"],
+            "stream_sha_ok": None if gold is None else bool(len(z) == gold["zn"] and hashlib.sha256(z).hexdigest() == gold["sha256_lz"]),
+            "roundtrip_ok": bool(back == data.tobytes()),
+            "scaling_measured": bool(min(shards, ndev) > 1),
+            "note": "strong scaling of one stream; `value` above is the weak-scaling files mode. host_serial_ms = host time between the "
+                    "phases that no device overlaps (per gate iteration: the shards' boundary maps chained on the host, enqueue)"}
 
 
 def golden_full(kind, n, seed, sb, la):
@@ -219,6 +293,8 @@ def main():
     ap.add_argument("--kind", default="text")
     ap.add_argument("--cpu-sample", type=int, default=64_000_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-file-to-file", action="store_true")
+    ap.add_argument("--no-shard-record", action="store_true", help="N > 1: skip the S4 one-stream-sharded sub-record")
     ap.add_argument("--streams", type=int, default=4, help="also report k concurrent streams on one GPU (informational; 1 = skip)")
     ap.add_argument("--mode", choices=("files", "shard"), default="files",
                     help="files: an independent stream per GPU (default; weak scaling).  shard: ONE stream (default the 1 GB "
@@ -255,6 +331,9 @@ def main():
             dist.init_process_group("nccl", device_id=torch.device("cuda", local))
         else:
             dist.init_process_group(backend)
+        # host-side rendezvous for the part outside the timed region where rank 0 alone drives every device: an RCCL
+        # barrier would park a spinning kernel on the very GPUs rank 0 is using
+        cpu_group = dist.new_group(backend="gloo")
     import lz77_amd as L
     from lz77_amd import synth
 
@@ -309,6 +388,19 @@ def main():
         ok = bool(okt[0].item())
         sha_ok = None if int(okt[1].item()) == 2 else bool(okt[1].item())
 
+    shard_rec = None
+    if world > 1 and not a.no_shard_record:
+        # BASELINE config 5 (one stream over the N devices), outside the timed region: rank 0 drives every device, the
+        # other ranks wait at the barrier
+        if rank == 0:
+            try:
+                del d_z, d_back
+                torch.cuda.empty_cache()
+                shard_rec = shard_record(L, synth, a, world)
+            except Exception as e:                                # pragma: no cover - must never break the line
+                shard_rec = {"error": str(e)[:300]}
+        dist.barrier(group=cpu_group)
+
     if rank == 0:
         K = max(a.steps, 1)
         mean = lambda xs, k: sum(x[k] for x in xs) / max(len(xs), 1)
@@ -329,6 +421,7 @@ def main():
         if dom_ms <= 0:
             dom_name, dom_ms, dom_launches, dom_key = "match stage (sort + walkers + finalize)", k_match_ms, launches, None
         achieved = alg_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
+        t_device_ms = sum(mean(enc_stats, k) for k in ("k_match_ms", "k_chain_ms", "k_prio_ms", "k_token_ms"))
         traffic = None
         tfile = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tfile) and dom_key:
@@ -357,6 +450,10 @@ def main():
                          "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic,
                          "traffic_source": "profiles/traffic.json (PMC passes of the committed rocprofv3 run, per launch; not measured in this run)",
+                         "frac_op": round(alg_bytes / (t_device_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 6) if t_device_ms > 0 else 0.0,
+                         "frac_op_def": "SURVEY 8d: algorithmic bytes / SUM of the encode's kernel times (match + chain + recurrence + "
+                                        "hand-over index, tie-break and pack) / peak -- the whole operation, beside the dominant kernel's `frac`",
+                         "t_device_ms": round(t_device_ms, 3),
                          "launches_per_step": dom_launches,
                          "algorithmic_bytes_per_launch": alg_bytes // dom_launches,
                          "kernel_ms_per_launch": round(dom_ms / dom_launches, 3),
@@ -389,6 +486,13 @@ def main():
                 out["concurrent_streams"] = {"error": str(e)[:200]}
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(data, a.sb, a.la, min(a.cpu_sample, n))
+        if world == 1 and not a.no_file_to_file:
+            try:
+                out["file_to_file"] = file_to_file(L, data, a.sb, a.la)
+            except Exception as e:                                # pragma: no cover - must never break the line
+                out["file_to_file"] = {"error": str(e)[:200]}
+        if shard_rec is not None:
+            out["shard"] = shard_rec
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()

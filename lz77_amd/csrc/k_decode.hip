@@ -7,7 +7,7 @@
 /* ------------------------------------------------------------------ decode ----------- */
 
 /* lz77.c:260-283 + bitio.c:256-298: fixed-width tokens, so token k is simply bits [32+kT, ..) */
-__global__ void k_dec_parse(const uint8_t *__restrict__ z, uint32_t ntok, int ob, int lb, int T,
+__global__ void k_dec_parse(const uint8_t *__restrict__ z, uint32_t ntok, int ob, int lb, int T, uint32_t sb,
                             uint32_t *__restrict__ tokval, uint32_t *__restrict__ len1, uint32_t *__restrict__ stale_flag)
 {
     const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
@@ -20,7 +20,11 @@ __global__ void k_dec_parse(const uint8_t *__restrict__ z, uint32_t ntok, int ob
     len1[k] = len + 1u;
     /* a copy from distance 0: the reference's encoder emits it when -s is a power of two (the offset sb does
      * not fit its field); its decoder then reads whatever its cyclic buffer holds (lz77.c:178-181) */
-    if (off == 0 && len > 0 && stale_flag) *stale_flag = 1u;
+    if (off == 0 && len > 0 && stale_flag) stale_flag[0] = 1u;
+    /* a distance beyond the window (the field is wider than sb unless sb = 2^k - 1): never written by the reference's
+     * encoder (tree.c:140: off <= sb); such a stream takes the general per-byte path, the window-bounded ones
+     * (k_dec_seg's ring, the shard hand-off) assume off <= sb */
+    if (off > sb && len > 0 && stale_flag) stale_flag[1] = 1u;
 }
 
 /* lz77.c:178-194 as data flow: every copied byte j points at j-off, every literal at itself.
@@ -646,7 +650,8 @@ __global__ __launch_bounds__(256) void k_dec_patch(uint8_t *__restrict__ out, co
     }
 }
 
-int lz77k_dec_seg_supported(const lz77x_geom &g) { return g.sb <= 8192; }
+/* la <= 255 (main.c:103): the step / tile bounds assume a token never spans more than one boundary */
+int lz77k_dec_seg_supported(const lz77x_geom &g) { return g.sb <= 8192 && g.la <= 255; }
 
 static void dec_seg_plan(uint32_t n, uint32_t *seg_bytes, uint32_t *nseg)
 {
@@ -746,7 +751,7 @@ hipError_t lz77k_dec_parse(const uint8_t *d_z, uint32_t ntok, const lz77x_geom &
                            uint32_t *d_stale_flag)
 {
     if (ntok == 0) return hipSuccess;
-    hipLaunchKernelGGL(k_dec_parse, dim3((ntok + 255) / 256), dim3(256), 0, s, d_z, ntok, g.ob, g.lb, g.T, d_tokval, d_len1, d_stale_flag);
+    hipLaunchKernelGGL(k_dec_parse, dim3((ntok + 255) / 256), dim3(256), 0, s, d_z, ntok, g.ob, g.lb, g.T, (uint32_t)g.sb, d_tokval, d_len1, d_stale_flag);
     return hipGetLastError();
 }
 

@@ -199,7 +199,8 @@ hipError_t lz77k_pack(const uint32_t *d_tokval, uint64_t ntok, const lz77x_geom 
 hipError_t lz77k_pack_range(const uint32_t *d_tokval, uint64_t k_first, uint64_t k_end, const lz77x_geom &g, uint32_t *d_out_words,
                             uint64_t w0, uint64_t nw, hipStream_t s);
 
-/* *d_stale_flag (may be null) is set when a token copies from distance 0 (power-of-two -s) */
+/* d_stale_flag (may be null; two words): [0] is set when a token copies from distance 0 (power-of-two -s),
+ * [1] when one copies from beyond the window (off > sb: no stream of the reference's encoder) */
 hipError_t lz77k_dec_parse(const uint8_t *d_z, uint32_t ntok, const lz77x_geom &g,
                            uint32_t *d_tokval, uint32_t *d_len1, hipStream_t s, uint32_t *d_stale_flag = nullptr);
 /* d_cyc[0..ncyc]: output offsets at which the reference's staging buffer starts a new pass (+ a final n), for

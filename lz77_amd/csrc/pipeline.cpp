@@ -28,6 +28,7 @@
 #include <atomic>
 #include <condition_variable>
 #include <mutex>
+#include <string>
 #include <thread>
 #include <vector>
 
@@ -122,6 +123,39 @@ struct PinBuf {
     }
     template <class T> T *as() const { return reinterpret_cast<T *>(p); }
 };
+
+/* whatever way a multi-device function is left, the thread's current device is the one it came in with (a
+ * HIPCHK return in the middle of a per-shard loop would otherwise leave another shard's device current, and the
+ * next library call would rebuild every cached context there) */
+struct DeviceRestore {
+    int dev;
+    explicit DeviceRestore(int d) : dev(d) {}
+    ~DeviceRestore() { hipError_t e = hipSetDevice(dev); (void)e; }
+    DeviceRestore(const DeviceRestore &) = delete;
+    DeviceRestore &operator=(const DeviceRestore &) = delete;
+};
+
+/* fn(d) for every shard d, each on a host thread of its own (the first on the calling thread): per-device
+ * allocations, copies from the caller's pageable buffer (which block their thread) and result fetches of D devices
+ * overlap instead of queueing behind one another.  fn makes its device current itself; the first error wins, its
+ * text ends up in the caller's g_err */
+template <class F> int for_each_shard(size_t D, F fn)
+{
+    std::vector<int> rcs(D, LZ77X_OK);
+    std::vector<std::string> msgs(D);
+    auto run = [&](size_t d) {
+        g_err[0] = 0;
+        rcs[d] = fn(d);
+        if (rcs[d]) msgs[d] = g_err;
+    };
+    std::vector<std::thread> th;
+    for (size_t d = 1; d < D; d++) th.emplace_back(run, d);
+    if (D) run(0);
+    for (auto &t : th) t.join();
+    for (size_t d = 0; d < D; d++)
+        if (rcs[d]) { snprintf(g_err, sizeof g_err, "%s", msgs[d].c_str()); return rcs[d]; }
+    return LZ77X_OK;
+}
 
 struct Ctx {
     bool ready = false;
@@ -809,6 +843,7 @@ int decode_core(Ctx &c, size_t zn, hipStream_t s, bool want_data, size_t *n_out)
 
     uint64_t n = 0;
     bool stale = false;                       /* the stream copies from distance 0 somewhere (power-of-two -s) */
+    bool general = false;                     /* not a stream of the reference's encoder: no window / token-length assumptions */
     HIPCHK(hipEventRecord(c.ev[0], s));
     if (ntok) {
         if ((rc = c.tokval.need(((size_t)ntok + 8) * 4))) return rc;
@@ -816,7 +851,7 @@ int decode_core(Ctx &c, size_t zn, hipStream_t s, bool want_data, size_t *n_out)
         if ((rc = c.dst.need(((size_t)ntok + 8) * 4))) return rc;
         if ((rc = c.scantmp.need(lz77k_scan_tmp_bytes(ntok + 1)))) return rc;
         if ((rc = c.flag.need(64))) return rc;
-        HIPCHK(hipMemsetAsync(c.flag.as<uint32_t>() + 8, 0, 4, s));
+        HIPCHK(hipMemsetAsync(c.flag.as<uint32_t>() + 8, 0, 8, s));
         HIPCHK(lz77k_dec_parse(c.z.as<uint8_t>(), ntok, g, c.tokval.as<uint32_t>(), c.len1.as<uint32_t>(), s, c.flag.as<uint32_t>() + 8));
         HIPCHK(hipMemsetAsync(c.len1.as<uint32_t>() + ntok, 0, 4, s));
         /* decoded size can exceed 32 bits for hostile streams: bound it (64-bit sum on the device)
@@ -832,10 +867,13 @@ int decode_core(Ctx &c, size_t zn, hipStream_t s, bool want_data, size_t *n_out)
         HIPCHK(lz77k_scan_u32(c.len1.as<uint32_t>(), c.dst.as<uint32_t>(), ntok + 1, c.scantmp.p, s));
         uint32_t *tot = reinterpret_cast<uint32_t *>(hdr + 16);
         HIPCHK(hipMemcpyAsync(tot, c.dst.as<uint32_t>() + ntok, 4, hipMemcpyDeviceToHost, s));
-        HIPCHK(hipMemcpyAsync(tot + 1, c.flag.as<uint32_t>() + 8, 4, hipMemcpyDeviceToHost, s));
+        HIPCHK(hipMemcpyAsync(tot + 1, c.flag.as<uint32_t>() + 8, 8, hipMemcpyDeviceToHost, s));
         HIPCHK(hipStreamSynchronize(s));
         n = *tot;
         stale = tot[1] != 0;
+        /* distances beyond the window, or a lookahead field no CLI run can produce (main.c:103 caps -l at 255; a token
+         * may then span several tiles): the per-byte pointer path, which assumes nothing about either */
+        general = tot[2] != 0 || la > 255;
     }
     *n_out = (size_t)n;
     uint32_t rounds = 0;
@@ -885,7 +923,7 @@ int decode_core(Ctx &c, size_t zn, hipStream_t s, bool want_data, size_t *n_out)
             d_cyc = c.scratch.as<uint32_t>();
         }
         const char *dv = getenv("LZ77X_DECODE_VARIANT");            /* 0 production, 1 tile pass + jumping, (LZ77X_DECODE_V1: round 1) */
-        if (!stale && lz77k_dec_seg_supported(g) && !(dv && atoi(dv)) && !getenv("LZ77X_DECODE_V1")) {
+        if (!stale && !general && lz77k_dec_seg_supported(g) && !(dv && atoi(dv)) && !getenv("LZ77X_DECODE_V1")) {
             if ((rc = c.tstart.need(lz77k_dec_seg_tmp_bytes(n32, g)))) return rc;
             HIPCHK(lz77k_dec_segments(c.tokval.as<uint32_t>(), c.dst.as<uint32_t>(), ntok, g, c.out.as<uint8_t>(), c.ptr.p, n32, c.tstart.p, s));
         } else {
@@ -896,8 +934,9 @@ int decode_core(Ctx &c, size_t zn, hipStream_t s, bool want_data, size_t *n_out)
         uint32_t *hcount = reinterpret_cast<uint32_t *>(hdr + 32);
         uint32_t total = n32;
         const uint32_t *in_list = nullptr;
-        if (getenv("LZ77X_DECODE_V1")) {
-            /* round 1: a pointer per output byte in HBM, jumped there (kept as a cross-check) */
+        if (general || getenv("LZ77X_DECODE_V1")) {
+            /* round 1: a pointer per output byte in HBM, jumped there (kept as a cross-check, and for streams
+             * that no run of the reference's encoder produces) */
             HIPCHK(lz77k_dec_expand(c.tokval.as<uint32_t>(), c.dst.as<uint32_t>(), ntok, g, c.out.as<uint8_t>(),
                                     c.ptr.as<uint32_t>(), n32, s, d_cyc, ncyc));
             for (;;) {
@@ -963,6 +1002,7 @@ int decode_sharded(std::vector<Ctx *> &cs, const uint8_t *z, size_t zn, uint8_t 
     const double t_begin = now_ms();
     *handled = 0;
     int rc;
+    DeviceRestore restore(cs[0]->device);
     if (zn < 4) return LZ77X_E_FORMAT;
     const int sb = z[0] | (z[1] << 8), la = z[2] | (z[3] << 8);               /* lz77.c:157-158 */
     if (sb < 1 || la < 1) return LZ77X_E_FORMAT;
@@ -979,8 +1019,10 @@ int decode_sharded(std::vector<Ctx *> &cs, const uint8_t *z, size_t zn, uint8_t 
     for (size_t d = 0; d <= D; d++) k0[d] = (uint32_t)lz77x_shard_token_cut(ntok, (int)D, (int)d);
     struct Sh { uint32_t ntok = 0, n = 0; lz77k_dec_seg_state P; const uint16_t *d_smap = nullptr; };
     std::vector<Sh> sh(D);
-    /* 1. every shard: its bytes of the stream behind a header of its own, parse, scan */
-    for (size_t d = 0; d < D; d++) {
+    /* 1. every shard: its bytes of the stream behind a header of its own, parse, scan (a host thread per shard: the
+     *    copies out of the caller's pageable stream block their thread) */
+    rc = for_each_shard(D, [&](size_t d) -> int {
+        int rc;
         Ctx &c = *cs[d];
         HIPCHK(hipSetDevice(c.device));
         hipStream_t s = c.stream;
@@ -998,15 +1040,17 @@ int decode_sharded(std::vector<Ctx *> &cs, const uint8_t *z, size_t zn, uint8_t 
         if ((rc = c.dst.need(((size_t)S.ntok + 8) * 4))) return rc;
         if ((rc = c.scantmp.need(lz77k_scan_tmp_bytes(S.ntok + 1)))) return rc;
         if ((rc = c.flag.need(64))) return rc;
-        HIPCHK(hipMemsetAsync(c.flag.as<uint32_t>() + 8, 0, 4, s));
+        HIPCHK(hipMemsetAsync(c.flag.as<uint32_t>() + 8, 0, 8, s));
         HIPCHK(lz77k_dec_parse(c.z.as<uint8_t>(), S.ntok, g, c.tokval.as<uint32_t>(), c.len1.as<uint32_t>(), s, c.flag.as<uint32_t>() + 8));
         HIPCHK(hipMemsetAsync(c.len1.as<uint32_t>() + S.ntok, 0, 4, s));
         HIPCHK(lz77k_sum_u32(c.len1.as<uint32_t>(), S.ntok, c.flag.as<unsigned long long>() + 2, s));
         HIPCHK(lz77k_scan_u32(c.len1.as<uint32_t>(), c.dst.as<uint32_t>(), S.ntok + 1, c.scantmp.p, s));
         uint32_t *h = c.h_small.as<uint32_t>();
         HIPCHK(hipMemcpyAsync(h + 4, c.flag.as<unsigned long long>() + 2, 8, hipMemcpyDeviceToHost, s));
-        HIPCHK(hipMemcpyAsync(h + 8, c.flag.as<uint32_t>() + 8, 4, hipMemcpyDeviceToHost, s));
-    }
+        HIPCHK(hipMemcpyAsync(h + 8, c.flag.as<uint32_t>() + 8, 8, hipMemcpyDeviceToHost, s));
+        return LZ77X_OK;
+    });
+    if (rc) return rc;
     uint64_t n = 0;
     bool fits = true;
     std::vector<uint64_t> o0(D + 1, 0);
@@ -1016,7 +1060,7 @@ int decode_sharded(std::vector<Ctx *> &cs, const uint8_t *z, size_t zn, uint8_t 
         HIPCHK(hipStreamSynchronize(c.stream));
         const uint32_t *h = c.h_small.as<uint32_t>();
         const uint64_t nd = *reinterpret_cast<const unsigned long long *>(h + 4);
-        if (h[8] != 0 || nd < usb || nd > LZ77X_MAX_N) fits = false;        /* distance-0 copies / a shard inside one window */
+        if (h[8] != 0 || h[9] != 0 || nd < usb || nd > LZ77X_MAX_N) fits = false;   /* distance-0 copies, distances beyond the window / a shard inside one window */
         sh[d].n = (uint32_t)nd;
         o0[d + 1] = o0[d] + nd;
     }
@@ -1054,13 +1098,13 @@ int decode_sharded(std::vector<Ctx *> &cs, const uint8_t *z, size_t zn, uint8_t 
         if (e == hipSuccess) e = lz77k_dec_segments_back(g, c.out.as<uint8_t>(), c.ptr.p, sh[d].n, sh[d].P, c.stream);
         if (e != hipSuccess) { free(buf); snprintf(g_err, sizeof g_err, "HIP: %s", hipGetErrorString(e)); return LZ77X_E_HIP; }
     }
-    for (size_t d = 0; d < D; d++) {
+    rc = for_each_shard(D, [&](size_t d) -> int {           /* the gather: every device fetches its bytes at once */
         Ctx &c = *cs[d];
-        hipError_t e = hipSetDevice(c.device);
-        if (e == hipSuccess) e = hipStreamSynchronize(c.stream);
-        if (e != hipSuccess) { free(buf); snprintf(g_err, sizeof g_err, "HIP: %s", hipGetErrorString(e)); return LZ77X_E_HIP; }
-        if ((rc = fetch_result(c, buf + o0[d], c.out.p, sh[d].n))) { free(buf); return rc; }
-    }
+        HIPCHK(hipSetDevice(c.device));
+        HIPCHK(hipStreamSynchronize(c.stream));
+        return fetch_result(c, buf + o0[d], c.out.p, sh[d].n);
+    });
+    if (rc) { free(buf); return rc; }
     HIPCHK(hipSetDevice(cs[0]->device));
     memset(&g_stats, 0, sizeof g_stats);
     g_stats.n = n;
@@ -1213,6 +1257,9 @@ struct Sink {
     virtual ~Sink() {}
     /* the next `bytes` of the stream, resident at d_src and complete in stream order on s */
     virtual int write(Ctx &c, const uint8_t *d_src, size_t bytes, hipStream_t s) = 0;
+    /* host memory for the next `bytes` of the stream, to be filled by the caller in any order (several devices fetch
+     * their pieces at once); null when the sink only takes bytes in sequence */
+    virtual uint8_t *direct(size_t bytes) { (void)bytes; return nullptr; }
     size_t total = 0;
 };
 
@@ -1233,6 +1280,15 @@ struct MemSource : Source {
 struct FileSource : Source {
     FILE *f;
     explicit FileSource(FILE *file) : f(file) {}
+    size_t size_hint() const override
+    {
+        /* regular files only (a pipe has no size): what lies between the read position and the end */
+        struct stat st;
+        const int fd = fileno(f);
+        if (fd < 0 || fstat(fd, &st) != 0 || !S_ISREG(st.st_mode)) return 0;
+        const off_t at = ftello(f);
+        return at >= 0 && st.st_size > at ? (size_t)(st.st_size - at) : 0;
+    }
     int read(Ctx &c, uint8_t *d_dst, size_t want, hipStream_t s, size_t *got) override
     {
         /* fread of piece k+1 overlaps the DMA of piece k (two pinned staging slots) */
@@ -1292,6 +1348,20 @@ struct HostSink : Sink {
         const int rc = fetch_result(c, buf + total, d_src, bytes);
         total += bytes;
         return rc;
+    }
+    uint8_t *direct(size_t bytes) override
+    {
+        if (total + bytes > cap) {
+            size_t ncap = cap ? cap : (size_t)1 << 20;
+            while (ncap < total + bytes) ncap *= 2;
+            uint8_t *nb = (uint8_t *)realloc(buf, ncap);
+            if (!nb) return nullptr;
+            buf = nb;
+            cap = ncap;
+        }
+        uint8_t *at = buf + total;
+        total += bytes;
+        return at;
     }
     uint8_t *release() { uint8_t *b = buf; buf = nullptr; return b ? b : (uint8_t *)malloc(1); }
 };
@@ -1571,7 +1641,7 @@ int seg_tokens(SegJob &J, const lz77x_geom &g, const SegCarry &carry)
     return LZ77X_OK;
 }
 
-int seg_finish(SegJob &J, SegCarry &carry, Sink &sink, double *waited)
+int seg_finish(SegJob &J, SegCarry &carry, Sink &sink, double *waited, hipStream_t caller)
 {
     Ctx &c = *J.c;
     hipStream_t s = J.s;
@@ -1584,6 +1654,12 @@ int seg_finish(SegJob &J, SegCarry &carry, Sink &sink, double *waited)
         carry.ntail = J.have_tail;
     }
     if ((rc = sink.write(c, c.out.as<uint8_t>(), (size_t)J.out_bytes, s))) return rc;
+    if (caller && caller != s) {
+        /* a device sink copies on this segment's stream: the caller's stream must see every segment's words, not
+         * only those of the last one (an odd segment runs on the sibling stream) */
+        HIPCHK(hipEventRecord(c.pipe_ev[1], s));
+        HIPCHK(hipStreamWaitEvent(caller, c.pipe_ev[1], 0));
+    }
     if (J.E > J.start) g_stats.transfers += c.h_small.as<unsigned long long>()[2];
 
     float ms = 0;
@@ -1661,6 +1737,10 @@ int encode_stream_device(Ctx &c, Source &src, Sink &sink, const lz77x_geom &g, h
             const char *sp = getenv("LZ77X_SPLIT");
             if (sp && atoi(sp) && pipelined && hint >= ((size_t)32 << 20) && hint / 2 + csub < seg) seg = (hint / 2 + csub) / csub * csub;
         }
+        /* a source of known size below a segment: buffers sized for it, not for 2^30 positions (the whole input
+         * is then one segment: want = seg + halo > what is left, so the first load sees the end) */
+        const size_t known = src.size_hint();
+        if (known && known < seg) seg = (known + csub - 1) / csub * csub;
         if (seg < lo) seg = lo;
         if (seg > ((size_t)3 << 30)) seg = (size_t)3 << 30;      /* local coordinates are 32-bit */
     }
@@ -1732,7 +1812,7 @@ int encode_stream_device(Ctx &c, Source &src, Sink &sink, const lz77x_geom &g, h
             /* the next segment's input and match stage, behind this one's match stage on the other stream */
             if (prev_unfinished >= 0) {
                 /* its context is the one segment k-1 still occupies: its last tokens and its words are taken first */
-                if ((rc = seg_finish(J[prev_unfinished & 1], carry, sink, &waited))) return rc;
+                if ((rc = seg_finish(J[prev_unfinished & 1], carry, sink, &waited, s))) return rc;
                 prev_unfinished = -1;
             }
             if ((rc = load(k + 1, &K))) return rc;
@@ -1743,22 +1823,17 @@ int encode_stream_device(Ctx &c, Source &src, Sink &sink, const lz77x_geom &g, h
         if ((rc = seg_mid(K, g, carry, single, &fb, &waited))) return rc;
         if (fb) { *fallback = true; *n_fallback = K.nloc; return LZ77X_OK; }
         if (prev_unfinished >= 0) {
-            if ((rc = seg_finish(J[prev_unfinished & 1], carry, sink, &waited))) return rc;
+            if ((rc = seg_finish(J[prev_unfinished & 1], carry, sink, &waited, s))) return rc;
             prev_unfinished = -1;
         }
         if ((rc = seg_tokens(K, g, carry))) return rc;
         if (K.last) {
-            if ((rc = seg_finish(K, carry, sink, &waited))) return rc;
-            if (K.s != s) {
-                /* the caller's stream sees the whole result */
-                HIPCHK(hipEventRecord(K.c->pipe_ev[1], K.s));
-                HIPCHK(hipStreamWaitEvent(s, K.c->pipe_ev[1], 0));
-            }
+            if ((rc = seg_finish(K, carry, sink, &waited, s))) return rc;     /* (joins the caller's stream) */
             break;
         }
         if (pipelined) prev_unfinished = k;
         else {
-            if ((rc = seg_finish(K, carry, sink, &waited))) return rc;
+            if ((rc = seg_finish(K, carry, sink, &waited, s))) return rc;
             if ((rc = load(k + 1, &K))) return rc;
             if ((rc = seg_front(J[(k + 1) & 1], g))) return rc;
         }
@@ -1879,8 +1954,14 @@ int encode_sharded(std::vector<Ctx *> &cs, const uint8_t *src, size_t n, const l
     };
     const size_t hwords = 4 * usb + 1024;                 /* pinned words per shard beyond the tbase copy */
 
-    /* -- phase A: every shard on its own: input, match stage, the parse chain's maps, round masks -- */
-    for (size_t d = 0; d < D; d++) {
+    /* -- phase A: every shard on its own: input, match stage, the parse chain's maps, round masks.  One host thread
+     *    per shard: the copy out of the caller's pageable buffer blocks its thread (hipMemcpyAsync stages it), and D of
+     *    them in sequence on one thread were D x n/D bytes of serial PCIe time before the last device saw a byte -- */
+    DeviceRestore restore(cs[0]->device);
+    double host_serial_ms = 0;                              /* host time between the phases that no device overlaps */
+    std::vector<uint32_t> launches_of(D, 0);
+    rc = for_each_shard(D, [&](size_t d) -> int {
+        int rc;
         ShardJob &j = J[d];
         j.c = cs[d];
         Ctx &c = *j.c;
@@ -1928,7 +2009,7 @@ int encode_sharded(std::vector<Ctx *> &cs, const uint8_t *src, size_t n, const l
         for (uint32_t r0 = 0; r0 < nregions; r0 += batch) {
             const uint32_t nr = nregions - r0 < batch ? nregions - r0 : batch;
             HIPCHK(lz77k_match(c.in.as<uint8_t>(), j.nloc, g, r0, nr, c.ps.as<uint32_t>(), c.maxlen.as<uint8_t>(), c.scratch.p, 0, s, nullptr, nullptr));
-            g_stats.match_launches++;
+            launches_of[d]++;
         }
         const uint8_t *d_wexit = nullptr;
         const uint32_t *d_wcnt = nullptr;
@@ -1936,8 +2017,12 @@ int encode_sharded(std::vector<Ctx *> &cs, const uint8_t *src, size_t n, const l
         HIPCHK(hipMemcpyAsync(j.h, d_wcnt, 256 * 4, hipMemcpyDeviceToHost, s));
         HIPCHK(hipMemcpyAsync(j.h + 256, d_wexit, 256, hipMemcpyDeviceToHost, s));
         HIPCHK(lz77k_prio_begin(j.P, c.ps.as<uint32_t>(), j.nx, g.sb, c.xval.as<uint32_t>(), c.prio_tmp.p, (uint32_t)j.gpos0, nullptr, s));
-    }
-    if ((rc = sync_all())) return rc;
+        HIPCHK(hipStreamSynchronize(s));
+        return LZ77X_OK;
+    });
+    if (rc) return rc;
+    for (uint32_t l : launches_of) g_stats.match_launches += l;
+    double t_serial = now_ms();
 
     /* -- the parse chain across the cuts (lz77.c:98): entry offset and first-token index of every shard -- */
     {
@@ -1982,7 +2067,9 @@ int encode_sharded(std::vector<Ctx *> &cs, const uint8_t *src, size_t n, const l
                 if ((rc = dev(j))) return rc;
                 HIPCHK(lz77k_prio_maps(j.P, j.c->stream, false, nullptr, nullptr));
             }
+            host_serial_ms += now_ms() - t_serial;
             if ((rc = sync_all())) return rc;
+            t_serial = now_ms();
             for (size_t i = 0; i < usb; i++) v[i] = (uint32_t)i;          /* the start of the input: every cell its own position */
             for (size_t d = 0; d < D; d++) {
                 ShardJob &j = J[d];
@@ -2001,7 +2088,9 @@ int encode_sharded(std::vector<Ctx *> &cs, const uint8_t *src, size_t n, const l
                 if ((rc = dev(j))) return rc;
                 HIPCHK(lz77k_prio_sweep(j.P, j.c->stream, j.c->h_small.as<uint32_t>() + 8, nullptr));
             }
+            host_serial_ms += now_ms() - t_serial;
             if ((rc = sync_all())) return rc;
+            t_serial = now_ms();
             iters++;
             bool any = false, earlier = false;
             for (size_t d = 0; d < D; d++) {
@@ -2073,15 +2162,37 @@ int encode_sharded(std::vector<Ctx *> &cs, const uint8_t *src, size_t n, const l
         ntail = m < 4 ? m : 4;
         for (uint32_t i = 0; i < ntail; i++) tail[4 - ntail + i] = merged[m - ntail + i];
     }
-    for (size_t d = 0; d < D; d++) {
-        ShardJob &j = J[d];
-        if ((rc = dev(j))) return rc;
-        if ((rc = sink.write(*j.c, j.c->out.as<uint8_t>(), (size_t)piece[d], j.c->stream))) return rc;
-        unsigned long long cnt = 0;
-        HIPCHK(hipMemcpy(&cnt, j.c->flag.as<unsigned long long>() + 1, 8, hipMemcpyDeviceToHost));
-        g_stats.transfers += cnt;
+    host_serial_ms += now_ms() - t_serial;
+    {
+        /* the pieces leave: every device fetches its own into the sink's memory at once when the sink is host memory
+         * (the gather north_star describes), else one after the other in stream order */
+        uint64_t all = 0;
+        std::vector<uint64_t> at(D, 0);
+        for (size_t d = 0; d < D; d++) { at[d] = all; all += piece[d]; }
+        std::vector<unsigned long long> cnt(D, 0);
+        uint8_t *base = sink.direct((size_t)all);
+        if (base) {
+            rc = for_each_shard(D, [&](size_t d) -> int {
+                ShardJob &j = J[d];
+                HIPCHK(hipSetDevice(j.c->device));
+                HIPCHK(hipStreamSynchronize(j.c->stream));
+                HIPCHK(hipMemcpy(&cnt[d], j.c->flag.as<unsigned long long>() + 1, 8, hipMemcpyDeviceToHost));
+                return fetch_result(*j.c, base + at[d], j.c->out.p, (size_t)piece[d]);
+            });
+            if (rc) return rc;
+        } else {
+            for (size_t d = 0; d < D; d++) {
+                ShardJob &j = J[d];
+                if ((rc = dev(j))) return rc;
+                if ((rc = sink.write(*j.c, j.c->out.as<uint8_t>(), (size_t)piece[d], j.c->stream))) return rc;
+                HIPCHK(hipMemcpy(&cnt[d], j.c->flag.as<unsigned long long>() + 1, 8, hipMemcpyDeviceToHost));
+            }
+        }
+        for (unsigned long long c : cnt) g_stats.transfers += c;
     }
     HIPCHK(hipSetDevice(cs[0]->device));
+    g_stats.host_chain_ms = 0;
+    g_stats.copy_ms = host_serial_ms;                      /* sharded: host time no device overlaps (exchange + enqueue) */
     g_stats.n = n;
     g_stats.zn = sink.total;
     g_stats.ntok = K_all;

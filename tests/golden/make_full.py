@@ -27,13 +27,15 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 OUT = os.path.join(HERE, "golden_full.json")
 
 # name -> (kind, n, seed, sb, la).  S1..S4 are SURVEY 8d / BASELINE.json configs[1..4]; S1r<k> are the
-# per-rank streams of bench.py at N > 1 (seed + rank); S5 crosses 4 GiB (device-side segmentation).
+# per-rank streams of bench.py at N > 1 (seed + rank); S5 and S6 cross 4 GiB (device-side segmentation).
 JOBS = {
     "S1": ("text", 100_000_000, 0x5EED0001, 4095, 15),
     "S3": ("mixed", 212_000_000, 0x5EED0003, 65535, 255),
     "S2": ("random", 1 << 30, 0x5EED0002, 4095, 15),
     "S4": ("text", 1_000_000_000, 0x5EED0004, 4095, 15),
     "S5": ("text", 5 * (1 << 30), 0x5EED0005, 4095, 15),
+    # crosses 4 GiB like S5 but generates in seconds (raw splitmix64): the segment carry in the DEFAULT gpu suite
+    "S6": ("random", 4_400_000_000, 0x5EED0006, 4095, 15),
 }
 for _r in range(1, 8):
     JOBS["S1r%d" % _r] = ("text", 100_000_000, 0x5EED0001 + _r, 4095, 15)

@@ -104,6 +104,37 @@ def test_s5_5gib_through_bounded_device_memory():
     _run("S5")
 
 
+def test_s6_4_4gb_segment_carry_past_4gib():
+    """the >= 4 GiB segment carry in the DEFAULT suite: 4.4 GB of raw splitmix64 bytes (generated in seconds) through
+    the FILE* entry point -- five segments of 2^30 positions, two in flight, 64-bit token/byte counts in the carry --
+    equals the reference's stream (digest made by make_full.py S6)"""
+    if "S6" not in FULL:
+        pytest.skip("golden_full.json has no S6 record yet")
+    st = _run("S6")
+    assert st["host_stageb_ms"] == 0
+
+
+def test_s4_sharded_over_8_contexts(monkeypatch):
+    """BASELINE configs[4] as config 5 runs it: the 1 GB stream position-sharded over 8 device contexts (sharing the
+    test box's single GPU: LZ77X_FAKE_DEVICES) through the host-buffer entry points -- the reference's digest on the
+    way in, the input's bytes on the way back (decode sharded by token ranges)"""
+    r = FULL["S4"]
+    n, sb, la = r["n"], r["sb"], r["la"]
+    data = synth.make(r["kind"], n, r["seed"])
+    monkeypatch.setenv("LZ77X_FAKE_DEVICES", "8")
+    try:
+        assert L.lib().lz77x_set_shards(8) == 0
+        z = L.encode(data, la, sb)
+        st = L.last_stats()
+        assert len(z) == r["zn"] and st["ntok"] == r["ntok"] and st["host_stageb_ms"] == 0
+        assert hashlib.sha256(z).hexdigest() == r["sha256_lz"], "sharded stream differs from the reference's"
+        back = L.decode(z)
+        assert L.last_stats()["k_decode_ms"] == 0, "the single-device decoder ran"
+        assert len(back) == n and hashlib.sha256(back).hexdigest() == r["sha256_in"]
+    finally:
+        L.lib().lz77x_set_shards(1)
+
+
 def test_s1_enwik8_like_100mb():
     """BASELINE.json configs[1]: 100 MB text, s=4095 l=15 -- the bench workload; everything on the device"""
     st = _run("S1")

@@ -637,3 +637,134 @@ def test_device_api_with_torch():
     d_back = torch.empty(n, dtype=torch.uint8, device="cuda")
     assert L.decode_device(d_out.data_ptr(), zn, d_back.data_ptr(), n, stream=stream) == n
     assert torch.equal(d_back, d_in)
+
+
+def _libc():
+    libc = ctypes.CDLL(None)
+    libc.fopen.restype = ctypes.c_void_p
+    libc.fopen.argtypes = [ctypes.c_char_p, ctypes.c_char_p]
+    libc.fclose.argtypes = [ctypes.c_void_p]
+    return libc
+
+
+@pytest.mark.parametrize("sb,la", [(4095, 15), (1000, 10), (65535, 255)])
+def test_batch_files_api(sb, la, tmp_path, monkeypatch):
+    """SURVEY 8f-2, batch half: lz77x_encode_files / lz77x_decode_files -- six files of different kinds and sizes (one
+    empty, one a single byte) over fewer context sets than files (LZ77X_MAX_CONTEXTS=2: the worker lanes take the
+    files one after the other), every stream equal to the oracle's BST encoder for that file, every round trip
+    equal to the input; then a batch with one unreadable slot: that file alone reports the error"""
+    monkeypatch.setenv("LZ77X_MAX_CONTEXTS", "2")
+    libc = _libc()
+    specs = [("text", 301, 900_000), ("random", 302, 300_000), ("mixed", 303, 1_200_000), ("lowent", 304, 250_000),
+             ("zeros", 0, 0), ("records", 305, 1)]
+    datas = [synth.make(k, n, s) for k, s, n in specs]
+    nf = len(datas)
+    srcs = [str(tmp_path / ("f%d.bin" % i)) for i in range(nf)]
+    lzs = [str(tmp_path / ("f%d.lz" % i)) for i in range(nf)]
+    outs = [str(tmp_path / ("f%d.out" % i)) for i in range(nf)]
+    for d, p in zip(datas, srcs):
+        d.tofile(p)
+    FP = ctypes.c_void_p * nf
+    rcs = (ctypes.c_int * nf)()
+
+    def run(fn, ins, ous, *geom):
+        fi = FP(*[libc.fopen(p.encode(), b"rb") for p in ins])
+        fo = FP(*[libc.fopen(p.encode(), b"wb") for p in ous])
+        try:
+            return fn(nf, fi, fo, *geom, rcs)
+        finally:
+            for f in list(fi) + list(fo):
+                if f:
+                    libc.fclose(f)
+
+    assert run(L.lib().lz77x_encode_files, srcs, lzs, la, sb) == 0, L.lib().lz77x_last_error()
+    assert list(rcs) == [0] * nf
+    for d, p in zip(datas, lzs):
+        assert open(p, "rb").read() == O.encode_bst(d, sb, la)
+    assert run(L.lib().lz77x_decode_files, lzs, outs) == 0, L.lib().lz77x_last_error()
+    assert list(rcs) == [0] * nf
+    for d, p in zip(datas, outs):
+        assert open(p, "rb").read() == d.tobytes()
+    # one slot that is not a stream (3 bytes: shorter than a header): its rc alone is E_FORMAT, the others decode
+    bad = list(lzs)
+    bad[2] = srcs[5] if os.path.getsize(srcs[5]) < 4 else srcs[4]
+    rc = run(L.lib().lz77x_decode_files, bad, outs)
+    assert rc != 0 and rcs[2] == rc and [rcs[i] for i in range(nf) if i != 2] == [0] * (nf - 1)
+    for i, (d, p) in enumerate(zip(datas, outs)):
+        if i != 2:
+            assert open(p, "rb").read() == d.tobytes()
+
+
+@pytest.mark.parametrize("seg", ["60000", "250000"])
+def test_device_sink_sees_every_segment(seg, monkeypatch):
+    """lz77x_encode_device over three and more segments, two in flight: the words of an odd segment are copied into the
+    caller's buffer on the sibling stream, and the call returns only when all of them have landed"""
+    import torch
+    monkeypatch.setenv("LZ77X_SEGMENT", seg)
+    data = synth.text(1_400_000, 311)
+    want = O.encode_bst(data)
+    d_in = torch.from_numpy(data).cuda()
+    cap = L.encode_bound(data.size)
+    for _ in range(3):
+        d_out = torch.zeros(cap, dtype=torch.uint8, device="cuda")
+        st = torch.cuda.Stream()
+        zn = L.encode_device(d_in.data_ptr(), data.size, d_out.data_ptr(), cap, stream=st.cuda_stream)
+        # no synchronisation of ours in between: the call itself must have made the result visible
+        assert d_out[:zn].cpu().numpy().tobytes() == want
+
+
+def _foreign_stream(rng, sb, la, n_target, off_max=None):
+    """a stream no run of the reference's encoder produces: random (off, len) tokens with off <= bytes so far"""
+    ob, lb = O.bitof(sb), O.bitof(la)
+    T = ob + lb + 8
+    toks = []
+    j = 0
+    while j < n_target:
+        ln = int(rng.integers(0, min(1 << lb, 70000))) if rng.random() < 0.3 else int(rng.integers(0, 12))
+        off = 0
+        if j == 0:
+            ln = 0
+        if ln:
+            off = int(rng.integers(1, min(j, off_max or sb, (1 << ob) - 1) + 1))
+        toks.append(off | (ln << ob) | (int(rng.integers(0, 256)) << (ob + lb)))
+        j += ln + 1
+    bits = 0
+    acc = bytearray([sb & 0xFF, sb >> 8, la & 0xFF, la >> 8])
+    v = 0
+    for t in toks:
+        v |= t << bits
+        bits += T
+        while bits >= 8:
+            acc.append(v & 0xFF)
+            v >>= 8
+            bits -= 8
+    if bits:
+        acc.append(v & 0xFF)
+    return bytes(acc)
+
+
+@pytest.mark.parametrize("sb,la", [(200, 65535), (255, 40000), (4095, 4096), (100, 300)])
+def test_decode_streams_with_a_lookahead_beyond_the_cli_limit(sb, la):
+    """the header carries 16 bits of la; main.c:103 caps -l at 255 but decode() (lz77.c:157-158) takes what it reads:
+    tokens longer than a decode step or tile (unset step bounds) go through the per-byte path and decode
+    like the reference's decoder"""
+    rng = np.random.default_rng(sb * 7 + la)
+    z = _foreign_stream(rng, sb, la, 600_000)
+    assert L.decode(z) == O.decode(z)
+
+
+def test_decode_distances_beyond_the_window_are_safe():
+    """off > sb (the offset field is wider than sb unless sb = 2^k - 1): outside the contract (the reference reads
+    whatever its staging buffer holds), but it must decode deterministically, without touching
+    unseeded state, on one device and sharded"""
+    rng = np.random.default_rng(5)
+    z = _foreign_stream(rng, 300, 15, 400_000, off_max=511)
+    a = L.decode(z)
+    assert L.decode(z) == a and len(a) == len(O.decode(z))
+    try:
+        os.environ["LZ77X_FAKE_DEVICES"] = "4"
+        assert L.lib().lz77x_set_shards(4) == 0
+        assert L.decode(z) == a
+    finally:
+        L.lib().lz77x_set_shards(1)
+        del os.environ["LZ77X_FAKE_DEVICES"]
