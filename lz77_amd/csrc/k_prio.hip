@@ -484,17 +484,26 @@ __global__ void k_prio_reset(uint32_t *summary)
  * iteration behind: 8 iterations at 16K, 5 at 64K on 100 MB of text) and make the boundary scan short;
  * but a sweep wants >= ~1500 blocks in flight (one wavefront each): nx/1536 clamped to [16K, 64K].
  * LZ77X_PRIO_BLOCK overrides. */
-static uint32_t prio_block_steps(uint32_t nx, uint32_t sb)
+static uint32_t prio_block_steps(uint32_t nx, uint32_t sb, uint32_t W, bool pack18, uint32_t ring_n)
 {
     const char *e = getenv("LZ77X_PRIO_BLOCK");
     uint32_t B = e && atoi(e) > 0 ? (uint32_t)atoi(e) : nx / 1536u;
-    const uint32_t unit = 64u * PRIO_SG;
+    const uint32_t unit = W > 64u ? W : 64u * PRIO_SG;
     if (!(e && atoi(e) > 0)) {
-        if (B > 65536u) B = 65536u;
+        /* a workgroup per block is through a block 10x sooner than a wavefront, and the maps of a block are sb entries
+         * whatever its length: longer blocks, fewer maps to build, scan and keep */
+        const uint32_t hi = sb > 4096u ? 131072u : 65536u;
+        if (B > hi) B = hi;
         if (B < 16384u) B = 16384u;
     }
     if (B < sb) B = sb;                                   /* every entry cell must be evicted inside its block */
-    return (B + unit - 1u) / unit * unit;
+    B = (B + unit - 1u) / unit * unit;
+    if (pack18) {
+        /* codes: sb ranks + the positions x0 .. x0 + B + ring_n must fit 18 bits */
+        const uint32_t cap = ((1u << 18) - sb - ring_n) / unit * unit;
+        if (B > cap) B = cap;
+    }
+    return B;
 }
 
 /* ---- the iteration, as phases (one device drives them in a loop: lz77k_prio; several devices, each with a
@@ -503,13 +512,16 @@ static uint32_t prio_block_steps(uint32_t nx, uint32_t sb)
 static void prio_layout(lz77k_prio_plan &P)
 {
     const uint32_t sb = P.sb, nx = P.nx;
-    P.B = prio_block_steps(nx, sb);
+    P.W = lz77kw_width((int)sb);
+    P.sb_r = (sb + 63u) & ~63u;
+    P.ring_n = P.sb_r + P.W;
+    P.pack18 = P.W > 64u && lz77kw_pack18(P.ring_n);
+    P.B = prio_block_steps(nx, sb, P.W, P.pack18, P.ring_n);
     P.NB = nx ? (nx + P.B - 1u) / P.B : 0u;
     P.ngroups = (nx + 63u) / 64u;
-    P.sb_r = (sb + 63u) & ~63u;
-    P.ring_n = P.sb_r + 64u;
     uint32_t G = 1;
-    while ((uint64_t)G * G < P.NB) G++;
+    if (sb > 4096u) while ((uint64_t)G * G * G < P.NB) G++;      /* two levels of groups (lz77kw_scan): the cube root */
+    else while ((uint64_t)G * G < P.NB) G++;
     const char *e = getenv("LZ77X_PRIO_SCAN_GROUP");
     if (e && atoi(e) > 0) G = (uint32_t)atoi(e);
     P.G = G;
@@ -527,6 +539,12 @@ static void prio_layout(lz77k_prio_plan &P)
     P.o_gin = take(((size_t)P.NG + 2) * sb * 4);
     P.o_sum = take(256);
     P.o_dirty = take(((size_t)P.NB + 2) * 2 * 4);            /* per block: [0, NB+2) its gates changed in the last sweep, then its entry cells changed in the last scan */
+    if (P.pack18) {
+        P.o_codes = take(((size_t)P.NB + 1) * sb * 4);
+        P.o_gval = take(((size_t)P.NB + 1) * sb * 4);
+    }
+    if (sb > 4096u) P.o_scan = take(lz77kw_scan_tmp_bytes(P.NG, sb));
+    if (P.W > 64u) P.o_inprev = take(((size_t)P.NB + 2) * sb * 4);        /* the cells every block's last sweep started from */
     P.total = o;
 }
 
@@ -539,7 +557,7 @@ size_t lz77k_prio_tmp_bytes(uint32_t nx, int sb)
     return P.total + 256;
 }
 
-int lz77k_prio_supported(int sb) { return sb >= 1 && sb <= 4096; }
+int lz77k_prio_supported(int sb) { return sb >= 1 && sb <= 65535; }
 
 #define PRIO_PTR(T, off) reinterpret_cast<T *>(reinterpret_cast<uint8_t *>(P.tmp) + (off))
 
@@ -558,14 +576,18 @@ hipError_t lz77k_prio_begin(lz77k_prio_plan &P, const uint32_t *d_ps, uint32_t n
     P.first = 0;
     prio_layout(P);
     if (nx == 0) return hipSuccess;
-    const uint32_t tagn = P.ring_n + 64u;
-    const size_t lds = (size_t)4 * tagn * sizeof(uint32_t);
     hipError_t e;
-    if (lds > 48 * 1024 &&
-        (e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_prio_prep), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)) != hipSuccess)
-        return e;
-    const uint32_t blocks = min((P.ngroups + 3u) / 4u, 256u * 8u);
-    hipLaunchKernelGGL(k_prio_prep, dim3(blocks), dim3(256), lds, s, d_ps, nx, tagn, PRIO_PTR(uint64_t, P.o_rmask), PRIO_PTR(uint64_t, P.o_gate[0]));
+    if (P.W > 64u) {
+        if ((e = lz77kw_prep(d_ps, nx, P.sb_r, P.W, PRIO_PTR(uint64_t, P.o_rmask), PRIO_PTR(uint64_t, P.o_gate[0]), s)) != hipSuccess) return e;
+    } else {
+        const uint32_t tagn = P.ring_n + 64u;
+        const size_t lds = (size_t)4 * tagn * sizeof(uint32_t);
+        if (lds > 48 * 1024 &&
+            (e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_prio_prep), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)) != hipSuccess)
+            return e;
+        const uint32_t blocks = min((P.ngroups + 3u) / 4u, 256u * 8u);
+        hipLaunchKernelGGL(k_prio_prep, dim3(blocks), dim3(256), lds, s, d_ps, nx, tagn, PRIO_PTR(uint64_t, P.o_rmask), PRIO_PTR(uint64_t, P.o_gate[0]));
+    }
     hipLaunchKernelGGL(k_prio_in0, dim3((P.sb + 255u) / 256u), dim3(256), 0, s, PRIO_PTR(uint32_t, P.o_in), P.sb, voff, d_carried);
     /* every block's map has to be built and every block swept once */
     P.in0_dirty = false;
@@ -592,6 +614,12 @@ hipError_t lz77k_prio_maps(lz77k_prio_plan &P, hipStream_t s, bool whole, const 
     uint16_t *dest = PRIO_PTR(uint16_t, P.o_dest), *gdest = PRIO_PTR(uint16_t, P.o_gdest);
     uint32_t *loc = PRIO_PTR(uint32_t, P.o_loc), *gloc = PRIO_PTR(uint32_t, P.o_gloc);
     const uint32_t nb = P.NB - P.first;
+    if (P.W > 64u) {
+        hipError_t e = lz77kw_back(P.ps, P.nx, P.sb, P.B, P.ring_n, P.W, P.first, nb, PRIO_PTR(uint64_t, P.o_gate[P.cur]), dest, loc, P.voff, P.ncarried,
+                                   PRIO_PTR(uint32_t, P.o_dirty), s);
+        if (e != hipSuccess) return e;
+        if (whole && P.sb > 4096u) return hipErrorNotSupported;       /* the whole-plan map of a shard: LDS scans only */
+    } else
     hipLaunchKernelGGL(k_prio_back, dim3(nb), dim3(64), lds_back, s, P.ps, P.nx, P.sb, P.B, P.ring_n, P.first, PRIO_PTR(uint64_t, P.o_gate[P.cur]),
                        dest, loc, P.voff, P.ncarried, PRIO_PTR(uint32_t, P.o_dirty));
     if (whole) {
@@ -628,17 +656,20 @@ hipError_t lz77k_prio_sweep(lz77k_prio_plan &P, hipStream_t s, uint32_t *h_flag,
     /* only where it pays: with at most one round of blocks in flight (9 wavefronts per CU) a sweep is one wavefront's
      * latency whatever the number of blocks, and comparing the rows costs the scans 0.4 ms per 100 MB */
     const char *sk = getenv("LZ77X_PRIO_SKIP");
-    const bool track = P.sweeps > 0 && (sk ? atoi(sk) != 0 : P.NB > 2304u);
+    const bool track = P.W == 64u && P.sweeps > 0 && (sk ? atoi(sk) != 0 : P.NB > 2304u);
     if (track) {
         if ((e = hipMemsetAsync(in_changed + first, 0, (size_t)nb * 4, s)) != hipSuccess) return e;
         if (P.in0_dirty && first == 0 && (e = hipMemsetAsync(in_changed, 1, 4, s)) != hipSuccess) return e;
-    } else if (P.sweeps > 0) {
+    } else if (P.sweeps > 0 && P.W == 64u) {
         if ((e = hipMemsetAsync(gates_changed, 1, ((size_t)P.NB + 2) * 2 * 4, s)) != hipSuccess) return e;
     }
+    const uint32_t have_prev = P.sweeps > 0 ? 1u : 0u;                   /* (a workgroup sweep keeps its own record of what changed) */
     P.in0_dirty = false;
     P.sweeps++;
     uint32_t *changed = track ? in_changed : nullptr;
-    if (nb > 1) {
+    if (nb > 1 && sb > 4096u) {
+        if ((e = lz77kw_scan(dest, loc, in, sb, first, nb - 1u, P.G, gdest, gloc, gin, PRIO_PTR(uint8_t, P.o_scan), s)) != hipSuccess) return e;
+    } else if (nb > 1) {
         /* maps first .. NB-2 */
         const uint32_t nmaps = nb - 1, G = P.G;
         const uint32_t NG = (nmaps + G - 1u) / G;
@@ -663,6 +694,13 @@ hipError_t lz77k_prio_sweep(lz77k_prio_plan &P, hipStream_t s, uint32_t *h_flag,
         }
     }
     if (ev3 && (e = hipEventRecord(ev3[1], s)) != hipSuccess) return e;
+    if (P.W > 64u) {
+        if ((e = lz77kw_fwd(P.ps, P.nx, sb, P.B, P.ring_n, P.W, first, nb, PRIO_PTR(uint64_t, P.o_rmask), PRIO_PTR(uint64_t, P.o_gate[P.cur]),
+                            PRIO_PTR(uint64_t, P.o_gate[P.cur ^ 1]), in, P.xval, summary, P.voff, d_out_state, P.ncarried,
+                            P.pack18 ? PRIO_PTR(uint32_t, P.o_codes) : nullptr, P.pack18 ? PRIO_PTR(uint32_t, P.o_gval) : nullptr,
+                            PRIO_PTR(uint32_t, P.o_inprev), have_prev, gates_changed, s)) != hipSuccess)
+            return e;
+    } else
     hipLaunchKernelGGL(k_prio_fwd<true>, dim3(nb), dim3(64), lds_fwd, s, P.ps, P.nx, sb, P.B, P.ring_n, first, PRIO_PTR(uint64_t, P.o_rmask),
                        PRIO_PTR(uint64_t, P.o_gate[P.cur]), PRIO_PTR(uint64_t, P.o_gate[P.cur ^ 1]), in, P.xval, summary, P.voff, d_out_state,
                        gates_changed, (const uint32_t *)in_changed);
@@ -715,6 +753,7 @@ hipError_t lz77k_prio(const uint32_t *d_ps, uint32_t nx, int sb_i, uint32_t *d_x
             if ((e = hipEventElapsedTime(&t, ev4[0], ev4[1])) != hipSuccess) return e;
             ms3[2] += t;
         }
+        if (P.W > 64u) lz77kw_debug_dump();
         if (getenv("LZ77X_PRIO_TRACE"))
             fprintf(stderr, "prio it %d: B %u NB %u first %u flips %u min flipped block %u\n", it, P.B, P.NB, P.first, h_flag[0], h_flag[1]);
         if (h_flag[0] == 0) break;

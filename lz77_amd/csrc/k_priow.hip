@@ -1,0 +1,1043 @@
+/*
+ * k_priow.hip -- the priority recurrence of k_prio.hip with a WORKGROUP per block of steps.
+ *
+ * k_prio.hip gives a block of the recurrence (tree.c:202-231: which node a delete() promotes) to ONE wavefront whose
+ * 64 lanes take 64 consecutive steps, split into rounds wherever a step reads a cell an earlier one of the 64 writes;
+ * the sb live cells are a ring of 32-bit priorities in LDS.  Two things stop that design at sb = 4096:
+ *   - the ring: 65535 cells x 4 B do not fit the 160 KB of a CU;
+ *   - the latency: one wavefront per CU (the ring takes the whole LDS) at ~20 cycles per step is slower than a host core.
+ * Here W = 256 .. 1024 threads take W consecutive steps.  The conflicts that split a group into rounds are between
+ * steps whose neighbours lie close together in the window; with windows of 64 K they are rare -- measured on the S3
+ * stream: 5.5 rounds per 1024 steps against 17 (one per 64-step group) -- so a block costs a third of the rounds and a
+ * round is one workgroup barrier.  And the ring holds 18-bit CODES instead of priorities: every live priority is either
+ * OLD (< the block's first position: then it sits in one of the sb cells the block starts from, and only its order
+ * among those matters: its rank) or the own position of a cell of this block:
+ *       code = rank among the old entry values            (0 .. sb-1)
+ *            | sb + (position - x0)                        (sb .. sb + B + ring_n)
+ * an order-preserving map into 2^18 values: 16 bits in a uint16 ring + a 2-bit plane = 147 KB.  The ranks come from a
+ * sort of the old entry values in LDS before the sweep (the ring's space, not yet in use); what is handed over leaves as
+ * a true priority again through a per-block table rank -> value.
+ *
+ * The backward sweep (the blocks' maps) keeps a uint16 ring of exit cells and sends the per-exit-cell minima to HBM
+ * atomically; the boundary scan (k_pw_scan_*) applies a map as one grid-wide launch per step, because two vectors of
+ * 65535 priorities do not fit LDS either.
+ */
+#include "kernels_common.h"
+#include <stdio.h>
+
+#define PW_NONE 0xFFFFFFFFu
+#define PW_DEAD 0xFFFFu
+#define PW_SORT_CAP 32768u              /* keys sorted per pass of the rank prologue (128 KB of LDS) */
+
+/* LZ77X_PW_DEBUG=1: cycle stamps of workgroup 0 of the last back / fwd / prep launch (development aid) */
+__device__ unsigned long long pw_dbg[64];
+#define PW_STAMP(k) do { if (blockIdx.x == 0 && threadIdx.x == 0) pw_dbg[k] = __builtin_readcyclecounter(); } while (0)
+
+/* orders LDS traffic only: __syncthreads() also waits for every global load and store in flight (s_waitcnt vmcnt(0)),
+ * which put a round trip to HBM -- the next group's prefetched operands, the last group's result stores -- into every
+ * barrier of the sweeps' inner loops */
+__device__ __forceinline__ void pw_lds_barrier()
+{
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+/* Rows that ONE workgroup writes, lowers atomically and reads back within one launch (the blocks' loc rows, the rows of
+ * the boundary scan).  Everything stays at WORKGROUP scope: the atomics are performed in the L2 of the workgroup's XCD,
+ * where its own loads (sc0: never a line its L1 held from before) and stores meet them; other launches see the rows after
+ * the launch boundary.  Agent scope is the wrong tool on this part (eight XCDs, an L2 each): agent-scope atomics and sc1
+ * accesses are performed beyond the L2 -- a round trip of several microseconds that every s_waitcnt vmcnt behind them
+ * pays -- and an agent-scope fence (__threadfence()) is `buffer_wbl2 sc1` + `buffer_inv sc1`, a write-back and
+ * invalidate of the whole L2.  Ordering inside the workgroup: pw_fence_wg (the operations have been performed:
+ * s_waitcnt vmcnt(0)) + a barrier. */
+__device__ __forceinline__ uint32_t pw_ld_wg(const uint32_t *p)
+{
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+__device__ __forceinline__ void pw_st_wg(uint32_t *p, uint32_t v)
+{
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+__device__ __forceinline__ void pw_min_wg(uint32_t *p, uint32_t v)
+{
+    (void)__hip_atomic_fetch_min(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+__device__ __forceinline__ void pw_fence_wg()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+/* ------------------------------------------------------------------ round masks ------ */
+
+__device__ __forceinline__ void pw_cas_min16(uint32_t *tab, uint32_t idx, uint32_t tag)
+{
+    uint32_t *w = tab + (idx >> 1);
+    const uint32_t sh = (idx & 1u) * 16u;
+    uint32_t old = *w;                                      /* (no volatile: a volatile access through a cast pointer is a FLAT load, sc0 sc1,
+                                                               behind s_waitcnt vmcnt(0) -- every outstanding global operation) */
+    while (((old >> sh) & 0xFFFFu) > tag) {
+        const uint32_t nw = (old & ~(0xFFFFu << sh)) | (tag << sh);
+        const uint32_t got = atomicCAS(w, old, nw);
+        if (got == old) break;
+        old = got;
+    }
+}
+
+__device__ __forceinline__ uint32_t pw_rd16(const uint32_t *tab, uint32_t idx)
+{
+    return (reinterpret_cast<const uint16_t *>(tab))[idx];  /* (re-read after every barrier: pw_lds_barrier clobbers memory) */
+}
+
+/* Per group of W consecutive steps: the initial gates (every step that has both neighbours) and the round mask -- bit
+ * i set <=> step i starts a new round because some step j of the current round (j < i) writes a cell step i reads (its
+ * own, its predecessor's or its successor's).  tab[c - xg] = (version, lowest step of the current round that writes
+ * cell c), 16 bits per cell, kept with a compare-and-swap minimum: versions count DOWN, so a newer entry always
+ * replaces an older one and nothing is reset between rounds (every 63 rounds the table is cleared). */
+template <int W>
+__global__ __launch_bounds__(W) void k_pw_prep(const uint32_t *__restrict__ ps, uint32_t nx, uint32_t tagn,
+                                               uint64_t *__restrict__ rmask, uint64_t *__restrict__ gate0)
+{
+    extern __shared__ uint32_t pw_tab[];
+    __shared__ uint32_t s_first[2];
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const uint32_t ngroups = (nx + W - 1u) / W;
+    for (uint32_t i = tid; i < tagn / 2u; i += W) pw_tab[i] = 0xFFFFFFFFu;
+    if (tid < 2) s_first[tid] = W;
+    __syncthreads();
+    uint32_t ver = 0;                                       /* 0 .. 62; code 62 - ver; code 63 = a cleared entry */
+    int par = 0;
+    PW_STAMP(16);
+    uint32_t nrounds_dbg = 0;
+    uint32_t vnext = blockIdx.x < ngroups ? ps[min(blockIdx.x * W + tid, nx - 1u)] : 0u;
+    for (uint32_t g = blockIdx.x; g < ngroups; g += gridDim.x) {
+        const uint32_t x = g * W + tid;
+        const uint32_t v = x < nx ? vnext : 0u;
+        vnext = ps[min((g + gridDim.x) * W + tid, nx - 1u)];          /* the next group's steps arrive during this one's rounds */
+        const uint32_t p = v & 0xFFFFu, s = v >> 16;
+        const bool has = p && s;
+        bool isstart = tid == 0;
+        uint32_t start = 0;
+        for (;;) {
+            if (ver == 63u) {
+                pw_lds_barrier();
+                for (uint32_t i = tid; i < tagn / 2u; i += W) pw_tab[i] = 0xFFFFFFFFu;
+                ver = 0;
+                pw_lds_barrier();
+            }
+            const uint32_t code = 62u - ver;
+            if (has && tid >= start) pw_cas_min16(pw_tab, tid + s, (code << 10) | tid);
+            pw_lds_barrier();
+            if (tid == 0) s_first[par ^ 1] = W;
+            bool blocked = false;
+            if (has && tid > start) {
+                const uint32_t t0 = pw_rd16(pw_tab, tid), t1 = pw_rd16(pw_tab, tid + p), t2 = pw_rd16(pw_tab, tid + s);
+                const bool b0 = (t0 >> 10) == code && (t0 & 1023u) < tid;
+                const bool b1 = (t1 >> 10) == code && (t1 & 1023u) < tid;
+                const bool b2 = (t2 >> 10) == code && (t2 & 1023u) < tid;
+                blocked = b0 | b1 | b2;
+            }
+            const uint64_t bm = __ballot(blocked);
+            if (bm && lane == 0) atomicMin(&s_first[par], wave * 64u + (uint32_t)__builtin_ctzll(bm));
+            pw_lds_barrier();
+            const uint32_t first = s_first[par];
+            nrounds_dbg++;
+            ver++;
+            par ^= 1;
+            if (first >= (uint32_t)W) break;
+            start = first;
+            if (tid == first) isstart = true;
+        }
+        const uint64_t rm = __ballot(isstart), hm = __ballot(has);
+        const uint32_t wi = ((g * W) >> 6) + wave;
+        if (lane == 0 && g * W + wave * 64u < nx) { rmask[wi] = rm; gate0[wi] = hm; }
+    }
+    PW_STAMP(17);
+    if (blockIdx.x == 0 && threadIdx.x == 0) { pw_dbg[18] = nrounds_dbg; pw_dbg[19] = (ngroups + gridDim.x - 1) / gridDim.x; }
+}
+
+/* ------------------------------------------------------------------ forward sweep ---- */
+
+/* the live cells of a sweep: 32-bit priorities, or 18-bit codes as a uint16 array + a plane of 2 bits per cell */
+template <bool PACK> struct pw_ring;
+
+template <> struct pw_ring<false> {
+    uint32_t *r;
+    __device__ __forceinline__ uint32_t rd(uint32_t i) const { return r[i]; }
+    __device__ __forceinline__ void wr(uint32_t i, uint32_t nv, uint32_t) const { r[i] = nv; }
+    __device__ __forceinline__ void put(uint32_t i, uint32_t nv) const { r[i] = nv; }        /* old content unknown */
+};
+
+template <> struct pw_ring<true> {
+    uint16_t *lo;
+    uint32_t *hi;
+    __device__ __forceinline__ uint32_t rd(uint32_t i) const
+    {
+        return (uint32_t)lo[i] | (((hi[i >> 4] >> ((i & 15u) * 2u)) & 3u) << 16);
+    }
+    /* one writer per cell and round, and it has read the cell in this round: the plane changes by an exclusive or of
+     * old and new (other cells of the word may change under other lanes at the same time) */
+    __device__ __forceinline__ void wr(uint32_t i, uint32_t nv, uint32_t ov) const
+    {
+        lo[i] = (uint16_t)nv;
+        const uint32_t d = ((nv ^ ov) >> 16) & 3u;
+        if (d) atomicXor(&hi[i >> 4], d << ((i & 15u) * 2u));
+    }
+    __device__ __forceinline__ void put(uint32_t i, uint32_t nv) const
+    {
+        const uint32_t oh = (hi[i >> 4] >> ((i & 15u) * 2u)) & 3u;
+        lo[i] = (uint16_t)nv;
+        const uint32_t d = ((nv >> 16) ^ oh) & 3u;
+        if (d) atomicXor(&hi[i >> 4], d << ((i & 15u) * 2u));
+    }
+};
+
+/* exclusive prefix of one value per thread over the workgroup (W threads); *total = the sum.  Two barriers. */
+template <int W>
+__device__ __forceinline__ uint32_t pw_block_excl(uint32_t v, uint32_t *s_w /* W/64 + 1 words */, uint32_t *total)
+{
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    uint32_t inc = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t t = (uint32_t)__shfl_up((int)inc, d, 64);
+        if (lane >= (uint32_t)d) inc += t;
+    }
+    __syncthreads();
+    if (lane == 63) s_w[wave] = inc;
+    __syncthreads();
+    uint32_t base = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < W / 64; w++) {
+        const uint32_t t = s_w[w];
+        if ((uint32_t)w < wave) base += t;
+        tot += t;
+    }
+    *total = tot;
+    return base + inc - v;
+}
+
+/* Block b = steps [b*B, min((b+1)*B, nx)).  in[b][i] = value of cell b*B+i before the block's first step.  The sweep is
+ * the recurrence itself; gold[] (the gates the boundary values came from) is only compared against.
+ * PACK: codes[b][i] / gval[b][r] are the block's scratch rows (code of entry cell i; value of old rank r). */
+template <int W, bool PACK>
+__global__ __launch_bounds__(W) void k_pw_fwd(const uint32_t *__restrict__ ps, uint32_t nx, uint32_t sb, uint32_t B, uint32_t ring_n,
+                                              uint32_t b_first, const uint64_t *__restrict__ rmask, const uint64_t *__restrict__ gold,
+                                              uint64_t *__restrict__ gnew, const uint32_t *__restrict__ in, uint32_t *__restrict__ xval,
+                                              uint32_t *__restrict__ summary, uint32_t voff, uint32_t *__restrict__ out_state,
+                                              uint32_t ncarried, uint32_t *__restrict__ codes, uint32_t *__restrict__ gval,
+                                              uint32_t sort_cap /* keys per pass of the rank prologue (<= PW_SORT_CAP) */,
+                                              uint32_t probe /* timing probes (results wrong): 1 no main loop, 2 no sort, 4 no rank search */,
+                                              uint32_t *__restrict__ in_prev /* rows: the cells each block's last sweep started from */,
+                                              uint32_t have_prev /* 0: first sweep, in_prev holds nothing yet */,
+                                              uint32_t *__restrict__ gates_changed /* [b] = this sweep flipped a gate of block b */)
+{
+    extern __shared__ uint32_t pw_lds[];
+    __shared__ uint32_t s_w[W / 64 + 1];
+    __shared__ uint32_t s_flip;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const uint32_t b = b_first + blockIdx.x;
+    const uint32_t x0 = b * B;
+    const uint32_t x1 = nx - x0 < B ? nx : x0 + B;
+    pw_ring<PACK> ring;
+    if constexpr (PACK) {
+        ring.lo = reinterpret_cast<uint16_t *>(pw_lds);
+        ring.hi = pw_lds + ring_n / 2u;
+    } else {
+        ring.r = pw_lds;
+    }
+    if (tid == 0) s_flip = 0;
+    const uint32_t *inb = in + (size_t)b * sb;
+    PW_STAMP(8);
+    {
+        /* the sweep is a function of the entry cells alone: the same cells as last time give the same xval[] and the gates
+         * the maps of this iteration were built from -- nothing to do, no flip.  (The tail iterations change the cells
+         * of a fraction of the blocks.) */
+        uint32_t *pb = in_prev + (size_t)b * sb;
+        bool diff = !have_prev;
+        for (uint32_t i = tid; i < sb; i += W) {
+            const uint32_t a = inb[i];
+            if (a != pb[i]) { diff = true; pb[i] = a; }
+        }
+        if (!__syncthreads_or(diff) && !(out_state && x1 == nx)) {
+            for (uint32_t i = tid; i < (x1 - x0 + 63u) / 64u; i += W) gnew[(x0 >> 6) + i] = gold[(x0 >> 6) + i];
+            if (tid == 0) gates_changed[b] = 0;
+            return;
+        }
+    }
+
+    if constexpr (PACK) {
+        /* ---- ranks of the old entry values (see the header).  Entry i = q*W + tid lives in a register from the one
+         *      coalesced read of the row to the ring: val[q] holds the value until its rank is known, then its code.
+         *      Old values are positions below hi; most lie within a few windows of it, so they are ranked by COUNTING:
+         *      pass r marks the values at distance [r*D, (r+1)*D) below hi in a bitmap of D bits and a value's rank in
+         *      the pass is the number of set bits below its own (word popcounts, two levels of prefix sums).  The few
+         *      that lie further back (priorities are handed down for ever) are sorted.  A bitonic sort of all old values
+         *      (19 K of the 65535 on the S3 stream) took 300 us per block, twice the sweep proper. ---- */
+        constexpr uint32_t EPT = 65536u / W;                /* entries per thread, at most (sb <= 65535) */
+        constexpr uint32_t BM_WORDS = 24576u, BM_BITS = BM_WORDS * 32u;     /* D = 786432 = 3 << 18 positions: 96 KB */
+        constexpr uint32_t NPASS = 6u;                      /* 4.7 M positions back; beyond: the sorted tail */
+        constexpr uint32_t NCO = BM_BITS / 1024u;           /* coarse prefix entries (1024 bits each) */
+        uint32_t *bm = pw_lds;
+        uint32_t *coarse = pw_lds + BM_WORDS;
+        uint16_t *fine = reinterpret_cast<uint16_t *>(pw_lds + BM_WORDS + NCO);   /* per 256 bits, relative to coarse */
+        uint32_t *skey = pw_lds;                            /* the tail sort comes first: the bitmap's space */
+        uint32_t *cb = codes + (size_t)b * sb, *gv = gval + (size_t)b * sb;
+        const bool all_old = b == 0 && ncarried != 0;       /* carried cells hold ranks of their own: none is "its own position" */
+        const uint32_t hi = all_old ? sb : x0 + voff;       /* every old value is below hi */
+        const uint64_t lt = (1ull << lane) - 1ull;
+        __shared__ uint32_t s_cls[NPASS + 2];               /* old values per pass; [NPASS] the tail */
+        uint32_t val[EPT];
+#pragma unroll
+        for (uint32_t q = 0; q < EPT; q++) val[q] = inb[min(q * W + tid, sb - 1u)];
+        if (tid < NPASS + 2) s_cls[tid] = 0;
+        __syncthreads();
+        /* class of an entry: its bitmap pass, NPASS = tail, 7 = not old / beyond the row */
+        uint64_t oldm = 0;                                  /* bit q: entry q is old and has no rank yet */
+        uint64_t old0 = 0;                                  /* bit q: entry q is old */
+        uint32_t mycnt[NPASS];
+#pragma unroll
+        for (uint32_t r = 0; r < NPASS; r++) mycnt[r] = 0;
+#pragma unroll
+        for (uint32_t q = 0; q < EPT; q++) {
+            const uint32_t i = q * W + tid;
+            const uint32_t v = val[q];
+            const bool old = i < sb && (all_old || v != x0 + i + voff);
+            const uint32_t u = hi - 1u - v;
+            const uint32_t r = old ? (u >> 18) / 3u : 7u;
+            if (old) { oldm |= 1ull << q; old0 |= 1ull << q; }
+#pragma unroll
+            for (uint32_t k = 0; k < NPASS; k++) mycnt[k] += r == k ? 1u : 0u;
+            /* tail values go straight into the sort buffer (any order does) */
+            const bool tail = old && r >= NPASS;
+            const uint64_t bmk = __ballot(tail);
+            if (bmk) {
+                uint32_t base = 0;
+                if (lane == (uint32_t)__builtin_ctzll(bmk)) base = atomicAdd(&s_cls[NPASS], (uint32_t)__popcll(bmk));
+                base = (uint32_t)__shfl((int)base, __builtin_ctzll(bmk), 64);
+                const uint32_t slot = base + (uint32_t)__popcll(bmk & lt);
+                if (tail) {
+                    if (slot < sort_cap) skey[slot] = v;
+                    cb[i] = slot;                           /* only read back when the tail needs several passes */
+                }
+            }
+        }
+#pragma unroll
+        for (uint32_t k = 0; k < NPASS; k++) {
+            uint32_t t = mycnt[k];
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) t += (uint32_t)__shfl_xor((int)t, d, 64);
+            if (lane == 0 && t) atomicAdd(&s_cls[k], t);
+        }
+        __syncthreads();
+        const uint32_t Kt = s_cls[NPASS];
+        PW_STAMP(11);
+        /* ---- the tail: sorted, sort_cap keys a pass (one pass unless most of the window holds ancient priorities) ---- */
+        if (Kt) {
+            const bool one = Kt <= sort_cap;
+            if (!one) {
+#pragma unroll
+                for (uint32_t q = 0; q < EPT; q++) {
+                    const uint32_t i = q * W + tid;
+                    if (((oldm >> q) & 1ull) && (hi - 1u - val[q]) / BM_BITS >= NPASS) gv[i] = 0;     /* rank accumulators */
+                }
+            }
+            for (uint32_t c0 = 0; c0 < Kt; c0 += sort_cap) {
+                const uint32_t m = min(Kt - c0, sort_cap);
+                uint32_t P = 64;
+                while (P < m) P <<= 1;
+                if (c0) {
+                    __syncthreads();
+#pragma unroll
+                    for (uint32_t q = 0; q < EPT; q++) {
+                        const uint32_t i = q * W + tid;
+                        if (((oldm >> q) & 1ull) && (hi - 1u - val[q]) / BM_BITS >= NPASS) {
+                            const uint32_t sl = cb[i];
+                            if (sl >= c0 && sl < c0 + m) skey[sl - c0] = val[q];
+                        }
+                    }
+                }
+                for (uint32_t i = m + tid; i < P; i += W) skey[i] = 0xFFFFFFFFu;
+                __syncthreads();
+                for (uint32_t k = 2; k <= P && !(probe & 2u); k <<= 1) {
+                    for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+                        for (uint32_t q = tid; q < P / 2u; q += W) {
+                            const uint32_t a = ((q & ~(j - 1u)) << 1) | (q & (j - 1u)), c = a | j;
+                            const uint32_t ka = skey[a], kc = skey[c];
+                            const bool up = (a & k) == 0;
+                            if ((ka > kc) == up) { skey[a] = kc; skey[c] = ka; }
+                        }
+                        __syncthreads();
+                    }
+                }
+#pragma unroll
+                for (uint32_t q = 0; q < EPT; q++) {
+                    const uint32_t i = q * W + tid;
+                    const uint32_t v = val[q];
+                    if (((oldm >> q) & 1ull) && (hi - 1u - v) / BM_BITS >= NPASS) {
+                        uint32_t pos = 0;
+                        for (uint32_t st = P >> 1; st; st >>= 1)
+                            if (skey[pos + st - 1u] < v) pos += st;
+                        pos += skey[pos] < v ? 1u : 0u;         /* a full pass of keys that are all below v (v sits in another pass) */
+                        if (one) { gv[pos] = v; val[q] = pos; oldm &= ~(1ull << q); }
+                        else gv[i] += pos;
+                    }
+                }
+            }
+            if (!one) {
+                __syncthreads();
+                uint32_t rk[EPT / 8];                           /* (register pressure: eight entries at a time) */
+                for (uint32_t q0 = 0; q0 < EPT; q0 += EPT / 8) {
+#pragma unroll
+                    for (uint32_t k = 0; k < EPT / 8; k++) {
+                        const uint32_t q = q0 + k, i = q * W + tid;
+                        rk[k] = ((oldm >> q) & 1ull) && (hi - 1u - val[q]) / BM_BITS >= NPASS ? gv[i] : PW_NONE;
+                    }
+                    __syncthreads();                            /* (every accumulator of the slice is read before a table entry lands on one) */
+#pragma unroll
+                    for (uint32_t k = 0; k < EPT / 8; k++) {
+                        const uint32_t q = q0 + k;
+                        if (rk[k] != PW_NONE) { cb[q * W + tid] = rk[k]; }
+                    }
+                }
+                __syncthreads();
+#pragma unroll
+                for (uint32_t q = 0; q < EPT; q++) {
+                    const uint32_t i = q * W + tid;
+                    if (((oldm >> q) & 1ull) && (hi - 1u - val[q]) / BM_BITS >= NPASS) {
+                        const uint32_t rkq = cb[i];
+                        gv[rkq] = val[q];
+                        val[q] = rkq;
+                        oldm &= ~(1ull << q);
+                    }
+                }
+            }
+            __syncthreads();
+        }
+        PW_STAMP(12);
+        /* ---- the bitmap passes, oldest first: a pass's ranks follow everything older ---- */
+        uint32_t below = Kt;
+        for (int r = (int)NPASS - 1; r >= 0; r--) {
+            const uint32_t Kr = s_cls[r];
+            if (!Kr) continue;
+            for (uint32_t i = tid; i < BM_WORDS; i += W) bm[i] = 0;
+            __syncthreads();
+#pragma unroll
+            for (uint32_t q = 0; q < EPT; q++) {
+                const uint32_t u = hi - 1u - val[q];
+                if (((oldm >> q) & 1ull) && u / BM_BITS == (uint32_t)r) {
+                    const uint32_t bit = BM_BITS - 1u - (u - (uint32_t)r * BM_BITS);
+                    atomicOr(&bm[bit >> 5], 1u << (bit & 31u));
+                }
+            }
+            __syncthreads();
+            uint32_t tot = 0;
+            if (tid < NCO) {
+#pragma unroll
+                for (uint32_t w = 0; w < 32; w++) {
+                    if ((w & 7u) == 0) fine[tid * 4u + (w >> 3)] = (uint16_t)tot;
+                    tot += (uint32_t)__popc(bm[tid * 32u + w]);
+                }
+            }
+            uint32_t all;
+            const uint32_t ex = pw_block_excl<W>(tot, s_w, &all);
+            if (tid < NCO) coarse[tid] = ex;
+            __syncthreads();
+#pragma unroll
+            for (uint32_t q = 0; q < EPT; q++) {
+                const uint32_t v = val[q];
+                const uint32_t u = hi - 1u - v;
+                if (((oldm >> q) & 1ull) && u / BM_BITS == (uint32_t)r) {
+                    const uint32_t bit = BM_BITS - 1u - (u - (uint32_t)r * BM_BITS);
+                    uint32_t rk = below + coarse[bit >> 10] + (uint32_t)fine[bit >> 8];
+                    for (uint32_t w = (bit >> 8) * 8u; w < (bit >> 5); w++) rk += (uint32_t)__popc(bm[w]);
+                    rk += (uint32_t)__popc(bm[bit >> 5] & ((1u << (bit & 31u)) - 1u));
+                    gv[rk] = v;
+                    val[q] = rk;
+                    oldm &= ~(1ull << q);
+                }
+            }
+            below += Kr;
+            __syncthreads();
+        }
+        PW_STAMP(13);
+        if (blockIdx.x == 0 && tid == 0) pw_dbg[14] = Kt;
+        /* ---- codes into the ring: own positions are sb + i (the plane is filled as if every cell held its own, then
+         *      the old entries clear their bits: ranks are below 2^16) ---- */
+        for (uint32_t wd = tid; wd < ring_n / 16u; wd += W) {
+            uint32_t hw = 0;
+#pragma unroll
+            for (uint32_t k = 0; k < 16; k++) hw |= (((sb + wd * 16u + k) >> 16) & 3u) << (2u * k);
+            ring.hi[wd] = hw;
+        }
+        __syncthreads();
+#pragma unroll
+        for (uint32_t q = 0; q < EPT; q++) {
+            const uint32_t i = q * W + tid;
+            if (i < sb) {
+                const bool own = !((old0 >> q) & 1ull);
+                const uint32_t code = own ? sb + i : val[q];
+                ring.lo[i] = (uint16_t)code;
+                if (!own) {
+                    const uint32_t hb = ((sb + i) >> 16) & 3u;
+                    if (hb) atomicAnd(&ring.hi[i >> 4], ~(hb << ((i & 15u) * 2u)));
+                }
+            }
+        }
+        for (uint32_t r = sb + tid; r < ring_n; r += W) ring.lo[r] = (uint16_t)(sb + r);
+    } else {
+        for (uint32_t r = tid; r < ring_n; r += W) ring.r[r] = r < sb ? inb[r] : x0 + r + voff;
+    }
+    __syncthreads();
+
+    PW_STAMP(9);
+    constexpr uint32_t NW = W / 64;
+    const uint32_t xlast = x1 - 1u;
+    uint32_t off = 0;                                       /* ring slot of cell xg */
+    uint32_t nflip = 0;
+    /* the operands of SG groups are fetched together, one super-group ahead (unconditional, clamped loads: see
+     * k_prio_fwd): a group is about as long as a round trip to HBM under load, one group ahead was not enough */
+    constexpr int SG = 4;
+    uint32_t v[SG], vn[SG];
+    uint64_t rmw[SG], rmn[SG], gow[SG], gon[SG];
+    auto fetch = [&](uint32_t xs, uint32_t (&vv)[SG], uint64_t (&rr)[SG], uint64_t (&gg)[SG]) {
+#pragma unroll
+        for (int k = 0; k < SG; k++) {
+            const uint32_t xk = xs + (uint32_t)k * W;
+            vv[k] = ps[min(xk + tid, xlast)];
+            rr[k] = rmask[min(xk + 64u * (lane & (NW - 1u)), xlast) >> 6];
+            gg[k] = gold[min(xk + 64u * wave, xlast) >> 6];
+        }
+    };
+    fetch(x0, v, rmw, gow);
+    uint32_t pend_x = PW_NONE, pend_v = PW_NONE;           /* PACK: a handed-over old rank on its way through gval[] */
+    for (uint32_t xs = x0; xs < x1 && !(probe & 1u); xs += SG * W) {
+        fetch(xs + SG * W, vn, rmn, gon);
+#pragma unroll
+        for (int k = 0; k < SG; k++) {
+            const uint32_t xg = xs + (uint32_t)k * W;
+            if (xg >= x1) continue;                         /* (workgroup-uniform) */
+            const uint32_t x = xg + tid;
+            const uint32_t vv = x < x1 ? v[k] : 0u;
+            const uint32_t p = vv & 0xFFFFu, s = vv >> 16;
+            const bool has = p && s;
+            /* my round: round starts at or before me, minus one; rounds of the group */
+            uint32_t before = 0, nr = 0;
+            const uint32_t pc = (uint32_t)__popcll(rmw[k]);
+#pragma unroll
+            for (uint32_t w = 0; w < NW; w++) {
+                const uint32_t t = (uint32_t)__builtin_amdgcn_readlane((int)pc, (int)w);
+                before += w < wave ? t : 0u;
+                nr += t;
+            }
+            const uint64_t myw = ((uint64_t)(uint32_t)__shfl((int)(uint32_t)(rmw[k] >> 32), (int)wave, 64) << 32) |
+                                 (uint32_t)__shfl((int)(uint32_t)rmw[k], (int)wave, 64);
+            const uint32_t myr = before + (uint32_t)__popcll(myw & ((2ull << lane) - 1ull)) - 1u;
+            uint32_t ix = off + tid;
+            ix -= ix >= ring_n ? ring_n : 0u;
+            uint32_t ip = ix + p;
+            ip -= ip >= ring_n ? ring_n : 0u;
+            uint32_t is = ix + s;
+            is -= is >= ring_n ? ring_n : 0u;
+            uint32_t ng = 0, out = PW_NONE;
+            for (uint32_t r = 0; r < nr; r++) {
+                /* a round in two halves: every step of the round reads, then every step writes.  The round masks only
+                 * split where a step READS what an earlier step of the round writes; a later step of the round may well
+                 * write what an earlier one reads (its successor cell = the other's predecessor cell), and across
+                 * wavefronts nothing but a barrier orders that write behind the read (inside one wavefront the lanes run
+                 * in lockstep: k_prio_fwd) */
+                const bool mine = has && myr == r;
+                uint32_t a = 0, sv = 0;
+                bool hand = false;
+                if (mine) {
+                    a = ring.rd(ix);
+                    const uint32_t w = ring.rd(ip);
+                    sv = ring.rd(is);
+                    const bool gate = a < w;
+                    ng = gate ? 1u : 0u;                        /* the gate: x's predecessor hangs below x */
+                    hand = gate && a < sv;
+                }
+                pw_lds_barrier();
+                if (hand) { ring.wr(is, a, sv); out = a; }      /* tree.c:202-231: S takes x's place */
+                pw_lds_barrier();
+            }
+            const uint64_t gnb = __ballot(ng != 0u);
+            nflip += xg + 64u * wave < x1 ? (uint32_t)__popcll(gnb ^ gow[k]) : 0u;
+            if (lane == 0 && xg + 64u * wave < x1) gnew[(xg >> 6) + wave] = gnb;
+            if constexpr (PACK) {
+                /* the store of the group before: its table look-up had this group's rounds to arrive */
+                if (pend_x != PW_NONE) xval[pend_x] = pend_v;
+                pend_x = PW_NONE;
+                if (x < x1) {
+                    if (out != PW_NONE && out < sb) { pend_x = x; pend_v = gval[(size_t)b * sb + out]; }
+                    else xval[x] = out == PW_NONE ? PW_NONE : x0 + (out - sb) + voff;
+                }
+            } else {
+                if (x < x1) xval[x] = out;
+            }
+            /* cell xg + ring_n + tid becomes live with the next group; its slot held cell xg + tid (the lanes past the
+             * last step keep their cells: out_state) */
+            if constexpr (PACK) {
+                const uint32_t nc = sb + (xg + ring_n + tid - x0);
+                if (xg + W <= x1) {
+                    /* whole group: the plane a word (16 cells, 16 consecutive codes) at a time -- an exclusive or per cell
+                     * made 16 lanes queue on every word */
+                    ring.lo[ix] = (uint16_t)nc;
+                    if ((tid & 15u) == 0) {
+                        uint32_t hw = 0;
+#pragma unroll
+                        for (uint32_t q = 0; q < 16; q++) hw |= (((nc + q) >> 16) & 3u) << (2u * q);
+                        ring.hi[ix >> 4] = hw;
+                    }
+                } else if (x < x1) ring.put(ix, nc);
+            } else {
+                if (x < x1) ring.put(ix, xg + ring_n + tid + voff);
+            }
+            off += W;
+            off -= off >= ring_n ? ring_n : 0u;
+            pw_lds_barrier();
+        }
+#pragma unroll
+        for (int k = 0; k < SG; k++) { v[k] = vn[k]; rmw[k] = rmn[k]; gow[k] = gon[k]; }
+    }
+    if constexpr (PACK) { if (pend_x != PW_NONE) xval[pend_x] = pend_v; }
+    PW_STAMP(10);
+    if (out_state && x1 == nx) {
+        /* cells nx .. nx+sb-1, what the next segment of a long input starts from: the ring holds the cells [x1, x1 + ring_n) */
+        for (uint32_t i = tid; i < sb; i += W) {
+            const uint32_t c = ring.rd((x1 - x0 + i) % ring_n);
+            if constexpr (PACK) out_state[i] = c < sb ? gval[(size_t)b * sb + c] : x0 + (c - sb) + voff;
+            else out_state[i] = c;
+        }
+    }
+    if (lane == 0 && nflip) atomicAdd(&s_flip, nflip);
+    __syncthreads();
+    if (tid == 0) gates_changed[b] = s_flip ? 1u : 0u;
+    if (tid == 0 && s_flip) {
+        atomicAdd(&summary[0], s_flip);
+        atomicMin(&summary[1], b);
+    }
+}
+
+/* ------------------------------------------------------------------ backward sweep --- */
+
+/* dest[b][i]: the exit cell (relative to the block's end x1) that the chain of open gates starting at entry cell b*B+i
+ * reaches, or DEAD when it ends inside the block; loc[b][d]: the lowest position of the block whose chain reaches exit
+ * cell d.  loc lives in HBM (32 bits x sb do not fit beside the ring): initialised here, lowered atomically. */
+template <int W>
+__global__ __launch_bounds__(W) void k_pw_back(const uint32_t *__restrict__ ps, uint32_t nx, uint32_t sb, uint32_t B, uint32_t ring_n,
+                                               uint32_t b_first, const uint64_t *__restrict__ gates, uint16_t *__restrict__ dest,
+                                               uint32_t *__restrict__ loc, uint32_t voff, uint32_t ncarried,
+                                               const uint32_t *__restrict__ gates_changed)
+{
+    extern __shared__ uint32_t pw_lds[];
+    __shared__ uint32_t s_d[W];
+    __shared__ int s_p[W];
+    __shared__ uint32_t s_any[2];
+    __shared__ uint32_t s_tab[4096];                                   /* per group: (exit cell, lowest step that reaches it) */
+    uint16_t *dr = reinterpret_cast<uint16_t *>(pw_lds);               /* ring_n entries */
+    const uint32_t tid = threadIdx.x, wave = tid >> 6, lane = tid & 63u;
+    const uint32_t b = b_first + blockIdx.x;
+    if (gates_changed && !gates_changed[b]) return;                    /* the block's map of the last iteration still holds */
+    const uint32_t x0 = b * B;
+    const uint32_t x1 = nx - x0 < B ? nx : x0 + B;
+    uint32_t *lb = loc + (size_t)b * sb;
+    PW_STAMP(0);
+    /* what reaches exit cell x1+i when nothing older comes in: its own priority -- unless it is a carried cell (a short
+     * first block of a later segment: its value comes in through in[0]) */
+    for (uint32_t i = tid; i < sb; i += W) pw_st_wg(lb + i, x1 + i >= ncarried ? x1 + i + voff : PW_NONE);
+    for (uint32_t i = tid; i < ring_n; i += W) dr[i] = (uint16_t)PW_DEAD;
+    if (tid < 2) s_any[tid] = 0;
+    for (uint32_t i = tid; i < 4096u; i += W) s_tab[i] = 0xFFFFFFFFu;
+    pw_fence_wg();                                                     /* the rows are where the atomics will find them */
+    __syncthreads();
+    uint32_t anyk = 0;                                                 /* parity of the "anything pending" flag in use */
+    PW_STAMP(1);
+    const uint32_t ngr = (x1 - x0 + W - 1u) / W;
+    const uint32_t xlast = x1 - 1u;
+    constexpr int SG = 4;                                              /* groups fetched together: a group is far shorter than a
+                                                                          round trip to HBM, the next SG are in flight meanwhile */
+    const uint32_t nsg = (ngr + SG - 1u) / SG;
+    uint32_t off_run = (uint32_t)(((uint64_t)nsg * SG * W) % ring_n);
+    uint32_t v[SG], vn[SG];
+    uint64_t gw[SG], gwn[SG];
+    auto fetch = [&](int32_t sgi, uint32_t (&vv)[SG], uint64_t (&gg)[SG]) {       /* unconditional, clamped loads (see k_prio_fwd) */
+        const uint32_t xs = x0 + (uint32_t)(sgi < 0 ? 0 : sgi) * SG * W;
+#pragma unroll
+        for (int k = 0; k < SG; k++) {
+            vv[k] = ps[min(xs + (uint32_t)k * W + tid, xlast)];
+            gg[k] = gates[min(xs + (uint32_t)k * W + 64u * wave, xlast) >> 6];
+        }
+    };
+    fetch((int32_t)nsg - 1, v, gw);
+    for (int32_t sgi = (int32_t)nsg - 1; sgi >= 0; sgi--) {
+        fetch(sgi - 1, vn, gwn);
+#pragma unroll
+        for (int k = SG - 1; k >= 0; k--) {
+            const uint32_t xg = x0 + ((uint32_t)sgi * SG + (uint32_t)k) * W;
+            off_run = off_run >= (uint32_t)W ? off_run - W : off_run + ring_n - W;     /* = (xg - x0) % ring_n */
+            if (xg >= x1) continue;                                    /* (workgroup-uniform) */
+            const uint32_t x = xg + tid;
+            const bool valid = x < x1;
+            const uint32_t s = (valid ? v[k] : 0u) >> 16;
+            const bool gate = valid && xg + 64u * wave < x1 && ((gw[k] >> lane) & 1ull);
+            const uint32_t t = x + s;
+            uint32_t it = off_run + tid + (gate ? s : 0u);
+            it -= it >= ring_n ? ring_n : 0u;
+            const uint32_t dring = dr[it];
+            const bool past = t >= x1, near = t < xg + W;
+            uint32_t d = !gate ? (uint32_t)PW_DEAD : past ? t - x1 : near ? (uint32_t)PW_DEAD : dring;
+            int ptr = gate && !past && near ? (int)(t - xg) : -1;
+            /* chains inside the group: pointer jumping through LDS (pointers only lead to later steps).  s_any[k]: some
+             * step still has a pointer; the flag of the other parity is cleared while this one is in use (LDS-only
+             * barriers: the prefetched operands and the atomics stay in flight) */
+            for (;;) {
+                s_d[tid] = d;
+                s_p[tid] = ptr;
+                if (__ballot(ptr >= 0) && lane == 0) s_any[anyk] = 1u;
+                pw_lds_barrier();
+                const bool any = s_any[anyk] != 0u;
+                if (tid == 0) s_any[anyk ^ 1u] = 0u;
+                anyk ^= 1u;
+                if (!any) break;
+                if (ptr >= 0) {
+                    const uint32_t dn = s_d[ptr];
+                    const int pn = s_p[ptr];
+                    if (pn < 0) { d = dn; ptr = -1; } else ptr = pn;
+                }
+                pw_lds_barrier();
+            }
+            /* x's own priority reaches d -- unless x is a carried cell of a later segment (its value comes in through
+             * in[0]).  The chains of a block merge: hundreds of steps of a group reach the same few exit cells, and
+             * same-address atomics queue in the L2 at ~100 cycles each (10 K cycles a group) -- only the lowest step per
+             * exit cell goes out (a 4096-slot table; a slot taken by another cell's step: both go) */
+            const bool want = valid && d != PW_DEAD && x >= ncarried;
+            const uint32_t slot = d & 4095u;
+            if (want) atomicMin(&s_tab[slot], (d << 10) | tid);
+            pw_lds_barrier();
+            if (valid) {
+                uint32_t ix = off_run + tid;
+                ix -= ix >= ring_n ? ring_n : 0u;
+                dr[ix] = (uint16_t)d;
+                if (want) {
+                    const uint32_t e = s_tab[slot];
+                    if ((e >> 10) != d || (e & 1023u) == tid) pw_min_wg(&lb[d], x + voff);
+                }
+            }
+            pw_lds_barrier();
+            if (want) s_tab[slot] = 0xFFFFFFFFu;                       /* (the next group's first barrier comes before its first use) */
+        }
+#pragma unroll
+        for (int k = 0; k < SG; k++) { v[k] = vn[k]; gw[k] = gwn[k]; }
+    }
+    PW_STAMP(2);
+    for (uint32_t i = tid; i < sb; i += W) {
+        /* an entry cell that is not evicted inside a (short, last) block is still live at its end */
+        dest[(size_t)b * sb + i] = x0 + i < x1 ? dr[i] : (uint16_t)(i - (x1 - x0));
+    }
+    PW_STAMP(3);
+    if (blockIdx.x == 0 && threadIdx.x == 0) pw_dbg[4] = ngr;
+}
+
+/* ------------------------------------------------------------------ boundary scan ---- */
+
+/* in[j+1] = F_j(in[j]),  F_j(v)[d] = min(loc_j[d], min{ v[c] : dest_j[c] = d }),  groups of G maps as in k_prio_scan_*:
+ * compose each group's maps, run the group maps in sequence, replay every group.  A vector of sb priorities does not fit
+ * LDS twice, so it lives in REGISTERS: one workgroup of 512 threads per group, thread t keeps the cells c = q*512 + t
+ * (128 values), and a map is applied through LDS in two halves of the destination range -- cells with a live value lower
+ * acc[dest] (LDS atomics), every thread then takes its own cells back.  Nothing of the running vector goes through HBM
+ * (the rows are only written out, for the sweeps), and no global atomic is involved: the first versions applied a map with
+ * global atomicMin -- many cells share a destination (the chains of a block merge), and same-address atomics queue in
+ * the L2 at ~100 cycles each: 2-5 ms per launch. */
+#define PW_SCAN_T 512u                  /* 512 threads: 256 VGPRs each -- the 128 cells of a thread plus a batch of operands
+                                           (1024 threads x 64 cells spilled 800 registers) */
+#define PW_SCAN_EPT 128u
+#define PW_SCAN_HALF 32768u
+
+/* val[q] (cell q*T + tid) -> the vector after the map (dest row dj, loc row lj); `row` (sb words in HBM) receives it
+ * too.  The whole register file of a CU is 64 K cells x 8 bytes: there is room for the vector, the map's destinations
+ * (16 bits a cell) and a batch of operands, so the first half of the new vector waits in `row` (a thread reads back what
+ * it stored itself) while the old one still feeds the second half.  acc[] (32 K words of LDS) starts each half as the
+ * map's loc for the cells of that half; the cells with a live value then lower their destination.  A step is about
+ * six round trips to memory (destinations; loc in four batches, each fetched before the barrier it is needed behind;
+ * the read-back): the first version re-read the destinations per phase in batches of 16 -- 44 round trips, 41 us. */
+__device__ __forceinline__ void pw_apply_map(uint32_t (&val)[PW_SCAN_EPT], const uint16_t *__restrict__ dj, const uint32_t *__restrict__ lj,
+                                             uint32_t sb, uint32_t *acc, uint32_t *row)
+{
+    constexpr uint32_t BQ = 8;                              /* pairs per batch of operands */
+    constexpr uint32_t NP = PW_SCAN_EPT / 2;                /* a thread's cells are NP adjacent pairs: cells 2P, 2P+1, P = q*T + tid */
+    /* every phase works from an opaque copy of the thread index: the cell offsets are loop invariants, and hoisted out
+     * of the map loop (and shared between the phases) they took every register the vector had left */
+#define PW_TB() uint32_t tb = threadIdx.x; asm volatile("" : "+v"(tb))
+    uint32_t dd[NP];                                        /* destinations of a pair: one (unaligned) 32-bit load; DEAD: nothing to send */
+    {
+        PW_TB();
+#pragma unroll
+        for (uint32_t q = 0; q < NP; q++) {
+            const uint32_t c0 = 2u * (q * PW_SCAN_T + tb);
+            dd[q] = ld32u(reinterpret_cast<const uint8_t *>(dj + min(c0, sb - 2u)));
+            if ((q & 7u) == 7u) __builtin_amdgcn_sched_barrier(0);       /* (eight addresses at a time in registers) */
+        }
+#pragma unroll
+        for (uint32_t q = 0; q < NP; q++) {
+            const uint32_t c0 = 2u * (q * PW_SCAN_T + tb);
+            if (c0 + 1u >= sb) dd[q] = c0 < sb ? (uint32_t)dj[c0] | 0xFFFF0000u : 0xFFFFFFFFu;      /* (the last pair of an odd row) */
+            if (val[2 * q] == PW_NONE) dd[q] |= 0xFFFFu;
+            if (val[2 * q + 1] == PW_NONE) dd[q] |= 0xFFFF0000u;
+        }
+    }
+#pragma unroll
+    for (uint32_t h = 0; h < 2; h++) {
+        const uint32_t base = h * PW_SCAN_HALF;
+        /* acc <- loc for my cells of this half, a batch at a time */
+#pragma unroll
+        for (uint32_t q0 = h * (NP / 2); q0 < (h + 1) * (NP / 2); q0 += BQ) {
+            PW_TB();
+            uint32_t l0[BQ], l1[BQ];
+#pragma unroll
+            for (uint32_t k = 0; k < BQ; k++) {
+                const uint32_t c0 = 2u * ((q0 + k) * PW_SCAN_T + tb);
+                l0[k] = lj[min(c0, sb - 1u)];
+                l1[k] = lj[min(c0 + 1u, sb - 1u)];
+            }
+#pragma unroll
+            for (uint32_t k = 0; k < BQ; k++) {
+                const uint32_t c0 = 2u * ((q0 + k) * PW_SCAN_T + tb);
+                acc[c0 - base] = l0[k];
+                acc[c0 + 1u - base] = l1[k];
+            }
+        }
+        pw_lds_barrier();
+#pragma unroll
+        for (uint32_t q = 0; q < NP; q++) {
+            const uint32_t d0 = dd[q] & 0xFFFFu, d1 = dd[q] >> 16;
+            if (d0 != PW_DEAD && (d0 >> 15) == h) atomicMin(&acc[d0 - base], val[2 * q]);
+            if (d1 != PW_DEAD && (d1 >> 15) == h) atomicMin(&acc[d1 - base], val[2 * q + 1]);
+        }
+        pw_lds_barrier();
+#pragma unroll
+        for (uint32_t q0 = h * (NP / 2); q0 < (h + 1) * (NP / 2); q0 += BQ) {    /* my cells of this half */
+            PW_TB();
+#pragma unroll
+            for (uint32_t k = 0; k < BQ; k++) {
+                const uint32_t q = q0 + k;
+                const uint32_t c0 = 2u * (q * PW_SCAN_T + tb);
+                const uint32_t n0 = acc[c0 - base], n1 = acc[c0 + 1u - base];
+                if (c0 < sb) row[c0] = n0;
+                if (c0 + 1u < sb) row[c0 + 1u] = n1;
+                if (h == 1) { val[2 * q] = n0; val[2 * q + 1] = n1; }          /* (the old second half has fed both scatters) */
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                  /* (a batch of LDS reads at a time in registers) */
+        }
+        pw_lds_barrier();
+    }
+    /* the first half of the new vector: what this thread stored itself (same wavefront, same addresses: in order) */
+#pragma unroll
+    for (uint32_t q0 = 0; q0 < NP / 2; q0 += BQ) {
+        PW_TB();
+        uint32_t *rw = row;
+        asm volatile("" : "+s"(rw) :: "memory");             /* (a fresh pointer: not the values just stored, kept in registers) */
+        const __attribute__((address_space(1))) uint32_t *rg = (const __attribute__((address_space(1))) uint32_t *)rw;   /* (global, not flat) */
+#pragma unroll
+        for (uint32_t k = 0; k < BQ; k++) {
+            const uint32_t c0 = 2u * ((q0 + k) * PW_SCAN_T + tb);
+            val[2 * (q0 + k)] = rg[min(c0, sb - 1u)];
+            val[2 * (q0 + k) + 1] = rg[min(c0 + 1u, sb - 1u)];
+        }
+    }
+#undef PW_TB
+}
+
+/* group g = blockIdx.x applies its maps m0 .. m1-1 (map number m is row `first + m` of dest / loc) in sequence.
+ * REPLAY: from row g of vin; row `first + m + 1` of `v` receives the vector after map m.
+ * else (compose, loc half): from "nothing" (the identity map); row g of `v` receives what the group's maps send to each
+ * exit cell from inside the group (it is overwritten map after map: only the last state counts) */
+template <bool REPLAY>
+__global__ __launch_bounds__(PW_SCAN_T) void k_pw_maps(const uint16_t *__restrict__ dest, const uint32_t *__restrict__ loc, uint32_t sb, uint32_t first,
+                                                       uint32_t nmaps, uint32_t G, const uint32_t *vin, uint32_t *v)
+{
+    extern __shared__ uint32_t pw_lds[];
+    const uint32_t g = blockIdx.x, tid = threadIdx.x;
+    const uint32_t m0 = g * G, m1 = min(m0 + G, nmaps);
+    if (m0 >= m1) return;
+    uint32_t val[PW_SCAN_EPT];
+    if constexpr (REPLAY) {
+        const uint32_t *src = vin + (size_t)g * sb;
+#pragma unroll
+        for (uint32_t q = 0; q < PW_SCAN_EPT / 2; q++) {
+            const uint32_t c0 = 2u * (q * PW_SCAN_T + tid);
+            val[2 * q] = src[min(c0, sb - 1u)];
+            val[2 * q + 1] = src[min(c0 + 1u, sb - 1u)];
+            if ((q & 7u) == 7u) __builtin_amdgcn_sched_barrier(0);
+        }
+    } else {
+#pragma unroll
+        for (uint32_t q = 0; q < PW_SCAN_EPT; q++) val[q] = PW_NONE;
+    }
+    for (uint32_t m = m0; m < m1; m++) {
+        const size_t j = (size_t)first + m;
+        pw_apply_map(val, dest + j * sb, loc + j * sb, sb, pw_lds, REPLAY ? v + (j + 1) * sb : v + (size_t)g * sb);
+    }
+}
+
+/* the dest half of a group's composed map: gdest[g][c] = the exit cell entry cell c reaches through all the group's
+ * maps (or DEAD): 16 bits a cell in registers, one gather per map */
+__global__ __launch_bounds__(PW_SCAN_T) void k_pw_cdest(const uint16_t *__restrict__ dest, uint32_t sb, uint32_t first, uint32_t nmaps, uint32_t G,
+                                                        uint16_t *__restrict__ gdest)
+{
+    const uint32_t g = blockIdx.x, tid = threadIdx.x;
+    const uint32_t m0 = g * G, m1 = min(m0 + G, nmaps);
+    if (m0 >= m1) return;
+    uint32_t cd[PW_SCAN_EPT];
+#pragma unroll
+    for (uint32_t q = 0; q < PW_SCAN_EPT; q++) cd[q] = q * PW_SCAN_T + tid < sb ? q * PW_SCAN_T + tid : (uint32_t)PW_DEAD;
+    for (uint32_t m = m0; m < m1; m++) {
+        const uint16_t *dj = dest + ((size_t)first + m) * sb;
+#pragma unroll
+        for (uint32_t q = 0; q < PW_SCAN_EPT; q++) cd[q] = cd[q] == PW_DEAD ? (uint32_t)PW_DEAD : (uint32_t)dj[min(cd[q], sb - 1u)];
+    }
+#pragma unroll
+    for (uint32_t q = 0; q < PW_SCAN_EPT; q++)
+        if (q * PW_SCAN_T + tid < sb) gdest[(size_t)g * sb + q * PW_SCAN_T + tid] = (uint16_t)cd[q];
+}
+
+/* ------------------------------------------------------------------ launchers -------- */
+
+void lz77kw_debug_dump(void)
+{
+    if (!getenv("LZ77X_PW_DEBUG")) return;
+    unsigned long long h[64];
+    if (hipMemcpyFromSymbol(h, HIP_SYMBOL(pw_dbg), sizeof h) != hipSuccess) return;
+    fprintf(stderr, "[pw] back wg0: init %llu loop %llu (%llu groups: %llu each) out %llu cycles | fwd wg0: prologue %llu (classify %llu, tail of %llu keys %llu, bitmaps %llu, ring %llu) loop %llu | prep wg0: %llu cycles, %llu rounds, %llu groups\n",
+            h[1] - h[0], h[2] - h[1], h[4], h[4] ? (h[2] - h[1]) / h[4] : 0ull, h[3] - h[2], h[9] - h[8], h[11] - h[8], h[14], h[12] - h[11], h[13] - h[12],
+            h[9] - h[13], h[10] - h[9], h[17] - h[16], h[18], h[19]);
+}
+
+uint32_t lz77kw_width(int sb)
+{
+    const char *e = getenv("LZ77X_PRIO_WIDE");
+    if (e) { const int w = atoi(e); if (w == 256 || w == 1024) return (uint32_t)w; if (w == 64) return 64u; }
+    return sb > 4096 ? 1024u : 64u;
+}
+
+/* the ring of a W-wide sweep: 32-bit priorities while they fit the LDS of a CU, else 18-bit codes */
+bool lz77kw_pack18(uint32_t ring_n) { return (size_t)ring_n * 4 > (size_t)150 * 1024; }
+
+template <class K> static hipError_t pw_lds_attr(K kern, size_t lds)
+{
+    if (lds <= 48 * 1024) return hipSuccess;
+    return hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+}
+
+hipError_t lz77kw_prep(const uint32_t *d_ps, uint32_t nx, uint32_t sb_r, uint32_t W, uint64_t *d_rmask, uint64_t *d_gate0, hipStream_t s)
+{
+    const uint32_t tagn = sb_r + W;                        /* cells a group can touch, relative to its first step */
+    const size_t lds = (size_t)tagn * 2;
+    const uint32_t ngroups = (nx + W - 1u) / W;
+    hipError_t e;
+    if (W == 1024u) {
+        if ((e = pw_lds_attr(k_pw_prep<1024>, lds)) != hipSuccess) return e;
+        const uint32_t per_cu = (uint32_t)std::max<size_t>(1, std::min<size_t>(2, ((size_t)160 * 1024) / (lds + 64)));
+        hipLaunchKernelGGL(k_pw_prep<1024>, dim3(std::min(ngroups, 256u * per_cu)), dim3(1024), lds, s, d_ps, nx, tagn, d_rmask, d_gate0);
+    } else {
+        if ((e = pw_lds_attr(k_pw_prep<256>, lds)) != hipSuccess) return e;
+        hipLaunchKernelGGL(k_pw_prep<256>, dim3(std::min(ngroups, 256u * 8u)), dim3(256), lds, s, d_ps, nx, tagn, d_rmask, d_gate0);
+    }
+    return hipGetLastError();
+}
+
+hipError_t lz77kw_fwd(const uint32_t *d_ps, uint32_t nx, uint32_t sb, uint32_t B, uint32_t ring_n, uint32_t W, uint32_t b_first, uint32_t nb,
+                      const uint64_t *d_rmask, const uint64_t *d_gold, uint64_t *d_gnew, const uint32_t *d_in, uint32_t *d_xval,
+                      uint32_t *d_summary, uint32_t voff, uint32_t *d_out_state, uint32_t ncarried, uint32_t *d_codes, uint32_t *d_gval,
+                      uint32_t *d_in_prev, uint32_t have_prev, uint32_t *d_gates_changed, hipStream_t s)
+{
+    const bool pack = lz77kw_pack18(ring_n);
+    hipError_t e;
+    uint32_t sort_cap = PW_SORT_CAP;
+    {
+        const char *ce = getenv("LZ77X_PRIO_SORTCAP");      /* test hook: several passes of the rank prologue on small inputs */
+        if (ce && atoi(ce) >= 64 && (uint32_t)atoi(ce) < PW_SORT_CAP) sort_cap = (uint32_t)atoi(ce);
+    }
+    const uint32_t probe = getenv("LZ77X_PW_PROBE") ? (uint32_t)atoi(getenv("LZ77X_PW_PROBE")) : 0u;
+#define PW_FWD(WW, PK, LDS)                                                                                                        \
+    do {                                                                                                                           \
+        if ((e = pw_lds_attr(k_pw_fwd<WW, PK>, (LDS))) != hipSuccess) return e;                                                    \
+        hipLaunchKernelGGL((k_pw_fwd<WW, PK>), dim3(nb), dim3(WW), (LDS), s, d_ps, nx, sb, B, ring_n, b_first, d_rmask, d_gold, d_gnew, \
+                           d_in, d_xval, d_summary, voff, d_out_state, ncarried, d_codes, d_gval, sort_cap, probe, d_in_prev, have_prev, d_gates_changed); \
+    } while (0)
+    if (pack) {
+        /* the uint16 ring + the 2-bit plane; the rank prologue sorts up to PW_SORT_CAP keys in the same space */
+        const size_t lds = std::max((size_t)ring_n * 2 + (size_t)ring_n / 4, (size_t)PW_SORT_CAP * 4);
+        if (W != 1024u) return hipErrorInvalidValue;
+        PW_FWD(1024, true, lds);
+    } else {
+        const size_t lds = (size_t)ring_n * 4;
+        if (W == 1024u) PW_FWD(1024, false, lds); else PW_FWD(256, false, lds);
+    }
+#undef PW_FWD
+    return hipGetLastError();
+}
+
+hipError_t lz77kw_back(const uint32_t *d_ps, uint32_t nx, uint32_t sb, uint32_t B, uint32_t ring_n, uint32_t W, uint32_t b_first, uint32_t nb,
+                       const uint64_t *d_gates, uint16_t *d_dest, uint32_t *d_loc, uint32_t voff, uint32_t ncarried, const uint32_t *d_gates_changed,
+                       hipStream_t s)
+{
+    const size_t lds = (size_t)ring_n * 2;
+    hipError_t e;
+    if (W == 1024u) {
+        if ((e = pw_lds_attr(k_pw_back<1024>, lds)) != hipSuccess) return e;
+        hipLaunchKernelGGL(k_pw_back<1024>, dim3(nb), dim3(1024), lds, s, d_ps, nx, sb, B, ring_n, b_first, d_gates, d_dest, d_loc, voff, ncarried, d_gates_changed);
+    } else {
+        if ((e = pw_lds_attr(k_pw_back<256>, lds)) != hipSuccess) return e;
+        hipLaunchKernelGGL(k_pw_back<256>, dim3(nb), dim3(256), lds, s, d_ps, nx, sb, B, ring_n, b_first, d_gates, d_dest, d_loc, voff, ncarried, d_gates_changed);
+    }
+    return hipGetLastError();
+}
+
+/* the scan's own workspace: the composed maps and inputs of the groups of groups (second level) */
+size_t lz77kw_scan_tmp_bytes(uint32_t NG, uint32_t sb)
+{
+    uint32_t G2 = 1;
+    while ((uint64_t)G2 * G2 < NG) G2++;
+    const size_t NG2 = (NG + G2 - 1) / G2 + 6;              /* (+ slack: the scan sizes its groups from the maps it is given) */
+    return NG2 * sb * (2 + 4 + 4) + 1024;
+}
+
+/* in rows first+1 .. first+nmaps from in[first] through the maps first .. first+nmaps-1, groups of G.
+ * gdest/gloc/gin: NG+2 rows each.  A workgroup moves ~25 GB/s and a map is 0.8 MB to apply, so what counts is how many
+ * groups work at once and how few maps each applies in sequence: the group maps are scanned the same way, recursively
+ * (1630 blocks: 136 groups of 12, 12 groups of 12 of those -- 59 maps in sequence instead of 121, 136 workgroups wide
+ * instead of 40) */
+hipError_t lz77kw_scan(const uint16_t *d_dest, const uint32_t *d_loc, uint32_t *d_in, uint32_t sb, uint32_t first, uint32_t nmaps, uint32_t G,
+                       uint16_t *d_gdest, uint32_t *d_gloc, uint32_t *d_gin, void *d_tmp, hipStream_t s)
+{
+    if (!nmaps) return hipSuccess;
+    const uint32_t NG = (nmaps + G - 1u) / G;
+    const size_t lds = (size_t)PW_SCAN_HALF * 4;
+    hipError_t e;
+    if ((e = pw_lds_attr(k_pw_maps<true>, lds)) != hipSuccess) return e;
+    if ((e = pw_lds_attr(k_pw_maps<false>, lds)) != hipSuccess) return e;
+    const uint32_t *vin = d_in + (size_t)first * sb;
+    if (NG > 1) {
+        /* the groups' composed maps (the last group's is nobody's input) */
+        hipLaunchKernelGGL(k_pw_cdest, dim3(NG - 1u), dim3(PW_SCAN_T), 0, s, d_dest, sb, first, nmaps, G, d_gdest);
+        hipLaunchKernelGGL(k_pw_maps<false>, dim3(NG - 1u), dim3(PW_SCAN_T), lds, s, d_dest, d_loc, sb, first, nmaps, G, (const uint32_t *)nullptr, d_gloc);
+        /* gin[0] = in[first]; gin[g+1] = group map g applied to gin[g] */
+        if ((e = hipMemcpyAsync(d_gin, d_in + (size_t)first * sb, (size_t)sb * 4, hipMemcpyDeviceToDevice, s)) != hipSuccess) return e;
+        if (d_tmp && NG - 1u > 16u) {
+            uint32_t G2 = 1;
+            while ((uint64_t)G2 * G2 < NG - 1u) G2++;
+            const size_t NG2 = (NG - 1u + G2 - 1) / G2 + 2;
+            uint8_t *t = reinterpret_cast<uint8_t *>(d_tmp);
+            uint32_t *gloc2 = reinterpret_cast<uint32_t *>(t);
+            uint32_t *gin2 = gloc2 + NG2 * sb;
+            uint16_t *gdest2 = reinterpret_cast<uint16_t *>(gin2 + NG2 * sb);
+            if ((e = lz77kw_scan(d_gdest, d_gloc, d_gin, sb, 0u, NG - 1u, G2, gdest2, gloc2, gin2, nullptr, s)) != hipSuccess) return e;
+        } else {
+            hipLaunchKernelGGL(k_pw_maps<true>, dim3(1), dim3(PW_SCAN_T), lds, s, d_gdest, d_gloc, sb, 0u, NG - 1u, NG - 1u, d_gin, d_gin);
+        }
+        vin = d_gin;
+    }
+    /* every group from its input (row g of gin; a single group: in[first] itself) */
+    hipLaunchKernelGGL(k_pw_maps<true>, dim3(NG), dim3(PW_SCAN_T), lds, s, d_dest, d_loc, sb, first, nmaps, G, vin, d_in);
+    return hipGetLastError();
+}

@@ -110,7 +110,8 @@ hipError_t lz77k_scan_u32(const uint32_t *d_in, uint32_t *d_out, uint32_t m, voi
 /* ---- device-resident sequential stages (k_prio.hip, k_chain.hip) ---- */
 
 /* The priority recurrence (SURVEY A.5 stage B, tree.c:202-231) on the device: xval[x] for x < nx from
- * ps[] (distances P | S << 16).  Supported for sb <= 4096 (the live cells of a sweep are an LDS ring).
+ * ps[] (distances P | S << 16).  sb <= 4096: a wavefront per block, the live cells a ring of priorities in LDS
+ * (k_prio.hip); above: a workgroup per block, 18-bit codes in the ring, boundary scan through HBM (k_priow.hip).
  * h_flag: 8 bytes of pinned host memory.  Synchronises the stream once per iteration; *converged = 0
  * when max_iters did not suffice (the caller then runs the host recurrence instead). */
 size_t lz77k_prio_tmp_bytes(uint32_t nx, int sb);
@@ -132,12 +133,32 @@ struct lz77k_prio_plan {
     void *tmp = nullptr;
     uint32_t nx = 0, sb = 0, voff = 0, ncarried = 0;
     uint32_t B = 0, NB = 0, ngroups = 0, sb_r = 0, ring_n = 0, G = 0, NG = 0;
+    uint32_t W = 64;          /* steps a sweep takes together: 64 = one wavefront per block (k_prio.hip), 256 / 1024 = a workgroup (k_priow.hip) */
+    bool pack18 = false;      /* W > 64: the ring holds 18-bit codes (rank of an old value | block-local position), not priorities */
     size_t o_gate[2] = {0, 0}, o_rmask = 0, o_dest = 0, o_loc = 0, o_in = 0, o_gdest = 0, o_gloc = 0, o_gin = 0, o_sum = 0, o_dirty = 0, total = 0;
+    size_t o_codes = 0, o_gval = 0, o_scan = 0, o_inprev = 0;      /* pack18: per-block rows entry cell -> code, rank -> value; sb > 4096: the HBM scan's running pairs */
     int cur = 0;              /* gate buffer the next maps/sweep read */
     uint32_t sweeps = 0;      /* sweeps so far (the first one visits every block) */
     bool in0_dirty = false;   /* the cells block 0 starts from were replaced (lz77k_prio_set_in0) since its last sweep */
     uint32_t first = 0;       /* blocks before it are final */
 };
+/* k_priow.hip: the sweeps with a workgroup of W threads per block, the boundary scan through HBM (windows whose
+ * vectors of sb priorities do not fit LDS) */
+uint32_t lz77kw_width(int sb);
+void lz77kw_debug_dump(void);
+bool lz77kw_pack18(uint32_t ring_n);
+hipError_t lz77kw_prep(const uint32_t *d_ps, uint32_t nx, uint32_t sb_r, uint32_t W, uint64_t *d_rmask, uint64_t *d_gate0, hipStream_t s);
+hipError_t lz77kw_fwd(const uint32_t *d_ps, uint32_t nx, uint32_t sb, uint32_t B, uint32_t ring_n, uint32_t W, uint32_t b_first, uint32_t nb,
+                      const uint64_t *d_rmask, const uint64_t *d_gold, uint64_t *d_gnew, const uint32_t *d_in, uint32_t *d_xval,
+                      uint32_t *d_summary, uint32_t voff, uint32_t *d_out_state, uint32_t ncarried, uint32_t *d_codes, uint32_t *d_gval,
+                      uint32_t *d_in_prev, uint32_t have_prev, uint32_t *d_gates_changed, hipStream_t s);
+hipError_t lz77kw_back(const uint32_t *d_ps, uint32_t nx, uint32_t sb, uint32_t B, uint32_t ring_n, uint32_t W, uint32_t b_first, uint32_t nb,
+                       const uint64_t *d_gates, uint16_t *d_dest, uint32_t *d_loc, uint32_t voff, uint32_t ncarried, const uint32_t *d_gates_changed,
+                       hipStream_t s);
+size_t lz77kw_scan_tmp_bytes(uint32_t NG, uint32_t sb);
+hipError_t lz77kw_scan(const uint16_t *d_dest, const uint32_t *d_loc, uint32_t *d_in, uint32_t sb, uint32_t first, uint32_t nmaps, uint32_t G,
+                       uint16_t *d_gdest, uint32_t *d_gloc, uint32_t *d_gin, void *d_tmp, hipStream_t s);
+
 hipError_t lz77k_prio_begin(lz77k_prio_plan &P, const uint32_t *d_ps, uint32_t nx, int sb, uint32_t *d_xval, void *d_tmp, uint32_t voff,
                             const uint32_t *d_carried, hipStream_t s);
 hipError_t lz77k_prio_set_in0(lz77k_prio_plan &P, const uint32_t *h_or_d_in0, hipMemcpyKind kind, hipStream_t s);

@@ -1441,7 +1441,8 @@ int seg_front(SegJob &J, const lz77x_geom &g)
         /* 3 GB of scratch: 100 MB at C1 (8138 regions of 287 KB) in ONE launch -- the walkers are latency bound (a
          * launch takes its fill + 2048 steps whatever its size), a second launch is a second 0.75 ms */
         const size_t per = lz77k_match_scratch_bytes(g, 1);
-        const uint32_t fit = (uint32_t)(((size_t)3 << 30) / per);
+        /* (large windows: 16 GB -- their walkers are latency bound too and a region's scratch is 16x a small window's) */
+        const uint32_t fit = (uint32_t)(((size_t)(g.fast ? 3 : 16) << 30) / per);
         if (batch > fit) batch = fit ? fit : 1;
         const char *gs = getenv("LZ77X_MATCH_BATCH");
         if (gs && atoi(gs) > 0 && (uint32_t)atoi(gs) < batch) batch = (uint32_t)atoi(gs);
@@ -1451,9 +1452,11 @@ int seg_front(SegJob &J, const lz77x_geom &g)
     if ((rc = c.ps.need((np + 8) * 4))) return rc;
     if ((rc = c.maxlen.need(np + 64))) return rc;
     /* the regions' sorted order stays resident for the tie-break (RP uint16 per region: 2.7 B per input byte) */
-    const bool keep_order = g.fast && J.tvariant == 0 && !getenv("LZ77X_TOKENS_BUCKET");
-    if (keep_order && (rc = c.ranks_all.need((size_t)nregions * g.RP * 2 + 64))) return rc;
+    const bool keep_order = J.tvariant == 0 && !(g.fast && getenv("LZ77X_TOKENS_BUCKET"));
+    /* large windows: rank + inverse arrays, (2RP + 8) words per region, for the rank-order tie-break */
+    if (keep_order && (rc = c.ranks_all.need(g.fast ? (size_t)nregions * g.RP * 2 + 64 : (size_t)nregions * (2 * (size_t)g.RP + 8) * sizeof(uint32_t)))) return rc;
     J.d_order = keep_order ? c.ranks_all.as<uint32_t>() : nullptr;
+    if (!g.fast && !keep_order && (rc = c.bidx.need(lz77k_tokens_index_bytes(g, (size_t)J.nloc)))) return rc;
     const uint32_t nlaunch = (nregions + batch - 1) / batch;
     while (c.sort_ev.size() < 3 * (size_t)nlaunch) { hipEvent_t e; HIPCHK(hipEventCreate(&e)); c.sort_ev.push_back(e); }
     while (c.match_ev.size() < 8) { hipEvent_t e; HIPCHK(hipEventCreate(&e)); c.match_ev.push_back(e); }
@@ -1608,10 +1611,13 @@ int seg_tokens(SegJob &J, const lz77x_geom &g, const SegCarry &carry)
             const uint32_t dbase = b > usb ? (uint32_t)(b - usb) : 0u;
             const uint32_t xa = dbase > (uint32_t)g.sb ? dbase - (uint32_t)g.sb : 0u;
             const size_t x_new = ci == 0 ? 0 : (b > usb ? b - usb : 0);
+            /* (destination blocks build their lists in LDS from the evictions of the sb positions before them: a 9-fold
+             * re-read at sb = 65535; large windows count and place through HBM instead) */
             HIPCHK(lz77k_xfer_index(c.ps.as<uint32_t>(), c.xval.as<uint32_t>(), xa, (uint32_t)x_done, dbase, (uint32_t)e, c.ofs.as<uint32_t>(),
-                                    c.ent.as<uint2>(), c.scantmp.p, s, (uint32_t)x_new, c.flag.as<unsigned long long>() + 1, (uint32_t)g.sb));
+                                    c.ent.as<uint2>(), c.scantmp.p, s, (uint32_t)x_new, c.flag.as<unsigned long long>() + 1, g.fast ? (uint32_t)g.sb : 0u));
             HIPCHK(lz77k_tokens(c.in.as<uint8_t>(), J.nloc, g, c.chain.as<uint32_t>() + ta, tb - ta, c.maxlen.as<uint8_t>(), c.ofs.as<uint32_t>(),
-                                c.ent.as<uint2>(), dbase, (uint32_t)b, (uint32_t)e, tokbuf + 4 + ta, c.tstart.as<uint32_t>(), nullptr,
+                                c.ent.as<uint2>(), dbase, (uint32_t)b, (uint32_t)e, tokbuf + 4 + ta, c.tstart.as<uint32_t>(),
+                                g.fast || J.d_order ? nullptr : c.bidx.p,
                                 J.tvariant, s, &c.tie_ev[2 * ci], J.d_order, J.first ? nullptr : look_cur, J.nlook, 0u));
             J.tie_timed[ci] = tb > ta;
         }
@@ -2207,7 +2213,7 @@ int encode_sharded(std::vector<Ctx *> &cs, const uint8_t *src, size_t n, const l
 bool device_pipeline_ok(size_t ndev, const lz77x_geom &g)
 {
     const char *hs = getenv("LZ77X_HOST_STAGEB"), *vs = getenv("LZ77X_MATCH_VARIANT");
-    return ndev == 1 && g.fast && g.shifted && lz77k_prio_supported(g.sb) && !(hs && atoi(hs)) && !(vs && atoi(vs)) && !getenv("LZ77X_SERIAL");
+    return ndev == 1 && g.shifted && lz77k_prio_supported(g.sb) && !(hs && atoi(hs)) && !(vs && atoi(vs)) && !getenv("LZ77X_SERIAL");
 }
 
 /* memory -> sink.  src: host or device pointer of n bytes */
@@ -2217,7 +2223,9 @@ int encode_any(std::vector<Ctx *> &cs, const void *src, bool src_on_device, size
     const void *host_src = src;
     bool host_on_device = src_on_device;
     uint32_t iters = 0;                                    /* gate iterations spent before giving up */
-    if (cs.size() > 1 && !src_on_device && device_pipeline_ok(1, g))
+    /* (large windows: the shards' whole-plan maps would have to be composed through HBM; they take the host-assisted
+     * pipeline, which shards by chunks) */
+    if (cs.size() > 1 && !src_on_device && g.fast && device_pipeline_ok(1, g))
         return encode_sharded(cs, reinterpret_cast<const uint8_t *>(src), n, g, sink);
     if (device_pipeline_ok(cs.size(), g)) {
         MemSource ms(src, n, src_on_device);

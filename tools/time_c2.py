@@ -19,7 +19,7 @@ for it in range(int(os.environ.get("ITERS", 3))):
     torch.cuda.synchronize(); t1 = time.perf_counter()
     s = L.last_stats()
     print("encode %.1f ms (%.0f MB/s)" % ((t1 - t0) * 1e3, n / (t1 - t0) / 1e6),
-          {k: round(s[k], 1) for k in ("k_match_ms", "k_sort_ms", "k_walk_ms", "k_token_ms", "k_tiebreak_ms", "host_chain_ms", "host_stageb_ms")}, flush=True)
+          {k: round(s[k], 1) for k in ("k_match_ms", "k_sort_ms", "k_walk_ms", "k_token_ms", "k_tiebreak_ms", "k_chain_ms", "k_prio_ms", "k_prio_fwd_ms", "k_prio_back_ms", "k_prio_scan_ms", "prio_iters", "host_chain_ms", "host_stageb_ms")}, flush=True)
 sha = hashlib.sha256(d_z[:zn].cpu().numpy().tobytes()).hexdigest()
 gold = [r for r in json.load(open(os.path.join(ROOT, "tests", "golden", "golden_full.json")))["full"] if (r["kind"], r["n"], r["sb"], r["la"]) == (kind, n, sb, la)]
 print("zn", zn, "sha", sha[:16], "golden", (gold[0]["sha256_lz"][:16], gold[0]["sha256_lz"] == sha) if gold else None)
