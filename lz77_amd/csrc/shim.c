@@ -16,9 +16,11 @@
  * message on stdout and returns (lz77.c:79-82); device failures are reported on stderr and end the
  * process with EXIT_FAILURE like the reference's own fatal path (lz77.c:273-277).
  */
+#define _GNU_SOURCE                                                     /* fopencookie */
 #include "../../include/lz77_mi355x.h"
 #include <stdlib.h>
 #include <string.h>
+#include <sys/types.h>
 
 struct bitFILE;                                                         /* bitio.h:18, opaque */
 int bitIO_write(struct bitFILE *bitF, void *info, int nbit);           /* bitio.h:30 */
@@ -35,56 +37,54 @@ static void die(const char *what, int rc)
     exit(EXIT_FAILURE);
 }
 
-static uint8_t *grow(uint8_t *buf, size_t *cap, size_t need)
+/* The compressed side as a stdio stream: a FILE* whose writes / reads go through the reference's own bitIO_write /
+ * bitIO_read, so that lz77x_encode_file / lz77x_decode_file STREAM both sides (segments through bounded device
+ * memory, two pinned staging slots) exactly as they do for the CLI -- the first version read the whole input and
+ * held the whole stream in host memory. */
+static ssize_t bit_sink(void *cookie, const char *buf, size_t size)
 {
-    if (need <= *cap) return buf;
-    size_t ncap = *cap ? *cap : (size_t)1 << 20;
-    while (ncap < need) ncap *= 2;
-    uint8_t *nb = (uint8_t *)realloc(buf, ncap);
-    if (!nb) { free(buf); fprintf(stderr, "lz77 (MI355X): out of memory\n"); exit(EXIT_FAILURE); }
-    *cap = ncap;
-    return nb;
+    struct bitFILE *out = (struct bitFILE *)cookie;
+    for (size_t at = 0; at < size;) {                                   /* byte-aligned appends; bitIO_close pads nothing more */
+        const size_t m = size - at < SHIM_PIECE ? size - at : SHIM_PIECE;
+        if (bitIO_write(out, (void *)(buf + at), (int)(8 * m)) != (int)(8 * m)) return 0;   /* short write: bitio.c:87-88 stays silent too */
+        at += m;
+    }
+    return (ssize_t)size;
+}
+
+static ssize_t bit_source(void *cookie, char *buf, size_t size)
+{
+    struct bitFILE *in = (struct bitFILE *)cookie;
+    size_t got = 0;
+    while (got < size) {
+        const size_t m = size - got < SHIM_PIECE ? size - got : SHIM_PIECE;
+        const int bits = bitIO_read(in, buf + got, (int)m, (int)(8 * m));
+        if (bits <= 0) break;
+        got += (size_t)bits / 8;                                        /* a partial trailing byte cannot hold a token */
+        if (bits < (int)(8 * m)) break;
+    }
+    return (ssize_t)got;
 }
 
 void encode(FILE *file, struct bitFILE *out, int la, int sb)
 {
-    uint8_t *data = NULL, *z = NULL;
-    size_t cap = 0, n = 0, zn = 0;
-    for (;;) {                                                          /* the whole input (lz77.c:78,121 read it window by window) */
-        data = grow(data, &cap, n + SHIM_PIECE);
-        const size_t got = fread(data + n, 1, SHIM_PIECE, file);
-        n += got;
-        if (got < SHIM_PIECE) {
-            if (ferror(file)) { printf("Error loading the data in the window.\n"); free(data); return; }   /* lz77.c:79-82 */
-            break;
-        }
-    }
-    const int rc = lz77x_encode(data, n, sb, la, &z, &zn);              /* -1 = default like lz77.c:65-66 */
-    free(data);
+    cookie_io_functions_t io = {NULL, bit_sink, NULL, NULL};
+    FILE *sink = fopencookie(out, "w", io);
+    if (!sink) { fprintf(stderr, "lz77 (MI355X): out of memory\n"); exit(EXIT_FAILURE); }
+    const int rc = lz77x_encode_file(file, sink, la, sb);               /* -1 = default like lz77.c:65-66 */
+    fclose(sink);                                                       /* (flushes stdio's buffer into bitIO_write; `out` stays main()'s) */
+    if (rc == LZ77X_E_IO) { printf("Error loading the data in the window.\n"); return; }   /* lz77.c:79-82 */
     if (rc != LZ77X_OK) die("encode", rc);
-    for (size_t at = 0; at < zn;) {                                     /* byte-aligned appends; bitIO_close pads nothing more */
-        const size_t m = zn - at < SHIM_PIECE ? zn - at : SHIM_PIECE;
-        if (bitIO_write(out, z + at, (int)(8 * m)) != (int)(8 * m)) break;   /* short write: bitio.c:87-88 stays silent too */
-        at += m;
-    }
-    lz77x_free(z);
 }
 
 void decode(struct bitFILE *file, FILE *out)
 {
-    uint8_t *z = NULL, *data = NULL;
-    size_t cap = 0, zn = 0, n = 0;
-    for (;;) {
-        z = grow(z, &cap, zn + SHIM_PIECE);
-        const int bits = bitIO_read(file, z + zn, SHIM_PIECE, 8 * SHIM_PIECE);
-        if (bits <= 0) break;
-        zn += (size_t)bits / 8;                                         /* a partial trailing byte cannot hold a token */
-        if (bits < 8 * SHIM_PIECE) break;
-    }
-    const int rc = lz77x_decode(z, zn, &data, &n);
-    free(z);
+    cookie_io_functions_t io = {bit_source, NULL, NULL, NULL};
+    FILE *src = fopencookie(file, "r", io);
+    if (!src) { fprintf(stderr, "lz77 (MI355X): out of memory\n"); exit(EXIT_FAILURE); }
+    const int rc = lz77x_decode_file(src, out);
+    fclose(src);
     if (rc == LZ77X_E_FORMAT) return;                                   /* shorter than its header: nothing to write */
+    if (rc == LZ77X_E_IO) { perror("Writing output file"); return; }
     if (rc != LZ77X_OK) die("decode", rc);
-    if (n && fwrite(data, 1, n, out) != n) perror("Writing output file");
-    lz77x_free(data);
 }

@@ -142,8 +142,9 @@ def test_s1_enwik8_like_100mb():
 
 
 def test_s3_silesia_like_212mb_large_window():
-    """configs[3]: 212 MB mixed, s=65535 l=255"""
-    _run("S3")
+    """configs[3]: 212 MB mixed, s=65535 l=255 -- everything on the device (k_priow.hip: no host recurrence, no host chain)"""
+    st = _run("S3")
+    assert st["prio_iters"] >= 1 and st["host_stageb_ms"] == 0 and st["host_chain_ms"] == 0
 
 
 def test_s2_random_1gib():

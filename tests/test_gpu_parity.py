@@ -768,3 +768,66 @@ def test_decode_distances_beyond_the_window_are_safe():
     finally:
         L.lib().lz77x_set_shards(1)
         del os.environ["LZ77X_FAKE_DEVICES"]
+
+
+WIDE_CASES = [
+    # (kind, seed, n, sb, la, env)
+    ("text", 51, 30000, 4095, 15, {"LZ77X_PRIO_WIDE": "256"}),
+    ("random", 52, 200000, 1000, 10, {"LZ77X_PRIO_WIDE": "256", "LZ77X_PRIO_BLOCK": "1024", "LZ77X_PRIO_SCAN_GROUP": "3"}),
+    ("lowent", 53, 100000, 100, 10, {"LZ77X_PRIO_WIDE": "256", "LZ77X_PRIO_BLOCK": "512"}),
+    ("zeros", 0, 60000, 4095, 15, {"LZ77X_PRIO_WIDE": "256", "LZ77X_PRIO_BLOCK": "4096"}),
+    ("mixed", 54, 300000, 255, 7, {"LZ77X_PRIO_WIDE": "256", "LZ77X_PRIO_BLOCK": "512", "LZ77X_PRIO_SCAN_GROUP": "7"}),
+    ("text", 58, 12000, 1, 15, {"LZ77X_PRIO_WIDE": "256"}),
+    ("random", 60, 9000, 3, 2, {"LZ77X_PRIO_WIDE": "1024"}),
+    ("code", 57, 200000, 4096, 16, {"LZ77X_PRIO_WIDE": "1024"}),
+    ("text", 67, 1 << 20, 4095, 15, {"LZ77X_PRIO_WIDE": "1024"}),
+    ("text", 61, 300000, 8191, 16, {}),
+    ("mixed", 62, 1 << 20, 8192, 31, {"LZ77X_PRIO_BLOCK": "16384", "LZ77X_PRIO_SCAN_GROUP": "3"}),
+    ("lowent", 63, 400000, 20000, 100, {"LZ77X_PRIO_BLOCK": "20480"}),
+    ("text", 64, 1 << 20, 40000, 255, {}),
+    ("text", 64, 1 << 20, 40000, 255, {"LZ77X_PRIO_SCAN_GROUP": "2", "LZ77X_PRIO_SORTCAP": "64"}),
+    ("mixed", 65, 3 << 20, 65535, 255, {}),
+    ("mixed", 65, 3 << 20, 65535, 255, {"LZ77X_PRIO_SCAN_GROUP": "3", "LZ77X_PRIO_SORTCAP": "128"}),
+    ("mixed", 65, 3 << 20, 65535, 255, {"LZ77X_PRIO_BLOCK": "65536", "LZ77X_PRIO_SCAN_GROUP": "2"}),
+    ("random", 66, 1 << 20, 65535, 255, {}),
+    ("records", 67, 2 << 20, 65535, 255, {}),
+    ("zeros", 0, 300000, 65535, 255, {}),
+    ("text", 68, 140000, 65535, 255, {}),
+    ("text", 68, 70000, 65535, 255, {}),
+]
+
+
+@pytest.mark.parametrize("kind,seed,n,sb,la,env", WIDE_CASES)
+def test_stage_priorities_workgroup_sweeps(kind, seed, n, sb, la, env, monkeypatch):
+    """k_priow.hip: the recurrence with a workgroup per block -- 32-bit ring (LZ77X_PRIO_WIDE on small windows, windows up
+    to ~37 K) and 18-bit codes (above: ranks of the old entry values by bitmap counting, the tail of ancient values
+    sorted, in several passes when LZ77X_PRIO_SORTCAP is tiny), boundary scan through registers and LDS in one and in
+    two levels of groups -- equals the sequential recurrence of the oracle (tree.c:202-231)"""
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    data = synth.make(kind, n, seed)
+    P, S, two = O.stage_a(data, sb, la, tree=True)
+    xv, iters = L.stage_priorities_device(P, S, sb)
+    assert iters >= 0, "the gate iteration gave up"
+    assert np.array_equal(xv, O.stage_b(P, S, sb))
+
+
+@pytest.mark.parametrize("env", [{}, {"LZ77X_HOST_STAGEB": "1"}, {"LZ77X_SEGMENT": "300001"}, {"LZ77X_SEGMENT": "300001", "LZ77X_PIPELINE": "0"},
+                                 {"LZ77X_TOKEN_CHUNK": "100000", "LZ77X_MATCH_BATCH": "2"}],
+                         ids=["device", "host", "segments", "segments-serial", "chunks"])
+@pytest.mark.parametrize("kind,seed,n,sb,la", [("mixed", 188, 1_600_000, 65535, 255), ("text", 189, 900_000, 20000, 40),
+                                              ("lowent", 190, 700_000, 8192, 16), ("records", 191, 1_100_000, 40000, 255)])
+def test_large_window_device_pipeline(kind, seed, n, sb, la, env, monkeypatch):
+    """windows above 4096 through the device pipeline (no host stage: lz77.c:89-103 entirely on the GPU), whole and in
+    segments (the carried cells of a later segment are all "old": ranked, none its own position), against the
+    host-assisted pipeline and the reference stream"""
+    data = synth.make(kind, n, seed)
+    want = O.encode_bst(data, sb, la)
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    assert L.encode(data, la, sb) == want
+    st = L.last_stats()
+    if env.get("LZ77X_HOST_STAGEB"):
+        assert st["host_stageb_ms"] > 0
+    else:
+        assert st["prio_iters"] >= 1 and st["host_stageb_ms"] == 0 and st["host_chain_ms"] == 0

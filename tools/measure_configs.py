@@ -36,7 +36,9 @@ for name, kind, n, sb, la, seed in (("S1 text 100 MB, s4095 l15", "text", 100_00
                 "encode_ms": round(te * 1e3, 2), "decode_ms": round(td * 1e3, 2),
                 "encode_MBps": round(n / te / 1e6, 1), "decode_MBps": round(n / td / 1e6, 1),
                 "encode_plus_decode_MBps": round(n / tot / 1e6, 1),
-                "encode_breakdown_ms": {k: round(se[k], 2) for k in ("k_match_ms", "k_sort_ms", "k_walk_ms", "k_token_ms", "k_tiebreak_ms", "host_chain_ms", "host_stageb_ms")},
+                "encode_breakdown_ms": {k: round(se[k], 2) for k in ("k_match_ms", "k_sort_ms", "k_walk_ms", "k_chain_ms", "k_prio_ms", "k_prio_fwd_ms", "k_prio_back_ms", "k_prio_scan_ms",
+                                                                              "k_token_ms", "k_tiebreak_ms", "host_chain_ms", "host_stageb_ms")},
+                "prio_iters": se["prio_iters"],
                 "decode_kernel_ms": round(sd["k_decode_ms"], 2), "roundtrip_ok": True})
     del d_in, d_z, d_back
     torch.cuda.empty_cache()
