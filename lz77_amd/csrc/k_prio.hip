@@ -513,6 +513,8 @@ static void prio_layout(lz77k_prio_plan &P)
 {
     const uint32_t sb = P.sb, nx = P.nx;
     P.W = lz77kw_width((int)sb);
+    P.rs = sb > 4096u ? (sb + 7u) & ~7u : sb;             /* (the HBM scan reads its rows 16 bytes a lane) */
+    const size_t rs = P.rs;
     P.sb_r = (sb + 63u) & ~63u;
     P.ring_n = P.sb_r + P.W;
     P.pack18 = P.W > 64u && lz77kw_pack18(P.ring_n);
@@ -531,20 +533,20 @@ static void prio_layout(lz77k_prio_plan &P)
     P.o_gate[0] = take((size_t)P.ngroups * 8 + 64);
     P.o_gate[1] = take((size_t)P.ngroups * 8 + 64);
     P.o_rmask = take((size_t)P.ngroups * 8 + 64);
-    P.o_dest = take(((size_t)P.NB + 1) * sb * 2);
-    P.o_loc = take(((size_t)P.NB + 1) * sb * 4);
-    P.o_in = take(((size_t)P.NB + 2) * sb * 4);
-    P.o_gdest = take(((size_t)P.NG + 2) * sb * 2);
-    P.o_gloc = take(((size_t)P.NG + 2) * sb * 4);
-    P.o_gin = take(((size_t)P.NG + 2) * sb * 4);
+    P.o_dest = take(((size_t)P.NB + 1) * rs * 2);
+    P.o_loc = take(((size_t)P.NB + 1) * rs * 4);
+    P.o_in = take(((size_t)P.NB + 2) * rs * 4);
+    P.o_gdest = take(((size_t)P.NG + 2) * rs * 2);
+    P.o_gloc = take(((size_t)P.NG + 2) * rs * 4);
+    P.o_gin = take(((size_t)P.NG + 2) * rs * 4);
     P.o_sum = take(256);
     P.o_dirty = take(((size_t)P.NB + 2) * 2 * 4);            /* per block: [0, NB+2) its gates changed in the last sweep, then its entry cells changed in the last scan */
     if (P.pack18) {
-        P.o_codes = take(((size_t)P.NB + 1) * sb * 4);
-        P.o_gval = take(((size_t)P.NB + 1) * sb * 4);
+        P.o_codes = take(((size_t)P.NB + 1) * rs * 4);
+        P.o_gval = take(((size_t)P.NB + 1) * rs * 4);
     }
-    if (sb > 4096u) P.o_scan = take(lz77kw_scan_tmp_bytes(P.NG, sb));
-    if (P.W > 64u) P.o_inprev = take(((size_t)P.NB + 2) * sb * 4);        /* the cells every block's last sweep started from */
+    if (sb > 4096u) P.o_scan = take(lz77kw_scan_tmp_bytes(P.NG, P.rs));
+    if (P.W > 64u) P.o_inprev = take(((size_t)P.NB + 2) * rs * 4);        /* the cells every block's last sweep started from */
     P.total = o;
 }
 
@@ -615,7 +617,7 @@ hipError_t lz77k_prio_maps(lz77k_prio_plan &P, hipStream_t s, bool whole, const 
     uint32_t *loc = PRIO_PTR(uint32_t, P.o_loc), *gloc = PRIO_PTR(uint32_t, P.o_gloc);
     const uint32_t nb = P.NB - P.first;
     if (P.W > 64u) {
-        hipError_t e = lz77kw_back(P.ps, P.nx, P.sb, P.B, P.ring_n, P.W, P.first, nb, PRIO_PTR(uint64_t, P.o_gate[P.cur]), dest, loc, P.voff, P.ncarried,
+        hipError_t e = lz77kw_back(P.ps, P.nx, P.sb, P.rs, P.B, P.ring_n, P.W, P.first, nb, PRIO_PTR(uint64_t, P.o_gate[P.cur]), dest, loc, P.voff, P.ncarried,
                                    PRIO_PTR(uint32_t, P.o_dirty), s);
         if (e != hipSuccess) return e;
         if (whole && P.sb > 4096u) return hipErrorNotSupported;       /* the whole-plan map of a shard: LDS scans only */
@@ -668,7 +670,7 @@ hipError_t lz77k_prio_sweep(lz77k_prio_plan &P, hipStream_t s, uint32_t *h_flag,
     P.sweeps++;
     uint32_t *changed = track ? in_changed : nullptr;
     if (nb > 1 && sb > 4096u) {
-        if ((e = lz77kw_scan(dest, loc, in, sb, first, nb - 1u, P.G, gdest, gloc, gin, PRIO_PTR(uint8_t, P.o_scan), s)) != hipSuccess) return e;
+        if ((e = lz77kw_scan(dest, loc, in, sb, P.rs, first, nb - 1u, P.G, gdest, gloc, gin, PRIO_PTR(uint8_t, P.o_scan), s)) != hipSuccess) return e;
     } else if (nb > 1) {
         /* maps first .. NB-2 */
         const uint32_t nmaps = nb - 1, G = P.G;
@@ -695,7 +697,7 @@ hipError_t lz77k_prio_sweep(lz77k_prio_plan &P, hipStream_t s, uint32_t *h_flag,
     }
     if (ev3 && (e = hipEventRecord(ev3[1], s)) != hipSuccess) return e;
     if (P.W > 64u) {
-        if ((e = lz77kw_fwd(P.ps, P.nx, sb, P.B, P.ring_n, P.W, first, nb, PRIO_PTR(uint64_t, P.o_rmask), PRIO_PTR(uint64_t, P.o_gate[P.cur]),
+        if ((e = lz77kw_fwd(P.ps, P.nx, sb, P.rs, P.B, P.ring_n, P.W, first, nb, PRIO_PTR(uint64_t, P.o_rmask), PRIO_PTR(uint64_t, P.o_gate[P.cur]),
                             PRIO_PTR(uint64_t, P.o_gate[P.cur ^ 1]), in, P.xval, summary, P.voff, d_out_state, P.ncarried,
                             P.pack18 ? PRIO_PTR(uint32_t, P.o_codes) : nullptr, P.pack18 ? PRIO_PTR(uint32_t, P.o_gval) : nullptr,
                             PRIO_PTR(uint32_t, P.o_inprev), have_prev, gates_changed, s)) != hipSuccess)

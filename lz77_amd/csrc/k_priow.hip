@@ -220,7 +220,7 @@ __device__ __forceinline__ uint32_t pw_block_excl(uint32_t v, uint32_t *s_w /* W
  * the recurrence itself; gold[] (the gates the boundary values came from) is only compared against.
  * PACK: codes[b][i] / gval[b][r] are the block's scratch rows (code of entry cell i; value of old rank r). */
 template <int W, bool PACK>
-__global__ __launch_bounds__(W) void k_pw_fwd(const uint32_t *__restrict__ ps, uint32_t nx, uint32_t sb, uint32_t B, uint32_t ring_n,
+__global__ __launch_bounds__(W) void k_pw_fwd(const uint32_t *__restrict__ ps, uint32_t nx, uint32_t sb, uint32_t rs /* row stride of in / in_prev / codes / gval */, uint32_t B, uint32_t ring_n,
                                               uint32_t b_first, const uint64_t *__restrict__ rmask, const uint64_t *__restrict__ gold,
                                               uint64_t *__restrict__ gnew, const uint32_t *__restrict__ in, uint32_t *__restrict__ xval,
                                               uint32_t *__restrict__ summary, uint32_t voff, uint32_t *__restrict__ out_state,
@@ -246,13 +246,13 @@ __global__ __launch_bounds__(W) void k_pw_fwd(const uint32_t *__restrict__ ps, u
         ring.r = pw_lds;
     }
     if (tid == 0) s_flip = 0;
-    const uint32_t *inb = in + (size_t)b * sb;
+    const uint32_t *inb = in + (size_t)b * rs;
     PW_STAMP(8);
     {
         /* the sweep is a function of the entry cells alone: the same cells as last time give the same xval[] and the gates
          * the maps of this iteration were built from -- nothing to do, no flip.  (The tail iterations change the cells
          * of a fraction of the blocks.) */
-        uint32_t *pb = in_prev + (size_t)b * sb;
+        uint32_t *pb = in_prev + (size_t)b * rs;
         bool diff = !have_prev;
         for (uint32_t i = tid; i < sb; i += W) {
             const uint32_t a = inb[i];
@@ -281,7 +281,7 @@ __global__ __launch_bounds__(W) void k_pw_fwd(const uint32_t *__restrict__ ps, u
         uint32_t *coarse = pw_lds + BM_WORDS;
         uint16_t *fine = reinterpret_cast<uint16_t *>(pw_lds + BM_WORDS + NCO);   /* per 256 bits, relative to coarse */
         uint32_t *skey = pw_lds;                            /* the tail sort comes first: the bitmap's space */
-        uint32_t *cb = codes + (size_t)b * sb, *gv = gval + (size_t)b * sb;
+        uint32_t *cb = codes + (size_t)b * rs, *gv = gval + (size_t)b * rs;
         const bool all_old = b == 0 && ncarried != 0;       /* carried cells hold ranks of their own: none is "its own position" */
         const uint32_t hi = all_old ? sb : x0 + voff;       /* every old value is below hi */
         const uint64_t lt = (1ull << lane) - 1ull;
@@ -568,7 +568,7 @@ __global__ __launch_bounds__(W) void k_pw_fwd(const uint32_t *__restrict__ ps, u
                 if (pend_x != PW_NONE) xval[pend_x] = pend_v;
                 pend_x = PW_NONE;
                 if (x < x1) {
-                    if (out != PW_NONE && out < sb) { pend_x = x; pend_v = gval[(size_t)b * sb + out]; }
+                    if (out != PW_NONE && out < sb) { pend_x = x; pend_v = gval[(size_t)b * rs + out]; }
                     else xval[x] = out == PW_NONE ? PW_NONE : x0 + (out - sb) + voff;
                 }
             } else {
@@ -605,7 +605,7 @@ __global__ __launch_bounds__(W) void k_pw_fwd(const uint32_t *__restrict__ ps, u
         /* cells nx .. nx+sb-1, what the next segment of a long input starts from: the ring holds the cells [x1, x1 + ring_n) */
         for (uint32_t i = tid; i < sb; i += W) {
             const uint32_t c = ring.rd((x1 - x0 + i) % ring_n);
-            if constexpr (PACK) out_state[i] = c < sb ? gval[(size_t)b * sb + c] : x0 + (c - sb) + voff;
+            if constexpr (PACK) out_state[i] = c < sb ? gval[(size_t)b * rs + c] : x0 + (c - sb) + voff;
             else out_state[i] = c;
         }
     }
@@ -624,7 +624,7 @@ __global__ __launch_bounds__(W) void k_pw_fwd(const uint32_t *__restrict__ ps, u
  * reaches, or DEAD when it ends inside the block; loc[b][d]: the lowest position of the block whose chain reaches exit
  * cell d.  loc lives in HBM (32 bits x sb do not fit beside the ring): initialised here, lowered atomically. */
 template <int W>
-__global__ __launch_bounds__(W) void k_pw_back(const uint32_t *__restrict__ ps, uint32_t nx, uint32_t sb, uint32_t B, uint32_t ring_n,
+__global__ __launch_bounds__(W) void k_pw_back(const uint32_t *__restrict__ ps, uint32_t nx, uint32_t sb, uint32_t rs /* row stride of dest / loc */, uint32_t B, uint32_t ring_n,
                                                uint32_t b_first, const uint64_t *__restrict__ gates, uint16_t *__restrict__ dest,
                                                uint32_t *__restrict__ loc, uint32_t voff, uint32_t ncarried,
                                                const uint32_t *__restrict__ gates_changed)
@@ -640,7 +640,7 @@ __global__ __launch_bounds__(W) void k_pw_back(const uint32_t *__restrict__ ps, 
     if (gates_changed && !gates_changed[b]) return;                    /* the block's map of the last iteration still holds */
     const uint32_t x0 = b * B;
     const uint32_t x1 = nx - x0 < B ? nx : x0 + B;
-    uint32_t *lb = loc + (size_t)b * sb;
+    uint32_t *lb = loc + (size_t)b * rs;
     PW_STAMP(0);
     /* what reaches exit cell x1+i when nothing older comes in: its own priority -- unless it is a carried cell (a short
      * first block of a later segment: its value comes in through in[0]) */
@@ -732,7 +732,7 @@ __global__ __launch_bounds__(W) void k_pw_back(const uint32_t *__restrict__ ps, 
     PW_STAMP(2);
     for (uint32_t i = tid; i < sb; i += W) {
         /* an entry cell that is not evicted inside a (short, last) block is still live at its end */
-        dest[(size_t)b * sb + i] = x0 + i < x1 ? dr[i] : (uint16_t)(i - (x1 - x0));
+        dest[(size_t)b * rs + i] = x0 + i < x1 ? dr[i] : (uint16_t)(i - (x1 - x0));
     }
     PW_STAMP(3);
     if (blockIdx.x == 0 && threadIdx.x == 0) pw_dbg[4] = ngr;
@@ -753,135 +753,82 @@ __global__ __launch_bounds__(W) void k_pw_back(const uint32_t *__restrict__ ps, 
 #define PW_SCAN_EPT 128u
 #define PW_SCAN_HALF 32768u
 
-/* val[q] (cell q*T + tid) -> the vector after the map (dest row dj, loc row lj); `row` (sb words in HBM) receives it
- * too.  The whole register file of a CU is 64 K cells x 8 bytes: there is room for the vector, the map's destinations
- * (16 bits a cell) and a batch of operands, so the first half of the new vector waits in `row` (a thread reads back what
- * it stored itself) while the old one still feeds the second half.  acc[] (32 K words of LDS) starts each half as the
- * map's loc for the cells of that half; the cells with a live value then lower their destination.  A step is about
- * six round trips to memory (destinations; loc in four batches, each fetched before the barrier it is needed behind;
- * the read-back): the first version re-read the destinations per phase in batches of 16 -- 44 round trips, 41 us. */
-__device__ __forceinline__ void pw_apply_map(uint32_t (&val)[PW_SCAN_EPT], const uint16_t *__restrict__ dj, const uint32_t *__restrict__ lj,
-                                             uint32_t sb, uint32_t *acc, uint32_t *row)
+/* One map applied by a workgroup: out[d] = min(lj[d], min{ cur[c] : dj[c] = d }) for d < sb.  The vectors are rows in
+ * HBM (the one just written sits in the L2 of the workgroup's XCD); LDS holds acc[] for half of the destination range
+ * at a time: it starts as the map's loc, the cells with a live value lower their destination (LDS atomics), the new
+ * row is written from it.  `cur` null: nothing comes in (the first map of a composition).
+ * An earlier version kept the vector in registers (128 cells a thread, the destinations re-read or packed beside them):
+ * fully unrolled over a register array it spilled, waited on vmcnt 494 times a step and took 65 us a map; streaming
+ * the rows costs 1.3 MB of traffic a map instead of 0.8 and is several times faster. */
+#define PW_MAP_T 1024u
+#define PW_MAP_HALF 32768u
+
+/* (rows are 16-byte aligned: four cells a lane per load -- a workgroup's rate is its bytes in flight over the latency,
+ * and with one cell a lane a map took 54 us) */
+typedef uint32_t pw_u32x4 __attribute__((ext_vector_type(4)));
+typedef uint16_t pw_u16x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ void pw_apply_map(const uint32_t *cur, const uint16_t *__restrict__ dj, const uint32_t *__restrict__ lj,
+                                             uint32_t sb, uint32_t *acc, uint32_t *out)
 {
-    constexpr uint32_t BQ = 8;                              /* pairs per batch of operands */
-    constexpr uint32_t NP = PW_SCAN_EPT / 2;                /* a thread's cells are NP adjacent pairs: cells 2P, 2P+1, P = q*T + tid */
-    /* every phase works from an opaque copy of the thread index: the cell offsets are loop invariants, and hoisted out
-     * of the map loop (and shared between the phases) they took every register the vector had left */
-#define PW_TB() uint32_t tb = threadIdx.x; asm volatile("" : "+v"(tb))
-    uint32_t dd[NP];                                        /* destinations of a pair: one (unaligned) 32-bit load; DEAD: nothing to send */
-    {
-        PW_TB();
-#pragma unroll
-        for (uint32_t q = 0; q < NP; q++) {
-            const uint32_t c0 = 2u * (q * PW_SCAN_T + tb);
-            dd[q] = ld32u(reinterpret_cast<const uint8_t *>(dj + min(c0, sb - 2u)));
-            if ((q & 7u) == 7u) __builtin_amdgcn_sched_barrier(0);       /* (eight addresses at a time in registers) */
-        }
-#pragma unroll
-        for (uint32_t q = 0; q < NP; q++) {
-            const uint32_t c0 = 2u * (q * PW_SCAN_T + tb);
-            if (c0 + 1u >= sb) dd[q] = c0 < sb ? (uint32_t)dj[c0] | 0xFFFF0000u : 0xFFFFFFFFu;      /* (the last pair of an odd row) */
-            if (val[2 * q] == PW_NONE) dd[q] |= 0xFFFFu;
-            if (val[2 * q + 1] == PW_NONE) dd[q] |= 0xFFFF0000u;
-        }
-    }
-#pragma unroll
+    const uint32_t tid = threadIdx.x;
+    const uint32_t sb4 = (sb + 3u) / 4u;                    /* quads of cells; the rows are padded to a multiple of 8 cells */
+    const pw_u32x4 *lj4 = reinterpret_cast<const pw_u32x4 *>(lj);
+    const pw_u16x4 *dj4 = reinterpret_cast<const pw_u16x4 *>(dj);
+    const pw_u32x4 *cur4 = reinterpret_cast<const pw_u32x4 *>(cur);
+    pw_u32x4 *out4 = reinterpret_cast<pw_u32x4 *>(out), *acc4 = reinterpret_cast<pw_u32x4 *>(acc);
     for (uint32_t h = 0; h < 2; h++) {
-        const uint32_t base = h * PW_SCAN_HALF;
-        /* acc <- loc for my cells of this half, a batch at a time */
+        const uint32_t base = h * PW_MAP_HALF, q0 = base / 4u, q1 = min(q0 + PW_MAP_HALF / 4u, sb4);
+#pragma unroll 4
+        for (uint32_t q = q0 + tid; q < q1; q += PW_MAP_T) acc4[q - q0] = lj4[q];
+        pw_lds_barrier();
+        if (cur) {
+#pragma unroll 4
+            for (uint32_t q = tid; q < sb4; q += PW_MAP_T) {
+                const pw_u16x4 d = dj4[q];
+                const pw_u32x4 val = cur4[q];
 #pragma unroll
-        for (uint32_t q0 = h * (NP / 2); q0 < (h + 1) * (NP / 2); q0 += BQ) {
-            PW_TB();
-            uint32_t l0[BQ], l1[BQ];
-#pragma unroll
-            for (uint32_t k = 0; k < BQ; k++) {
-                const uint32_t c0 = 2u * ((q0 + k) * PW_SCAN_T + tb);
-                l0[k] = lj[min(c0, sb - 1u)];
-                l1[k] = lj[min(c0 + 1u, sb - 1u)];
-            }
-#pragma unroll
-            for (uint32_t k = 0; k < BQ; k++) {
-                const uint32_t c0 = 2u * ((q0 + k) * PW_SCAN_T + tb);
-                acc[c0 - base] = l0[k];
-                acc[c0 + 1u - base] = l1[k];
+                for (int k = 0; k < 4; k++) {
+                    const uint32_t dk = d[k], vk = val[k];
+                    if (4u * q + (uint32_t)k < sb && dk != PW_DEAD && (dk >> 15) == h && vk != PW_NONE) atomicMin(&acc[dk - base], vk);
+                }
             }
         }
         pw_lds_barrier();
-#pragma unroll
-        for (uint32_t q = 0; q < NP; q++) {
-            const uint32_t d0 = dd[q] & 0xFFFFu, d1 = dd[q] >> 16;
-            if (d0 != PW_DEAD && (d0 >> 15) == h) atomicMin(&acc[d0 - base], val[2 * q]);
-            if (d1 != PW_DEAD && (d1 >> 15) == h) atomicMin(&acc[d1 - base], val[2 * q + 1]);
-        }
-        pw_lds_barrier();
-#pragma unroll
-        for (uint32_t q0 = h * (NP / 2); q0 < (h + 1) * (NP / 2); q0 += BQ) {    /* my cells of this half */
-            PW_TB();
-#pragma unroll
-            for (uint32_t k = 0; k < BQ; k++) {
-                const uint32_t q = q0 + k;
-                const uint32_t c0 = 2u * (q * PW_SCAN_T + tb);
-                const uint32_t n0 = acc[c0 - base], n1 = acc[c0 + 1u - base];
-                if (c0 < sb) row[c0] = n0;
-                if (c0 + 1u < sb) row[c0 + 1u] = n1;
-                if (h == 1) { val[2 * q] = n0; val[2 * q + 1] = n1; }          /* (the old second half has fed both scatters) */
-            }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                  /* (a batch of LDS reads at a time in registers) */
-        }
+#pragma unroll 4
+        for (uint32_t q = q0 + tid; q < q1; q += PW_MAP_T) out4[q] = acc4[q - q0];
         pw_lds_barrier();
     }
-    /* the first half of the new vector: what this thread stored itself (same wavefront, same addresses: in order) */
-#pragma unroll
-    for (uint32_t q0 = 0; q0 < NP / 2; q0 += BQ) {
-        PW_TB();
-        uint32_t *rw = row;
-        asm volatile("" : "+s"(rw) :: "memory");             /* (a fresh pointer: not the values just stored, kept in registers) */
-        const __attribute__((address_space(1))) uint32_t *rg = (const __attribute__((address_space(1))) uint32_t *)rw;   /* (global, not flat) */
-#pragma unroll
-        for (uint32_t k = 0; k < BQ; k++) {
-            const uint32_t c0 = 2u * ((q0 + k) * PW_SCAN_T + tb);
-            val[2 * (q0 + k)] = rg[min(c0, sb - 1u)];
-            val[2 * (q0 + k) + 1] = rg[min(c0 + 1u, sb - 1u)];
-        }
-    }
-#undef PW_TB
+    pw_fence_wg();                                            /* the row is written: the next map reads it */
+    __syncthreads();
 }
 
 /* group g = blockIdx.x applies its maps m0 .. m1-1 (map number m is row `first + m` of dest / loc) in sequence.
  * REPLAY: from row g of vin; row `first + m + 1` of `v` receives the vector after map m.
  * else (compose, loc half): from "nothing" (the identity map); row g of `v` receives what the group's maps send to each
- * exit cell from inside the group (it is overwritten map after map: only the last state counts) */
+ * exit cell from inside the group; the running vector alternates between two rows of `tmp` (2 rows a group) */
 template <bool REPLAY>
-__global__ __launch_bounds__(PW_SCAN_T) void k_pw_maps(const uint16_t *__restrict__ dest, const uint32_t *__restrict__ loc, uint32_t sb, uint32_t first,
-                                                       uint32_t nmaps, uint32_t G, const uint32_t *vin, uint32_t *v)
+__global__ __launch_bounds__(PW_MAP_T) void k_pw_maps(const uint16_t *__restrict__ dest, const uint32_t *__restrict__ loc, uint32_t sb, uint32_t rs, uint32_t first,
+                                                      uint32_t nmaps, uint32_t G, const uint32_t *vin, uint32_t *v, uint32_t *tmp)
 {
     extern __shared__ uint32_t pw_lds[];
-    const uint32_t g = blockIdx.x, tid = threadIdx.x;
+    const uint32_t g = blockIdx.x;
     const uint32_t m0 = g * G, m1 = min(m0 + G, nmaps);
     if (m0 >= m1) return;
-    uint32_t val[PW_SCAN_EPT];
-    if constexpr (REPLAY) {
-        const uint32_t *src = vin + (size_t)g * sb;
-#pragma unroll
-        for (uint32_t q = 0; q < PW_SCAN_EPT / 2; q++) {
-            const uint32_t c0 = 2u * (q * PW_SCAN_T + tid);
-            val[2 * q] = src[min(c0, sb - 1u)];
-            val[2 * q + 1] = src[min(c0 + 1u, sb - 1u)];
-            if ((q & 7u) == 7u) __builtin_amdgcn_sched_barrier(0);
-        }
-    } else {
-#pragma unroll
-        for (uint32_t q = 0; q < PW_SCAN_EPT; q++) val[q] = PW_NONE;
-    }
+    const uint32_t *cur = REPLAY ? vin + (size_t)g * rs : nullptr;
     for (uint32_t m = m0; m < m1; m++) {
         const size_t j = (size_t)first + m;
-        pw_apply_map(val, dest + j * sb, loc + j * sb, sb, pw_lds, REPLAY ? v + (j + 1) * sb : v + (size_t)g * sb);
+        uint32_t *out;
+        if constexpr (REPLAY) out = v + (j + 1) * rs;
+        else out = m + 1u == m1 ? v + (size_t)g * rs : tmp + ((size_t)2 * g + ((m - m0) & 1u)) * rs;
+        pw_apply_map(cur, dest + j * rs, loc + j * rs, sb, pw_lds, out);
+        cur = out;
     }
 }
 
 /* the dest half of a group's composed map: gdest[g][c] = the exit cell entry cell c reaches through all the group's
  * maps (or DEAD): 16 bits a cell in registers, one gather per map */
-__global__ __launch_bounds__(PW_SCAN_T) void k_pw_cdest(const uint16_t *__restrict__ dest, uint32_t sb, uint32_t first, uint32_t nmaps, uint32_t G,
+__global__ __launch_bounds__(PW_SCAN_T) void k_pw_cdest(const uint16_t *__restrict__ dest, uint32_t sb, uint32_t rs, uint32_t first, uint32_t nmaps, uint32_t G,
                                                         uint16_t *__restrict__ gdest)
 {
     const uint32_t g = blockIdx.x, tid = threadIdx.x;
@@ -891,13 +838,13 @@ __global__ __launch_bounds__(PW_SCAN_T) void k_pw_cdest(const uint16_t *__restri
 #pragma unroll
     for (uint32_t q = 0; q < PW_SCAN_EPT; q++) cd[q] = q * PW_SCAN_T + tid < sb ? q * PW_SCAN_T + tid : (uint32_t)PW_DEAD;
     for (uint32_t m = m0; m < m1; m++) {
-        const uint16_t *dj = dest + ((size_t)first + m) * sb;
+        const uint16_t *dj = dest + ((size_t)first + m) * rs;
 #pragma unroll
         for (uint32_t q = 0; q < PW_SCAN_EPT; q++) cd[q] = cd[q] == PW_DEAD ? (uint32_t)PW_DEAD : (uint32_t)dj[min(cd[q], sb - 1u)];
     }
 #pragma unroll
     for (uint32_t q = 0; q < PW_SCAN_EPT; q++)
-        if (q * PW_SCAN_T + tid < sb) gdest[(size_t)g * sb + q * PW_SCAN_T + tid] = (uint16_t)cd[q];
+        if (q * PW_SCAN_T + tid < sb) gdest[(size_t)g * rs + q * PW_SCAN_T + tid] = (uint16_t)cd[q];
 }
 
 /* ------------------------------------------------------------------ launchers -------- */
@@ -945,7 +892,7 @@ hipError_t lz77kw_prep(const uint32_t *d_ps, uint32_t nx, uint32_t sb_r, uint32_
     return hipGetLastError();
 }
 
-hipError_t lz77kw_fwd(const uint32_t *d_ps, uint32_t nx, uint32_t sb, uint32_t B, uint32_t ring_n, uint32_t W, uint32_t b_first, uint32_t nb,
+hipError_t lz77kw_fwd(const uint32_t *d_ps, uint32_t nx, uint32_t sb, uint32_t rs, uint32_t B, uint32_t ring_n, uint32_t W, uint32_t b_first, uint32_t nb,
                       const uint64_t *d_rmask, const uint64_t *d_gold, uint64_t *d_gnew, const uint32_t *d_in, uint32_t *d_xval,
                       uint32_t *d_summary, uint32_t voff, uint32_t *d_out_state, uint32_t ncarried, uint32_t *d_codes, uint32_t *d_gval,
                       uint32_t *d_in_prev, uint32_t have_prev, uint32_t *d_gates_changed, hipStream_t s)
@@ -961,7 +908,7 @@ hipError_t lz77kw_fwd(const uint32_t *d_ps, uint32_t nx, uint32_t sb, uint32_t B
 #define PW_FWD(WW, PK, LDS)                                                                                                        \
     do {                                                                                                                           \
         if ((e = pw_lds_attr(k_pw_fwd<WW, PK>, (LDS))) != hipSuccess) return e;                                                    \
-        hipLaunchKernelGGL((k_pw_fwd<WW, PK>), dim3(nb), dim3(WW), (LDS), s, d_ps, nx, sb, B, ring_n, b_first, d_rmask, d_gold, d_gnew, \
+        hipLaunchKernelGGL((k_pw_fwd<WW, PK>), dim3(nb), dim3(WW), (LDS), s, d_ps, nx, sb, rs, B, ring_n, b_first, d_rmask, d_gold, d_gnew, \
                            d_in, d_xval, d_summary, voff, d_out_state, ncarried, d_codes, d_gval, sort_cap, probe, d_in_prev, have_prev, d_gates_changed); \
     } while (0)
     if (pack) {
@@ -977,7 +924,7 @@ hipError_t lz77kw_fwd(const uint32_t *d_ps, uint32_t nx, uint32_t sb, uint32_t B
     return hipGetLastError();
 }
 
-hipError_t lz77kw_back(const uint32_t *d_ps, uint32_t nx, uint32_t sb, uint32_t B, uint32_t ring_n, uint32_t W, uint32_t b_first, uint32_t nb,
+hipError_t lz77kw_back(const uint32_t *d_ps, uint32_t nx, uint32_t sb, uint32_t rs, uint32_t B, uint32_t ring_n, uint32_t W, uint32_t b_first, uint32_t nb,
                        const uint64_t *d_gates, uint16_t *d_dest, uint32_t *d_loc, uint32_t voff, uint32_t ncarried, const uint32_t *d_gates_changed,
                        hipStream_t s)
 {
@@ -985,59 +932,72 @@ hipError_t lz77kw_back(const uint32_t *d_ps, uint32_t nx, uint32_t sb, uint32_t 
     hipError_t e;
     if (W == 1024u) {
         if ((e = pw_lds_attr(k_pw_back<1024>, lds)) != hipSuccess) return e;
-        hipLaunchKernelGGL(k_pw_back<1024>, dim3(nb), dim3(1024), lds, s, d_ps, nx, sb, B, ring_n, b_first, d_gates, d_dest, d_loc, voff, ncarried, d_gates_changed);
+        hipLaunchKernelGGL(k_pw_back<1024>, dim3(nb), dim3(1024), lds, s, d_ps, nx, sb, rs, B, ring_n, b_first, d_gates, d_dest, d_loc, voff, ncarried, d_gates_changed);
     } else {
         if ((e = pw_lds_attr(k_pw_back<256>, lds)) != hipSuccess) return e;
-        hipLaunchKernelGGL(k_pw_back<256>, dim3(nb), dim3(256), lds, s, d_ps, nx, sb, B, ring_n, b_first, d_gates, d_dest, d_loc, voff, ncarried, d_gates_changed);
+        hipLaunchKernelGGL(k_pw_back<256>, dim3(nb), dim3(256), lds, s, d_ps, nx, sb, rs, B, ring_n, b_first, d_gates, d_dest, d_loc, voff, ncarried, d_gates_changed);
     }
     return hipGetLastError();
 }
 
 /* the scan's own workspace: the composed maps and inputs of the groups of groups (second level) */
-size_t lz77kw_scan_tmp_bytes(uint32_t NG, uint32_t sb)
+size_t lz77kw_scan_tmp_bytes(uint32_t NG, uint32_t rs)
 {
     uint32_t G2 = 1;
     while ((uint64_t)G2 * G2 < NG) G2++;
     const size_t NG2 = (NG + G2 - 1) / G2 + 6;              /* (+ slack: the scan sizes its groups from the maps it is given) */
-    return NG2 * sb * (2 + 4 + 4) + 1024;
+    /* + two rows a group for the running vector of a composition, at both levels */
+    return NG2 * rs * (2 + 4 + 4) + ((size_t)NG + NG2 + 4) * 2 * rs * 4 + 1024;
 }
 
-/* in rows first+1 .. first+nmaps from in[first] through the maps first .. first+nmaps-1, groups of G.
- * gdest/gloc/gin: NG+2 rows each.  A workgroup moves ~25 GB/s and a map is 0.8 MB to apply, so what counts is how many
- * groups work at once and how few maps each applies in sequence: the group maps are scanned the same way, recursively
- * (1630 blocks: 136 groups of 12, 12 groups of 12 of those -- 59 maps in sequence instead of 121, 136 workgroups wide
- * instead of 40) */
-hipError_t lz77kw_scan(const uint16_t *d_dest, const uint32_t *d_loc, uint32_t *d_in, uint32_t sb, uint32_t first, uint32_t nmaps, uint32_t G,
+/* in rows first+1 .. first+nmaps from in[first] through the maps first .. first+nmaps-1, groups of G; rows are rs
+ * cells apart (a multiple of 8: every row 16-byte aligned).  gdest/gloc/gin: NG+2 rows each.  One workgroup applies a
+ * map in ~20 us whatever else runs, so what counts is how few maps each applies in sequence: the group maps are scanned
+ * the same way (1630 blocks: 136 groups of 12, 12 groups of 12 of those -- 59 maps in sequence instead of 121) */
+hipError_t lz77kw_scan(const uint16_t *d_dest, const uint32_t *d_loc, uint32_t *d_in, uint32_t sb, uint32_t rs, uint32_t first, uint32_t nmaps, uint32_t G,
                        uint16_t *d_gdest, uint32_t *d_gloc, uint32_t *d_gin, void *d_tmp, hipStream_t s)
 {
     if (!nmaps) return hipSuccess;
     const uint32_t NG = (nmaps + G - 1u) / G;
-    const size_t lds = (size_t)PW_SCAN_HALF * 4;
+    const size_t lds = (size_t)PW_MAP_HALF * 4;
     hipError_t e;
     if ((e = pw_lds_attr(k_pw_maps<true>, lds)) != hipSuccess) return e;
     if ((e = pw_lds_attr(k_pw_maps<false>, lds)) != hipSuccess) return e;
-    const uint32_t *vin = d_in + (size_t)first * sb;
+    const uint32_t *vin = d_in + (size_t)first * rs;
     if (NG > 1) {
+        /* workspace: [second level: gloc2, gin2, gdest2] [compose rows of this level] [compose rows of the second level] */
+        uint32_t G2 = 1;
+        while ((uint64_t)G2 * G2 < NG - 1u) G2++;
+        const size_t NG2 = (NG - 1u + G2 - 1) / G2 + 2;
+        uint8_t *t = reinterpret_cast<uint8_t *>(d_tmp);
+        uint32_t *gloc2 = reinterpret_cast<uint32_t *>(t);
+        uint32_t *gin2 = gloc2 + NG2 * rs;
+        uint16_t *gdest2 = reinterpret_cast<uint16_t *>(gin2 + NG2 * rs);
+        uint32_t *rows1 = reinterpret_cast<uint32_t *>(t + ((NG2 * rs * 10 + 255) & ~(size_t)255));
+        uint32_t *rows2 = rows1 + (size_t)2 * NG * rs;
         /* the groups' composed maps (the last group's is nobody's input) */
-        hipLaunchKernelGGL(k_pw_cdest, dim3(NG - 1u), dim3(PW_SCAN_T), 0, s, d_dest, sb, first, nmaps, G, d_gdest);
-        hipLaunchKernelGGL(k_pw_maps<false>, dim3(NG - 1u), dim3(PW_SCAN_T), lds, s, d_dest, d_loc, sb, first, nmaps, G, (const uint32_t *)nullptr, d_gloc);
+        hipLaunchKernelGGL(k_pw_cdest, dim3(NG - 1u), dim3(PW_SCAN_T), 0, s, d_dest, sb, rs, first, nmaps, G, d_gdest);
+        hipLaunchKernelGGL(k_pw_maps<false>, dim3(NG - 1u), dim3(PW_MAP_T), lds, s, d_dest, d_loc, sb, rs, first, nmaps, G, (const uint32_t *)nullptr, d_gloc, rows1);
         /* gin[0] = in[first]; gin[g+1] = group map g applied to gin[g] */
-        if ((e = hipMemcpyAsync(d_gin, d_in + (size_t)first * sb, (size_t)sb * 4, hipMemcpyDeviceToDevice, s)) != hipSuccess) return e;
-        if (d_tmp && NG - 1u > 16u) {
-            uint32_t G2 = 1;
-            while ((uint64_t)G2 * G2 < NG - 1u) G2++;
-            const size_t NG2 = (NG - 1u + G2 - 1) / G2 + 2;
-            uint8_t *t = reinterpret_cast<uint8_t *>(d_tmp);
-            uint32_t *gloc2 = reinterpret_cast<uint32_t *>(t);
-            uint32_t *gin2 = gloc2 + NG2 * sb;
-            uint16_t *gdest2 = reinterpret_cast<uint16_t *>(gin2 + NG2 * sb);
-            if ((e = lz77kw_scan(d_gdest, d_gloc, d_gin, sb, 0u, NG - 1u, G2, gdest2, gloc2, gin2, nullptr, s)) != hipSuccess) return e;
+        if ((e = hipMemcpyAsync(d_gin, d_in + (size_t)first * rs, (size_t)sb * 4, hipMemcpyDeviceToDevice, s)) != hipSuccess) return e;
+        if (NG - 1u > 16u) {
+            /* the group maps scanned the same way, one level up */
+            const uint32_t n2 = NG - 1u, NGG = (n2 + G2 - 1u) / G2;
+            if (NGG > 1) {
+                hipLaunchKernelGGL(k_pw_cdest, dim3(NGG - 1u), dim3(PW_SCAN_T), 0, s, d_gdest, sb, rs, 0u, n2, G2, gdest2);
+                hipLaunchKernelGGL(k_pw_maps<false>, dim3(NGG - 1u), dim3(PW_MAP_T), lds, s, d_gdest, d_gloc, sb, rs, 0u, n2, G2, (const uint32_t *)nullptr, gloc2, rows2);
+                if ((e = hipMemcpyAsync(gin2, d_gin, (size_t)sb * 4, hipMemcpyDeviceToDevice, s)) != hipSuccess) return e;
+                hipLaunchKernelGGL(k_pw_maps<true>, dim3(1), dim3(PW_MAP_T), lds, s, gdest2, gloc2, sb, rs, 0u, NGG - 1u, NGG - 1u, gin2, gin2, (uint32_t *)nullptr);
+                hipLaunchKernelGGL(k_pw_maps<true>, dim3(NGG), dim3(PW_MAP_T), lds, s, d_gdest, d_gloc, sb, rs, 0u, n2, G2, gin2, d_gin, (uint32_t *)nullptr);
+            } else {
+                hipLaunchKernelGGL(k_pw_maps<true>, dim3(1), dim3(PW_MAP_T), lds, s, d_gdest, d_gloc, sb, rs, 0u, n2, n2, d_gin, d_gin, (uint32_t *)nullptr);
+            }
         } else {
-            hipLaunchKernelGGL(k_pw_maps<true>, dim3(1), dim3(PW_SCAN_T), lds, s, d_gdest, d_gloc, sb, 0u, NG - 1u, NG - 1u, d_gin, d_gin);
+            hipLaunchKernelGGL(k_pw_maps<true>, dim3(1), dim3(PW_MAP_T), lds, s, d_gdest, d_gloc, sb, rs, 0u, NG - 1u, NG - 1u, d_gin, d_gin, (uint32_t *)nullptr);
         }
         vin = d_gin;
     }
     /* every group from its input (row g of gin; a single group: in[first] itself) */
-    hipLaunchKernelGGL(k_pw_maps<true>, dim3(NG), dim3(PW_SCAN_T), lds, s, d_dest, d_loc, sb, first, nmaps, G, vin, d_in);
+    hipLaunchKernelGGL(k_pw_maps<true>, dim3(NG), dim3(PW_MAP_T), lds, s, d_dest, d_loc, sb, rs, first, nmaps, G, vin, d_in, (uint32_t *)nullptr);
     return hipGetLastError();
 }

@@ -133,6 +133,7 @@ struct lz77k_prio_plan {
     void *tmp = nullptr;
     uint32_t nx = 0, sb = 0, voff = 0, ncarried = 0;
     uint32_t B = 0, NB = 0, ngroups = 0, sb_r = 0, ring_n = 0, G = 0, NG = 0;
+    uint32_t rs = 0;          /* cells between the rows of the per-block arrays (dest, loc, in, ...): sb, or sb rounded up to 8 for windows above 4096 */
     uint32_t W = 64;          /* steps a sweep takes together: 64 = one wavefront per block (k_prio.hip), 256 / 1024 = a workgroup (k_priow.hip) */
     bool pack18 = false;      /* W > 64: the ring holds 18-bit codes (rank of an old value | block-local position), not priorities */
     size_t o_gate[2] = {0, 0}, o_rmask = 0, o_dest = 0, o_loc = 0, o_in = 0, o_gdest = 0, o_gloc = 0, o_gin = 0, o_sum = 0, o_dirty = 0, total = 0;
@@ -148,15 +149,15 @@ uint32_t lz77kw_width(int sb);
 void lz77kw_debug_dump(void);
 bool lz77kw_pack18(uint32_t ring_n);
 hipError_t lz77kw_prep(const uint32_t *d_ps, uint32_t nx, uint32_t sb_r, uint32_t W, uint64_t *d_rmask, uint64_t *d_gate0, hipStream_t s);
-hipError_t lz77kw_fwd(const uint32_t *d_ps, uint32_t nx, uint32_t sb, uint32_t B, uint32_t ring_n, uint32_t W, uint32_t b_first, uint32_t nb,
+hipError_t lz77kw_fwd(const uint32_t *d_ps, uint32_t nx, uint32_t sb, uint32_t rs, uint32_t B, uint32_t ring_n, uint32_t W, uint32_t b_first, uint32_t nb,
                       const uint64_t *d_rmask, const uint64_t *d_gold, uint64_t *d_gnew, const uint32_t *d_in, uint32_t *d_xval,
                       uint32_t *d_summary, uint32_t voff, uint32_t *d_out_state, uint32_t ncarried, uint32_t *d_codes, uint32_t *d_gval,
                       uint32_t *d_in_prev, uint32_t have_prev, uint32_t *d_gates_changed, hipStream_t s);
-hipError_t lz77kw_back(const uint32_t *d_ps, uint32_t nx, uint32_t sb, uint32_t B, uint32_t ring_n, uint32_t W, uint32_t b_first, uint32_t nb,
+hipError_t lz77kw_back(const uint32_t *d_ps, uint32_t nx, uint32_t sb, uint32_t rs, uint32_t B, uint32_t ring_n, uint32_t W, uint32_t b_first, uint32_t nb,
                        const uint64_t *d_gates, uint16_t *d_dest, uint32_t *d_loc, uint32_t voff, uint32_t ncarried, const uint32_t *d_gates_changed,
                        hipStream_t s);
-size_t lz77kw_scan_tmp_bytes(uint32_t NG, uint32_t sb);
-hipError_t lz77kw_scan(const uint16_t *d_dest, const uint32_t *d_loc, uint32_t *d_in, uint32_t sb, uint32_t first, uint32_t nmaps, uint32_t G,
+size_t lz77kw_scan_tmp_bytes(uint32_t NG, uint32_t rs);
+hipError_t lz77kw_scan(const uint16_t *d_dest, const uint32_t *d_loc, uint32_t *d_in, uint32_t sb, uint32_t rs, uint32_t first, uint32_t nmaps, uint32_t G,
                        uint16_t *d_gdest, uint32_t *d_gloc, uint32_t *d_gin, void *d_tmp, hipStream_t s);
 
 hipError_t lz77k_prio_begin(lz77k_prio_plan &P, const uint32_t *d_ps, uint32_t nx, int sb, uint32_t *d_xval, void *d_tmp, uint32_t voff,
