@@ -1441,15 +1441,24 @@ __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v)
     return v;
 }
 
-__global__ __launch_bounds__(64) void k_walk_wave(const uint32_t *__restrict__ ranks, uint32_t n, int sb, uint32_t RP,
-                                                  uint32_t TILE, uint32_t region0, uint32_t nregions, uint32_t run_len,
-                                                  uint32_t runs_per_tile, uint2 *__restrict__ wf, uint2 *__restrict__ wb,
-                                                  uint2 *__restrict__ wb0)
+#define WW_WAVES 4u                                 /* wavefronts that share a run's bitmap (below) */
+
+__global__ __launch_bounds__(64 * WW_WAVES) void k_walk_wave(const uint32_t *__restrict__ ranks, uint32_t n, int sb, uint32_t RP,
+                                                             uint32_t TILE, uint32_t region0, uint32_t nregions, uint32_t run_len,
+                                                             uint32_t runs_per_tile, uint2 *__restrict__ wf, uint2 *__restrict__ wb,
+                                                             uint2 *__restrict__ wb0)
 {
+    /* FOUR wavefronts share a run and its bitmap (round 3).  A group of 64 steps is (1) clear, (2) core queries, (4) set --
+     * which must follow one another group after group -- and (3) the fringe all-to-all, 64 x 8 compare/select/min-max:
+     * 4200 of a group's 5100 instructions, and it reads nothing but the group's own 128 ranks.  With one wavefront per
+     * run (and the 33 KB bitmap allowing four per CU, one per SIMD, a dependent instruction every ~7 cycles: 36 K
+     * cycles a group) everything was serial.  Now wavefront w takes the groups w, w+4, ...: it computes its group's
+     * fringe whenever it likes and does (1)(2)(4) when the turn counter in LDS reaches its group. */
     extern __shared__ uint32_t wv_bm[];
+    __shared__ uint32_t s_turn, s_lo, s_hi, s_mn[WW_WAVES], s_mx[WW_WAVES];
     const uint32_t NW = RP >> 5, NS = (NW + 31) >> 5;
     uint32_t *word = wv_bm, *summ = wv_bm + NW;
-    const uint32_t lane = threadIdx.x;
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     const uint32_t run = blockIdx.x % runs_per_tile, reg = blockIdx.x / runs_per_tile;
     const uint32_t usb = (uint32_t)sb;
     const uint32_t NONE = 0xFFFFFFFFu;
@@ -1467,31 +1476,43 @@ __global__ __launch_bounds__(64) void k_walk_wave(const uint32_t *__restrict__ r
     const bool first = region0 + reg == 0 && run == 0;
     auto wsync = [&]() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); };
 
-    for (uint32_t w = lane; w < NW + NS; w += 64) wv_bm[w] = 0;
-    wsync();
-    /* no set bit lies in a summary word below lo_s or above hi_s (wave-uniform): what keeps a query that has no
-     * neighbour on one side -- every step of a stretch of equal bytes -- from scanning the whole summary */
-    uint32_t lo_s = NS, hi_s = 0;
-    if (!first) {
-        const uint32_t e = min(ta + usb, R);
+    for (uint32_t w = threadIdx.x; w < NW + NS; w += 64 * WW_WAVES) wv_bm[w] = 0;
+    if (threadIdx.x == 0) s_turn = 0;
+    __syncthreads();
+    /* no set bit lies in a summary word below lo_s or above hi_s: what keeps a query that has no neighbour on one side
+     * -- every step of a stretch of equal bytes -- from scanning the whole summary.  Shared through LDS: read at the
+     * start of a turn, written back at its end */
+    {
         uint32_t mn = NONE, mx = 0;
-        for (uint32_t i0 = ta; i0 < e; i0 += 64 * 4) {
-            uint32_t r[4];
+        if (!first) {
+            const uint32_t e = min(ta + usb, R);
+            for (uint32_t i0 = ta; i0 < e; i0 += 64 * WW_WAVES * 4) {
+                uint32_t r[4];
 #pragma unroll
-            for (int u = 0; u < 4; u++) { const uint32_t i = i0 + 64 * u + lane; r[u] = i < e ? rk[i] : NONE; }
+                for (int u = 0; u < 4; u++) { const uint32_t i = i0 + 64 * WW_WAVES * u + threadIdx.x; r[u] = i < e ? rk[i] : NONE; }
 #pragma unroll
-            for (int u = 0; u < 4; u++)
-                if (r[u] != NONE) {
-                    atomicOr(&word[r[u] >> 5], 1u << (r[u] & 31));
-                    atomicOr(&summ[r[u] >> 10], 1u << ((r[u] >> 5) & 31));
-                    mn = min(mn, r[u] >> 10);
-                    mx = max(mx, r[u] >> 10);
-                }
+                for (int u = 0; u < 4; u++)
+                    if (r[u] != NONE) {
+                        atomicOr(&word[r[u] >> 5], 1u << (r[u] & 31));
+                        atomicOr(&summ[r[u] >> 10], 1u << ((r[u] >> 5) & 31));
+                        mn = min(mn, r[u] >> 10);
+                        mx = max(mx, r[u] >> 10);
+                    }
+            }
         }
-        lo_s = min(wave_min_u32(mn), NS);
-        hi_s = wave_max_u32(mx);
-        wsync();
+        mn = wave_min_u32(mn);
+        mx = wave_max_u32(mx);
+        if (lane == 0) { s_mn[wave] = mn; s_mx[wave] = mx; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            uint32_t a = NONE, b = 0;
+            for (uint32_t w = 0; w < WW_WAVES; w++) { a = min(a, s_mn[w]); b = max(b, s_mx[w]); }
+            s_lo = first ? NS : min(a, NS);
+            s_hi = first ? 0u : b;
+        }
+        __syncthreads();
     }
+    uint32_t lo_s = NS, hi_s = 0;
     /* first set rank in words > w / last set rank in words < w, through the summary (a summary bit whose word is
      * empty is skipped); *dry: the scan ran out -- nothing lies beyond w on that side */
     auto up_slow = [&](uint32_t w, bool &dry) -> uint32_t {
@@ -1551,32 +1572,21 @@ __global__ __launch_bounds__(64) void k_walk_wave(const uint32_t *__restrict__ r
         const uint32_t y = (uint32_t)(t + (int32_t)usb);
         ry = (act && y < R) ? rk[y] : NONE;
     };
+    const int32_t stride = 64 * (int32_t)WW_WAVES;
     uint32_t rx, ry, rxn = NONE, ryn = NONE;
-    fetch(tstart, rx, ry);
-    for (int32_t tg = tstart; tg < (int32_t)tb; tg += 64) {
-        if (tg + 64 < (int32_t)tb) fetch(tg + 64, rxn, ryn);      /* the next group's ranks travel while this one runs */
+    int32_t tg0 = tstart + 64 * (int32_t)wave;
+    if (tg0 < (int32_t)tb) fetch(tg0, rx, ry);
+    uint32_t gi = wave;                                          /* my group's number: its turn */
+    for (int32_t tg = tg0; tg < (int32_t)tb; tg += stride, gi += WW_WAVES) {
+        if (tg + stride < (int32_t)tb) fetch(tg + stride, rxn, ryn);      /* my next group's ranks travel while this one runs */
         const int32_t t = tg + (int32_t)lane;
-        /* 1. the old positions leave */
-        if (rx != NONE) {
-            const uint32_t bit = 1u << (rx & 31);
-            const uint32_t old = atomicAnd(&word[rx >> 5], ~bit);
-            if ((old & ~bit) == 0u) atomicAnd(&summ[rx >> 10], ~(1u << ((rx >> 5) & 31)));
-        }
-        wsync();
-        /* 2. the core */
-        uint32_t fs = NONE, fp = NONE, bs = NONE, bp = NONE;
-        dry_up = NONE;
-        dry_dn = 0;
-        if (rx != NONE) core(rx, fs, fp);
-        if (ry != NONE) core(ry, bs, bp);
-        /* 3. the fringe: O_j counts for the backward query of lanes i <= j and the forward query of lanes i < j,
-         *    N_j for both queries of lanes i > j.  Ranks are distinct; "closer than the current answer" in unsigned
-         *    arithmetic with NONE = 0xFFFFFFFF as "no successor" and pred stored + 1 (0 = none). */
+        /* 3. the fringe (needs nothing but this group's ranks): O_j counts for the backward query of lanes i <= j and the
+         *    forward query of lanes i < j, N_j for both queries of lanes i > j.  Ranks are distinct; "closer than the
+         *    current answer" in unsigned arithmetic with NONE = 0xFFFFFFFF as "no successor" and pred stored + 1 (0 = none). */
+        uint32_t fs = NONE, bs = NONE, fp1 = 0u, bp1 = 0u;
         {
             /* branch-free: which lanes a fringe rank is admissible for is a wave-uniform mask of j, so a candidate
-             * costs compare + mask + select + min/max; a single wavefront per SIMD issues one instruction every
-             * 5-8 cycles, the count is what matters */
-            uint32_t fp1 = fp + 1u, bp1 = bp + 1u;               /* NONE + 1 = 0 */
+             * costs compare + mask + select + min/max */
             const uint64_t hasx = __ballot(rx != NONE), hasy = __ballot(ry != NONE);
             for (int j = 0; j < 64; j++) {
                 const uint32_t co = (uint32_t)__builtin_amdgcn_readlane((int)rx, j);
@@ -1598,9 +1608,27 @@ __global__ __launch_bounds__(64) void k_walk_wave(const uint32_t *__restrict__ r
                 fs = min(fs, (me_nf && cn > rx) ? cn : NONE);
                 fp1 = max(fp1, (me_nf && cn < rx) ? cn + 1u : 0u);
             }
-            fp = fp1 - 1u;
-            bp = bp1 - 1u;
         }
+        /* my turn: the groups before mine have left the bitmap as my window's */
+        while (__hip_atomic_load(&s_turn, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != gi) __builtin_amdgcn_s_sleep(2);
+        lo_s = s_lo;
+        hi_s = s_hi;
+        /* 1. the old positions leave */
+        if (rx != NONE) {
+            const uint32_t bit = 1u << (rx & 31);
+            const uint32_t old = atomicAnd(&word[rx >> 5], ~bit);
+            if ((old & ~bit) == 0u) atomicAnd(&summ[rx >> 10], ~(1u << ((rx >> 5) & 31)));
+        }
+        wsync();
+        /* 2. the core */
+        uint32_t cfs = NONE, cfp = NONE, cbs = NONE, cbp = NONE;
+        dry_up = NONE;
+        dry_dn = 0;
+        if (rx != NONE) core(rx, cfs, cfp);
+        if (ry != NONE) core(ry, cbs, cbp);
+        fs = min(fs, cfs);
+        bs = min(bs, cbs);
+        const uint32_t fp = max(fp1, cfp + 1u) - 1u, bp = max(bp1, cbp + 1u) - 1u;      /* NONE + 1 = 0 */
         wsync();
         /* 4. the new positions enter */
         uint32_t mn = NONE, mx = 0;
@@ -1617,7 +1645,9 @@ __global__ __launch_bounds__(64) void k_walk_wave(const uint32_t *__restrict__ r
             const uint32_t smn = wave_min_u32(mn), smx = wave_max_u32(mx);
             if (smn != NONE) { lo_s = min(lo_s, smn); hi_s = max(hi_s, smx); }
         }
-        wsync();
+        if (lane == 0) { s_lo = lo_s; s_hi = hi_s; }
+        wsync();                                                 /* (every LDS operation of the turn has been performed) */
+        if (lane == 0) __hip_atomic_store(&s_turn, gi + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
         if (t < (int32_t)tb) {
             if (t >= 0) {
                 of[t] = make_uint2(fs, fp);
@@ -2086,7 +2116,7 @@ hipError_t lz77k_match(const uint8_t *d_in, uint32_t n, const lz77x_geom &g, uin
                 e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_walk_wave), hipFuncAttributeMaxDynamicSharedMemorySize, (int)wlds);
                 if (e != hipSuccess) return e;
             }
-            hipLaunchKernelGGL(k_walk_wave, dim3((uint32_t)walkers), dim3(64), wlds, s, ranks, n, g.sb, g.RP, g.TILE, region0, nregions, run_len,
+            hipLaunchKernelGGL(k_walk_wave, dim3((uint32_t)walkers), dim3(64 * WW_WAVES), wlds, s, ranks, n, g.sb, g.RP, g.TILE, region0, nregions, run_len,
                                runs, wf, wb, wb0);
         } else
         hipLaunchKernelGGL(k_walk_big, dim3((uint32_t)((walkers + 63) / 64)), dim3(64), 0, s, ranks, n, g.sb, g.RP, g.TILE,
