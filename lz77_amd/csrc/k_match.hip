@@ -392,7 +392,7 @@ __device__ __forceinline__ void region_sort_merge(IdxT *ix, const uint8_t *by, u
 #define C1_CH 4096u
 #define C1_BLOCK 256
 
-__global__ __launch_bounds__(C1_BLOCK) void k_c1_chunks(const uint8_t *__restrict__ in, uint32_t n, int la, uint64_t pos0,
+__global__ __launch_bounds__(C1_BLOCK) __attribute__((amdgpu_num_sgpr(80))) void k_c1_chunks(const uint8_t *__restrict__ in, uint32_t n, int la, uint64_t pos0,
                                                        uint16_t *__restrict__ out)
 {
     __shared__ __attribute__((aligned(16))) uint16_t ix[C1_CH];

@@ -545,7 +545,7 @@ __device__ __forceinline__ uint32_t ts_wg_scan(uint32_t v, uint32_t *wsum, uint3
     return run;
 }
 
-__global__ __launch_bounds__(TS_BLOCK) void k_tokens_sorted(const uint8_t *__restrict__ in, uint32_t n, int sb, int la, int ob, int lb,
+__global__ __launch_bounds__(TS_BLOCK) __attribute__((amdgpu_num_sgpr(80))) void k_tokens_sorted(const uint8_t *__restrict__ in, uint32_t n, int sb, int la, int ob, int lb,
                                                             const uint32_t *__restrict__ chain, const uint32_t *__restrict__ tstart,
                                                             const uint8_t *__restrict__ maxlen, const uint32_t *__restrict__ ofs,
                                                             const uint2 *__restrict__ ent, uint32_t dbase, uint32_t pos0, uint32_t pos1,
