@@ -545,27 +545,49 @@ __device__ __forceinline__ uint32_t ts_wg_scan(uint32_t v, uint32_t *wsum, uint3
     return run;
 }
 
-__global__ __launch_bounds__(TS_BLOCK) __attribute__((amdgpu_num_sgpr(80))) void k_tokens_sorted(const uint8_t *__restrict__ in, uint32_t n, int sb, int la, int ob, int lb,
+/* The hand-over lists of the tile's window cells are built HERE, in LDS, from ps/xval (round 3; until then two kernels
+ * -- k_xfer_blocksum/blockfill, 1.2 ms and 4.6 GB of HBM traffic per 100 MB -- grouped every hand-over of the input by
+ * destination in HBM and the tile read its slice back).  A hand-over x -> x + S[x] that a token p of the tile [a, b) can
+ * see into a cell of its window [a - sb, b) has x + sb < p and x > cell - sb: x in [a - 2 sb, b - sb), at most TS_TT + sb
+ * evictions -- as many as the window has cells.  Count per cell (two 16-bit counters per LDS word), prefix sums in
+ * place, place through the same counters: list(co) = lent[ lofs[co] .. lofs[co + 1] ). */
+#define TS_SRC ((TS_TT + 4096 + TS_BLOCK - 1) / TS_BLOCK)            /* evictions per thread: sb <= 4096 on this path */
+#define TS_SLOTS 32u                                                  /* words the tiles' hand-over counts are spread over */
+
+/* total[0] += total[1 .. TS_SLOTS], which are cleared */
+__global__ void k_ts_total(unsigned long long *total)
+{
+    unsigned long long v = threadIdx.x < TS_SLOTS ? total[1u + threadIdx.x] : 0ull;
+    if (threadIdx.x < TS_SLOTS) total[1u + threadIdx.x] = 0ull;
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) v += __shfl_xor(v, d, 64);
+    if (threadIdx.x == 0) total[0] += v;
+}
+
+__global__ __launch_bounds__(TS_BLOCK, 8) __attribute__((amdgpu_num_sgpr(80))) void k_tokens_sorted(const uint8_t *__restrict__ in, uint32_t n, int sb, int la, int ob, int lb,
                                                             const uint32_t *__restrict__ chain, const uint32_t *__restrict__ tstart,
-                                                            const uint8_t *__restrict__ maxlen, const uint32_t *__restrict__ ofs,
-                                                            const uint2 *__restrict__ ent, uint32_t dbase, uint32_t pos0, uint32_t pos1,
+                                                            const uint8_t *__restrict__ maxlen, const uint32_t *__restrict__ ps,
+                                                            const uint32_t *__restrict__ xval, uint32_t pos0, uint32_t pos1,
                                                             uint32_t *__restrict__ tokval, uint32_t ent_cap, uint32_t off_sorted,
                                                             uint32_t off_inv, uint32_t off_lofs, uint32_t off_tk, uint32_t off_lent,
                                                             const uint32_t *__restrict__ look, uint32_t nlook, uint32_t voff,
-                                                            const uint16_t *__restrict__ order_all, uint32_t RP, ts_grid G, uint32_t tile0, uint32_t ntiles, int ablate)
+                                                            const uint16_t *__restrict__ order_all, uint32_t RP, ts_grid G, uint32_t tile0, uint32_t ntiles,
+                                                            unsigned long long *__restrict__ total /* [1 + a slot] += hand-overs of the evictions [a - sb, b - sb) (a statistic) */)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     uint8_t *by = smem;
     uint16_t *sorted = reinterpret_cast<uint16_t *>(smem + off_sorted);        /* window cells (offsets from wbase) in key order */
     uint16_t *inv = reinterpret_cast<uint16_t *>(smem + off_inv);              /* slot of every tile position */
-    uint16_t *lofs = reinterpret_cast<uint16_t *>(smem + off_lofs);
+    uint16_t *lofs = reinterpret_cast<uint16_t *>(smem + off_lofs);            /* 8 * TS_BLOCK entries */
+    uint32_t *lofs32 = reinterpret_cast<uint32_t *>(smem + off_lofs);
     unsigned long long *tk_best = reinterpret_cast<unsigned long long *>(smem + off_tk);   /* TS_TB */
     uint32_t *tk_cum = reinterpret_cast<uint32_t *>(tk_best + TS_TB);                      /* TS_TB + 1 */
     uint32_t *tk_pl = tk_cum + TS_TB + 4;                                                   /* TS_TB: offset | len << 16 */
     uint16_t *tk_lo = reinterpret_cast<uint16_t *>(tk_pl + TS_TB);                         /* TS_TB */
     uint16_t *tk_hi = tk_lo + TS_TB;                                                        /* TS_TB */
-    uint2 *lent = reinterpret_cast<uint2 *>(smem + off_lent);
-    __shared__ uint32_t wsum[TS_BLOCK / 64];
+    uint2 *lent = reinterpret_cast<uint2 *>(smem + off_lent);                              /* (eviction, priority handed over) */
+    uint16_t *lentx = reinterpret_cast<uint16_t *>(smem + off_lent);                       /* !staged: eviction - xs0 only */
+    __shared__ uint32_t wsum[TS_BLOCK / 64], s_own[TS_BLOCK / 64];
     __shared__ uint32_t s_total;
     __shared__ uint16_t fb_lo[256], fb_hi[256];
 
@@ -576,7 +598,6 @@ __global__ __launch_bounds__(TS_BLOCK) __attribute__((amdgpu_num_sgpr(80))) void
     const uint32_t per_xcd = gridDim.x >> 3;
     const uint32_t tl = (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);
     if (tl >= ntiles) return;
-    if ((ablate & 15) == 15) return;
     uint32_t a, b, region;
     ts_tile_range(G, tile0 + tl, a, b, region);
     a = max(a, pos0);
@@ -585,20 +606,14 @@ __global__ __launch_bounds__(TS_BLOCK) __attribute__((amdgpu_num_sgpr(80))) void
     const uint32_t t0r = region * G.TILE;
     const uint32_t wlo = a > usb ? a - usb : 0u;
     const uint32_t wbase = wlo & ~3u;
-#define LIST_START(c) ((c) > dbase ? ofs[(c) - dbase - 1] : 0u)
-#define LIST_END(c) ((c) >= dbase ? ofs[(c) - dbase] : 0u)
-    const uint32_t NO = b - wbase;
     /* ---- everything the tile needs from HBM is requested at once (one latency, not seven in a row): the region's
-     *      order, the token range, the hand-over offsets, the window bytes; the barriers in between only order
-     *      LDS traffic (ts_barrier_lds does not wait for loads in flight) ---- */
+     *      order, the token range, the evictions, the window bytes; the barriers in between only order LDS traffic
+     *      (ts_barrier_lds does not wait for loads in flight) ---- */
     uint32_t mine[16];
     {
         const uint32_t K = RP / TS_BLOCK;                  /* 4, 8 or 16 consecutive slots per thread */
         const uint16_t *ord = order_all + (size_t)region * RP + (size_t)tid * K;
-        if (ablate & 16) {
-#pragma unroll
-            for (int q = 0; q < 16; q++) mine[q] = tid * 16 + q;
-        } else if (K == 16) {
+        if (K == 16) {
             const uint4 v0 = *reinterpret_cast<const uint4 *>(ord), v1 = *reinterpret_cast<const uint4 *>(ord + 8);
             const uint32_t w[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
 #pragma unroll
@@ -621,37 +636,28 @@ __global__ __launch_bounds__(TS_BLOCK) __attribute__((amdgpu_num_sgpr(80))) void
     /* the first batch's token positions (and, once they are here, their lengths) travel with the tile's other requests:
      * under the batch loop they were two exposed round trips, one behind the other */
     const uint32_t p_pre = chain[min(k0 + (tid >> 1), max(k1, 1u) - 1u)];
-    const uint32_t ebase = LIST_START(wbase);
-    const uint32_t ecount = LIST_END(b - 1) - ebase;
-    /* the hand-over entries of the window go straight to LDS (LDS-DMA: global_load_lds, 16 bytes = two entries per
-     * lane, wave-uniform LDS base + lane * 16): no staging registers, and all of them are in flight with the rest of
-     * the tile's requests instead of one round trip per 1024 entries behind the filter */
-    const bool staged = ecount <= ent_cap && ecount < 65536u;
-    if (staged && !(ablate & 128)) {
-        const uint32_t npieces = (ecount + 1u) >> 1;
-        const uint8_t *src = reinterpret_cast<const uint8_t *>(ent + ebase);
-        for (uint32_t p0 = 0; p0 < npieces; p0 += TS_BLOCK) {
-            const uint32_t piece = p0 + tid;
-            if (piece < npieces)
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + (size_t)piece * 16u),
-                                                 (__attribute__((address_space(3))) void *)(reinterpret_cast<uint8_t *>(lent) + (size_t)(p0 + (tid & ~63u)) * 16u),
-                                                 16, 0, 0);
+    /* the evictions [xs0, xs1) (every load unconditional, clamped: the compiler keeps them in flight) */
+    const uint32_t xs0 = wlo > usb ? wlo - usb : 0u, xs1 = b > usb ? b - usb : 0u;
+    uint32_t xv[TS_SRC], xc[TS_SRC];                        /* priority handed over / the cell it goes to (offset from wbase) */
+    {
+        const uint32_t xl = xs1 ? xs1 - 1u : 0u;
+#pragma unroll
+        for (int r = 0; r < TS_SRC; r++) {
+            const uint32_t x = xs0 + tid + (uint32_t)r * TS_BLOCK;
+            const uint32_t xq = min(x, xl);
+            xv[r] = xval[xq];
+            xc[r] = ps[xq];
         }
     }
-    constexpr int LOFS_PER = (TS_TT + 4096 + 8 + TS_BLOCK - 1) / TS_BLOCK;       /* sb <= 4096 on this path */
     constexpr int BY_PER = (TS_TT + 4096 + 256 + 16 + 4 * TS_BLOCK - 1) / (4 * TS_BLOCK);
-    uint32_t lo_raw[LOFS_PER], by_raw[BY_PER];
-#pragma unroll
-    for (int r = 0; r < LOFS_PER; r++) {
-        const uint32_t i = tid + (uint32_t)r * TS_BLOCK;
-        lo_raw[r] = (i <= NO && !(ablate & 32)) ? LIST_START(wbase + i) : 0u;
-    }
+    uint32_t by_raw[BY_PER];
     const uint32_t nb = (b + (uint32_t)la + 8 - wbase + 3) & ~3u;
 #pragma unroll
     for (int r = 0; r < BY_PER; r++) {
         const uint32_t i = (tid + (uint32_t)r * TS_BLOCK) * 4u;
-        by_raw[r] = (i < nb && !(ablate & 64)) ? *reinterpret_cast<const uint32_t *>(in + wbase + i) : 0u;
+        by_raw[r] = i < nb ? *reinterpret_cast<const uint32_t *>(in + wbase + i) : 0u;
     }
+    *reinterpret_cast<uint4 *>(lofs32 + 4u * tid) = make_uint4(0u, 0u, 0u, 0u);     /* the counters (ordered before the counting by the scan's barriers) */
     /* the region's order, filtered down to the cells of [wlo, b) */
     uint32_t N;
     {
@@ -671,24 +677,52 @@ __global__ __launch_bounds__(TS_BLOCK) __attribute__((amdgpu_num_sgpr(80))) void
             }
         }
     }
-    if ((ablate & 15) == 14) return;
     const uint32_t len_pre = maxlen[p_pre];
 #pragma unroll
     for (int r = 0; r < BY_PER; r++) {
         const uint32_t i = (tid + (uint32_t)r * TS_BLOCK) * 4u;
         if (i < nb) *reinterpret_cast<uint32_t *>(by + i) = by_raw[r];
     }
-    if (staged) {
+    /* hand-overs per cell: counter of cell co = entry co + 1 (entry 0 stays 0), two entries per word */
+    {
+        uint32_t own = 0;
 #pragma unroll
-        for (int r = 0; r < LOFS_PER; r++) {
-            const uint32_t i = tid + (uint32_t)r * TS_BLOCK;
-            if (i <= NO) lofs[i] = (uint16_t)(lo_raw[r] - ebase);
+        for (int r = 0; r < TS_SRC; r++) {
+            const uint32_t x = xs0 + tid + (uint32_t)r * TS_BLOCK;
+            const uint32_t dst = x + (xc[r] >> 16);
+            const bool ok = x < xs1 && xv[r] != LZ77X_NONE32 && dst >= wlo;
+            own += (ok && x + usb >= a) ? 1u : 0u;
+            xc[r] = ok ? dst - wbase + 1u : 0u;
+            if (ok) atomicAdd(&lofs32[xc[r] >> 1], 1u << (16u * (xc[r] & 1u)));
         }
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) own += __shfl_xor(own, d, 64);
+        if ((tid & 63u) == 0) s_own[tid >> 6] = own;
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         /* the LDS-DMA pieces have landed (the compiler does not track them) */
-    if ((ablate & 15) == 13) return;
     ts_barrier_lds();
     N = s_total;                                            /* = b - wlo: every cell of the window is in the region */
+    if (total && tid == 0) {
+        /* one atomic per workgroup, spread over TS_SLOTS words: atomics to ONE address queue in the L2 at ~100 cycles each
+         * (one per wavefront -- 781 K of them per 100 MB -- took 7 ms) */
+        uint32_t own = 0;
+        for (uint32_t w = 0; w < TS_BLOCK / 64; w++) own += s_own[w];
+        if (own) atomicAdd(&total[1u + (blockIdx.x & (TS_SLOTS - 1u))], (unsigned long long)own);
+    }
+    bool staged;
+    {
+        /* prefix sums in place: eight entries a thread */
+        const uint4 w = *reinterpret_cast<const uint4 *>(lofs32 + 4u * tid);
+        uint32_t c[8] = {w.x & 0xFFFFu, w.x >> 16, w.y & 0xFFFFu, w.y >> 16, w.z & 0xFFFFu, w.z >> 16, w.w & 0xFFFFu, w.w >> 16};
+        uint32_t sum = 0;
+#pragma unroll
+        for (int q = 0; q < 8; q++) sum += c[q];
+        uint32_t run = ts_wg_scan(sum, wsum, &s_total);     /* (its first barrier: every thread has read N) */
+        /* entry e becomes the START of the list of cell e - 1 ... and, once the placing below has bumped it by the
+         * list's length, the start of the list of cell e: list(co) = [lofs[co], lofs[co + 1]) */
+#pragma unroll
+        for (int q = 0; q < 8; q++) { const uint32_t t = c[q]; c[q] = run; run += t; }
+        *reinterpret_cast<uint4 *>(lofs32 + 4u * tid) = make_uint4(c[0] | c[1] << 16, c[2] | c[3] << 16, c[4] | c[5] << 16, c[6] | c[7] << 16);
+    }
     /* cells by first byte: [fb_lo[c], fb_hi[c]) -- the run of a token of length 1, without a search */
     for (uint32_t i = tid; i < N; i += TS_BLOCK) {
         const uint32_t c = by[sorted[i]];
@@ -699,10 +733,23 @@ __global__ __launch_bounds__(TS_BLOCK) __attribute__((amdgpu_num_sgpr(80))) void
         }
         if (i + 1 == N) fb_hi[c] = (uint16_t)N;
     }
+    ts_barrier_lds();
+    /* more hand-overs than the LDS left over holds (never seen on text: four in ten evictions hand over): the lists
+     * keep the evictions only and a look-up fetches the priority from xval[] */
+    staged = s_total <= ent_cap;
+#pragma unroll
+    for (int r = 0; r < TS_SRC; r++) {
+        if (xc[r]) {
+            const uint32_t x = xs0 + tid + (uint32_t)r * TS_BLOCK;
+            const uint32_t sh = 16u * (xc[r] & 1u);
+            const uint32_t slot = (atomicAdd(&lofs32[xc[r] >> 1], 1u << sh) >> sh) & 0xFFFFu;
+            if (staged) lent[slot] = make_uint2(x, xv[r]);
+            else lentx[slot] = (uint16_t)(x - xs0);
+        }
+    }
     __syncthreads();
 
     const uint32_t omask = ob >= 32 ? 0xFFFFFFFFu : (1u << ob) - 1u;
-    if ((ablate & 15) == 1) return;                         /* timing ablations (LZ77X_TS_ABLATE): the output is wrong */
     for (uint32_t kb = k0; kb < k1; kb += TS_TB) {
         const uint32_t nt = min(TS_TB, k1 - kb);
         /* ---- A: the run of cells sharing the token's len bytes; lane pair = (down, up) ---- */
@@ -771,7 +818,6 @@ __global__ __launch_bounds__(TS_BLOCK) __attribute__((amdgpu_num_sgpr(80))) void
             }
         }
         __syncthreads();
-        if ((ablate & 15) == 2) continue;
         /* ---- the runs laid end to end ---- */
         {
             uint32_t cnt = 0;
@@ -780,7 +826,7 @@ __global__ __launch_bounds__(TS_BLOCK) __attribute__((amdgpu_num_sgpr(80))) void
             if (tid < nt) { tk_cum[tid] = ex; tk_best[tid] = ~0ull; }
             __syncthreads();
         }
-        const uint32_t W = (ablate & 15) == 3 ? 0u : s_total;
+        const uint32_t W = s_total;
         if (tid == 0) tk_cum[nt] = W;
         /* ---- B: every run member: inside the token's window?  then its priority at time p ---- */
         {
@@ -807,20 +853,21 @@ __global__ __launch_bounds__(TS_BLOCK) __attribute__((amdgpu_num_sgpr(80))) void
                         const uint32_t co = sorted[slot0 + w];
                         const uint32_t c = wbase + co;
                         if (c < cmin || c >= p) continue;
+                        /* the latest hand-over into c by an eviction before p (x + sb < p), else what c came with */
                         uint32_t prio = c < nlook ? look[c] : c + voff, latest = 0;
                         bool any = false;
+                        const uint32_t e1 = lofs[co + 1];
                         if (staged) {
-                            const uint32_t e1 = lofs[co + 1];
                             for (uint32_t e = lofs[co]; e < e1; e++) {
                                 const uint2 t = lent[e];
                                 if ((uint64_t)t.x + usb < p && (!any || t.x > latest)) { any = true; latest = t.x; prio = t.y; }
                             }
                         } else {
-                            const uint32_t e1 = LIST_END(c);
-                            for (uint32_t e = LIST_START(c); e < e1; e++) {
-                                const uint2 t = ent[e];
-                                if ((uint64_t)t.x + usb < p && (!any || t.x > latest)) { any = true; latest = t.x; prio = t.y; }
+                            for (uint32_t e = lofs[co]; e < e1; e++) {
+                                const uint32_t x = xs0 + lentx[e];
+                                if ((uint64_t)x + usb < p && (!any || x > latest)) { any = true; latest = x; }
                             }
+                            if (any) prio = xval[latest];
                         }
                         const unsigned long long key = ((unsigned long long)prio << 32) | c;
                         best = key < best ? key : best;
@@ -839,8 +886,6 @@ __global__ __launch_bounds__(TS_BLOCK) __attribute__((amdgpu_num_sgpr(80))) void
         }
         __syncthreads();
     }
-#undef LIST_START
-#undef LIST_END
 }
 
 /* ---- large windows (sb > 8192): the candidate index lives in global memory -------------------
@@ -972,18 +1017,14 @@ __global__ __launch_bounds__(256) void k_tokens_big(const uint8_t *__restrict__ 
  * run ends at the first failure in each direction; run members inside the window [p-sb, p) are the
  * candidates.  No candidate index to build, and a token costs (run length)/32 rounds instead of a scan
  * of every window position that starts with its two bytes (tens of thousands for "\0\0" at sb 65535). */
-__global__ __launch_bounds__(256) void k_tokens_rank(const uint8_t *__restrict__ in, uint32_t n, int sb, int ob, int lb,
-                                                     uint32_t RP, uint32_t TILE, const uint32_t *__restrict__ ranks_all,
-                                                     const uint32_t *__restrict__ chain, uint32_t ntok,
-                                                     const uint8_t *__restrict__ maxlen, const uint32_t *__restrict__ ofs,
-                                                     const uint2 *__restrict__ ent, uint32_t dbase, uint32_t *__restrict__ tokval,
-                                                     const uint32_t *__restrict__ look, uint32_t nlook, uint32_t voff,
-                                                     uint32_t whole_order /* the order holds every position < n of the region's RP
-                                                                             slots (lz77k_big_sort_shared), not only its first R */)
+__device__ __forceinline__ void rank_token(uint32_t k, const uint32_t lane, const uint8_t *__restrict__ in, uint32_t n, int sb, int ob, int lb,
+                                           uint32_t RP, uint32_t TILE, const uint32_t *__restrict__ ranks_all,
+                                           const uint32_t *__restrict__ chain, const uint8_t *__restrict__ maxlen,
+                                           const uint32_t *__restrict__ ofs, const uint2 *__restrict__ ent, uint32_t dbase,
+                                           uint32_t *__restrict__ tokval, const uint32_t *__restrict__ look, uint32_t nlook, uint32_t voff,
+                                           uint32_t whole_order /* the order holds every position < n of the region's RP slots
+                                                                   (lz77k_big_sort_shared), not only its first R */)
 {
-    const uint32_t lane = threadIdx.x & 63;
-    const uint32_t k = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    if (k >= ntok) return;
     const uint32_t p = chain[k];
     const uint32_t len = maxlen[p];
     const uint32_t next = in[p + len];
@@ -1101,6 +1142,18 @@ __global__ __launch_bounds__(256) void k_tokens_rank(const uint8_t *__restrict__
     }
 }
 
+
+__global__ __launch_bounds__(256) void k_tokens_rank(const uint8_t *__restrict__ in, uint32_t n, int sb, int ob, int lb,
+                                                     uint32_t RP, uint32_t TILE, const uint32_t *__restrict__ ranks_all,
+                                                     const uint32_t *__restrict__ chain, uint32_t ntok,
+                                                     const uint8_t *__restrict__ maxlen, const uint32_t *__restrict__ ofs,
+                                                     const uint2 *__restrict__ ent, uint32_t dbase, uint32_t *__restrict__ tokval,
+                                                     const uint32_t *__restrict__ look, uint32_t nlook, uint32_t voff, uint32_t whole_order)
+{
+    const uint32_t w = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (w < ntok) rank_token(w, threadIdx.x & 63, in, n, sb, ob, lb, RP, TILE, ranks_all, chain, maxlen, ofs, ent, dbase, tokval, look, nlook, voff, whole_order);
+}
+
 /* bytes of the global candidate index for token positions spanning npos (0 when the LDS tile kernel applies) */
 size_t lz77k_tokens_index_bytes(const lz77x_geom &g, size_t npos)
 {
@@ -1110,13 +1163,16 @@ size_t lz77k_tokens_index_bytes(const lz77x_geom &g, size_t npos)
 }
 
 /* one word per tile + 1: the sorted-order kernel cuts every region into ceil(TILE / TS_TT) tiles (TILE >= 3064) */
-size_t lz77k_tokens_tmp_bytes(uint32_t n) { return ((size_t)(n / 1024u) + 64) * sizeof(uint32_t); }
+size_t lz77k_tokens_tmp_bytes(uint32_t n, const lz77x_geom &) { return ((size_t)(n / 1024u) + 64) * sizeof(uint32_t); }
+
+bool lz77k_tokens_builds_lists(const lz77x_geom &g, int variant, const void *d_ranks_all) { return variant == 0 && g.fast && d_ranks_all; }
 
 /* tokens d_chain[0..ntok) all lie in [pos0, pos1); the hand-over index covers dst >= dbase */
 hipError_t lz77k_tokens(const uint8_t *d_in, uint32_t n, const lz77x_geom &g, const uint32_t *d_chain, uint32_t ntok,
                         const uint8_t *d_maxlen, const uint32_t *d_ofs, const uint2 *d_ent, uint32_t dbase,
                         uint32_t pos0, uint32_t pos1, uint32_t *d_tokval, uint32_t *d_tstart, void *d_index, int variant,
-                        hipStream_t s, hipEvent_t *ev_tie, const uint32_t *d_ranks_all, const uint32_t *d_look, uint32_t nlook, uint32_t voff)
+                        hipStream_t s, hipEvent_t *ev_tie, const uint32_t *d_ranks_all, const uint32_t *d_look, uint32_t nlook, uint32_t voff,
+                        const uint32_t *d_ps, const uint32_t *d_xval, unsigned long long *d_total)
 {
     if (ntok == 0) return hipSuccess;
 #define TIE_EV(i) do { if (ev_tie) { hipError_t ee_ = hipEventRecord(ev_tie[i], s); if (ee_ != hipSuccess) return ee_; } } while (0)
@@ -1144,7 +1200,7 @@ hipError_t lz77k_tokens(const uint8_t *d_in, uint32_t n, const lz77x_geom &g, co
         TIE_EV(1);
         return hipGetLastError();
     }
-    if (variant == 0 && g.fast && d_ranks_all && d_tstart) {
+    if (d_ps && d_xval && d_tstart && lz77k_tokens_builds_lists(g, variant, d_ranks_all)) {
         /* production, LDS-sized windows: runs of the regions' sorted order (d_ranks_all = RP uint16 per region) */
         const ts_grid G = ts_make_grid(g);
         const uint32_t tile0 = ts_tile_of(G, pos0), ntiles = ts_tile_of(G, pos1 - 1u) - tile0 + 1u;
@@ -1152,11 +1208,12 @@ hipError_t lz77k_tokens(const uint8_t *d_in, uint32_t n, const lz77x_geom &g, co
         const uint32_t off_sorted = (span + (uint32_t)g.la + 16 + 15) & ~15u;
         const uint32_t off_inv = (off_sorted + 2 * span + 15) & ~15u;
         const uint32_t off_lofs = (off_inv + 2 * TS_TT + 15) & ~15u;
-        const uint32_t off_tk = (off_lofs + 2 * (span + 2) + 15) & ~15u;
+        const uint32_t off_tk = off_lofs + 2 * 8 * TS_BLOCK;                /* eight list offsets per thread: span + 2 <= 8192 */
         const uint32_t off_lent = (off_tk + TS_TB * 8 + (TS_TB + 4) * 4 + TS_TB * 4 + TS_TB * 2 * 2 + 15) & ~15u;
         const uint32_t budget = 78u * 1024u;                              /* two workgroups per CU */
-        const uint32_t ent_cap = off_lent + 8 * 512 < budget ? (budget - off_lent) / 8 : 512;
-        const size_t lds = (size_t)off_lent + (size_t)ent_cap * 8 + 16;      /* + the odd half of the last LDS-DMA piece */
+        /* (at least a uint16 per eviction of a tile: what the lists fall back to when the entries do not fit) */
+        const uint32_t ent_cap = max((budget - off_lent) / 8u, (span * 2u + 7u) / 8u);
+        const size_t lds = (size_t)off_lent + (size_t)ent_cap * 8;
         if (lds > 48 * 1024) {
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_tokens_sorted), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             if (e != hipSuccess) return e;
@@ -1164,10 +1221,10 @@ hipError_t lz77k_tokens(const uint8_t *d_in, uint32_t n, const lz77x_geom &g, co
         hipLaunchKernelGGL(k_tok_bounds_grid, dim3((ntok + 256) / 256), dim3(256), 0, s, d_chain, ntok, G, tile0, ntiles, d_tstart);
         TIE_EV(0);
         hipLaunchKernelGGL(k_tokens_sorted, dim3((ntiles + 7u) / 8u * 8u), dim3(TS_BLOCK), lds, s, d_in, n, g.sb, g.la, g.ob, g.lb, d_chain, d_tstart, d_maxlen,
-                           d_ofs, d_ent, dbase, pos0, pos1, d_tokval, ent_cap, off_sorted, off_inv, off_lofs, off_tk, off_lent, d_look, nlook, voff,
-                           reinterpret_cast<const uint16_t *>(d_ranks_all), g.RP, G, tile0, ntiles,
-                           getenv("LZ77X_TS_ABLATE") ? atoi(getenv("LZ77X_TS_ABLATE")) : 0);
+                           d_ps, d_xval, pos0, pos1, d_tokval, ent_cap, off_sorted, off_inv, off_lofs, off_tk, off_lent, d_look, nlook, voff,
+                           reinterpret_cast<const uint16_t *>(d_ranks_all), g.RP, G, tile0, ntiles, d_total);
         TIE_EV(1);
+        if (d_total) hipLaunchKernelGGL(k_ts_total, dim3(1), dim3(64), 0, s, d_total);
         return hipGetLastError();
     }
     if ((variant == 0 || variant == 2) && g.sb <= 8192 && d_tstart) {

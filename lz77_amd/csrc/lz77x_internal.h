@@ -200,7 +200,7 @@ hipError_t lz77k_xfer_index(const uint32_t *d_ps, const uint32_t *d_xval, uint32
  * tiled without the index (every candidate visited); variant 3: large windows through the global two-byte
  * index; else / variant 1: one wave per token straight from global memory.
  * d_tstart: lz77k_tokens_tmp_bytes(pos1-pos0). */
-size_t lz77k_tokens_tmp_bytes(uint32_t n);
+size_t lz77k_tokens_tmp_bytes(uint32_t n, const lz77x_geom &g);
 /* large windows (sb > 8192): bytes of the global two-byte candidate index for npos token positions */
 size_t lz77k_tokens_index_bytes(const lz77x_geom &g, size_t npos);
 hipError_t lz77k_tokens(const uint8_t *d_in, uint32_t n, const lz77x_geom &g,
@@ -212,7 +212,12 @@ hipError_t lz77k_tokens(const uint8_t *d_in, uint32_t n, const lz77x_geom &g,
                         const uint32_t *d_ranks_all = nullptr /* large windows: the regions' rank + inverse arrays */,
                         const uint32_t *d_look = nullptr, uint32_t nlook = 0 /* positions < nlook start with priority d_look[c] (a later
                                                                                   segment's look-back) */,
-                        uint32_t voff = 0 /* a position's own priority = position + voff */);
+                        uint32_t voff = 0 /* a position's own priority = position + voff */,
+                        const uint32_t *d_ps = nullptr, const uint32_t *d_xval = nullptr /* lz77k_tokens_builds_lists: the tie-break
+                                                                                            builds its tiles' hand-over lists itself */,
+                        unsigned long long *d_total = nullptr /* [0] += hand-overs of the evictions [pos0 - sb, pos1 - sb); [1..32]: zeroed scratch */);
+/* the production tie-break of LDS-sized windows reads ps/xval itself (no lz77k_xfer_index, d_ofs/d_ent unused) */
+bool lz77k_tokens_builds_lists(const lz77x_geom &g, int variant, const void *d_ranks_all);
 
 /* words [w0, w0+nw) of the output stream (word 0 = header) from tokval[0..ntok) */
 hipError_t lz77k_pack(const uint32_t *d_tokval, uint64_t ntok, const lz77x_geom &g,

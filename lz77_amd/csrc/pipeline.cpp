@@ -449,7 +449,7 @@ int encode_core_host(std::vector<Ctx *> &cs, const void *src, bool src_on_device
             if ((rc = c.ent.need((idx_span + 8) * 8))) return rc;
             if ((rc = c.tokval.need((n + 8) * 4))) return rc;
             if ((rc = c.scantmp.need(lz77k_scan_tmp_bytes((uint32_t)idx_span + 1)))) return rc;
-            if ((rc = c.tstart.need(lz77k_tokens_tmp_bytes((uint32_t)idx_span)))) return rc;
+            if ((rc = c.tstart.need(lz77k_tokens_tmp_bytes((uint32_t)idx_span, g)))) return rc;
             if ((rc = c.flag.need(64))) return rc;
             HIPCHK(hipMemsetAsync(c.flag.p, 0, 64, kstream(d)));
             if (keep_ranks) {
@@ -1494,13 +1494,13 @@ int seg_mid(SegJob &J, const lz77x_geom &g, SegCarry &carry, bool allow_fallback
         const size_t np = (size_t)J.nloc, span = (size_t)E - start;
         if ((rc = c.xval.need((np + 8) * 4))) return rc;
         if ((rc = c.chain.need((np + 8) * 4))) return rc;
-        if ((rc = c.flag.need(64))) return rc;
+        if ((rc = c.flag.need(1024))) return rc;          /* [64, 64 + 8 * 33): the hand-over count and the slots the tiles spread it over */
         if ((rc = c.prio_tmp.need(lz77k_prio_tmp_bytes(J.nx, g.sb)))) return rc;
         if ((rc = c.chain_tmp.need(lz77k_chain_tmp_bytes(E - start, g.la)))) return rc;
         if ((rc = c.look.need((size_t)2 * (usb + 8) * 4))) return rc;
         const uint32_t nsub_max = (uint32_t)((span + csub - 1) / csub);
         if ((rc = c.h_tbase.need(((size_t)nsub_max + 2) * 4 + (usb + 8) * 4))) return rc;
-        HIPCHK(hipMemsetAsync(c.flag.p, 0, 64, s));
+        HIPCHK(hipMemsetAsync(c.flag.p, 0, 1024, s));
         /* c.look: [0, sb) the cells this segment starts from, [sb+8, ..) the cells it leaves behind */
         uint32_t *look_cur = c.look.as<uint32_t>(), *look_next = look_cur + usb + 8;
         uint32_t *h_tbase = c.h_tbase.as<uint32_t>(), *h_state = h_tbase + nsub_max + 2;
@@ -1594,7 +1594,7 @@ int seg_tokens(SegJob &J, const lz77x_geom &g, const SegCarry &carry)
         if ((rc = c.ofs.need((idx_span + 8) * 4))) return rc;
         if ((rc = c.ent.need((idx_span + 8) * 8))) return rc;
         if ((rc = c.scantmp.need(lz77k_scan_tmp_bytes((uint32_t)idx_span + 1)))) return rc;
-        if ((rc = c.tstart.need(lz77k_tokens_tmp_bytes((uint32_t)idx_span)))) return rc;
+        if ((rc = c.tstart.need(lz77k_tokens_tmp_bytes((uint32_t)idx_span, g)))) return rc;
         while (c.tie_ev.size() < 2 * (size_t)nchunks + 8) { hipEvent_t e; HIPCHK(hipEventCreate(&e)); c.tie_ev.push_back(e); }
         uint32_t *look_cur = c.look.as<uint32_t>();
         const uint32_t *h_tbase = c.h_tbase.as<uint32_t>();
@@ -1613,15 +1613,19 @@ int seg_tokens(SegJob &J, const lz77x_geom &g, const SegCarry &carry)
             const size_t x_new = ci == 0 ? 0 : (b > usb ? b - usb : 0);
             /* (destination blocks build their lists in LDS from the evictions of the sb positions before them: a 9-fold
              * re-read at sb = 65535; large windows count and place through HBM instead) */
-            HIPCHK(lz77k_xfer_index(c.ps.as<uint32_t>(), c.xval.as<uint32_t>(), xa, (uint32_t)x_done, dbase, (uint32_t)e, c.ofs.as<uint32_t>(),
-                                    c.ent.as<uint2>(), c.scantmp.p, s, (uint32_t)x_new, c.flag.as<unsigned long long>() + 1, g.fast ? (uint32_t)g.sb : 0u));
+            /* (LDS-sized windows: the tie-break builds the lists of a tile's window in LDS, straight from ps/xval) */
+            const bool fused = lz77k_tokens_builds_lists(g, J.tvariant, J.d_order);
+            if (!fused)
+                HIPCHK(lz77k_xfer_index(c.ps.as<uint32_t>(), c.xval.as<uint32_t>(), xa, (uint32_t)x_done, dbase, (uint32_t)e, c.ofs.as<uint32_t>(),
+                                        c.ent.as<uint2>(), c.scantmp.p, s, (uint32_t)x_new, c.flag.as<unsigned long long>() + 8, g.fast ? (uint32_t)g.sb : 0u));
             HIPCHK(lz77k_tokens(c.in.as<uint8_t>(), J.nloc, g, c.chain.as<uint32_t>() + ta, tb - ta, c.maxlen.as<uint8_t>(), c.ofs.as<uint32_t>(),
                                 c.ent.as<uint2>(), dbase, (uint32_t)b, (uint32_t)e, tokbuf + 4 + ta, c.tstart.as<uint32_t>(),
                                 g.fast || J.d_order ? nullptr : c.bidx.p,
-                                J.tvariant, s, &c.tie_ev[2 * ci], J.d_order, J.first ? nullptr : look_cur, J.nlook, 0u));
+                                J.tvariant, s, &c.tie_ev[2 * ci], J.d_order, J.first ? nullptr : look_cur, J.nlook, 0u,
+                                fused ? c.ps.as<uint32_t>() : nullptr, fused ? c.xval.as<uint32_t>() : nullptr, c.flag.as<unsigned long long>() + 8));
             J.tie_timed[ci] = tb > ta;
         }
-        HIPCHK(hipMemcpyAsync(c.h_small.as<unsigned long long>() + 2, c.flag.as<unsigned long long>() + 1, 8, hipMemcpyDeviceToHost, s));
+        HIPCHK(hipMemcpyAsync(c.h_small.as<unsigned long long>() + 2, c.flag.as<unsigned long long>() + 8, 8, hipMemcpyDeviceToHost, s));
     } else {
         if ((rc = c.tokval.need(64))) return rc;
         uint32_t *tokbuf = c.tokval.as<uint32_t>();
@@ -2001,7 +2005,7 @@ int encode_sharded(std::vector<Ctx *> &cs, const uint8_t *src, size_t n, const l
         if ((rc = c.ofs.need((idx_span + 8) * 4))) return rc;
         if ((rc = c.ent.need((idx_span + 8) * 8))) return rc;
         if ((rc = c.scantmp.need(lz77k_scan_tmp_bytes((uint32_t)idx_span + 1)))) return rc;
-        if ((rc = c.tstart.need(lz77k_tokens_tmp_bytes((uint32_t)idx_span)))) return rc;
+        if ((rc = c.tstart.need(lz77k_tokens_tmp_bytes((uint32_t)idx_span, g)))) return rc;
         if ((rc = c.flag.need(64))) return rc;
         if ((rc = c.prio_tmp.need(lz77k_prio_tmp_bytes(j.nx, g.sb)))) return rc;
         if ((rc = c.chain_tmp.need(lz77k_chain_tmp_bytes((uint32_t)span, g.la)))) return rc;
