@@ -330,6 +330,144 @@ __global__ __launch_bounds__(64) void k_prio_back(const uint32_t *__restrict__ p
     }
 }
 
+/* The same maps WITHOUT a sequential sweep (round 3).  With the gates fixed a block is a forest of pointers
+ * x -> x + S[x] (open gates), and dest is "follow them until they leave the block": pointer doubling, not a
+ * recurrence.  A workgroup takes the block in sub-blocks of BK2_SUB cells from the last to the first: the cells' pointers
+ * (relative, uint16) are doubled in LDS until every one has left the sub-block or died (a pointer advances at least one
+ * cell a hop: log2 rounds at worst, three to five on text), then one look-up in the resolved first sb cells of the
+ * sub-block behind it (dn[]) finishes them.  k_prio_back walks 64 K steps on one wavefront (0.28 ms whatever the number
+ * of blocks: 1.4 of an encode's 13.4 ms); this is ~10 us of a workgroup per block. */
+#define BK2_T 1024u
+#define BK2_SUB 8192u
+#define BK2_CPT (BK2_SUB / BK2_T)
+
+__device__ __forceinline__ void bk2_barrier()
+{
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   /* LDS traffic only: the prefetched rows stay in flight */
+}
+
+__global__ __launch_bounds__(BK2_T, 8) __attribute__((amdgpu_num_sgpr(80))) void k_prio_back2(const uint32_t *__restrict__ ps, uint32_t nx, uint32_t sb, uint32_t B, uint32_t b_first,
+                                                     const uint64_t *__restrict__ gates, uint16_t *__restrict__ dest,
+                                                     uint32_t *__restrict__ loc, uint32_t voff, uint32_t ncarried,
+                                                     const uint32_t *__restrict__ gates_changed)
+{
+    __shared__ uint16_t ptr[BK2_SUB];                    /* pointer of cell c of the sub-block: < L inside, >= L an exit (cell y1 + ptr - L), DEAD */
+    __shared__ uint16_t dn[2][4096];                     /* dest of the cells y1 + i behind the current sub-block */
+    __shared__ uint32_t lloc[4096];
+    __shared__ uint32_t s_more[2];                       /* "a pointer is still inside": one flag per parity of the doubling round */
+    const uint32_t b = b_first + blockIdx.x;
+    if (gates_changed && !gates_changed[b]) return;
+    const uint32_t tid = threadIdx.x;
+    const uint32_t x0 = b * B;
+    const uint32_t x1 = nx - x0 < B ? nx : x0 + B;
+    const uint32_t nsub = (x1 - x0 + BK2_SUB - 1u) / BK2_SUB;
+    for (uint32_t i = tid; i < sb; i += BK2_T) {
+        lloc[i] = x1 + i >= ncarried ? x1 + i + voff : PRIO_NONE;     /* what reaches exit cell i when nothing older comes in (see k_prio_back) */
+        dn[0][i] = (uint16_t)i;                                        /* cell x1 + i IS exit cell i */
+    }
+    if (tid < 2) s_more[tid] = 0;
+    uint32_t v[BK2_CPT], vn[BK2_CPT];
+    uint32_t g[BK2_CPT], gn[BK2_CPT];
+    const uint32_t xlast = x1 - 1u;
+    const uint32_t *g32 = reinterpret_cast<const uint32_t *>(gates);                        /* bit x of the gates = bit x & 31 of word x >> 5 */
+    auto fetch = [&](int32_t j, uint32_t (&vv)[BK2_CPT], uint32_t (&gg)[BK2_CPT]) {        /* unconditional, clamped loads */
+        const uint32_t y0 = x0 + BK2_SUB * (uint32_t)(j < 0 ? 0 : j);
+#pragma unroll
+        for (uint32_t k = 0; k < BK2_CPT; k++) {
+            const uint32_t x = min(y0 + tid + BK2_T * k, xlast);
+            vv[k] = ps[x];
+            gg[k] = g32[x >> 5];
+        }
+    };
+    fetch((int32_t)nsub - 1, v, g);
+    int w = 0;
+    for (int32_t j = (int32_t)nsub - 1; j >= 0; j--) {
+        fetch(j - 1, vn, gn);
+        const uint32_t y0 = x0 + BK2_SUB * (uint32_t)j, y1 = min(y0 + BK2_SUB, x1), L = y1 - y0;
+        uint32_t p[BK2_CPT];
+#pragma unroll
+        for (uint32_t k = 0; k < BK2_CPT; k++) {
+            const uint32_t c = tid + BK2_T * k, x = y0 + c;
+            const bool gate = c < L && ((g[k] >> (x & 31u)) & 1u);
+            p[k] = gate ? c + (v[k] >> 16) : (uint32_t)PRIO_DEAD;
+            ptr[c] = (uint16_t)p[k];
+        }
+        bk2_barrier();                                    /* (also: the flags, dn[w] of the sub-block before; __syncthreads() would wait for the prefetch) */
+        for (uint32_t r = 0;; r++) {
+            bool more = false, mine = false;
+            uint32_t q[BK2_CPT];
+#pragma unroll
+            for (uint32_t k = 0; k < BK2_CPT; k++) mine |= p[k] < L;
+            /* a wavefront whose pointers have all left the sub-block only keeps the barriers company (after two or three
+             * rounds that is most of them) */
+            const bool active = __ballot(mine) != 0ull;
+            if (active) {
+                /* two hops a round (half the rounds, and a round is mostly its two barriers); the reads of a hop leave
+                 * together: one LDS round trip for the eight cells, not eight */
+                uint32_t h[BK2_CPT];
+#pragma unroll
+                for (uint32_t k = 0; k < BK2_CPT; k++) h[k] = ptr[min(p[k], L - 1u)];
+#pragma unroll
+                for (uint32_t k = 0; k < BK2_CPT; k++) h[k] = p[k] < L ? h[k] : p[k];          /* (DEAD >= L) */
+#pragma unroll
+                for (uint32_t k = 0; k < BK2_CPT; k++) q[k] = ptr[min(h[k], L - 1u)];
+#pragma unroll
+                for (uint32_t k = 0; k < BK2_CPT; k++) {
+                    q[k] = h[k] < L ? q[k] : h[k];
+                    more |= q[k] < L;
+                }
+                if (__ballot(more) && (tid & 63u) == 0) s_more[r & 1u] = 1;
+            }
+            bk2_barrier();                                 /* every read of the round before any write */
+            const bool again = s_more[r & 1u] != 0;
+            if (tid == 0) s_more[(r + 1u) & 1u] = 0;       /* (last read before this round's first barrier, next written behind its second) */
+            if (active) {
+#pragma unroll
+                for (uint32_t k = 0; k < BK2_CPT; k++) {
+                    if (q[k] != p[k]) ptr[tid + BK2_T * k] = (uint16_t)q[k];
+                    p[k] = q[k];
+                }
+            }
+            bk2_barrier();
+            if (!again) break;
+        }
+        if (tid < 2) s_more[tid] = 0;                      /* (ordered before the next sub-block's rounds by its barrier) */
+        /* the exits: dest of cell y1 + e, e = pointer - L */
+        const uint16_t *dcur = dn[w];
+        uint16_t *dnew = dn[w ^ 1];
+        uint32_t d[BK2_CPT], dk[BK2_CPT];
+        /* (unconditional reads, selected afterwards: they leave together) */
+#pragma unroll
+        for (uint32_t k = 0; k < BK2_CPT; k++) d[k] = dcur[p[k] == PRIO_DEAD ? 0u : p[k] - L];
+#pragma unroll
+        for (uint32_t k = 0; k < BK2_CPT; k++) {
+            const uint32_t c = tid + BK2_T * k;
+            dk[k] = c < sb && c >= L ? (uint32_t)dcur[c - L] : 0u;       /* (a short last sub-block: the cells behind it) */
+        }
+#pragma unroll
+        for (uint32_t k = 0; k < BK2_CPT; k++) d[k] = p[k] == PRIO_DEAD ? (uint32_t)PRIO_DEAD : d[k];
+#pragma unroll
+        for (uint32_t k = 0; k < BK2_CPT; k++) {
+            const uint32_t x = y0 + tid + BK2_T * k;
+            if (d[k] != PRIO_DEAD && x >= ncarried) atomicMin(&lloc[d[k]], x + voff);    /* (d != DEAD: an open gate, a cell of the sub-block) */
+        }
+        /* dn for the sub-block before this one: dest of the cells y0 + i, i < sb -- mine, then the cells behind me */
+#pragma unroll
+        for (uint32_t k = 0; k < BK2_CPT; k++) {
+            const uint32_t c = tid + BK2_T * k;
+            if (c < sb) dnew[c] = (uint16_t)(c < L ? d[k] : dk[k]);
+        }
+        w ^= 1;
+#pragma unroll
+        for (uint32_t k = 0; k < BK2_CPT; k++) { v[k] = vn[k]; g[k] = gn[k]; }
+        bk2_barrier();
+    }
+    for (uint32_t i = tid; i < sb; i += BK2_T) {
+        dest[(size_t)b * sb + i] = dn[w][i];             /* (an entry cell a short last block does not evict: still live at its end) */
+        loc[(size_t)b * sb + i] = lloc[i];
+    }
+}
+
 /* ------------------------------------------------------------------ scan over blocks -- */
 
 /* in[j+1] = F_j(in[j]),  F_j(v)[d] = min(loc_j[d], min{ v[c] : dest_j[c] = d }),  for the maps
@@ -621,9 +759,15 @@ hipError_t lz77k_prio_maps(lz77k_prio_plan &P, hipStream_t s, bool whole, const 
                                    PRIO_PTR(uint32_t, P.o_dirty), s);
         if (e != hipSuccess) return e;
         if (whole && P.sb > 4096u) return hipErrorNotSupported;       /* the whole-plan map of a shard: LDS scans only */
-    } else
-    hipLaunchKernelGGL(k_prio_back, dim3(nb), dim3(64), lds_back, s, P.ps, P.nx, P.sb, P.B, P.ring_n, P.first, PRIO_PTR(uint64_t, P.o_gate[P.cur]),
-                       dest, loc, P.voff, P.ncarried, PRIO_PTR(uint32_t, P.o_dirty));
+    } else {
+        static const bool sweep = getenv("LZ77X_PRIO_BACK_SWEEP") != nullptr;        /* the sequential form (cross-check) */
+        if (sweep)
+            hipLaunchKernelGGL(k_prio_back, dim3(nb), dim3(64), lds_back, s, P.ps, P.nx, P.sb, P.B, P.ring_n, P.first, PRIO_PTR(uint64_t, P.o_gate[P.cur]),
+                               dest, loc, P.voff, P.ncarried, PRIO_PTR(uint32_t, P.o_dirty));
+        else
+            hipLaunchKernelGGL(k_prio_back2, dim3(nb), dim3(BK2_T), 0, s, P.ps, P.nx, P.sb, P.B, P.first, PRIO_PTR(uint64_t, P.o_gate[P.cur]),
+                               dest, loc, P.voff, P.ncarried, PRIO_PTR(uint32_t, P.o_dirty));
+    }
     if (whole) {
         /* every block 0 .. NB-1 (the maps of the blocks before P.first are still there and final), in groups,
          * then the groups */
@@ -663,7 +807,10 @@ hipError_t lz77k_prio_sweep(lz77k_prio_plan &P, hipStream_t s, uint32_t *h_flag,
         if ((e = hipMemsetAsync(in_changed + first, 0, (size_t)nb * 4, s)) != hipSuccess) return e;
         if (P.in0_dirty && first == 0 && (e = hipMemsetAsync(in_changed, 1, 4, s)) != hipSuccess) return e;
     } else if (P.sweeps > 0 && P.W == 64u) {
-        if ((e = hipMemsetAsync(gates_changed, 1, ((size_t)P.NB + 2) * 2 * 4, s)) != hipSuccess) return e;
+        /* every block is swept; which blocks' gates the last sweep flipped stays as it is: a block without a flip keeps
+         * its map (k_prio_back2 is bound by what it reads, not by one block's latency: the tail iterations flip gates in
+         * a few dozen blocks) */
+        if ((e = hipMemsetAsync(in_changed, 1, ((size_t)P.NB + 2) * 4, s)) != hipSuccess) return e;
     }
     const uint32_t have_prev = P.sweeps > 0 ? 1u : 0u;                   /* (a workgroup sweep keeps its own record of what changed) */
     P.in0_dirty = false;
