@@ -466,7 +466,7 @@ __global__ __launch_bounds__(TOK_BLOCK) void k_tokens_tile(const uint8_t *__rest
  * Tile grid: region r (positions [r*TILE, r*TILE + TILE + sb) sorted) owns the backward windows of
  * y in [r*TILE + sb, (r+1)*TILE + sb), cut into ceil(TILE / TS_TT) tiles; region 0 also owns y < sb
  * ("head" tiles). */
-#define TS_TT 2048u
+#define TS_TT 3072u
 #define TS_BLOCK 1024
 #define TS_TB 512u                                   /* tokens per batch (two lanes each in phase A) */
 
@@ -585,8 +585,8 @@ __global__ __launch_bounds__(TS_BLOCK, 8) __attribute__((amdgpu_num_sgpr(80))) v
     uint32_t *tk_pl = tk_cum + TS_TB + 4;                                                   /* TS_TB: offset | len << 16 */
     uint16_t *tk_lo = reinterpret_cast<uint16_t *>(tk_pl + TS_TB);                         /* TS_TB */
     uint16_t *tk_hi = tk_lo + TS_TB;                                                        /* TS_TB */
-    uint2 *lent = reinterpret_cast<uint2 *>(smem + off_lent);                              /* (eviction, priority handed over) */
-    uint16_t *lentx = reinterpret_cast<uint16_t *>(smem + off_lent);                       /* !staged: eviction - xs0 only */
+    uint16_t *lentx = reinterpret_cast<uint16_t *>(smem + off_lent);                       /* eviction - xs0 of every list entry */
+    uint32_t *lentv = reinterpret_cast<uint32_t *>(smem + off_lent + 2u * ent_cap);        /* staged: the priority it handed over */
     __shared__ uint32_t wsum[TS_BLOCK / 64], s_own[TS_BLOCK / 64];
     __shared__ uint32_t s_total;
     __shared__ uint16_t fb_lo[256], fb_hi[256];
@@ -743,8 +743,8 @@ __global__ __launch_bounds__(TS_BLOCK, 8) __attribute__((amdgpu_num_sgpr(80))) v
             const uint32_t x = xs0 + tid + (uint32_t)r * TS_BLOCK;
             const uint32_t sh = 16u * (xc[r] & 1u);
             const uint32_t slot = (atomicAdd(&lofs32[xc[r] >> 1], 1u << sh) >> sh) & 0xFFFFu;
-            if (staged) lent[slot] = make_uint2(x, xv[r]);
-            else lentx[slot] = (uint16_t)(x - xs0);
+            lentx[slot] = (uint16_t)(x - xs0);
+            if (staged) lentv[slot] = xv[r];
         }
     }
     __syncthreads();
@@ -847,6 +847,7 @@ __global__ __launch_bounds__(TS_BLOCK, 8) __attribute__((amdgpu_num_sgpr(80))) v
                     const uint32_t pl = tk_pl[ti], cbase = tk_cum[ti], cend = min(tk_cum[ti + 1], w1);
                     const uint32_t p = wbase + (pl & 0xFFFFu);
                     const uint32_t cmin = p > usb ? p - usb : 0u;
+                    const uint32_t xlim = cmin;              /* an eviction x is before p: x + sb < p */
                     const uint32_t slot0 = (uint32_t)tk_lo[ti] - cbase;
                     unsigned long long best = ~0ull;
                     for (; w < cend; w++) {
@@ -854,21 +855,14 @@ __global__ __launch_bounds__(TS_BLOCK, 8) __attribute__((amdgpu_num_sgpr(80))) v
                         const uint32_t c = wbase + co;
                         if (c < cmin || c >= p) continue;
                         /* the latest hand-over into c by an eviction before p (x + sb < p), else what c came with */
-                        uint32_t prio = c < nlook ? look[c] : c + voff, latest = 0;
+                        uint32_t prio = c < nlook ? look[c] : c + voff, latest = 0, at = 0;
                         bool any = false;
                         const uint32_t e1 = lofs[co + 1];
-                        if (staged) {
-                            for (uint32_t e = lofs[co]; e < e1; e++) {
-                                const uint2 t = lent[e];
-                                if ((uint64_t)t.x + usb < p && (!any || t.x > latest)) { any = true; latest = t.x; prio = t.y; }
-                            }
-                        } else {
-                            for (uint32_t e = lofs[co]; e < e1; e++) {
-                                const uint32_t x = xs0 + lentx[e];
-                                if ((uint64_t)x + usb < p && (!any || x > latest)) { any = true; latest = x; }
-                            }
-                            if (any) prio = xval[latest];
+                        for (uint32_t e = lofs[co]; e < e1; e++) {
+                            const uint32_t x = xs0 + lentx[e];
+                            if (x < xlim && (!any || x > latest)) { any = true; latest = x; at = e; }
                         }
+                        if (any) prio = staged ? lentv[at] : xval[latest];
                         const unsigned long long key = ((unsigned long long)prio << 32) | c;
                         best = key < best ? key : best;
                     }
@@ -1211,9 +1205,10 @@ hipError_t lz77k_tokens(const uint8_t *d_in, uint32_t n, const lz77x_geom &g, co
         const uint32_t off_tk = off_lofs + 2 * 8 * TS_BLOCK;                /* eight list offsets per thread: span + 2 <= 8192 */
         const uint32_t off_lent = (off_tk + TS_TB * 8 + (TS_TB + 4) * 4 + TS_TB * 4 + TS_TB * 2 * 2 + 15) & ~15u;
         const uint32_t budget = 78u * 1024u;                              /* two workgroups per CU */
-        /* (at least a uint16 per eviction of a tile: what the lists fall back to when the entries do not fit) */
-        const uint32_t ent_cap = max((budget - off_lent) / 8u, (span * 2u + 7u) / 8u);
-        const size_t lds = (size_t)off_lent + (size_t)ent_cap * 8;
+        /* a list entry is 6 bytes (eviction: uint16 from the tile's first, priority: uint32, two arrays); the area also
+         * holds a uint16 per eviction of a tile, what the lists fall back to when the priorities do not fit */
+        const uint32_t ent_cap = ((budget - off_lent) / 6u) & ~1u;
+        const size_t lds = (size_t)off_lent + max((size_t)ent_cap * 6, (size_t)span * 2);
         if (lds > 48 * 1024) {
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_tokens_sorted), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             if (e != hipSuccess) return e;
