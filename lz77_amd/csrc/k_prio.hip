@@ -576,13 +576,14 @@ __global__ __launch_bounds__(PRIO_SCAN_BLOCK) void k_prio_scan_replay(const uint
     __builtin_amdgcn_s_setprio(3);
     const uint32_t gi = blockIdx.x;
     const uint32_t m0 = gi * G, m1 = min(m0 + G, nmaps);
-    if (m0 >= m1) return;
+    if (m0 > nmaps) return;
     const uint32_t *src = vin + (size_t)gi * vin_stride;
     for (uint32_t i = threadIdx.x; i < sb; i += PRIO_SCAN_BLOCK) {
         const uint32_t val = src[i];
         scan_lds[i] = val;
         if (store_first) vout[(vout_row0 + m0) * sb + i] = val;
     }
+    if (m0 >= m1) return;                               /* (a group that only passes its input on: the row after the last map) */
     scan_regs rr[SCAN_AHEAD];
 #pragma unroll
     for (uint32_t u = 0; u < SCAN_AHEAD; u++) scan_fetch(rr[u], dest, loc, row0 + min(m0 + u, m1 - 1u), sb);
@@ -660,8 +661,7 @@ static void prio_layout(lz77k_prio_plan &P)
     P.NB = nx ? (nx + P.B - 1u) / P.B : 0u;
     P.ngroups = (nx + 63u) / 64u;
     uint32_t G = 1;
-    if (sb > 4096u) while ((uint64_t)G * G * G < P.NB) G++;      /* two levels of groups (lz77kw_scan): the cube root */
-    else while ((uint64_t)G * G < P.NB) G++;
+    while ((uint64_t)G * G * G < P.NB) G++;                      /* two levels of groups: the cube root */
     const char *e = getenv("LZ77X_PRIO_SCAN_GROUP");
     if (e && atoi(e) > 0) G = (uint32_t)atoi(e);
     P.G = G;
@@ -677,6 +677,12 @@ static void prio_layout(lz77k_prio_plan &P)
     P.o_gdest = take(((size_t)P.NG + 2) * rs * 2);
     P.o_gloc = take(((size_t)P.NG + 2) * rs * 4);
     P.o_gin = take(((size_t)P.NG + 2) * rs * 4);
+    P.NG2 = P.NG ? (P.NG + G - 1u) / G : 0u;
+    if (sb <= 4096u) {                                           /* the groups of groups (LDS scans) */
+        P.o_g2dest = take(((size_t)P.NG2 + 2) * rs * 2);
+        P.o_g2loc = take(((size_t)P.NG2 + 2) * rs * 4);
+        P.o_g2in = take(((size_t)P.NG2 + 2) * rs * 4);
+    }
     P.o_sum = take(256);
     P.o_dirty = take(((size_t)P.NB + 2) * 2 * 4);            /* per block: [0, NB+2) its gates changed in the last sweep, then its entry cells changed in the last scan */
     if (P.pack18) {
@@ -822,7 +828,26 @@ hipError_t lz77k_prio_sweep(lz77k_prio_plan &P, hipStream_t s, uint32_t *h_flag,
         /* maps first .. NB-2 */
         const uint32_t nmaps = nb - 1, G = P.G;
         const uint32_t NG = (nmaps + G - 1u) / G;
-        if (NG > 1) {
+        const uint32_t NG2 = (NG + G - 1u) / G;
+        if (NG2 > 1) {
+            /* three levels: groups of G maps, groups of G group maps, and those in sequence -- 5 G map applications one after
+             * the other instead of the 3 sqrt(NB) of two levels (1526 blocks: 60 instead of 117, each ~1.4 us) */
+            uint16_t *g2dest = PRIO_PTR(uint16_t, P.o_g2dest);
+            uint32_t *g2loc = PRIO_PTR(uint32_t, P.o_g2loc), *g2in = PRIO_PTR(uint32_t, P.o_g2in);
+            hipLaunchKernelGGL(k_prio_scan_compose, dim3(NG), dim3(PRIO_SCAN_BLOCK), lds_scan, s, dest, loc, sb, P.sb_r, first, nmaps, G, gdest, gloc);
+            hipLaunchKernelGGL(k_prio_scan_compose, dim3(NG2), dim3(PRIO_SCAN_BLOCK), lds_scan, s, gdest, gloc, sb, P.sb_r, 0u, NG, G, g2dest, g2loc);
+            /* g2in[j] = input of super-group j; gin[g] = input of group g; in[first + m + 1] = the cells after map m */
+            hipLaunchKernelGGL(k_prio_scan_replay<false>, dim3(1), dim3(PRIO_SCAN_BLOCK), lds_scan, s, g2dest, g2loc, sb, P.sb_r, (size_t)0, NG2 - 1u, NG2,
+                               in + (size_t)first * sb, (size_t)0, g2in, (size_t)0, 1u, (uint32_t *)nullptr);
+            hipLaunchKernelGGL(k_prio_scan_replay<false>, dim3(NG2), dim3(PRIO_SCAN_BLOCK), lds_scan, s, gdest, gloc, sb, P.sb_r, (size_t)0, NG - 1u, G,
+                               g2in, (size_t)sb, gin, (size_t)0, 1u, (uint32_t *)nullptr);
+            if (changed)
+                hipLaunchKernelGGL(k_prio_scan_replay<true>, dim3(NG), dim3(PRIO_SCAN_BLOCK), lds_scan, s, dest, loc, sb, P.sb_r, (size_t)first, nmaps, G, gin,
+                                   (size_t)sb, in, (size_t)first, 0u, changed);
+            else
+                hipLaunchKernelGGL(k_prio_scan_replay<false>, dim3(NG), dim3(PRIO_SCAN_BLOCK), lds_scan, s, dest, loc, sb, P.sb_r, (size_t)first, nmaps, G, gin,
+                                   (size_t)sb, in, (size_t)first, 0u, changed);
+        } else if (NG > 1) {
             hipLaunchKernelGGL(k_prio_scan_compose, dim3(NG), dim3(PRIO_SCAN_BLOCK), lds_scan, s, dest, loc, sb, P.sb_r, first, nmaps, G, gdest, gloc);
             /* gin[g] = input of group g: replay the group maps from in[first] */
             hipLaunchKernelGGL(k_prio_scan_replay<false>, dim3(1), dim3(PRIO_SCAN_BLOCK), lds_scan, s, gdest, gloc, sb, P.sb_r, (size_t)0, NG - 1u, NG,
