@@ -60,7 +60,6 @@ def build(force: bool = False) -> str:
     return LIB_PATH
 
 
-_lib = None
 
 _sz = ctypes.c_size_t
 _vp = ctypes.c_void_p
@@ -98,12 +97,34 @@ SYMBOLS = {
 }
 
 
+VARIANTS_LIB_PATH = os.path.join(_HERE, "liblz77_mi355x_variants.so")
+_libs = {}
+_variants = False
+
+
+def use_variants(on: bool) -> None:
+    """Tests only: route every call of this module through liblz77_mi355x_variants.so -- the build with the cross-check
+    kernels of earlier rounds, the timing probes and the knobs that force fallbacks (LZ77X_MATCH_VARIANT, ...).  The
+    product library does not contain them and does not read those knobs."""
+    global _variants
+    _variants = bool(on)
+
+
+# the knobs only the variants build reads (csrc/lz77x_internal.h, LZ77X_VENV)
+VARIANT_KNOBS = ("LZ77X_MATCH_VARIANT", "LZ77X_TOKEN_VARIANT", "LZ77X_SORT_VARIANT", "LZ77X_DECODE_V1", "LZ77X_DECODE_VARIANT",
+                 "LZ77X_XFER_V1", "LZ77X_WALK_BIG_V1", "LZ77X_TOKENS_BUCKET", "LZ77X_C1_SORT_V1", "LZ77X_BIG_SORT_V1",
+                 "LZ77X_PRIO_BACK_SWEEP", "LZ77X_PW_PROBE", "LZ77X_PW_DEBUG", "LZ77X_WALK_DEBUG", "LZ77X_SERIAL", "LZ77X_SPLIT",
+                 "LZ77X_CHAIN_STREAM", "LZ77X_PRIO_SORTCAP", "LZ77X_PRIO_WIDE", "LZ77X_HOST_STAGEB", "LZ77X_TS_ENTCAP")
+
+
 def lib():
-    """dlopen liblz77_mi355x.so (fails loudly if it has not been built)."""
-    global _lib
-    if _lib is None:
-        if not os.path.exists(LIB_PATH):
-            raise Lz77Error(-4, "liblz77_mi355x.so is not built (run `python -c 'import __graft_entry__ as g; g.build()'`)")
+    """dlopen liblz77_mi355x.so (fails loudly if it has not been built).  A process that sets one of VARIANT_KNOBS -- a
+    cross-check test -- gets the variants build for that call; nothing else does."""
+    path = VARIANTS_LIB_PATH if (_variants or any(k in os.environ for k in VARIANT_KNOBS)) else LIB_PATH
+    L = _libs.get(path)
+    if L is None:
+        if not os.path.exists(path):
+            raise Lz77Error(-4, os.path.basename(path) + " is not built (run `python -c 'import __graft_entry__ as g; g.build()'`)")
         # torch ships its own libamdhip64.so.7; whichever HIP runtime is mapped first serves the
         # whole process, and device pointers are only shareable within ONE runtime.  Let torch
         # (the memory/stream plumbing of tests and bench.py) map its copy before we bind ours.
@@ -112,13 +133,13 @@ def lib():
                 import torch  # noqa: F401
             except Exception:
                 pass
-        L = ctypes.CDLL(LIB_PATH)
+        L = ctypes.CDLL(path)
         for name, (res, args) in SYMBOLS.items():
             fn = getattr(L, name)
             fn.restype = res
             fn.argtypes = args
-        _lib = L
-    return _lib
+        _libs[path] = L
+    return L
 
 
 def _check(rc: int):

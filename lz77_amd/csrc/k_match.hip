@@ -411,8 +411,8 @@ __global__ __launch_bounds__(C1_BLOCK) __attribute__((amdgpu_num_sgpr(80))) void
 
 static bool c1_shared_sort(const lz77x_geom &g)
 {
-    return g.fast && g.shifted && g.RP == 16u * MATCH_BLOCK && g.SBu * 4u == g.RP && !getenv("LZ77X_C1_SORT_V1") &&
-           !(getenv("LZ77X_SORT_VARIANT") && atoi(getenv("LZ77X_SORT_VARIANT")));
+    return g.fast && g.shifted && g.RP == 16u * MATCH_BLOCK && g.SBu * 4u == g.RP && !LZ77X_VENV("LZ77X_C1_SORT_V1") &&
+           !(LZ77X_VENV("LZ77X_SORT_VARIANT") && atoi(LZ77X_VENV("LZ77X_SORT_VARIANT")));
 }
 
 template <bool FAST> struct rank_traits;
@@ -554,6 +554,10 @@ __global__ __launch_bounds__(MATCH_BLOCK, (FAST && MODE == 3) ? 8 : 1) void k_ma
                                                        const uint16_t *__restrict__ chunks /* FAST production, tile = 3/4 region: the sorted orders of
                                                                                               the launch's 4 K chunks (k_c1_chunks), else null */)
 {
+#ifndef LZ77X_VARIANTS
+    sort_variant = 0;                                    /* the product build has the merge sorts only (the bitonic networks and the
+                                                            timing ablations below are dead code there) */
+#endif
     typedef typename rank_traits<FAST>::rank_t rank_t;
     constexpr uint32_t HALF = rank_traits<FAST>::HALF;
     constexpr uint32_t RMASK = rank_traits<FAST>::MASK;
@@ -1180,6 +1184,7 @@ __global__ __launch_bounds__(WFIN_BLOCK) void k_walk_final_lds(const uint8_t *__
     }
 }
 
+#ifdef LZ77X_VARIANTS   /* (round 1's walkers: the cross-check of k_walk_wave) */
 /* ---- large windows (RP > 16384): same walk, bitmap in global memory (L2 resident), 32-bit ranks.
  * The walker converts neighbour ranks to distances itself: forward results go straight to ps[],
  * backward ones (candidates of the longest match) to wb[] / wb0[] for k_walk_final_big. ---- */
@@ -1412,6 +1417,7 @@ __global__ __launch_bounds__(64) void k_walk_big(const uint32_t *__restrict__ ra
         r_add = ry; q = qn; ry = ryn;
     }
 }
+#endif
 
 /* ---- large windows, production: ONE WAVEFRONT per run, the bitmap in LDS, 64 steps at a time -------------
  *
@@ -1877,8 +1883,8 @@ __global__ __launch_bounds__(256) void k_big_ranks(uint32_t *__restrict__ ranks,
 
 int lz77k_big_sort_shared(const lz77x_geom &g)
 {
-    return !g.fast && g.shifted && g.RP >= 2 * BIG_BLK && g.TILE % BIG_BLK == 0 && !getenv("LZ77X_BIG_SORT_V1") &&
-           !(getenv("LZ77X_SORT_VARIANT") && atoi(getenv("LZ77X_SORT_VARIANT")));
+    return !g.fast && g.shifted && g.RP >= 2 * BIG_BLK && g.TILE % BIG_BLK == 0 && !LZ77X_VENV("LZ77X_BIG_SORT_V1") &&
+           !(LZ77X_VENV("LZ77X_SORT_VARIANT") && atoi(LZ77X_VENV("LZ77X_SORT_VARIANT")));
 }
 
 /* bytes behind the walkers' part of the scratch: two uint16 arrays over the launch's positions + the splits */
@@ -2033,7 +2039,7 @@ static hipError_t launch_match(const uint8_t *d_in, uint32_t n, const lz77x_geom
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
     }
-    const char *sv = getenv("LZ77X_SORT_VARIANT");
+    const char *sv = LZ77X_VENV("LZ77X_SORT_VARIANT");
     hipLaunchKernelGGL(fn, dim3(nregions), dim3(MATCH_BLOCK), lds, s, d_in, n, g.sb, g.la, g.SBu, g.RP, g.TILE, region0,
                        d_ps, d_maxlen, reinterpret_cast<uint32_t *>(d_scratch), sv ? atoi(sv) : 0, g.fast ? walk_run_lds(g) : 0u, d_order, d_chunks);
     return hipGetLastError();
@@ -2048,9 +2054,13 @@ hipError_t lz77k_match(const uint8_t *d_in, uint32_t n, const lz77x_geom &g, uin
     if (ev_sort && !(variant == 0 || variant > 3)) ev_sort = nullptr;
 #define LZ77K_MATCH_ARGS d_in, n, g, region0, nregions, d_ps, d_maxlen, d_scratch, s
     if (g.fast) {
+#ifdef LZ77X_VARIANTS
         if (variant == 1) return launch_match<true, 1>(LZ77K_MATCH_ARGS);
         if (variant == 2) return launch_match<true, 2>(LZ77K_MATCH_ARGS);
         if (variant == 3) return launch_match<true, 0>(LZ77K_MATCH_ARGS);      /* exhaustive packed pair scan */
+#else
+        if (variant != 0) return hipErrorNotSupported;
+#endif
         /* production: sort -> per-lane bitmap walkers -> finalize */
         hipError_t e = ev_sort ? hipEventRecord(ev_sort[0], s) : hipSuccess;
         if (e != hipSuccess) return e;
@@ -2083,9 +2093,13 @@ hipError_t lz77k_match(const uint8_t *d_in, uint32_t n, const lz77x_geom &g, uin
                            g.TILE, region0, nregions, run_len, runs, subs, wf, wb, wb0, d_ps, d_maxlen);
         return hipGetLastError();
     }
+#ifdef LZ77X_VARIANTS
     if (variant == 1) return launch_match<false, 1>(LZ77K_MATCH_ARGS);
     if (variant == 2) return launch_match<false, 2>(LZ77K_MATCH_ARGS);
     if (variant == 3) return launch_match<false, 0>(LZ77K_MATCH_ARGS);         /* exhaustive pair scan */
+#else
+    if (variant != 0) return hipErrorNotSupported;
+#endif
     {
         /* production for large windows: sort (ranks stay in scratch) -> global-bitmap walkers -> finalize */
         hipError_t e = ev_sort ? hipEventRecord(ev_sort[0], s) : hipSuccess;
@@ -2102,7 +2116,7 @@ hipError_t lz77k_match(const uint8_t *d_in, uint32_t n, const lz77x_geom &g, uin
         if (e != hipSuccess) return e;
         if (ev_sort && (e = hipEventRecord(ev_sort[1], s)) != hipSuccess) return e;
         const size_t nws = (g.RP >> 5) + (((g.RP >> 5) + 31) >> 5);
-        const bool wave_walk = !getenv("LZ77X_WALK_BIG_V1") && nws * 4 <= 64 * 1024;
+        const bool wave_walk = !LZ77X_VENV("LZ77X_WALK_BIG_V1") && nws * 4 <= 64 * 1024;
         const uint32_t run_len = wave_walk ? walk_run_wave(g) : walk_run_big(g);
         const uint32_t runs = (g.TILE + run_len - 1) / run_len;
         const uint64_t walkers = (uint64_t)nregions * runs;
@@ -2118,9 +2132,14 @@ hipError_t lz77k_match(const uint8_t *d_in, uint32_t n, const lz77x_geom &g, uin
             }
             hipLaunchKernelGGL(k_walk_wave, dim3((uint32_t)walkers), dim3(64 * WW_WAVES), wlds, s, ranks, n, g.sb, g.RP, g.TILE, region0, nregions, run_len,
                                runs, wf, wb, wb0);
-        } else
-        hipLaunchKernelGGL(k_walk_big, dim3((uint32_t)((walkers + 63) / 64)), dim3(64), 0, s, ranks, n, g.sb, g.RP, g.TILE,
-                           region0, nregions, run_len, runs, bitmaps, wf, wb, wb0, getenv("LZ77X_WALK_DEBUG") ? atoi(getenv("LZ77X_WALK_DEBUG")) : 0);
+        } else {
+#ifdef LZ77X_VARIANTS
+            hipLaunchKernelGGL(k_walk_big, dim3((uint32_t)((walkers + 63) / 64)), dim3(64), 0, s, ranks, n, g.sb, g.RP, g.TILE,
+                               region0, nregions, run_len, runs, bitmaps, wf, wb, wb0, LZ77X_VENV("LZ77X_WALK_DEBUG") ? atoi(LZ77X_VENV("LZ77X_WALK_DEBUG")) : 0);
+#else
+            return hipErrorNotSupported;                    /* (RP <= 2^18: the bitmap of every legal window fits the LDS) */
+#endif
+        }
         if (ev_sort && (e = hipEventRecord(ev_sort[2], s)) != hipSuccess) return e;
         const uint64_t npos = (uint64_t)nregions * g.TILE;
         hipLaunchKernelGGL(k_walk_final_big, dim3((uint32_t)((npos + 255) / 256)), dim3(256), 0, s, d_in, n, g.sb, g.la, g.RP, g.TILE,

@@ -233,6 +233,7 @@ __global__ __launch_bounds__(64) void k_prio_fwd(const uint32_t *__restrict__ ps
     if (lane == 0 && gates_changed) gates_changed[b] = nflip ? 1u : 0u;
 }
 
+#ifdef LZ77X_VARIANTS   /* (the sequential form of the maps: the cross-check of k_prio_back2) */
 /* ------------------------------------------------------------------ backward sweep --- */
 
 /* dest[b][i]: the exit cell (relative to the block's end x1) that the chain of open gates starting at
@@ -329,6 +330,8 @@ __global__ __launch_bounds__(64) void k_prio_back(const uint32_t *__restrict__ p
         loc[(size_t)b * sb + i] = lloc[i];
     }
 }
+
+#endif
 
 /* The same maps WITHOUT a sequential sweep (round 3).  With the gates fixed a block is a forest of pointers
  * x -> x + S[x] (open gates), and dest is "follow them until they leave the block": pointer doubling, not a
@@ -755,7 +758,7 @@ hipError_t lz77k_prio_set_in0(lz77k_prio_plan &P, const uint32_t *h_or_d_in0, hi
 hipError_t lz77k_prio_maps(lz77k_prio_plan &P, hipStream_t s, bool whole, const uint16_t **d_sdest, const uint32_t **d_sloc)
 {
     if (P.nx == 0) return hipSuccess;
-    const size_t lds_back = (size_t)P.sb_r * 4 + (size_t)P.ring_n * 2;
+    [[maybe_unused]] const size_t lds_back = (size_t)P.sb_r * 4 + (size_t)P.ring_n * 2;
     const size_t lds_scan = (size_t)P.sb_r * (4 + 4 + 2 + 2);
     uint16_t *dest = PRIO_PTR(uint16_t, P.o_dest), *gdest = PRIO_PTR(uint16_t, P.o_gdest);
     uint32_t *loc = PRIO_PTR(uint32_t, P.o_loc), *gloc = PRIO_PTR(uint32_t, P.o_gloc);
@@ -766,11 +769,12 @@ hipError_t lz77k_prio_maps(lz77k_prio_plan &P, hipStream_t s, bool whole, const 
         if (e != hipSuccess) return e;
         if (whole && P.sb > 4096u) return hipErrorNotSupported;       /* the whole-plan map of a shard: LDS scans only */
     } else {
-        static const bool sweep = getenv("LZ77X_PRIO_BACK_SWEEP") != nullptr;        /* the sequential form (cross-check) */
-        if (sweep)
+#ifdef LZ77X_VARIANTS
+        if (LZ77X_VENV("LZ77X_PRIO_BACK_SWEEP"))                                           /* the sequential form (cross-check) */
             hipLaunchKernelGGL(k_prio_back, dim3(nb), dim3(64), lds_back, s, P.ps, P.nx, P.sb, P.B, P.ring_n, P.first, PRIO_PTR(uint64_t, P.o_gate[P.cur]),
                                dest, loc, P.voff, P.ncarried, PRIO_PTR(uint32_t, P.o_dirty));
         else
+#endif
             hipLaunchKernelGGL(k_prio_back2, dim3(nb), dim3(BK2_T), 0, s, P.ps, P.nx, P.sb, P.B, P.first, PRIO_PTR(uint64_t, P.o_gate[P.cur]),
                                dest, loc, P.voff, P.ncarried, PRIO_PTR(uint32_t, P.o_dirty));
     }

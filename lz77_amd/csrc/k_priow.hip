@@ -30,8 +30,14 @@
 #define PW_SORT_CAP 32768u              /* keys sorted per pass of the rank prologue (128 KB of LDS) */
 
 /* LZ77X_PW_DEBUG=1: cycle stamps of workgroup 0 of the last back / fwd / prep launch (development aid) */
+#ifdef LZ77X_VARIANTS
 __device__ unsigned long long pw_dbg[64];
 #define PW_STAMP(k) do { if (blockIdx.x == 0 && threadIdx.x == 0) pw_dbg[k] = __builtin_readcyclecounter(); } while (0)
+#define PW_NOTE(k, v) do { pw_dbg[k] = (v); } while (0)
+#else
+#define PW_STAMP(k) do { } while (0)
+#define PW_NOTE(k, v) do { (void)(v); } while (0)
+#endif
 
 /* orders LDS traffic only: __syncthreads() also waits for every global load and store in flight (s_waitcnt vmcnt(0)),
  * which put a round trip to HBM -- the next group's prefetched operands, the last group's result stores -- into every
@@ -107,7 +113,7 @@ __global__ __launch_bounds__(W) void k_pw_prep(const uint32_t *__restrict__ ps, 
     uint32_t ver = 0;                                       /* 0 .. 62; code 62 - ver; code 63 = a cleared entry */
     int par = 0;
     PW_STAMP(16);
-    uint32_t nrounds_dbg = 0;
+    [[maybe_unused]] uint32_t nrounds_dbg = 0;
     uint32_t vnext = blockIdx.x < ngroups ? ps[min(blockIdx.x * W + tid, nx - 1u)] : 0u;
     for (uint32_t g = blockIdx.x; g < ngroups; g += gridDim.x) {
         const uint32_t x = g * W + tid;
@@ -152,7 +158,7 @@ __global__ __launch_bounds__(W) void k_pw_prep(const uint32_t *__restrict__ ps, 
         if (lane == 0 && g * W + wave * 64u < nx) { rmask[wi] = rm; gate0[wi] = hm; }
     }
     PW_STAMP(17);
-    if (blockIdx.x == 0 && threadIdx.x == 0) { pw_dbg[18] = nrounds_dbg; pw_dbg[19] = (ngroups + gridDim.x - 1) / gridDim.x; }
+    if (blockIdx.x == 0 && threadIdx.x == 0) { PW_NOTE(18, nrounds_dbg); PW_NOTE(19, (ngroups + gridDim.x - 1) / gridDim.x); }
 }
 
 /* ------------------------------------------------------------------ forward sweep ---- */
@@ -460,7 +466,7 @@ __global__ __launch_bounds__(W) void k_pw_fwd(const uint32_t *__restrict__ ps, u
             __syncthreads();
         }
         PW_STAMP(13);
-        if (blockIdx.x == 0 && tid == 0) pw_dbg[14] = Kt;
+        if (blockIdx.x == 0 && tid == 0) PW_NOTE(14, Kt);
         /* ---- codes into the ring: own positions are sb + i (the plane is filled as if every cell held its own, then
          *      the old entries clear their bits: ranks are below 2^16) ---- */
         for (uint32_t wd = tid; wd < ring_n / 16u; wd += W) {
@@ -735,7 +741,7 @@ __global__ __launch_bounds__(W) void k_pw_back(const uint32_t *__restrict__ ps, 
         dest[(size_t)b * rs + i] = x0 + i < x1 ? dr[i] : (uint16_t)(i - (x1 - x0));
     }
     PW_STAMP(3);
-    if (blockIdx.x == 0 && threadIdx.x == 0) pw_dbg[4] = ngr;
+    if (blockIdx.x == 0 && threadIdx.x == 0) PW_NOTE(4, ngr);
 }
 
 /* ------------------------------------------------------------------ boundary scan ---- */
@@ -851,17 +857,19 @@ __global__ __launch_bounds__(PW_SCAN_T) void k_pw_cdest(const uint16_t *__restri
 
 void lz77kw_debug_dump(void)
 {
-    if (!getenv("LZ77X_PW_DEBUG")) return;
+#ifdef LZ77X_VARIANTS
+    if (!LZ77X_VENV("LZ77X_PW_DEBUG")) return;
     unsigned long long h[64];
     if (hipMemcpyFromSymbol(h, HIP_SYMBOL(pw_dbg), sizeof h) != hipSuccess) return;
     fprintf(stderr, "[pw] back wg0: init %llu loop %llu (%llu groups: %llu each) out %llu cycles | fwd wg0: prologue %llu (classify %llu, tail of %llu keys %llu, bitmaps %llu, ring %llu) loop %llu | prep wg0: %llu cycles, %llu rounds, %llu groups\n",
             h[1] - h[0], h[2] - h[1], h[4], h[4] ? (h[2] - h[1]) / h[4] : 0ull, h[3] - h[2], h[9] - h[8], h[11] - h[8], h[14], h[12] - h[11], h[13] - h[12],
             h[9] - h[13], h[10] - h[9], h[17] - h[16], h[18], h[19]);
+#endif
 }
 
 uint32_t lz77kw_width(int sb)
 {
-    const char *e = getenv("LZ77X_PRIO_WIDE");
+    const char *e = LZ77X_VENV("LZ77X_PRIO_WIDE");
     if (e) { const int w = atoi(e); if (w == 256 || w == 1024) return (uint32_t)w; if (w == 64) return 64u; }
     return sb > 4096 ? 1024u : 64u;
 }
@@ -901,10 +909,10 @@ hipError_t lz77kw_fwd(const uint32_t *d_ps, uint32_t nx, uint32_t sb, uint32_t r
     hipError_t e;
     uint32_t sort_cap = PW_SORT_CAP;
     {
-        const char *ce = getenv("LZ77X_PRIO_SORTCAP");      /* test hook: several passes of the rank prologue on small inputs */
+        const char *ce = LZ77X_VENV("LZ77X_PRIO_SORTCAP");      /* test hook: several passes of the rank prologue on small inputs */
         if (ce && atoi(ce) >= 64 && (uint32_t)atoi(ce) < PW_SORT_CAP) sort_cap = (uint32_t)atoi(ce);
     }
-    const uint32_t probe = getenv("LZ77X_PW_PROBE") ? (uint32_t)atoi(getenv("LZ77X_PW_PROBE")) : 0u;
+    const uint32_t probe = LZ77X_VENV("LZ77X_PW_PROBE") ? (uint32_t)atoi(LZ77X_VENV("LZ77X_PW_PROBE")) : 0u;
 #define PW_FWD(WW, PK, LDS)                                                                                                        \
     do {                                                                                                                           \
         if ((e = pw_lds_attr(k_pw_fwd<WW, PK>, (LDS))) != hipSuccess) return e;                                                    \

@@ -141,7 +141,7 @@ hipError_t lz77k_xfer_index(const uint32_t *d_ps, const uint32_t *d_xval, uint32
                             unsigned long long *d_total, uint32_t sb)
 {
     const uint32_t nd = dend - dbase;
-    if (sb && xb > xa && !getenv("LZ77X_XFER_V1")) {
+    if (sb && xb > xa && !LZ77X_VENV("LZ77X_XFER_V1")) {
         const uint32_t nblocks = (nd + XF_DB - 1u) / XF_DB;
         uint32_t *sums = reinterpret_cast<uint32_t *>(d_scan_tmp);
         void *tmp2 = sums + ((nblocks + 64u) & ~63u);
@@ -882,6 +882,7 @@ __global__ __launch_bounds__(TS_BLOCK, 8) __attribute__((amdgpu_num_sgpr(80))) v
     }
 }
 
+#ifdef LZ77X_VARIANTS   /* (round 1's large-window tie-break: the cross-check of k_tokens_rank, LZ77X_TOKEN_VARIANT=3) */
 /* ---- large windows (sb > 8192): the candidate index lives in global memory -------------------
  * Per tile of BIG_TT positions, every candidate position (tile + its SB look-back) is bucketed by
  * its first two bytes (exact 16-bit key, so a length-1 token reads the 256 adjacent buckets of its
@@ -1002,6 +1003,8 @@ __global__ __launch_bounds__(256) void k_tokens_big(const uint8_t *__restrict__ 
         tokval[k] = (off & omask) | (len << ob) | (next << (ob + lb));
     }
 }
+
+#endif
 
 /* ---- large windows, production: candidates in RANK order -----------------------------------------
  * The candidates whose match with p has the full length `len` are, with every other position of the
@@ -1151,9 +1154,14 @@ __global__ __launch_bounds__(256) void k_tokens_rank(const uint8_t *__restrict__
 /* bytes of the global candidate index for token positions spanning npos (0 when the LDS tile kernel applies) */
 size_t lz77k_tokens_index_bytes(const lz77x_geom &g, size_t npos)
 {
+#ifndef LZ77X_VARIANTS
+    (void)g; (void)npos;
+    return 0;
+#else
     if (g.sb <= 8192) return 0;
     const size_t ntiles = (npos + BIG_TT - 1) / BIG_TT;
     return ntiles * ((size_t)BIG_KEYS + BIG_TT + (size_t)g.sb + 8) * sizeof(uint32_t) + 256;
+#endif
 }
 
 /* one word per tile + 1: the sorted-order kernel cuts every region into ceil(TILE / TS_TT) tiles (TILE >= 3064) */
@@ -1177,6 +1185,7 @@ hipError_t lz77k_tokens(const uint8_t *d_in, uint32_t n, const lz77x_geom &g, co
         TIE_EV(1);
         return hipGetLastError();
     }
+#ifdef LZ77X_VARIANTS
     if ((variant == 0 || variant == 3) && g.sb > 8192 && d_index) {
         const uint32_t ntiles = (pos1 - pos0 + BIG_TT - 1) / BIG_TT;
         const uint32_t span = BIG_TT + (uint32_t)g.sb + 8;
@@ -1194,6 +1203,9 @@ hipError_t lz77k_tokens(const uint8_t *d_in, uint32_t n, const lz77x_geom &g, co
         TIE_EV(1);
         return hipGetLastError();
     }
+#else
+    (void)d_index;
+#endif
     if (d_ps && d_xval && d_tstart && lz77k_tokens_builds_lists(g, variant, d_ranks_all)) {
         /* production, LDS-sized windows: runs of the regions' sorted order (d_ranks_all = RP uint16 per region) */
         const ts_grid G = ts_make_grid(g);
@@ -1207,7 +1219,8 @@ hipError_t lz77k_tokens(const uint8_t *d_in, uint32_t n, const lz77x_geom &g, co
         const uint32_t budget = 78u * 1024u;                              /* two workgroups per CU */
         /* a list entry is 6 bytes (eviction: uint16 from the tile's first, priority: uint32, two arrays); the area also
          * holds a uint16 per eviction of a tile, what the lists fall back to when the priorities do not fit */
-        const uint32_t ent_cap = ((budget - off_lent) / 6u) & ~1u;
+        uint32_t ent_cap = ((budget - off_lent) / 6u) & ~1u;
+        if (const char *ec = LZ77X_VENV("LZ77X_TS_ENTCAP")) ent_cap = min(ent_cap, (uint32_t)atoi(ec) & ~1u);     /* test hook: the fallback lists */
         const size_t lds = (size_t)off_lent + max((size_t)ent_cap * 6, (size_t)span * 2);
         if (lds > 48 * 1024) {
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_tokens_sorted), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -1237,7 +1250,12 @@ hipError_t lz77k_tokens(const uint8_t *d_in, uint32_t n, const lz77x_geom &g, co
         uint32_t ent_cap = lent_off + 5 * span < budget ? (budget - lent_off) / 8 : span;
         if (bucket && ent_cap < TOK_HASH / 2) ent_cap = TOK_HASH / 2; /* the lent area doubles as bcur (TOK_HASH words) */
         const size_t lds = (size_t)lent_off + (size_t)ent_cap * 8;
+#ifdef LZ77X_VARIANTS
         auto fn = bucket ? k_tokens_tile<true> : k_tokens_tile<false>;
+#else
+        auto fn = k_tokens_tile<true>;
+        if (!bucket) return hipErrorNotSupported;
+#endif
         if (lds > 48 * 1024) {
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             if (e != hipSuccess) return e;

@@ -81,6 +81,16 @@ int lz77x_encode_file_buffered(FILE *in, FILE *out, int la, int sb);
 #ifdef __cplusplus
 #include <hip/hip_runtime_api.h>
 
+/* Cross-check variants, timing probes and forced fallbacks (the kernels of earlier rounds, the pair-scan matcher, the
+ * bitonic sorts, the host recurrence on demand, ...) exist in the build the tests load -- -DLZ77X_VARIANTS,
+ * liblz77_mi355x_variants.so -- and nowhere else: the product library has one path per stage and does not read their
+ * environment knobs. */
+#ifdef LZ77X_VARIANTS
+#define LZ77X_VENV(name) getenv(name)
+#else
+#define LZ77X_VENV(name) (static_cast<const char *>(nullptr))
+#endif
+
 /* ---- kernel launchers (k_match.hip, k_tokens.hip, k_decode.hip, k_util.hip).  All enqueue on `s` and return immediately. ----- */
 
 size_t lz77k_match_scratch_bytes(const lz77x_geom &g, uint32_t nregions);

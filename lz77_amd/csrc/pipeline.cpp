@@ -310,7 +310,7 @@ int shard_contexts(CtxSet &S, int want, std::vector<Ctx *> &cs)
 static void make_encode_geom(lz77x_geom *g, int sb, int la)
 {
     lz77x_make_geom(g, sb, la);
-    const char *vs = getenv("LZ77X_MATCH_VARIANT");
+    const char *vs = LZ77X_VENV("LZ77X_MATCH_VARIANT");
     const int variant = vs ? atoi(vs) : 0;
     if (variant == 1 || variant == 3) lz77x_geom_legacy(g);
 }
@@ -392,12 +392,12 @@ int encode_core_host(std::vector<Ctx *> &cs, const void *src, bool src_on_device
         for (int d = (int)D - 1; d >= 0; d--)
             if (first_chunk[d] == nchunks) first_chunk[d] = first_chunk[d + 1];      /* shard without chunks */
 
-        const char *vs = getenv("LZ77X_MATCH_VARIANT");
+        const char *vs = LZ77X_VENV("LZ77X_MATCH_VARIANT");
         const int variant = vs ? atoi(vs) : 0;
-        const char *tv = getenv("LZ77X_TOKEN_VARIANT");
+        const char *tv = LZ77X_VENV("LZ77X_TOKEN_VARIANT");
         const int tvariant = tv ? atoi(tv) : 0;
         const bool keep_ranks = !g.fast && tvariant == 0 && (variant == 0 || variant > 3);
-        const char *sv = getenv("LZ77X_SERIAL");               /* profiling aid: token kernels queue behind */
+        const char *sv = LZ77X_VENV("LZ77X_SERIAL");               /* profiling aid: token kernels queue behind */
         const bool serial = sv && atoi(sv);                    /* the match launches, no overlap */
         auto tstream = [&](uint32_t d) { return serial ? kstream(d) : cs[d]->tok; };
 
@@ -922,8 +922,8 @@ int decode_core(Ctx &c, size_t zn, hipStream_t s, bool want_data, size_t *n_out)
             HIPCHK(hipMemcpy(c.scratch.p, cyc.data(), cyc.size() * 4, hipMemcpyHostToDevice));
             d_cyc = c.scratch.as<uint32_t>();
         }
-        const char *dv = getenv("LZ77X_DECODE_VARIANT");            /* 0 production, 1 tile pass + jumping, (LZ77X_DECODE_V1: round 1) */
-        if (!stale && !general && lz77k_dec_seg_supported(g) && !(dv && atoi(dv)) && !getenv("LZ77X_DECODE_V1")) {
+        const char *dv = LZ77X_VENV("LZ77X_DECODE_VARIANT");            /* 0 production, 1 tile pass + jumping, (LZ77X_DECODE_V1: round 1) */
+        if (!stale && !general && lz77k_dec_seg_supported(g) && !(dv && atoi(dv)) && !LZ77X_VENV("LZ77X_DECODE_V1")) {
             if ((rc = c.tstart.need(lz77k_dec_seg_tmp_bytes(n32, g)))) return rc;
             HIPCHK(lz77k_dec_segments(c.tokval.as<uint32_t>(), c.dst.as<uint32_t>(), ntok, g, c.out.as<uint8_t>(), c.ptr.p, n32, c.tstart.p, s));
         } else {
@@ -934,7 +934,7 @@ int decode_core(Ctx &c, size_t zn, hipStream_t s, bool want_data, size_t *n_out)
         uint32_t *hcount = reinterpret_cast<uint32_t *>(hdr + 32);
         uint32_t total = n32;
         const uint32_t *in_list = nullptr;
-        if (general || getenv("LZ77X_DECODE_V1")) {
+        if (general || LZ77X_VENV("LZ77X_DECODE_V1")) {
             /* round 1: a pointer per output byte in HBM, jumped there (kept as a cross-check, and for streams
              * that no run of the reference's encoder produces) */
             HIPCHK(lz77k_dec_expand(c.tokval.as<uint32_t>(), c.dst.as<uint32_t>(), ntok, g, c.out.as<uint8_t>(),
@@ -1013,7 +1013,7 @@ int decode_sharded(std::vector<Ctx *> &cs, const uint8_t *z, size_t zn, uint8_t 
     if (ntok64 > LZ77X_MAX_N) return LZ77X_E_TOOBIG;
     const uint32_t ntok = (uint32_t)ntok64;
     const size_t D = cs.size();
-    if (!lz77k_dec_seg_supported(g) || getenv("LZ77X_DECODE_VARIANT") || getenv("LZ77X_DECODE_V1") || ntok < 64 * D) return LZ77X_OK;
+    if (!lz77k_dec_seg_supported(g) || LZ77X_VENV("LZ77X_DECODE_VARIANT") || LZ77X_VENV("LZ77X_DECODE_V1") || ntok < 64 * D) return LZ77X_OK;
     const size_t usb = (size_t)sb;
     std::vector<uint32_t> k0(D + 1);
     for (size_t d = 0; d <= D; d++) k0[d] = (uint32_t)lz77x_shard_token_cut(ntok, (int)D, (int)d);
@@ -1428,7 +1428,7 @@ int seg_front(SegJob &J, const lz77x_geom &g)
         if (nregions > all) nregions = all;
     }
     J.nregions = nregions;
-    const char *tv = getenv("LZ77X_TOKEN_VARIANT");
+    const char *tv = LZ77X_VENV("LZ77X_TOKEN_VARIANT");
     J.tvariant = tv ? atoi(tv) : 0;
     J.d_order = nullptr;
     if (!nregions) {
@@ -1452,7 +1452,7 @@ int seg_front(SegJob &J, const lz77x_geom &g)
     if ((rc = c.ps.need((np + 8) * 4))) return rc;
     if ((rc = c.maxlen.need(np + 64))) return rc;
     /* the regions' sorted order stays resident for the tie-break (RP uint16 per region: 2.7 B per input byte) */
-    const bool keep_order = J.tvariant == 0 && !(g.fast && getenv("LZ77X_TOKENS_BUCKET"));
+    const bool keep_order = J.tvariant == 0 && !(g.fast && LZ77X_VENV("LZ77X_TOKENS_BUCKET"));
     /* large windows: rank + inverse arrays, (2RP + 8) words per region, for the rank-order tie-break */
     if (keep_order && (rc = c.ranks_all.need(g.fast ? (size_t)nregions * g.RP * 2 + 64 : (size_t)nregions * (2 * (size_t)g.RP + 8) * sizeof(uint32_t)))) return rc;
     J.d_order = keep_order ? c.ranks_all.as<uint32_t>() : nullptr;
@@ -1513,7 +1513,7 @@ int seg_mid(SegJob &J, const lz77x_geom &g, SegCarry &carry, bool allow_fallback
          *    LZ77X_CHAIN_STREAM=1 runs it on a stream of its own beside the recurrence -- */
         const uint32_t *d_tbase = nullptr, *d_exit = nullptr;
         uint32_t nsub = 0;
-        hipStream_t sc = getenv("LZ77X_CHAIN_STREAM") ? c.tok : s;   /* measured: beside the recurrence it costs the recurrence more (6.0 -> 6.5 ms) than it hides (0.4) */
+        hipStream_t sc = LZ77X_VENV("LZ77X_CHAIN_STREAM") ? c.tok : s;   /* measured: beside the recurrence it costs the recurrence more (6.0 -> 6.5 ms) than it hides (0.4) */
         if (sc != s) HIPCHK(hipStreamWaitEvent(sc, c.ev[1], 0));               /* the match stage is through */
         HIPCHK(hipEventRecord(c.match_ev[0], sc));
         HIPCHK(lz77k_chain(c.maxlen.as<uint8_t>(), E, g.la, c.chain.as<uint32_t>(), c.chain_tmp.p, sc, &d_tbase, &nsub, start, &d_exit));
@@ -1744,7 +1744,7 @@ int encode_stream_device(Ctx &c, Source &src, Sink &sink, const lz77x_geom &g, h
              * per 50 MB half against 6.0 for 100 MB, co-running kernels included), so S1 ends at 23.1 ms against
              * 20.8 in one segment */
             const size_t hint = src.size_hint();
-            const char *sp = getenv("LZ77X_SPLIT");
+            const char *sp = LZ77X_VENV("LZ77X_SPLIT");
             if (sp && atoi(sp) && pipelined && hint >= ((size_t)32 << 20) && hint / 2 + csub < seg) seg = (hint / 2 + csub) / csub * csub;
         }
         /* a source of known size below a segment: buffers sized for it, not for 2^30 positions (the whole input
@@ -1955,7 +1955,7 @@ int encode_sharded(std::vector<Ctx *> &cs, const uint8_t *src, size_t n, const l
     const size_t D = (size_t)planned;
     std::vector<ShardJob> J(D);
     int rc;
-    const char *tv = getenv("LZ77X_TOKEN_VARIANT");
+    const char *tv = LZ77X_VENV("LZ77X_TOKEN_VARIANT");
     const int tvariant = tv ? atoi(tv) : 0;
     auto dev = [&](ShardJob &j) -> int { HIPCHK(hipSetDevice(j.c->device)); return LZ77X_OK; };
     auto sync_all = [&]() -> int {
@@ -2216,8 +2216,8 @@ int encode_sharded(std::vector<Ctx *> &cs, const uint8_t *src, size_t n, const l
  * otherwise (LZ77X_HOST_STAGEB=1 forces it) or when the gate iteration gives up. */
 bool device_pipeline_ok(size_t ndev, const lz77x_geom &g)
 {
-    const char *hs = getenv("LZ77X_HOST_STAGEB"), *vs = getenv("LZ77X_MATCH_VARIANT");
-    return ndev == 1 && g.shifted && lz77k_prio_supported(g.sb) && !(hs && atoi(hs)) && !(vs && atoi(vs)) && !getenv("LZ77X_SERIAL");
+    const char *hs = LZ77X_VENV("LZ77X_HOST_STAGEB"), *vs = LZ77X_VENV("LZ77X_MATCH_VARIANT");
+    return ndev == 1 && g.shifted && lz77k_prio_supported(g.sb) && !(hs && atoi(hs)) && !(vs && atoi(vs)) && !LZ77X_VENV("LZ77X_SERIAL");
 }
 
 /* memory -> sink.  src: host or device pointer of n bytes */
@@ -2536,7 +2536,7 @@ static int run_match_only(CtxSet &S, const uint8_t *in, size_t n, int sb, int la
         if (batch > nregions) batch = nregions;
         if ((rc = c.scratch.need(lz77k_match_scratch_bytes(*g, batch)))) return rc;
     }
-    const char *vs = getenv("LZ77X_MATCH_VARIANT");
+    const char *vs = LZ77X_VENV("LZ77X_MATCH_VARIANT");
     const int variant = vs ? atoi(vs) : 0;
     for (uint32_t r0 = 0; r0 < nregions; r0 += batch) {
         const uint32_t nr = nregions - r0 < batch ? nregions - r0 : batch;

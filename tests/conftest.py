@@ -20,7 +20,8 @@ def pytest_sessionstart(session):
     import subprocess
     lib = os.path.join(ROOT, "lz77_amd", "liblz77_mi355x.so")
     cli = os.path.join(ROOT, "lz77_amd", "lz77")
-    if not (os.path.exists(lib) and os.path.exists(cli)):
+    var = os.path.join(ROOT, "lz77_amd", "liblz77_mi355x_variants.so")
+    if not (os.path.exists(lib) and os.path.exists(cli) and os.path.exists(var)):
         subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "lz77_amd", "csrc")])
     if not os.path.exists(os.path.join(ROOT, "oracle", "liblz77_oracle.so")):
         subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle")])

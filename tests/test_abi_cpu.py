@@ -36,6 +36,24 @@ def test_library_is_the_hip_build():
     assert b"lz77o_" not in blob                # the oracle is not linked into the product
 
 
+def test_product_library_has_one_path_per_stage():
+    """The cross-check kernels (pair-scan matcher, round-1 walkers and tie-break, sequential boundary maps) live in
+    liblz77_mi355x_variants.so only; both libraries export the same C ABI."""
+    import re
+    def kernels(path):
+        return set(re.findall(rb"_Z\d+k_[a-z0-9_]+(?:ILb[01]ELi\d)?", open(path, "rb").read()))
+    prod, var = kernels(L.LIB_PATH), kernels(L.VARIANTS_LIB_PATH)
+    cross = [b"_Z10k_walk_big", b"_Z11k_prio_back", b"_Z12k_tokens_big", b"_Z12k_bidx_count", b"_Z7k_matchILb1ELi1", b"_Z7k_matchILb0ELi0"]
+    for k in cross:
+        assert k not in prod, k
+        assert k in var, k
+    for k in (b"_Z15k_tokens_sorted", b"_Z12k_prio_back2", b"_Z11k_walk_wave", b"_Z7k_matchILb1ELi3", b"_Z9k_dec_seg"):
+        assert k in prod and k in var, k
+    V = ctypes.CDLL(L.VARIANTS_LIB_PATH)
+    for name in L.SYMBOLS:
+        assert hasattr(V, name), name
+
+
 def test_strerror_and_version():
     lib = L.lib()
     assert lib.lz77x_version().startswith(b"lz77-mi355x")

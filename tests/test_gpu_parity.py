@@ -47,10 +47,11 @@ def test_stage_neighbours(kind, seed, n, sb, la):
     assert np.array_equal(gS[:nx], S[:nx])
 
 
-PRIO_ENVS = [{}, {"LZ77X_PRIO_BLOCK": "512", "LZ77X_PRIO_SCAN_GROUP": "3"}, {"LZ77X_PRIO_BLOCK": "4096"}]
+PRIO_ENVS = [{}, {"LZ77X_PRIO_BLOCK": "512", "LZ77X_PRIO_SCAN_GROUP": "3"}, {"LZ77X_PRIO_BLOCK": "4096"},
+             {"LZ77X_PRIO_BACK_SWEEP": "1"}, {"LZ77X_PRIO_BLOCK": "20480", "LZ77X_PRIO_SCAN_GROUP": "2"}]
 
 
-@pytest.mark.parametrize("env", PRIO_ENVS, ids=["default", "b512g3", "b4096"])
+@pytest.mark.parametrize("env", PRIO_ENVS, ids=["default", "b512g3", "b4096", "sweepmaps", "b20480g2"])
 @pytest.mark.parametrize("kind,seed,n,sb,la", [c for c in STAGE_CASES if c[3] <= 4096] +
                          [("records", 65, 300000, 255, 7), ("mixed", 66, 400000, 1000, 10), ("zeros", 0, 70000, 100, 15),
                           ("text", 67, 1 << 20, 4095, 15), ("lowent", 68, 300000, 4095, 15)])
@@ -352,10 +353,12 @@ def test_segments_give_identical_bytes(kind, seed, n, sb, la, seg, monkeypatch):
 @pytest.mark.parametrize("env", [{"LZ77X_MATCH_VARIANT": "1"}, {"LZ77X_MATCH_VARIANT": "3"}, {"LZ77X_SORT_VARIANT": "1"},
                                  {"LZ77X_SORT_VARIANT": "2"}, {"LZ77X_TOKEN_VARIANT": "1"}, {"LZ77X_TOKEN_VARIANT": "2"}, {"LZ77X_WALK_RUN": "256"}, {"LZ77X_WALK_RUN": "1000"},
                                  {"LZ77X_WALK_RUN": "4096"}, {"LZ77X_C1_SORT_V1": "1"}, {"LZ77X_MATCH_BATCH": "7"}, {"LZ77X_PRIO_SKIP": "1"},
-                                 {"LZ77X_PRIO_SKIP": "1", "LZ77X_PRIO_BLOCK": "16384"}, {"LZ77X_PRIO_SKIP": "0", "LZ77X_PRIO_BLOCK": "16384"}])
+                                 {"LZ77X_PRIO_SKIP": "1", "LZ77X_PRIO_BLOCK": "16384"}, {"LZ77X_PRIO_SKIP": "0", "LZ77X_PRIO_BLOCK": "16384"},
+                                 {"LZ77X_PRIO_BACK_SWEEP": "1"}, {"LZ77X_TS_ENTCAP": "64"}, {"LZ77X_TS_ENTCAP": "1500"}])
 def test_kernel_variants_agree(env, monkeypatch):
     """independent formulations of the same stage (exhaustive pair scan vs bitmap walkers, merge sort vs
-    plain / blocked bitonic sort, three token kernels) all reproduce the reference stream"""
+    plain / blocked bitonic sort, three token kernels, sequential vs pointer-doubling boundary maps; LZ77X_TS_ENTCAP: the
+    tie-break's hand-over lists when the priorities do not fit the LDS) all reproduce the reference stream"""
     data = synth.mixed(3_000_000, 86)
     want = O.encode_bst(data)
     for k, v in env.items():
