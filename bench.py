@@ -408,12 +408,13 @@ def main():
         tlaunches = max(int(mean(enc_stats, "token_launches")), 1)
         k_match_ms = mean(enc_stats, "k_match_ms")               # sort + window walkers + finalize
         alg_bytes = n + zn                                        # encode reads n, writes zn
-        # the three big kernels of an encode, each timed by its own hipEvent pair on the stream it runs on
+        # the big kernels of an encode, each timed by its own hipEvent pair on the stream it runs on
         iters = max(int(round(mean(enc_stats, "prio_iters"))), 1)
         cands = {
             "k_tokens_sorted (offset tie-break: equal-length candidates as runs of the regions' sorted order)": (mean(enc_stats, "k_tiebreak_ms"), tlaunches, "k_tokens_sorted"),
             "k_walk (bitmap window walkers: in-order neighbours of every position)": (mean(enc_stats, "k_walk_ms"), launches, "k_walk"),
-            "k_match<true,3> (region key sort + rank export)": (mean(enc_stats, "k_sort_ms"), launches, "k_match"),
+            "k_c1_chunks (key sort of every 4 K chunk of positions)": (mean(enc_stats, "k_sort_chunks_ms"), launches, "k_c1_chunks"),
+            "k_match<true,3> (a region's last two merge levels + rank export)": (mean(enc_stats, "k_sort_ms") - mean(enc_stats, "k_sort_chunks_ms"), launches, "k_match"),
             "k_prio_fwd (priority recurrence: forward sweep of one gate iteration)": (mean(enc_stats, "k_prio_fwd_ms"), iters, "k_prio_fwd"),
         }
         dom_name = max(cands, key=lambda k: cands[k][0])
@@ -452,7 +453,7 @@ def main():
                          "traffic_source": "profiles/traffic.json (PMC passes of the committed rocprofv3 run, per launch; not measured in this run)",
                          "frac_op": round(alg_bytes / (t_device_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 6) if t_device_ms > 0 else 0.0,
                          "frac_op_def": "SURVEY 8d: algorithmic bytes / SUM of the encode's kernel times (match + chain + recurrence + "
-                                        "hand-over index, tie-break and pack) / peak -- the whole operation, beside the dominant kernel's `frac`",
+                                        "tie-break with its hand-over lists, and pack) / peak -- the whole operation, beside the dominant kernel's `frac`",
                          "t_device_ms": round(t_device_ms, 3),
                          "launches_per_step": dom_launches,
                          "algorithmic_bytes_per_launch": alg_bytes // dom_launches,
@@ -472,7 +473,7 @@ def main():
             "encode_MBps": round(n / (mean(enc_stats, "total_ms") * 1e-3) / 1e6, 2),
             "decode_MBps": round(n / (mean(dec_stats, "total_ms") * 1e-3) / 1e6, 2),
             "encode_breakdown_ms": {k: round(mean(enc_stats, k), 2) for k in
-                                    ("total_ms", "k_match_ms", "k_sort_ms", "k_walk_ms", "k_token_ms", "k_tiebreak_ms", "k_prio_ms",
+                                    ("total_ms", "k_match_ms", "k_sort_ms", "k_sort_chunks_ms", "k_walk_ms", "k_token_ms", "k_tiebreak_ms", "k_prio_ms",
                                      "k_prio_fwd_ms", "k_prio_back_ms", "k_prio_scan_ms", "k_chain_ms", "host_chain_ms",
                                      "host_stageb_ms", "copy_ms")},
             "prio_iters": iters,

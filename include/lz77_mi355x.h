@@ -147,6 +147,7 @@ typedef struct lz77x_stats {
     double k_prio_fwd_ms;     /* of k_prio_ms: the forward sweeps (k_prio_fwd), summed over the iterations */
     double k_prio_back_ms;    /* of k_prio_ms: the backward sweeps (k_prio_back) */
     double k_prio_scan_ms;    /* of k_prio_ms: the block-boundary scans (k_prio_scan_*) */
+    double k_sort_chunks_ms;  /* of k_sort_ms: the chunk-sort kernel alone (k_c1_chunks; 0 where the region kernel sorts everything) */
 } lz77x_stats;
 int lz77x_last_stats(lz77x_stats *st);
 

@@ -45,7 +45,7 @@ class Stats(ctypes.Structure):
                 ("decode_rounds", ctypes.c_uint32), ("k_walk_ms", ctypes.c_double), ("k_tiebreak_ms", ctypes.c_double),
                 ("token_launches", ctypes.c_uint32), ("prio_iters", ctypes.c_uint32),
                 ("k_prio_ms", ctypes.c_double), ("k_chain_ms", ctypes.c_double), ("k_prio_fwd_ms", ctypes.c_double),
-                ("k_prio_back_ms", ctypes.c_double), ("k_prio_scan_ms", ctypes.c_double)]
+                ("k_prio_back_ms", ctypes.c_double), ("k_prio_scan_ms", ctypes.c_double), ("k_sort_chunks_ms", ctypes.c_double)]
 
     def as_dict(self) -> dict:
         return {k: getattr(self, k) for k, _ in self._fields_}

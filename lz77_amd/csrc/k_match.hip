@@ -2070,6 +2070,7 @@ hipError_t lz77k_match(const uint8_t *d_in, uint32_t n, const lz77x_geom &g, uin
             hipLaunchKernelGGL(k_c1_chunks, dim3(nregions * 3u + 1u), dim3(C1_BLOCK), 0, s, d_in, n, g.la, (uint64_t)region0 * g.TILE, ch);
             d_chunks = ch;
         }
+        if (ev_sort && (e = hipEventRecord(ev_sort[3], s)) != hipSuccess) return e;        /* [0] .. [3]: the chunk sort alone */
         e = launch_match<true, 3>(LZ77K_MATCH_ARGS, reinterpret_cast<uint16_t *>(d_ranks_all), d_chunks);
         if (e != hipSuccess) return e;
         if (ev_sort && (e = hipEventRecord(ev_sort[1], s)) != hipSuccess) return e;
@@ -2104,6 +2105,7 @@ hipError_t lz77k_match(const uint8_t *d_in, uint32_t n, const lz77x_geom &g, uin
         /* production for large windows: sort (ranks stay in scratch) -> global-bitmap walkers -> finalize */
         hipError_t e = ev_sort ? hipEventRecord(ev_sort[0], s) : hipSuccess;
         if (e != hipSuccess) return e;
+        if (ev_sort && (e = hipEventRecord(ev_sort[3], s)) != hipSuccess) return e;        /* (no chunk kernel of its own to time) */
         /* rank + inverse of every region: in the caller's persistent array (the rank-order tie-break
          * reads them again once the host stage is through the chunk) or at the head of the scratch */
         const size_t stride = 2 * (size_t)g.RP + 8;

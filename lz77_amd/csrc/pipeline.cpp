@@ -462,7 +462,7 @@ int encode_core_host(std::vector<Ctx *> &cs, const void *src, bool src_on_device
                 HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming | hipEventBlockingSync));
                 c.chunk_ev.push_back(e);
             }
-            while (c.sort_ev.size() < 3 * (size_t)nchunks) {
+            while (c.sort_ev.size() < 4 * (size_t)nchunks) {
                 hipEvent_t e;
                 HIPCHK(hipEventCreate(&e));                                    /* region sort | walkers */
                 c.sort_ev.push_back(e);
@@ -508,7 +508,7 @@ int encode_core_host(std::vector<Ctx *> &cs, const void *src, bool src_on_device
             }
             if (G.d == 0) HIPCHK(hipEventRecord(c.match_ev[2 * launches0], kstream(G.d)));
             HIPCHK(lz77k_match(c.in.as<uint8_t>(), n32, g, r0, nr, c.ps.as<uint32_t>(), c.maxlen.as<uint8_t>(),
-                               c.scratch.p, variant, kstream(G.d), G.d == 0 ? &c.sort_ev[3 * launches0] : nullptr,
+                               c.scratch.p, variant, kstream(G.d), G.d == 0 ? &c.sort_ev[4 * launches0] : nullptr,
                                keep_ranks ? c.ranks_all.as<uint32_t>() : nullptr));
             g_stats.match_launches++;
             {
@@ -798,9 +798,11 @@ int encode_core_host(std::vector<Ctx *> &cs, const void *src, bool src_on_device
     if (sort_timed && D == 1) {
         double sort_ms = 0, walk_ms = 0;
         for (uint32_t i = 0; i < launches0_total; i++) {
-            HIPCHK(hipEventElapsedTime(&ms, c0.sort_ev[3 * i], c0.sort_ev[3 * i + 1]));
+            HIPCHK(hipEventElapsedTime(&ms, c0.sort_ev[4 * i], c0.sort_ev[4 * i + 3]));
+            g_stats.k_sort_chunks_ms += ms;
+            HIPCHK(hipEventElapsedTime(&ms, c0.sort_ev[4 * i], c0.sort_ev[4 * i + 1]));
             sort_ms += ms;
-            HIPCHK(hipEventElapsedTime(&ms, c0.sort_ev[3 * i + 1], c0.sort_ev[3 * i + 2]));
+            HIPCHK(hipEventElapsedTime(&ms, c0.sort_ev[4 * i + 1], c0.sort_ev[4 * i + 2]));
             walk_ms += ms;
         }
         g_stats.k_sort_ms = sort_ms;
@@ -1458,14 +1460,14 @@ int seg_front(SegJob &J, const lz77x_geom &g)
     J.d_order = keep_order ? c.ranks_all.as<uint32_t>() : nullptr;
     if (!g.fast && !keep_order && (rc = c.bidx.need(lz77k_tokens_index_bytes(g, (size_t)J.nloc)))) return rc;
     const uint32_t nlaunch = (nregions + batch - 1) / batch;
-    while (c.sort_ev.size() < 3 * (size_t)nlaunch) { hipEvent_t e; HIPCHK(hipEventCreate(&e)); c.sort_ev.push_back(e); }
+    while (c.sort_ev.size() < 4 * (size_t)nlaunch) { hipEvent_t e; HIPCHK(hipEventCreate(&e)); c.sort_ev.push_back(e); }
     while (c.match_ev.size() < 8) { hipEvent_t e; HIPCHK(hipEventCreate(&e)); c.match_ev.push_back(e); }
     /* -- match stage (replaces tree.c insert/delete/find): ps[], maxlen[] -- */
     HIPCHK(hipEventRecord(c.ev[0], s));
     for (uint32_t r0 = 0; r0 < nregions; r0 += batch) {
         const uint32_t nr = nregions - r0 < batch ? nregions - r0 : batch;
         HIPCHK(lz77k_match(c.in.as<uint8_t>(), J.nloc, g, r0, nr, c.ps.as<uint32_t>(), c.maxlen.as<uint8_t>(), c.scratch.p, 0, s,
-                           &c.sort_ev[3 * J.launches], J.d_order));
+                           &c.sort_ev[4 * J.launches], J.d_order));
         J.launches++;
     }
     HIPCHK(hipEventRecord(c.ev[1], s));
@@ -1678,9 +1680,11 @@ int seg_finish(SegJob &J, SegCarry &carry, Sink &sink, double *waited, hipStream
     HIPCHK(hipEventElapsedTime(&ms, c.ev[2], c.ev[3]));
     g_stats.k_token_ms += ms;
     for (uint32_t i = 0; i < J.launches; i++) {
-        HIPCHK(hipEventElapsedTime(&ms, c.sort_ev[3 * i], c.sort_ev[3 * i + 1]));
+        HIPCHK(hipEventElapsedTime(&ms, c.sort_ev[4 * i], c.sort_ev[4 * i + 3]));
+        g_stats.k_sort_chunks_ms += ms;
+        HIPCHK(hipEventElapsedTime(&ms, c.sort_ev[4 * i], c.sort_ev[4 * i + 1]));
         g_stats.k_sort_ms += ms;
-        HIPCHK(hipEventElapsedTime(&ms, c.sort_ev[3 * i + 1], c.sort_ev[3 * i + 2]));
+        HIPCHK(hipEventElapsedTime(&ms, c.sort_ev[4 * i + 1], c.sort_ev[4 * i + 2]));
         g_stats.k_walk_ms += ms;
     }
     if (J.E > J.start) {
