@@ -294,7 +294,7 @@ __global__ __launch_bounds__(W) void k_pw_fwd(const uint32_t *__restrict__ ps, u
         __shared__ uint32_t s_cls[NPASS + 2];               /* old values per pass; [NPASS] the tail */
         uint32_t val[EPT];
 #pragma unroll
-        for (uint32_t q = 0; q < EPT; q++) val[q] = inb[min(q * W + tid, sb - 1u)];
+        for (uint32_t q = 0; q < EPT; q++) { uint32_t tq = tid; asm volatile("" : "+v"(tq)); val[q] = inb[min(q * W + tq, sb - 1u)]; }
         if (tid < NPASS + 2) s_cls[tid] = 0;
         __syncthreads();
         /* class of an entry: its bitmap pass, NPASS = tail, 7 = not old / beyond the row */
@@ -305,7 +305,7 @@ __global__ __launch_bounds__(W) void k_pw_fwd(const uint32_t *__restrict__ ps, u
         for (uint32_t r = 0; r < NPASS; r++) mycnt[r] = 0;
 #pragma unroll
         for (uint32_t q = 0; q < EPT; q++) {
-            const uint32_t i = q * W + tid;
+            uint32_t tq = tid; asm volatile("" : "+v"(tq)); const uint32_t i = q * W + tq;
             const uint32_t v = val[q];
             const bool old = i < sb && (all_old || v != x0 + i + voff);
             const uint32_t u = hi - 1u - v;
@@ -343,7 +343,7 @@ __global__ __launch_bounds__(W) void k_pw_fwd(const uint32_t *__restrict__ ps, u
             if (!one) {
 #pragma unroll
                 for (uint32_t q = 0; q < EPT; q++) {
-                    const uint32_t i = q * W + tid;
+                    uint32_t tq = tid; asm volatile("" : "+v"(tq)); const uint32_t i = q * W + tq;
                     if (((oldm >> q) & 1ull) && (hi - 1u - val[q]) / BM_BITS >= NPASS) gv[i] = 0;     /* rank accumulators */
                 }
             }
@@ -355,7 +355,7 @@ __global__ __launch_bounds__(W) void k_pw_fwd(const uint32_t *__restrict__ ps, u
                     __syncthreads();
 #pragma unroll
                     for (uint32_t q = 0; q < EPT; q++) {
-                        const uint32_t i = q * W + tid;
+                        uint32_t tq = tid; asm volatile("" : "+v"(tq)); const uint32_t i = q * W + tq;
                         if (((oldm >> q) & 1ull) && (hi - 1u - val[q]) / BM_BITS >= NPASS) {
                             const uint32_t sl = cb[i];
                             if (sl >= c0 && sl < c0 + m) skey[sl - c0] = val[q];
@@ -377,7 +377,7 @@ __global__ __launch_bounds__(W) void k_pw_fwd(const uint32_t *__restrict__ ps, u
                 }
 #pragma unroll
                 for (uint32_t q = 0; q < EPT; q++) {
-                    const uint32_t i = q * W + tid;
+                    uint32_t tq = tid; asm volatile("" : "+v"(tq)); const uint32_t i = q * W + tq;
                     const uint32_t v = val[q];
                     if (((oldm >> q) & 1ull) && (hi - 1u - v) / BM_BITS >= NPASS) {
                         uint32_t pos = 0;
@@ -395,7 +395,7 @@ __global__ __launch_bounds__(W) void k_pw_fwd(const uint32_t *__restrict__ ps, u
                 for (uint32_t q0 = 0; q0 < EPT; q0 += EPT / 8) {
 #pragma unroll
                     for (uint32_t k = 0; k < EPT / 8; k++) {
-                        const uint32_t q = q0 + k, i = q * W + tid;
+                        uint32_t tq = tid; asm volatile("" : "+v"(tq)); const uint32_t q = q0 + k, i = q * W + tq;
                         rk[k] = ((oldm >> q) & 1ull) && (hi - 1u - val[q]) / BM_BITS >= NPASS ? gv[i] : PW_NONE;
                     }
                     __syncthreads();                            /* (every accumulator of the slice is read before a table entry lands on one) */
@@ -408,7 +408,7 @@ __global__ __launch_bounds__(W) void k_pw_fwd(const uint32_t *__restrict__ ps, u
                 __syncthreads();
 #pragma unroll
                 for (uint32_t q = 0; q < EPT; q++) {
-                    const uint32_t i = q * W + tid;
+                    uint32_t tq = tid; asm volatile("" : "+v"(tq)); const uint32_t i = q * W + tq;
                     if (((oldm >> q) & 1ull) && (hi - 1u - val[q]) / BM_BITS >= NPASS) {
                         const uint32_t rkq = cb[i];
                         gv[rkq] = val[q];
@@ -478,7 +478,7 @@ __global__ __launch_bounds__(W) void k_pw_fwd(const uint32_t *__restrict__ ps, u
         __syncthreads();
 #pragma unroll
         for (uint32_t q = 0; q < EPT; q++) {
-            const uint32_t i = q * W + tid;
+            uint32_t tq = tid; asm volatile("" : "+v"(tq)); const uint32_t i = q * W + tq;
             if (i < sb) {
                 const bool own = !((old0 >> q) & 1ull);
                 const uint32_t code = own ? sb + i : val[q];
