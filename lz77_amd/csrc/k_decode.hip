@@ -605,48 +605,45 @@ __global__ __launch_bounds__(1024) void k_dec_tails_replay(const uint16_t *__res
     }
 }
 
-/* flagged bytes take their value from the resolved tail of the segment before theirs.  A lane fetches one
- * 64-bit flag word; the wave then visits only the words that have a flag (they cluster at segment starts). */
-__global__ __launch_bounds__(256) void k_dec_patch(uint8_t *__restrict__ out, const uint16_t *__restrict__ ref16,
-                                                   const unsigned long long *__restrict__ flags,
-                                                   const uint8_t *__restrict__ tres0 /* row s = the resolved sb bytes BEFORE segment s (row 0: a shard's
-                                                                                        incoming bytes; never read otherwise) */,
-                                                   uint32_t n, uint32_t seg_bytes, uint32_t sb)
+/* Flagged bytes take their value from the resolved tail of the segment before theirs: a workgroup per segment with the
+ * segment's row of resolved bytes in LDS.  On text a quarter of all bytes are flagged (a copy chain is six hops on
+ * average, one in five more than twelve: the first 25 KB of a 98 KB segment mostly lead back across its start); until
+ * round 3 a grid-wide kernel fetched every one of them with a gather of its own from the row in HBM -- 64 sectors per
+ * wave instruction, 0.17 ms, the address path's limit.  Here the row is 4 KB of LDS, the references of eight flag words
+ * are in flight together and the bytes leave as whole lines. */
+#define DPS_T 1024u                                  /* a wavefront's batches follow one another, two round trips each: many wavefronts per segment */
+__global__ __launch_bounds__(DPS_T) void k_dec_patch_seg(uint8_t *__restrict__ out, const uint16_t *__restrict__ ref16,
+                                                       const unsigned long long *__restrict__ flags,
+                                                       const uint8_t *__restrict__ tres0, uint32_t n, uint32_t seg_bytes, uint32_t sb)
 {
-    const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t nwords = (n + 63u) / 64u;
-    const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = (gridDim.x * blockDim.x) >> 6;
-    for (uint32_t w0 = wave * 64u; w0 < nwords; w0 += nwaves * 64u) {
-        const uint32_t wi = w0 + lane;
-        const unsigned long long m = wi < nwords ? flags[wi] : 0ull;
-        unsigned long long have = __ballot(m != 0ull);
-        while (have) {
-            /* four flagged words per trip: their dependent loads (ref16 -> tres) overlap */
-            uint32_t j[4], r[4];
-            bool on[4];
+    __shared__ uint8_t row[DS_TAIL_MAX];
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const uint32_t sg = blockIdx.x;
+    const uint32_t a = sg * seg_bytes, b = n - a < seg_bytes ? n : a + seg_bytes;
+    for (uint32_t i = tid * 4u; i < sb; i += DPS_T * 4u)                /* (rows are sb bytes apart: no alignment to count on) */
 #pragma unroll
-            for (int u = 0; u < 4; u++) {
-                on[u] = false;
-                j[u] = 0;
-                if (have) {
-                    const int l = __builtin_ctzll(have);
-                    have &= have - 1ull;
-                    const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)m, l);
-                    const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(m >> 32), l);
-                    const unsigned long long mm = ((unsigned long long)hi << 32) | lo;
-                    j[u] = (w0 + (uint32_t)l) * 64u + lane;
-                    on[u] = (mm >> lane) & 1ull;
-                }
-            }
+        for (uint32_t q = 0; q < 4; q++) if (i + q < sb) row[i + q] = tres0[(size_t)sg * sb + i + q];
+    __syncthreads();
+    const uint32_t w_lo = a >> 6, w_hi = (b + 63u) >> 6;               /* seg_bytes is a multiple of 4096 */
+    const uint32_t wlast = w_hi - 1u;
+    unsigned long long mn = flags[min(w_lo + wave * 8u + (lane & 7u), wlast)];          /* (unconditional, clamped: the next batch's flags travel with this batch's references) */
+    for (uint32_t wb = w_lo + wave * 8u; wb < w_hi; wb += DPS_T / 8u) {
+        const unsigned long long m = lane < 8u && wb + lane < w_hi ? mn : 0ull;
+        mn = flags[min(wb + DPS_T / 8u + (lane & 7u), wlast)];
+        if (!__ballot(m != 0ull)) continue;
+        uint32_t r[8];
+        bool on[8];
 #pragma unroll
-            for (int u = 0; u < 4; u++) r[u] = ref16[on[u] ? j[u] : 0u];
-            uint8_t v[4];
-#pragma unroll
-            for (int u = 0; u < 4; u++) v[u] = tres0[on[u] ? (size_t)(j[u] / seg_bytes) * sb + r[u] : (size_t)sb];
-#pragma unroll
-            for (int u = 0; u < 4; u++)
-                if (on[u]) out[j[u]] = v[u];
+        for (int k = 0; k < 8; k++) {
+            const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)m, k);
+            const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(m >> 32), k);
+            const unsigned long long mm = ((unsigned long long)hi << 32) | lo;
+            on[k] = (mm >> lane) & 1ull;
+            r[k] = ref16[on[k] ? (wb + (uint32_t)k) * 64u + lane : a];      /* unconditional: the eight loads leave together */
         }
+#pragma unroll
+        for (int k = 0; k < 8; k++)
+            if (on[k]) out[(wb + (uint32_t)k) * 64u + lane] = row[r[k]];
     }
 }
 
@@ -731,8 +728,7 @@ hipError_t lz77k_dec_segments_back(const lz77x_geom &g, uint8_t *d_out, void *d_
     } else {
         hipLaunchKernelGGL(k_dec_tails_replay, dim3(1), dim3(1024), 0, s, P.tail, P.ntails, P.ntails, (const uint8_t *)nullptr, tres, usb, before0);
     }
-    const uint32_t blocks = min((n / 64u + 255u) / 256u + 1u, 256u * 8u);
-    hipLaunchKernelGGL(k_dec_patch, dim3(blocks), dim3(256), 0, s, d_out, reinterpret_cast<const uint16_t *>(d_ref), P.flags, P.tres0, n, P.sbytes,
+    hipLaunchKernelGGL(k_dec_patch_seg, dim3(P.nseg), dim3(DPS_T), 0, s, d_out, reinterpret_cast<const uint16_t *>(d_ref), P.flags, P.tres0, n, P.sbytes,
                        usb);
     return hipGetLastError();
 }
