@@ -46,11 +46,16 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_scan_local(const uint32_t *in,
     __shared__ uint32_t wsum[SCAN_THREADS / 64];
     const uint32_t base = blockIdx.x * SCAN_CHUNK + threadIdx.x * SCAN_ITEMS;
     uint32_t v[SCAN_ITEMS], tot = 0;
+    const bool whole = base + SCAN_ITEMS <= m;          /* eight consecutive words of a thread: two 16-byte accesses (the buffers are 256-byte aligned) */
+    if (whole) {
+        const uint4 a = *reinterpret_cast<const uint4 *>(in + base), b = *reinterpret_cast<const uint4 *>(in + base + 4);
+        v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+    } else {
 #pragma unroll
-    for (int i = 0; i < SCAN_ITEMS; i++) {
-        v[i] = base + i < m ? in[base + i] : 0;
-        tot += v[i];
+        for (int i = 0; i < SCAN_ITEMS; i++) v[i] = base + i < m ? in[base + i] : 0;
     }
+#pragma unroll
+    for (int i = 0; i < SCAN_ITEMS; i++) tot += v[i];
     /* inclusive scan of tot across the wave, then across the 4 waves */
     uint32_t incl = tot;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -68,10 +73,18 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_scan_local(const uint32_t *in,
         btot += wsum[w];
     }
     uint32_t run = woff + incl - tot;
+    if (whole) {
+        uint32_t o[SCAN_ITEMS];
 #pragma unroll
-    for (int i = 0; i < SCAN_ITEMS; i++) {
-        if (base + i < m) out[base + i] = run;
-        run += v[i];
+        for (int i = 0; i < SCAN_ITEMS; i++) { o[i] = run; run += v[i]; }
+        *reinterpret_cast<uint4 *>(out + base) = make_uint4(o[0], o[1], o[2], o[3]);
+        *reinterpret_cast<uint4 *>(out + base + 4) = make_uint4(o[4], o[5], o[6], o[7]);
+    } else {
+#pragma unroll
+        for (int i = 0; i < SCAN_ITEMS; i++) {
+            if (base + i < m) out[base + i] = run;
+            run += v[i];
+        }
     }
     if (threadIdx.x == 0 && sums) sums[blockIdx.x] = btot;
 }
@@ -80,6 +93,13 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_scan_add(uint32_t *__restrict_
 {
     const uint32_t add = offs[blockIdx.x];
     const uint32_t base = blockIdx.x * SCAN_CHUNK + threadIdx.x * SCAN_ITEMS;
+    if (base + SCAN_ITEMS <= m) {
+        uint4 a = *reinterpret_cast<const uint4 *>(out + base), b = *reinterpret_cast<const uint4 *>(out + base + 4);
+        a.x += add; a.y += add; a.z += add; a.w += add; b.x += add; b.y += add; b.z += add; b.w += add;
+        *reinterpret_cast<uint4 *>(out + base) = a;
+        *reinterpret_cast<uint4 *>(out + base + 4) = b;
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < SCAN_ITEMS; i++)
         if (base + i < m) out[base + i] += add;
@@ -91,7 +111,7 @@ size_t lz77k_scan_tmp_bytes(uint32_t m)
     uint64_t cur = m;
     while (cur > SCAN_CHUNK) {
         cur = (cur + SCAN_CHUNK - 1) / SCAN_CHUNK;
-        total += (cur + 64) * sizeof(uint32_t);
+        total += ((cur + 64 + 3) & ~(uint64_t)3) * sizeof(uint32_t);
     }
     return total + 256;
 }
@@ -106,7 +126,7 @@ hipError_t lz77k_scan_u32(const uint32_t *d_in, uint32_t *d_out, uint32_t m, voi
     }
     uint32_t *sums = reinterpret_cast<uint32_t *>(d_tmp);
     hipLaunchKernelGGL(k_scan_local, dim3(blocks), dim3(SCAN_THREADS), 0, s, d_in, d_out, m, sums);
-    hipError_t e = lz77k_scan_u32(sums, sums, blocks, sums + blocks + 64, s);
+    hipError_t e = lz77k_scan_u32(sums, sums, blocks, sums + ((blocks + 64u + 3u) & ~3u), s);   /* (16-byte aligned: the kernels read four words at a time) */
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(k_scan_add, dim3(blocks), dim3(SCAN_THREADS), 0, s, d_out, m, sums);
     return hipGetLastError();
