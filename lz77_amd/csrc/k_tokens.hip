@@ -862,7 +862,12 @@ __global__ __launch_bounds__(TS_BLOCK, 8) __attribute__((amdgpu_num_sgpr(80))) v
                             const uint32_t x = xs0 + lentx[e];
                             if (x < xlim && (!any || x > latest)) { any = true; latest = x; at = e; }
                         }
-                        if (any) prio = staged ? lentv[at] : xval[latest];
+                        if (any) {
+                            /* (never `staged ? lentv[at] : xval[latest]`: the compiler turns that into ONE flat load through a
+                             * selected generic pointer, behind s_waitcnt vmcnt(0) lgkmcnt(0), for every member with a hand-over) */
+                            prio = lentv[min(at, ent_cap - 1u)];
+                            if (!staged) prio = xval[latest];
+                        }
                         const unsigned long long key = ((unsigned long long)prio << 32) | c;
                         best = key < best ? key : best;
                     }
