@@ -432,7 +432,7 @@ __global__ __launch_bounds__(BK2_T, 8) __attribute__((amdgpu_num_sgpr(80))) void
                 }
             }
             bk2_barrier();
-            if (!again) break;
+            if (!again || r >= 15u) break;                 /* (a pointer advances at least one cell a hop, two hops a round: seven rounds at most) */
         }
         if (tid < 2) s_more[tid] = 0;                      /* (ordered before the next sub-block's rounds by its barrier) */
         /* the exits: dest of cell y1 + e, e = pointer - L */
