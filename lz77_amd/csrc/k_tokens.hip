@@ -1019,20 +1019,176 @@ __global__ __launch_bounds__(256) void k_tokens_big(const uint8_t *__restrict__ 
  * run ends at the first failure in each direction; run members inside the window [p-sb, p) are the
  * candidates.  No candidate index to build, and a token costs (run length)/32 rounds instead of a scan
  * of every window position that starts with its two bytes (tens of thousands for "\0\0" at sb 65535). */
+/* ---- large windows: the tokens of LENGTH ONE without visiting their candidates one by one (round 3) --------------------
+ * The candidates of a length-1 token are the window cells with its first byte: 256 of the 65535 on random bytes, where
+ * 37 % of the tokens have length 1, and the rank walk below pays a dependent `ofs` -> `ent` look-up for each: 4.3 G
+ * requests to the L2 per launch, all but a tenth of what the kernel does.  With the positions cut into blocks of sb, a
+ * token p of block b sees cells of b (every one still alive) and the cells >= p - sb of b - 1, and its answer is the
+ * minimum of four scans over CONTIGUOUS arrays of the (block, first byte) buckets:
+ *   cells of (b, v) below p at their own priority; hand-overs into cells of (b, v) by evictions before p;
+ *   cells of (b-1, v) from p - sb on at `base` = their priority at the block boundary T = b * sb;
+ *   hand-overs into cells of (b-1, v) by evictions in [T, p) whose cell is still in the window.
+ * A cell only ever decreases, so the minimum over "own priority or any hand-over seen so far" is the minimum over the
+ * cells' CURRENT priorities: the lowest value cannot have been replaced by a lower one in its own cell.  The buckets
+ * are built once per token launch from the hand-over lists (k_sx_count, a scan, k_sx_scatter). */
+#define SX_CHUNK 8192u                               /* cells per workgroup of the index kernels: at most two blocks (sb > 8192 here) */
+
+struct sx_index {
+    const uint32_t *off_c, *off_h;                   /* bucket -> first cell / hand-over record (exclusive prefix sums, one past the end) */
+    const uint2 *cells;                              /* (position, base) */
+    const uint2 *hx;                                 /* (eviction, priority handed over) */
+    const uint32_t *hd;                              /* its destination cell */
+    uint32_t bl0, nbl;                               /* first block of the index, number of blocks */
+};
+
+__device__ __forceinline__ uint32_t sx_own(uint32_t c, const uint32_t *__restrict__ look, uint32_t nlook, uint32_t voff)
+{
+    return c < nlook ? look[c] : c + voff;
+}
+
+/* phase 0 / 1 of both index kernels: the cells [c0, c1) of this workgroup by bucket, in LDS */
+__global__ __launch_bounds__(256) void k_sx_count(const uint8_t *__restrict__ in, uint32_t c0, uint32_t c1, uint32_t sb, uint32_t bl0,
+                                                  const uint32_t *__restrict__ ofs, uint32_t dbase, uint32_t *__restrict__ cnt_c,
+                                                  uint32_t *__restrict__ cnt_h)
+{
+    __shared__ uint32_t h_c[2][256], h_h[2][256];
+    const uint32_t tid = threadIdx.x;
+    const uint32_t a = c0 + blockIdx.x * SX_CHUNK, b = min(a + SX_CHUNK, c1);
+    const uint32_t blk_a = a / sb;
+    for (uint32_t i = tid; i < 512; i += 256) { (&h_c[0][0])[i] = 0; (&h_h[0][0])[i] = 0; }
+    __syncthreads();
+    for (uint32_t c = a + tid; c < b; c += 256) {
+        const uint32_t j = c / sb - blk_a, v = in[c];
+        const uint32_t lo = c > dbase ? ofs[c - dbase - 1] : 0u, hi = ofs[c - dbase];
+        atomicAdd(&h_c[j][v], 1u);
+        if (hi > lo) atomicAdd(&h_h[j][v], hi - lo);
+    }
+    __syncthreads();
+    for (uint32_t i = tid; i < 512; i += 256) {
+        const uint32_t j = i >> 8, v = i & 255u;
+        const uint32_t bucket = (blk_a + j - bl0) * 256u + v;
+        if (h_c[j][v]) atomicAdd(&cnt_c[bucket], h_c[j][v]);
+        if (h_h[j][v]) atomicAdd(&cnt_h[bucket], h_h[j][v]);
+    }
+}
+
+__global__ __launch_bounds__(256) void k_sx_scatter(const uint8_t *__restrict__ in, uint32_t c0, uint32_t c1, uint32_t sb, uint32_t bl0,
+                                                    const uint32_t *__restrict__ ofs, const uint2 *__restrict__ ent, uint32_t dbase,
+                                                    const uint32_t *__restrict__ off_c, const uint32_t *__restrict__ off_h,
+                                                    uint32_t *__restrict__ cur_c, uint32_t *__restrict__ cur_h, uint2 *__restrict__ cells,
+                                                    uint2 *__restrict__ hx, uint32_t *__restrict__ hd, const uint32_t *__restrict__ look,
+                                                    uint32_t nlook, uint32_t voff)
+{
+    __shared__ uint32_t h_c[2][256], h_h[2][256];
+    const uint32_t tid = threadIdx.x;
+    const uint32_t a = c0 + blockIdx.x * SX_CHUNK, b = min(a + SX_CHUNK, c1);
+    const uint32_t blk_a = a / sb;
+    for (uint32_t i = tid; i < 512; i += 256) { (&h_c[0][0])[i] = 0; (&h_h[0][0])[i] = 0; }
+    __syncthreads();
+    for (uint32_t c = a + tid; c < b; c += 256) {
+        const uint32_t j = c / sb - blk_a, v = in[c];
+        const uint32_t lo = c > dbase ? ofs[c - dbase - 1] : 0u, hi = ofs[c - dbase];
+        atomicAdd(&h_c[j][v], 1u);
+        if (hi > lo) atomicAdd(&h_h[j][v], hi - lo);
+    }
+    __syncthreads();
+    /* my share of every bucket: a range behind what the workgroups before me (in time, not in position: the records of a
+     * bucket are in no particular order) have taken */
+    for (uint32_t i = tid; i < 512; i += 256) {
+        const uint32_t j = i >> 8, v = i & 255u;
+        const uint32_t bucket = (blk_a + j - bl0) * 256u + v;
+        const uint32_t nc = h_c[j][v], nh = h_h[j][v];
+        h_c[j][v] = nc ? off_c[bucket] + atomicAdd(&cur_c[bucket], nc) : 0u;
+        h_h[j][v] = nh ? off_h[bucket] + atomicAdd(&cur_h[bucket], nh) : 0u;
+    }
+    __syncthreads();
+    for (uint32_t c = a + tid; c < b; c += 256) {
+        const uint32_t blk = c / sb, j = blk - blk_a, v = in[c];
+        const uint32_t lo = c > dbase ? ofs[c - dbase - 1] : 0u, hi = ofs[c - dbase];
+        /* base: the cell's priority when the next block begins (every token of that block sees these hand-overs) */
+        const uint64_t T = ((uint64_t)blk + 1u) * sb;
+        uint32_t base = sx_own(c, look, nlook, voff), latest = 0;
+        bool any = false;
+        uint32_t slot_h = hi > lo ? atomicAdd(&h_h[j][v], hi - lo) : 0u;
+        for (uint32_t e = lo; e < hi; e++) {
+            const uint2 t = ent[e];
+            if ((uint64_t)t.x + sb < T && (!any || t.x > latest)) { any = true; latest = t.x; base = t.y; }
+            hx[slot_h] = t;
+            hd[slot_h] = c;
+            slot_h++;
+        }
+        cells[atomicAdd(&h_c[j][v], 1u)] = make_uint2(c, base);
+    }
+}
+
+/* the token at p (its first byte v) of length one: offset of the candidate nearest the root (see above); all 64 lanes */
+__device__ __forceinline__ uint32_t sx_query(const sx_index &X, uint32_t p, uint32_t v, uint32_t lane, uint32_t usb,
+                                             const uint32_t *__restrict__ look, uint32_t nlook, uint32_t voff)
+{
+    const uint32_t b = p / usb;
+    const uint32_t cmin = p > usb ? p - usb : 0u;
+    uint64_t best = ~0ull;
+    {
+        const uint32_t bucket = (b - X.bl0) * 256u + v;
+        for (uint32_t i = X.off_c[bucket] + lane, e = X.off_c[bucket + 1]; i < e; i += 64) {
+            const uint32_t c = X.cells[i].x;
+            if (c < p) {                                                   /* (a cell of block b is never older than p - sb) */
+                const uint64_t key = ((uint64_t)sx_own(c, look, nlook, voff) << 32) | c;
+                best = key < best ? key : best;
+            }
+        }
+        for (uint32_t i = X.off_h[bucket] + lane, e = X.off_h[bucket + 1]; i < e; i += 64) {
+            const uint2 t = X.hx[i];
+            if ((uint64_t)t.x + usb < p) {
+                const uint64_t key = ((uint64_t)t.y << 32) | X.hd[i];
+                best = key < best ? key : best;
+            }
+        }
+    }
+    if (b > X.bl0) {
+        const uint32_t bucket = (b - 1u - X.bl0) * 256u + v;
+        const uint64_t T = (uint64_t)b * usb;
+        for (uint32_t i = X.off_c[bucket] + lane, e = X.off_c[bucket + 1]; i < e; i += 64) {
+            const uint2 t = X.cells[i];
+            if (t.x >= cmin) {
+                const uint64_t key = ((uint64_t)t.y << 32) | t.x;
+                best = key < best ? key : best;
+            }
+        }
+        for (uint32_t i = X.off_h[bucket] + lane, e = X.off_h[bucket + 1]; i < e; i += 64) {
+            const uint2 t = X.hx[i];
+            const uint32_t d = X.hd[i];
+            if ((uint64_t)t.x + usb >= T && (uint64_t)t.x + usb < p && d >= cmin) {
+                const uint64_t key = ((uint64_t)t.y << 32) | d;
+                best = key < best ? key : best;
+            }
+        }
+    }
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) {
+        const uint64_t o = (uint64_t)__shfl_xor((unsigned long long)best, d, 64);
+        best = o < best ? o : best;
+    }
+    return p - (uint32_t)(best & 0xFFFFFFFFu);
+}
+
 __device__ __forceinline__ void rank_token(uint32_t k, const uint32_t lane, const uint8_t *__restrict__ in, uint32_t n, int sb, int ob, int lb,
                                            uint32_t RP, uint32_t TILE, const uint32_t *__restrict__ ranks_all,
                                            const uint32_t *__restrict__ chain, const uint8_t *__restrict__ maxlen,
                                            const uint32_t *__restrict__ ofs, const uint2 *__restrict__ ent, uint32_t dbase,
                                            uint32_t *__restrict__ tokval, const uint32_t *__restrict__ look, uint32_t nlook, uint32_t voff,
                                            uint32_t whole_order /* the order holds every position < n of the region's RP slots
-                                                                   (lz77k_big_sort_shared), not only its first R */)
+                                                                   (lz77k_big_sort_shared), not only its first R */,
+                                           const sx_index &X /* off_c == null: no index, length-1 tokens walk like the others */)
 {
     const uint32_t p = chain[k];
     const uint32_t len = maxlen[p];
     const uint32_t next = in[p + len];
     const uint32_t usb = (uint32_t)sb;
     uint32_t off = 0;
-    if (len > 0) {
+    if (len == 1 && X.off_c) {
+        off = sx_query(X, p, in[p], lane, usb, look, nlook, voff);
+    } else if (len > 0) {
         const uint32_t reg = p >= usb ? (p - usb) / TILE : 0u;          /* the region whose walk answered p */
         const uint32_t t0 = reg * TILE, ly = p - t0;
         const uint64_t rend = (uint64_t)t0 + (whole_order ? RP : TILE + usb);
@@ -1150,23 +1306,26 @@ __global__ __launch_bounds__(256) void k_tokens_rank(const uint8_t *__restrict__
                                                      const uint32_t *__restrict__ chain, uint32_t ntok,
                                                      const uint8_t *__restrict__ maxlen, const uint32_t *__restrict__ ofs,
                                                      const uint2 *__restrict__ ent, uint32_t dbase, uint32_t *__restrict__ tokval,
-                                                     const uint32_t *__restrict__ look, uint32_t nlook, uint32_t voff, uint32_t whole_order)
+                                                     const uint32_t *__restrict__ look, uint32_t nlook, uint32_t voff, uint32_t whole_order,
+                                                     sx_index X)
 {
     const uint32_t w = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    if (w < ntok) rank_token(w, threadIdx.x & 63, in, n, sb, ob, lb, RP, TILE, ranks_all, chain, maxlen, ofs, ent, dbase, tokval, look, nlook, voff, whole_order);
+    if (w < ntok) rank_token(w, threadIdx.x & 63, in, n, sb, ob, lb, RP, TILE, ranks_all, chain, maxlen, ofs, ent, dbase, tokval, look, nlook, voff, whole_order, X);
 }
 
 /* bytes of the global candidate index for token positions spanning npos (0 when the LDS tile kernel applies) */
 size_t lz77k_tokens_index_bytes(const lz77x_geom &g, size_t npos)
 {
-#ifndef LZ77X_VARIANTS
-    (void)g; (void)npos;
-    return 0;
-#else
     if (g.sb <= 8192) return 0;
+    /* the (block, first byte) buckets of the length-1 tokens: npos token positions look back over npos + sb cells */
+    const size_t nc = npos + (size_t)g.sb + 16, nbk = (nc / (size_t)g.sb + 3) * 256;
+    size_t need = 4 * ((nbk + 1) * 4 + 256) + lz77k_scan_tmp_bytes((uint32_t)nbk + 1) + 256 + nc * 8 + (nc + g.sb + 16) * 12 + 3 * 256;
+#ifdef LZ77X_VARIANTS
     const size_t ntiles = (npos + BIG_TT - 1) / BIG_TT;
-    return ntiles * ((size_t)BIG_KEYS + BIG_TT + (size_t)g.sb + 8) * sizeof(uint32_t) + 256;
+    const size_t v3 = ntiles * ((size_t)BIG_KEYS + BIG_TT + (size_t)g.sb + 8) * sizeof(uint32_t) + 256;
+    if (v3 > need) need = v3;
 #endif
+    return need;
 }
 
 /* one word per tile + 1: the sorted-order kernel cuts every region into ceil(TILE / TS_TT) tiles (TILE >= 3064) */
@@ -1185,8 +1344,33 @@ hipError_t lz77k_tokens(const uint8_t *d_in, uint32_t n, const lz77x_geom &g, co
 #define TIE_EV(i) do { if (ev_tie) { hipError_t ee_ = hipEventRecord(ev_tie[i], s); if (ee_ != hipSuccess) return ee_; } } while (0)
     if (variant == 0 && !g.fast && d_ranks_all) {
         TIE_EV(0);
+        sx_index X = {};
+        if (d_index && g.sb > 8192 && !LZ77X_VENV("LZ77X_NO_SHORT_INDEX")) {
+            /* the (block, first byte) buckets of the cells [dbase, pos1) and of the hand-overs into them: what the tokens of
+             * length one are resolved from (sx_query) */
+            const uint32_t usb = (uint32_t)g.sb, c0 = dbase, c1 = pos1, nc = c1 - c0;
+            const uint32_t bl0 = c0 / usb, nbl = (c1 - 1u) / usb - bl0 + 1u, nbk = nbl * 256u;
+            uint8_t *base = reinterpret_cast<uint8_t *>(d_index);
+            size_t o = 0;
+            auto take = [&](size_t bytes) { uint8_t *q = base + o; o += (bytes + 255) & ~(size_t)255; return q; };
+            uint32_t *off_c = reinterpret_cast<uint32_t *>(take(((size_t)nbk + 1) * 4)), *off_h = reinterpret_cast<uint32_t *>(take(((size_t)nbk + 1) * 4));
+            uint32_t *cur_c = reinterpret_cast<uint32_t *>(take((size_t)nbk * 4)), *cur_h = reinterpret_cast<uint32_t *>(take((size_t)nbk * 4));
+            void *stmp = take(lz77k_scan_tmp_bytes(nbk + 1));
+            uint2 *cells = reinterpret_cast<uint2 *>(take((size_t)nc * 8));
+            uint2 *hx = reinterpret_cast<uint2 *>(take(((size_t)nc + usb + 16) * 8));
+            uint32_t *hd = reinterpret_cast<uint32_t *>(take(((size_t)nc + usb + 16) * 4));
+            hipError_t e = hipMemsetAsync(base, 0, (size_t)(reinterpret_cast<uint8_t *>(stmp) - base), s);
+            if (e != hipSuccess) return e;
+            const uint32_t wgs = (nc + SX_CHUNK - 1u) / SX_CHUNK;
+            hipLaunchKernelGGL(k_sx_count, dim3(wgs), dim3(256), 0, s, d_in, c0, c1, usb, bl0, d_ofs, dbase, off_c, off_h);
+            if ((e = lz77k_scan_u32(off_c, off_c, nbk + 1, stmp, s)) != hipSuccess) return e;
+            if ((e = lz77k_scan_u32(off_h, off_h, nbk + 1, stmp, s)) != hipSuccess) return e;
+            hipLaunchKernelGGL(k_sx_scatter, dim3(wgs), dim3(256), 0, s, d_in, c0, c1, usb, bl0, d_ofs, d_ent, dbase, off_c, off_h, cur_c, cur_h, cells, hx,
+                               hd, d_look, nlook, voff);
+            X.off_c = off_c; X.off_h = off_h; X.cells = cells; X.hx = hx; X.hd = hd; X.bl0 = bl0; X.nbl = nbl;
+        }
         hipLaunchKernelGGL(k_tokens_rank, dim3((ntok + 3) / 4), dim3(256), 0, s, d_in, n, g.sb, g.ob, g.lb, g.RP, g.TILE, d_ranks_all,
-                           d_chain, ntok, d_maxlen, d_ofs, d_ent, dbase, d_tokval, d_look, nlook, voff, (uint32_t)lz77k_big_sort_shared(g));
+                           d_chain, ntok, d_maxlen, d_ofs, d_ent, dbase, d_tokval, d_look, nlook, voff, (uint32_t)lz77k_big_sort_shared(g), X);
         TIE_EV(1);
         return hipGetLastError();
     }

@@ -455,7 +455,9 @@ int encode_core_host(std::vector<Ctx *> &cs, const void *src, bool src_on_device
             if (keep_ranks) {
                 /* large windows: the regions' rank + inverse arrays stay resident for the rank-order tie-break */
                 if ((rc = c.ranks_all.need((size_t)nregions * (2 * (size_t)g.RP + 8) * sizeof(uint32_t)))) return rc;
-            } else if ((rc = c.bidx.need(lz77k_tokens_index_bytes(g, chunk_pos < n ? chunk_pos : n)))) return rc;
+            }
+            /* (the rank-order tie-break builds its short-token buckets here too; the variants' two-byte index shares the buffer) */
+            if ((rc = c.bidx.need(lz77k_tokens_index_bytes(g, (chunk_pos < n ? chunk_pos : n) + 2 * (size_t)g.sb)))) return rc;
             while (c.chunk_ev.size() < 3 * (size_t)nchunks) {
                 hipEvent_t e;
                 /* ordering only; host waiters sleep instead of spinning next to the recurrence thread */
@@ -1458,7 +1460,14 @@ int seg_front(SegJob &J, const lz77x_geom &g)
     /* large windows: rank + inverse arrays, (2RP + 8) words per region, for the rank-order tie-break */
     if (keep_order && (rc = c.ranks_all.need(g.fast ? (size_t)nregions * g.RP * 2 + 64 : (size_t)nregions * (2 * (size_t)g.RP + 8) * sizeof(uint32_t)))) return rc;
     J.d_order = keep_order ? c.ranks_all.as<uint32_t>() : nullptr;
-    if (!g.fast && !keep_order && (rc = c.bidx.need(lz77k_tokens_index_bytes(g, (size_t)J.nloc)))) return rc;
+    /* large windows: the (block, first byte) buckets the tokens of length one are resolved from (built per token chunk) */
+    if (!g.fast) {
+        size_t chunk_pos = (size_t)128 << 20;
+        const char *ce = getenv("LZ77X_TOKEN_CHUNK");
+        if (ce && atoi(ce) > 0) chunk_pos = (size_t)atoi(ce);
+        chunk_pos += lz77k_chain_sub();
+        if ((rc = c.bidx.need(lz77k_tokens_index_bytes(g, chunk_pos < (size_t)J.nloc ? chunk_pos : (size_t)J.nloc)))) return rc;
+    }
     const uint32_t nlaunch = (nregions + batch - 1) / batch;
     while (c.sort_ev.size() < 4 * (size_t)nlaunch) { hipEvent_t e; HIPCHK(hipEventCreate(&e)); c.sort_ev.push_back(e); }
     while (c.match_ev.size() < 8) { hipEvent_t e; HIPCHK(hipEventCreate(&e)); c.match_ev.push_back(e); }
@@ -1622,7 +1631,7 @@ int seg_tokens(SegJob &J, const lz77x_geom &g, const SegCarry &carry)
                                         c.ent.as<uint2>(), c.scantmp.p, s, (uint32_t)x_new, c.flag.as<unsigned long long>() + 8, g.fast ? (uint32_t)g.sb : 0u));
             HIPCHK(lz77k_tokens(c.in.as<uint8_t>(), J.nloc, g, c.chain.as<uint32_t>() + ta, tb - ta, c.maxlen.as<uint8_t>(), c.ofs.as<uint32_t>(),
                                 c.ent.as<uint2>(), dbase, (uint32_t)b, (uint32_t)e, tokbuf + 4 + ta, c.tstart.as<uint32_t>(),
-                                g.fast || J.d_order ? nullptr : c.bidx.p,
+                                g.fast ? nullptr : c.bidx.p,
                                 J.tvariant, s, &c.tie_ev[2 * ci], J.d_order, J.first ? nullptr : look_cur, J.nlook, 0u,
                                 fused ? c.ps.as<uint32_t>() : nullptr, fused ? c.xval.as<uint32_t>() : nullptr, c.flag.as<unsigned long long>() + 8));
             J.tie_timed[ci] = tb > ta;

@@ -422,6 +422,21 @@ def test_large_window_token_variants_agree(tokv, sb, la, kind, monkeypatch):
     assert L.encode(data, la, sb) == want
 
 
+@pytest.mark.parametrize("env", [{}, {"LZ77X_NO_SHORT_INDEX": "1"}, {"LZ77X_TOKEN_CHUNK": "150000"},
+                                 {"LZ77X_SEGMENT": "400000", "LZ77X_TOKEN_CHUNK": "100000"}], ids=["index", "walk", "chunks", "segments"])
+@pytest.mark.parametrize("sb,la,kind,n", [(65535, 255, "random", 1_200_000), (65535, 255, "mixed", 2_500_000), (9000, 3, "text", 600_000),
+                                          (40000, 2, "random", 500_000), (65535, 2, "lowent", 100_000)])
+def test_large_window_short_token_index(env, sb, la, kind, n, monkeypatch):
+    """large windows: the tokens of length one from the (block, first byte) buckets (sx_query: cells and hand-overs of the
+    token's block and of the one before) == walked candidate by candidate == the reference stream; la = 2 makes every
+    match a length-1 token, several token chunks and segments move the bucket range and the carried priorities"""
+    data = synth.make(kind, n, 97)
+    want = O.encode_bst(data, sb, la)
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    assert L.encode(data, la, sb) == want
+
+
 @pytest.mark.parametrize("sb,la", [(4095, 15), (65535, 255), (20000, 40)])
 @pytest.mark.parametrize("period", [1, 2, 7, 300, 5000])
 def test_periodic_inputs(sb, la, period):
