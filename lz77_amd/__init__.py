@@ -56,7 +56,7 @@ def build(force: bool = False) -> str:
     srcdir = os.path.join(_HERE, "csrc")
     if force:
         subprocess.check_call(["make", "-s", "-C", srcdir, "clean"])
-    subprocess.check_call(["make", "-s", "-C", srcdir])
+    subprocess.check_call(["make", "-s", "-j8", "-C", srcdir])
     return LIB_PATH
 
 
