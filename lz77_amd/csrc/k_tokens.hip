@@ -1313,6 +1313,98 @@ __global__ __launch_bounds__(256) void k_tokens_rank(const uint8_t *__restrict__
     if (w < ntok) rank_token(w, threadIdx.x & 63, in, n, sb, ob, lb, RP, TILE, ranks_all, chain, maxlen, ofs, ent, dbase, tokval, look, nlook, voff, whole_order, X);
 }
 
+/* The same walk with LPT lanes per token (LPT / 2 down, LPT / 2 up) and 64 / LPT tokens per wavefront: once the tokens
+ * of length one come from the buckets and most runs are a handful of cells, a wavefront per token is five dependent round
+ * trips to HBM with one token's worth of loads in flight, 28.7 M wavefronts on S3.  A token whose run is still open after
+ * RANKG_ROUNDS rounds in one direction, and every token of length one, is then resolved by the whole wavefront
+ * (rank_token): the 64-ary search for the ends of a long run and the bucket scans want all its lanes. */
+#define RANKG_ROUNDS 4u
+
+template <int LPT>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80))) void k_tokens_rank_group(const uint8_t *__restrict__ in, uint32_t n, int sb, int ob, int lb,
+                                                           uint32_t RP, uint32_t TILE, const uint32_t *__restrict__ ranks_all,
+                                                           const uint32_t *__restrict__ chain, uint32_t ntok,
+                                                           const uint8_t *__restrict__ maxlen, const uint32_t *__restrict__ ofs,
+                                                           const uint2 *__restrict__ ent, uint32_t dbase, uint32_t *__restrict__ tokval,
+                                                           const uint32_t *__restrict__ look, uint32_t nlook, uint32_t voff,
+                                                           uint32_t whole_order, sx_index X)
+{
+    constexpr uint32_t H = LPT / 2, TPW = 64 / LPT;
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t grp = lane / LPT, gl = lane % LPT, sub = gl % H;
+    const bool up = gl >= H;
+    const uint32_t kk = (blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * TPW + grp;
+    const bool valid = kk < ntok;
+    const uint32_t k = valid ? kk : ntok - 1u;
+    const uint32_t p = chain[k];
+    const uint32_t len = maxlen[p];
+    const uint32_t next = in[p + len];
+    const uint32_t usb = (uint32_t)sb;
+    const uint32_t reg = p >= usb ? (p - usb) / TILE : 0u;              /* the region whose walk answered p */
+    const uint32_t t0 = reg * TILE, ly = p - t0;
+    const uint64_t rend = (uint64_t)t0 + (whole_order ? RP : TILE + usb);
+    const uint32_t R = (rend < n ? (uint32_t)rend : n) - t0;                /* ranks [0, R) are sorted positions */
+    const uint32_t *rk = ranks_all + (size_t)reg * (2 * (size_t)RP + 8), *ix = rk + RP + 8;
+    const uint8_t *by = in + t0, *q = in + p;
+    const uint32_t ry = rk[ly];
+    const uint64_t q0 = ld64u(q);                                          /* (the input is padded past n) */
+    const uint64_t m0 = len >= 8 ? ~0ull : (1ull << (8 * len)) - 1ull;
+    const bool whole_wave = len == 1 && X.off_c;                           /* the buckets: all 64 lanes, below */
+    bool open = valid && len > 0 && !whole_wave;                           /* my direction of my token */
+    uint64_t best = ~0ull;
+    for (uint32_t r = 0; r < RANKG_ROUNDS && __ballot(open); r++) {
+        const uint32_t d = 1u + r * H + sub;
+        const bool live = open && (up ? ry + d < R : d <= ry);
+        uint32_t e = 0;
+        bool same = false;
+        if (live) {
+            e = ix[up ? ry + d : ry - d];
+            const uint8_t *c = by + e;
+            same = ((ld64u(c) ^ q0) & m0) == 0ull;
+            for (uint32_t j = 8; same && j < len; j += 8) {
+                uint64_t x = ld64u(c + j) ^ ld64u(q + j);
+                const uint32_t rem = len - j;
+                if (rem < 8) x &= (1ull << (8 * rem)) - 1ull;
+                same = x == 0ull;
+            }
+        }
+        /* my direction's lanes of this round: how many from the nearest on share? */
+        const uint64_t okm = __ballot(same);
+        const uint32_t mine = (uint32_t)(okm >> (grp * LPT + (up ? H : 0u))) & ((1u << H) - 1u);
+        const uint32_t lead = mine == (1u << H) - 1u ? H : (uint32_t)__builtin_ctz(~mine);
+        if (same && sub < lead && e < ly && ly - e <= usb) {
+            const uint32_t c = t0 + e;
+            uint32_t prio = c < nlook ? look[c] : c + voff, latest = 0;
+            bool any = false;
+            const uint32_t lo = c > dbase ? ofs[c - dbase - 1] : 0, hi = c >= dbase ? ofs[c - dbase] : 0;
+            for (uint32_t i = lo; i < hi; i++) {
+                const uint2 t = ent[i];
+                if ((uint64_t)t.x + usb < p && (!any || t.x > latest)) { any = true; latest = t.x; prio = t.y; }
+            }
+            const uint64_t key = ((uint64_t)prio << 32) | c;
+            best = key < best ? key : best;
+        }
+        open = open && lead == H;
+    }
+    /* a direction still open, or a token for the buckets: the whole token goes to the whole wavefront */
+    const uint64_t om = __ballot(open || (valid && whole_wave));
+    const bool defer = ((om >> (grp * LPT)) & ((1ull << LPT) - 1ull)) != 0ull;
+#pragma unroll
+    for (int d = LPT / 2; d > 0; d >>= 1) {
+        const uint64_t o = (uint64_t)__shfl_xor((unsigned long long)best, d, 64);
+        best = o < best ? o : best;
+    }
+    if (gl == 0 && valid && !defer) {
+        const uint32_t off = len ? p - (uint32_t)(best & 0xFFFFFFFFu) : 0u;
+        const uint32_t omask = ob >= 32 ? 0xFFFFFFFFu : (1u << ob) - 1u;
+        tokval[k] = (off & omask) | (len << ob) | (next << (ob + lb));
+    }
+    for (uint64_t dm = __ballot(defer && gl == 0 && valid); dm; dm &= dm - 1) {
+        const uint32_t kd = (uint32_t)__builtin_amdgcn_readlane((int)k, __builtin_ctzll(dm));
+        rank_token(kd, lane, in, n, sb, ob, lb, RP, TILE, ranks_all, chain, maxlen, ofs, ent, dbase, tokval, look, nlook, voff, whole_order, X);
+    }
+}
+
 /* bytes of the global candidate index for token positions spanning npos (0 when the LDS tile kernel applies) */
 size_t lz77k_tokens_index_bytes(const lz77x_geom &g, size_t npos)
 {
@@ -1369,8 +1461,20 @@ hipError_t lz77k_tokens(const uint8_t *d_in, uint32_t n, const lz77x_geom &g, co
                                hd, d_look, nlook, voff);
             X.off_c = off_c; X.off_h = off_h; X.cells = cells; X.hx = hx; X.hd = hd; X.bl0 = bl0; X.nbl = nbl;
         }
-        hipLaunchKernelGGL(k_tokens_rank, dim3((ntok + 3) / 4), dim3(256), 0, s, d_in, n, g.sb, g.ob, g.lb, g.RP, g.TILE, d_ranks_all,
-                           d_chain, ntok, d_maxlen, d_ofs, d_ent, dbase, d_tokval, d_look, nlook, voff, (uint32_t)lz77k_big_sort_shared(g), X);
+        {
+            /* several tokens per wavefront (LZ77X_RANK_LPT=64 in the variants build: one) */
+            const char *le = LZ77X_VENV("LZ77X_RANK_LPT");
+            const int lpt = le ? atoi(le) : 8;
+            if (lpt >= 64)
+                hipLaunchKernelGGL(k_tokens_rank, dim3((ntok + 3) / 4), dim3(256), 0, s, d_in, n, g.sb, g.ob, g.lb, g.RP, g.TILE, d_ranks_all,
+                                   d_chain, ntok, d_maxlen, d_ofs, d_ent, dbase, d_tokval, d_look, nlook, voff, (uint32_t)lz77k_big_sort_shared(g), X);
+            else {
+                const uint32_t tpw = 64u / (lpt == 8 ? 8u : 16u), waves = (ntok + tpw - 1u) / tpw;
+                auto fn = lpt == 8 ? k_tokens_rank_group<8> : k_tokens_rank_group<16>;
+                hipLaunchKernelGGL(fn, dim3((waves + 3u) / 4u), dim3(256), 0, s, d_in, n, g.sb, g.ob, g.lb, g.RP, g.TILE, d_ranks_all, d_chain, ntok,
+                                   d_maxlen, d_ofs, d_ent, dbase, d_tokval, d_look, nlook, voff, (uint32_t)lz77k_big_sort_shared(g), X);
+            }
+        }
         TIE_EV(1);
         return hipGetLastError();
     }

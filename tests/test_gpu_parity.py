@@ -423,7 +423,8 @@ def test_large_window_token_variants_agree(tokv, sb, la, kind, monkeypatch):
 
 
 @pytest.mark.parametrize("env", [{}, {"LZ77X_NO_SHORT_INDEX": "1"}, {"LZ77X_TOKEN_CHUNK": "150000"},
-                                 {"LZ77X_SEGMENT": "400000", "LZ77X_TOKEN_CHUNK": "100000"}], ids=["index", "walk", "chunks", "segments"])
+                                 {"LZ77X_SEGMENT": "400000", "LZ77X_TOKEN_CHUNK": "100000"}, {"LZ77X_RANK_LPT": "64"}, {"LZ77X_RANK_LPT": "16"}],
+                         ids=["index", "walk", "chunks", "segments", "lpt64", "lpt16"])
 @pytest.mark.parametrize("sb,la,kind,n", [(65535, 255, "random", 1_200_000), (65535, 255, "mixed", 2_500_000), (9000, 3, "text", 600_000),
                                           (40000, 2, "random", 500_000), (65535, 2, "lowent", 100_000)])
 def test_large_window_short_token_index(env, sb, la, kind, n, monkeypatch):
