@@ -1536,7 +1536,12 @@ int seg_mid(SegJob &J, const lz77x_geom &g, SegCarry &carry, bool allow_fallback
 
         /* -- priority recurrence (tree.c:202-231) over steps [0, nx) from the carried cells -- */
         int iters = 0, converged = 1;
-        int max_iters = allow_fallback ? 96 : 1 << 30;     /* a sweep finalises at least one more block: it always ends */
+        /* a sweep finalises at least one more block: it always ends.  The guard before the host loop takes over comes from
+         * what was measured (profiles/r03_prio_classes.json, tools/time_c2.py per data class): 4-7 iterations on every class at
+         * C1, 9-13 at C2 except record-structured data (31: the flips decay slowly but steadily, and the seven iterations
+         * past 24 are cheaper than starting over on the host).  Twice the largest count seen; an iteration costs 1/20
+         * (C2) to 1/100 (C1, text) of the host loop, so a pathological input is bounded at about three times its cost */
+        int max_iters = allow_fallback ? 64 : 1 << 30;
         {
             const char *me = getenv("LZ77X_PRIO_MAX_ITERS");
             if (me && atoi(me) > 0 && allow_fallback) max_iters = atoi(me);
