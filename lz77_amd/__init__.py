@@ -15,7 +15,7 @@ import subprocess
 
 import numpy as np
 
-__all__ = ["encode", "decode", "encode_device", "decode_device", "last_stats", "build", "lib",
+__all__ = ["encode", "decode", "encode_device", "decode_device", "encode_path", "decode_path", "last_stats", "build", "lib",
            "Lz77Error", "LIB_PATH", "CLI_PATH"]
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
@@ -176,6 +176,45 @@ def decode(stream) -> bytes:
         return ctypes.string_at(out, n.value)
     finally:
         lib().lz77x_free(out)
+
+
+_libc = None
+
+
+def _fopen(path: str, mode: bytes):
+    """a FILE* of the C library for the FILE* entry points (lz77.h:14-15 take FILE*, main.c:141-158 opens them)"""
+    global _libc
+    if _libc is None:
+        _libc = ctypes.CDLL(None)
+        _libc.fopen.restype = ctypes.c_void_p
+        _libc.fopen.argtypes = [ctypes.c_char_p, ctypes.c_char_p]
+        _libc.fclose.argtypes = [ctypes.c_void_p]
+    f = _libc.fopen(os.fsencode(path), mode)
+    if not f:
+        raise OSError("cannot open " + path)
+    return f
+
+
+def encode_path(src: str, dst: str, la: int = -1, sb: int = -1) -> None:
+    """lz77x_encode_file on two paths: what `lz77 -c -i src -o dst` does inside this process"""
+    fi, fo = _fopen(src, b"rb"), _fopen(dst, b"wb")
+    try:
+        rc = lib().lz77x_encode_file(fi, fo, int(la), int(sb))
+    finally:
+        _libc.fclose(fi)
+        _libc.fclose(fo)
+    _check(rc)
+
+
+def decode_path(src: str, dst: str) -> None:
+    """lz77x_decode_file on two paths: what `lz77 -d -i src -o dst` does inside this process"""
+    fi, fo = _fopen(src, b"rb"), _fopen(dst, b"wb")
+    try:
+        rc = lib().lz77x_decode_file(fi, fo)
+    finally:
+        _libc.fclose(fi)
+        _libc.fclose(fo)
+    _check(rc)
 
 
 def encode_bound(n: int, la: int = -1, sb: int = -1) -> int:

@@ -27,40 +27,57 @@ __global__ void k_dec_parse(const uint8_t *__restrict__ z, uint32_t ntok, int ob
     if (off > sb && len > 0 && stale_flag) stale_flag[1] = 1u;
 }
 
+
+/* ---- distance-0 copies (power-of-two -s) --------------------------------------------------------
+ * The reference's decoder stages its output in W = 3*SB+LA bytes; pass 0 starts at buffer index 0, every later pass at
+ * index sb (lz77.c:172-175).  A copy from distance 0 re-reads the byte its buffer still holds at that index
+ * (lz77.c:178-181): what an earlier pass left there, or calloc's zero.  Q.cyc[c] = output offset of the first byte of
+ * pass c of the list, Q.cyc[ncyc] = the end of the output so far.  All offsets are in the coordinates of the buffer the
+ * kernels work on: `pre` bytes of history (a stream decoded range by range: the bytes before the range, and -- Q.img --
+ * the image of the reference's buffer at indices [sb, W) as the ranges before left it) followed by the range's output.
+ * Pass 0 of the list may have begun before the range (cyc[0] < pre); Q.first0: it is pass 0 of the whole stream. */
+__device__ __forceinline__ uint32_t dec_stale_b0(const lz77k_dec_stale &Q, uint32_t c, uint32_t sb) { return (c == 0 && Q.first0) ? 0u : sb; }
+
+__device__ __forceinline__ uint32_t dec_stale_pass(const lz77k_dec_stale &Q, uint32_t d)
+{
+    uint32_t lo = 0, hi = Q.ncyc;                             /* last pass that starts at or before d */
+    while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (Q.cyc[mid] <= d) lo = mid; else hi = mid; }
+    return lo;
+}
+
+/* source of the stale read at buffer index idx during pass c: an offset into the working buffer, or `zero` */
+__device__ __forceinline__ uint32_t dec_stale_src(const lz77k_dec_stale &Q, uint32_t c, uint32_t idx, uint32_t sb, uint32_t pre, uint32_t zero)
+{
+    for (uint32_t cc = c; cc-- > 0;) {
+        const uint32_t b0 = dec_stale_b0(Q, cc, sb);
+        if (idx < b0) break;                                  /* below sb every pass rewrites the index: never read stale */
+        const uint32_t cand = Q.cyc[cc] + (idx - b0);
+        if (cand < Q.cyc[cc + 1]) {                           /* pass cc got that far */
+            if (cand >= pre) return cand;
+            break;                                            /* ... before this range began: the image has it */
+        }
+    }
+    return (Q.img != LZ77X_NONE32 && idx >= sb) ? Q.img + (idx - sb) : zero;
+}
+
 /* lz77.c:178-194 as data flow: every copied byte j points at j-off, every literal at itself.
  * Position n is a zero byte that degenerate tokens (off==0 or off>j) point at. */
 __global__ void k_dec_expand(const uint32_t *__restrict__ tokval, const uint32_t *__restrict__ dst, uint32_t ntok,
-                             int ob, int lb, uint8_t *__restrict__ out, uint32_t *__restrict__ ptr, uint32_t n,
-                             const uint32_t *__restrict__ cyc /* output offsets at which the reference's buffer wraps */,
-                             uint32_t ncyc, uint32_t sb)
+                             int ob, int lb, uint8_t *__restrict__ out, uint32_t *__restrict__ ptr, uint32_t n /* pre + the range's bytes */,
+                             lz77k_dec_stale Q, uint32_t sb, uint32_t pre /* bytes of history in front of the range's output */)
 {
     const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k == 0) { out[n] = 0; ptr[n] = n; }
+    for (uint32_t j = k; j < pre; j += gridDim.x * blockDim.x) ptr[j] = j;        /* history: resolved bytes */
     if (k >= ntok) return;
     const uint32_t v = tokval[k];
     const uint32_t off = ob ? (v & ((1u << ob) - 1u)) : 0;
     const uint32_t len = (v >> ob) & ((1u << lb) - 1u);
     const uint32_t lit = (v >> (ob + lb)) & 0xFFu;
-    const uint32_t j0 = dst[k];
-    if (off == 0 && len > 0 && cyc) {
-        /* lz77.c:178-181 with off == back: buffer[back] = buffer[back], i.e. the byte the reference's
-         * 3*SB+LA staging buffer still holds at that index: the output byte that was stored there the last
-         * time the buffer passed it, or 0 (calloc, lz77.c:162).  cyc[c] = output offset of the first byte
-         * of pass c (pass 0 starts at buffer index 0, every later one at index sb, lz77.c:172-175). */
-        uint32_t lo = 0, hi = ncyc;                           /* last pass that starts at or before j0 */
-        while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (cyc[mid] <= j0) lo = mid; else hi = mid; }
-        const uint32_t c = lo, idx0 = (c ? sb : 0u) + (j0 - cyc[c]);
-        for (uint32_t i = 0; i < len; i++) {
-            const uint32_t idx = idx0 + i;
-            uint32_t src = n;
-            for (uint32_t cc = c; cc-- > 0;) {
-                const uint32_t b0 = cc ? sb : 0u;
-                if (idx < b0) break;                          /* below sb every pass rewrites the index: never read stale */
-                const uint32_t cand = cyc[cc] + (idx - b0);
-                if (cand < cyc[cc + 1]) { src = cand; break; }   /* pass cc got that far */
-            }
-            ptr[j0 + i] = src;
-        }
+    const uint32_t j0 = dst[k] + pre;
+    if (off == 0 && len > 0 && Q.cyc) {
+        const uint32_t c = dec_stale_pass(Q, j0), idx0 = dec_stale_b0(Q, c, sb) + (j0 - Q.cyc[c]);
+        for (uint32_t i = 0; i < len; i++) ptr[j0 + i] = dec_stale_src(Q, c, idx0 + i, sb, pre, n);
         out[j0 + len] = (uint8_t)lit;
         ptr[j0 + len] = j0 + len;
         return;
@@ -153,18 +170,18 @@ __global__ void k_dec_gather(uint8_t *__restrict__ out, const uint32_t *__restri
  * it points at a resolved one (whose value the tile pass already wrote and nothing changes any more), then one
  * gather.  unres[] is immutable after the tile pass, ptr32[j] only ever moves along j's own chain: any
  * interleaving is safe. */
-#define DT_TB 12288u                                 /* 5 B of LDS per byte: two workgroups per CU */
+#define DT_TB LZ77K_DEC_TILE_BYTES                               /* 5 B of LDS per byte: two workgroups per CU */
 #define DT_BLOCK 1024
 #define DT_INT 0u
 #define DT_LIT 1u
 #define DT_EXT 2u
 
 /* tfirst[t] = the token whose bytes contain output offset t * DT_TB */
-__global__ void k_dec_bounds(const uint32_t *__restrict__ dst, uint32_t ntok, uint32_t *__restrict__ tfirst)
+__global__ void k_dec_bounds(const uint32_t *__restrict__ dst, uint32_t ntok, uint32_t *__restrict__ tfirst, uint32_t pre)
 {
     const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= ntok) return;
-    const uint32_t a = dst[k], b = dst[k + 1];
+    const uint32_t a = dst[k] + pre, b = dst[k + 1] + pre;
     const uint32_t t = (a + DT_TB - 1u) / DT_TB;
     if ((uint64_t)t * DT_TB < b) tfirst[t] = k;
 }
@@ -172,14 +189,14 @@ __global__ void k_dec_bounds(const uint32_t *__restrict__ dst, uint32_t ntok, ui
 __global__ __launch_bounds__(DT_BLOCK) void k_dec_tile(const uint32_t *__restrict__ tokval, const uint32_t *__restrict__ dst, uint32_t ntok,
                                                        int ob, int lb, uint8_t *__restrict__ out, uint32_t *__restrict__ ptr32,
                                                        unsigned long long *__restrict__ unres, uint32_t n, uint32_t ntiles,
-                                                       const uint32_t *__restrict__ tfirst, const uint32_t *__restrict__ cyc, uint32_t ncyc,
-                                                       uint32_t sb)
+                                                       const uint32_t *__restrict__ tfirst, lz77k_dec_stale Q, uint32_t sb,
+                                                       uint32_t pre /* bytes of history before the range's output: a multiple of DT_TB */)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t dt_smem[];
     uint32_t *val = reinterpret_cast<uint32_t *>(dt_smem);           /* local index | byte value | absolute source */
     uint8_t *tag = dt_smem + (size_t)DT_TB * 4;
     const uint32_t tid = threadIdx.x;
-    const uint32_t t = blockIdx.x;
+    const uint32_t t = blockIdx.x + pre / DT_TB;
     const uint32_t j0 = t * DT_TB, j1 = n - j0 < DT_TB ? n : j0 + DT_TB, cnt = j1 - j0;
     const uint32_t k0 = tfirst[t], k1 = t + 1 < ntiles ? tfirst[t + 1] + 1u : ntok;
 
@@ -189,16 +206,14 @@ __global__ __launch_bounds__(DT_BLOCK) void k_dec_tile(const uint32_t *__restric
         const uint32_t off = ob ? (v & ((1u << ob) - 1u)) : 0;
         const uint32_t len = (v >> ob) & ((1u << lb) - 1u);
         const uint32_t lit = (v >> (ob + lb)) & 0xFFu;
-        const uint32_t d = dst[k];
-        const bool stale = off == 0 && len > 0 && cyc;
+        const uint32_t d = dst[k] + pre;
+        const bool stale = off == 0 && len > 0 && Q.cyc;
         uint32_t c = 0, idx0 = 0;
         if (stale) {
             /* a copy from distance 0 (power-of-two -s): the byte the reference's 3*SB+LA staging buffer still
-             * holds at that index (lz77.c:172-181), see k_dec_expand */
-            uint32_t lo = 0, hi = ncyc;
-            while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (cyc[mid] <= d) lo = mid; else hi = mid; }
-            c = lo;
-            idx0 = (c ? sb : 0u) + (d - cyc[c]);
+             * holds at that index (lz77.c:172-181), see dec_stale_src */
+            c = dec_stale_pass(Q, d);
+            idx0 = dec_stale_b0(Q, c, sb) + (d - Q.cyc[c]);
         }
         const uint32_t ia = d < j0 ? j0 - d : 0u;                     /* first byte of the token inside the tile */
         for (uint32_t i = ia; i <= len; i++) {
@@ -208,13 +223,7 @@ __global__ __launch_bounds__(DT_BLOCK) void k_dec_tile(const uint32_t *__restric
             if (i < len) {
                 uint32_t src = n;                                     /* n = "a zero byte" (degenerate tokens) */
                 if (stale) {
-                    const uint32_t idx = idx0 + i;
-                    for (uint32_t cc = c; cc-- > 0;) {
-                        const uint32_t b0 = cc ? sb : 0u;
-                        if (idx < b0) break;
-                        const uint32_t cand = cyc[cc] + (idx - b0);
-                        if (cand < cyc[cc + 1]) { src = cand; break; }
-                    }
+                    src = dec_stale_src(Q, c, idx0 + i, sb, pre, n);
                 } else if (off > 0 && off <= j) {
                     src = j - off;
                 }
@@ -352,19 +361,20 @@ size_t lz77k_dec_tile_tmp_bytes(uint32_t n)
  * *d_unres receives the bitmap's address inside it. */
 hipError_t lz77k_dec_tiles(const uint32_t *d_tokval, const uint32_t *d_dst, uint32_t ntok, const lz77x_geom &g, uint8_t *d_out,
                            uint32_t *d_ptr, uint32_t n, void *d_tmp, const unsigned long long **d_unres, hipStream_t s,
-                           const uint32_t *d_cyc, uint32_t ncyc)
+                           const lz77k_dec_stale &Q, uint32_t pre)
 {
-    if (n == 0 || ntok == 0) return hipSuccess;
-    const uint32_t ntiles = (uint32_t)(((size_t)n + DT_TB - 1) / DT_TB);
+    if (n <= pre || ntok == 0) return hipSuccess;
+    const uint32_t ntiles = (uint32_t)(((size_t)n + DT_TB - 1) / DT_TB), t0 = pre / DT_TB;
     uint32_t *tfirst = reinterpret_cast<uint32_t *>(d_tmp);
     unsigned long long *unres = reinterpret_cast<unsigned long long *>(reinterpret_cast<uint8_t *>(d_tmp) + (((size_t)ntiles + 8) * 4 + 255) / 256 * 256);
     *d_unres = unres;
     const size_t lds = (size_t)DT_TB * 5;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_dec_tile), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(k_dec_bounds, dim3((ntok + 255) / 256), dim3(256), 0, s, d_dst, ntok, tfirst);
-    hipLaunchKernelGGL(k_dec_tile, dim3(ntiles), dim3(DT_BLOCK), lds, s, d_tokval, d_dst, ntok, g.ob, g.lb, d_out, d_ptr, unres, n, ntiles,
-                       tfirst, d_cyc, ncyc, (uint32_t)g.sb);
+    if (pre && (e = hipMemsetAsync(unres, 0, (size_t)pre / 8, s)) != hipSuccess) return e;      /* the history is resolved */
+    hipLaunchKernelGGL(k_dec_bounds, dim3((ntok + 255) / 256), dim3(256), 0, s, d_dst, ntok, tfirst, pre);
+    hipLaunchKernelGGL(k_dec_tile, dim3(ntiles - t0), dim3(DT_BLOCK), lds, s, d_tokval, d_dst, ntok, g.ob, g.lb, d_out, d_ptr, unres, n, ntiles,
+                       tfirst, Q, (uint32_t)g.sb, pre);
     return hipGetLastError();
 }
 
@@ -752,10 +762,76 @@ hipError_t lz77k_dec_parse(const uint8_t *d_z, uint32_t ntok, const lz77x_geom &
 }
 
 hipError_t lz77k_dec_expand(const uint32_t *d_tokval, const uint32_t *d_dst, uint32_t ntok, const lz77x_geom &g,
-                            uint8_t *d_out, uint32_t *d_ptr, uint32_t n, hipStream_t s, const uint32_t *d_cyc, uint32_t ncyc)
+                            uint8_t *d_out, uint32_t *d_ptr, uint32_t n, hipStream_t s, const lz77k_dec_stale &Q, uint32_t pre)
 {
-    hipLaunchKernelGGL(k_dec_expand, dim3(ntok ? (ntok + 255) / 256 : 1), dim3(256), 0, s, d_tokval, d_dst, ntok, g.ob, g.lb, d_out, d_ptr, n,
-                       d_cyc, ncyc, (uint32_t)g.sb);
+    const uint32_t need = ntok > pre / 64u ? ntok : pre / 64u;
+    hipLaunchKernelGGL(k_dec_expand, dim3(need ? (need + 255) / 256 : 1), dim3(256), 0, s, d_tokval, d_dst, ntok, g.ob, g.lb, d_out, d_ptr, n,
+                       Q, (uint32_t)g.sb, pre);
+    return hipGetLastError();
+}
+
+/* ---- a stream decoded range by range (lz77.c:160-195 through bounded memory): what one range leaves to the next ---- */
+
+/* carry_new = the last cb bytes of [carry_old | out[0, n)) */
+__global__ void k_dec_carry(const uint8_t *__restrict__ carry_old, const uint8_t *__restrict__ out, uint32_t n, uint32_t cb,
+                            uint8_t *__restrict__ carry_new)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= cb) return;
+    const int64_t sidx = (int64_t)n - (int64_t)cb + (int64_t)i;
+    carry_new[i] = sidx >= 0 ? out[sidx] : carry_old[(int64_t)cb + sidx];
+}
+
+hipError_t lz77k_dec_carry(const uint8_t *d_carry_old, const uint8_t *d_out, uint32_t n, uint32_t cb, uint8_t *d_carry_new, hipStream_t s)
+{
+    if (!cb) return hipSuccess;
+    hipLaunchKernelGGL(k_dec_carry, dim3((cb + 255) / 256), dim3(256), 0, s, d_carry_old, d_out, n, cb, d_carry_new);
+    return hipGetLastError();
+}
+
+/* the reference's staging buffer at indices [sb, W) after this range: per index the byte the latest pass that reached
+ * it left there (dec_stale_src reads it in the ranges that follow); x = the working buffer, resolved */
+__global__ void k_dec_image(const uint8_t *__restrict__ x, lz77k_dec_stale Q, uint32_t sb, uint32_t W, uint32_t pre,
+                            const uint8_t *__restrict__ img_old, uint8_t *__restrict__ img_new)
+{
+    const uint32_t idx = sb + blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= W) return;
+    uint8_t v = img_old[idx - sb];
+    for (uint32_t cc = Q.ncyc; cc-- > 0;) {
+        const uint32_t b0 = dec_stale_b0(Q, cc, sb);
+        if (idx < b0) continue;
+        const uint32_t cand = Q.cyc[cc] + (idx - b0);
+        if (cand < Q.cyc[cc + 1]) {
+            if (cand >= pre) v = x[cand];                     /* else: written before this range -- the old image holds it */
+            break;
+        }
+    }
+    img_new[idx - sb] = v;
+}
+
+hipError_t lz77k_dec_image(const uint8_t *d_x, const lz77k_dec_stale &Q, uint32_t sb, uint32_t W, uint32_t pre, const uint8_t *d_img_old,
+                           uint8_t *d_img_new, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_dec_image, dim3((W - sb + 255) / 256), dim3(256), 0, s, d_x, Q, sb, W, pre, d_img_old, d_img_new);
+    return hipGetLastError();
+}
+
+/* the largest multiple of eight k <= ntok with dst[k] <= cap (a range whose tokens expand past the output budget is cut
+ * there: every range starts on a byte of the stream); res[0] = k, res[1] = dst[k] */
+__global__ void k_dec_cut(const uint32_t *__restrict__ dst, uint32_t ntok, uint32_t cap, uint32_t *__restrict__ res)
+{
+    uint32_t lo = 0, hi = ntok / 8u;                          /* dst[8 * lo] <= cap (dst[0] = 0) */
+    while (lo < hi) {
+        const uint32_t mid = lo + (hi - lo + 1u) / 2u;
+        if (dst[8u * mid] <= cap) lo = mid; else hi = mid - 1u;
+    }
+    res[0] = 8u * lo;
+    res[1] = dst[8u * lo];
+}
+
+hipError_t lz77k_dec_cut(const uint32_t *d_dst, uint32_t ntok, uint32_t cap, uint32_t *d_res, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_dec_cut, dim3(1), dim3(1), 0, s, d_dst, ntok, cap, d_res);
     return hipGetLastError();
 }
 

@@ -241,11 +241,25 @@ hipError_t lz77k_pack_range(const uint32_t *d_tokval, uint64_t k_first, uint64_t
  * [1] when one copies from beyond the window (off > sb: no stream of the reference's encoder) */
 hipError_t lz77k_dec_parse(const uint8_t *d_z, uint32_t ntok, const lz77x_geom &g,
                            uint32_t *d_tokval, uint32_t *d_len1, hipStream_t s, uint32_t *d_stale_flag = nullptr);
-/* d_cyc[0..ncyc]: output offsets at which the reference's staging buffer starts a new pass (+ a final n), for
- * the distance-0 copies; null when the stream has none */
+/* Distance-0 copies (power-of-two -s): cyc[0..ncyc] = offsets at which the reference's staging buffer starts a new pass
+ * (+ a final end), in the coordinates of the working buffer = `pre` bytes of history + the output; cyc == null when the
+ * stream has none.  A stream decoded range by range: pass 0 of the list may have begun before the range (first0: it is the
+ * first pass of the whole stream), img = offset in the working buffer of the image of the reference's buffer at index sb
+ * (LZ77X_NONE32: there is none, a never-written index reads as zero).  See dec_stale_src in k_decode.hip. */
+struct lz77k_dec_stale {
+    const uint32_t *cyc = nullptr;
+    uint32_t ncyc = 0, first0 = 1, img = LZ77X_NONE32;
+};
+/* n = pre + output bytes: the working buffer d_out / d_ptr holds `pre` bytes of resolved history in front of the output */
 hipError_t lz77k_dec_expand(const uint32_t *d_tokval, const uint32_t *d_dst, uint32_t ntok,
                             const lz77x_geom &g, uint8_t *d_out, uint32_t *d_ptr, uint32_t n, hipStream_t s,
-                            const uint32_t *d_cyc = nullptr, uint32_t ncyc = 0);
+                            const lz77k_dec_stale &Q = lz77k_dec_stale(), uint32_t pre = 0);
+/* what a range of a stream leaves to the next one (k_decode.hip) */
+hipError_t lz77k_dec_carry(const uint8_t *d_carry_old, const uint8_t *d_out, uint32_t n, uint32_t cb, uint8_t *d_carry_new, hipStream_t s);
+hipError_t lz77k_dec_image(const uint8_t *d_x, const lz77k_dec_stale &Q, uint32_t sb, uint32_t W, uint32_t pre, const uint8_t *d_img_old,
+                           uint8_t *d_img_new, hipStream_t s);
+hipError_t lz77k_dec_cut(const uint32_t *d_dst, uint32_t ntok, uint32_t cap, uint32_t *d_res, hipStream_t s);
+#define LZ77K_DEC_TILE_BYTES 12288u      /* the tile pass works on tiles of this many output bytes: `pre` is a multiple of it */
 /* one pass over in_list[0..total) (or over every j < total when in_list is null); entries that moved are
  * appended to out_list, *out_count += their number */
 hipError_t lz77k_dec_jump(uint32_t *d_ptr, uint32_t total, const uint32_t *d_in_list, uint32_t *d_out_list, uint32_t *d_out_count,
@@ -256,7 +270,7 @@ hipError_t lz77k_dec_gather(uint8_t *d_out, const uint32_t *d_ptr, uint32_t n, h
 size_t lz77k_dec_tile_tmp_bytes(uint32_t n);
 hipError_t lz77k_dec_tiles(const uint32_t *d_tokval, const uint32_t *d_dst, uint32_t ntok, const lz77x_geom &g, uint8_t *d_out,
                            uint32_t *d_ptr, uint32_t n, void *d_tmp, const unsigned long long **d_unres, hipStream_t s,
-                           const uint32_t *d_cyc = nullptr, uint32_t ncyc = 0);
+                           const lz77k_dec_stale &Q = lz77k_dec_stale(), uint32_t pre = 0);
 hipError_t lz77k_dec_jump2(uint32_t *d_ptr, const unsigned long long *d_unres, uint32_t total, const uint32_t *d_in_list,
                            uint32_t *d_out_list, uint32_t *d_out_count, hipStream_t s);
 /* segment decode (production for sb <= 8192, no distance-0 copies): a workgroup walks a segment of the output

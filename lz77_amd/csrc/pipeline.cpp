@@ -172,12 +172,12 @@ struct Ctx {
     Ctx *pipe = nullptr;                     /* second context set on the same device (two segments of one stream in flight) */
     std::vector<hipEvent_t> chunk_ev, tok_ev, sort_ev, match_ev, tie_ev;
     DevBuf in, ps, maxlen, scratch, xval, chain, ofs, ent, tokval, out, scantmp;
-    DevBuf z, len1, dst, ptr, flag, tstart, bidx, cells, ranks_all, prio_tmp, chain_tmp, look;
+    DevBuf z, z2, dcarry, len1, dst, ptr, flag, tstart, bidx, cells, ranks_all, prio_tmp, chain_tmp, look;
     PinBuf h_ps, h_maxlen, h_xval, h_chain, h_small, h_tok, h_stage, h_tbase;
     /* every cached buffer, so that no release path can forget one */
     std::vector<DevBuf *> dev_bufs()
     {
-        return {&in, &ps, &maxlen, &scratch, &xval, &chain, &ofs, &ent, &tokval, &out, &scantmp, &z, &len1, &dst, &ptr,
+        return {&in, &ps, &maxlen, &scratch, &xval, &chain, &ofs, &ent, &tokval, &out, &scantmp, &z, &z2, &dcarry, &len1, &dst, &ptr,
                 &flag, &tstart, &bidx, &cells, &ranks_all, &prio_tmp, &chain_tmp, &look};
     }
     std::vector<PinBuf *> pin_bufs() { return {&h_ps, &h_maxlen, &h_xval, &h_chain, &h_small, &h_tok, &h_stage, &h_tbase}; }
@@ -822,171 +822,7 @@ int encode_core_host(std::vector<Ctx *> &cs, const void *src, bool src_on_device
 
 /* ---------------------------------------------------------------- decode ------------ */
 
-/* Stream must already be in c.z (device, padded).  Computes geometry and decoded size;
- * when want_data the decoded bytes end up in c.out. */
-int decode_core(Ctx &c, size_t zn, hipStream_t s, bool want_data, size_t *n_out)
-{
-    const double t_begin = now_ms();
-    memset(&g_stats, 0, sizeof g_stats);
-    if (zn < 4) return LZ77X_E_FORMAT;
-    int rc;
-    if ((rc = c.h_small.need(64))) return rc;
-    uint8_t *hdr = c.h_small.as<uint8_t>();
-    HIPCHK(hipMemcpyAsync(hdr, c.z.p, 4, hipMemcpyDeviceToHost, s));
-    HIPCHK(hipStreamSynchronize(s));
-    const int sb = hdr[0] | (hdr[1] << 8), la = hdr[2] | (hdr[3] << 8);       /* lz77.c:157-158 */
-    if (sb < 1 || la < 1) return LZ77X_E_FORMAT;
-    lz77x_geom g;
-    lz77x_make_geom(&g, sb, la);
-    /* the header is 16 bits of la, but main.c:103 never lets la past 255: a token wider than 32 bits
-     * cannot come from the reference's encoder, and the kernels carry tokens in 32-bit words */
-    if (g.T > 32) return LZ77X_E_FORMAT;
-    const uint64_t ntok64 = ((uint64_t)zn * 8 - 32) / (uint64_t)g.T;          /* lz77.c:271: short read = EOF */
-    if (ntok64 > LZ77X_MAX_N) return LZ77X_E_TOOBIG;
-    const uint32_t ntok = (uint32_t)ntok64;
-
-    uint64_t n = 0;
-    bool stale = false;                       /* the stream copies from distance 0 somewhere (power-of-two -s) */
-    bool general = false;                     /* not a stream of the reference's encoder: no window / token-length assumptions */
-    HIPCHK(hipEventRecord(c.ev[0], s));
-    if (ntok) {
-        if ((rc = c.tokval.need(((size_t)ntok + 8) * 4))) return rc;
-        if ((rc = c.len1.need(((size_t)ntok + 8) * 4))) return rc;
-        if ((rc = c.dst.need(((size_t)ntok + 8) * 4))) return rc;
-        if ((rc = c.scantmp.need(lz77k_scan_tmp_bytes(ntok + 1)))) return rc;
-        if ((rc = c.flag.need(64))) return rc;
-        HIPCHK(hipMemsetAsync(c.flag.as<uint32_t>() + 8, 0, 8, s));
-        HIPCHK(lz77k_dec_parse(c.z.as<uint8_t>(), ntok, g, c.tokval.as<uint32_t>(), c.len1.as<uint32_t>(), s, c.flag.as<uint32_t>() + 8));
-        HIPCHK(hipMemsetAsync(c.len1.as<uint32_t>() + ntok, 0, 4, s));
-        /* decoded size can exceed 32 bits for hostile streams: bound it (64-bit sum on the device)
-         * before trusting the 32-bit scan */
-        if ((uint64_t)ntok * ((1u << g.lb)) > LZ77X_MAX_N) {
-            if ((rc = c.flag.need(64))) return rc;
-            unsigned long long *htot = reinterpret_cast<unsigned long long *>(hdr + 48);
-            HIPCHK(lz77k_sum_u32(c.len1.as<uint32_t>(), ntok, c.flag.as<unsigned long long>() + 2, s));
-            HIPCHK(hipMemcpyAsync(htot, c.flag.as<unsigned long long>() + 2, 8, hipMemcpyDeviceToHost, s));
-            HIPCHK(hipStreamSynchronize(s));
-            if (*htot > LZ77X_MAX_N) return LZ77X_E_TOOBIG;
-        }
-        HIPCHK(lz77k_scan_u32(c.len1.as<uint32_t>(), c.dst.as<uint32_t>(), ntok + 1, c.scantmp.p, s));
-        uint32_t *tot = reinterpret_cast<uint32_t *>(hdr + 16);
-        HIPCHK(hipMemcpyAsync(tot, c.dst.as<uint32_t>() + ntok, 4, hipMemcpyDeviceToHost, s));
-        HIPCHK(hipMemcpyAsync(tot + 1, c.flag.as<uint32_t>() + 8, 8, hipMemcpyDeviceToHost, s));
-        HIPCHK(hipStreamSynchronize(s));
-        n = *tot;
-        stale = tot[1] != 0;
-        /* distances beyond the window, or a lookahead field no CLI run can produce (main.c:103 caps -l at 255; a token
-         * may then span several tiles): the per-byte pointer path, which assumes nothing about either */
-        general = tot[2] != 0 || la > 255;
-    }
-    *n_out = (size_t)n;
-    uint32_t rounds = 0;
-    if (want_data && n) {
-        const uint32_t n32 = (uint32_t)n;
-        if ((rc = c.out.need(n + 16))) return rc;
-        if ((rc = c.ptr.need((n + 8) * 4))) return rc;
-        if ((rc = c.flag.need(64))) return rc;
-        const uint32_t *d_cyc = nullptr;
-        uint32_t ncyc = 0;
-        if (stale) {
-            /* The reference's decoder stages its output in a buffer of W = 3*SB+LA bytes that restarts at index
-             * SB whenever the next token would not fit (lz77.c:172-175); a copy from distance 0 re-reads the byte
-             * an earlier pass left at the same index.  Where the passes begin is a sequential function of the
-             * token lengths -- one step per ~2*SB bytes of output: walked here on the host over dst[] (only
-             * streams from a power-of-two -s ever come this way). */
-            std::vector<uint32_t> hdst((size_t)ntok + 1);
-            HIPCHK(hipMemcpy(hdst.data(), c.dst.p, ((size_t)ntok + 1) * 4, hipMemcpyDeviceToHost));
-            const uint64_t W = 3 * (uint64_t)g.sb + (uint64_t)g.la;
-            const uint32_t lmax = (1u << g.lb) - 1u;
-            std::vector<uint32_t> cyc;
-            cyc.push_back(0);
-            uint32_t ks = 0;
-            for (;;) {
-                const uint64_t back0 = cyc.size() == 1 ? 0 : (uint64_t)g.sb, J = hdst[ks];
-                /* first token k >= ks with back0 + (dst[k] - J) + len_k > W - 1 */
-                uint32_t lo = ks, hi = ntok;                  /* tokens below lo certainly fit */
-                const uint64_t safe = W - 1 > lmax ? W - 1 - lmax : 0;
-                while (lo < hi) {                             /* first k whose start is past the always-safe zone */
-                    const uint32_t mid = lo + (hi - lo) / 2;
-                    if (back0 + (hdst[mid] - J) <= safe) lo = mid + 1; else hi = mid;
-                }
-                uint32_t k = lo > ks ? lo - 1 : ks;
-                for (; k < ntok; k++) {
-                    const uint64_t len = (uint64_t)hdst[k + 1] - hdst[k] - 1;
-                    if (back0 + (hdst[k] - J) + len > W - 1) break;
-                }
-                if (k >= ntok) break;
-                if (k == ks && cyc.size() > 1 && back0 + ((uint64_t)hdst[k + 1] - hdst[k] - 1) > W - 1) break;   /* a token longer than the buffer: malformed */
-                cyc.push_back(hdst[k]);
-                ks = k;
-            }
-            cyc.push_back(n32);
-            ncyc = (uint32_t)cyc.size() - 1;
-            if ((rc = c.scratch.need(cyc.size() * 4 + 64))) return rc;
-            HIPCHK(hipMemcpy(c.scratch.p, cyc.data(), cyc.size() * 4, hipMemcpyHostToDevice));
-            d_cyc = c.scratch.as<uint32_t>();
-        }
-        const char *dv = LZ77X_VENV("LZ77X_DECODE_VARIANT");            /* 0 production, 1 tile pass + jumping, (LZ77X_DECODE_V1: round 1) */
-        if (!stale && !general && lz77k_dec_seg_supported(g) && !(dv && atoi(dv)) && !LZ77X_VENV("LZ77X_DECODE_V1")) {
-            if ((rc = c.tstart.need(lz77k_dec_seg_tmp_bytes(n32, g)))) return rc;
-            HIPCHK(lz77k_dec_segments(c.tokval.as<uint32_t>(), c.dst.as<uint32_t>(), ntok, g, c.out.as<uint8_t>(), c.ptr.p, n32, c.tstart.p, s));
-        } else {
-        /* work lists of the pointer-jumping passes (encode's ps/cells buffers are idle during a decode) */
-        if ((rc = c.ps.need((n + 8) * 4))) return rc;
-        if ((rc = c.cells.need((n + 8) * 4))) return rc;
-        uint32_t *lists[2] = {c.ps.as<uint32_t>(), c.cells.as<uint32_t>()};
-        uint32_t *hcount = reinterpret_cast<uint32_t *>(hdr + 32);
-        uint32_t total = n32;
-        const uint32_t *in_list = nullptr;
-        if (general || LZ77X_VENV("LZ77X_DECODE_V1")) {
-            /* round 1: a pointer per output byte in HBM, jumped there (kept as a cross-check, and for streams
-             * that no run of the reference's encoder produces) */
-            HIPCHK(lz77k_dec_expand(c.tokval.as<uint32_t>(), c.dst.as<uint32_t>(), ntok, g, c.out.as<uint8_t>(),
-                                    c.ptr.as<uint32_t>(), n32, s, d_cyc, ncyc));
-            for (;;) {
-                HIPCHK(hipMemsetAsync(c.flag.p, 0, 4, s));
-                HIPCHK(lz77k_dec_jump(c.ptr.as<uint32_t>(), total, in_list, lists[rounds & 1], c.flag.as<uint32_t>(), s));
-                HIPCHK(hipMemcpyAsync(hcount, c.flag.p, 4, hipMemcpyDeviceToHost, s));
-                HIPCHK(hipStreamSynchronize(s));
-                in_list = lists[rounds & 1];
-                total = *hcount;
-                rounds += 1;
-                if (!total || rounds > 80) break;
-            }
-            HIPCHK(lz77k_dec_gather(c.out.as<uint8_t>(), c.ptr.as<uint32_t>(), n32, s));
-        } else {
-            /* tiles resolve in LDS what stays inside them; only the pointers that leave a tile are jumped in HBM */
-            if ((rc = c.tstart.need(lz77k_dec_tile_tmp_bytes(n32)))) return rc;
-            const unsigned long long *d_unres = nullptr;
-            HIPCHK(lz77k_dec_tiles(c.tokval.as<uint32_t>(), c.dst.as<uint32_t>(), ntok, g, c.out.as<uint8_t>(), c.ptr.as<uint32_t>(), n32,
-                                   c.tstart.p, &d_unres, s, d_cyc, ncyc));
-            for (;;) {
-                HIPCHK(hipMemsetAsync(c.flag.p, 0, 4, s));
-                HIPCHK(lz77k_dec_jump2(c.ptr.as<uint32_t>(), d_unres, total, in_list, lists[rounds & 1], c.flag.as<uint32_t>(), s));
-                HIPCHK(hipMemcpyAsync(hcount, c.flag.p, 4, hipMemcpyDeviceToHost, s));
-                HIPCHK(hipStreamSynchronize(s));
-                in_list = lists[rounds & 1];
-                total = *hcount;
-                rounds += 1;
-                if (!total || rounds > 80) break;
-            }
-            HIPCHK(lz77k_dec_gather2(c.out.as<uint8_t>(), c.ptr.as<uint32_t>(), d_unres, n32, s));
-        }
-        }
-    }
-    HIPCHK(hipEventRecord(c.ev[1], s));
-    HIPCHK(hipStreamSynchronize(s));
-    float ms = 0;
-    HIPCHK(hipEventElapsedTime(&ms, c.ev[0], c.ev[1]));
-    g_stats.k_decode_ms = ms;
-    g_stats.n = n;
-    g_stats.zn = zn;
-    g_stats.ntok = ntok;
-    g_stats.decode_rounds = rounds;
-    g_stats.total_ms = now_ms() - t_begin;
-    g_stats.copy_ms = g_stats.total_ms - g_stats.k_decode_ms;
-    return LZ77X_OK;
-}
+/* (the decoder proper -- decode_stream -- follows the sources and sinks it reads from and writes to) */
 
 int fetch_result(Ctx &c, uint8_t *dst, const void *d_src, size_t bytes);
 extern "C" uint64_t lz77x_shard_token_cut(uint64_t ntok, int shards, int d);
@@ -1121,16 +957,6 @@ int decode_sharded(std::vector<Ctx *> &cs, const uint8_t *z, size_t zn, uint8_t 
     return LZ77X_OK;
 }
 
-int load_stream(Ctx &c, const void *src, bool on_device, size_t zn, hipStream_t s)
-{
-    int rc;
-    if ((rc = c.z.need(zn + 32))) return rc;
-    HIPCHK(hipMemsetAsync(c.z.as<uint8_t>() + zn, 0, 32, s));
-    if (zn) HIPCHK(hipMemcpyAsync(c.z.p, src, zn, on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, s));
-    return LZ77X_OK;
-}
-
-
 /* device -> caller's pageable buffer through two pinned staging slots: the DMA of piece k+1 runs
  * while the host copies piece k out (a direct hipMemcpy into pageable memory is ~2 GB/s) */
 int fetch_result(Ctx &c, uint8_t *dst, const void *d_src, size_t bytes)
@@ -1264,6 +1090,8 @@ struct Sink {
     /* host memory for the next `bytes` of the stream, to be filled by the caller in any order (several devices fetch
      * their pieces at once); null when the sink only takes bytes in sequence */
     virtual uint8_t *direct(size_t bytes) { (void)bytes; return nullptr; }
+    /* a sink of fixed capacity that has been offered more than it holds: only the count matters from here on */
+    virtual bool overflowed() const { return false; }
     size_t total = 0;
 };
 
@@ -1333,6 +1161,7 @@ struct DeviceSink : Sink {
         total += bytes;                                        /* past cap: keep counting, the caller reports the need */
         return LZ77X_OK;
     }
+    bool overflowed() const override { return total > cap; }
 };
 
 struct HostSink : Sink {
@@ -1380,6 +1209,340 @@ struct FileSink : Sink {
         return stream_out(c, f, d_src, bytes);
     }
 };
+
+/* ---------------------------------------------------------------- decode ------------ */
+
+/* lz77.c:160-195 decodes a stream of any length through a buffer of 3*SB+LA bytes.  Here a stream is decoded RANGE by
+ * range: a range is a run of consecutive tokens that starts on a multiple of eight tokens -- tokens have a fixed width
+ * T, so it starts on a byte of the stream -- of at most `range_tokens` tokens and at most `range_bytes` bytes of output
+ * (a range whose tokens expand further is cut at the last multiple of eight that fits; what was read beyond the cut
+ * opens the next range).  Device memory is a function of those two numbers and not of the stream's length, host memory
+ * is two staging slots; the stream may be a pipe and may decode to more than 4 GiB (offsets inside a range are 32-bit,
+ * counts across ranges 64-bit).  What a range needs from everything before it is what the reference's buffer holds
+ * (DecCarry): the last cb bytes of the output, and for streams with distance-0 copies (a power-of-two -s)
+ * the image of the staging buffer's upper 2*SB+LA bytes and where its current pass began. */
+struct DecCarry {
+    uint32_t cb = 0;             /* bytes of history a copy can reach: max(sb, 2^ob - 1) (the offset field is wider than sb unless sb = 2^k - 1) */
+    uint32_t W = 0;              /* 3*sb + la: the reference's buffer (lz77.c:160) */
+    uint32_t pre = 0;            /* the paths that keep pointers work on [pre bytes of history | the range's output]: a multiple of the tile size */
+    bool track = false;          /* distance-0 copies are followed: pass structure + image */
+    int cur = 0;                 /* which half of the double-buffered device state is current */
+    uint8_t *d_carry[2] = {nullptr, nullptr};
+    uint8_t *d_img[2] = {nullptr, nullptr};
+    uint64_t produced = 0;       /* output bytes before the range */
+    uint64_t pass_start = 0;     /* output offset at which the staging buffer's current pass began */
+    bool first_pass = true;      /* ... and it is the first pass of the stream (it starts at buffer index 0, the others at sb) */
+};
+
+/* Where the reference's staging buffer starts a new pass (lz77.c:172-175: when the next token's copy would not fit) is a
+ * sequential function of the token lengths -- one step per ~2*SB bytes of output, walked here on the host over dst[] (only
+ * streams from a power-of-two -s ever come this way).  Offsets are in working-buffer coordinates (pre + dst[k]); the pass
+ * in progress when the range begins started at `start` (<= pre). */
+void dec_pass_walk(const uint32_t *hdst, uint32_t ntok, const lz77x_geom &g, uint32_t pre, uint32_t start, bool first_pass,
+                   std::vector<uint32_t> &cyc)
+{
+    const uint64_t W = 3 * (uint64_t)g.sb + (uint64_t)g.la;
+    const uint32_t lmax = (1u << g.lb) - 1u;
+    const uint64_t safe = W - 1 > lmax ? W - 1 - lmax : 0;
+    cyc.clear();
+    cyc.push_back(start);
+    bool firstp = first_pass;
+    uint32_t ks = 0;
+    for (;;) {
+        const uint64_t back0 = firstp ? 0 : (uint64_t)g.sb, J = cyc.back();
+        /* first token k >= ks with back0 + (pre + dst[k] - J) + len_k > W - 1 */
+        uint32_t lo = ks, hi = ntok;                              /* tokens below lo certainly fit */
+        while (lo < hi) {                                         /* first k whose start is past the always-safe zone */
+            const uint32_t mid = lo + (hi - lo) / 2;
+            if (back0 + ((uint64_t)pre + hdst[mid] - J) <= safe) lo = mid + 1; else hi = mid;
+        }
+        uint32_t k = lo > ks ? lo - 1 : ks;
+        for (; k < ntok; k++) {
+            const uint64_t len = (uint64_t)hdst[k + 1] - hdst[k] - 1;
+            if (back0 + ((uint64_t)pre + hdst[k] - J) + len > W - 1) break;
+        }
+        if (k >= ntok) break;
+        if ((uint64_t)pre + hdst[k] == J && !firstp) break;      /* a token longer than the buffer opens the pass: malformed */
+        cyc.push_back(pre + hdst[k]);
+        ks = k;
+        firstp = false;
+    }
+    cyc.push_back(pre + hdst[ntok]);
+}
+
+/* The copy resolution of one range: tokens c.tokval / c.dst [0, ntok) -> n bytes at *d_bytes (inside c.out), complete in
+ * stream order on s.  K == null: the range is the whole stream. */
+int decode_resolve(Ctx &c, const lz77x_geom &g, uint32_t ntok, uint32_t n, hipStream_t s, bool stale, bool general, DecCarry *K,
+                   uint8_t **d_bytes, uint32_t *rounds_out)
+{
+    int rc;
+    uint32_t rounds = 0;
+    const char *dv = LZ77X_VENV("LZ77X_DECODE_VARIANT");            /* 0 production, 1 tile pass + jumping, (LZ77X_DECODE_V1: round 1) */
+    const bool track = K && K->track;
+    const bool use_seg = !stale && !general && !track && lz77k_dec_seg_supported(g) && !(dv && atoi(dv)) && !LZ77X_VENV("LZ77X_DECODE_V1");
+    const uint32_t pre = K && !use_seg ? K->pre : 0u;
+    const uint32_t N = pre + n;
+    if ((rc = c.out.need((size_t)N + 16))) return rc;
+    if ((rc = c.ptr.need(use_seg ? ((size_t)N + 8) * 2 : ((size_t)N + 8) * 4))) return rc;
+    if ((rc = c.flag.need(64))) return rc;
+    if ((rc = c.h_small.need(128))) return rc;
+    uint8_t *hdr = c.h_small.as<uint8_t>();
+    uint8_t *X = c.out.as<uint8_t>();
+    *d_bytes = X + pre;
+    lz77k_dec_stale Q;
+    std::vector<uint32_t> cyc;
+    if (pre) {
+        /* history in front of the output: zeros (what a copy from before the first byte reads), the image, the carry */
+        HIPCHK(hipMemsetAsync(X, 0, pre, s));
+        HIPCHK(hipMemcpyAsync(X + pre - K->cb, K->d_carry[K->cur], K->cb, hipMemcpyDeviceToDevice, s));
+        if (track) {
+            Q.img = pre - K->cb - (K->W - (uint32_t)g.sb);
+            HIPCHK(hipMemcpyAsync(X + Q.img, K->d_img[K->cur], K->W - (uint32_t)g.sb, hipMemcpyDeviceToDevice, s));
+        }
+    }
+    if (stale || track) {
+        std::vector<uint32_t> hdst((size_t)ntok + 1);
+        HIPCHK(hipMemcpyAsync(hdst.data(), c.dst.p, ((size_t)ntok + 1) * 4, hipMemcpyDeviceToHost, s));
+        HIPCHK(hipStreamSynchronize(s));
+        const uint32_t start = K ? (uint32_t)((uint64_t)pre - (K->produced - K->pass_start)) : 0u;
+        Q.first0 = K ? (K->first_pass ? 1u : 0u) : 1u;
+        dec_pass_walk(hdst.data(), ntok, g, pre, start, Q.first0 != 0, cyc);
+        Q.ncyc = (uint32_t)cyc.size() - 1;
+        if ((rc = c.scratch.need(cyc.size() * 4 + 64))) return rc;
+        HIPCHK(hipMemcpyAsync(c.scratch.p, cyc.data(), cyc.size() * 4, hipMemcpyHostToDevice, s));
+        HIPCHK(hipStreamSynchronize(s));                                     /* cyc is pageable: the copy has left it */
+        Q.cyc = c.scratch.as<uint32_t>();
+    }
+    if (use_seg) {
+        /* a workgroup per segment of the output, the roots of the last sb bytes in an LDS ring (k_dec_seg); the sb bytes
+         * before the range are symbolic references like those before any segment, resolved from the carry */
+        const bool ext0 = K && K->produced > 0;
+        if ((rc = c.tstart.need(lz77k_dec_seg_tmp_bytes(n, g)))) return rc;
+        lz77k_dec_seg_state P;
+        HIPCHK(lz77k_dec_segments_front(c.tokval.as<uint32_t>(), c.dst.as<uint32_t>(), ntok, g, X, c.ptr.p, n, c.tstart.p, s, ext0, P, nullptr));
+        if (ext0 && P.tres0)
+            HIPCHK(hipMemcpyAsync(P.tres0, K->d_carry[K->cur] + (K->cb - (uint32_t)g.sb), (size_t)g.sb, hipMemcpyDeviceToDevice, s));
+        HIPCHK(lz77k_dec_segments_back(g, X, c.ptr.p, n, P, s));
+    } else {
+        /* work lists of the pointer-jumping passes (encode's ps/cells buffers are idle during a decode) */
+        if ((rc = c.ps.need(((size_t)N + 8) * 4))) return rc;
+        if ((rc = c.cells.need(((size_t)N + 8) * 4))) return rc;
+        uint32_t *lists[2] = {c.ps.as<uint32_t>(), c.cells.as<uint32_t>()};
+        uint32_t *hcount = reinterpret_cast<uint32_t *>(hdr + 32);
+        uint32_t total = N;
+        const uint32_t *in_list = nullptr;
+        if (general || LZ77X_VENV("LZ77X_DECODE_V1")) {
+            /* a pointer per output byte in HBM, jumped there: streams that no run of the reference's encoder produces
+             * (distances beyond the window, la > 255) -- it assumes nothing about either -- and round 1's cross-check */
+            HIPCHK(lz77k_dec_expand(c.tokval.as<uint32_t>(), c.dst.as<uint32_t>(), ntok, g, X, c.ptr.as<uint32_t>(), N, s, Q, pre));
+            for (;;) {
+                HIPCHK(hipMemsetAsync(c.flag.p, 0, 4, s));
+                HIPCHK(lz77k_dec_jump(c.ptr.as<uint32_t>(), total, in_list, lists[rounds & 1], c.flag.as<uint32_t>(), s));
+                HIPCHK(hipMemcpyAsync(hcount, c.flag.p, 4, hipMemcpyDeviceToHost, s));
+                HIPCHK(hipStreamSynchronize(s));
+                in_list = lists[rounds & 1];
+                total = *hcount;
+                rounds += 1;
+                if (!total || rounds > 80) break;
+            }
+            HIPCHK(lz77k_dec_gather(X, c.ptr.as<uint32_t>(), N, s));
+        } else {
+            /* tiles resolve in LDS what stays inside them; only the pointers that leave a tile are jumped in HBM */
+            if ((rc = c.tstart.need(lz77k_dec_tile_tmp_bytes(N)))) return rc;
+            const unsigned long long *d_unres = nullptr;
+            HIPCHK(lz77k_dec_tiles(c.tokval.as<uint32_t>(), c.dst.as<uint32_t>(), ntok, g, X, c.ptr.as<uint32_t>(), N, c.tstart.p, &d_unres, s, Q, pre));
+            for (;;) {
+                HIPCHK(hipMemsetAsync(c.flag.p, 0, 4, s));
+                HIPCHK(lz77k_dec_jump2(c.ptr.as<uint32_t>(), d_unres, total, in_list, lists[rounds & 1], c.flag.as<uint32_t>(), s));
+                HIPCHK(hipMemcpyAsync(hcount, c.flag.p, 4, hipMemcpyDeviceToHost, s));
+                HIPCHK(hipStreamSynchronize(s));
+                in_list = lists[rounds & 1];
+                total = *hcount;
+                rounds += 1;
+                if (!total || rounds > 80) break;
+            }
+            HIPCHK(lz77k_dec_gather2(X, c.ptr.as<uint32_t>(), d_unres, N, s));
+        }
+    }
+    if (K) {
+        /* what the next range starts from */
+        HIPCHK(lz77k_dec_carry(K->d_carry[K->cur], X + pre, n, K->cb, K->d_carry[K->cur ^ 1], s));
+        if (track) {
+            HIPCHK(lz77k_dec_image(X, Q, (uint32_t)g.sb, K->W, pre, K->d_img[K->cur], K->d_img[K->cur ^ 1], s));
+            if (Q.ncyc > 1) K->first_pass = false;
+            K->pass_start = K->produced + (uint64_t)cyc[Q.ncyc - 1] - pre;      /* (cyc[0] < pre: wraps back to the carried start) */
+        }
+        K->cur ^= 1;
+        K->produced += n;
+    }
+    *rounds_out += rounds;
+    return LZ77X_OK;
+}
+
+/* knobs of the range decoder: tokens per range (a multiple of eight) and bytes of output per range */
+void dec_range_plan(const lz77x_geom &g, uint32_t *range_tokens, uint32_t *range_bytes)
+{
+    const char *e = getenv("LZ77X_DECODE_RANGE");
+    uint64_t R = e && atoll(e) > 0 ? (uint64_t)atoll(e) : (uint64_t)1 << 26;
+    e = getenv("LZ77X_DECODE_RANGE_BYTES");
+    uint64_t cap = e && atoll(e) > 0 ? (uint64_t)atoll(e) : (uint64_t)1 << 30;
+    const uint64_t rmax = (uint64_t)0xFF000000u >> g.lb;              /* 32-bit offsets inside a range, whatever its tokens hold */
+    if (R > rmax) R = rmax;
+    R &= ~(uint64_t)7;
+    if (R < 8) R = 8;
+    if (cap < ((uint64_t)8 << g.lb)) cap = (uint64_t)8 << g.lb;       /* eight tokens always fit */
+    if (cap > 0xFF000000u) cap = 0xFF000000u;
+    *range_tokens = (uint32_t)R;
+    *range_bytes = (uint32_t)cap;
+}
+
+/* The decoder: stream from `src` (its first four bytes are the header, lz77.c:157-158), bytes to `sink` (null: only the
+ * decoded size is wanted).  s: the stream every kernel is enqueued on. */
+int decode_stream(Ctx &c, Source &src, Sink *sink, hipStream_t s, uint64_t *n_out)
+{
+    const double t_begin = now_ms();
+    memset(&g_stats, 0, sizeof g_stats);
+    int rc;
+    if ((rc = c.h_small.need(128))) return rc;
+    if ((rc = c.z.need(64))) return rc;
+    if ((rc = c.flag.need(64))) return rc;
+    uint8_t *hdr = c.h_small.as<uint8_t>();
+    size_t got = 0;
+    if ((rc = src.read(c, c.z.as<uint8_t>(), 4, s, &got))) return rc;
+    if (got < 4) return LZ77X_E_FORMAT;
+    HIPCHK(hipMemcpyAsync(hdr, c.z.p, 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    const int sb = hdr[0] | (hdr[1] << 8), la = hdr[2] | (hdr[3] << 8);       /* lz77.c:157-158 */
+    if (sb < 1 || la < 1) return LZ77X_E_FORMAT;
+    lz77x_geom g;
+    lz77x_make_geom(&g, sb, la);
+    /* the header is 16 bits of la, but main.c:103 never lets la past 255: a token wider than 32 bits
+     * cannot come from the reference's encoder, and the kernels carry tokens in 32-bit words */
+    if (g.T > 32) return LZ77X_E_FORMAT;
+    uint32_t R = 0, cap = 0;
+    dec_range_plan(g, &R, &cap);
+    /* a stream whose size is known and lies inside one range is sized by what it holds: the range shrinks to the stream plus
+     * one token (reading then meets the end of the stream inside it) */
+    {
+        const size_t hint = src.size_hint();
+        if (hint && hint / (size_t)g.T + 2 < (size_t)R / 8) R = (uint32_t)((hint / (size_t)g.T + 2) * 8);
+    }
+    const size_t rbytes = (size_t)R / 8 * (size_t)g.T;                        /* R tokens are exactly this many bytes */
+    DevBuf *zb[2] = {&c.z, &c.z2};
+    DecCarry K;
+    bool have_k = false;
+    uint64_t total_out = 0, total_tok = 0, zn = 4;
+    size_t L = 0;                                                             /* bytes of zb[cur] already there (read past the last cut) */
+    int cur = 0;
+    bool eof = false;
+    uint32_t rounds = 0, range_idx = 0;
+    float k_ms = 0;
+    for (;;) {
+        DevBuf &zc = *zb[cur];
+        if ((rc = zc.need(4 + rbytes + 32))) return rc;
+        size_t avail = L;
+        if (!eof) {
+            const size_t want = rbytes - L;
+            got = 0;
+            if ((rc = src.read(c, zc.as<uint8_t>() + 4 + L, want, s, &got))) return rc;
+            if (got < want) eof = true;
+            avail += got;
+            zn += got;
+        }
+        DevBuf &zr = *zb[cur];
+        const uint64_t ntok64 = eof ? (uint64_t)avail * 8 / (uint64_t)g.T : (uint64_t)R;   /* lz77.c:271: short read = EOF */
+        if (ntok64 == 0) break;
+        uint32_t ntok = (uint32_t)ntok64;
+        HIPCHK(hipMemsetAsync(zr.as<uint8_t>() + 4 + avail, 0, 32, s));
+        HIPCHK(hipEventRecord(c.ev[0], s));
+        if ((rc = c.tokval.need(((size_t)ntok + 8) * 4))) return rc;
+        if ((rc = c.len1.need(((size_t)ntok + 8) * 4))) return rc;
+        if ((rc = c.dst.need(((size_t)ntok + 8) * 4))) return rc;
+        if ((rc = c.scantmp.need(lz77k_scan_tmp_bytes(ntok + 1)))) return rc;
+        HIPCHK(hipMemsetAsync(c.flag.as<uint32_t>() + 8, 0, 8, s));
+        HIPCHK(lz77k_dec_parse(zr.as<uint8_t>(), ntok, g, c.tokval.as<uint32_t>(), c.len1.as<uint32_t>(), s, c.flag.as<uint32_t>() + 8));
+        HIPCHK(hipMemsetAsync(c.len1.as<uint32_t>() + ntok, 0, 4, s));
+        HIPCHK(lz77k_scan_u32(c.len1.as<uint32_t>(), c.dst.as<uint32_t>(), ntok + 1, c.scantmp.p, s));     /* ntok << lb fits 32 bits (dec_range_plan) */
+        uint32_t *tot = reinterpret_cast<uint32_t *>(hdr + 16);
+        HIPCHK(hipMemcpyAsync(tot, c.dst.as<uint32_t>() + ntok, 4, hipMemcpyDeviceToHost, s));
+        HIPCHK(hipMemcpyAsync(tot + 1, c.flag.as<uint32_t>() + 8, 8, hipMemcpyDeviceToHost, s));
+        HIPCHK(hipStreamSynchronize(s));
+        uint32_t n = tot[0], use = ntok;
+        const bool stale = tot[1] != 0;             /* the range copies from distance 0 somewhere (power-of-two -s) */
+        /* distances beyond the window, or a lookahead field no CLI run can produce (main.c:103 caps -l at 255; a token
+         * may then span several tiles): the per-byte pointer path, which assumes nothing about either */
+        const bool general = tot[2] != 0 || la > 255;
+        if (n > cap) {
+            HIPCHK(lz77k_dec_cut(c.dst.as<uint32_t>(), ntok, cap, c.flag.as<uint32_t>() + 12, s));
+            HIPCHK(hipMemcpyAsync(tot + 4, c.flag.as<uint32_t>() + 12, 8, hipMemcpyDeviceToHost, s));
+            HIPCHK(hipStreamSynchronize(s));
+            use = tot[4];
+            n = tot[5];
+        }
+        const bool last = eof && use == ntok;
+        if (range_idx == 0 && !last) {
+            /* more than one range: the state they hand on.  Distance-0 copies are followed from the first range on when
+             * the window is a power of two (the only streams of the reference's encoder that hold them) or the first
+             * range holds one. */
+            K.cb = (uint32_t)sb;
+            if (g.ob && (1u << g.ob) - 1u > K.cb) K.cb = (1u << g.ob) - 1u;
+            K.W = 3u * (uint32_t)sb + (uint32_t)la;
+            K.track = (sb & (sb - 1)) == 0 || stale;
+            const uint32_t hist = K.cb + (K.track ? K.W - (uint32_t)sb : 0u);
+            K.pre = (hist + LZ77K_DEC_TILE_BYTES - 1u) / LZ77K_DEC_TILE_BYTES * LZ77K_DEC_TILE_BYTES;
+            const size_t img = (size_t)K.W - (size_t)sb;
+            if ((rc = c.dcarry.need(2 * ((size_t)K.cb + 256) + 2 * (img + 256)))) return rc;
+            uint8_t *b = c.dcarry.as<uint8_t>();
+            K.d_carry[0] = b;
+            K.d_carry[1] = b + K.cb + 256;
+            K.d_img[0] = b + 2 * ((size_t)K.cb + 256);
+            K.d_img[1] = K.d_img[0] + img + 256;
+            HIPCHK(hipMemsetAsync(b, 0, 2 * ((size_t)K.cb + 256) + 2 * (img + 256), s));
+            have_k = true;
+        }
+        if (have_k && stale && !K.track) {
+            /* the reference reads a byte of its staging buffer whose history this decoder did not follow */
+            snprintf(g_err, sizeof g_err, "a distance-0 copy appears %llu tokens into a stream whose window is not a power of two",
+                     (unsigned long long)total_tok);
+            return LZ77X_E_FORMAT;
+        }
+        if (sink && !sink->overflowed() && n) {
+            uint8_t *d_bytes = nullptr;
+            if ((rc = decode_resolve(c, g, use, n, s, stale, general, have_k ? &K : nullptr, &d_bytes, &rounds))) return rc;
+            HIPCHK(hipEventRecord(c.ev[1], s));
+            if ((rc = sink->write(c, d_bytes, n, s))) return rc;
+        } else {
+            HIPCHK(hipEventRecord(c.ev[1], s));
+            if (sink) sink->total += n;
+        }
+        HIPCHK(hipStreamSynchronize(s));
+        float ms = 0;
+        HIPCHK(hipEventElapsedTime(&ms, c.ev[0], c.ev[1]));
+        k_ms += ms;
+        total_out += n;
+        total_tok += use;
+        range_idx += 1;
+        if (last) break;
+        const size_t used = (size_t)use / 8 * (size_t)g.T;                     /* use is a multiple of eight here */
+        L = avail - used;
+        if (L) {
+            DevBuf &zo = *zb[cur ^ 1];
+            if ((rc = zo.need(4 + rbytes + 32))) return rc;
+            HIPCHK(hipMemcpyAsync(zo.as<uint8_t>() + 4, zr.as<uint8_t>() + 4 + used, L, hipMemcpyDeviceToDevice, s));
+        }
+        cur ^= L ? 1 : 0;
+    }
+    *n_out = total_out;
+    g_stats.k_decode_ms = k_ms;
+    g_stats.n = total_out;
+    g_stats.zn = zn;
+    g_stats.ntok = total_tok;
+    g_stats.decode_rounds = rounds;
+    g_stats.match_launches = range_idx;          /* ranges the stream was decoded in */
+    g_stats.total_ms = now_ms() - t_begin;
+    g_stats.copy_ms = g_stats.total_ms - g_stats.k_decode_ms;
+    return LZ77X_OK;
+}
 
 /* What one segment hands to the next (host side): where the parse chain continues, how many tokens are
  * out, the last tokens (a stream word can straddle the boundary), and the priorities of the sb cells that are
@@ -2346,15 +2509,13 @@ int lz77x_decode(const uint8_t *z, size_t zn, uint8_t **out, size_t *out_n)
     }
     if ((rc = primary_context(*lease.set))) return rc;
     if (zn < 4) return LZ77X_E_FORMAT;
-    if ((rc = load_stream(g_ctx, z, false, zn, g_ctx.stream))) return rc;
-    size_t n = 0;
-    if ((rc = decode_core(g_ctx, zn, g_ctx.stream, true, &n))) return rc;
-    uint8_t *buf = (uint8_t *)malloc(n ? n : 1);
-    if (!buf) return LZ77X_E_NOMEM;
-    if ((rc = fetch_result(g_ctx, buf, g_ctx.out.p, n))) { free(buf); return rc; }
-    *out = buf;
-    *out_n = n;
-    return LZ77X_OK;
+    MemSource src(z, zn, false);
+    HostSink sink;
+    uint64_t n = 0;
+    if ((rc = decode_stream(g_ctx, src, &sink, g_ctx.stream, &n))) return rc;
+    *out_n = sink.total;
+    *out = sink.release();
+    return *out ? LZ77X_OK : LZ77X_E_NOMEM;
 }
 
 int lz77x_decode_device(const void *d_z, size_t zn, void *d_out, size_t out_cap, size_t *out_n, void *stream)
@@ -2367,15 +2528,18 @@ int lz77x_decode_device(const void *d_z, size_t zn, void *d_out, size_t out_cap,
     if ((rc = primary_context(*lease.set))) return rc;
     if (zn < 4) return LZ77X_E_FORMAT;
     hipStream_t s = (hipStream_t)stream;
-    if ((rc = load_stream(g_ctx, d_z, true, zn, s))) return rc;
-    size_t n = 0;
-    if (!d_out) return decode_core(g_ctx, zn, s, false, out_n);
-    if ((rc = decode_core(g_ctx, zn, s, true, &n))) return rc;
-    *out_n = n;
-    if (n > out_cap) return LZ77X_E_CAP;
-    if (n) HIPCHK(hipMemcpyAsync(d_out, g_ctx.out.p, n, hipMemcpyDeviceToDevice, s));
+    MemSource src(d_z, zn, true);
+    uint64_t n = 0;
+    if (!d_out) {
+        if ((rc = decode_stream(g_ctx, src, nullptr, s, &n))) return rc;
+        *out_n = (size_t)n;
+        return LZ77X_OK;
+    }
+    DeviceSink sink(d_out, out_cap);
+    if ((rc = decode_stream(g_ctx, src, &sink, s, &n))) return rc;
+    *out_n = (size_t)n;
     HIPCHK(hipStreamSynchronize(s));
-    return LZ77X_OK;
+    return n > out_cap ? LZ77X_E_CAP : LZ77X_OK;
 }
 
 /* lz77.h:14 encode(file, out, la, sb) as called at main.c:150 */
@@ -2431,14 +2595,11 @@ int lz77x_decode_file(FILE *in, FILE *out)
     (void)g_ctx;
     int rc;
     if ((rc = primary_context(*lease.set))) return rc;
-    Ctx &c = g_ctx;
-    size_t zn = 0;
-    if ((rc = stream_in(c, in, c.z, 32, &zn))) return rc;
-    if (zn < 4) return LZ77X_E_FORMAT;
-    HIPCHK(hipMemsetAsync(c.z.as<uint8_t>() + zn, 0, 32, c.stream));
-    size_t n = 0;
-    if ((rc = decode_core(c, zn, c.stream, true, &n))) return rc;
-    return stream_out(c, out, c.out.p, n);
+    /* any size, any kind of file: range by range through bounded device memory (lz77.c:160-195) */
+    FileSource src(in);
+    FileSink sink(out);
+    uint64_t n = 0;
+    return decode_stream(g_ctx, src, &sink, g_ctx.stream, &n);
 }
 
 void lz77x_free(void *p) { free(p); }

@@ -78,6 +78,20 @@ def _run_huge(r):
                     break
                 h.update(b)
         assert h.hexdigest() == r["sha256_lz"], "stream differs from the reference's"
+        # ... and back: lz77.c:160-195 decodes any length; the product's -d takes the stream range by range through
+        # bounded device memory (the output replaces the input file: /dev/shm holds one copy of each)
+        os.remove(fin)
+        L.decode_path(fout, fin)
+        dst = L.last_stats()
+        assert dst["n"] == n and dst["zn"] == r["zn"] and dst["ntok"] == r["ntok"] and dst["match_launches"] >= 2
+        h = hashlib.sha256()
+        with open(fin, "rb") as f:
+            while True:
+                b = f.read(1 << 26)
+                if not b:
+                    break
+                h.update(b)
+        assert h.hexdigest() == r["sha256_in"], "the decoded bytes differ from the input"
     return stats
 
 

@@ -602,16 +602,42 @@ def test_concurrent_calls_from_threads():
         assert back[i] == inputs[i].tobytes(), i
 
 
-def test_decode_refuses_streams_that_expand_past_4gib():
-    """hostile stream: 17 M maximal copy tokens (60 MB) would decode to 4.3 GB; the size is summed in
-    64 bits on the device before any 32-bit offset is trusted, and the call fails with LZ77X_E_TOOBIG"""
+def test_decode_streams_that_expand_past_4gib(tmp_path):
+    """17 M maximal copy tokens (60 MB) decode to 4.3 GB: more than 32-bit offsets hold.  The reference decodes any
+    length through its 3*SB+LA buffer (lz77.c:160-195); here the stream runs range by range, offsets inside a range are
+    32-bit and the counts across ranges 64-bit.  The size query needs no output buffer; the FILE* entry point writes the
+    4.3 GB (zeros: every copy reaches back to before the first byte) through bounded device memory"""
+    import torch
     v = 1 | (254 << 12)                                     # off=1, len=254, next=0 at s=4095 l=255 (T=28)
     pair = (v | (v << 28)).to_bytes(7, "little")
     z = bytes([0xFF, 0x0F, 0xFF, 0x00]) + pair * 8_500_000
-    with pytest.raises(L.Lz77Error) as e:
-        L.decode(z)
-    assert e.value.code == -8
-    assert L.decode(z[:4 + 7 * 1000]) == bytes(2000 * 255)   # the same tokens in a sane quantity decode (to zeros)
+    want_n = 17_000_000 * 255
+    d_z = torch.from_numpy(np.frombuffer(z, dtype=np.uint8).copy()).cuda()
+    assert L.decoded_size_device(d_z.data_ptr(), len(z)) == want_n
+    small = torch.empty(1000, dtype=torch.uint8, device="cuda")
+    n = ctypes.c_size_t(0)
+    rc = L.lib().lz77x_decode_device(d_z.data_ptr(), len(z), small.data_ptr(), 1000, ctypes.byref(n), None)
+    assert rc == -6 and n.value == want_n                   # LZ77X_E_CAP with the size needed
+    del d_z
+    d = "/dev/shm" if os.path.isdir("/dev/shm") else str(tmp_path)
+    lz, out = os.path.join(d, "lz77x_big.lz"), os.path.join(d, "lz77x_big.out")
+    try:
+        open(lz, "wb").write(z)
+        L.decode_path(lz, out)
+        st = L.last_stats()
+        assert st["n"] == want_n and st["match_launches"] >= 2
+        assert os.path.getsize(out) == want_n
+        with open(out, "rb") as f:
+            while True:
+                b = f.read(1 << 26)
+                if not b:
+                    break
+                assert b.count(0) == len(b)
+    finally:
+        for q in (lz, out):
+            if os.path.exists(q):
+                os.remove(q)
+    assert L.decode(z[:4 + 7 * 1000]) == bytes(2000 * 255)   # the same tokens in a sane quantity
 
 
 def test_cli_streams_large_files_and_pipes(tmp_path):
