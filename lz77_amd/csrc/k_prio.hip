@@ -64,7 +64,7 @@ __device__ __forceinline__ uint64_t readlane64(uint64_t v, int l)
  * writes cell c), kept with atomicMax: every round of every group has a version of its own, so stale tags are simply
  * older and nothing is ever reset (a round is two wavefront barriers instead of three and no clearing stores). */
 __global__ __launch_bounds__(256) void k_prio_prep(const uint32_t *__restrict__ ps, uint32_t nx, uint32_t tagn,
-                                                   uint64_t *__restrict__ rmask, uint64_t *__restrict__ gate0)
+                                                   uint64_t *__restrict__ rmask, uint64_t *__restrict__ gate0, uint64_t *__restrict__ cmask)
 {
     extern __shared__ uint32_t prep_tags[];
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
@@ -79,28 +79,38 @@ __global__ __launch_bounds__(256) void k_prio_prep(const uint32_t *__restrict__ 
         const uint32_t p = v & 0xFFFFu, s = v >> 16;
         const bool has = p && s;
         const uint32_t cp = lane + p, cs = lane + s;
-        uint64_t mask = 1;
+        uint64_t mask = 1, chain = 0;
         uint32_t start = 0;
         for (;;) {
             if (has && lane >= start) atomicMax(&tag[cs], (ver << 6) | (63u - lane));
             wave_sync();
-            uint32_t blocked = 0;
+            uint32_t blocked = 0, linked = 0;
             if (has && lane > start) {
                 const uint32_t t0 = tag[lane], t1 = tag[cp], t2 = tag[cs];
-                const uint32_t b0 = (t0 >> 6) == ver && 63u - (t0 & 63u) < lane;
+                const uint32_t w0 = 63u - (t0 & 63u);
+                /* the step before this one hands its priority to THIS cell (S[x-1] = x: runs of equal bytes, periods):
+                 * not a new round -- the sweep resolves such chains with a scan (k_prio_fwd).  One writer per cell and round:
+                 * a second one would read the first one's successor cell and start a round of its own (b2). */
+                const uint32_t own = (t0 >> 6) == ver && w0 < lane;
+                linked = own && w0 + 1u == lane;
+                const uint32_t b0 = own && !linked;
                 const uint32_t b1 = (t1 >> 6) == ver && 63u - (t1 & 63u) < lane;
                 const uint32_t b2 = (t2 >> 6) == ver && 63u - (t2 & 63u) < lane;
                 blocked = b0 | b1 | b2;
             }
             wave_sync();
             ver++;
-            const uint64_t bm = __ballot(blocked != 0u);
+            const uint64_t bm = __ballot(blocked != 0u), lm = __ballot(linked != 0u);
+            const uint32_t end = bm ? (uint32_t)__builtin_ctzll(bm) : 64u;
+            /* the lanes [start, end) are a round; what they saw of each other is final */
+            chain |= lm & ((end < 64u ? (1ull << end) : 0ull) - (1ull << start));
             if (!bm) break;
-            start = (uint32_t)__builtin_ctzll(bm);
+            start = end;
             mask |= 1ull << start;
         }
         const uint64_t hm = __ballot(has);
-        if (lane == 0) { rmask[g] = mask; gate0[g] = hm; }
+        /* (bit 0 of a round mask says nothing -- lane 0 always opens a round: cleared, it flags a group with chains) */
+        if (lane == 0) { rmask[g] = chain ? mask & ~1ull : mask; gate0[g] = hm; cmask[g] = chain; }
     }
 }
 
@@ -112,6 +122,50 @@ __global__ void k_prio_in0(uint32_t *__restrict__ in0, uint32_t sb, uint32_t vof
     if (i < sb) in0[i] = carried ? carried[i] : i + voff;
 }
 
+/* ---- chains inside a round --------------------------------------------------------------------------------
+ * Where the eviction of x hands its priority to x + 1 (S[x] = x + 1: runs of equal bytes at least a lookahead long,
+ * periodic data), step x + 1 reads the cell step x has just written, and a group of 64 such steps took 64 rounds (the
+ * "run cliff": low-entropy data swept 8x slower than text).  But along such a chain the step is a map on ONE value:
+ * with w = the predecessor cell and c = the successor cell as they were before the round (nobody else in the round
+ * writes them), the cell x + 1 holds after step x
+ *     f(a) = a < min(w, c) ? a : c          (tree.c:202-231: the successor takes x's place only below both children)
+ * and threshold maps (t, c), c >= t, are closed under composition:
+ *     (t2, c2) o (t1, c1) = (min(t1, t2),  t2 < t1 ? c2 : c1 < t2 ? c1 : c2)
+ * so a round resolves its chains with an inclusive scan over the lanes (DPP row shifts + two row broadcasts) instead
+ * of one round per link.  A lane whose own cell nobody of the round writes enters the scan as a CONSTANT map
+ * (threshold 0): whatever lies to its left is cut off, no segment flags needed. */
+struct prio_tc { uint32_t t, c; };
+
+__device__ __forceinline__ prio_tc prio_tc_then(prio_tc first, prio_tc second)
+{
+    prio_tc r;
+    r.t = min(first.t, second.t);
+    r.c = second.t < first.t ? second.c : (first.c < second.t ? first.c : second.c);
+    return r;
+}
+
+template <int CTRL, int ROWS>
+__device__ __forceinline__ prio_tc prio_tc_dpp(prio_tc v)
+{
+    /* lanes without a source (or outside the row mask) get the identity (t = 2^32 - 1 passes every priority) */
+    prio_tc e;
+    e.t = (uint32_t)__builtin_amdgcn_update_dpp((int)0xFFFFFFFFu, (int)v.t, CTRL, ROWS, 0xF, false);
+    e.c = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v.c, CTRL, ROWS, 0xF, false);
+    return e;
+}
+
+/* inclusive scan over the 64 lanes: lane i <- v[i] o v[i-1] o ... o v[0] */
+__device__ __forceinline__ prio_tc prio_tc_scan(prio_tc v)
+{
+    v = prio_tc_then(prio_tc_dpp<0x111, 0xF>(v), v);          /* row_shr:1 */
+    v = prio_tc_then(prio_tc_dpp<0x112, 0xF>(v), v);          /* row_shr:2 */
+    v = prio_tc_then(prio_tc_dpp<0x114, 0xF>(v), v);          /* row_shr:4 */
+    v = prio_tc_then(prio_tc_dpp<0x118, 0xF>(v), v);          /* row_shr:8 */
+    v = prio_tc_then(prio_tc_dpp<0x142, 0xA>(v), v);          /* row_bcast:15 into rows 1 and 3 */
+    v = prio_tc_then(prio_tc_dpp<0x143, 0xC>(v), v);          /* row_bcast:31 into rows 2 and 3 */
+    return v;
+}
+
 /* ------------------------------------------------------------------ forward sweep ---- */
 
 /* Block b = steps [b*B, min((b+1)*B, nx)).  in[b][i] = value of cell b*B+i before the block's first
@@ -121,6 +175,7 @@ __global__ void k_prio_in0(uint32_t *__restrict__ in0, uint32_t sb, uint32_t vof
 template <bool STORE>
 __global__ __launch_bounds__(64) void k_prio_fwd(const uint32_t *__restrict__ ps, uint32_t nx, uint32_t sb, uint32_t B,
                                                  uint32_t ring_n, uint32_t b_first, const uint64_t *__restrict__ rmask,
+                                                 const uint64_t *__restrict__ cmask /* lanes whose own cell the lane before them writes in their round */,
                                                  const uint64_t *__restrict__ gold, uint64_t *__restrict__ gnew,
                                                  const uint32_t *__restrict__ in, uint32_t *__restrict__ xval,
                                                  uint32_t *__restrict__ summary /* [0] += flips, [1] = min block with a flip */,
@@ -149,11 +204,11 @@ __global__ __launch_bounds__(64) void k_prio_fwd(const uint32_t *__restrict__ ps
     uint32_t off = 0;                                  /* ring slot of cell xg */
     uint32_t nflip = 0;
     uint32_t v[PRIO_SG], vn[PRIO_SG];
-    uint64_t rm_l = 0, go_l = 0, rm_n = 0, go_n = 0;
+    uint64_t rm_l = 0, go_l = 0, rm_n = 0, go_n = 0, cm_l = 0, cm_n = 0;
     /* every load is unconditional (clamped address, value masked afterwards): a load under a branch makes
      * the compiler wait for ALL outstanding loads at the first use, and the prefetch would overlap nothing */
     const uint32_t xlast = x1 - 1u;
-    auto fetch = [&](uint32_t xs, uint32_t (&vv)[PRIO_SG], uint64_t &rml, uint64_t &gol) {
+    auto fetch = [&](uint32_t xs, uint32_t (&vv)[PRIO_SG], uint64_t &rml, uint64_t &gol, uint64_t &cml) {
 #pragma unroll
         for (uint32_t k = 0; k < PRIO_SG; k++) {
             const uint32_t x = xs + 64u * k + lane;
@@ -163,10 +218,11 @@ __global__ __launch_bounds__(64) void k_prio_fwd(const uint32_t *__restrict__ ps
         const uint32_t xq = min(xs + 64u * (lane & (PRIO_SG - 1u)), xlast);
         rml = rmask[xq >> 6];
         gol = gold[xq >> 6];
+        cml = cmask[xq >> 6];
     };
-    fetch(x0, v, rm_l, go_l);
+    fetch(x0, v, rm_l, go_l, cm_l);
     for (uint32_t xs = x0; xs < x1; xs += 64u * PRIO_SG) {
-        fetch(xs + 64u * PRIO_SG, vn, rm_n, go_n);     /* next super-group in flight while this one runs */
+        fetch(xs + 64u * PRIO_SG, vn, rm_n, go_n, cm_n);     /* next super-group in flight while this one runs */
         uint64_t gn_l = 0;
 #pragma unroll
         for (uint32_t k = 0; k < PRIO_SG; k++) {
@@ -185,20 +241,52 @@ __global__ __launch_bounds__(64) void k_prio_fwd(const uint32_t *__restrict__ ps
                 uint32_t ng = 0;                                      /* a VGPR flag, not a bool: as a lane mask the compiler merges it
                                                                          through three levels of exec masks, 20 scalar instructions a round */
                 uint32_t out = PRIO_NONE;
-                uint64_t r = rm;
-                do {
-                    const uint32_t start = (uint32_t)__builtin_ctzll(r);
-                    r &= r - 1;
-                    const uint32_t end = r ? (uint32_t)__builtin_ctzll(r) : 64u;
-                    if (has && lane >= start && lane < end) {
-                        /* the three reads leave together (one LDS round trip per round, not two: no short circuit) */
-                        const uint32_t a = ring[ix], w = ring[ip], sv = ring[is];
-                        const bool gate = a < w, lower = a < sv;
-                        ng = gate ? 1u : 0u;                          /* the gate: x's predecessor hangs below x */
-                        if (gate & lower) { ring[is] = a; out = a; }  /* tree.c:202-231: S takes x's place */
-                    }
-                    wave_sync();
-                } while (r);
+                uint64_t r = rm | 1ull;
+                if (__builtin_expect((rm & 1ull) != 0ull, 1)) {
+                    /* no chain in the group (wave-uniform): rounds of independent steps */
+                    do {
+                        const uint32_t start = (uint32_t)__builtin_ctzll(r);
+                        r &= r - 1;
+                        const uint32_t end = r ? (uint32_t)__builtin_ctzll(r) : 64u;
+                        if (has && lane >= start && lane < end) {
+                            /* the three reads leave together (one LDS round trip per round, not two: no short circuit) */
+                            const uint32_t a = ring[ix], w = ring[ip], sv = ring[is];
+                            const bool gate = a < w, lower = a < sv;
+                            ng = gate ? 1u : 0u;                          /* the gate: x's predecessor hangs below x */
+                            if (gate & lower) { ring[is] = a; out = a; }  /* tree.c:202-231: S takes x's place */
+                        }
+                        wave_sync();
+                    } while (r);
+                } else {
+                    /* some rounds hold chains: every lane takes part in their scans */
+                    const uint64_t cm = readlane64(cm_l, (int)k);
+                    do {
+                        const uint32_t start = (uint32_t)__builtin_ctzll(r);
+                        r &= r - 1;
+                        const uint32_t end = r ? (uint32_t)__builtin_ctzll(r) : 64u;
+                        const bool on = has && lane >= start && lane < end;
+                        const bool linked = on && ((cm >> lane) & 1ull);
+                        uint32_t a = 0, w = 0, sv = 0;
+                        if (on) { a = ring[ix]; w = ring[ip]; sv = ring[is]; }
+                        if (cm & ((end < 64u ? (1ull << end) : 0ull) - (1ull << start))) {
+                            prio_tc f;
+                            f.t = min(w, sv);
+                            f.c = sv;
+                            if (!linked) { f.c = a < f.t ? a : f.c; f.t = 0u; }     /* its own cell is what the ring holds: a constant */
+                            if (!on) { f.t = 0u; f.c = 0u; }
+                            f = prio_tc_scan(f);
+                            /* lane i now holds the cell its step leaves behind; a linked lane starts from its left neighbour's */
+                            const uint32_t left = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)f.c, 0x138 /* wave_shr:1 */, 0xF, 0xF, false);
+                            if (linked) a = left;
+                        }
+                        if (on) {
+                            const bool gate = a < w, lower = a < sv;
+                            ng = gate ? 1u : 0u;
+                            if (gate & lower) { ring[is] = a; out = a; }
+                        }
+                        wave_sync();
+                    } while (r);
+                }
                 const uint64_t gnb = __ballot(ng != 0u);
                 nflip += (uint32_t)__popcll(gnb ^ go);
                 if (lane == k) gn_l = gnb;
@@ -219,6 +307,7 @@ __global__ __launch_bounds__(64) void k_prio_fwd(const uint32_t *__restrict__ ps
         for (uint32_t k = 0; k < PRIO_SG; k++) v[k] = vn[k];
         rm_l = rm_n;
         go_l = go_n;
+        cm_l = cm_n;
     }
     wave_sync();
     if (out_state && x1 == nx) {
@@ -674,6 +763,7 @@ static void prio_layout(lz77k_prio_plan &P)
     P.o_gate[0] = take((size_t)P.ngroups * 8 + 64);
     P.o_gate[1] = take((size_t)P.ngroups * 8 + 64);
     P.o_rmask = take((size_t)P.ngroups * 8 + 64);
+    P.o_cmask = take((size_t)P.ngroups * 8 + 64);
     P.o_dest = take(((size_t)P.NB + 1) * rs * 2);
     P.o_loc = take(((size_t)P.NB + 1) * rs * 4);
     P.o_in = take(((size_t)P.NB + 2) * rs * 4);
@@ -735,7 +825,8 @@ hipError_t lz77k_prio_begin(lz77k_prio_plan &P, const uint32_t *d_ps, uint32_t n
             (e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_prio_prep), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)) != hipSuccess)
             return e;
         const uint32_t blocks = min((P.ngroups + 3u) / 4u, 256u * 8u);
-        hipLaunchKernelGGL(k_prio_prep, dim3(blocks), dim3(256), lds, s, d_ps, nx, tagn, PRIO_PTR(uint64_t, P.o_rmask), PRIO_PTR(uint64_t, P.o_gate[0]));
+        hipLaunchKernelGGL(k_prio_prep, dim3(blocks), dim3(256), lds, s, d_ps, nx, tagn, PRIO_PTR(uint64_t, P.o_rmask), PRIO_PTR(uint64_t, P.o_gate[0]),
+                           PRIO_PTR(uint64_t, P.o_cmask));
     }
     hipLaunchKernelGGL(k_prio_in0, dim3((P.sb + 255u) / 256u), dim3(256), 0, s, PRIO_PTR(uint32_t, P.o_in), P.sb, voff, d_carried);
     /* every block's map has to be built and every block swept once */
@@ -880,7 +971,7 @@ hipError_t lz77k_prio_sweep(lz77k_prio_plan &P, hipStream_t s, uint32_t *h_flag,
             return e;
     } else
     hipLaunchKernelGGL(k_prio_fwd<true>, dim3(nb), dim3(64), lds_fwd, s, P.ps, P.nx, sb, P.B, P.ring_n, first, PRIO_PTR(uint64_t, P.o_rmask),
-                       PRIO_PTR(uint64_t, P.o_gate[P.cur]), PRIO_PTR(uint64_t, P.o_gate[P.cur ^ 1]), in, P.xval, summary, P.voff, d_out_state,
+                       PRIO_PTR(uint64_t, P.o_cmask), PRIO_PTR(uint64_t, P.o_gate[P.cur]), PRIO_PTR(uint64_t, P.o_gate[P.cur ^ 1]), in, P.xval, summary, P.voff, d_out_state,
                        gates_changed, (const uint32_t *)in_changed);
     if (ev3 && (e = hipEventRecord(ev3[2], s)) != hipSuccess) return e;
     return hipMemcpyAsync(h_flag, summary, 8, hipMemcpyDeviceToHost, s);

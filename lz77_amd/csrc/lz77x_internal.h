@@ -146,7 +146,7 @@ struct lz77k_prio_plan {
     uint32_t rs = 0;          /* cells between the rows of the per-block arrays (dest, loc, in, ...): sb, or sb rounded up to 8 for windows above 4096 */
     uint32_t W = 64;          /* steps a sweep takes together: 64 = one wavefront per block (k_prio.hip), 256 / 1024 = a workgroup (k_priow.hip) */
     bool pack18 = false;      /* W > 64: the ring holds 18-bit codes (rank of an old value | block-local position), not priorities */
-    size_t o_gate[2] = {0, 0}, o_rmask = 0, o_dest = 0, o_loc = 0, o_in = 0, o_gdest = 0, o_gloc = 0, o_gin = 0, o_sum = 0, o_dirty = 0, total = 0;
+    size_t o_gate[2] = {0, 0}, o_rmask = 0, o_cmask = 0, o_dest = 0, o_loc = 0, o_in = 0, o_gdest = 0, o_gloc = 0, o_gin = 0, o_sum = 0, o_dirty = 0, total = 0;
     size_t o_g2dest = 0, o_g2loc = 0, o_g2in = 0;                  /* sb <= 4096: the groups of groups of the boundary scan */
     size_t o_codes = 0, o_gval = 0, o_scan = 0, o_inprev = 0;      /* pack18: per-block rows entry cell -> code, rank -> value; sb > 4096: the HBM scan's running pairs */
     int cur = 0;              /* gate buffer the next maps/sweep read */

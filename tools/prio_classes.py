@@ -37,11 +37,12 @@ def run(kind, n, sb=4095, la=15, seed=synth.SEED_S1):
 
 out = []
 n = int(os.environ.get("N", 100_000_000))
-for kind in ("text", "mixed", "lowent", "records", "code", "zeros", "random"):
+for kind in os.environ.get("KINDS", "text,mixed,lowent,records,code,zeros,random").split(","):
     out.append(run(kind, n))
     print(out[-1], file=sys.stderr, flush=True)
-out.append(run("mixed", 4 << 20))
-out[-1]["note"] = "the 4 MiB case of gpurun_out/prio1.log (early round 2: 106 iterations, 141.7 ms)"
+if "KINDS" not in os.environ:
+    out.append(run("mixed", 4 << 20))
+    out[-1]["note"] = "the 4 MiB case of gpurun_out/prio1.log (early round 2: 106 iterations, 141.7 ms)"
 text_per_byte = out[0]["k_prio_ms"] / out[0]["bytes"]
 for r in out:
     r["k_prio_vs_text_per_byte"] = round(r["k_prio_ms"] / r["bytes"] / text_per_byte, 2) if text_per_byte else None
