@@ -58,10 +58,24 @@ bool trace_on()
     do { if (trace_on()) fprintf(stderr, "[lz77x] %-28s %8.2f ms\n", label, now_ms() - (t0)); } while (0)
 
 double now_ms();
+void trace_allocs(const char *what);
 double now_ms()
 {
     using namespace std::chrono;
     return duration<double, std::milli>(steady_clock::now().time_since_epoch()).count();
+}
+
+/* LZ77X_TRACE: where a call's wall time goes besides kernels and copies (per thread, reset by the entry points) */
+thread_local double g_alloc_ms = 0, g_pin_ms = 0;
+thread_local size_t g_alloc_bytes = 0, g_pin_bytes = 0;
+
+void trace_allocs(const char *what)
+{
+    if (!trace_on()) return;
+    fprintf(stderr, "[lz77x] %-28s hipMalloc %.2f ms (%.1f MB), pinned host %.2f ms (%.1f MB)\n", what, g_alloc_ms, g_alloc_bytes / 1e6, g_pin_ms,
+            g_pin_bytes / 1e6);
+    g_alloc_ms = g_pin_ms = 0;
+    g_alloc_bytes = g_pin_bytes = 0;
 }
 
 struct DevBuf {
@@ -70,10 +84,12 @@ struct DevBuf {
     int need(size_t bytes)
     {
         if (bytes <= cap) return LZ77X_OK;
+        const double t0 = trace_on() ? now_ms() : 0;
         if (p) { hipError_t e0 = hipFree(p); (void)e0; p = nullptr; cap = 0; }
         size_t want = bytes + bytes / 8 + 4096;
         HIPCHK(hipMalloc(&p, want));
         cap = want;
+        if (trace_on()) { g_alloc_ms += now_ms() - t0; g_alloc_bytes += want; }
         return LZ77X_OK;
     }
     template <class T> T *as() const { return reinterpret_cast<T *>(p); }
@@ -98,6 +114,12 @@ struct PinBuf {
     int need(size_t bytes)
     {
         if (bytes <= cap) return LZ77X_OK;
+        struct Timer {
+            double t0 = trace_on() ? now_ms() : 0;
+            size_t bytes;
+            explicit Timer(size_t b) : bytes(b) {}
+            ~Timer() { if (trace_on()) { g_pin_ms += now_ms() - t0; g_pin_bytes += bytes; } }
+        } timer(bytes);
         release();
         size_t want = bytes + bytes / 8 + 4096;
         const char *hp = getenv("LZ77X_HUGEPAGES");
@@ -233,7 +255,9 @@ int ctx_init(Ctx &c, int device = -1)
 {
     if (c.ready) return LZ77X_OK;
     int nd = 0;
+    const double t_rt = now_ms();
     hipError_t e = hipGetDeviceCount(&nd);
+    TRACE("  hipGetDeviceCount (runtime init)", t_rt);
     if (e != hipSuccess || nd <= 0) {
         snprintf(g_err, sizeof g_err, "no HIP device (%s)", e == hipSuccess ? "count 0" : hipGetErrorString(e));
         return LZ77X_E_NODEV;
@@ -241,14 +265,26 @@ int ctx_init(Ctx &c, int device = -1)
     c.ndev = nd;
     if (device < 0) HIPCHK(hipGetDevice(&device));
     c.device = device;
+    const double t_dev = now_ms();
     HIPCHK(hipSetDevice(device));
     HIPCHK(hipStreamCreateWithFlags(&c.stream, hipStreamNonBlocking));
-    HIPCHK(hipStreamCreateWithFlags(&c.copy, hipStreamNonBlocking));
-    HIPCHK(hipStreamCreateWithFlags(&c.up, hipStreamNonBlocking));
-    HIPCHK(hipStreamCreateWithFlags(&c.tok, hipStreamNonBlocking));
+    TRACE("  hipSetDevice + first stream", t_dev);
+    /* (copy / up / tok: created by the paths that use them, need_stream -- a stream costs ~8 ms of a short-lived process) */
     for (auto &ev : c.ev) HIPCHK(hipEventCreate(&ev));
     for (auto &ev : c.pipe_ev) HIPCHK(hipEventCreate(&ev));
     c.ready = true;
+    return LZ77X_OK;
+}
+
+/* the context's auxiliary streams exist from their first use on */
+int need_stream(Ctx &c, hipStream_t Ctx::*m)
+{
+    if (c.*m) return LZ77X_OK;
+    int cur = -1;
+    HIPCHK(hipGetDevice(&cur));
+    if (cur != c.device) HIPCHK(hipSetDevice(c.device));
+    HIPCHK(hipStreamCreateWithFlags(&(c.*m), hipStreamNonBlocking));
+    if (cur != c.device) HIPCHK(hipSetDevice(cur));
     return LZ77X_OK;
 }
 
@@ -329,6 +365,9 @@ int encode_core_host(std::vector<Ctx *> &cs, const void *src, bool src_on_device
     const double t_begin = now_ms();
     memset(&g_stats, 0, sizeof g_stats);
     if (n > LZ77X_MAX_N) return LZ77X_E_TOOBIG;
+    for (Ctx *cc : cs)
+        for (hipStream_t Ctx::*m : {&Ctx::copy, &Ctx::up, &Ctx::tok})
+            if (int r = need_stream(*cc, m)) return r;
     Ctx &c0 = *cs[0];
     const uint32_t D = (uint32_t)cs.size();
     if (D > 1 && src_on_device) return LZ77X_E_ARG;
@@ -963,6 +1002,7 @@ int fetch_result(Ctx &c, uint8_t *dst, const void *d_src, size_t bytes)
 {
     const size_t piece = (size_t)16 << 20;
     int rc;
+    if ((rc = need_stream(c, &Ctx::copy))) return rc;
     if ((rc = c.h_stage.need(2 * piece))) return rc;
     uint8_t *slot[2] = {c.h_stage.as<uint8_t>(), c.h_stage.as<uint8_t>() + piece};
     const uint8_t *src = reinterpret_cast<const uint8_t *>(d_src);
@@ -998,6 +1038,7 @@ int stream_in(Ctx &c, FILE *f, DevBuf &dst, size_t slack, size_t *n_out)
 {
     const size_t piece = (size_t)16 << 20;
     int rc;
+    if ((rc = need_stream(c, &Ctx::up))) return rc;
     if ((rc = c.h_stage.need(2 * piece))) return rc;
     uint8_t *slot[2] = {c.h_stage.as<uint8_t>(), c.h_stage.as<uint8_t>() + piece};
     size_t hint = 0;
@@ -1044,6 +1085,7 @@ int stream_out(Ctx &c, FILE *f, const void *d_src, size_t bytes)
 {
     const size_t piece = (size_t)16 << 20;
     int rc;
+    if ((rc = need_stream(c, &Ctx::copy))) return rc;
     if ((rc = c.h_stage.need(2 * piece))) return rc;
     uint8_t *slot[2] = {c.h_stage.as<uint8_t>(), c.h_stage.as<uint8_t>() + piece};
     const uint8_t *src = reinterpret_cast<const uint8_t *>(d_src);
@@ -1126,6 +1168,7 @@ struct FileSource : Source {
         /* fread of piece k+1 overlaps the DMA of piece k (two pinned staging slots) */
         const size_t piece = (size_t)16 << 20;
         int rc;
+        if ((rc = need_stream(c, &Ctx::up))) return rc;
         if ((rc = c.h_stage.need(2 * piece))) return rc;
         uint8_t *slot[2] = {c.h_stage.as<uint8_t>(), c.h_stage.as<uint8_t>() + piece};
         HIPCHK(hipStreamSynchronize(s));                       /* d_dst may still be read by the previous segment's kernels */
@@ -1687,6 +1730,7 @@ int seg_mid(SegJob &J, const lz77x_geom &g, SegCarry &carry, bool allow_fallback
          *    LZ77X_CHAIN_STREAM=1 runs it on a stream of its own beside the recurrence -- */
         const uint32_t *d_tbase = nullptr, *d_exit = nullptr;
         uint32_t nsub = 0;
+        if (LZ77X_VENV("LZ77X_CHAIN_STREAM") && (rc = need_stream(c, &Ctx::tok))) return rc;
         hipStream_t sc = LZ77X_VENV("LZ77X_CHAIN_STREAM") ? c.tok : s;   /* measured: beside the recurrence it costs the recurrence more (6.0 -> 6.5 ms) than it hides (0.4) */
         if (sc != s) HIPCHK(hipStreamWaitEvent(sc, c.ev[1], 0));               /* the match stage is through */
         HIPCHK(hipEventRecord(c.match_ev[0], sc));
@@ -1936,11 +1980,7 @@ int encode_stream_device(Ctx &c, Source &src, Sink &sink, const lz77x_geom &g, h
         if (seg > ((size_t)3 << 30)) seg = (size_t)3 << 30;      /* local coordinates are 32-bit */
     }
     Ctx *cx[2] = {&c, &c};
-    hipStream_t sx[2] = {s, s};
-    if (pipelined) {
-        if ((rc = ctx_sibling(c, &cx[1]))) return rc;
-        sx[1] = cx[1]->stream;
-    }
+    hipStream_t sx[2] = {s, s};            /* (the second context set: created when a second segment turns up) */
     SegCarry carry;
     SegJob J[2];
     uint64_t n_total = 0;
@@ -2005,6 +2045,10 @@ int encode_stream_device(Ctx &c, Source &src, Sink &sink, const lz77x_geom &g, h
                 /* its context is the one segment k-1 still occupies: its last tokens and its words are taken first */
                 if ((rc = seg_finish(J[prev_unfinished & 1], carry, sink, &waited, s))) return rc;
                 prev_unfinished = -1;
+            }
+            if (cx[1] == &c) {
+                if ((rc = ctx_sibling(c, &cx[1]))) return rc;
+                sx[1] = cx[1]->stream;
             }
             if ((rc = load(k + 1, &K))) return rc;
             HIPCHK(hipStreamWaitEvent(J[(k + 1) & 1].s, K.c->ev[1], 0));
@@ -2570,6 +2614,7 @@ int lz77x_encode_file(FILE *in, FILE *out, int la, int sb)
         const double t1 = now_ms();
         rc = encode_stream_device(c, src, sink, g, c.stream, &fallback, &n);
         TRACE("file -> device -> file", t1);
+        trace_allocs("  of which allocations:");
         if (rc || !fallback) return rc;                         /* fallback: the whole (single-segment) input sits in c.in */
     } else {
         const double t1 = now_ms();
@@ -2594,12 +2639,18 @@ int lz77x_decode_file(FILE *in, FILE *out)
     Ctx &g_ctx = lease.set->primary;
     (void)g_ctx;
     int rc;
+    const double t0 = now_ms();
     if ((rc = primary_context(*lease.set))) return rc;
+    TRACE("runtime + context init", t0);
     /* any size, any kind of file: range by range through bounded device memory (lz77.c:160-195) */
     FileSource src(in);
     FileSink sink(out);
     uint64_t n = 0;
-    return decode_stream(g_ctx, src, &sink, g_ctx.stream, &n);
+    const double t1 = now_ms();
+    rc = decode_stream(g_ctx, src, &sink, g_ctx.stream, &n);
+    TRACE("file -> device -> file (decode)", t1);
+    trace_allocs("  of which allocations:");
+    return rc;
 }
 
 void lz77x_free(void *p) { free(p); }
@@ -2656,9 +2707,8 @@ void ctx_release(Ctx &c)
     for (auto &ev : c.ev) e = hipEventDestroy(ev);
     for (auto &ev : c.pipe_ev) e = hipEventDestroy(ev);
     e = hipStreamDestroy(c.stream);
-    e = hipStreamDestroy(c.copy);
-    e = hipStreamDestroy(c.up);
-    e = hipStreamDestroy(c.tok);
+    for (hipStream_t *q : {&c.copy, &c.up, &c.tok})
+        if (*q) { e = hipStreamDestroy(*q); *q = nullptr; }
     (void)e;
     c.ready = false;
 }
