@@ -67,8 +67,9 @@ def cpu_baseline(data, sb, la, budget_bytes):
 
 def concurrent_streams(L, synth, torch, a, n, k):
     """Aggregate encode+decode rate of k independent streams sharing the GPU (threads of this process,
-    each leasing its own context from the library).  One stream keeps the GPU busy for a third of its
-    wall time -- the rest is the sequential host recurrence -- so this is what a multi-file job sees."""
+    each leasing its own context from the library).  Every stage of a stream runs on the device and its
+    latency-bound stages (the recurrence's sweeps, one wavefront per block) leave most of the chip idle, so
+    several streams overlap: this is what a multi-file job sees."""
     import threading
     os.environ.setdefault("LZ77X_MAX_CONTEXTS", str(k))
     cap = L.encode_bound(n, a.la, a.sb)
@@ -101,9 +102,9 @@ def concurrent_streams(L, synth, torch, a, n, k):
 
 def file_to_file(L, data, sb, la):
     """what a CLI user sees -- `lz77 -c` then `lz77 -d` as separate processes on a tmpfs file: process
-    start, HIP runtime + code-object load, file -> pinned slots -> device -> file.  Run twice: the first pair pays
-    whatever the box has not cached yet ("cold"), the second is "warm"; `process_start_ms` is an encode of an EMPTY
-    file (everything but the data)."""
+    start, HIP runtime init, file -> pinned slots -> device -> file, process exit.  Three pairs: `first` pays whatever
+    the box has not cached yet, `warm` is the best of the three (runtime init alone varies by 50-250 ms from run to
+    run, profiles/r04_cli_startup.txt); `process_start_ms` is an encode of an EMPTY file (everything but the data)."""
     import numpy as np
     tmp = "/dev/shm" if os.path.isdir("/dev/shm") else "/tmp"
     fin, flz, fout, fempty = (os.path.join(tmp, "lz77f2f_%d.%s" % (os.getpid(), e)) for e in ("in", "lz", "out", "empty"))
@@ -111,29 +112,97 @@ def file_to_file(L, data, sb, la):
     data.tofile(fin)
     open(fempty, "wb").close()
     geo = ["-s", str(sb), "-l", str(la)]
-    res = {}
+    runs = []
     try:
-        for label in ("cold", "warm"):
+        for _ in range(3):
             t0 = time.perf_counter()
             subprocess.check_call([L.CLI_PATH, "-c", "-i", fin, "-o", flz] + geo)
             t1 = time.perf_counter()
             subprocess.check_call([L.CLI_PATH, "-d", "-i", flz, "-o", fout])
             t2 = time.perf_counter()
-            res[label] = {"encode_ms": round((t1 - t0) * 1e3, 1), "decode_ms": round((t2 - t1) * 1e3, 1)}
-        t0 = time.perf_counter()
-        subprocess.check_call([L.CLI_PATH, "-c", "-i", fempty, "-o", flz + ".e"] + geo)
-        start_ms = (time.perf_counter() - t0) * 1e3
+            runs.append({"encode_ms": round((t1 - t0) * 1e3, 1), "decode_ms": round((t2 - t1) * 1e3, 1)})
+        starts = []
+        for _ in range(3):
+            t0 = time.perf_counter()
+            subprocess.check_call([L.CLI_PATH, "-c", "-i", fempty, "-o", flz + ".e"] + geo)
+            starts.append((time.perf_counter() - t0) * 1e3)
         ok = bool(np.array_equal(np.fromfile(fout, dtype=np.uint8), data))
     finally:
         for p in (fin, flz, fout, fempty, flz + ".e"):
             if os.path.exists(p):
                 os.unlink(p)
-    w = res["warm"]
+    w = {"encode_ms": min(r["encode_ms"] for r in runs), "decode_ms": min(r["decode_ms"] for r in runs)}
     return {"encode_MBps": round(n / w["encode_ms"] / 1e3, 1), "decode_MBps": round(n / w["decode_ms"] / 1e3, 1),
             "encode_plus_decode_MBps": round(n / (w["encode_ms"] + w["decode_ms"]) / 1e3, 1),
-            "cold_start_ms": round(res["cold"]["encode_ms"] - w["encode_ms"], 1), "process_start_ms": round(start_ms, 1),
-            "cold": res["cold"], "warm": w, "roundtrip_ok": ok, "bytes": n,
-            "note": "whole-process wall time of lz77_amd/lz77 on a tmpfs file (PCIe, process start and runtime init included); never `value`"}
+            "cold_start_ms": round(runs[0]["encode_ms"] - w["encode_ms"], 1), "process_start_ms": round(min(starts), 1),
+            "first": runs[0], "warm": w, "runs": runs, "process_start_runs_ms": [round(x, 1) for x in starts],
+            "roundtrip_ok": ok, "bytes": n,
+            "note": "whole-process wall time of lz77_amd/lz77 on a tmpfs file (process start, HIP runtime init -- 56-250 ms by itself, "
+                    "profiles/r04_cli_startup.txt --, PCIe and process exit included); never `value`"}
+
+
+def other_configs(L, synth, torch):
+    """BASELINE.json configs[2] and configs[3] beside the headline line (never `value`): S2 = 1 GiB of raw splitmix64 bytes
+    at s=4095 l=15, S3 = 212 MB Silesia-like mixed data at s=65535 l=255.  Each: encode + decode with buffers resident in
+    HBM (second of two runs), the digest of the stream against the compiled reference's, the largest kernel's and the whole
+    encode's fraction of the HBM roofline (algorithmic bytes n + zn)."""
+    import hashlib
+    recs = []
+    for name, kind, n, seed, sb, la in (("S2", "random", 1 << 30, synth.SEED_S2, 4095, 15), ("S3", "mixed", 212_000_000, synth.SEED_S3, 65535, 255)):
+        try:
+            data = synth.make(kind, n, seed)
+            d_in = torch.from_numpy(data).cuda()
+            cap = L.encode_bound(n, la, sb)
+            d_z = torch.empty(cap, dtype=torch.uint8, device="cuda")
+            d_back = torch.empty(n, dtype=torch.uint8, device="cuda")
+            st = torch.cuda.current_stream().cuda_stream
+            for _ in range(2):
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                zn = L.encode_device(d_in.data_ptr(), n, d_z.data_ptr(), cap, la, sb, st)
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                se = L.last_stats()
+                m = L.decode_device(d_z.data_ptr(), zn, d_back.data_ptr(), n, st)
+                torch.cuda.synchronize()
+                t2 = time.perf_counter()
+                sd = L.last_stats()
+            ok = bool(m == n and torch.equal(d_back, d_in))
+            gold = golden_full(kind, n, seed, sb, la)
+            sha_ok = None
+            if gold is not None:
+                h = hashlib.sha256()
+                for at in range(0, zn, 1 << 28):
+                    h.update(d_z[at:min(at + (1 << 28), zn)].cpu().numpy().tobytes())
+                sha_ok = bool(zn == gold["zn"] and h.hexdigest() == gold["sha256_lz"])
+            alg = n + zn
+            iters = max(int(se["prio_iters"]), 1)
+            kern = {"tie-break (k_tokens_sorted / k_tokens_rank_group)": (se["k_tiebreak_ms"], max(int(se["token_launches"]), 1)),
+                    "window walkers (k_walk / k_walk_wave)": (se["k_walk_ms"], max(int(se["match_launches"]), 1)),
+                    "key sort (k_c1_chunks + k_match / k_big_*)": (se["k_sort_ms"], max(int(se["match_launches"]), 1)),
+                    "recurrence forward sweeps (k_prio_fwd / k_pw_fwd), all iterations": (se["k_prio_fwd_ms"], iters)}
+            dom = max(kern, key=lambda k: kern[k][0])
+            dom_ms, dom_launches = kern[dom]
+            t_dev = se["k_match_ms"] + se["k_chain_ms"] + se["k_prio_ms"] + se["k_token_ms"]
+            recs.append({"name": name, "workload": "%s %s, %d bytes, s=%d l=%d, buffers resident in HBM" % (name, kind, n, sb, la),
+                         "encode_ms": round((t1 - t0) * 1e3, 2), "decode_ms": round((t2 - t1) * 1e3, 2),
+                         "encode_MBps": round(n / (t1 - t0) / 1e6, 1), "decode_MBps": round(n / (t2 - t1) / 1e6, 1),
+                         "encode_plus_decode_MBps": round(n / (t2 - t0) / 1e6, 1),
+                         "stream_sha_ok": sha_ok, "roundtrip_ok": ok, "ratio": round(zn / n, 4), "prio_iters": int(se["prio_iters"]),
+                         "host_stageb_ms": round(se["host_stageb_ms"], 2),
+                         "dominant_kernel": dom, "dominant_kernel_ms": round(dom_ms, 3), "dominant_kernel_launches": dom_launches,
+                         "frac": round(alg / (dom_ms / dom_launches * 1e-3) / 1e9 / HBM_PEAK_GBS / dom_launches, 6) if dom_ms > 0 else None,
+                         "frac_op": round(alg / (t_dev * 1e-3) / 1e9 / HBM_PEAK_GBS, 6) if t_dev > 0 else None,
+                         "frac_decode": round(alg / (sd["k_decode_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 6) if sd["k_decode_ms"] > 0 else None,
+                         "kernels_ms": {k: round(se[k], 2) for k in ("k_match_ms", "k_sort_ms", "k_walk_ms", "k_chain_ms", "k_prio_ms", "k_prio_fwd_ms",
+                                                                      "k_token_ms", "k_tiebreak_ms")},
+                         "k_decode_ms": round(sd["k_decode_ms"], 3)})
+            del d_in, d_z, d_back, data
+            torch.cuda.empty_cache()
+            L.lib().lz77x_shutdown()                               # the next configuration sizes its own buffers
+        except Exception as e:                                    # pragma: no cover - must never break the line
+            recs.append({"name": name, "error": str(e)[:300]})
+    return recs
 
 
 def shard_record(L, synth, a, shards):
@@ -291,9 +360,10 @@ def main():
     ap.add_argument("--sb", type=int, default=4095)
     ap.add_argument("--la", type=int, default=15)
     ap.add_argument("--kind", default="text")
-    ap.add_argument("--cpu-sample", type=int, default=64_000_000)
+    ap.add_argument("--cpu-sample", type=int, default=100_000_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-file-to-file", action="store_true")
+    ap.add_argument("--no-configs", action="store_true", help="skip the S2 / S3 records (BASELINE configs[2], configs[3])")
     ap.add_argument("--no-shard-record", action="store_true", help="N > 1: skip the S4 one-stream-sharded sub-record")
     ap.add_argument("--streams", type=int, default=4, help="also report k concurrent streams on one GPU (informational; 1 = skip)")
     ap.add_argument("--mode", choices=("files", "shard"), default="files",
@@ -479,6 +549,13 @@ def main():
             "prio_iters": iters,
             "decode_breakdown_ms": {k: round(mean(dec_stats, k), 2) for k in ("total_ms", "k_decode_ms")},
         }
+        if world == 1 and not a.no_configs and corpus_label is None:
+            # BASELINE configs[2] and [3], driver-observed beside the headline (outside the timed region, never `value`)
+            del d_in, d_z, d_back
+            torch.cuda.empty_cache()
+            L.lib().lz77x_shutdown()
+            out["configs"] = other_configs(L, synth, torch)
+            d_in = d_z = d_back = None
         if world == 1 and a.streams > 1:
             # informational, never `value`: k independent streams on the one GPU, one thread each
             try:

@@ -37,7 +37,10 @@ extern "C" {
                                    would be wider than 32 bits (la > 255 with a wide sb: main.c:103 never emits it) */
 #define LZ77X_E_CAP      (-6)   /* caller-provided output buffer too small (*out_n holds the need) */
 #define LZ77X_E_IO       (-7)   /* fread/fwrite failed */
-#define LZ77X_E_TOOBIG   (-8)   /* input >= 4 GiB in one call (positions are 32-bit on device) */
+#define LZ77X_E_TOOBIG   (-8)   /* only the paths that hold a whole input at once: one stream cut over several devices
+                                   (lz77x_set_shards > 1) and the stage-level entry points, at >= 4 GiB (positions are
+                                   32-bit on a device).  lz77x_encode*, lz77x_decode* on one device take any length:
+                                   segments / token ranges through bounded device memory */
 
 #define LZ77X_DEFAULT_LA 15     /* lz77.c:21 */
 #define LZ77X_DEFAULT_SB 4095   /* lz77.c:22 */
@@ -50,7 +53,10 @@ extern "C" {
 int lz77x_encode(const uint8_t *in, size_t n, int sb, int la, uint8_t **out, size_t *out_n);
 
 /* Replaces decode() (lz77.c:148-197).  The header inside the stream supplies sb/la
- * (lz77.c:157-158); a trailing partial token is dropped (lz77.c:271-280). */
+ * (lz77.c:157-158); a trailing partial token is dropped (lz77.c:271-280).  Like the reference (lz77.c:160-195: any
+ * length through a 3*SB+LA buffer) the decoder takes a stream of any length: it runs range by range -- at most
+ * LZ77X_DECODE_RANGE tokens (default 2^26) and LZ77X_DECODE_RANGE_BYTES output bytes (default 2^30) at a time, device
+ * memory independent of the stream's length; a stream that fits one range is decoded in one piece. */
 int lz77x_decode(const uint8_t *z, size_t zn, uint8_t **out, size_t *out_n);
 
 void lz77x_free(void *p);

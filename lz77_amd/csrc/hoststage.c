@@ -1,12 +1,14 @@
 /*
- * hoststage.c -- the sequential host part of the encode hot path (plain C).
- *
- * Two recurrences of the reference are inherently serial over the byte stream and
- * stay on a host core:
+ * hoststage.c -- host-side helpers of the hot path (plain C): the token geometry (bitof, regions) and the
+ * SEQUENTIAL form of the two recurrences of the reference,
  *   - the greedy parse chain  p <- p + len + 1                      (lz77.c:89-98)
  *   - which node a tree.c:182-243 delete() promotes, restated as a priority
- *     hand-over between a position and its in-order successor       (SURVEY A.5 stage B)
- * Both consume per-position results of the match kernel and are O(1) per byte.
+ *     hand-over between a position and its in-order successor       (SURVEY A.5 stage B).
+ * Since round 3 both run on the DEVICE for every window size (k_chain.hip, k_prio.hip, k_priow.hip); the loops
+ * here are what the host-assisted pipeline (encode_core_host in pipeline.cpp) runs -- the fallback when the
+ * device's gate iteration does not converge, a large-window stream cut over several devices, and the
+ * lz77x_stage_priorities cross-check of the parity tests.  O(1) per byte on per-position results of the match
+ * kernels.
  */
 #include "lz77x_internal.h"
 #include <stdlib.h>

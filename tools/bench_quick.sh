@@ -1,7 +1,7 @@
 #!/bin/bash
 # usage (GPU box): bash tools/bench_quick.sh [tag] [ENV=VAL ...] -- one short bench run, the numbers that matter on one line
 tag=${1:-q}; shift
-env "$@" python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-file-to-file --streams 1 > gpurun_out/bq_$tag.log 2>&1
+env "$@" python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-configs --no-file-to-file --streams 1 > gpurun_out/bq_$tag.log 2>&1
 python - gpurun_out/bq_$tag.log <<'PY'
 import json,sys
 try:

@@ -3,7 +3,7 @@
 cd /tmp && export TMPDIR=/tmp
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 out=gpurun_out/gp_$$; rm -rf $out; mkdir -p $out
-env "$@" rocprofv3 --kernel-trace --memory-copy-trace --output-format csv -d $out -o t -- python bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-file-to-file --streams 1 > $out/log 2>&1
+env "$@" rocprofv3 --kernel-trace --memory-copy-trace --output-format csv -d $out -o t -- python bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-configs --no-file-to-file --streams 1 > $out/log 2>&1
 python - $out <<'PY'
 import csv,sys,glob
 out=sys.argv[1]

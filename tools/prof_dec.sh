@@ -1,6 +1,6 @@
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 for seg in 0 262144; do
-LZ77X_DECODE_SEGMENT=$seg rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_dec$seg -o t -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --streams 1 > /dev/null 2>&1
+LZ77X_DECODE_SEGMENT=$seg rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_dec$seg -o t -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-configs --streams 1 > /dev/null 2>&1
 echo seg $seg
 python - <<PY
 import csv

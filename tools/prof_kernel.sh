@@ -4,7 +4,7 @@ pat=$1; shift
 cd /tmp && export TMPDIR=/tmp
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 out=gpurun_out/pk_$$; rm -rf $out; mkdir -p $out
-env "$@" rocprofv3 --kernel-trace --stats --output-format csv -d $out -o t -- python bench.py --steps 1 --warmup 0 --no-cpu-baseline --streams 1 > $out/log 2>&1
+env "$@" rocprofv3 --kernel-trace --stats --output-format csv -d $out -o t -- python bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-configs --streams 1 > $out/log 2>&1
 python - $out "$pat" <<'PY'
 import csv,sys,glob,re
 out,pat=sys.argv[1],sys.argv[2]

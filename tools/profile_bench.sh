@@ -12,12 +12,12 @@ cd "${GRAFT_REPO_ROOT:-$(dirname "$0")/..}"
 out=gpurun_out/profile_$tag
 rm -rf $out && mkdir -p $out
 python bench.py > $out/${tag}_bench.json 2> $out/bench.err
-rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -o t -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --streams 1 > $out/trace.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -o t -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-configs --streams 1 > $out/trace.log 2>&1
 cp $out/trace/t_kernel_stats.csv $out/${tag}_bench_kernel_stats.csv
 grep -o '{"metric.*' $out/trace.log > $out/${tag}_bench_under_rocprof.json      # bench.py's own hipEvent timing in the profiled run
 for pass in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_WAIT_ANY" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR"; do
   name=$(echo $pass | cut -d' ' -f1)
-  rocprofv3 --kernel-trace --pmc $pass --output-format csv -d $out/pmc_$name -o p -- python bench.py --steps 1 --warmup 0 --no-cpu-baseline --streams 1 > $out/pmc_$name.log 2>&1
+  rocprofv3 --kernel-trace --pmc $pass --output-format csv -d $out/pmc_$name -o p -- python bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-configs --streams 1 > $out/pmc_$name.log 2>&1
 done
 python - $out $tag <<'PY'
 import csv, glob, json, sys, collections
@@ -46,7 +46,7 @@ def hbm(k):
     # FETCH_SIZE / WRITE_SIZE are in KB; gfx950 tallies 128-B read requests as 64 B -> fetch doubled
     return int((2 * a.get("FETCH_SIZE", 0) + a.get("WRITE_SIZE", 0)) * 1024 / max(nl[k], 1))
 tr = {"round": tag,
-      "command": "rocprofv3 --kernel-trace --pmc FETCH_SIZE | --pmc WRITE_SIZE (separate passes) -- python bench.py --steps 1 --warmup 0 --no-cpu-baseline --streams 1",
+      "command": "rocprofv3 --kernel-trace --pmc FETCH_SIZE | --pmc WRITE_SIZE (separate passes) -- python bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-configs --streams 1",
       "correction": "gfx950 FETCH_SIZE counts 128-B requests as 64 B (MI355X_MICROARCH.md, HBM): fetch doubled; WRITE_SIZE as reported",
       "hbm_bytes_per_launch": {k.split("<")[0]: hbm(k) for k in sorted(acc) if k.startswith("k_")},
       "launches": {k.split("<")[0]: nl[k] for k in sorted(acc) if k.startswith("k_")}}
