@@ -251,6 +251,30 @@ struct Lease {
     Lease &operator=(const Lease &) = delete;
 };
 
+/* Device memory one call may plan with: what is free now, shared with the other callers inside the library at this
+ * moment (each leases a context set of its own), plus what this call's context already holds in its cached buffers.
+ * LZ77X_DEVICE_MEM_LIMIT (bytes) caps it -- a test knob, and a way to keep the library's footprint below a share of the
+ * device.  The plans below (segment size of an encode, range size of a decode) size themselves to fit; they never
+ * change the output bytes. */
+int device_budget(Ctx &c, size_t *avail)
+{
+    size_t fr = 0, total = 0;
+    HIPCHK(hipMemGetInfo(&fr, &total));
+    size_t held = 0;
+    for (DevBuf *b : c.dev_bufs()) held += b->cap;
+    if (c.pipe) for (DevBuf *b : c.pipe->dev_bufs()) held += b->cap;
+    size_t busy = 0;
+    {
+        std::lock_guard<std::mutex> lk(g_mu);
+        for (CtxSet *q : g_pool) busy += q->busy ? 1 : 0;
+    }
+    size_t a = fr / (busy ? busy : 1) + held;
+    const char *e = getenv("LZ77X_DEVICE_MEM_LIMIT");
+    if (e && atoll(e) > 0 && (size_t)atoll(e) < a) a = (size_t)atoll(e);
+    *avail = a;
+    return LZ77X_OK;
+}
+
 int ctx_init(Ctx &c, int device = -1)
 {
     if (c.ready) return LZ77X_OK;
@@ -1423,7 +1447,7 @@ int decode_resolve(Ctx &c, const lz77x_geom &g, uint32_t ntok, uint32_t n, hipSt
 }
 
 /* knobs of the range decoder: tokens per range (a multiple of eight) and bytes of output per range */
-void dec_range_plan(const lz77x_geom &g, uint32_t *range_tokens, uint32_t *range_bytes)
+void dec_range_plan(const lz77x_geom &g, size_t avail, uint32_t *range_tokens, uint32_t *range_bytes)
 {
     const char *e = getenv("LZ77X_DECODE_RANGE");
     uint64_t R = e && atoll(e) > 0 ? (uint64_t)atoll(e) : (uint64_t)1 << 26;
@@ -1435,6 +1459,18 @@ void dec_range_plan(const lz77x_geom &g, uint32_t *range_tokens, uint32_t *range
     if (R < 8) R = 8;
     if (cap < ((uint64_t)8 << g.lb)) cap = (uint64_t)8 << g.lb;       /* eight tokens always fit */
     if (cap > 0xFF000000u) cap = 0xFF000000u;
+    /* a device with less to spare (device_budget) gets smaller ranges: per token two stream buffers + token words, lengths
+     * and offsets; per output byte the byte itself + a 16-bit reference (segment walk) or a pointer and two work-list
+     * entries (tile pass / per-byte pointers) */
+    const double per_tok = 2.0 * g.T / 8.0 + 12.5, per_byte = lz77k_dec_seg_supported(g) ? 3.3 : 13.3;
+    const double need = 1.125 * (per_tok * (double)R + per_byte * (double)cap) + 64e6;
+    if (avail && need > 0.9 * (double)avail) {
+        const double f = 0.9 * (double)avail / need;
+        R = (uint64_t)((double)R * f) & ~(uint64_t)7;
+        cap = (uint64_t)((double)cap * f);
+        if (R < 8) R = 8;
+        if (cap < ((uint64_t)8 << g.lb)) cap = (uint64_t)8 << g.lb;
+    }
     *range_tokens = (uint32_t)R;
     *range_bytes = (uint32_t)cap;
 }
@@ -1463,7 +1499,9 @@ int decode_stream(Ctx &c, Source &src, Sink *sink, hipStream_t s, uint64_t *n_ou
      * cannot come from the reference's encoder, and the kernels carry tokens in 32-bit words */
     if (g.T > 32) return LZ77X_E_FORMAT;
     uint32_t R = 0, cap = 0;
-    dec_range_plan(g, &R, &cap);
+    size_t avail = 0;
+    if ((rc = device_budget(c, &avail))) return rc;
+    dec_range_plan(g, avail, &R, &cap);
     /* a stream whose size is known and lies inside one range is sized by what it holds: the range shrinks to the stream plus
      * one token (reading then meets the end of the stream inside it) */
     {
@@ -1622,6 +1660,7 @@ struct SegJob {
     uint64_t K0 = 0;
     uint32_t have_tail = 0, ntail_in = 0;
     uint64_t out_bytes = 0;
+    size_t scratch_cap = 0;          /* match-stage scratch per launch (0: the default of the geometry) */
     std::vector<char> tie_timed;
 };
 
@@ -1652,7 +1691,8 @@ int seg_front(SegJob &J, const lz77x_geom &g)
          * launch takes its fill + 2048 steps whatever its size), a second launch is a second 0.75 ms */
         const size_t per = lz77k_match_scratch_bytes(g, 1);
         /* (large windows: 16 GB -- their walkers are latency bound too and a region's scratch is 16x a small window's) */
-        const uint32_t fit = (uint32_t)(((size_t)(g.fast ? 3 : 16) << 30) / per);
+        const size_t cap = J.scratch_cap ? J.scratch_cap : (size_t)(g.fast ? 3 : 16) << 30;      /* (encode_mem_plan lowers it on a tight device) */
+        const uint32_t fit = (uint32_t)(cap / per);
         if (batch > fit) batch = fit ? fit : 1;
         const char *gs = getenv("LZ77X_MATCH_BATCH");
         if (gs && atoi(gs) > 0 && (uint32_t)atoi(gs) < batch) batch = (uint32_t)atoi(gs);
@@ -1957,7 +1997,7 @@ int encode_stream_device(Ctx &c, Source &src, Sink &sink, const lz77x_geom &g, h
     HIPCHK(hipSetDevice(c.device));
     const size_t usb = (size_t)g.sb, halo = (size_t)g.la + 64;
     const uint32_t csub = lz77k_chain_sub();
-    size_t seg = (size_t)1 << 30;
+    size_t seg = (size_t)1 << 30, scratch_cap = 0;
     bool pipelined = !(getenv("LZ77X_PIPELINE") && atoi(getenv("LZ77X_PIPELINE")) == 0);
     {
         const size_t lo = 4 * usb + 3 * (size_t)csub;
@@ -1978,6 +2018,36 @@ int encode_stream_device(Ctx &c, Source &src, Sink &sink, const lz77x_geom &g, h
         if (known && known < seg) seg = (known + csub - 1) / csub * csub;
         if (seg < lo) seg = lo;
         if (seg > ((size_t)3 << 30)) seg = (size_t)3 << 30;      /* local coordinates are 32-bit */
+        /* ... and the device must hold it: per position of a segment ~27 B (windows in LDS: input, ps, maxlen, the regions'
+         * order, xval, chain, token words, gates) or ~62 B (large windows: rank + inverse arrays, hand-over index, bucket
+         * records), plus the match stage's scratch per launch; twice when a second segment is in flight (measured:
+         * tools/mem_probe.py).  A device with less to spare gets smaller launches, then smaller segments. */
+        size_t avail = 0;
+        if ((rc = device_budget(c, &avail))) return rc;
+        const size_t per_pos = g.fast ? 34 : 70, slack = (size_t)384 << 20;    /* (the cached buffers carry an eighth of headroom each) */
+        const size_t one_region = lz77k_match_scratch_bytes(g, 1);
+        for (int pass = 0; pass < 2; pass++) {
+            /* one context set while the input is one segment; two as soon as it is not (the second pass) */
+            const bool two = pipelined && (pass == 1 || !(known && known <= seg));
+            const size_t share = avail / 10 * 9 / (two ? 2 : 1);
+            scratch_cap = (size_t)(g.fast ? 3 : 16) << 30;
+            if (scratch_cap > share / 4) scratch_cap = share / 4;
+            if (scratch_cap < one_region) scratch_cap = one_region;
+            const size_t fixed = scratch_cap + slack + (g.fast ? 0 : (size_t)1 << 30);
+            if (share < fixed + per_pos * lo) {
+                snprintf(g_err, sizeof g_err, "device memory: %.1f MB to plan with, a segment of %zu positions needs %.1f MB", avail / 1e6, lo,
+                         (fixed + per_pos * lo) / 1e6);
+                return LZ77X_E_HIP;
+            }
+            const size_t seg_fit = (share - fixed) / per_pos / csub * csub;
+            const size_t seg_new = seg > seg_fit ? (seg_fit < lo ? lo : seg_fit) : seg;
+            const bool multi = !(known && known <= seg_new);
+            seg = seg_new;
+            if (two || !multi || !pipelined) break;              /* (else: it became several segments -- plan again for two in flight) */
+        }
+        if (trace_on())
+            fprintf(stderr, "[lz77x] memory plan: %.1f MB to plan with, segments of %zu positions, %.1f MB of match scratch per launch\n", avail / 1e6,
+                    seg, scratch_cap / 1e6);
     }
     Ctx *cx[2] = {&c, &c};
     hipStream_t sx[2] = {s, s};            /* (the second context set: created when a second segment turns up) */
@@ -1992,6 +2062,7 @@ int encode_stream_device(Ctx &c, Source &src, Sink &sink, const lz77x_geom &g, h
         N = SegJob();
         N.c = cx[k & 1];
         N.s = sx[k & 1];
+        N.scratch_cap = scratch_cap;
         Ctx &cn = *N.c;
         const size_t want_local = (k ? usb : 0) + seg + halo;
         int r;
