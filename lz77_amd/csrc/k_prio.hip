@@ -521,8 +521,15 @@ __global__ __launch_bounds__(BK2_T, 8) __attribute__((amdgpu_num_sgpr(80))) void
                 }
             }
             bk2_barrier();
-            if (!again || r >= 15u) break;                 /* (a pointer advances at least one cell a hop, two hops a round: seven rounds at most) */
+            /* a round replaces ptr by ptr o ptr o ptr (both hops read the array as the round found it): the reach triples, a
+             * sub-block of 8192 cells is through after nine rounds; pointers only ever point forward (S >= 1), so the bound is
+             * never met on any ps[] the match stage can write */
+            if (!again || r >= 15u) break;
         }
+        /* (should corrupt input ever stop the loop at its bound: a pointer still inside is dropped, not turned into an exit
+         * cell below zero) */
+#pragma unroll
+        for (uint32_t k = 0; k < BK2_CPT; k++) p[k] = p[k] < L ? (uint32_t)PRIO_DEAD : p[k];
         if (tid < 2) s_more[tid] = 0;                      /* (ordered before the next sub-block's rounds by its barrier) */
         /* the exits: dest of cell y1 + e, e = pointer - L */
         const uint16_t *dcur = dn[w];

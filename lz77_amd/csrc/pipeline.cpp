@@ -171,8 +171,18 @@ template <class F> int for_each_shard(size_t D, F fn)
         if (rcs[d]) msgs[d] = g_err;
     };
     std::vector<std::thread> th;
-    for (size_t d = 1; d < D; d++) th.emplace_back(run, d);
+    bool spawn_failed = false;
+    try {
+        th.reserve(D);
+        for (size_t d = 1; d < D; d++) th.emplace_back(run, d);
+    } catch (...) {
+        /* no exception crosses the C ABI, and a joinable std::thread must not be destroyed: what started is joined below,
+         * the shards without a thread run on this one */
+        spawn_failed = true;
+    }
     if (D) run(0);
+    if (spawn_failed)
+        for (size_t d = th.size() + 1; d < D; d++) run(d);
     for (auto &t : th) t.join();
     for (size_t d = 0; d < D; d++)
         if (rcs[d]) { snprintf(g_err, sizeof g_err, "%s", msgs[d].c_str()); return rcs[d]; }
@@ -1661,6 +1671,7 @@ struct SegJob {
     uint32_t have_tail = 0, ntail_in = 0;
     uint64_t out_bytes = 0;
     size_t scratch_cap = 0;          /* match-stage scratch per launch (0: the default of the geometry) */
+    size_t token_chunk = (size_t)128 << 20;   /* positions per token launch (LZ77X_TOKEN_CHUNK, read once per call) */
     std::vector<char> tie_timed;
 };
 
@@ -1708,9 +1719,7 @@ int seg_front(SegJob &J, const lz77x_geom &g)
     J.d_order = keep_order ? c.ranks_all.as<uint32_t>() : nullptr;
     /* large windows: the (block, first byte) buckets the tokens of length one are resolved from (built per token chunk) */
     if (!g.fast) {
-        size_t chunk_pos = (size_t)128 << 20;
-        const char *ce = getenv("LZ77X_TOKEN_CHUNK");
-        if (ce && atoi(ce) > 0) chunk_pos = (size_t)atoi(ce);
+        size_t chunk_pos = J.token_chunk;
         chunk_pos += lz77k_chain_sub();
         if ((rc = c.bidx.need(lz77k_tokens_index_bytes(g, chunk_pos < (size_t)J.nloc ? chunk_pos : (size_t)J.nloc)))) return rc;
     }
@@ -1843,12 +1852,7 @@ int seg_tokens(SegJob &J, const lz77x_geom &g, const SegCarry &carry)
         const uint32_t csub = lz77k_chain_sub();
         /* token chunks: up to 128M positions (one hand-over index and one tie-break launch each; the index
          * costs 12 bytes of scratch per position), a multiple of the chain sub-block, counted from `start` */
-        size_t chunk_pos = (size_t)128 << 20;
-        {
-            const char *ce = getenv("LZ77X_TOKEN_CHUNK");
-            if (ce && atoi(ce) > 0) chunk_pos = (size_t)atoi(ce);
-            chunk_pos = (chunk_pos + csub - 1) / csub * csub;
-        }
+        size_t chunk_pos = (J.token_chunk + csub - 1) / csub * csub;
         const size_t span = (size_t)E - start, np = (size_t)J.nloc;
         const uint32_t nchunks = (uint32_t)((span + chunk_pos - 1) / chunk_pos);
         J.nchunks = nchunks;
@@ -1997,7 +2001,12 @@ int encode_stream_device(Ctx &c, Source &src, Sink &sink, const lz77x_geom &g, h
     HIPCHK(hipSetDevice(c.device));
     const size_t usb = (size_t)g.sb, halo = (size_t)g.la + 64;
     const uint32_t csub = lz77k_chain_sub();
-    size_t seg = (size_t)1 << 30, scratch_cap = 0;
+    size_t seg = (size_t)1 << 30, scratch_cap = 0, token_chunk = (size_t)128 << 20;
+    {
+        const char *ce = getenv("LZ77X_TOKEN_CHUNK");
+        if (ce && atoll(ce) > 0) token_chunk = (size_t)atoll(ce);
+        if (token_chunk > ((size_t)1 << 31)) token_chunk = (size_t)1 << 31;
+    }
     bool pipelined = !(getenv("LZ77X_PIPELINE") && atoi(getenv("LZ77X_PIPELINE")) == 0);
     {
         const size_t lo = 4 * usb + 3 * (size_t)csub;
@@ -2063,6 +2072,7 @@ int encode_stream_device(Ctx &c, Source &src, Sink &sink, const lz77x_geom &g, h
         N.c = cx[k & 1];
         N.s = sx[k & 1];
         N.scratch_cap = scratch_cap;
+        N.token_chunk = token_chunk;
         Ctx &cn = *N.c;
         const size_t want_local = (k ? usb : 0) + seg + halo;
         int r;

@@ -72,8 +72,14 @@ void encode(FILE *file, struct bitFILE *out, int la, int sb)
     FILE *sink = fopencookie(out, "w", io);
     if (!sink) { fprintf(stderr, "lz77 (MI355X): out of memory\n"); exit(EXIT_FAILURE); }
     const int rc = lz77x_encode_file(file, sink, la, sb);               /* -1 = default like lz77.c:65-66 */
+    const int in_failed = ferror(file);                                 /* which side LZ77X_E_IO came from */
     fclose(sink);                                                       /* (flushes stdio's buffer into bitIO_write; `out` stays main()'s) */
-    if (rc == LZ77X_E_IO) { printf("Error loading the data in the window.\n"); return; }   /* lz77.c:79-82 */
+    if (rc == LZ77X_E_IO) {
+        /* a failed read of the input is the reference's one message (lz77.c:79-82, on stdout); a short write of the stream
+         * passes in silence there (bitio.c:87-88, 231-232) and does here */
+        if (in_failed) printf("Error loading the data in the window.\n");
+        return;
+    }
     if (rc != LZ77X_OK) die("encode", rc);
 }
 
@@ -83,8 +89,14 @@ void decode(struct bitFILE *file, FILE *out)
     FILE *src = fopencookie(file, "r", io);
     if (!src) { fprintf(stderr, "lz77 (MI355X): out of memory\n"); exit(EXIT_FAILURE); }
     const int rc = lz77x_decode_file(src, out);
+    const int in_failed = ferror(src);
     fclose(src);
     if (rc == LZ77X_E_FORMAT) return;                                   /* shorter than its header: nothing to write */
-    if (rc == LZ77X_E_IO) { perror("Writing output file"); return; }
+    if (rc == LZ77X_E_IO) {
+        /* lz77.c:273-277: a read error of the compressed side is perror("Error reading bits.\\n") + exit(EXIT_FAILURE); a failed putc
+         * of the output is not looked at by the reference at all */
+        if (in_failed) { perror("Error reading bits.\n"); exit(EXIT_FAILURE); }
+        return;
+    }
     if (rc != LZ77X_OK) die("decode", rc);
 }
