@@ -19,6 +19,35 @@ __device__ __forceinline__ void lds_barrier()
 
 typedef unsigned short us2 __attribute__((ext_vector_type(2)));
 
+/* Key bytes staged BACKWARDS (REV): the buffer holds by[top + 3 - i] at offset i, so the plain little-endian dword at
+ * offset top - a IS the big-endian dword of the bytes a .. a+3 -- the form keys are compared in (tree.c:77 is a memcmp).
+ * The production sorts stage their window this way: a key load is five LDS reads and four funnel shifts, no byte swaps
+ * (four v_perm per 16-byte key, on the one instruction stream the sort is bound by). */
+template <bool BYTES_LDS, bool REV>
+__device__ __forceinline__ uint32_t be32_at(const uint8_t *by, uint32_t top, uint32_t a)
+{
+    if constexpr (REV) return ld32_at<true>(by, top - a);
+    else return __builtin_bswap32(ld32_at<BYTES_LDS>(by, a));
+}
+
+/* key_less of kernels_common.h on either staging */
+template <bool BYTES_LDS, bool REV>
+__device__ __forceinline__ bool key_less_v(const uint8_t *by, uint32_t top, uint32_t a, uint32_t b, int la)
+{
+    if constexpr (!REV) return key_less<BYTES_LDS>(by, a, b, la);
+    for (int w = 0; w < la; w += 4) {
+        uint32_t va = be32_at<true, true>(by, top, a + (uint32_t)w), vb = be32_at<true, true>(by, top, b + (uint32_t)w);
+        const int rem = la - w;
+        if (rem < 4) {
+            const uint32_t m = 0xFFFFFFFFu << (8 * (4 - rem));
+            va &= m;
+            vb &= m;
+        }
+        if (va != vb) return va < vb;
+    }
+    return a < b;
+}
+
 /*
  * Bitonic sort of RP = 16*1024 local indices held in LDS, organised by how far apart the two
  * elements of a compare-exchange are:
@@ -27,26 +56,26 @@ typedef unsigned short us2 __attribute__((ext_vector_type(2)));
  *   stride < 1024  : both live in the 1024-slot segment ONE wave owns: LDS, no workgroup barrier
  *   stride >= 1024 : across waves: LDS + __syncthreads (10 of the 105 steps)
  */
-template <bool BYTES_LDS> __device__ __forceinline__ bool key_tail_less(const uint8_t *by, uint32_t a, uint32_t b, int la, int from);
+template <bool BYTES_LDS, bool REV = false> __device__ __forceinline__ bool key_tail_less(const uint8_t *by, uint32_t a, uint32_t b, int la, int from, uint32_t top = 0);
 
-template <bool BYTES_LDS>
-__device__ __forceinline__ bool sort_less(const uint8_t *by, uint32_t a, uint32_t pa, uint32_t b, uint32_t pb, uint32_t R, int la)
+template <bool BYTES_LDS, bool REV = false>
+__device__ __forceinline__ bool sort_less(const uint8_t *by, uint32_t a, uint32_t pa, uint32_t b, uint32_t pb, uint32_t R, int la, uint32_t top = 0)
 {
     if (pa != pb) return pa < pb;
     if (a >= R || b >= R) return a < b;
-    return la > 16 ? key_tail_less<BYTES_LDS>(by, a, b, la, 0) : key_less<BYTES_LDS>(by, a, b, la);
+    return la > 16 ? key_tail_less<BYTES_LDS, REV>(by, a, b, la, 0, top) : key_less_v<BYTES_LDS, REV>(by, top, a, b, la);
 }
 
-template <int J, bool STATIC_DIR, bool BYTES_LDS>
+template <int J, bool STATIC_DIR, bool BYTES_LDS, bool REV = false>
 __device__ __forceinline__ void sort_local_pass(uint32_t (&v)[16], uint32_t (&pf)[16], const uint8_t *by, uint32_t R, int la,
-                                                int k_static, bool up_uniform)
+                                                int k_static, bool up_uniform, uint32_t top = 0)
 {
 #pragma unroll
     for (int r = 0; r < 16; r++) {
         if (r & J) continue;
         const int s = r | J;
         const bool up = STATIC_DIR ? ((r & k_static) == 0) : up_uniform;
-        const bool s_lt_r = sort_less<BYTES_LDS>(by, v[s], pf[s], v[r], pf[r], R, la);
+        const bool s_lt_r = sort_less<BYTES_LDS, REV>(by, v[s], pf[s], v[r], pf[r], R, la, top);
         if (up ? s_lt_r : !s_lt_r) {
             const uint32_t tv = v[r], tp = pf[r];
             v[r] = v[s]; pf[r] = pf[s];
@@ -166,16 +195,45 @@ __device__ __forceinline__ void region_sort_blocked(IdxT *ix, const uint8_t *by,
     __syncthreads();
 }
 
+/* the REV staging of N bytes (a multiple of four; four more must be addressable behind them) of the input from `base`:
+ * positions past the input's 0xFF pad read 0xFF too */
+template <uint32_t NT>
+__device__ __forceinline__ void stage_rev(uint8_t *lby, uint32_t N, const uint8_t *in, uint64_t base, uint32_t n, uint32_t tid)
+{
+    const uint64_t lim = (uint64_t)n + LZ77X_PAD;
+    for (uint32_t i = tid * 4; i < N; i += NT * 4) {
+        const uint32_t v = base + i + 4 <= lim ? ld32u(in + base + i) : 0xFFFFFFFFu;
+        *reinterpret_cast<uint32_t *>(lby + (N - 4u - i)) = __builtin_bswap32(v);
+    }
+}
+
 /* The merge levels compare whole 16-byte key heads held in registers (big-endian dwords, bytes past
  * `la` masked off): with a 4-byte prefix nearly every step had SOME lane of the wave tie and drag all
  * 64 through the byte-loop fallback -- neighbours in key order share long prefixes.  For la <= 16
  * (C1) a compare never touches memory again. */
 struct key16 { uint64_t hi, lo; };
 
-template <bool BYTES_LDS>
-__device__ __forceinline__ key16 load_key16(const uint8_t *by, uint32_t a, bool valid, const uint32_t (&m)[4])
+template <bool BYTES_LDS, bool REV = false>
+__device__ __forceinline__ key16 load_key16(const uint8_t *by, uint32_t a, bool valid, const uint32_t (&m)[4], uint32_t top = 0)
 {
     uint32_t k[4];
+    if constexpr (REV) {
+        /* REV staging: every slot's bytes exist in LDS (padding slots and everything past the input read 0xFF, which sorts
+         * them last like the `valid` selects of the forward form did); `a` is clamped by the caller.  k[j] = the dword at
+         * offset top - a - 4j */
+        (void)valid;
+        const uint32_t lo = top - 12u - a;
+        const uint32_t *w = reinterpret_cast<const uint32_t *>(by + (lo & ~3u));
+        const uint32_t w0 = w[0], w1 = w[1], w2 = w[2], w3 = w[3], w4 = w[4], sh = lo & 3u;
+        k[3] = __builtin_amdgcn_alignbyte(w1, w0, sh);
+        k[2] = __builtin_amdgcn_alignbyte(w2, w1, sh);
+        k[1] = __builtin_amdgcn_alignbyte(w3, w2, sh);
+        k[0] = __builtin_amdgcn_alignbyte(w4, w3, sh);
+        key16 r;
+        r.hi = (((uint64_t)k[0] << 32) | k[1]) & (((uint64_t)m[0] << 32) | m[1]);
+        r.lo = (((uint64_t)k[2] << 32) | k[3]) & (((uint64_t)m[2] << 32) | m[3]);
+        return r;
+    } else {
     const uint32_t at = valid ? a : 0u;
     if constexpr (BYTES_LDS) {
         const uint32_t *w = reinterpret_cast<const uint32_t *>(by + (at & ~3u));
@@ -194,12 +252,13 @@ __device__ __forceinline__ key16 load_key16(const uint8_t *by, uint32_t a, bool 
     r.hi = ((uint64_t)k[0] << 32) | k[1];
     r.lo = ((uint64_t)k[2] << 32) | k[3];
     return r;
+    }
 }
 
 /* bytes from .. la-1 of two keys that agree before `from`, 16 at a time (la = 255 and repetitive
  * data: most late compares get here, and every round trip is paid by the whole wavefront) */
-template <bool BYTES_LDS>
-__device__ __forceinline__ bool key_tail_less(const uint8_t *by, uint32_t a, uint32_t b, int la, int from)
+template <bool BYTES_LDS, bool REV>
+__device__ __forceinline__ bool key_tail_less(const uint8_t *by, uint32_t a, uint32_t b, int la, int from, uint32_t top)
 {
     for (int w = from; w < la; w += 16) {
         uint32_t m[4];
@@ -208,27 +267,27 @@ __device__ __forceinline__ bool key_tail_less(const uint8_t *by, uint32_t a, uin
             const int rem = la - w - 4 * i;
             m[i] = rem >= 4 ? 0xFFFFFFFFu : rem <= 0 ? 0u : 0xFFFFFFFFu << (8 * (4 - rem));
         }
-        const key16 ka = load_key16<BYTES_LDS>(by, a + (uint32_t)w, true, m), kb = load_key16<BYTES_LDS>(by, b + (uint32_t)w, true, m);
+        const key16 ka = load_key16<BYTES_LDS, REV>(by, a + (uint32_t)w, true, m, top), kb = load_key16<BYTES_LDS, REV>(by, b + (uint32_t)w, true, m, top);
         if (ka.hi != kb.hi) return ka.hi < kb.hi;
         if (ka.lo != kb.lo) return ka.lo < kb.lo;
     }
     return a < b;
 }
 
-template <bool BYTES_LDS>
-__device__ __forceinline__ bool sort_less16(const uint8_t *by, uint32_t a, const key16 &ka, uint32_t b, const key16 &kb, uint32_t R, int la)
+template <bool BYTES_LDS, bool REV = false>
+__device__ __forceinline__ bool sort_less16(const uint8_t *by, uint32_t a, const key16 &ka, uint32_t b, const key16 &kb, uint32_t R, int la, uint32_t top = 0)
 {
     if (ka.hi != kb.hi) return ka.hi < kb.hi;
     if (ka.lo != kb.lo) return ka.lo < kb.lo;
     if (a >= R || b >= R) return a < b;
-    if (la > 16) return key_tail_less<BYTES_LDS>(by, a, b, la, 16);
+    if (la > 16) return key_tail_less<BYTES_LDS, REV>(by, a, b, la, 16, top);
     return a < b;
 }
 
 /* v[0..16) = outputs d .. d+15 of the merge of the sorted runs A[0..L) and A[L..2L) */
-template <class IdxT, bool BYTES_LDS>
+template <class IdxT, bool BYTES_LDS, bool REV = false>
 __device__ __forceinline__ void merge16(const IdxT *A, uint32_t L, uint32_t d, const uint8_t *by, uint32_t R, int la,
-                                        uint32_t (&v)[16])
+                                        uint32_t (&v)[16], uint32_t top = 0, uint32_t slots = 0 /* REV: slots with staged bytes (an exhausted run's index is clamped to it) */)
 {
     uint32_t m[4];
 #pragma unroll
@@ -241,16 +300,16 @@ __device__ __forceinline__ void merge16(const IdxT *A, uint32_t L, uint32_t d, c
     while (lo < hi) {                                        /* merge path: how many of the first d outputs come from A */
         const uint32_t mid = (lo + hi) >> 1;
         const uint32_t a = A[mid], b = B[d - 1 - mid];
-        const key16 ka = load_key16<BYTES_LDS>(by, a, a < R, m), kb = load_key16<BYTES_LDS>(by, b, b < R, m);
-        if (sort_less16<BYTES_LDS>(by, a, ka, b, kb, R, la)) lo = mid + 1; else hi = mid;
+        const key16 ka = load_key16<BYTES_LDS, REV>(by, a, a < R, m, top), kb = load_key16<BYTES_LDS, REV>(by, b, b < R, m, top);
+        if (sort_less16<BYTES_LDS, REV>(by, a, ka, b, kb, R, la, top)) lo = mid + 1; else hi = mid;
     }
     uint32_t ia = lo, ib = d - lo;
     bool va = ia < L, vb = ib < L;
     uint32_t a = va ? (uint32_t)A[ia] : 0xFFFFFFFFu, b = vb ? (uint32_t)B[ib] : 0xFFFFFFFFu;
-    key16 ka = load_key16<BYTES_LDS>(by, a, a < R, m), kb = load_key16<BYTES_LDS>(by, b, b < R, m);
+    key16 ka = load_key16<BYTES_LDS, REV>(by, REV ? min(a, slots) : a, a < R, m, top), kb = load_key16<BYTES_LDS, REV>(by, REV ? min(b, slots) : b, b < R, m, top);
 #pragma unroll
     for (int r = 0; r < 16; r++) {
-        const bool take_a = !vb || (va && sort_less16<BYTES_LDS>(by, a, ka, b, kb, R, la));
+        const bool take_a = !vb || (va && sort_less16<BYTES_LDS, REV>(by, a, ka, b, kb, R, la, top));
         v[r] = take_a ? a : b;
         if (r == 15) break;
         ia += take_a ? 1u : 0u;
@@ -258,7 +317,7 @@ __device__ __forceinline__ void merge16(const IdxT *A, uint32_t L, uint32_t d, c
         const uint32_t pos = take_a ? ia : L + ib;
         const bool valid = (take_a ? ia : ib) < L;
         const uint32_t nv = valid ? (uint32_t)A[pos] : 0xFFFFFFFFu;
-        const key16 nk = load_key16<BYTES_LDS>(by, nv, nv < R, m);
+        const key16 nk = load_key16<BYTES_LDS, REV>(by, REV ? min(nv, slots) : nv, nv < R, m, top);
         if (take_a) { a = nv; ka = nk; va = valid; } else { b = nv; kb = nk; vb = valid; }
     }
 }
@@ -316,14 +375,16 @@ __device__ __forceinline__ void merge_run_global(const uint32_t *A, uint32_t L, 
  * (key, index) is a strict total order, so the merge path is unique.  O(CH log CH) key compares
  * instead of the bitonic network's O(CH log^2 CH): ~3.5x fewer random LDS reads per region.
  */
-template <class IdxT, bool BYTES_LDS, uint32_t NT = MATCH_BLOCK>
+template <class IdxT, bool BYTES_LDS, uint32_t NT = MATCH_BLOCK, bool REV = false>
 __device__ __forceinline__ void region_sort_merge(IdxT *ix, const uint8_t *by, uint32_t R, int la, uint32_t tid,
-                                                  uint32_t L_first = 0 /* > 0: ix[] already holds sorted runs of L_first slots */)
+                                                  uint32_t L_first = 0 /* > 0: ix[] already holds sorted runs of L_first slots */,
+                                                  uint32_t top = 0 /* REV: offset of the dword that holds the bytes 0..3 (be32_at) */)
 {
     constexpr uint32_t CH = 16 * NT;
     const uint32_t pmask = la >= 4 ? 0xFFFFFFFFu : 0xFFFFFFFFu << (8 * (4 - la));
     auto prefix = [&](uint32_t a) -> uint32_t {
-        return a < R ? (__builtin_bswap32(ld32_at<BYTES_LDS>(by, a)) & pmask) : 0xFFFFFFFFu;
+        if constexpr (REV) return be32_at<true, true>(by, top, a) & pmask;       /* (padding slots read 0xFF bytes) */
+        else return a < R ? (__builtin_bswap32(ld32_at<BYTES_LDS>(by, a)) & pmask) : 0xFFFFFFFFu;
     };
     uint32_t v[16];
     if (!L_first) {
@@ -342,16 +403,16 @@ __device__ __forceinline__ void region_sort_merge(IdxT *ix, const uint8_t *by, u
         }
 #pragma unroll
         for (int r = 0; r < 16; r++) pf[r] = prefix(v[r]);
-        sort_local_pass<1, true, BYTES_LDS>(v, pf, by, R, la, 2, false);
-        sort_local_pass<2, true, BYTES_LDS>(v, pf, by, R, la, 4, false);
-        sort_local_pass<1, true, BYTES_LDS>(v, pf, by, R, la, 4, false);
-        sort_local_pass<4, true, BYTES_LDS>(v, pf, by, R, la, 8, false);
-        sort_local_pass<2, true, BYTES_LDS>(v, pf, by, R, la, 8, false);
-        sort_local_pass<1, true, BYTES_LDS>(v, pf, by, R, la, 8, false);
-        sort_local_pass<8, false, BYTES_LDS>(v, pf, by, R, la, 0, true);
-        sort_local_pass<4, false, BYTES_LDS>(v, pf, by, R, la, 0, true);
-        sort_local_pass<2, false, BYTES_LDS>(v, pf, by, R, la, 0, true);
-        sort_local_pass<1, false, BYTES_LDS>(v, pf, by, R, la, 0, true);
+        sort_local_pass<1, true, BYTES_LDS, REV>(v, pf, by, R, la, 2, false, top);
+        sort_local_pass<2, true, BYTES_LDS, REV>(v, pf, by, R, la, 4, false, top);
+        sort_local_pass<1, true, BYTES_LDS, REV>(v, pf, by, R, la, 4, false, top);
+        sort_local_pass<4, true, BYTES_LDS, REV>(v, pf, by, R, la, 8, false, top);
+        sort_local_pass<2, true, BYTES_LDS, REV>(v, pf, by, R, la, 8, false, top);
+        sort_local_pass<1, true, BYTES_LDS, REV>(v, pf, by, R, la, 8, false, top);
+        sort_local_pass<8, false, BYTES_LDS, REV>(v, pf, by, R, la, 0, true, top);
+        sort_local_pass<4, false, BYTES_LDS, REV>(v, pf, by, R, la, 0, true, top);
+        sort_local_pass<2, false, BYTES_LDS, REV>(v, pf, by, R, la, 0, true, top);
+        sort_local_pass<1, false, BYTES_LDS, REV>(v, pf, by, R, la, 0, true, top);
     }
     auto store_mine = [&]() {
         if constexpr (sizeof(IdxT) == 2) {
@@ -375,7 +436,7 @@ __device__ __forceinline__ void region_sort_merge(IdxT *ix, const uint8_t *by, u
         const bool wide = 2 * L > 1024;
         barrier(wide);
         const uint32_t o0 = 16 * tid, base = o0 & ~(2 * L - 1);
-        merge16<IdxT, BYTES_LDS>(ix + base, L, o0 - base, by, R, la, v);
+        merge16<IdxT, BYTES_LDS, REV>(ix + base, L, o0 - base, by, R, la, v, top, CH - 1u);
         barrier(wide);
         store_mine();
     }
@@ -400,11 +461,11 @@ __global__ __launch_bounds__(C1_BLOCK) __attribute__((amdgpu_num_sgpr(80))) void
     const uint32_t tid = threadIdx.x;
     const uint64_t base = pos0 + (uint64_t)blockIdx.x * C1_CH;
     const uint32_t Rl = base >= n ? 0u : (n - (uint32_t)base < C1_CH ? n - (uint32_t)base : C1_CH);
-    const uint32_t nb = Rl ? (Rl + (uint32_t)la + 24 + 3) & ~3u : 0u;
-    for (uint32_t i = tid * 4; i < nb; i += C1_BLOCK * 4) *reinterpret_cast<uint32_t *>(lby + i) = ld32u(in + base + i);
+    constexpr uint32_t NB = C1_CH + 256 + 24;             /* every slot's key: 4096 positions + la <= 255 + the key loads' slack */
+    if (Rl) stage_rev<C1_BLOCK>(lby, NB, in, base, n, tid);
     for (uint32_t i = tid; i < C1_CH; i += C1_BLOCK) ix[i] = (uint16_t)i;
     __syncthreads();
-    if (Rl) region_sort_merge<uint16_t, true, C1_BLOCK>(ix, lby, Rl, la, tid);
+    if (Rl) region_sort_merge<uint16_t, true, C1_BLOCK, true>(ix, lby, Rl, la, tid, 0, NB - 4u);
     uint16_t *o = out + (size_t)blockIdx.x * C1_CH;
     for (uint32_t e = tid * 8; e < C1_CH; e += C1_BLOCK * 8) *reinterpret_cast<uint4 *>(o + e) = *reinterpret_cast<const uint4 *>(ix + e);
 }
@@ -590,9 +651,14 @@ __global__ __launch_bounds__(MATCH_BLOCK, (FAST && MODE == 3) ? 8 : 1) void k_ma
         /* shared chunks: the order holds every position < n of the RP slots (the one past TILE + sb is sorted in its
          * chunk like any other), so the merge levels must see its key too */
         const uint32_t Rs = chunks ? (n - rstart < RP ? n - rstart : RP) : R;
-        const uint32_t nb = (Rs + (uint32_t)la + 8 + 3) & ~3u;
-        for (uint32_t i = tid * 4; i < nb; i += MATCH_BLOCK * 4)
-            *reinterpret_cast<uint32_t *>(stage + i) = *reinterpret_cast<const uint32_t *>(in + rstart + i);
+        if (chunks || (RP == 16 * MATCH_BLOCK && sort_variant == 0)) {
+            /* the merge sorts read their keys from the REV staging (be32_at): every slot's bytes, RP + la + slack */
+            stage_rev<MATCH_BLOCK>(stage, RP + 288u, in, rstart, n, tid);
+        } else {
+            const uint32_t nb = (Rs + (uint32_t)la + 8 + 3) & ~3u;
+            for (uint32_t i = tid * 4; i < nb; i += MATCH_BLOCK * 4)
+                *reinterpret_cast<uint32_t *>(stage + i) = *reinterpret_cast<const uint32_t *>(in + rstart + i);
+        }
         by = stage;
     } else {
         rk = reinterpret_cast<rank_t *>(scratch + (size_t)blockIdx.x * (2 * (size_t)RP + 8));
@@ -618,10 +684,10 @@ __global__ __launch_bounds__(MATCH_BLOCK, (FAST && MODE == 3) ? 8 : 1) void k_ma
     if (FAST && chunks) {
         if constexpr (FAST) {
             const uint32_t Rs = n - rstart < RP ? n - rstart : RP;
-            region_sort_merge<uint16_t, true>(reinterpret_cast<uint16_t *>(ix), by, Rs, la, tid, C1_CH);
+            region_sort_merge<uint16_t, true, MATCH_BLOCK, true>(reinterpret_cast<uint16_t *>(ix), by, Rs, la, tid, C1_CH, RP + 284u);
         }
     } else if (FAST && RP == 16 * MATCH_BLOCK && sort_variant == 0) {
-        if constexpr (FAST) region_sort_merge<uint16_t, true>(reinterpret_cast<uint16_t *>(ix), by, R, la, tid);
+        if constexpr (FAST) region_sort_merge<uint16_t, true, MATCH_BLOCK, true>(reinterpret_cast<uint16_t *>(ix), by, R, la, tid, 0, RP + 284u);
     } else if (FAST && RP == 16 * MATCH_BLOCK && sort_variant == 2) {
         if constexpr (FAST) region_sort_blocked<uint16_t, true>(reinterpret_cast<uint16_t *>(ix), by, R, la, tid, false, true);
     } else if (!FAST && RP > 16 * MATCH_BLOCK && (sort_variant & 15) == 0) {
@@ -1740,11 +1806,11 @@ __global__ __launch_bounds__(MATCH_BLOCK, 8) void k_big_chunks(const uint8_t *__
     const uint32_t tid = threadIdx.x;
     const uint64_t base = pos0 + (uint64_t)blockIdx.x * BIG_CH;
     const uint32_t Rl = base >= n ? 0u : (n - (uint32_t)base < BIG_CH ? n - (uint32_t)base : BIG_CH);
-    const uint32_t nb = Rl ? (Rl + (uint32_t)la + 24 + 3) & ~3u : 0u;
-    for (uint32_t i = tid * 4; i < nb; i += MATCH_BLOCK * 4) *reinterpret_cast<uint32_t *>(lby + i) = ld32u(in + base + i);
+    constexpr uint32_t NB = BIG_CH + 256 + 24;            /* (lds: BIG_CH + 256 + 32 bytes behind the indices) */
+    if (Rl) stage_rev<MATCH_BLOCK>(lby, NB, in, base, n, tid);
     for (uint32_t i = tid; i < BIG_CH; i += MATCH_BLOCK) ix[i] = (uint16_t)i;
     __syncthreads();
-    if (Rl) region_sort_merge<uint16_t, true>(ix, lby, Rl, la, tid);
+    if (Rl) region_sort_merge<uint16_t, true, MATCH_BLOCK, true>(ix, lby, Rl, la, tid, 0, NB - 4u);
     uint16_t *o = out + (size_t)blockIdx.x * BIG_CH;
     for (uint32_t e = tid * 8; e < BIG_CH; e += MATCH_BLOCK * 8) *reinterpret_cast<uint4 *>(o + e) = *reinterpret_cast<const uint4 *>(ix + e);
 }
