@@ -94,6 +94,7 @@ __device__ __forceinline__ uint32_t pw_rd16(const uint32_t *tab, uint32_t idx)
     return (reinterpret_cast<const uint16_t *>(tab))[idx];  /* (re-read after every barrier: pw_lds_barrier clobbers memory) */
 }
 
+#ifdef LZ77X_VARIANTS   /* (round 3's form: the cross-check of k_pw_prep_ranked, LZ77X_PW_PREP_V1) */
 /* Per group of W consecutive steps: the initial gates (every step that has both neighbours) and the round mask -- bit
  * i set <=> step i starts a new round because some step j of the current round (j < i) writes a cell step i reads (its
  * own, its predecessor's or its successor's).  tab[c - xg] = (version, lowest step of the current round that writes
@@ -159,6 +160,131 @@ __global__ __launch_bounds__(W) void k_pw_prep(const uint32_t *__restrict__ ps, 
     }
     PW_STAMP(17);
     if (blockIdx.x == 0 && threadIdx.x == 0) { PW_NOTE(18, nrounds_dbg); PW_NOTE(19, (ngroups + gridDim.x - 1) / gridDim.x); }
+}
+
+#endif
+
+/* The same round masks with the cells RANKED first (round 4).  k_pw_prep keeps a 16-bit tag for each of the W + sb cells a
+ * group can touch: 133 KB at sb 65535 -- ONE workgroup per CU -- and a compare-and-swap loop per tag.  But a group only
+ * touches the <= 3 W cells its steps read or write: mark them in a bitmap (one bit per cell: 8 KB), take word popcounts and
+ * their prefix sums, and a cell's rank among the touched cells (prefix of its word + the set bits below its own) indexes a
+ * table of 3 W 32-bit entries -- native ds_min_u32, versions that never run out, 29 KB per workgroup.  256 threads take the
+ * W steps (item q of thread t = step q * 256 + t, so a wavefront's lanes hold 64 consecutive steps and a ballot is a word
+ * of the mask): eight workgroups per CU. */
+#define PWP_T 256
+template <int W>
+__global__ __launch_bounds__(PWP_T, 8) void k_pw_prep_ranked(const uint32_t *__restrict__ ps, uint32_t nx, uint32_t tagn,
+                                                           uint64_t *__restrict__ rmask, uint64_t *__restrict__ gate0)
+{
+    constexpr int ITEMS = W / PWP_T;
+    extern __shared__ uint32_t pwp_lds[];
+    const uint32_t nw = (tagn + 31u) / 32u;                  /* words of the bitmap */
+    uint32_t *bits = pwp_lds;                                /* nw */
+    uint32_t *pref = bits + nw;                              /* nw: touched cells before the word */
+    uint32_t *tab = pref + nw;                               /* 3 W: (version, lowest step of the round that writes the cell) */
+    __shared__ uint32_t s_first[2], wsum[PWP_T / 64];
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const uint32_t ngroups = (nx + W - 1u) / W;
+    for (uint32_t i = tid; i < 3u * W; i += PWP_T) tab[i] = 0xFFFFFFFFu;
+    if (tid < 2) s_first[tid] = W;
+    uint32_t ver = 0;                                        /* counts up; code = 0x3FFFFE - ver: newer entries are smaller */
+    int par = 0;
+    const uint32_t wpt = (nw + PWP_T - 1u) / PWP_T;          /* bitmap words per thread (9 at sb 65535) */
+    for (uint32_t g = blockIdx.x; g < ngroups; g += gridDim.x) {
+        uint32_t p[ITEMS], sd[ITEMS];
+        bool has[ITEMS];
+#pragma unroll
+        for (int q = 0; q < ITEMS; q++) {
+            const uint32_t x = g * W + (uint32_t)q * PWP_T + tid;
+            const uint32_t v = x < nx ? ps[x] : 0u;
+            p[q] = v & 0xFFFFu;
+            sd[q] = v >> 16;
+            has[q] = p[q] && sd[q];
+        }
+        for (uint32_t i = tid; i < nw; i += PWP_T) bits[i] = 0u;
+        pw_lds_barrier();
+#pragma unroll
+        for (int q = 0; q < ITEMS; q++) {
+            if (has[q]) {
+                const uint32_t c0 = (uint32_t)q * PWP_T + tid, c1 = c0 + p[q], c2 = c0 + sd[q];
+                atomicOr(&bits[c0 >> 5], 1u << (c0 & 31u));
+                atomicOr(&bits[c1 >> 5], 1u << (c1 & 31u));
+                atomicOr(&bits[c2 >> 5], 1u << (c2 & 31u));
+            }
+        }
+        pw_lds_barrier();
+        {
+            /* prefix sums of the word popcounts: a thread owns wpt consecutive words */
+            const uint32_t w0 = tid * wpt;
+            uint32_t cnt = 0;
+            for (uint32_t k = 0; k < wpt; k++) cnt += w0 + k < nw ? (uint32_t)__builtin_popcount(bits[w0 + k]) : 0u;
+            uint32_t incl = cnt;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const uint32_t t = __shfl_up(incl, d, 64);
+                if (lane >= (uint32_t)d) incl += t;
+            }
+            if (lane == 63) wsum[wave] = incl;
+            pw_lds_barrier();
+            uint32_t run = incl - cnt;
+            for (uint32_t w = 0; w < wave; w++) run += wsum[w];
+            for (uint32_t k = 0; k < wpt; k++)
+                if (w0 + k < nw) { pref[w0 + k] = run; run += (uint32_t)__builtin_popcount(bits[w0 + k]); }
+        }
+        pw_lds_barrier();
+        uint32_t r0[ITEMS], r1[ITEMS], r2[ITEMS];
+#pragma unroll
+        for (int q = 0; q < ITEMS; q++) {
+            const uint32_t c0 = (uint32_t)q * PWP_T + tid, c1 = c0 + p[q], c2 = c0 + sd[q];
+            auto rank = [&](uint32_t c) { return pref[c >> 5] + (uint32_t)__builtin_popcount(bits[c >> 5] & ((1u << (c & 31u)) - 1u)); };
+            r0[q] = has[q] ? rank(c0) : 0u;
+            r1[q] = has[q] ? rank(c1) : 0u;
+            r2[q] = has[q] ? rank(c2) : 0u;
+        }
+        uint32_t isstart = tid == 0 ? 1u : 0u;               /* bit q: item q opens a round */
+        uint32_t start = 0;
+        for (;;) {
+            const uint32_t code = 0x3FFFFEu - ver;
+#pragma unroll
+            for (int q = 0; q < ITEMS; q++) {
+                const uint32_t i = (uint32_t)q * PWP_T + tid;
+                if (has[q] && i >= start) atomicMin(&tab[r2[q]], (code << 10) | i);
+            }
+            pw_lds_barrier();
+            if (tid == 0) s_first[par ^ 1] = W;
+            uint32_t first_mine = W;
+#pragma unroll
+            for (int q = 0; q < ITEMS; q++) {
+                const uint32_t i = (uint32_t)q * PWP_T + tid;
+                bool blocked = false;
+                if (has[q] && i > start) {
+                    const uint32_t t0 = tab[r0[q]], t1 = tab[r1[q]], t2 = tab[r2[q]];
+                    const bool b0 = (t0 >> 10) == code && (t0 & 1023u) < i;
+                    const bool b1 = (t1 >> 10) == code && (t1 & 1023u) < i;
+                    const bool b2 = (t2 >> 10) == code && (t2 & 1023u) < i;
+                    blocked = b0 | b1 | b2;
+                }
+                const uint64_t bm = __ballot(blocked);
+                if (bm) first_mine = min(first_mine, (uint32_t)q * PWP_T + wave * 64u + (uint32_t)__builtin_ctzll(bm));
+            }
+            if (first_mine < (uint32_t)W && lane == 0) atomicMin(&s_first[par], first_mine);
+            pw_lds_barrier();
+            const uint32_t first = s_first[par];
+            ver++;
+            par ^= 1;
+            if (first >= (uint32_t)W) break;
+            start = first;
+#pragma unroll
+            for (int q = 0; q < ITEMS; q++)
+                if ((uint32_t)q * PWP_T + tid == first) isstart |= 1u << q;
+        }
+#pragma unroll
+        for (int q = 0; q < ITEMS; q++) {
+            const uint64_t rm = __ballot((isstart >> q) & 1u), hm = __ballot(has[q]);
+            const uint32_t x0 = g * W + (uint32_t)q * PWP_T + wave * 64u;
+            if (lane == 0 && x0 < nx) { rmask[x0 >> 6] = rm; gate0[x0 >> 6] = hm; }
+        }
+    }
 }
 
 /* ------------------------------------------------------------------ forward sweep ---- */
@@ -886,16 +1012,30 @@ template <class K> static hipError_t pw_lds_attr(K kern, size_t lds)
 hipError_t lz77kw_prep(const uint32_t *d_ps, uint32_t nx, uint32_t sb_r, uint32_t W, uint64_t *d_rmask, uint64_t *d_gate0, hipStream_t s)
 {
     const uint32_t tagn = sb_r + W;                        /* cells a group can touch, relative to its first step */
-    const size_t lds = (size_t)tagn * 2;
     const uint32_t ngroups = (nx + W - 1u) / W;
     hipError_t e;
+#ifdef LZ77X_VARIANTS
+    if (LZ77X_VENV("LZ77X_PW_PREP_V1")) {                  /* round 3's tag table (one 16-bit tag per cell): the cross-check */
+        const size_t lds = (size_t)tagn * 2;
+        if (W == 1024u) {
+            if ((e = pw_lds_attr(k_pw_prep<1024>, lds)) != hipSuccess) return e;
+            const uint32_t per_cu = (uint32_t)std::max<size_t>(1, std::min<size_t>(2, ((size_t)160 * 1024) / (lds + 64)));
+            hipLaunchKernelGGL(k_pw_prep<1024>, dim3(std::min(ngroups, 256u * per_cu)), dim3(1024), lds, s, d_ps, nx, tagn, d_rmask, d_gate0);
+        } else {
+            if ((e = pw_lds_attr(k_pw_prep<256>, lds)) != hipSuccess) return e;
+            hipLaunchKernelGGL(k_pw_prep<256>, dim3(std::min(ngroups, 256u * 8u)), dim3(256), lds, s, d_ps, nx, tagn, d_rmask, d_gate0);
+        }
+        return hipGetLastError();
+    }
+#endif
+    const size_t lds = ((size_t)(tagn + 31u) / 32u * 2 + 3 * (size_t)W) * 4;
+    const uint32_t per_cu = (uint32_t)std::max<size_t>(1, std::min<size_t>(8, ((size_t)160 * 1024) / (lds + 128)));
     if (W == 1024u) {
-        if ((e = pw_lds_attr(k_pw_prep<1024>, lds)) != hipSuccess) return e;
-        const uint32_t per_cu = (uint32_t)std::max<size_t>(1, std::min<size_t>(2, ((size_t)160 * 1024) / (lds + 64)));
-        hipLaunchKernelGGL(k_pw_prep<1024>, dim3(std::min(ngroups, 256u * per_cu)), dim3(1024), lds, s, d_ps, nx, tagn, d_rmask, d_gate0);
+        if ((e = pw_lds_attr(k_pw_prep_ranked<1024>, lds)) != hipSuccess) return e;
+        hipLaunchKernelGGL(k_pw_prep_ranked<1024>, dim3(std::min(ngroups, 256u * per_cu)), dim3(PWP_T), lds, s, d_ps, nx, tagn, d_rmask, d_gate0);
     } else {
-        if ((e = pw_lds_attr(k_pw_prep<256>, lds)) != hipSuccess) return e;
-        hipLaunchKernelGGL(k_pw_prep<256>, dim3(std::min(ngroups, 256u * 8u)), dim3(256), lds, s, d_ps, nx, tagn, d_rmask, d_gate0);
+        if ((e = pw_lds_attr(k_pw_prep_ranked<256>, lds)) != hipSuccess) return e;
+        hipLaunchKernelGGL(k_pw_prep_ranked<256>, dim3(std::min(ngroups, 256u * per_cu)), dim3(PWP_T), lds, s, d_ps, nx, tagn, d_rmask, d_gate0);
     }
     return hipGetLastError();
 }

@@ -839,6 +839,10 @@ WIDE_CASES = [
     ("zeros", 0, 300000, 65535, 255, {}),
     ("text", 68, 140000, 65535, 255, {}),
     ("text", 68, 70000, 65535, 255, {}),
+    # round 3's round masks (a 16-bit tag per cell) beside the ranked cells of round 4
+    ("mixed", 65, 3 << 20, 65535, 255, {"LZ77X_PW_PREP_V1": "1"}),
+    ("lowent", 63, 400000, 20000, 100, {"LZ77X_PRIO_BLOCK": "20480", "LZ77X_PW_PREP_V1": "1"}),
+    ("code", 57, 200000, 4096, 16, {"LZ77X_PRIO_WIDE": "1024", "LZ77X_PW_PREP_V1": "1"}),
 ]
 
 
