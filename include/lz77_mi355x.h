@@ -91,7 +91,8 @@ int lz77x_decode_file(FILE *in, FILE *out);
  * bytes are identical for every shard count.  lz77x_encode cuts the input by
  * positions, lz77x_decode cuts the stream by token ranges (the sb bytes before a range reach it
  * as a map chained on the host; lz77.c:172-192 across the cuts); streams it cannot cut that way
- * (distance-0 copies of a power-of-two -s, windows above 8192) decode on one device. */
+ * (distance-0 copies of a power-of-two -s, shards shorter than a window, streams of 4 GiB and more) decode on one
+ * device, range by range. */
 int lz77x_set_shards(int shards);
 int lz77x_device_count(void);
 /* Release every cached device/pinned buffer, stream and event (they are otherwise kept for the
@@ -121,6 +122,8 @@ void lz77x_shard_compose_chain(const uint8_t *exit_of, const uint32_t *tokens_of
  * it: map[i] = a byte value, or 0x8000 | index into `incoming`; outgoing = the last sb bytes of the shard's output */
 uint64_t lz77x_shard_token_cut(uint64_t ntok, int shards, int d);
 void lz77x_shard_compose_tail(const uint16_t *map, int sb, const uint8_t *incoming, uint8_t *outgoing);
+/* the same for windows above 8192 (the tile pass, 32-bit states): map[i] = a byte value, or 0x10000 | index into `incoming` */
+void lz77x_shard_compose_tail32(const uint32_t *map, int sb, const uint8_t *incoming, uint8_t *outgoing);
 
 /* ---- several files at once (each on a context of its own, up to LZ77X_MAX_CONTEXTS at a time) -------
  * rc[i] receives the status of file i; returns 0 when all succeeded, else the first failure. */

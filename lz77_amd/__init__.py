@@ -92,6 +92,7 @@ SYMBOLS = {
     "lz77x_shard_compose_chain": (None, [_vp, _vp, _vp, _vp]),
     "lz77x_shard_token_cut": (ctypes.c_uint64, [ctypes.c_uint64, ctypes.c_int, ctypes.c_int]),
     "lz77x_shard_compose_tail": (None, [_vp, ctypes.c_int, _vp, _vp]),
+    "lz77x_shard_compose_tail32": (None, [_vp, ctypes.c_int, _vp, _vp]),
     "lz77x_encode_files": (ctypes.c_int, [ctypes.c_int, _vp, _vp, ctypes.c_int, ctypes.c_int, _vp]),
     "lz77x_decode_files": (ctypes.c_int, [ctypes.c_int, _vp, _vp, _vp]),
 }

@@ -816,6 +816,34 @@ hipError_t lz77k_dec_image(const uint8_t *d_x, const lz77k_dec_stale &Q, uint32_
     return hipGetLastError();
 }
 
+/* One stream over several devices, windows the segment walk does not take (decode_sharded): a shard runs the
+ * tile pass + jumping on [pre bytes of history | its output] BEFORE the history is known -- afterwards every byte either
+ * holds its value or points at a byte that does (inside the shard) or at a byte of the history.  The shard's last cb
+ * bytes as a map on the cb bytes before it: map[i] = a byte value, or 0x10000 | index into those bytes; the host chains
+ * the shards' maps front to back (lz77x_shard_compose_tail32), every shard then receives its history and gathers. */
+__global__ void k_dec_tail_map(const uint8_t *__restrict__ x, const uint32_t *__restrict__ ptr, const unsigned long long *__restrict__ unres,
+                               uint32_t pre, uint32_t n /* pre + the shard's bytes */, uint32_t cb, uint32_t *__restrict__ map)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= cb) return;
+    const uint32_t j = n - cb + i;                           /* (n - pre >= cb: shorter shards decode on one device) */
+    uint32_t v;
+    if (dt_unres(unres, j)) {
+        const uint32_t src = ptr[j];
+        v = src < pre ? (src >= pre - cb ? 0x10000u | (src - (pre - cb)) : 0u /* before the first byte of the stream: a zero */) : (uint32_t)x[src];
+    } else {
+        v = x[j];
+    }
+    map[i] = v;
+}
+
+hipError_t lz77k_dec_tail_map(const uint8_t *d_x, const uint32_t *d_ptr, const unsigned long long *d_unres, uint32_t pre, uint32_t n, uint32_t cb,
+                              uint32_t *d_map, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_dec_tail_map, dim3((cb + 255) / 256), dim3(256), 0, s, d_x, d_ptr, d_unres, pre, n, cb, d_map);
+    return hipGetLastError();
+}
+
 /* the largest multiple of eight k <= ntok with dst[k] <= cap (a range whose tokens expand past the output budget is cut
  * there: every range starts on a byte of the stream); res[0] = k, res[1] = dst[k] */
 __global__ void k_dec_cut(const uint32_t *__restrict__ dst, uint32_t ntok, uint32_t cap, uint32_t *__restrict__ res)

@@ -259,6 +259,9 @@ hipError_t lz77k_dec_carry(const uint8_t *d_carry_old, const uint8_t *d_out, uin
 hipError_t lz77k_dec_image(const uint8_t *d_x, const lz77k_dec_stale &Q, uint32_t sb, uint32_t W, uint32_t pre, const uint8_t *d_img_old,
                            uint8_t *d_img_new, hipStream_t s);
 hipError_t lz77k_dec_cut(const uint32_t *d_dst, uint32_t ntok, uint32_t cap, uint32_t *d_res, hipStream_t s);
+/* a shard's last cb bytes as a map on the cb bytes before it (after the tile pass and the jumping on [pre | output]) */
+hipError_t lz77k_dec_tail_map(const uint8_t *d_x, const uint32_t *d_ptr, const unsigned long long *d_unres, uint32_t pre, uint32_t n, uint32_t cb,
+                              uint32_t *d_map, hipStream_t s);
 #define LZ77K_DEC_TILE_BYTES 12288u      /* the tile pass works on tiles of this many output bytes: `pre` is a multiple of it */
 /* one pass over in_list[0..total) (or over every j < total when in_list is null); entries that moved are
  * appended to out_list, *out_count += their number */

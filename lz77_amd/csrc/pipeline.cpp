@@ -900,6 +900,7 @@ int encode_core_host(std::vector<Ctx *> &cs, const void *src, bool src_on_device
 int fetch_result(Ctx &c, uint8_t *dst, const void *d_src, size_t bytes);
 extern "C" uint64_t lz77x_shard_token_cut(uint64_t ntok, int shards, int d);
 extern "C" void lz77x_shard_compose_tail(const uint16_t *map, int sb, const uint8_t *incoming, uint8_t *outgoing);
+extern "C" void lz77x_shard_compose_tail32(const uint32_t *map, int sb, const uint8_t *incoming, uint8_t *outgoing);
 
 /* ONE stream decoded on SEVERAL devices: the tokens are cut into D contiguous ranges at multiples of
  * eight tokens (every range then starts on a byte of the stream); device d parses and scans its range and walks
@@ -923,10 +924,13 @@ int decode_sharded(std::vector<Ctx *> &cs, const uint8_t *z, size_t zn, uint8_t 
     lz77x_make_geom(&g, sb, la);
     if (g.T > 32) return LZ77X_E_FORMAT;
     const uint64_t ntok64 = ((uint64_t)zn * 8 - 32) / (uint64_t)g.T;
-    if (ntok64 > LZ77X_MAX_N) return LZ77X_E_TOOBIG;
+    if (ntok64 > LZ77X_MAX_N) return LZ77X_OK;                                  /* (the range decoder takes any length on one device) */
     const uint32_t ntok = (uint32_t)ntok64;
     const size_t D = cs.size();
-    if (!lz77k_dec_seg_supported(g) || LZ77X_VENV("LZ77X_DECODE_VARIANT") || LZ77X_VENV("LZ77X_DECODE_V1") || ntok < 64 * D) return LZ77X_OK;
+    if (la > 255 || LZ77X_VENV("LZ77X_DECODE_V1") || ntok < 64 * D) return LZ77X_OK;
+    /* windows the segment walk takes (sb <= 8192): symbolic tails per segment; above: the tile pass on [history | output]
+     * with the history still unknown (lz77k_dec_tail_map) */
+    const bool tiles = !lz77k_dec_seg_supported(g) || LZ77X_VENV("LZ77X_DECODE_VARIANT");
     const size_t usb = (size_t)sb;
     std::vector<uint32_t> k0(D + 1);
     for (size_t d = 0; d <= D; d++) k0[d] = (uint32_t)lz77x_shard_token_cut(ntok, (int)D, (int)d);
@@ -979,6 +983,68 @@ int decode_sharded(std::vector<Ctx *> &cs, const uint8_t *z, size_t zn, uint8_t 
     }
     n = o0[D];
     if (!fits || n > LZ77X_MAX_N) { HIPCHK(hipSetDevice(cs[0]->device)); return LZ77X_OK; }
+    uint8_t *buf = nullptr;
+    const uint32_t pre = tiles ? (uint32_t)((usb + LZ77K_DEC_TILE_BYTES - 1) / LZ77K_DEC_TILE_BYTES * LZ77K_DEC_TILE_BYTES) : 0u;
+    std::vector<const unsigned long long *> d_unres(D, nullptr);
+    if (tiles) {
+        /* 2t. every shard, on a host thread of its own (the jumping rounds look at a counter between passes): tile pass and
+         *     jumping on [pre bytes of history | output]; the history counts as resolved, so afterwards every byte holds its
+         *     value or points at one that does -- inside the shard or in the history; then the shard's last sb bytes as a map */
+        std::vector<std::vector<uint32_t>> tmap(D, std::vector<uint32_t>(usb));
+        rc = for_each_shard(D, [&](size_t d) -> int {
+            int rc;
+            Ctx &c = *cs[d];
+            HIPCHK(hipSetDevice(c.device));
+            hipStream_t st = c.stream;
+            Sh &S = sh[d];
+            const uint32_t N = pre + S.n;
+            if ((rc = c.out.need((size_t)N + 16))) return rc;
+            if ((rc = c.ptr.need(((size_t)N + 8) * 4))) return rc;
+            if ((rc = c.ps.need(((size_t)N + 8) * 4))) return rc;
+            if ((rc = c.cells.need(((size_t)N + 8) * 4))) return rc;
+            if ((rc = c.tstart.need(lz77k_dec_tile_tmp_bytes(N) + usb * 4 + 256))) return rc;
+            if ((rc = c.flag.need(64))) return rc;
+            uint8_t *X = c.out.as<uint8_t>();
+            HIPCHK(hipMemsetAsync(X, 0, pre, st));
+            HIPCHK(lz77k_dec_tiles(c.tokval.as<uint32_t>(), c.dst.as<uint32_t>(), S.ntok, g, X, c.ptr.as<uint32_t>(), N, c.tstart.p, &d_unres[d], st,
+                                   lz77k_dec_stale(), pre));
+            uint32_t *lists[2] = {c.ps.as<uint32_t>(), c.cells.as<uint32_t>()};
+            uint32_t *hcount = c.h_small.as<uint32_t>() + 16;
+            uint32_t total = N, rounds = 0;
+            const uint32_t *in_list = nullptr;
+            for (;;) {
+                HIPCHK(hipMemsetAsync(c.flag.p, 0, 4, st));
+                HIPCHK(lz77k_dec_jump2(c.ptr.as<uint32_t>(), d_unres[d], total, in_list, lists[rounds & 1], c.flag.as<uint32_t>(), st));
+                HIPCHK(hipMemcpyAsync(hcount, c.flag.p, 4, hipMemcpyDeviceToHost, st));
+                HIPCHK(hipStreamSynchronize(st));
+                in_list = lists[rounds & 1];
+                total = *hcount;
+                rounds += 1;
+                if (!total || rounds > 80) break;
+            }
+            uint32_t *d_map = reinterpret_cast<uint32_t *>(reinterpret_cast<uint8_t *>(c.tstart.p) + ((lz77k_dec_tile_tmp_bytes(N) + 255) & ~(size_t)255));
+            HIPCHK(lz77k_dec_tail_map(X, c.ptr.as<uint32_t>(), d_unres[d], pre, N, (uint32_t)usb, d_map, st));
+            HIPCHK(hipMemcpyAsync(tmap[d].data(), d_map, usb * 4, hipMemcpyDeviceToHost, st));
+            HIPCHK(hipStreamSynchronize(st));
+            return LZ77X_OK;
+        });
+        if (rc) return rc;
+        /* 3t. the host chains the maps (nothing lies before the first shard: zeros) */
+        std::vector<std::vector<uint8_t>> incoming(D, std::vector<uint8_t>(usb, 0));
+        for (size_t d = 0; d + 1 < D; d++) lz77x_shard_compose_tail32(tmap[d].data(), sb, incoming[d].data(), incoming[d + 1].data());
+        /* 4t. every shard: its history in, the bytes that point somewhere gathered */
+        buf = (uint8_t *)malloc(n ? (size_t)n : 1);
+        if (!buf) return LZ77X_E_NOMEM;
+        for (size_t d = 0; d < D; d++) {
+            Ctx &c = *cs[d];
+            hipError_t e = hipSetDevice(c.device);
+            uint8_t *X = c.out.as<uint8_t>();
+            if (e == hipSuccess) e = hipMemcpyAsync(X + pre - usb, incoming[d].data(), usb, hipMemcpyHostToDevice, c.stream);
+            if (e == hipSuccess) e = hipStreamSynchronize(c.stream);                 /* (incoming[] is pageable) */
+            if (e == hipSuccess) e = lz77k_dec_gather2(X, c.ptr.as<uint32_t>(), d_unres[d], pre + sh[d].n, c.stream);
+            if (e != hipSuccess) { free(buf); snprintf(g_err, sizeof g_err, "HIP: %s", hipGetErrorString(e)); return LZ77X_E_HIP; }
+        }
+    } else {
     /* 2. every shard: segment walk, tails composed into the shard's map */
     std::vector<std::vector<uint16_t>> smap(D, std::vector<uint16_t>(usb));
     for (size_t d = 0; d < D; d++) {
@@ -1002,7 +1068,7 @@ int decode_sharded(std::vector<Ctx *> &cs, const uint8_t *z, size_t zn, uint8_t 
         lz77x_shard_compose_tail(smap[d].data(), sb, incoming[d].data(), incoming[d + 1].data());
     }
     /* 4. every shard: incoming bytes in, tails resolved, flagged bytes patched, output to the host */
-    uint8_t *buf = (uint8_t *)malloc(n ? (size_t)n : 1);
+    buf = (uint8_t *)malloc(n ? (size_t)n : 1);
     if (!buf) return LZ77X_E_NOMEM;
     for (size_t d = 0; d < D; d++) {
         Ctx &c = *cs[d];
@@ -1011,11 +1077,12 @@ int decode_sharded(std::vector<Ctx *> &cs, const uint8_t *z, size_t zn, uint8_t 
         if (e == hipSuccess) e = lz77k_dec_segments_back(g, c.out.as<uint8_t>(), c.ptr.p, sh[d].n, sh[d].P, c.stream);
         if (e != hipSuccess) { free(buf); snprintf(g_err, sizeof g_err, "HIP: %s", hipGetErrorString(e)); return LZ77X_E_HIP; }
     }
+    }
     rc = for_each_shard(D, [&](size_t d) -> int {           /* the gather: every device fetches its bytes at once */
         Ctx &c = *cs[d];
         HIPCHK(hipSetDevice(c.device));
         HIPCHK(hipStreamSynchronize(c.stream));
-        return fetch_result(c, buf + o0[d], c.out.p, sh[d].n);
+        return fetch_result(c, buf + o0[d], c.out.as<uint8_t>() + pre, sh[d].n);
     });
     if (rc) { free(buf); return rc; }
     HIPCHK(hipSetDevice(cs[0]->device));
@@ -2231,6 +2298,15 @@ void lz77x_shard_compose_tail(const uint16_t *map, int sb, const uint8_t *incomi
     for (int i = 0; i < sb; i++) {
         const uint16_t x = map[i];
         outgoing[i] = (x & 0xC000u) == 0x8000u ? incoming[x & 0x3FFFu] : (uint8_t)x;
+    }
+}
+
+/* the same for windows above 8192 (the tile pass leaves 32-bit states: k_dec_tail_map) */
+void lz77x_shard_compose_tail32(const uint32_t *map, int sb, const uint8_t *incoming, uint8_t *outgoing)
+{
+    for (int i = 0; i < sb; i++) {
+        const uint32_t x = map[i];
+        outgoing[i] = (x & 0x10000u) ? incoming[x & 0xFFFFu] : (uint8_t)x;
     }
 }
 

@@ -110,6 +110,17 @@ def compose_tail(smap, incoming):
     return o
 
 
+def compose_tail32(smap, incoming):
+    """the same for windows above 8192 (32-bit states: a byte, or 0x10000 | index into the incoming bytes)"""
+    import numpy as np
+    from . import lib
+    m = np.ascontiguousarray(smap, dtype=np.uint32)
+    i = np.ascontiguousarray(incoming, dtype=np.uint8)
+    o = np.empty(m.size, dtype=np.uint8)
+    lib().lz77x_shard_compose_tail32(m.ctypes.data, int(m.size), i.ctypes.data, o.ctypes.data)
+    return o
+
+
 def aggregate_time(dt: float, dist=None) -> float:
     """MAX over ranks of a wall time (the bench contract); identity without a process group."""
     if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:

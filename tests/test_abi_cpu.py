@@ -293,7 +293,11 @@ for d in range(world):
         assert np.array_equal(incoming, truth), "bytes this decode shard starts from"
         mine_out = np.array([incoming[v - 256] if v >= 256 else v for v in outv], dtype=np.uint8)
         assert np.array_equal(mine_out, data[start:start + len(outv)]), "this shard's bytes"
-    incoming = shard.compose_tail(maps[d].astype(np.uint16), incoming)
+    nxt = shard.compose_tail(maps[d].astype(np.uint16), incoming)
+    # the 32-bit form of the same map (windows above 8192: lz77x_shard_compose_tail32) chains to the same bytes
+    m32 = np.array([0x10000 | (int(v) & 0x3FFF) if (int(v) & 0xC000) == 0x8000 else int(v) for v in maps[d]], dtype=np.uint32)
+    assert np.array_equal(shard.compose_tail32(m32, incoming), nxt)
+    incoming = nxt
     start += int(lens[d][0])
 assert start == n
 seeds = [shard.stream_seed(0x5EED0001, r) for r in range(world)]

@@ -225,12 +225,14 @@ def test_shards_give_identical_bytes(kind, seed, n, sb, la, monkeypatch):
 
 @pytest.mark.parametrize("kind,seed,n,sb,la", [("text", 91, 3_000_000, 4095, 15), ("random", 92, 1_200_000, 4095, 15),
                                               ("mixed", 93, 2_000_000, 1000, 10), ("lowent", 94, 1_500_000, 8191, 16),
-                                              ("zeros", 0, 700_000, 4095, 15), ("records", 95, 900_000, 255, 7)])
+                                              ("zeros", 0, 700_000, 4095, 15), ("records", 95, 900_000, 255, 7),
+                                              ("mixed", 96, 2_500_000, 65535, 255), ("text", 97, 1_500_000, 20000, 40),
+                                              ("lowent", 98, 1_200_000, 8193, 255)])
 def test_sharded_decode_gives_identical_bytes(kind, seed, n, sb, la, monkeypatch):
     """SURVEY 8e, decode side: the tokens cut into 2/3/4/8 ranges (one device context each, sharing the test box's GPU),
     every range decoded with the sb bytes before it as symbolic references, the shards' maps chained on the host
     (lz77.c:172-192 across the cuts): the same bytes as the reference's decoder; small decode segments so that a
-    shard holds several"""
+    shard holds several.  Windows above 8192 take the tile pass with the history unknown (k_dec_tail_map)"""
     data = synth.make(kind, n, seed)
     z = O.encode_bst(data, sb, la)
     monkeypatch.setenv("LZ77X_FAKE_DEVICES", "8")
@@ -246,11 +248,12 @@ def test_sharded_decode_gives_identical_bytes(kind, seed, n, sb, la, monkeypatch
 
 def test_sharded_decode_falls_back(monkeypatch):
     """streams the sharded decoder does not take (a power-of-two -s with distance-0 copies; fewer tokens than 64 per
-    shard; a shard shorter than the window) decode on one device, same bytes"""
+    shard; a shard shorter than the window, small or large) decode on one device, same bytes"""
     monkeypatch.setenv("LZ77X_FAKE_DEVICES", "8")
     try:
         assert L.lib().lz77x_set_shards(4) == 0
-        for data, sb, la in ((synth.text(400_000, 96), 4096, 15), (synth.text(150, 97), 4095, 15), (synth.zeros(9000), 4095, 15)):
+        for data, sb, la in ((synth.text(400_000, 96), 4096, 15), (synth.text(150, 97), 4095, 15), (synth.zeros(9000), 4095, 15),
+                             (synth.text(200_000, 98), 65535, 255), (synth.mixed(600_000, 99), 32768, 64)):
             z = O.encode_bst(data, sb, la)
             assert L.decode(z) == O.decode(z)
     finally:
