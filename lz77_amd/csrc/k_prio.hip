@@ -865,7 +865,14 @@ hipError_t lz77k_prio_maps(lz77k_prio_plan &P, hipStream_t s, bool whole, const 
         hipError_t e = lz77kw_back(P.ps, P.nx, P.sb, P.rs, P.B, P.ring_n, P.W, P.first, nb, PRIO_PTR(uint64_t, P.o_gate[P.cur]), dest, loc, P.voff, P.ncarried,
                                    PRIO_PTR(uint32_t, P.o_dirty), s);
         if (e != hipSuccess) return e;
-        if (whole && P.sb > 4096u) return hipErrorNotSupported;       /* the whole-plan map of a shard: LDS scans only */
+        if (whole && P.sb > 4096u) {
+            /* the whole-plan map of a shard, through HBM like the boundary scan (a vector of sb priorities does not fit LDS
+             * twice): every block 0 .. NB-1 -- the maps of the blocks before P.first are still there and final */
+            if ((e = lz77kw_compose_all(dest, loc, P.sb, P.rs, P.NB, P.G, gdest, gloc, PRIO_PTR(uint8_t, P.o_scan), s)) != hipSuccess) return e;
+            if (d_sdest) *d_sdest = gdest + (size_t)(P.NG + 1) * P.rs;
+            if (d_sloc) *d_sloc = gloc + (size_t)(P.NG + 1) * P.rs;
+            return hipGetLastError();
+        }
     } else {
 #ifdef LZ77X_VARIANTS
         if (LZ77X_VENV("LZ77X_PRIO_BACK_SWEEP"))                                           /* the sequential form (cross-check) */

@@ -1098,6 +1098,33 @@ size_t lz77kw_scan_tmp_bytes(uint32_t NG, uint32_t rs)
     return NG2 * rs * (2 + 4 + 4) + ((size_t)NG + NG2 + 4) * 2 * rs * 4 + 1024;
 }
 
+/* ALL the maps 0 .. nmaps-1 of a plan composed into ONE (what a shard of a stream cut over several devices sends to the
+ * host): groups of G maps composed side by side, then the group maps by one workgroup.  The result is row
+ * NG + 1 of gdest / gloc (NG = ceil(nmaps / G)); d_tmp: lz77kw_scan_tmp_bytes(NG, rs), the boundary scan's workspace. */
+hipError_t lz77kw_compose_all(const uint16_t *d_dest, const uint32_t *d_loc, uint32_t sb, uint32_t rs, uint32_t nmaps, uint32_t G,
+                              uint16_t *d_gdest, uint32_t *d_gloc, void *d_tmp, hipStream_t s)
+{
+    if (!nmaps) return hipSuccess;
+    const uint32_t NG = (nmaps + G - 1u) / G;
+    const size_t lds = (size_t)PW_MAP_HALF * 4;
+    hipError_t e;
+    if ((e = pw_lds_attr(k_pw_maps<false>, lds)) != hipSuccess) return e;
+    uint32_t G2 = 1;
+    while ((uint64_t)G2 * G2 < NG) G2++;
+    const size_t NG2 = (NG + G2 - 1) / G2 + 6;              /* (the layout of lz77kw_scan_tmp_bytes) */
+    uint8_t *t = reinterpret_cast<uint8_t *>(d_tmp);
+    uint32_t *rows1 = reinterpret_cast<uint32_t *>(t + ((NG2 * rs * 10 + 255) & ~(size_t)255));
+    uint32_t *rows2 = rows1 + (size_t)2 * NG * rs;
+    uint16_t *out_dest = d_gdest + (size_t)(NG + 1u) * rs;
+    uint32_t *out_loc = d_gloc + (size_t)(NG + 1u) * rs;
+    hipLaunchKernelGGL(k_pw_cdest, dim3(NG), dim3(PW_SCAN_T), 0, s, d_dest, sb, rs, 0u, nmaps, G, d_gdest);
+    hipLaunchKernelGGL(k_pw_maps<false>, dim3(NG), dim3(PW_MAP_T), lds, s, d_dest, d_loc, sb, rs, 0u, nmaps, G, (const uint32_t *)nullptr, d_gloc, rows1);
+    /* the NG group maps (rows 0 .. NG-1 of gdest / gloc) in sequence */
+    hipLaunchKernelGGL(k_pw_cdest, dim3(1), dim3(PW_SCAN_T), 0, s, d_gdest, sb, rs, 0u, NG, NG, out_dest);
+    hipLaunchKernelGGL(k_pw_maps<false>, dim3(1), dim3(PW_MAP_T), lds, s, d_gdest, d_gloc, sb, rs, 0u, NG, NG, (const uint32_t *)nullptr, out_loc, rows2);
+    return hipGetLastError();
+}
+
 /* in rows first+1 .. first+nmaps from in[first] through the maps first .. first+nmaps-1, groups of G; rows are rs
  * cells apart (a multiple of 8: every row 16-byte aligned).  gdest/gloc/gin: NG+2 rows each.  One workgroup applies a
  * map in ~20 us whatever else runs, so what counts is how few maps each applies in sequence: the group maps are scanned

@@ -168,6 +168,8 @@ hipError_t lz77kw_back(const uint32_t *d_ps, uint32_t nx, uint32_t sb, uint32_t 
                        const uint64_t *d_gates, uint16_t *d_dest, uint32_t *d_loc, uint32_t voff, uint32_t ncarried, const uint32_t *d_gates_changed,
                        hipStream_t s);
 size_t lz77kw_scan_tmp_bytes(uint32_t NG, uint32_t rs);
+hipError_t lz77kw_compose_all(const uint16_t *d_dest, const uint32_t *d_loc, uint32_t sb, uint32_t rs, uint32_t nmaps, uint32_t G,
+                              uint16_t *d_gdest, uint32_t *d_gloc, void *d_tmp, hipStream_t s);
 hipError_t lz77kw_scan(const uint16_t *d_dest, const uint32_t *d_loc, uint32_t *d_in, uint32_t sb, uint32_t rs, uint32_t first, uint32_t nmaps, uint32_t G,
                        uint16_t *d_gdest, uint32_t *d_gloc, uint32_t *d_gin, void *d_tmp, hipStream_t s);
 

@@ -2392,6 +2392,12 @@ int encode_sharded(std::vector<Ctx *> &cs, const uint8_t *src, size_t n, const l
         if ((rc = c.prio_tmp.need(lz77k_prio_tmp_bytes(j.nx, g.sb)))) return rc;
         if ((rc = c.chain_tmp.need(lz77k_chain_tmp_bytes((uint32_t)span, g.la)))) return rc;
         if ((rc = c.h_small.need(128))) return rc;
+        /* large windows: the regions' rank + inverse arrays stay resident for the rank-order tie-break, and the (block,
+         * first byte) buckets of the tokens of length one (as in a segment of the single-device pipeline) */
+        if (!g.fast) {
+            if ((rc = c.ranks_all.need((size_t)nregions * (2 * (size_t)g.RP + 8) * sizeof(uint32_t)))) return rc;
+            if ((rc = c.bidx.need(lz77k_tokens_index_bytes(g, idx_span)))) return rc;
+        }
         const uint32_t nsub_max = (uint32_t)((span + csub - 1) / csub);
         if ((rc = c.h_tbase.need(((size_t)nsub_max + 2 + hwords) * 4))) return rc;
         j.h = c.h_tbase.as<uint32_t>() + nsub_max + 2;
@@ -2400,7 +2406,8 @@ int encode_sharded(std::vector<Ctx *> &cs, const uint8_t *src, size_t n, const l
         HIPCHK(lz77k_fill_pad(c.in.as<uint8_t>(), j.nloc, s));
         for (uint32_t r0 = 0; r0 < nregions; r0 += batch) {
             const uint32_t nr = nregions - r0 < batch ? nregions - r0 : batch;
-            HIPCHK(lz77k_match(c.in.as<uint8_t>(), j.nloc, g, r0, nr, c.ps.as<uint32_t>(), c.maxlen.as<uint8_t>(), c.scratch.p, 0, s, nullptr, nullptr));
+            HIPCHK(lz77k_match(c.in.as<uint8_t>(), j.nloc, g, r0, nr, c.ps.as<uint32_t>(), c.maxlen.as<uint8_t>(), c.scratch.p, 0, s, nullptr,
+                               g.fast ? nullptr : c.ranks_all.as<uint32_t>()));
             launches_of[d]++;
         }
         const uint8_t *d_wexit = nullptr;
@@ -2512,10 +2519,11 @@ int encode_sharded(std::vector<Ctx *> &cs, const uint8_t *src, size_t n, const l
             const uint32_t dbase = b > usb ? (uint32_t)(b - usb) : 0u;
             const uint32_t xa = dbase > (uint32_t)g.sb ? dbase - (uint32_t)g.sb : 0u;
             HIPCHK(lz77k_xfer_index(c.ps.as<uint32_t>(), c.xval.as<uint32_t>(), xa, (uint32_t)x_done, dbase, (uint32_t)e, c.ofs.as<uint32_t>(),
-                                    c.ent.as<uint2>(), c.scantmp.p, s, 0u, c.flag.as<unsigned long long>() + 1, (uint32_t)g.sb));
+                                    c.ent.as<uint2>(), c.scantmp.p, s, 0u, c.flag.as<unsigned long long>() + 1, g.fast ? (uint32_t)g.sb : 0u));
             HIPCHK(lz77k_tokens(c.in.as<uint8_t>(), j.nloc, g, c.chain.as<uint32_t>(), j.ntok, c.maxlen.as<uint8_t>(), c.ofs.as<uint32_t>(),
-                                c.ent.as<uint2>(), dbase, (uint32_t)b, (uint32_t)e, c.tokval.as<uint32_t>() + 4, c.tstart.as<uint32_t>(), nullptr,
-                                tvariant, s, nullptr, nullptr, look, j.look, (uint32_t)j.gpos0));
+                                c.ent.as<uint2>(), dbase, (uint32_t)b, (uint32_t)e, c.tokval.as<uint32_t>() + 4, c.tstart.as<uint32_t>(),
+                                g.fast ? nullptr : c.bidx.p, tvariant, s, nullptr, g.fast ? nullptr : c.ranks_all.as<uint32_t>(), look, j.look,
+                                (uint32_t)j.gpos0));
         }
         const uint32_t have = j.ntok < 4 ? j.ntok : 4;
         if (have) HIPCHK(hipMemcpyAsync(j.h, c.tokval.as<uint32_t>() + 4 + j.ntok - have, have * 4, hipMemcpyDeviceToHost, s));
@@ -2609,9 +2617,9 @@ int encode_any(std::vector<Ctx *> &cs, const void *src, bool src_on_device, size
     const void *host_src = src;
     bool host_on_device = src_on_device;
     uint32_t iters = 0;                                    /* gate iterations spent before giving up */
-    /* (large windows: the shards' whole-plan maps would have to be composed through HBM; they take the host-assisted
-     * pipeline, which shards by chunks) */
-    if (cs.size() > 1 && !src_on_device && g.fast && device_pipeline_ok(1, g))
+    /* one stream over several devices: every window size on the device pipeline (large windows compose their shards'
+     * whole-plan maps through HBM, lz77kw_compose_all) */
+    if (cs.size() > 1 && !src_on_device && device_pipeline_ok(1, g))
         return encode_sharded(cs, reinterpret_cast<const uint8_t *>(src), n, g, sink);
     if (device_pipeline_ok(cs.size(), g)) {
         MemSource ms(src, n, src_on_device);

