@@ -469,6 +469,17 @@ __global__ __launch_bounds__(TOK_BLOCK) void k_tokens_tile(const uint8_t *__rest
 #define TS_TT 3072u
 #define TS_BLOCK 1024
 #define TS_TB 512u                                   /* tokens per batch (two lanes each in phase A) */
+/* A token whose run holds this many cells or more, few of them with hand-overs, is not dealt member by member (round 4:
+ * all-zero input spent 29 of its
+ * 37 ms per 100 MB here -- every token's run is the whole window, 4095 members each, and not one hand-over among them: a
+ * position without a predecessor in key order never hands its priority on; runs of zeros are what binaries are made of).
+ * Only a member that some eviction handed a priority to can sit below its own position in the treap;
+ * every other member's priority IS its position (tree.c:102-105: a new node is a leaf; + voff), so among those the winner is
+ * simply the OLDEST one in the window.  A big token therefore goes to one wavefront, which (1) visits the run's members WITH
+ * hand-overs through a bitmap over the sorted slots (one bit per slot: 64 slots a word) and (2) finds the oldest member
+ * without by walking the window's positions upwards from its first cell, 64 at a time, until one shares the token's bytes:
+ * cells * 64 / run positions on average instead of `run` members. */
+#define TS_BIG 1024u
 
 struct ts_grid { uint32_t sb, TILE, head, tpr; };
 
@@ -588,8 +599,10 @@ __global__ __launch_bounds__(TS_BLOCK, 8) __attribute__((amdgpu_num_sgpr(80))) v
     uint16_t *lentx = reinterpret_cast<uint16_t *>(smem + off_lent);                       /* eviction - xs0 of every list entry */
     uint32_t *lentv = reinterpret_cast<uint32_t *>(smem + off_lent + 2u * ent_cap);        /* staged: the priority it handed over */
     __shared__ uint32_t wsum[TS_BLOCK / 64], s_own[TS_BLOCK / 64];
-    __shared__ uint32_t s_total;
+    __shared__ uint32_t s_total, s_nbig, s_want;
     __shared__ uint16_t fb_lo[256], fb_hi[256];
+    __shared__ unsigned long long hl[(TS_TT + 4096 + 64 + 63) / 64];      /* bit i: the cell of sorted slot i has hand-overs (or a carried priority) */
+    __shared__ uint16_t big[TS_TB];                                       /* the batch's tokens with a run of TS_BIG cells or more */
 
     const uint32_t tid = threadIdx.x;
     const uint32_t usb = (uint32_t)sb;
@@ -748,6 +761,9 @@ __global__ __launch_bounds__(TS_BLOCK, 8) __attribute__((amdgpu_num_sgpr(80))) v
         }
     }
     __syncthreads();
+    if (tid == 0) { s_nbig = 0; s_want = 0; }
+    __syncthreads();
+    bool hl_built = false;                                 /* the bitmap of B' exists (built when the tile meets its first big run) */
 
     const uint32_t omask = ob >= 32 ? 0xFFFFFFFFu : (1u << ob) - 1u;
     for (uint32_t kb = k0; kb < k1; kb += TS_TB) {
@@ -822,6 +838,40 @@ __global__ __launch_bounds__(TS_BLOCK, 8) __attribute__((amdgpu_num_sgpr(80))) v
         {
             uint32_t cnt = 0;
             if (tid < nt && (tk_pl[tid] >> 16)) cnt = (uint32_t)tk_hi[tid] - (uint32_t)tk_lo[tid];
+            /* big runs: the first one a tile meets builds the bitmap of the slots whose cells have hand-overs */
+            if (cnt >= TS_BIG) s_want = 1u;
+            __syncthreads();
+            if (s_want) {
+                if (!hl_built) {
+                    /* (a wavefront's 64 consecutive slots are a word; a cell of a later segment's look-back counts as having
+                     * one: its carried priority is a rank, not its position) */
+                    for (uint32_t i0 = (tid & ~63u); i0 < N; i0 += TS_BLOCK) {
+                        const uint32_t i = i0 + (tid & 63u);
+                        bool h = false;
+                        if (i < N) {
+                            const uint32_t co = sorted[i];
+                            h = lofs[co + 1] != lofs[co] || wbase + co < nlook;
+                        }
+                        const unsigned long long m = __ballot(h);
+                        if ((tid & 63u) == 0) hl[i0 >> 6] = m;
+                    }
+                    hl_built = true;
+                    __syncthreads();
+                }
+                if (cnt >= TS_BIG) {
+                    /* ... a wavefront of its own (below) when few of its members have hand-overs, an eighth at most: a run
+                     * that is dense with them is cheaper member by member, dealt over the whole workgroup */
+                    const uint32_t lo = tk_lo[tid], hi = tk_hi[tid];
+                    uint32_t withl = 0;
+                    for (uint32_t wd = lo >> 6; wd <= ((hi - 1u) >> 6); wd++) {
+                        unsigned long long m = hl[wd];
+                        if (wd == (lo >> 6)) m &= ~0ull << (lo & 63u);
+                        if (wd == ((hi - 1u) >> 6) && (hi & 63u)) m &= ~0ull >> (64u - (hi & 63u));
+                        withl += (uint32_t)__popcll(m);
+                    }
+                    if (withl * 8u <= cnt) { big[atomicAdd(&s_nbig, 1u)] = (uint16_t)tid; cnt = 0; }
+                }
+            }
             const uint32_t ex = ts_wg_scan(cnt, wsum, &s_total);
             if (tid < nt) { tk_cum[tid] = ex; tk_best[tid] = ~0ull; }
             __syncthreads();
@@ -875,7 +925,86 @@ __global__ __launch_bounds__(TS_BLOCK, 8) __attribute__((amdgpu_num_sgpr(80))) v
                 }
             }
         }
+        /* ---- B': the big runs, a wavefront each ---- */
+        {
+            const uint32_t nbig = s_nbig, lane = tid & 63u, wave = tid >> 6;
+            for (uint32_t bi = wave; bi < nbig; bi += TS_BLOCK / 64u) {
+                const uint32_t ti = big[bi];
+                const uint32_t pl = tk_pl[ti], qo = pl & 0xFFFFu, len = pl >> 16;
+                const uint32_t p = wbase + qo, cmin = p > usb ? p - usb : 0u, xlim = cmin;
+                const uint32_t lo = tk_lo[ti], hi = tk_hi[ti];
+                unsigned long long best = ~0ull;
+                /* (1) the members some eviction handed a priority to: the set bits of hl over the slots [lo, hi), a word a lane */
+                for (uint32_t wd = (lo >> 6) + lane; wd <= ((hi - 1u) >> 6); wd += 64u) {
+                    unsigned long long m = hl[wd];
+                    if (wd == (lo >> 6)) m &= ~0ull << (lo & 63u);
+                    if (wd == ((hi - 1u) >> 6) && (hi & 63u)) m &= ~0ull >> (64u - (hi & 63u));
+                    while (m) {
+                        const uint32_t i = wd * 64u + (uint32_t)__builtin_ctzll(m);
+                        m &= m - 1ull;
+                        const uint32_t co = sorted[i], c = wbase + co;
+                        if (c < cmin || c >= p) continue;
+                        uint32_t prio = c < nlook ? look[c] : c + voff, latest = 0, at = 0;
+                        bool any = false;
+                        const uint32_t e1 = lofs[co + 1];
+                        for (uint32_t e = lofs[co]; e < e1; e++) {
+                            const uint32_t x = xs0 + lentx[e];
+                            if (x < xlim && (!any || x > latest)) { any = true; latest = x; at = e; }
+                        }
+                        if (any) {
+                            prio = lentv[min(at, ent_cap - 1u)];
+                            if (!staged) prio = xval[latest];
+                        }
+                        const unsigned long long key = ((unsigned long long)prio << 32) | c;
+                        best = key < best ? key : best;
+                    }
+                }
+                /* (2) the oldest member of the window without one: its priority is its position */
+                {
+                    uint32_t qw[4];
+#pragma unroll
+                    for (int w = 0; w < 4; w++) qw[w] = (uint32_t)(4 * w) < len ? ld32_at<true>(by, qo + 4 * w) : 0u;
+                    for (uint32_t c0 = max(cmin, nlook); c0 < p; c0 += 64u) {
+                        const uint32_t c = c0 + lane;
+                        bool ok = false;
+                        if (c < p) {
+                            const uint32_t co = c - wbase;
+                            ok = lofs[co + 1] == lofs[co];
+#pragma unroll
+                            for (int w = 0; w < 4; w++) {
+                                if ((uint32_t)(4 * w) < len) {
+                                    uint32_t x = ld32_at<true>(by, co + 4 * w) ^ qw[w];
+                                    const uint32_t rem = len - 4 * w;
+                                    if (rem < 4) x &= (1u << (8 * rem)) - 1u;
+                                    ok = ok && x == 0u;
+                                }
+                            }
+                            for (uint32_t i2 = 16; i2 < len && ok; i2 += 4) {
+                                uint32_t x = ld32_at<true>(by, co + i2) ^ ld32_at<true>(by, qo + i2);
+                                const uint32_t rem = len - i2;
+                                if (rem < 4) x &= (1u << (8 * rem)) - 1u;
+                                ok = x == 0u;
+                            }
+                        }
+                        const unsigned long long hit = __ballot(ok);
+                        if (hit) {
+                            const uint32_t c1 = c0 + (uint32_t)__builtin_ctzll(hit);
+                            const unsigned long long key = ((unsigned long long)(c1 + voff) << 32) | c1;
+                            best = key < best ? key : best;
+                            break;
+                        }
+                    }
+                }
+#pragma unroll
+                for (int d = 32; d > 0; d >>= 1) {
+                    const unsigned long long o = __shfl_xor(best, d, 64);
+                    best = o < best ? o : best;
+                }
+                if (lane == 0 && best != ~0ull) atomicMin(&tk_best[ti], best);
+            }
+        }
         __syncthreads();
+        if (tid == 0) { s_nbig = 0; s_want = 0; }          /* (the next batch counts its own; ordered by the barriers of phase A) */
         /* ---- C: the token ---- */
         if (tid < nt) {
             const uint32_t pl = tk_pl[tid], qo = pl & 0xFFFFu, len = pl >> 16;
@@ -1509,7 +1638,7 @@ hipError_t lz77k_tokens(const uint8_t *d_in, uint32_t n, const lz77x_geom &g, co
         const uint32_t off_lofs = (off_inv + 2 * TS_TT + 15) & ~15u;
         const uint32_t off_tk = off_lofs + 2 * 8 * TS_BLOCK;                /* eight list offsets per thread: span + 2 <= 8192 */
         const uint32_t off_lent = (off_tk + TS_TB * 8 + (TS_TB + 4) * 4 + TS_TB * 4 + TS_TB * 2 * 2 + 15) & ~15u;
-        const uint32_t budget = 78u * 1024u;                              /* two workgroups per CU */
+        const uint32_t budget = 77u * 1024u - 256u;                       /* two workgroups per CU: 160 KB less 2 x 3 KB of static LDS (hl, big, the tables) */
         /* a list entry is 6 bytes (eviction: uint16 from the tile's first, priority: uint32, two arrays); the area also
          * holds a uint16 per eviction of a tile, what the lists fall back to when the priorities do not fit */
         uint32_t ent_cap = ((budget - off_lent) / 6u) & ~1u;

@@ -462,6 +462,33 @@ def test_periodic_inputs(sb, la, period):
     assert L.decode(z) == data.tobytes()
 
 
+@pytest.mark.parametrize("seg", ["", "120000"])
+def test_long_runs_between_data(seg, monkeypatch):
+    """binary-like input: stretches of one byte (thousands long: runs of the tie-break that span the window) between
+    text, random bytes and short periods -- the tokens inside a stretch have more than a thousand equal candidates, few of
+    them with a handed-over priority: they take the tie-break's big-run path (the oldest candidate without a hand-over by
+    a walk over the window's positions, the others through a bitmap), in one segment and across segment cuts"""
+    rng = np.random.default_rng(5)
+    parts = []
+    for i in range(60):
+        parts.append(np.full(int(rng.integers(1500, 9000)), [0, 0xFF, 0x20, 0][i % 4], dtype=np.uint8))
+        kind = i % 3
+        m = int(rng.integers(200, 6000))
+        if kind == 0:
+            parts.append(synth.text(m, 700 + i))
+        elif kind == 1:
+            parts.append(synth.random_bytes(m, 800 + i))
+        else:
+            parts.append(np.tile(np.frombuffer(b"ab\x00\x00cd\x00", dtype=np.uint8), m // 7 + 1)[:m])
+    data = np.concatenate(parts)
+    want = O.encode_bst(data, 4095, 15)
+    if seg:
+        monkeypatch.setenv("LZ77X_SEGMENT", seg)
+    z = L.encode(data)
+    assert z == want
+    assert L.decode(z) == data.tobytes()
+
+
 def test_roundtrip_incompressible_large():
     """S2-like: 256 MiB of splitmix64 bytes (the match-miss path): size formulas and round trip"""
     n = 256 << 20
