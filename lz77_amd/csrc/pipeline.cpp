@@ -146,6 +146,66 @@ struct PinBuf {
     template <class T> T *as() const { return reinterpret_cast<T *>(p); }
 };
 
+/* ---- host copies between the caller's pageable memory and the pinned staging slots --------------------------------
+ * hipMemcpy on pageable memory is staged by the runtime on ONE thread (~5 GB/s: 100 MB in and 47 MB out cost an encode
+ * through lz77x_encode three times its kernels).  The buffer-level entry points stage through the context's two pinned
+ * slots themselves and cut every piece over a few host threads (memory bandwidth, not a core, is then the limit); the DMA
+ * of one slot runs while the other is filled or drained. */
+class CopyPool {
+    static constexpr int NW = 3;                          /* helpers beside the calling thread */
+    std::mutex job_mu;                                     /* one parallel copy at a time */
+    std::mutex mu;
+    std::condition_variable cv, done_cv;
+    std::thread th[NW];
+    struct Task { uint8_t *d = nullptr; const uint8_t *s = nullptr; size_t n = 0; } task[NW];
+    int pending = 0;
+    bool started = false, failed = false, stop = false;
+    void worker(int i)
+    {
+        std::unique_lock<std::mutex> lk(mu);
+        for (;;) {
+            cv.wait(lk, [&] { return stop || task[i].n; });
+            if (stop) return;
+            Task t = task[i];
+            lk.unlock();
+            memcpy(t.d, t.s, t.n);
+            lk.lock();
+            task[i].n = 0;
+            if (--pending == 0) done_cv.notify_all();
+        }
+    }
+public:
+    ~CopyPool()
+    {
+        { std::lock_guard<std::mutex> lk(mu); stop = true; }
+        cv.notify_all();
+        for (auto &t : th) if (t.joinable()) t.join();
+    }
+    void copy(void *dst, const void *src, size_t n)
+    {
+        if (n < ((size_t)2 << 20)) { memcpy(dst, src, n); return; }
+        std::lock_guard<std::mutex> job(job_mu);
+        if (!started && !failed) {
+            try { for (int i = 0; i < NW; i++) th[i] = std::thread(&CopyPool::worker, this, i); started = true; }
+            catch (...) { failed = true; }                 /* (no helpers: the caller copies alone; what did start is stopped by the destructor) */
+        }
+        if (!started) { memcpy(dst, src, n); return; }
+        const size_t part = (n / (NW + 1) + 63) & ~(size_t)63;
+        uint8_t *d = reinterpret_cast<uint8_t *>(dst);
+        const uint8_t *sp = reinterpret_cast<const uint8_t *>(src);
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            for (int i = 0; i < NW; i++) { task[i].d = d + (size_t)(i + 1) * part; task[i].s = sp + (size_t)(i + 1) * part; task[i].n = i + 1 < NW ? part : n - (size_t)NW * part; }
+            pending = NW;
+        }
+        cv.notify_all();
+        memcpy(d, sp, part);
+        std::unique_lock<std::mutex> lk(mu);
+        done_cv.wait(lk, [&] { return pending == 0; });
+    }
+};
+CopyPool g_copy;
+
 /* whatever way a multi-device function is left, the thread's current device is the one it came in with (a
  * HIPCHK return in the middle of a per-shard loop would otherwise leave another shard's device current, and the
  * next library call would rebuild every cached context there) */
@@ -898,6 +958,7 @@ int encode_core_host(std::vector<Ctx *> &cs, const void *src, bool src_on_device
 /* (the decoder proper -- decode_stream -- follows the sources and sinks it reads from and writes to) */
 
 int fetch_result(Ctx &c, uint8_t *dst, const void *d_src, size_t bytes);
+int upload_pageable(Ctx &c, uint8_t *d_dst, const uint8_t *h_src, size_t bytes);
 extern "C" uint64_t lz77x_shard_token_cut(uint64_t ntok, int shards, int d);
 extern "C" void lz77x_shard_compose_tail(const uint16_t *map, int sb, const uint8_t *incoming, uint8_t *outgoing);
 extern "C" void lz77x_shard_compose_tail32(const uint32_t *map, int sb, const uint8_t *incoming, uint8_t *outgoing);
@@ -951,7 +1012,8 @@ int decode_sharded(std::vector<Ctx *> &cs, const uint8_t *z, size_t zn, uint8_t 
         if ((rc = c.h_small.need(128))) return rc;
         HIPCHK(hipMemsetAsync(c.z.as<uint8_t>() + zb, 0, 32, s));
         HIPCHK(hipMemcpyAsync(c.z.p, z, 4, hipMemcpyHostToDevice, s));
-        HIPCHK(hipMemcpyAsync(c.z.as<uint8_t>() + 4, z + b0, b1 - b0, hipMemcpyHostToDevice, s));
+        HIPCHK(hipStreamSynchronize(s));
+        if ((rc = upload_pageable(c, c.z.as<uint8_t>() + 4, z + b0, b1 - b0))) return rc;
         if ((rc = c.tokval.need(((size_t)S.ntok + 8) * 4))) return rc;
         if ((rc = c.len1.need(((size_t)S.ntok + 8) * 4))) return rc;
         if ((rc = c.dst.need(((size_t)S.ntok + 8) * 4))) return rc;
@@ -1097,6 +1159,33 @@ int decode_sharded(std::vector<Ctx *> &cs, const uint8_t *z, size_t zn, uint8_t 
     return LZ77X_OK;
 }
 
+/* caller's pageable buffer -> device through the two pinned staging slots (the counterpart of fetch_result): the copy of
+ * piece k+1 into its slot runs while the DMA of piece k drains.  Returns when the last DMA has been waited for. */
+int upload_pageable(Ctx &c, uint8_t *d_dst, const uint8_t *h_src, size_t bytes)
+{
+    const size_t piece = (size_t)16 << 20;
+    int rc;
+    if (!bytes) return LZ77X_OK;
+    if (bytes <= 65536) { HIPCHK(hipMemcpy(d_dst, h_src, bytes, hipMemcpyHostToDevice)); return LZ77X_OK; }
+    if ((rc = need_stream(c, &Ctx::up))) return rc;
+    if ((rc = c.h_stage.need(2 * piece))) return rc;
+    uint8_t *slot[2] = {c.h_stage.as<uint8_t>(), c.h_stage.as<uint8_t>() + piece};
+    bool used[2] = {false, false};
+    size_t at = 0;
+    for (int k = 0; at < bytes; k++) {
+        const int sl = k & 1;
+        const size_t m = bytes - at < piece ? bytes - at : piece;
+        if (used[sl]) HIPCHK(hipEventSynchronize(c.ev[4 + sl]));
+        g_copy.copy(slot[sl], h_src + at, m);
+        HIPCHK(hipMemcpyAsync(d_dst + at, slot[sl], m, hipMemcpyHostToDevice, c.up));
+        HIPCHK(hipEventRecord(c.ev[4 + sl], c.up));
+        used[sl] = true;
+        at += m;
+    }
+    HIPCHK(hipStreamSynchronize(c.up));
+    return LZ77X_OK;
+}
+
 /* device -> caller's pageable buffer through two pinned staging slots: the DMA of piece k+1 runs
  * while the host copies piece k out (a direct hipMemcpy into pageable memory is ~2 GB/s) */
 int fetch_result(Ctx &c, uint8_t *dst, const void *d_src, size_t bytes)
@@ -1124,7 +1213,7 @@ int fetch_result(Ctx &c, uint8_t *dst, const void *d_src, size_t bytes)
             HIPCHK(hipEventRecord(c.ev[4 + ((k + 1) & 1)], c.copy));
             issued += m;
         }
-        memcpy(dst + done, slot[k & 1], cur);
+        g_copy.copy(dst + done, slot[k & 1], cur);
         done += cur;
         k++;
     }
@@ -1241,10 +1330,16 @@ struct Sink {
 struct MemSource : Source {
     const uint8_t *p; size_t n, at = 0; bool on_device;
     MemSource(const void *src, size_t bytes, bool dev) : p(reinterpret_cast<const uint8_t *>(src)), n(bytes), on_device(dev) {}
-    int read(Ctx &, uint8_t *d_dst, size_t want, hipStream_t s, size_t *got) override
+    int read(Ctx &c, uint8_t *d_dst, size_t want, hipStream_t s, size_t *got) override
     {
         const size_t m = n - at < want ? n - at : want;
-        if (m) HIPCHK(hipMemcpyAsync(d_dst, p + at, m, on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, s));
+        if (m && on_device) HIPCHK(hipMemcpyAsync(d_dst, p + at, m, hipMemcpyDeviceToDevice, s));
+        else if (m) {
+            /* pageable memory: through the pinned slots, the copies cut over a few threads (upload_pageable) */
+            HIPCHK(hipStreamSynchronize(s));               /* d_dst may still be read by the kernels of the segment before */
+            int rc = upload_pageable(c, d_dst, p + at, m);
+            if (rc) return rc;
+        }
         at += m;
         *got = m;
         return LZ77X_OK;
@@ -2402,7 +2497,7 @@ int encode_sharded(std::vector<Ctx *> &cs, const uint8_t *src, size_t n, const l
         if ((rc = c.h_tbase.need(((size_t)nsub_max + 2 + hwords) * 4))) return rc;
         j.h = c.h_tbase.as<uint32_t>() + nsub_max + 2;
         HIPCHK(hipMemsetAsync(c.flag.p, 0, 64, s));
-        HIPCHK(hipMemcpyAsync(c.in.p, src + j.gpos0, np, hipMemcpyHostToDevice, s));
+        if ((rc = upload_pageable(c, c.in.as<uint8_t>(), src + j.gpos0, np))) return rc;
         HIPCHK(lz77k_fill_pad(c.in.as<uint8_t>(), j.nloc, s));
         for (uint32_t r0 = 0; r0 < nregions; r0 += batch) {
             const uint32_t nr = nregions - r0 < batch ? nregions - r0 : batch;
