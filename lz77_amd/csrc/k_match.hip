@@ -651,8 +651,11 @@ __global__ __launch_bounds__(MATCH_BLOCK, (FAST && MODE == 3) ? 8 : 1) void k_ma
         /* shared chunks: the order holds every position < n of the RP slots (the one past TILE + sb is sorted in its
          * chunk like any other), so the merge levels must see its key too */
         const uint32_t Rs = chunks ? (n - rstart < RP ? n - rstart : RP) : R;
-        if (chunks || (RP == 16 * MATCH_BLOCK && sort_variant == 0)) {
-            /* the merge sorts read their keys from the REV staging (be32_at): every slot's bytes, RP + la + slack */
+        if (chunks) {
+            /* the merge levels over the shared chunks read their keys from the REV staging (be32_at): every slot's bytes,
+             * RP + la + slack.  (Only here: a slot beyond the region's positions must sort last, and in this layout such a
+             * slot lies beyond the input, where REV reads 0xFF; a region that sorts all its slots itself has padding slots
+             * INSIDE the input and keeps the forward staging with its validity selects.) */
             stage_rev<MATCH_BLOCK>(stage, RP + 288u, in, rstart, n, tid);
         } else {
             const uint32_t nb = (Rs + (uint32_t)la + 8 + 3) & ~3u;
@@ -687,7 +690,7 @@ __global__ __launch_bounds__(MATCH_BLOCK, (FAST && MODE == 3) ? 8 : 1) void k_ma
             region_sort_merge<uint16_t, true, MATCH_BLOCK, true>(reinterpret_cast<uint16_t *>(ix), by, Rs, la, tid, C1_CH, RP + 284u);
         }
     } else if (FAST && RP == 16 * MATCH_BLOCK && sort_variant == 0) {
-        if constexpr (FAST) region_sort_merge<uint16_t, true, MATCH_BLOCK, true>(reinterpret_cast<uint16_t *>(ix), by, R, la, tid, 0, RP + 284u);
+        if constexpr (FAST) region_sort_merge<uint16_t, true>(reinterpret_cast<uint16_t *>(ix), by, R, la, tid);
     } else if (FAST && RP == 16 * MATCH_BLOCK && sort_variant == 2) {
         if constexpr (FAST) region_sort_blocked<uint16_t, true>(reinterpret_cast<uint16_t *>(ix), by, R, la, tid, false, true);
     } else if (!FAST && RP > 16 * MATCH_BLOCK && (sort_variant & 15) == 0) {
