@@ -1008,13 +1008,23 @@ __global__ __launch_bounds__(64) void k_walk(const uint16_t *__restrict__ subs, 
     const uint16_t *rk = subs + ((size_t)reg * runs_per_tile + run) * SUB;
     uint32_t *of = wf + (size_t)reg * TILE + lo, *ob = wb + (size_t)reg * TILE + lo;   /* indexed by t */
 
-    for (uint32_t w = 0; w < NW; w++) bm[w * 64u + lane] = 0;
-    /* no set bit lies in a word below lo_w or above hi_w: what keeps a query that HAS no neighbour on
-     * one side (every step of a run of equal bytes: the window is the top or the bottom of the order)
-     * from scanning the whole bitmap.  Sets widen the bounds, a scan that finds nothing tightens them. */
+    /* a summary level -- bit w of it: word w of the bitmap is not empty -- behind the bitmap, word-interleaved like it
+     * (round 4).  The window's ranks are dense on text (two thirds of the bitmap: a neighbour lies in the three words at
+     * hand), but on low-entropy data they come in long stretches -- equal keys order by position, so what has left the
+     * window is a prefix of every key's stretch -- and the word-by-word scans for a far neighbour made the walkers 4.6x
+     * slower there (3.3 ms against 0.7 per 100 MB).  With the summary a far neighbour is two or three dependent reads
+     * wherever it lies, and a query that HAS no neighbour on one side (every step of a run of equal bytes) finds that out
+     * from at most NS words. */
+    const uint32_t NS = (NW + 31u) >> 5;
+#define SUM_WORD(k) bm[(NW + (k)) * 64u + lane]
+    for (uint32_t w = 0; w < NW + NS; w++) bm[w * 64u + lane] = 0;
+    /* no set bit lies in a word below lo_w or above hi_w: a query that HAS no neighbour on one side (every step of a run of
+     * equal bytes: the window is the top or the bottom of the order) answers from the bounds.  Sets widen them, a scan
+     * that finds nothing tightens them. */
     uint32_t lo_w = NW, hi_w = 0;
     auto set_bit = [&](uint32_t r) {
         atomicOr(&BM_WORD(r >> 5), 1u << (r & 31));
+        atomicOr(&SUM_WORD(r >> 10), 1u << ((r >> 5) & 31));
         lo_w = min(lo_w, r >> 5);
         hi_w = max(hi_w, r >> 5);
     };
@@ -1028,21 +1038,26 @@ __global__ __launch_bounds__(64) void k_walk(const uint16_t *__restrict__ subs, 
         v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
     };
     /* first set bit strictly above / below bit b0 of word w0, given that word and its two neighbours.  The bitmap is
-     * dense (two thirds full), so the answer nearly always lies in those three words: that case is branch-free 64-bit
-     * arithmetic (the walk is bound by the instructions and branches a lone wavefront per SIMD can issue: 2.4 ms ->
-     * see DESIGN.md); the loops over further words only run in nearly empty windows */
-    auto succ_far = [&](uint32_t w0) -> uint32_t {
-        uint32_t m = 0, w;
-        for (w = w0 + 2; w <= hi_w; w++) if ((m = BM_WORD(w))) break;
-        if (!m) hi_w = min(hi_w, w0);
-        return m ? (w << 5) + (uint32_t)__builtin_ctz(m) : WALK_NONE;
+     * dense (two thirds full) on text, so the answer nearly always lies in those three words: that case is branch-free
+     * 64-bit arithmetic (the walk is bound by the instructions and branches a lone wavefront per SIMD can issue: 2.4 ms ->
+     * see DESIGN.md); further words through the summary */
+    auto succ_far = [&](uint32_t w0) -> uint32_t {                       /* first non-empty word >= w0 + 2 */
+        const uint32_t f = w0 + 2u;
+        if (f > hi_w) return WALK_NONE;
+        uint32_t k = f >> 5, m = SUM_WORD(k) & (~0u << (f & 31u));
+        while (!m && ++k <= (hi_w >> 5)) m = SUM_WORD(k);
+        if (!m) { hi_w = min(hi_w, w0 + 1u); return WALK_NONE; }
+        const uint32_t w = (k << 5) + (uint32_t)__builtin_ctz(m);
+        return (w << 5) + (uint32_t)__builtin_ctz(BM_WORD(w));
     };
-    auto pred_far = [&](uint32_t w0) -> uint32_t {
-        uint32_t m = 0, w = w0;
-        if (w0 > 1 && w0 - 2 >= lo_w)
-            for (w = w0 - 2;; w--) { if ((m = BM_WORD(w)) || w == lo_w) break; }
-        if (!m) lo_w = max(lo_w, w0);
-        return m ? (w << 5) + 31u - (uint32_t)__builtin_clz(m) : WALK_NONE;
+    auto pred_far = [&](uint32_t w0) -> uint32_t {                       /* last non-empty word <= w0 - 2 */
+        if (w0 < 2u || w0 - 2u < lo_w) return WALK_NONE;
+        const uint32_t l = w0 - 2u;
+        uint32_t k = l >> 5, m = SUM_WORD(k) & (~0u >> (31u - (l & 31u)));
+        while (!m && k > (lo_w >> 5)) m = SUM_WORD(--k);
+        if (!m) { lo_w = max(lo_w, w0 - 1u); return WALK_NONE; }
+        const uint32_t w = (k << 5) + 31u - (uint32_t)__builtin_clz(m);
+        return (w << 5) + 31u - (uint32_t)__builtin_clz(BM_WORD(w));
     };
     /* the three-word case; returns bit 0: nothing above in them, bit 1: nothing below (the far scans are then due) */
     auto near3 = [&](uint32_t w0, uint32_t b0, uint32_t here, uint32_t next, uint32_t prev, uint32_t &su, uint32_t &pr) -> uint32_t {
@@ -1065,6 +1080,19 @@ __global__ __launch_bounds__(64) void k_walk(const uint16_t *__restrict__ subs, 
         const uint32_t here = BM_WORD(w0), next = BM_WORD(min(w0 + 1, NW - 1)), prev = BM_WORD(w0 ? w0 - 1 : 0);
         return neighbours(w0, b0, here, next, prev);
     };
+    /* (the fill leaves the summary alone -- 4095 more LDS operations per walker -- and builds it from the bitmap afterwards) */
+    auto fill_bit = [&](uint32_t r) {
+        atomicOr(&BM_WORD(r >> 5), 1u << (r & 31));
+        lo_w = min(lo_w, r >> 5);
+        hi_w = max(hi_w, r >> 5);
+    };
+    auto summarize = [&]() {
+        for (uint32_t k = 0; k < NS; k++) {
+            uint32_t m = 0;
+            for (uint32_t j = 0; j < 32u && (k << 5) + j < NW; j++) m |= BM_WORD((k << 5) + j) ? 1u << j : 0u;
+            SUM_WORD(k) = m;
+        }
+    };
     auto fill = [&](uint32_t b) {                            /* set the bits of positions [0, b) */
         uint32_t i = 0;
         for (; i + 32 <= b; i += 32) {                       /* four loads in flight: the fill is bound by their latency */
@@ -1074,15 +1102,16 @@ __global__ __launch_bounds__(64) void k_walk(const uint16_t *__restrict__ subs, 
 #pragma unroll
             for (int g4 = 0; g4 < 4; g4++)
 #pragma unroll
-                for (int j = 0; j < 8; j++) set_bit((v[g4][j >> 1] >> (16 * (j & 1))) & 0xFFFFu);
+                for (int j = 0; j < 8; j++) fill_bit((v[g4][j >> 1] >> (16 * (j & 1))) & 0xFFFFu);
         }
         for (; i + 8 <= b; i += 8) {
             uint32_t v[4];
             load8(i, v);
 #pragma unroll
-            for (int j = 0; j < 8; j++) set_bit((v[j >> 1] >> (16 * (j & 1))) & 0xFFFFu);
+            for (int j = 0; j < 8; j++) fill_bit((v[j >> 1] >> (16 * (j & 1))) & 0xFFFFu);
         }
-        for (; i < b; i++) set_bit(rk[i]);
+        for (; i < b; i++) fill_bit(rk[i]);
+        summarize();
     };
     if (head) {
         /* start of the input: y < sb looks back at [0, y) only; lane l takes y in [l*C, (l+1)*C) after setting [0, l*C) */
@@ -1119,7 +1148,9 @@ __global__ __launch_bounds__(64) void k_walk(const uint16_t *__restrict__ subs, 
         }
         resf = suq | (prq << 16);
         resb = hasy ? suy | (pry << 16) : (WALK_NONE | (WALK_NONE << 16));
-        BM_WORD(wq) = hq & ~(1u << bq);
+        const uint32_t left = hq & ~(1u << bq);
+        BM_WORD(wq) = left;
+        atomicAnd(&SUM_WORD(wq >> 5), left ? ~0u : ~(1u << (wq & 31u)));     /* (unconditional: cheaper than a branch around it) */
         r_add = ry;                                          /* position t+sb enters at the next step */
     };
     uint32_t t = 0;
@@ -1170,6 +1201,7 @@ __global__ __launch_bounds__(64) void k_walk(const uint16_t *__restrict__ subs, 
         ob[t] = b1;
     }
 #undef BM_WORD
+#undef SUM_WORD
 }
 
 /* sub-ranks -> positions -> the two per-position results of the match stage, per RUN with the run's inverse array
@@ -2150,7 +2182,8 @@ hipError_t lz77k_match(const uint8_t *d_in, uint32_t n, const lz77x_geom &g, uin
         uint32_t *wb = wf + (size_t)nregions * g.TILE;
         uint32_t *wb0 = wb + (size_t)nregions * g.TILE;
         const uint64_t walkers = (uint64_t)nregions * runs;
-        const size_t lds = (size_t)((SUB + 31) >> 5) * 64 * sizeof(uint32_t);
+        const size_t nwords = (SUB + 31) >> 5;
+        const size_t lds = (nwords + ((nwords + 31) >> 5)) * 64 * sizeof(uint32_t);      /* the lanes' bitmaps + their summaries */
         if (lds > 48 * 1024) {
             e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_walk), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             if (e != hipSuccess) return e;
