@@ -74,6 +74,21 @@ def test_ranges_through_the_file_and_device_entry_points(env, tmp_path, monkeypa
     assert r.returncode == 0 and r.stderr == b"" and open(out, "rb").read() == data.tobytes()
 
 
+@pytest.mark.parametrize("env", [RANGE_ENVS[0], RANGE_ENVS[1], RANGE_ENVS[3]], ids=[RANGE_IDS[0], RANGE_IDS[1], RANGE_IDS[3]])
+def test_golden_streams_in_ranges(env, golden, golden_dir, monkeypatch):
+    """the streams the compiled reference wrote (tests/golden/*.lz) decoded range by range: the reference's inputs"""
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    for s in golden["small"]:
+        z = open(os.path.join(golden_dir, s["stem"] + ".lz"), "rb").read()
+        want = open(os.path.join(golden_dir, s["stem"] + ".bin"), "rb").read()
+        assert L.decode(z) == want, s["stem"]
+        assert L.last_stats()["match_launches"] >= 2, s["stem"]
+    for k in golden["kat"]:
+        z = bytes.fromhex(k["lz_hex"])
+        assert L.decode(z) == bytes.fromhex(k["decoded_hex"]), (k["name"], k["sb"], k["la"])
+
+
 def _stream(tokens, sb, la):
     ob, lb = O.bitof(sb), O.bitof(la)
     T = ob + lb + 8
