@@ -462,8 +462,9 @@ def test_periodic_inputs(sb, la, period):
     assert L.decode(z) == data.tobytes()
 
 
+@pytest.mark.parametrize("entcap", ["", "64"])
 @pytest.mark.parametrize("seg", ["", "120000"])
-def test_long_runs_between_data(seg, monkeypatch):
+def test_long_runs_between_data(seg, entcap, monkeypatch):
     """binary-like input: stretches of one byte (thousands long: runs of the tie-break that span the window) between
     text, random bytes and short periods -- the tokens inside a stretch have more than a thousand equal candidates, few of
     them with a handed-over priority: they take the tie-break's big-run path (the oldest candidate without a hand-over by
@@ -484,6 +485,8 @@ def test_long_runs_between_data(seg, monkeypatch):
     want = O.encode_bst(data, 4095, 15)
     if seg:
         monkeypatch.setenv("LZ77X_SEGMENT", seg)
+    if entcap:
+        monkeypatch.setenv("LZ77X_TS_ENTCAP", entcap)        # (variants build) the lists without staged priorities
     z = L.encode(data)
     assert z == want
     assert L.decode(z) == data.tobytes()
