@@ -14,8 +14,11 @@
 #include "../../include/lz77_mi355x.h"
 
 #include <hip/hip_runtime_api.h>
+#include <errno.h>
+#include <fcntl.h>
 #include <sys/mman.h>
 #include <sys/stat.h>
+#include <unistd.h>
 #ifndef MADV_HUGEPAGE
 #define MADV_HUGEPAGE 14          /* Linux; not exposed in every compilation pass of hipcc */
 #endif
@@ -66,15 +69,15 @@ double now_ms()
 }
 
 /* LZ77X_TRACE: where a call's wall time goes besides kernels and copies (per thread, reset by the entry points) */
-thread_local double g_alloc_ms = 0, g_pin_ms = 0;
+thread_local double g_alloc_ms = 0, g_pin_ms = 0, g_fread_ms = 0, g_fwrite_ms = 0;
 thread_local size_t g_alloc_bytes = 0, g_pin_bytes = 0;
 
 void trace_allocs(const char *what)
 {
     if (!trace_on()) return;
-    fprintf(stderr, "[lz77x] %-28s hipMalloc %.2f ms (%.1f MB), pinned host %.2f ms (%.1f MB)\n", what, g_alloc_ms, g_alloc_bytes / 1e6, g_pin_ms,
-            g_pin_bytes / 1e6);
-    g_alloc_ms = g_pin_ms = 0;
+    fprintf(stderr, "[lz77x] %-28s hipMalloc %.2f ms (%.1f MB), pinned host %.2f ms (%.1f MB); in file reads %.2f ms, in file writes %.2f ms\n", what,
+            g_alloc_ms, g_alloc_bytes / 1e6, g_pin_ms, g_pin_bytes / 1e6, g_fread_ms, g_fwrite_ms);
+    g_alloc_ms = g_pin_ms = g_fread_ms = g_fwrite_ms = 0;
     g_alloc_bytes = g_pin_bytes = 0;
 }
 
@@ -157,22 +160,74 @@ class CopyPool {
     std::mutex mu;
     std::condition_variable cv, done_cv;
     std::thread th[NW];
-    struct Task { uint8_t *d = nullptr; const uint8_t *s = nullptr; size_t n = 0; } task[NW];
+    /* kind 0: memcpy(d, s, n); 1: pread(fd, d, n, off); 2: pwrite(fd, s, n, off) -- the last two until done, EOF or error */
+    struct Task { int kind = 0, fd = -1; uint8_t *d = nullptr; const uint8_t *s = nullptr; size_t n = 0; off_t off = 0; ssize_t done = 0; } task[NW + 1];
     int pending = 0;
     bool started = false, failed = false, stop = false;
+    static void run(Task &t)
+    {
+        if (t.kind == 0) { memcpy(t.d, t.s, t.n); t.done = (ssize_t)t.n; return; }
+        size_t at = 0;
+        while (at < t.n) {
+            const ssize_t r = t.kind == 1 ? pread(t.fd, t.d + at, t.n - at, t.off + (off_t)at) : pwrite(t.fd, t.s + at, t.n - at, t.off + (off_t)at);
+            if (r < 0) { if (errno == EINTR) continue; t.done = -1; return; }
+            if (r == 0) break;                             /* end of the file */
+            at += (size_t)r;
+        }
+        t.done = (ssize_t)at;
+    }
     void worker(int i)
     {
         std::unique_lock<std::mutex> lk(mu);
         for (;;) {
             cv.wait(lk, [&] { return stop || task[i].n; });
             if (stop) return;
-            Task t = task[i];
             lk.unlock();
-            memcpy(t.d, t.s, t.n);
+            run(task[i]);
             lk.lock();
             task[i].n = 0;
             if (--pending == 0) done_cv.notify_all();
         }
+    }
+    /* the job cut into NW + 1 parts; -> bytes done in order (a short part ends the count), or -1 */
+    ssize_t parallel(int kind, int fd, uint8_t *d, const uint8_t *sp, size_t n, off_t off)
+    {
+        std::lock_guard<std::mutex> job(job_mu);
+        if (!started && !failed) {
+            try { for (int i = 0; i < NW; i++) th[i] = std::thread(&CopyPool::worker, this, i); started = true; }
+            catch (...) { failed = true; }                 /* (no helpers: the caller works alone; what did start is stopped by the destructor) */
+        }
+        const int parts = started && n >= ((size_t)2 << 20) ? NW + 1 : 1;
+        const size_t part = parts == 1 ? n : (n / (size_t)parts + 4095) & ~(size_t)4095;
+        size_t want[NW + 1];
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            for (int i = 0; i < parts; i++) {
+                Task &t = task[i == 0 ? NW : i - 1];       /* part 0 is the caller's */
+                const size_t b = (size_t)i * part, e = i + 1 < parts ? b + part : n;
+                t.kind = kind; t.fd = fd; t.d = d ? d + b : nullptr; t.s = sp ? sp + b : nullptr; t.off = off + (off_t)b; t.done = 0;
+                want[i] = e > b ? e - b : 0;
+                t.n = i == 0 ? 0 : want[i];                /* (workers wake on n != 0) */
+            }
+            pending = 0;
+            for (int i = 1; i < parts; i++) pending += want[i] ? 1 : 0;
+        }
+        if (parts > 1) cv.notify_all();
+        Task mine = task[NW];
+        mine.n = want[0];
+        run(mine);
+        if (parts > 1) {
+            std::unique_lock<std::mutex> lk(mu);
+            done_cv.wait(lk, [&] { return pending == 0; });
+        }
+        ssize_t total = 0;
+        for (int i = 0; i < parts; i++) {
+            const ssize_t dn = i == 0 ? mine.done : task[i - 1].done;
+            if (dn < 0) return -1;
+            total += dn;
+            if ((size_t)dn < want[i]) break;               /* a short part: what lies behind it does not count */
+        }
+        return total;
     }
 public:
     ~CopyPool()
@@ -184,25 +239,12 @@ public:
     void copy(void *dst, const void *src, size_t n)
     {
         if (n < ((size_t)2 << 20)) { memcpy(dst, src, n); return; }
-        std::lock_guard<std::mutex> job(job_mu);
-        if (!started && !failed) {
-            try { for (int i = 0; i < NW; i++) th[i] = std::thread(&CopyPool::worker, this, i); started = true; }
-            catch (...) { failed = true; }                 /* (no helpers: the caller copies alone; what did start is stopped by the destructor) */
-        }
-        if (!started) { memcpy(dst, src, n); return; }
-        const size_t part = (n / (NW + 1) + 63) & ~(size_t)63;
-        uint8_t *d = reinterpret_cast<uint8_t *>(dst);
-        const uint8_t *sp = reinterpret_cast<const uint8_t *>(src);
-        {
-            std::lock_guard<std::mutex> lk(mu);
-            for (int i = 0; i < NW; i++) { task[i].d = d + (size_t)(i + 1) * part; task[i].s = sp + (size_t)(i + 1) * part; task[i].n = i + 1 < NW ? part : n - (size_t)NW * part; }
-            pending = NW;
-        }
-        cv.notify_all();
-        memcpy(d, sp, part);
-        std::unique_lock<std::mutex> lk(mu);
-        done_cv.wait(lk, [&] { return pending == 0; });
+        (void)parallel(0, -1, reinterpret_cast<uint8_t *>(dst), reinterpret_cast<const uint8_t *>(src), n, 0);
     }
+    /* a regular file's bytes [off, off + n) into dst / from src, cut over the threads: -> bytes moved (short at the end of
+     * the file), or -1 */
+    ssize_t read_at(int fd, void *dst, size_t n, off_t off) { return parallel(1, fd, reinterpret_cast<uint8_t *>(dst), nullptr, n, off); }
+    ssize_t write_at(int fd, const void *src, size_t n, off_t off) { return parallel(2, fd, nullptr, reinterpret_cast<const uint8_t *>(src), n, off); }
 };
 CopyPool g_copy;
 
@@ -957,8 +999,10 @@ int encode_core_host(std::vector<Ctx *> &cs, const void *src, bool src_on_device
 
 /* (the decoder proper -- decode_stream -- follows the sources and sinks it reads from and writes to) */
 
-int fetch_result(Ctx &c, uint8_t *dst, const void *d_src, size_t bytes);
-int upload_pageable(Ctx &c, uint8_t *d_dst, const uint8_t *h_src, size_t bytes);
+/* (st: an IDLE stream of the context's device the copies may use -- the caller has synchronised it -- or null: the context's
+ * staging stream, created on first use; a stream costs a short-lived process 8 ms) */
+int fetch_result(Ctx &c, uint8_t *dst, const void *d_src, size_t bytes, hipStream_t st = nullptr);
+int upload_pageable(Ctx &c, uint8_t *d_dst, const uint8_t *h_src, size_t bytes, hipStream_t st = nullptr);
 extern "C" uint64_t lz77x_shard_token_cut(uint64_t ntok, int shards, int d);
 extern "C" void lz77x_shard_compose_tail(const uint16_t *map, int sb, const uint8_t *incoming, uint8_t *outgoing);
 extern "C" void lz77x_shard_compose_tail32(const uint32_t *map, int sb, const uint8_t *incoming, uint8_t *outgoing);
@@ -1161,13 +1205,13 @@ int decode_sharded(std::vector<Ctx *> &cs, const uint8_t *z, size_t zn, uint8_t 
 
 /* caller's pageable buffer -> device through the two pinned staging slots (the counterpart of fetch_result): the copy of
  * piece k+1 into its slot runs while the DMA of piece k drains.  Returns when the last DMA has been waited for. */
-int upload_pageable(Ctx &c, uint8_t *d_dst, const uint8_t *h_src, size_t bytes)
+int upload_pageable(Ctx &c, uint8_t *d_dst, const uint8_t *h_src, size_t bytes, hipStream_t st)
 {
     const size_t piece = (size_t)16 << 20;
     int rc;
     if (!bytes) return LZ77X_OK;
     if (bytes <= 65536) { HIPCHK(hipMemcpy(d_dst, h_src, bytes, hipMemcpyHostToDevice)); return LZ77X_OK; }
-    if ((rc = need_stream(c, &Ctx::up))) return rc;
+    if (!st) { if ((rc = need_stream(c, &Ctx::up))) return rc; st = c.up; }
     if ((rc = c.h_stage.need(2 * piece))) return rc;
     uint8_t *slot[2] = {c.h_stage.as<uint8_t>(), c.h_stage.as<uint8_t>() + piece};
     bool used[2] = {false, false};
@@ -1177,22 +1221,22 @@ int upload_pageable(Ctx &c, uint8_t *d_dst, const uint8_t *h_src, size_t bytes)
         const size_t m = bytes - at < piece ? bytes - at : piece;
         if (used[sl]) HIPCHK(hipEventSynchronize(c.ev[4 + sl]));
         g_copy.copy(slot[sl], h_src + at, m);
-        HIPCHK(hipMemcpyAsync(d_dst + at, slot[sl], m, hipMemcpyHostToDevice, c.up));
-        HIPCHK(hipEventRecord(c.ev[4 + sl], c.up));
+        HIPCHK(hipMemcpyAsync(d_dst + at, slot[sl], m, hipMemcpyHostToDevice, st));
+        HIPCHK(hipEventRecord(c.ev[4 + sl], st));
         used[sl] = true;
         at += m;
     }
-    HIPCHK(hipStreamSynchronize(c.up));
+    HIPCHK(hipStreamSynchronize(st));
     return LZ77X_OK;
 }
 
 /* device -> caller's pageable buffer through two pinned staging slots: the DMA of piece k+1 runs
  * while the host copies piece k out (a direct hipMemcpy into pageable memory is ~2 GB/s) */
-int fetch_result(Ctx &c, uint8_t *dst, const void *d_src, size_t bytes)
+int fetch_result(Ctx &c, uint8_t *dst, const void *d_src, size_t bytes, hipStream_t st)
 {
     const size_t piece = (size_t)16 << 20;
     int rc;
-    if ((rc = need_stream(c, &Ctx::copy))) return rc;
+    if (!st) { if ((rc = need_stream(c, &Ctx::copy))) return rc; st = c.copy; }
     if ((rc = c.h_stage.need(2 * piece))) return rc;
     uint8_t *slot[2] = {c.h_stage.as<uint8_t>(), c.h_stage.as<uint8_t>() + piece};
     const uint8_t *src = reinterpret_cast<const uint8_t *>(d_src);
@@ -1200,8 +1244,8 @@ int fetch_result(Ctx &c, uint8_t *dst, const void *d_src, size_t bytes)
     int k = 0;
     if (bytes) {
         const size_t m = bytes < piece ? bytes : piece;
-        HIPCHK(hipMemcpyAsync(slot[0], src, m, hipMemcpyDeviceToHost, c.copy));
-        HIPCHK(hipEventRecord(c.ev[4], c.copy));
+        HIPCHK(hipMemcpyAsync(slot[0], src, m, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipEventRecord(c.ev[4], st));
         issued = m;
     }
     while (done < bytes) {
@@ -1209,8 +1253,8 @@ int fetch_result(Ctx &c, uint8_t *dst, const void *d_src, size_t bytes)
         HIPCHK(hipEventSynchronize(c.ev[4 + (k & 1)]));
         if (issued < bytes) {
             const size_t m = bytes - issued < piece ? bytes - issued : piece;
-            HIPCHK(hipMemcpyAsync(slot[(k + 1) & 1], src + issued, m, hipMemcpyDeviceToHost, c.copy));
-            HIPCHK(hipEventRecord(c.ev[4 + ((k + 1) & 1)], c.copy));
+            HIPCHK(hipMemcpyAsync(slot[(k + 1) & 1], src + issued, m, hipMemcpyDeviceToHost, st));
+            HIPCHK(hipEventRecord(c.ev[4 + ((k + 1) & 1)], st));
             issued += m;
         }
         g_copy.copy(dst + done, slot[k & 1], cur);
@@ -1219,6 +1263,30 @@ int fetch_result(Ctx &c, uint8_t *dst, const void *d_src, size_t bytes)
     }
     return LZ77X_OK;
 }
+
+/* A regular file behind a FILE* can be read and written at offsets by several threads at once (CopyPool::read_at /
+ * write_at: the page cache hands out 4-5 GB/s to one thread): its descriptor and position, or fd = -1 for anything else
+ * (a pipe, a cookie stream such as the shim's bitFILE, a file opened for appending), which keeps fread / fwrite.  The
+ * FILE's own position is put where the descriptor's work ended (raw_done). */
+struct RawFile { int fd = -1; off_t off = 0; };
+RawFile raw_file(FILE *f, bool writing)
+{
+    RawFile r;
+    const int fd = fileno(f);
+    struct stat st;
+    if (fd < 0 || fstat(fd, &st) != 0 || !S_ISREG(st.st_mode)) return r;
+    if (writing) {
+        if (fflush(f) != 0) return r;
+        const int fl = fcntl(fd, F_GETFL);
+        if (fl < 0 || (fl & O_APPEND)) return r;
+    }
+    const off_t at = ftello(f);
+    if (at < 0) return r;
+    r.fd = fd;
+    r.off = at;
+    return r;
+}
+bool raw_done(FILE *f, const RawFile &r) { return r.fd < 0 || fseeko(f, r.off, SEEK_SET) == 0; }
 
 /* FILE* -> device buffer `dst` (grown as needed, `slack` spare bytes kept behind the data), streamed
  * through the two pinned staging slots: the fread of piece k+1 overlaps the DMA of piece k.  Host
@@ -1271,20 +1339,21 @@ int stream_in(Ctx &c, FILE *f, DevBuf &dst, size_t slack, size_t *n_out)
 }
 
 /* device -> FILE*, the DMA of piece k+1 overlapping the fwrite of piece k */
-int stream_out(Ctx &c, FILE *f, const void *d_src, size_t bytes)
+int stream_out(Ctx &c, FILE *f, const void *d_src, size_t bytes, hipStream_t st = nullptr /* an idle stream to copy on, or null: the staging stream */)
 {
     const size_t piece = (size_t)16 << 20;
     int rc;
-    if ((rc = need_stream(c, &Ctx::copy))) return rc;
+    if (!st) { if ((rc = need_stream(c, &Ctx::copy))) return rc; st = c.copy; }
     if ((rc = c.h_stage.need(2 * piece))) return rc;
     uint8_t *slot[2] = {c.h_stage.as<uint8_t>(), c.h_stage.as<uint8_t>() + piece};
     const uint8_t *src = reinterpret_cast<const uint8_t *>(d_src);
     size_t issued = 0, done = 0;
     int k = 0;
+    RawFile raw = raw_file(f, true);
     if (bytes) {
         const size_t m = bytes < piece ? bytes : piece;
-        HIPCHK(hipMemcpyAsync(slot[0], src, m, hipMemcpyDeviceToHost, c.copy));
-        HIPCHK(hipEventRecord(c.ev[4], c.copy));
+        HIPCHK(hipMemcpyAsync(slot[0], src, m, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipEventRecord(c.ev[4], st));
         issued = m;
     }
     while (done < bytes) {
@@ -1292,14 +1361,24 @@ int stream_out(Ctx &c, FILE *f, const void *d_src, size_t bytes)
         HIPCHK(hipEventSynchronize(c.ev[4 + (k & 1)]));
         if (issued < bytes) {
             const size_t m = bytes - issued < piece ? bytes - issued : piece;
-            HIPCHK(hipMemcpyAsync(slot[(k + 1) & 1], src + issued, m, hipMemcpyDeviceToHost, c.copy));
-            HIPCHK(hipEventRecord(c.ev[4 + ((k + 1) & 1)], c.copy));
+            HIPCHK(hipMemcpyAsync(slot[(k + 1) & 1], src + issued, m, hipMemcpyDeviceToHost, st));
+            HIPCHK(hipEventRecord(c.ev[4 + ((k + 1) & 1)], st));
             issued += m;
         }
-        if (fwrite(slot[k & 1], 1, cur, f) != cur) { hipError_t e0 = hipStreamSynchronize(c.copy); (void)e0; return LZ77X_E_IO; }
+        bool ok;
+        const double tw = trace_on() ? now_ms() : 0;
+        if (raw.fd >= 0) {
+            ok = g_copy.write_at(raw.fd, slot[k & 1], cur, raw.off) == (ssize_t)cur;
+            raw.off += (off_t)cur;
+        } else {
+            ok = fwrite(slot[k & 1], 1, cur, f) == cur;
+        }
+        if (trace_on()) g_fwrite_ms += now_ms() - tw;
+        if (!ok) { hipError_t e0 = hipStreamSynchronize(st); (void)e0; return LZ77X_E_IO; }
         done += cur;
         k++;
     }
+    if (!raw_done(f, raw)) return LZ77X_E_IO;
     return fflush(f) == 0 ? LZ77X_OK : LZ77X_E_IO;
 }
 
@@ -1337,7 +1416,7 @@ struct MemSource : Source {
         else if (m) {
             /* pageable memory: through the pinned slots, the copies cut over a few threads (upload_pageable) */
             HIPCHK(hipStreamSynchronize(s));               /* d_dst may still be read by the kernels of the segment before */
-            int rc = upload_pageable(c, d_dst, p + at, m);
+            int rc = upload_pageable(c, d_dst, p + at, m, s);
             if (rc) return rc;
         }
         at += m;
@@ -1364,28 +1443,40 @@ struct FileSource : Source {
         /* fread of piece k+1 overlaps the DMA of piece k (two pinned staging slots) */
         const size_t piece = (size_t)16 << 20;
         int rc;
-        if ((rc = need_stream(c, &Ctx::up))) return rc;
         if ((rc = c.h_stage.need(2 * piece))) return rc;
         uint8_t *slot[2] = {c.h_stage.as<uint8_t>(), c.h_stage.as<uint8_t>() + piece};
-        HIPCHK(hipStreamSynchronize(s));                       /* d_dst may still be read by the previous segment's kernels */
+        HIPCHK(hipStreamSynchronize(s));                       /* d_dst may still be read by the previous segment's kernels; s is idle from
+                                                                  here on and carries the copies itself (no stream of their own) */
         size_t len = 0;
         bool used[2] = {false, false};
+        RawFile raw = raw_file(f, false);                      /* a regular file: its pieces are read by several threads at once */
         for (int k = 0; len < want; k++) {
             const int sl = k & 1;
             if (used[sl]) HIPCHK(hipEventSynchronize(c.ev[4 + sl]));
             const size_t ask = want - len < piece ? want - len : piece;
-            const size_t m = fread(slot[sl], 1, ask, f);
+            size_t m;
+            const double tr = trace_on() ? now_ms() : 0;
+            if (raw.fd >= 0) {
+                const ssize_t r = g_copy.read_at(raw.fd, slot[sl], ask, raw.off);
+                if (r < 0) return LZ77X_E_IO;
+                m = (size_t)r;
+                raw.off += (off_t)m;
+                if (!raw_done(f, raw)) return LZ77X_E_IO;      /* (the FILE follows: ftello / a later fread see what was consumed) */
+            } else {
+                m = fread(slot[sl], 1, ask, f);
+            }
+            if (trace_on()) g_fread_ms += now_ms() - tr;
             if (m == 0) {
-                if (ferror(f)) return LZ77X_E_IO;
+                if (raw.fd < 0 && ferror(f)) return LZ77X_E_IO;
                 break;
             }
-            HIPCHK(hipMemcpyAsync(d_dst + len, slot[sl], m, hipMemcpyHostToDevice, c.up));
-            HIPCHK(hipEventRecord(c.ev[4 + sl], c.up));
+            HIPCHK(hipMemcpyAsync(d_dst + len, slot[sl], m, hipMemcpyHostToDevice, s));
+            HIPCHK(hipEventRecord(c.ev[4 + sl], s));
             used[sl] = true;
             len += m;
             if (m < ask) break;
         }
-        HIPCHK(hipStreamSynchronize(c.up));
+        HIPCHK(hipStreamSynchronize(s));
         *got = len;
         return LZ77X_OK;
     }
@@ -1417,7 +1508,7 @@ struct HostSink : Sink {
             cap = ncap;
         }
         HIPCHK(hipStreamSynchronize(s));
-        const int rc = fetch_result(c, buf + total, d_src, bytes);
+        const int rc = fetch_result(c, buf + total, d_src, bytes, s);
         total += bytes;
         return rc;
     }
@@ -1445,7 +1536,7 @@ struct FileSink : Sink {
     {
         HIPCHK(hipStreamSynchronize(s));
         total += bytes;
-        return stream_out(c, f, d_src, bytes);
+        return stream_out(c, f, d_src, bytes, s);
     }
 };
 
@@ -2275,7 +2366,11 @@ int encode_stream_device(Ctx &c, Source &src, Sink &sink, const lz77x_geom &g, h
         else K.E = K.start + (K.cover - K.start) / csub * csub;
     };
 
-    if ((rc = load(0, nullptr))) return rc;
+    {
+        const double tl = now_ms();
+        if ((rc = load(0, nullptr))) return rc;
+        TRACE("  first segment loaded", tl);
+    }
     if ((rc = seg_front(J[0], g))) return rc;
     int prev_unfinished = -1;
     for (int k = 0;; k++) {
@@ -2298,15 +2393,19 @@ int encode_stream_device(Ctx &c, Source &src, Sink &sink, const lz77x_geom &g, h
             if ((rc = seg_front(J[(k + 1) & 1], g))) return rc;
         }
         bool fb = false;
+        const double tm = now_ms();
         if ((rc = seg_mid(K, g, carry, single, &fb, &waited))) return rc;
+        TRACE("  match stage waited for, chain + recurrence", tm);
         if (fb) { *fallback = true; *n_fallback = K.nloc; return LZ77X_OK; }
         if (prev_unfinished >= 0) {
             if ((rc = seg_finish(J[prev_unfinished & 1], carry, sink, &waited, s))) return rc;
             prev_unfinished = -1;
         }
+        const double tt = now_ms();
         if ((rc = seg_tokens(K, g, carry))) return rc;
         if (K.last) {
             if ((rc = seg_finish(K, carry, sink, &waited, s))) return rc;     /* (joins the caller's stream) */
+            TRACE("  tokens + the stream to the sink", tt);
             break;
         }
         if (pipelined) prev_unfinished = k;
