@@ -101,6 +101,7 @@ SYMBOLS = {
 VARIANTS_LIB_PATH = os.path.join(_HERE, "liblz77_mi355x_variants.so")
 _libs = {}
 _variants = False
+_last_path = None
 
 
 def use_variants(on: bool) -> None:
@@ -121,7 +122,13 @@ VARIANT_KNOBS = ("LZ77X_MATCH_VARIANT", "LZ77X_TOKEN_VARIANT", "LZ77X_SORT_VARIA
 def lib():
     """dlopen liblz77_mi355x.so (fails loudly if it has not been built).  A process that sets one of VARIANT_KNOBS -- a
     cross-check test -- gets the variants build for that call; nothing else does."""
+    global _last_path
     path = VARIANTS_LIB_PATH if (_variants or any(k in os.environ for k in VARIANT_KNOBS)) else LIB_PATH
+    if _last_path is not None and _last_path != path and _last_path in _libs:
+        # a test process that goes back and forth between the two builds: the one it leaves gives its cached device
+        # contexts and buffers back (each library caches its own -- gigabytes after a large encode)
+        _libs[_last_path].lz77x_shutdown()
+    _last_path = path
     L = _libs.get(path)
     if L is None:
         if not os.path.exists(path):
