@@ -7,21 +7,33 @@ import lz77_amd as L
 import oracle_lib as O
 from test_gpu_fuzz import _cases, _make
 
+import random
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
 t_end = time.time() + budget
 runs = 0
+rng = random.Random(seed)
 while time.time() < t_end:
     for sb, la, n, alpha, mode, s in _cases(seed, 20):
+        if rng.random() < 0.15 and sb <= 8193:
+            n = rng.randint(100_000, 500_000)                 # several blocks of the recurrence, several tiles, long runs
         data = _make(n, alpha, mode, s)
         want = O.encode_bst(data, sb, la)
+        # the encoder in one segment or a few, the decoder in one range or many (the knobs never change a byte)
+        for k in ("LZ77X_SEGMENT", "LZ77X_DECODE_RANGE", "LZ77X_DECODE_RANGE_BYTES"):
+            os.environ.pop(k, None)
+        if rng.random() < 0.3:
+            os.environ["LZ77X_SEGMENT"] = str(rng.choice([1, 30000, 100000]))
         got = L.encode(data, la, sb)
-        assert got == want, (seed, sb, la, n, alpha, mode, s)
+        assert got == want, (seed, sb, la, n, alpha, mode, s, dict(os.environ).get("LZ77X_SEGMENT"))
+        r = rng.random()
+        if r < 0.3:
+            os.environ["LZ77X_DECODE_RANGE"] = str(rng.choice([8, 64, 1000, 20000]))
+        elif r < 0.45:
+            os.environ["LZ77X_DECODE_RANGE_BYTES"] = str(rng.choice([3000, 40000]))
         dec = L.decode(want)
-        if sb & (sb - 1):
-            assert dec == data.tobytes(), (seed, sb, la, n, alpha, mode, s)
-        else:
-            assert len(dec) == data.size, (seed, sb, la, n, alpha, mode, s)
+        assert dec == (data.tobytes() if sb & (sb - 1) else O.decode(want)), (seed, sb, la, n, alpha, mode, s, os.environ.get("LZ77X_DECODE_RANGE"),
+                                                                             os.environ.get("LZ77X_DECODE_RANGE_BYTES"))
         runs += 1
     seed += 1
 print("fuzz ok: %d cases, seeds up to %d" % (runs, seed - 1))
