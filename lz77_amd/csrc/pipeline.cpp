@@ -30,6 +30,7 @@
 #include <algorithm>
 #include <atomic>
 #include <condition_variable>
+#include <deque>
 #include <mutex>
 #include <string>
 #include <thread>
@@ -306,12 +307,12 @@ struct Ctx {
     Ctx *pipe = nullptr;                     /* second context set on the same device (two segments of one stream in flight) */
     std::vector<hipEvent_t> chunk_ev, tok_ev, sort_ev, match_ev, tie_ev;
     DevBuf in, ps, maxlen, scratch, xval, chain, ofs, ent, tokval, out, scantmp;
-    DevBuf z, z2, dcarry, len1, dst, ptr, flag, tstart, bidx, cells, ranks_all, prio_tmp, chain_tmp, look;
+    DevBuf z, z2, out2, dcarry, len1, dst, ptr, flag, tstart, bidx, cells, ranks_all, prio_tmp, chain_tmp, look;
     PinBuf h_ps, h_maxlen, h_xval, h_chain, h_small, h_tok, h_stage, h_tbase;
     /* every cached buffer, so that no release path can forget one */
     std::vector<DevBuf *> dev_bufs()
     {
-        return {&in, &ps, &maxlen, &scratch, &xval, &chain, &ofs, &ent, &tokval, &out, &scantmp, &z, &z2, &dcarry, &len1, &dst, &ptr,
+        return {&in, &ps, &maxlen, &scratch, &xval, &chain, &ofs, &ent, &tokval, &out, &scantmp, &z, &z2, &out2, &dcarry, &len1, &dst, &ptr,
                 &flag, &tstart, &bidx, &cells, &ranks_all, &prio_tmp, &chain_tmp, &look};
     }
     std::vector<PinBuf *> pin_bufs() { return {&h_ps, &h_maxlen, &h_xval, &h_chain, &h_small, &h_tok, &h_stage, &h_tbase}; }
@@ -1403,6 +1404,9 @@ struct Sink {
     virtual uint8_t *direct(size_t bytes) { (void)bytes; return nullptr; }
     /* a sink of fixed capacity that has been offered more than it holds: only the count matters from here on */
     virtual bool overflowed() const { return false; }
+    /* the sink copies what it is handed out of device memory itself and blocks on the host while it does (a file, host
+     * memory): a decode of several ranges hands such a sink its ranges from a thread of its own (RangeDrain) */
+    virtual bool blocks_on_host() const { return false; }
     size_t total = 0;
 };
 
@@ -1527,6 +1531,7 @@ struct HostSink : Sink {
         return at;
     }
     uint8_t *release() { uint8_t *b = buf; buf = nullptr; return b ? b : (uint8_t *)malloc(1); }
+    bool blocks_on_host() const override { return true; }
 };
 
 struct FileSink : Sink {
@@ -1538,6 +1543,7 @@ struct FileSink : Sink {
         total += bytes;
         return stream_out(c, f, d_src, bytes, s);
     }
+    bool blocks_on_host() const override { return true; }
 };
 
 /* ---------------------------------------------------------------- decode ------------ */
@@ -1603,7 +1609,7 @@ void dec_pass_walk(const uint32_t *hdst, uint32_t ntok, const lz77x_geom &g, uin
 /* The copy resolution of one range: tokens c.tokval / c.dst [0, ntok) -> n bytes at *d_bytes (inside c.out), complete in
  * stream order on s.  K == null: the range is the whole stream. */
 int decode_resolve(Ctx &c, const lz77x_geom &g, uint32_t ntok, uint32_t n, hipStream_t s, bool stale, bool general, DecCarry *K,
-                   uint8_t **d_bytes, uint32_t *rounds_out)
+                   uint8_t **d_bytes, uint32_t *rounds_out, DevBuf &outb)
 {
     int rc;
     uint32_t rounds = 0;
@@ -1612,12 +1618,12 @@ int decode_resolve(Ctx &c, const lz77x_geom &g, uint32_t ntok, uint32_t n, hipSt
     const bool use_seg = !stale && !general && !track && lz77k_dec_seg_supported(g) && !(dv && atoi(dv)) && !LZ77X_VENV("LZ77X_DECODE_V1");
     const uint32_t pre = K && !use_seg ? K->pre : 0u;
     const uint32_t N = pre + n;
-    if ((rc = c.out.need((size_t)N + 16))) return rc;
+    if ((rc = outb.need((size_t)N + 16))) return rc;
     if ((rc = c.ptr.need(use_seg ? ((size_t)N + 8) * 2 : ((size_t)N + 8) * 4))) return rc;
     if ((rc = c.flag.need(64))) return rc;
     if ((rc = c.h_small.need(128))) return rc;
     uint8_t *hdr = c.h_small.as<uint8_t>();
-    uint8_t *X = c.out.as<uint8_t>();
+    uint8_t *X = outb.as<uint8_t>();
     *d_bytes = X + pre;
     lz77k_dec_stale Q;
     std::vector<uint32_t> cyc;
@@ -1725,7 +1731,7 @@ void dec_range_plan(const lz77x_geom &g, size_t avail, uint32_t *range_tokens, u
     /* a device with less to spare (device_budget) gets smaller ranges: per token two stream buffers + token words, lengths
      * and offsets; per output byte the byte itself + a 16-bit reference (segment walk) or a pointer and two work-list
      * entries (tile pass / per-byte pointers) */
-    const double per_tok = 2.0 * g.T / 8.0 + 12.5, per_byte = lz77k_dec_seg_supported(g) ? 3.3 : 13.3;
+    const double per_tok = 2.0 * g.T / 8.0 + 12.5, per_byte = lz77k_dec_seg_supported(g) ? 4.3 : 14.3;     /* (two output buffers: RangeDrain) */
     const double need = 1.125 * (per_tok * (double)R + per_byte * (double)cap) + 64e6;
     if (avail && need > 0.9 * (double)avail) {
         const double f = 0.9 * (double)avail / need;
@@ -1737,6 +1743,86 @@ void dec_range_plan(const lz77x_geom &g, size_t avail, uint32_t *range_tokens, u
     *range_tokens = (uint32_t)R;
     *range_bytes = (uint32_t)cap;
 }
+
+int ctx_sibling(Ctx &c, Ctx **out);
+
+/* A decode of several ranges: the bytes of range r leave -- D2H through pinned slots, then fwrite / pwrite or a copy into the
+ * caller's buffer: host work, a quarter of a second per gigabyte -- while range r + 1 is read, parsed and resolved (two
+ * ranges in flight: two output buffers, the sibling context's stream, slots and events for the drain).  One thread, first
+ * in first out, so a sink sees its bytes in order. */
+struct RangeDrain {
+    struct Job { const uint8_t *d = nullptr; size_t n = 0; hipEvent_t ready = nullptr; };
+    Sink *sink = nullptr;
+    Ctx *dc = nullptr;                    /* the context whose stream / staging slots the drain uses */
+    std::thread th;
+    std::mutex mu;
+    std::condition_variable cv;
+    std::deque<Job> q;
+    uint64_t submitted = 0, done = 0;
+    int rc = LZ77X_OK;
+    char err[256] = "";
+    bool stop = false, started = false;
+    void run()
+    {
+        hipError_t e = hipSetDevice(dc->device);
+        (void)e;
+        for (;;) {
+            Job j;
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                cv.wait(lk, [&] { return stop || !q.empty(); });
+                if (q.empty()) return;
+                j = q.front();
+                q.pop_front();
+            }
+            int r = LZ77X_OK;
+            g_err[0] = 0;
+            if (rc == LZ77X_OK) {
+                if (hipStreamWaitEvent(dc->stream, j.ready, 0) != hipSuccess) r = LZ77X_E_HIP;
+                else r = sink->write(*dc, j.d, j.n, dc->stream);
+            }
+            {
+                std::lock_guard<std::mutex> lk(mu);
+                if (r != LZ77X_OK && rc == LZ77X_OK) { rc = r; snprintf(err, sizeof err, "%s", g_err); }
+                done++;
+            }
+            cv.notify_all();
+        }
+    }
+    int start(Sink *sk, Ctx *drain_ctx)
+    {
+        sink = sk;
+        dc = drain_ctx;
+        try { th = std::thread(&RangeDrain::run, this); started = true; }
+        catch (...) { return LZ77X_E_NOMEM; }
+        return LZ77X_OK;
+    }
+    /* the bytes [d, d + n) are complete once `ready` has passed */
+    int submit(const uint8_t *d, size_t n, hipEvent_t ready)
+    {
+        std::lock_guard<std::mutex> lk(mu);
+        if (rc != LZ77X_OK) { snprintf(g_err, sizeof g_err, "%s", err); return rc; }
+        q.push_back(Job{d, n, ready});
+        submitted++;
+        cv.notify_all();
+        return LZ77X_OK;
+    }
+    /* until at most `in_flight` submitted jobs are unfinished */
+    int wait(uint64_t in_flight)
+    {
+        std::unique_lock<std::mutex> lk(mu);
+        cv.wait(lk, [&] { return submitted - done <= in_flight; });
+        if (rc != LZ77X_OK) snprintf(g_err, sizeof g_err, "%s", err);
+        return rc;
+    }
+    ~RangeDrain()
+    {
+        if (!started) return;
+        { std::lock_guard<std::mutex> lk(mu); stop = true; }
+        cv.notify_all();
+        th.join();
+    }
+};
 
 /* The decoder: stream from `src` (its first four bytes are the header, lz77.c:157-158), bytes to `sink` (null: only the
  * decoded size is wanted).  s: the stream every kernel is enqueued on. */
@@ -1773,6 +1859,10 @@ int decode_stream(Ctx &c, Source &src, Sink *sink, hipStream_t s, uint64_t *n_ou
     }
     const size_t rbytes = (size_t)R / 8 * (size_t)g.T;                        /* R tokens are exactly this many bytes */
     DevBuf *zb[2] = {&c.z, &c.z2};
+    DevBuf *outb[2] = {&c.out, &c.out2};
+    RangeDrain drain;                                      /* (joined on every way out of this function) */
+    bool use_drain = false;
+    const bool pipelined = !(getenv("LZ77X_PIPELINE") && atoi(getenv("LZ77X_PIPELINE")) == 0);
     DecCarry K;
     bool have_k = false;
     uint64_t total_out = 0, total_tok = 0, zn = 4;
@@ -1852,9 +1942,24 @@ int decode_stream(Ctx &c, Source &src, Sink *sink, hipStream_t s, uint64_t *n_ou
         }
         if (sink && !sink->overflowed() && n) {
             uint8_t *d_bytes = nullptr;
-            if ((rc = decode_resolve(c, g, use, n, s, stale, general, have_k ? &K : nullptr, &d_bytes, &rounds))) return rc;
+            /* several ranges into a sink that blocks on the host: two in flight -- this range resolves into the buffer the
+             * range before last has left, while the last one's bytes are still on their way out (RangeDrain) */
+            const bool async = have_k && pipelined && sink->blocks_on_host();
+            if (use_drain && (rc = drain.wait(1))) return rc;
+            DevBuf &ob = *outb[async ? (range_idx & 1u) : 0u];
+            if ((rc = decode_resolve(c, g, use, n, s, stale, general, have_k ? &K : nullptr, &d_bytes, &rounds, ob))) return rc;
             HIPCHK(hipEventRecord(c.ev[1], s));
-            if ((rc = sink->write(c, d_bytes, n, s))) return rc;
+            if (async) {
+                if (!use_drain) {
+                    Ctx *dc = nullptr;
+                    if ((rc = ctx_sibling(c, &dc))) return rc;
+                    if ((rc = drain.start(sink, dc))) return rc;
+                    use_drain = true;
+                }
+                hipEvent_t ready = c.pipe_ev[range_idx & 1u];
+                HIPCHK(hipEventRecord(ready, s));
+                if ((rc = drain.submit(d_bytes, n, ready))) return rc;
+            } else if ((rc = sink->write(c, d_bytes, n, s))) return rc;
         } else {
             HIPCHK(hipEventRecord(c.ev[1], s));
             if (sink) sink->total += n;
@@ -1876,6 +1981,7 @@ int decode_stream(Ctx &c, Source &src, Sink *sink, hipStream_t s, uint64_t *n_ou
         }
         cur ^= L ? 1 : 0;
     }
+    if (use_drain && (rc = drain.wait(0))) return rc;
     *n_out = total_out;
     g_stats.k_decode_ms = k_ms;
     g_stats.n = total_out;
