@@ -66,6 +66,36 @@ __device__ __forceinline__ bool sort_less(const uint8_t *by, uint32_t a, uint32_
     return la > 16 ? key_tail_less<BYTES_LDS, REV>(by, a, b, la, 0, top) : key_less_v<BYTES_LDS, REV>(by, top, a, b, la);
 }
 
+/* The merge sort's register stage on 16-bit slot indices (round 4): an element is ONE 64-bit word, the key's first six
+ * bytes above the index, and a compare-exchange one 64-bit compare and four selects; the byte loop is behind "the six
+ * bytes tie".  (With four cached bytes beside the index, one compare-exchange in four had some lane of the wavefront tie
+ * and take all 64 through that loop.) */
+template <bool BYTES_LDS, bool REV>
+__device__ __forceinline__ bool packed_less(const uint8_t *by, uint64_t xa, uint64_t xb, uint32_t R, int la, uint32_t top)
+{
+    if ((xa ^ xb) >> 16) return xa < xb;
+    const uint32_t a = (uint32_t)xa & 0xFFFFu, b = (uint32_t)xb & 0xFFFFu;
+    if (a >= R || b >= R) return a < b;
+    return la > 6 ? key_tail_less<BYTES_LDS, REV>(by, a, b, la, 6, top) : a < b;
+}
+
+template <int J, bool STATIC_DIR, bool BYTES_LDS, bool REV>
+__device__ __forceinline__ void sort_packed_pass(uint64_t (&x)[16], const uint8_t *by, uint32_t R, int la, int k_static, bool up_uniform, uint32_t top)
+{
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+        if (r & J) continue;
+        const int s = r | J;
+        const bool up = STATIC_DIR ? ((r & k_static) == 0) : up_uniform;
+        const bool s_lt_r = packed_less<BYTES_LDS, REV>(by, x[s], x[r], R, la, top);
+        if (up ? s_lt_r : !s_lt_r) {
+            const uint64_t t = x[r];
+            x[r] = x[s];
+            x[s] = t;
+        }
+    }
+}
+
 template <int J, bool STATIC_DIR, bool BYTES_LDS, bool REV = false>
 __device__ __forceinline__ void sort_local_pass(uint32_t (&v)[16], uint32_t (&pf)[16], const uint8_t *by, uint32_t R, int la,
                                                 int k_static, bool up_uniform, uint32_t top = 0)
@@ -381,38 +411,69 @@ __device__ __forceinline__ void region_sort_merge(IdxT *ix, const uint8_t *by, u
                                                   uint32_t top = 0 /* REV: offset of the dword that holds the bytes 0..3 (be32_at) */)
 {
     constexpr uint32_t CH = 16 * NT;
-    const uint32_t pmask = la >= 4 ? 0xFFFFFFFFu : 0xFFFFFFFFu << (8 * (4 - la));
-    auto prefix = [&](uint32_t a) -> uint32_t {
-        if constexpr (REV) return be32_at<true, true>(by, top, a) & pmask;       /* (padding slots read 0xFF bytes) */
-        else return a < R ? (__builtin_bswap32(ld32_at<BYTES_LDS>(by, a)) & pmask) : 0xFFFFFFFFu;
-    };
     uint32_t v[16];
     if (!L_first) {
-        uint32_t pf[16];
         if constexpr (sizeof(IdxT) == 2) {
-            const uint4 a = *reinterpret_cast<const uint4 *>(ix + 16 * tid), b = *reinterpret_cast<const uint4 *>(ix + 16 * tid + 8);
-            const uint32_t w[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+            const uint64_t pmask = la >= 6 ? ~0xFFFFull : ~0ull << (8 * (8 - la));
+            auto prefix = [&](uint32_t a) -> uint64_t {                           /* the key's first six bytes, big-endian, << 16 */
+                if constexpr (REV) {
+                    /* (padding slots read 0xFF bytes); the dwords at the offsets top - a - 4 and top - a */
+                    const uint32_t lo = top - 4u - a;
+                    const uint32_t *w = reinterpret_cast<const uint32_t *>(by + (lo & ~3u));
+                    const uint32_t w0 = w[0], w1 = w[1], w2 = w[2], sh = lo & 3u;
+                    return (((uint64_t)__builtin_amdgcn_alignbyte(w2, w1, sh) << 32) | __builtin_amdgcn_alignbyte(w1, w0, sh)) & pmask;
+                } else {
+                    if (a >= R) return ~0xFFFFull;
+                    return (((uint64_t)__builtin_bswap32(ld32_at<BYTES_LDS>(by, a)) << 32) | __builtin_bswap32(ld32_at<BYTES_LDS>(by, a + 4u))) & pmask;
+                }
+            };
+            uint64_t x[16];
+            {
+                const uint4 a = *reinterpret_cast<const uint4 *>(ix + 16 * tid), b = *reinterpret_cast<const uint4 *>(ix + 16 * tid + 8);
+                const uint32_t w[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
 #pragma unroll
-            for (int r = 0; r < 16; r++) v[r] = (w[r >> 1] >> (16 * (r & 1))) & 0xFFFFu;
+                for (int r = 0; r < 16; r++) {
+                    const uint32_t i = (w[r >> 1] >> (16 * (r & 1))) & 0xFFFFu;
+                    x[r] = prefix(i) | i;
+                }
+            }
+            sort_packed_pass<1, true, BYTES_LDS, REV>(x, by, R, la, 2, false, top);
+            sort_packed_pass<2, true, BYTES_LDS, REV>(x, by, R, la, 4, false, top);
+            sort_packed_pass<1, true, BYTES_LDS, REV>(x, by, R, la, 4, false, top);
+            sort_packed_pass<4, true, BYTES_LDS, REV>(x, by, R, la, 8, false, top);
+            sort_packed_pass<2, true, BYTES_LDS, REV>(x, by, R, la, 8, false, top);
+            sort_packed_pass<1, true, BYTES_LDS, REV>(x, by, R, la, 8, false, top);
+            sort_packed_pass<8, false, BYTES_LDS, REV>(x, by, R, la, 0, true, top);
+            sort_packed_pass<4, false, BYTES_LDS, REV>(x, by, R, la, 0, true, top);
+            sort_packed_pass<2, false, BYTES_LDS, REV>(x, by, R, la, 0, true, top);
+            sort_packed_pass<1, false, BYTES_LDS, REV>(x, by, R, la, 0, true, top);
+#pragma unroll
+            for (int r = 0; r < 16; r++) v[r] = (uint32_t)x[r] & 0xFFFFu;
         } else {
+            const uint32_t pmask = la >= 4 ? 0xFFFFFFFFu : 0xFFFFFFFFu << (8 * (4 - la));
+            auto prefix = [&](uint32_t a) -> uint32_t {
+                if constexpr (REV) return be32_at<true, true>(by, top, a) & pmask;       /* (padding slots read 0xFF bytes) */
+                else return a < R ? (__builtin_bswap32(ld32_at<BYTES_LDS>(by, a)) & pmask) : 0xFFFFFFFFu;
+            };
+            uint32_t pf[16];
 #pragma unroll
             for (int r = 0; r < 16; r += 4) {
                 const uint4 a = *reinterpret_cast<const uint4 *>(ix + 16 * tid + r);
                 v[r] = a.x; v[r + 1] = a.y; v[r + 2] = a.z; v[r + 3] = a.w;
             }
-        }
 #pragma unroll
-        for (int r = 0; r < 16; r++) pf[r] = prefix(v[r]);
-        sort_local_pass<1, true, BYTES_LDS, REV>(v, pf, by, R, la, 2, false, top);
-        sort_local_pass<2, true, BYTES_LDS, REV>(v, pf, by, R, la, 4, false, top);
-        sort_local_pass<1, true, BYTES_LDS, REV>(v, pf, by, R, la, 4, false, top);
-        sort_local_pass<4, true, BYTES_LDS, REV>(v, pf, by, R, la, 8, false, top);
-        sort_local_pass<2, true, BYTES_LDS, REV>(v, pf, by, R, la, 8, false, top);
-        sort_local_pass<1, true, BYTES_LDS, REV>(v, pf, by, R, la, 8, false, top);
-        sort_local_pass<8, false, BYTES_LDS, REV>(v, pf, by, R, la, 0, true, top);
-        sort_local_pass<4, false, BYTES_LDS, REV>(v, pf, by, R, la, 0, true, top);
-        sort_local_pass<2, false, BYTES_LDS, REV>(v, pf, by, R, la, 0, true, top);
-        sort_local_pass<1, false, BYTES_LDS, REV>(v, pf, by, R, la, 0, true, top);
+            for (int r = 0; r < 16; r++) pf[r] = prefix(v[r]);
+            sort_local_pass<1, true, BYTES_LDS, REV>(v, pf, by, R, la, 2, false, top);
+            sort_local_pass<2, true, BYTES_LDS, REV>(v, pf, by, R, la, 4, false, top);
+            sort_local_pass<1, true, BYTES_LDS, REV>(v, pf, by, R, la, 4, false, top);
+            sort_local_pass<4, true, BYTES_LDS, REV>(v, pf, by, R, la, 8, false, top);
+            sort_local_pass<2, true, BYTES_LDS, REV>(v, pf, by, R, la, 8, false, top);
+            sort_local_pass<1, true, BYTES_LDS, REV>(v, pf, by, R, la, 8, false, top);
+            sort_local_pass<8, false, BYTES_LDS, REV>(v, pf, by, R, la, 0, true, top);
+            sort_local_pass<4, false, BYTES_LDS, REV>(v, pf, by, R, la, 0, true, top);
+            sort_local_pass<2, false, BYTES_LDS, REV>(v, pf, by, R, la, 0, true, top);
+            sort_local_pass<1, false, BYTES_LDS, REV>(v, pf, by, R, la, 0, true, top);
+        }
     }
     auto store_mine = [&]() {
         if constexpr (sizeof(IdxT) == 2) {
@@ -453,7 +514,7 @@ __device__ __forceinline__ void region_sort_merge(IdxT *ix, const uint8_t *by, u
 #define C1_CH 4096u
 #define C1_BLOCK 256
 
-__global__ __launch_bounds__(C1_BLOCK) __attribute__((amdgpu_num_sgpr(80))) void k_c1_chunks(const uint8_t *__restrict__ in, uint32_t n, int la, uint64_t pos0,
+__global__ __launch_bounds__(C1_BLOCK) __attribute__((amdgpu_num_sgpr(80), amdgpu_waves_per_eu(6, 6))) void k_c1_chunks(const uint8_t *__restrict__ in, uint32_t n, int la, uint64_t pos0,
                                                        uint16_t *__restrict__ out)
 {
     __shared__ __attribute__((aligned(16))) uint16_t ix[C1_CH];

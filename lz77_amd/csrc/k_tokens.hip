@@ -905,18 +905,21 @@ __global__ __launch_bounds__(TS_BLOCK, 8) __attribute__((amdgpu_num_sgpr(80))) v
                         const uint32_t c = wbase + co;
                         if (c < cmin || c >= p) continue;
                         /* the latest hand-over into c by an eviction before p (x + sb < p), else what c came with */
-                        uint32_t prio = c < nlook ? look[c] : c + voff, latest = 0, at = 0;
-                        bool any = false;
+                        /* A hand-over only ever LOWERS its cell (k_prio_fwd stores xval[x] under `gate & lower`; tree.c:202-231:
+                         * the successor moves UP into x's place), so the latest one before p is also the smallest one before p: a
+                         * plain minimum over the list's entries in time, nothing to track */
+                        uint32_t prio = c < nlook ? look[c] : c + voff;
                         const uint32_t e1 = lofs[co + 1];
-                        for (uint32_t e = lofs[co]; e < e1; e++) {
-                            const uint32_t x = xs0 + lentx[e];
-                            if (x < xlim && (!any || x > latest)) { any = true; latest = x; at = e; }
-                        }
-                        if (any) {
-                            /* (never `staged ? lentv[at] : xval[latest]`: the compiler turns that into ONE flat load through a
-                             * selected generic pointer, behind s_waitcnt vmcnt(0) lgkmcnt(0), for every member with a hand-over) */
-                            prio = lentv[min(at, ent_cap - 1u)];
-                            if (!staged) prio = xval[latest];
+                        if (staged) {
+                            for (uint32_t e = lofs[co]; e < e1; e++) {
+                                const uint32_t x = xs0 + lentx[e], v = lentv[e];
+                                prio = x < xlim ? min(prio, v) : prio;
+                            }
+                        } else {
+                            for (uint32_t e = lofs[co]; e < e1; e++) {
+                                const uint32_t x = xs0 + lentx[e];
+                                if (x < xlim) prio = min(prio, xval[x]);
+                            }
                         }
                         const unsigned long long key = ((unsigned long long)prio << 32) | c;
                         best = key < best ? key : best;
