@@ -247,7 +247,9 @@ public:
     ssize_t read_at(int fd, void *dst, size_t n, off_t off) { return parallel(1, fd, reinterpret_cast<uint8_t *>(dst), nullptr, n, off); }
     ssize_t write_at(int fd, const void *src, size_t n, off_t off) { return parallel(2, fd, nullptr, reinterpret_cast<const uint8_t *>(src), n, off); }
 };
-CopyPool g_copy;
+CopyPool g_copy;                                           /* towards the device: copies out of pageable memory, file reads */
+CopyPool g_copy_out;                                       /* away from it: copies into pageable memory, file writes -- an encode of several
+                                                              segments reads its next one while the last one's words are written */
 
 /* whatever way a multi-device function is left, the thread's current device is the one it came in with (a
  * HIPCHK return in the middle of a per-shard loop would otherwise leave another shard's device current, and the
@@ -305,6 +307,8 @@ struct Ctx {
     hipEvent_t pipe_ev[3] = {};              /* [0] this context's input has arrived, [1] its last segment's result is out,
                                                 [2] the parse chain (runs beside the recurrence on `tok`) is done */
     Ctx *pipe = nullptr;                     /* second context set on the same device (two segments of one stream in flight) */
+    Ctx *drain = nullptr;                    /* a stream and two pinned slots for the thread that hands an encode's segments to a
+                                                file or host memory while the next ones are computed (nothing else is used) */
     std::vector<hipEvent_t> chunk_ev, tok_ev, sort_ev, match_ev, tie_ev;
     DevBuf in, ps, maxlen, scratch, xval, chain, ofs, ent, tokval, out, scantmp;
     DevBuf z, z2, out2, dcarry, len1, dst, ptr, flag, tstart, bidx, cells, ranks_all, prio_tmp, chain_tmp, look;
@@ -1258,7 +1262,7 @@ int fetch_result(Ctx &c, uint8_t *dst, const void *d_src, size_t bytes, hipStrea
             HIPCHK(hipEventRecord(c.ev[4 + ((k + 1) & 1)], st));
             issued += m;
         }
-        g_copy.copy(dst + done, slot[k & 1], cur);
+        g_copy_out.copy(dst + done, slot[k & 1], cur);
         done += cur;
         k++;
     }
@@ -1369,7 +1373,7 @@ int stream_out(Ctx &c, FILE *f, const void *d_src, size_t bytes, hipStream_t st 
         bool ok;
         const double tw = trace_on() ? now_ms() : 0;
         if (raw.fd >= 0) {
-            ok = g_copy.write_at(raw.fd, slot[k & 1], cur, raw.off) == (ssize_t)cur;
+            ok = g_copy_out.write_at(raw.fd, slot[k & 1], cur, raw.off) == (ssize_t)cur;
             raw.off += (off_t)cur;
         } else {
             ok = fwrite(slot[k & 1], 1, cur, f) == cur;
@@ -1394,6 +1398,9 @@ struct Source {
     /* up to `want` bytes to device address d_dst, enqueued on / ordered with stream s; fewer only at the end */
     virtual int read(Ctx &c, uint8_t *d_dst, size_t want, hipStream_t s, size_t *got) = 0;
     virtual size_t size_hint() const { return 0; }            /* bytes still to come, when known */
+    /* the bytes come out of host memory or a file: reading them keeps a host thread busy (an encode then loads its next
+     * segment from a thread of its own, beside the recurrence of the current one) */
+    virtual bool host_backed() const { return false; }
 };
 struct Sink {
     virtual ~Sink() {}
@@ -1428,11 +1435,13 @@ struct MemSource : Source {
         return LZ77X_OK;
     }
     size_t size_hint() const override { return n - at; }
+    bool host_backed() const override { return !on_device; }
 };
 
 struct FileSource : Source {
     FILE *f;
     explicit FileSource(FILE *file) : f(file) {}
+    bool host_backed() const override { return true; }
     size_t size_hint() const override
     {
         /* regular files only (a pipe has no size): what lies between the read position and the end */
@@ -2277,7 +2286,8 @@ int seg_tokens(SegJob &J, const lz77x_geom &g, const SegCarry &carry)
     return LZ77X_OK;
 }
 
-int seg_finish(SegJob &J, SegCarry &carry, Sink &sink, double *waited, hipStream_t caller)
+int seg_finish(SegJob &J, SegCarry &carry, Sink &sink, double *waited, hipStream_t caller, RangeDrain *dr = nullptr /* a sink that
+                   blocks on the host, behind a thread of its own: the segment's words are handed over, not written here */)
 {
     Ctx &c = *J.c;
     hipStream_t s = J.s;
@@ -2289,8 +2299,11 @@ int seg_finish(SegJob &J, SegCarry &carry, Sink &sink, double *waited, hipStream
         for (uint32_t i = 0; i < J.have_tail; i++) carry.tail[4 - J.have_tail + i] = c.h_small.as<uint32_t>()[20 + i];
         carry.ntail = J.have_tail;
     }
-    if ((rc = sink.write(c, c.out.as<uint8_t>(), (size_t)J.out_bytes, s))) return rc;
-    if (caller && caller != s) {
+    if (dr) {
+        HIPCHK(hipEventRecord(c.pipe_ev[1], s));
+        if ((rc = dr->submit(c.out.as<uint8_t>(), (size_t)J.out_bytes, c.pipe_ev[1]))) return rc;
+    } else if ((rc = sink.write(c, c.out.as<uint8_t>(), (size_t)J.out_bytes, s))) return rc;
+    if (!dr && caller && caller != s) {
         /* a device sink copies on this segment's stream: the caller's stream must see every segment's words, not
          * only those of the last one (an odd segment runs on the sibling stream) */
         HIPCHK(hipEventRecord(c.pipe_ev[1], s));
@@ -2333,6 +2346,15 @@ int ctx_sibling(Ctx &c, Ctx **out)
     int rc = ctx_init(*c.pipe, c.device);
     if (rc) return rc;
     *out = c.pipe;
+    return LZ77X_OK;
+}
+
+int ctx_drain(Ctx &c, Ctx **out)
+{
+    if (!c.drain) c.drain = new Ctx();
+    int rc = ctx_init(*c.drain, c.device);
+    if (rc) return rc;
+    *out = c.drain;
     return LZ77X_OK;
 }
 
@@ -2379,6 +2401,13 @@ int encode_stream_device(Ctx &c, Source &src, Sink &sink, const lz77x_geom &g, h
             const size_t hint = src.size_hint();
             const char *sp = LZ77X_VENV("LZ77X_SPLIT");
             if (sp && atoi(sp) && pipelined && hint >= ((size_t)32 << 20) && hint / 2 + csub < seg) seg = (hint / 2 + csub) / csub * csub;
+            /* a long input out of host memory or a file (or one of unknown length: a pipe): segments of 128 MB, so that
+             * the bytes of the next one travel -- from a thread of its own -- while the recurrence of this one runs, and
+             * the stream of the one before leaves while this one's kernels run.  In one segment of 2^30 the whole input
+             * crosses PCIe before the first kernel starts (1 GB of text from host memory: 162 ms against 108 resident;
+             * eight segments cost the resident case 117) */
+            const size_t host_seg = ((size_t)128 << 20) / csub * csub;
+            if (pipelined && g.fast && src.host_backed() && (hint == 0 || hint > 3 * host_seg) && seg > host_seg) seg = host_seg;
         }
         /* a source of known size below a segment: buffers sized for it, not for 2^30 positions (the whole input
          * is then one segment: want = seg + halo > what is left, so the first load sees the end) */
@@ -2419,6 +2448,7 @@ int encode_stream_device(Ctx &c, Source &src, Sink &sink, const lz77x_geom &g, h
     }
     Ctx *cx[2] = {&c, &c};
     hipStream_t sx[2] = {s, s};            /* (the second context set: created when a second segment turns up) */
+    double t_finish = 0, t_tokens = 0, t_join = 0, t_front = 0;
     SegCarry carry;
     SegJob J[2];
     uint64_t n_total = 0;
@@ -2472,6 +2502,19 @@ int encode_stream_device(Ctx &c, Source &src, Sink &sink, const lz77x_geom &g, h
         else K.E = K.start + (K.cover - K.start) / csub * csub;
     };
 
+    /* a file or host memory as the sink of several segments: a thread of its own copies a segment's words out of the device
+     * and writes them (RangeDrain, as in the decoder) while this one drives the next segment's recurrence -- on 1 GB of
+     * text from host memory to host memory the segments' words were 95 of 165 ms on this thread */
+    RangeDrain drain;
+    RangeDrain *dr = nullptr;
+    /* the thread that loads the next segment (joined on every way out) */
+    struct Loader {
+        std::thread t;
+        bool on = false;
+        int rc = LZ77X_OK;
+        int join() { if (on) { t.join(); on = false; return rc; } return LZ77X_OK; }
+        ~Loader() { if (on) t.join(); }
+    } loader;
     {
         const double tl = now_ms();
         if ((rc = load(0, nullptr))) return rc;
@@ -2487,36 +2530,73 @@ int encode_stream_device(Ctx &c, Source &src, Sink &sink, const lz77x_geom &g, h
             /* the next segment's input and match stage, behind this one's match stage on the other stream */
             if (prev_unfinished >= 0) {
                 /* its context is the one segment k-1 still occupies: its last tokens and its words are taken first */
-                if ((rc = seg_finish(J[prev_unfinished & 1], carry, sink, &waited, s))) return rc;
+                const double tf = now_ms();
+                if ((rc = seg_finish(J[prev_unfinished & 1], carry, sink, &waited, s, dr))) return rc;
+                t_finish += now_ms() - tf;
                 prev_unfinished = -1;
             }
             if (cx[1] == &c) {
                 if ((rc = ctx_sibling(c, &cx[1]))) return rc;
                 sx[1] = cx[1]->stream;
+                if (sink.blocks_on_host()) {
+                    Ctx *dctx = nullptr;
+                    if ((rc = ctx_drain(c, &dctx))) return rc;
+                    if (drain.start(&sink, dctx) == LZ77X_OK) dr = &drain;
+                }
             }
-            if ((rc = load(k + 1, &K))) return rc;
-            HIPCHK(hipStreamWaitEvent(J[(k + 1) & 1].s, K.c->ev[1], 0));
-            if ((rc = seg_front(J[(k + 1) & 1], g))) return rc;
+            if (src.host_backed()) {
+                /* reading the source blocks a host thread (preads or copies out of pageable memory into the pinned slots):
+                 * a thread of its own does it while this one drives the recurrence of segment k; the match stage of k + 1
+                 * then runs beside the tie-break of k instead of beside its recurrence */
+                SegJob *prev = &K;
+                try {
+                    loader.t = std::thread([&, k, prev]() {
+                        loader.rc = hipSetDevice(c.device) == hipSuccess ? load(k + 1, prev) : LZ77X_E_HIP;
+                    });
+                    loader.on = true;
+                } catch (...) {
+                    loader.on = false;
+                }
+            }
+            if (!loader.on) {
+                if ((rc = load(k + 1, &K))) return rc;
+                HIPCHK(hipStreamWaitEvent(J[(k + 1) & 1].s, K.c->ev[1], 0));
+                if ((rc = seg_front(J[(k + 1) & 1], g))) return rc;
+            }
         }
         bool fb = false;
         const double tm = now_ms();
         if ((rc = seg_mid(K, g, carry, single, &fb, &waited))) return rc;
         TRACE("  match stage waited for, chain + recurrence", tm);
         if (fb) { *fallback = true; *n_fallback = K.nloc; return LZ77X_OK; }
+        if (loader.on) {
+            const double tj = now_ms();
+            if ((rc = loader.join())) return rc;
+            t_join += now_ms() - tj;
+            HIPCHK(hipStreamWaitEvent(J[(k + 1) & 1].s, K.c->ev[1], 0));
+            const double tf = now_ms();
+            if ((rc = seg_front(J[(k + 1) & 1], g))) return rc;
+            t_front += now_ms() - tf;
+        }
         if (prev_unfinished >= 0) {
-            if ((rc = seg_finish(J[prev_unfinished & 1], carry, sink, &waited, s))) return rc;
+            const double tf = now_ms();
+            if ((rc = seg_finish(J[prev_unfinished & 1], carry, sink, &waited, s, dr))) return rc;
+            t_finish += now_ms() - tf;
             prev_unfinished = -1;
         }
         const double tt = now_ms();
+        if (dr && (rc = dr->wait(1))) return rc;                /* this context's words of two segments ago have left its buffer */
         if ((rc = seg_tokens(K, g, carry))) return rc;
+        t_tokens += now_ms() - tt;
         if (K.last) {
-            if ((rc = seg_finish(K, carry, sink, &waited, s))) return rc;     /* (joins the caller's stream) */
+            if ((rc = seg_finish(K, carry, sink, &waited, s, dr))) return rc;     /* (joins the caller's stream) */
+            if (dr && (rc = dr->wait(0))) return rc;
             TRACE("  tokens + the stream to the sink", tt);
             break;
         }
         if (pipelined) prev_unfinished = k;
         else {
-            if ((rc = seg_finish(K, carry, sink, &waited, s))) return rc;
+            if ((rc = seg_finish(K, carry, sink, &waited, s, dr))) return rc;
             if ((rc = load(k + 1, &K))) return rc;
             if ((rc = seg_front(J[(k + 1) & 1], g))) return rc;
         }
@@ -2526,6 +2606,9 @@ int encode_stream_device(Ctx &c, Source &src, Sink &sink, const lz77x_geom &g, h
     g_stats.ntok = carry.ntok;
     g_stats.total_ms = now_ms() - t_begin;
     g_stats.copy_ms = waited;
+    if (trace_on())
+        fprintf(stderr, "[lz77x]   in all: finishing segments %.2f ms, token stages %.2f ms, waiting for the loader %.2f ms, match stages enqueued in %.2f ms\n",
+                t_finish, t_tokens, t_join, t_front);
     TRACE("encode_stream_device total", t_begin);
     return LZ77X_OK;
 }
@@ -3156,6 +3239,7 @@ namespace {
 void ctx_release(Ctx &c)
 {
     if (c.pipe) { ctx_release(*c.pipe); delete c.pipe; c.pipe = nullptr; }
+    if (c.drain) { ctx_release(*c.drain); delete c.drain; c.drain = nullptr; }
     if (!c.ready) return;
     hipError_t e = hipSetDevice(c.device);
     e = hipDeviceSynchronize();
