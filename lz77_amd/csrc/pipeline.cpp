@@ -31,6 +31,7 @@
 #include <atomic>
 #include <condition_variable>
 #include <deque>
+#include <functional>
 #include <mutex>
 #include <string>
 #include <thread>
@@ -2507,14 +2508,66 @@ int encode_stream_device(Ctx &c, Source &src, Sink &sink, const lz77x_geom &g, h
      * text from host memory to host memory the segments' words were 95 of 165 ms on this thread */
     RangeDrain drain;
     RangeDrain *dr = nullptr;
-    /* the thread that loads the next segment (joined on every way out) */
+    /* the thread that loads the next segment: ONE per call, started when a second segment turns up, handed a segment at a
+     * time (a thread per segment was hundreds of short-lived threads, each with its own state inside the runtime, on the
+     * small segments the tests force) and joined on every way out */
     struct Loader {
         std::thread t;
-        bool on = false;
+        std::mutex mu;
+        std::condition_variable cv;
+        std::function<int(int, SegJob *)> fn;
+        int device = 0;
+        int req = -1;                         /* the segment to load, -1: none */
+        SegJob *prev = nullptr;
+        bool busy = false, stop = false, started = false, on = false;   /* on: a load has been handed over and not yet waited for */
         int rc = LZ77X_OK;
-        int join() { if (on) { t.join(); on = false; return rc; } return LZ77X_OK; }
-        ~Loader() { if (on) t.join(); }
+        void run()
+        {
+            const bool dev_ok = hipSetDevice(device) == hipSuccess;
+            std::unique_lock<std::mutex> lk(mu);
+            for (;;) {
+                cv.wait(lk, [&] { return stop || req >= 0; });
+                if (req < 0) return;
+                const int k = req;
+                SegJob *p = prev;
+                req = -1;
+                lk.unlock();
+                const int r = dev_ok ? fn(k, p) : LZ77X_E_HIP;
+                lk.lock();
+                rc = r;
+                busy = false;
+                cv.notify_all();
+            }
+        }
+        bool kick(int k, SegJob *p)
+        {
+            if (!started) {
+                try { t = std::thread(&Loader::run, this); started = true; }
+                catch (...) { return false; }
+            }
+            { std::lock_guard<std::mutex> lk(mu); req = k; prev = p; busy = true; }
+            cv.notify_all();
+            on = true;
+            return true;
+        }
+        int join()
+        {
+            if (!on) return LZ77X_OK;
+            std::unique_lock<std::mutex> lk(mu);
+            cv.wait(lk, [&] { return !busy; });
+            on = false;
+            return rc;
+        }
+        ~Loader()
+        {
+            if (!started) return;
+            { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&] { return !busy; }); stop = true; }
+            cv.notify_all();
+            t.join();
+        }
     } loader;
+    loader.device = c.device;
+    loader.fn = [&](int k, SegJob *p) { return load(k, p); };
     {
         const double tl = now_ms();
         if ((rc = load(0, nullptr))) return rc;
@@ -2548,15 +2601,7 @@ int encode_stream_device(Ctx &c, Source &src, Sink &sink, const lz77x_geom &g, h
                 /* reading the source blocks a host thread (preads or copies out of pageable memory into the pinned slots):
                  * a thread of its own does it while this one drives the recurrence of segment k; the match stage of k + 1
                  * then runs beside the tie-break of k instead of beside its recurrence */
-                SegJob *prev = &K;
-                try {
-                    loader.t = std::thread([&, k, prev]() {
-                        loader.rc = hipSetDevice(c.device) == hipSuccess ? load(k + 1, prev) : LZ77X_E_HIP;
-                    });
-                    loader.on = true;
-                } catch (...) {
-                    loader.on = false;
-                }
+                (void)loader.kick(k + 1, &K);                   /* (no thread to be had: loaded right here, below) */
             }
             if (!loader.on) {
                 if ((rc = load(k + 1, &K))) return rc;
