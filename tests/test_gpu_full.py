@@ -189,6 +189,44 @@ def test_s2_random_1gib():
     _run("S2")
 
 
+def test_s4_from_host_memory_and_from_a_file(tmp_path):
+    """S4 through the entry points whose input is NOT in device memory: such an input runs in segments of 128 MB, the next
+    one loaded by a thread of its own, the finished one's words written by another -- the stream must be the
+    reference's, byte for byte, and come back through the same entry points"""
+    r = FULL["S4"]
+    n, sb, la = r["n"], r["sb"], r["la"]
+    data = synth.make(r["kind"], n, r["seed"])
+    z = L.encode(data, la, sb)                              # lz77x_encode: host memory -> host memory
+    st = L.last_stats()
+    assert len(z) == r["zn"] and st["ntok"] == r["ntok"]
+    assert st["match_launches"] >= 7, "one segment: the input crossed PCIe before the first kernel"
+    assert hashlib.sha256(z).hexdigest() == r["sha256_lz"], "stream differs from the reference's"
+    back = L.decode(z)
+    assert hashlib.sha256(back).hexdigest() == r["sha256_in"]
+    del back
+    d = "/dev/shm" if os.path.isdir("/dev/shm") else str(tmp_path)
+    fin, flz, fout = (os.path.join(d, "lz77x_s4host." + e) for e in ("in", "lz", "out"))
+    try:
+        data.tofile(fin)
+        L.encode_path(fin, flz, la, sb)                     # lz77x_encode_file: file -> file
+        assert L.last_stats()["match_launches"] >= 7
+        with open(flz, "rb") as f:
+            assert f.read() == z
+        L.decode_path(flz, fout)
+        h = hashlib.sha256()
+        with open(fout, "rb") as f:
+            while True:
+                b = f.read(1 << 26)
+                if not b:
+                    break
+                h.update(b)
+        assert h.hexdigest() == r["sha256_in"]
+    finally:
+        for q in (fin, flz, fout):
+            if os.path.exists(q):
+                os.remove(q)
+
+
 def test_s4_enwik9_like_1gb():
     """configs[4] on one device: 1 GB text, s=4095 l=15"""
     _run("S4")
