@@ -1,5 +1,6 @@
+"""lz77x_encode on 1 GB of text in host memory, three times, with the library's own trace (LZ77X_TRACE=1 in the environment): python tools/trace_h2h.py"""
 import os, sys, time, ctypes
-sys.path.insert(0, "/root/repo")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import lz77_amd as L
 from lz77_amd import synth
 n = 1_000_000_000
