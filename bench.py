@@ -351,6 +351,29 @@ def shard_mode(a):
         dist.destroy_process_group()
 
 
+def respawn_if_needed(a):
+    """`python bench.py --gpus N` with N > 1 and no launcher around it: files mode is one process per GPU, so re-execute
+    under torch.distributed.run with N ranks (the driver's own launch line) instead of printing an n_gpus = 1 line.  A
+    launcher whose world size disagrees with --gpus is an error, not a silently different run."""
+    ws = os.environ.get("WORLD_SIZE")
+    if ws is not None:
+        if int(ws) != a.gpus:
+            raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%s: launch one rank per GPU "
+                             "(python -m torch.distributed.run --nproc-per-node %d ... bench.py --gpus %d)" % (a.gpus, ws, a.gpus, a.gpus))
+        return
+    if a.gpus <= 1:
+        return
+    import socket
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(a.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    sys.stdout.flush()
+    os.execv(sys.executable, cmd)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -372,6 +395,7 @@ def main():
     a = ap.parse_args()
     if a.mode == "shard":
         return shard_mode(a)
+    respawn_if_needed(a)
 
     import torch
     import torch.distributed as dist

@@ -20,8 +20,10 @@ __all__ = ["encode", "decode", "encode_device", "decode_device", "encode_path", 
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(_HERE)
-LIB_PATH = os.path.join(_HERE, "liblz77_mi355x.so")
-CLI_PATH = os.path.join(_HERE, "lz77")
+# LZ77X_TEST_LIB / LZ77X_TEST_CLI: tests/test_sanitize_cpu.py points the binding at the -fsanitize=address,undefined build
+# of the same sources (csrc/Makefile `asan`); nothing else sets them
+LIB_PATH = os.environ.get("LZ77X_TEST_LIB") or os.path.join(_HERE, "liblz77_mi355x.so")
+CLI_PATH = os.environ.get("LZ77X_TEST_CLI") or os.path.join(_HERE, "lz77")
 
 DEFAULT_LA = 15      # lz77.c:21
 DEFAULT_SB = 4095    # lz77.c:22
@@ -116,7 +118,7 @@ def use_variants(on: bool) -> None:
 VARIANT_KNOBS = ("LZ77X_MATCH_VARIANT", "LZ77X_TOKEN_VARIANT", "LZ77X_SORT_VARIANT", "LZ77X_DECODE_V1", "LZ77X_DECODE_VARIANT",
                  "LZ77X_XFER_V1", "LZ77X_WALK_BIG_V1", "LZ77X_TOKENS_BUCKET", "LZ77X_C1_SORT_V1", "LZ77X_BIG_SORT_V1",
                  "LZ77X_PRIO_BACK_SWEEP", "LZ77X_PW_PREP_V1", "LZ77X_PW_PROBE", "LZ77X_PW_DEBUG", "LZ77X_WALK_DEBUG", "LZ77X_SERIAL", "LZ77X_SPLIT",
-                 "LZ77X_CHAIN_STREAM", "LZ77X_PRIO_SORTCAP", "LZ77X_PRIO_WIDE", "LZ77X_HOST_STAGEB", "LZ77X_TS_ENTCAP", "LZ77X_NO_SHORT_INDEX", "LZ77X_RANK_LPT")
+                 "LZ77X_CHAIN_STREAM", "LZ77X_PRIO_SORTCAP", "LZ77X_PRIO_WIDE", "LZ77X_HOST_STAGEB", "LZ77X_TS_ENTCAP", "LZ77X_TS_V4", "LZ77X_TS_PROBE", "LZ77X_TS_BIG", "LZ77X_NO_SHORT_INDEX", "LZ77X_RANK_LPT")
 
 
 def lib():

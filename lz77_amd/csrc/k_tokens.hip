@@ -469,17 +469,16 @@ __global__ __launch_bounds__(TOK_BLOCK) void k_tokens_tile(const uint8_t *__rest
 #define TS_TT 3072u
 #define TS_BLOCK 1024
 #define TS_TB 512u                                   /* tokens per batch (two lanes each in phase A) */
-/* A token whose run holds this many cells or more, few of them with hand-overs, is not dealt member by member (round 4:
- * all-zero input spent 29 of its
- * 37 ms per 100 MB here -- every token's run is the whole window, 4095 members each, and not one hand-over among them: a
- * position without a predecessor in key order never hands its priority on; runs of zeros are what binaries are made of).
- * Only a member that some eviction handed a priority to can sit below its own position in the treap;
- * every other member's priority IS its position (tree.c:102-105: a new node is a leaf; + voff), so among those the winner is
- * simply the OLDEST one in the window.  A big token therefore goes to one wavefront, which (1) visits the run's members WITH
- * hand-overs through a bitmap over the sorted slots (one bit per slot: 64 slots a word) and (2) finds the oldest member
- * without by walking the window's positions upwards from its first cell, 64 at a time, until one shares the token's bytes:
- * cells * 64 / run positions on average instead of `run` members. */
-#define TS_BIG 1024u
+/* A token whose run holds this many cells or more is not dealt member by member.  Round 4: all-zero input spent 29 of its
+ * 37 ms per 100 MB there -- every token's run is the whole window, 4095 members each.  A member's own priority IS its
+ * position (tree.c:102-105: a new node is a leaf; + voff), so among the members' own priorities the winner is simply the
+ * OLDEST member in the window: walk the window's positions upwards from p - sb until one's slot lies in the run -- sb / run
+ * positions on average instead of `run` members, sixteen lanes a token; what hand-overs lowered comes in through the
+ * entries like everybody's (k_tokens_sorted, B2).  Round 4's form (a bitmap of the slots with hand-overs, threshold 1024,
+ * a density test) is in k_tokens_sorted_v4.  Measured on text, tie-break ms per 100 MB: 1024 2.81, 128 2.80, 64 2.86,
+ * 32 3.21; low-entropy data 5.1 at 1024, 4.3 at 64. */
+#define TS_BIG 128u
+#define TS_BIG_V4 1024u                                               /* round 4's kernel (variants build) */
 
 struct ts_grid { uint32_t sb, TILE, head, tpr; };
 
@@ -575,7 +574,491 @@ __global__ void k_ts_total(unsigned long long *total)
     if (threadIdx.x == 0) total[0] += v;
 }
 
+/* Exclusive prefixes of TWO values per thread over the workgroup (one set of barriers); *ta, *tb (LDS) = the sums. */
+__device__ __forceinline__ void ts_wg_scan2(uint32_t a, uint32_t b, uint32_t *wsa, uint32_t *wsb, uint32_t *ta, uint32_t *tb, uint32_t &ea, uint32_t &eb)
+{
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t ia = a, ib = b;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t t = __shfl_up(ia, d, 64), u = __shfl_up(ib, d, 64);
+        if (lane >= (uint32_t)d) { ia += t; ib += u; }
+    }
+    ts_barrier_lds();                                     /* the previous use of wsa / wsb is over */
+    if (lane == 63) { wsa[wave] = ia; wsb[wave] = ib; }
+    ts_barrier_lds();
+    uint32_t ra = ia - a, rb = ib - b, alla = 0, allb = 0;
+#pragma unroll
+    for (uint32_t w = 0; w < TS_BLOCK / 64; w++) {
+        const uint32_t t = wsa[w], u = wsb[w];
+        ra += w < wave ? t : 0u;
+        rb += w < wave ? u : 0u;
+        alla += t;
+        allb += u;
+    }
+    if (threadIdx.x == 0) { *ta = alla; *tb = allb; }
+    ea = ra;
+    eb = rb;
+}
+
+/* Round 5: the hand-overs are grouped by the SLOT of their cell in the tile's key order, not by the cell.
+ *
+ * prio_p(c) = min(what c came with, the hand-overs into c by evictions before p), and the token wants the argmin over the
+ * members c of its run inside its window.  A minimum of minima is a minimum over the union: over the members' OWN priorities
+ * (c + voff: monotone in c, so the winner among them is simply the oldest member in the window -- a compare and a minimum per
+ * member, no list look-up) and over every hand-over (x -> c, v) whose cell is a member -- and with the entries sorted by
+ * slot those are ONE contiguous range per token, [first entry with slot >= lo, first entry with slot >= hi), dealt to the
+ * threads like the members: per entry a time test, a window test, a 64-bit minimum.  (A stale hand-over never wins: the one
+ * that replaced it in the same cell is lower -- tree.c:202-231: the successor only moves up.)  Round 4 walked, per member,
+ * the list of its cell: ~170 wave instructions per 64 members with the wavefront's union of list lengths; now ~10 per 64
+ * members plus ~15 per 64 entries, and there are four entries to ten members.
+ *
+ * What it takes: the slot of EVERY window cell (`inv`, not only of the tile's positions: a hand-over's cell -> its slot),
+ * 16-bit counters per slot while the lists are built -- they share their 16 KB with the window bytes and the batch arrays,
+ * which are staged once the entries are placed --, a coarse index (the first entry of every 16th slot) to find a run's
+ * entries, and 8 bytes an entry (slot | eviction << 16, priority).  A long run (TS_BIG cells) needs no bitmap any
+ * more: its oldest member is found by walking the window's positions upwards, `inv[c]` in [lo, hi), and its hand-overs are
+ * entries like everybody's. */
+#define TS_CG 16u                                                     /* slots per coarse list offset */
+
 __global__ __launch_bounds__(TS_BLOCK, 8) __attribute__((amdgpu_num_sgpr(80))) void k_tokens_sorted(const uint8_t *__restrict__ in, uint32_t n, int sb, int la, int ob, int lb,
+                                                            const uint32_t *__restrict__ chain, const uint32_t *__restrict__ tstart,
+                                                            const uint8_t *__restrict__ maxlen, const uint32_t *__restrict__ ps,
+                                                            const uint32_t *__restrict__ xval, uint32_t pos0, uint32_t pos1,
+                                                            uint32_t *__restrict__ tokval, uint32_t ent_cap, uint32_t off_tk, uint32_t off_sorted,
+                                                            uint32_t off_inv, uint32_t off_cofs, uint32_t off_ent,
+                                                            const uint32_t *__restrict__ look, uint32_t nlook, uint32_t voff,
+                                                            const uint16_t *__restrict__ order_all, uint32_t RP, ts_grid G, uint32_t tile0, uint32_t ntiles,
+                                                            unsigned long long *__restrict__ total /* [1 + a slot] += hand-overs of the evictions [a - sb, b - sb) (a statistic) */
+                                                            , uint32_t big_min /* a run of this many cells or more finds its oldest member by walking positions (B') */
+#ifdef LZ77X_VARIANTS
+                                                            , uint32_t probe /* timing probe (LZ77X_TS_PROBE, wrong output): leave after 1 the set-up, 2 phase A + scans, 3 B1, 4 B2 */
+#endif
+                                                            )
+{
+#ifndef LZ77X_VARIANTS
+    constexpr uint32_t probe = 0;
+#endif
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    /* [0, off_sorted): while the lists are built, 8 * TS_BLOCK 16-bit counters; afterwards the window bytes and the batch arrays */
+    uint16_t *lofs = reinterpret_cast<uint16_t *>(smem);
+    uint32_t *lofs32 = reinterpret_cast<uint32_t *>(smem);
+    uint8_t *by = smem;
+    unsigned long long *tk_best = reinterpret_cast<unsigned long long *>(smem + off_tk);   /* TS_TB */
+    uint16_t *tk_nm = reinterpret_cast<uint16_t *>(tk_best);                               /* (before tk_best is set: members / entries per token) */
+    uint16_t *tk_ne = tk_nm + TS_TB;
+    uint32_t *tk_cum = reinterpret_cast<uint32_t *>(tk_best + TS_TB);                      /* TS_TB + 1: members */
+    uint32_t *tk_cume = tk_cum + TS_TB + 4;                                                 /* TS_TB + 1: entries */
+    uint32_t *tk_pl = tk_cume + TS_TB + 4;                                                  /* TS_TB: offset | len << 16 */
+    uint16_t *tk_lo = reinterpret_cast<uint16_t *>(tk_pl + TS_TB);                         /* TS_TB: first slot of the run */
+    uint16_t *tk_elo = tk_lo + TS_TB;                                                       /* TS_TB: first entry of the run */
+    uint16_t *sorted = reinterpret_cast<uint16_t *>(smem + off_sorted);        /* window cells (offsets from wbase) in key order */
+    uint16_t *inv = reinterpret_cast<uint16_t *>(smem + off_inv);              /* slot of every window cell */
+    uint16_t *cofs = reinterpret_cast<uint16_t *>(smem + off_cofs);            /* first entry of slot TS_CG * i */
+    uint32_t *ent_sx = reinterpret_cast<uint32_t *>(smem + off_ent);           /* slot | (eviction - xs0) << 16, sorted by slot */
+    uint32_t *ent_v = ent_sx + ent_cap;                                        /* staged: the priority handed over */
+    __shared__ uint32_t wsum[TS_BLOCK / 64], wsum2[TS_BLOCK / 64], s_own[TS_BLOCK / 64];
+    __shared__ uint32_t s_total, s_total2, s_nbig;
+    __shared__ uint16_t fb_lo[256], fb_hi[256];
+    __shared__ uint16_t big[TS_TB];                                       /* the batch's tokens with a run of TS_BIG cells or more (bit 31 of their tk_pl) */
+
+    const uint32_t tid = threadIdx.x;
+    const uint32_t usb = (uint32_t)sb;
+    /* consecutive workgroups go to different XCDs (eight L2s): give each XCD a contiguous stretch of tiles, so that
+     * the tiles that share a region's order array and overlap in their windows meet in the same L2 */
+    const uint32_t per_xcd = gridDim.x >> 3;
+    const uint32_t tl = (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);
+    if (tl >= ntiles) return;
+    uint32_t a, b, region;
+    ts_tile_range(G, tile0 + tl, a, b, region);
+    a = max(a, pos0);
+    b = min(b, pos1);
+    if (a >= b) return;
+    const uint32_t t0r = region * G.TILE;
+    const uint32_t wlo = a > usb ? a - usb : 0u;
+    const uint32_t wbase = wlo & ~3u;
+    /* ---- everything the tile needs from HBM is requested at once (one latency, not seven in a row): the region's
+     *      order, the token range, the evictions, the window bytes; the barriers in between only order LDS traffic
+     *      (ts_barrier_lds does not wait for loads in flight) ---- */
+    uint32_t mine[16];
+    {
+        const uint32_t K = RP / TS_BLOCK;                  /* 4, 8 or 16 consecutive slots per thread */
+        const uint16_t *ord = order_all + (size_t)region * RP + (size_t)tid * K;
+        if (K == 16) {
+            const uint4 v0 = *reinterpret_cast<const uint4 *>(ord), v1 = *reinterpret_cast<const uint4 *>(ord + 8);
+            const uint32_t w[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+#pragma unroll
+            for (int q = 0; q < 8; q++) { mine[2 * q] = w[q] & 0xFFFFu; mine[2 * q + 1] = w[q] >> 16; }
+        } else if (K == 8) {
+            const uint4 v0 = *reinterpret_cast<const uint4 *>(ord);
+            const uint32_t w[4] = {v0.x, v0.y, v0.z, v0.w};
+#pragma unroll
+            for (int q = 0; q < 4; q++) { mine[2 * q] = w[q] & 0xFFFFu; mine[2 * q + 1] = w[q] >> 16; }
+#pragma unroll
+            for (int q = 8; q < 16; q++) mine[q] = 0xFFFFFFFFu;
+        } else {
+            const uint2 v0 = *reinterpret_cast<const uint2 *>(ord);
+            mine[0] = v0.x & 0xFFFFu; mine[1] = v0.x >> 16; mine[2] = v0.y & 0xFFFFu; mine[3] = v0.y >> 16;
+#pragma unroll
+            for (int q = 4; q < 16; q++) mine[q] = 0xFFFFFFFFu;
+        }
+    }
+    const uint32_t k0 = tstart[tl], k1 = tstart[tl + 1];
+    /* the first batch's token positions (and, once they are here, their lengths) travel with the tile's other requests:
+     * under the batch loop they were two exposed round trips, one behind the other */
+    const uint32_t p_pre = chain[min(k0 + (tid >> 1), max(k1, 1u) - 1u)];
+    /* the evictions [xs0, xs1) (every load unconditional, clamped: the compiler keeps them in flight) */
+    const uint32_t xs0 = wlo > usb ? wlo - usb : 0u, xs1 = b > usb ? b - usb : 0u;
+    uint32_t xv[TS_SRC], xc[TS_SRC];                        /* priority handed over / the cell it goes to, then 1 + its slot */
+    {
+        const uint32_t xl = xs1 ? xs1 - 1u : 0u;
+#pragma unroll
+        for (int r = 0; r < TS_SRC; r++) {
+            const uint32_t x = xs0 + tid + (uint32_t)r * TS_BLOCK;
+            const uint32_t xq = min(x, xl);
+            xv[r] = xval[xq];
+            xc[r] = ps[xq];
+        }
+    }
+    constexpr int BY_PER = (TS_TT + 4096 + 256 + 16 + 4 * TS_BLOCK - 1) / (4 * TS_BLOCK);
+    uint32_t by_raw[BY_PER];
+    const uint32_t nb = (b + (uint32_t)la + 8 - wbase + 3) & ~3u;
+#pragma unroll
+    for (int r = 0; r < BY_PER; r++) {
+        const uint32_t i = (tid + (uint32_t)r * TS_BLOCK) * 4u;
+        by_raw[r] = i < nb ? *reinterpret_cast<const uint32_t *>(in + wbase + i) : 0u;
+    }
+    *reinterpret_cast<uint4 *>(lofs32 + 4u * tid) = make_uint4(0u, 0u, 0u, 0u);     /* the counters (ordered before the counting by the scan's barriers) */
+    /* the region's order, filtered down to the cells of [wlo, b) */
+    {
+        const uint32_t wl = wlo - t0r, wn = b - wlo;        /* region-local window */
+        uint32_t cnt = 0;
+#pragma unroll
+        for (int q = 0; q < 16; q++) cnt += (mine[q] - wl < wn) ? 1u : 0u;
+        uint32_t run = ts_wg_scan(cnt, wsum, &s_total);
+        const uint32_t shift = t0r - wbase;
+#pragma unroll
+        for (int q = 0; q < 16; q++) {
+            if (mine[q] - wl < wn) {
+                const uint32_t co = mine[q] + shift;
+                sorted[run] = (uint16_t)co;
+                inv[co] = (uint16_t)run;
+                run++;
+            }
+        }
+    }
+    const uint32_t len_pre = maxlen[p_pre];
+    ts_barrier_lds();                                       /* every cell has its slot */
+    const uint32_t N = s_total;                             /* = b - wlo: every cell of the window is in the region */
+    /* hand-overs per slot: counter of slot i = entry i + 1 (entry 0 stays 0), two entries per word */
+    {
+        uint32_t own = 0;
+#pragma unroll
+        for (int r = 0; r < TS_SRC; r++) {
+            const uint32_t x = xs0 + tid + (uint32_t)r * TS_BLOCK;
+            const uint32_t dst = x + (xc[r] >> 16);
+            const bool ok = x < xs1 && xv[r] != LZ77X_NONE32 && dst >= wlo;
+            own += (ok && x + usb >= a) ? 1u : 0u;
+            uint32_t e = 0;
+            if (ok) {
+                e = (uint32_t)inv[dst - wbase] + 1u;
+                atomicAdd(&lofs32[e >> 1], 1u << (16u * (e & 1u)));
+            }
+            xc[r] = e;
+        }
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) own += __shfl_xor(own, d, 64);
+        if ((tid & 63u) == 0) s_own[tid >> 6] = own;
+    }
+    ts_barrier_lds();
+    if (total && tid == 0) {
+        /* one atomic per workgroup, spread over TS_SLOTS words: atomics to ONE address queue in the L2 at ~100 cycles each
+         * (one per wavefront -- 781 K of them per 100 MB -- took 7 ms) */
+        uint32_t own = 0;
+        for (uint32_t w = 0; w < TS_BLOCK / 64; w++) own += s_own[w];
+        if (own) atomicAdd(&total[1u + (blockIdx.x & (TS_SLOTS - 1u))], (unsigned long long)own);
+    }
+    {
+        /* prefix sums in place: eight entries a thread */
+        const uint4 w = *reinterpret_cast<const uint4 *>(lofs32 + 4u * tid);
+        uint32_t c[8] = {w.x & 0xFFFFu, w.x >> 16, w.y & 0xFFFFu, w.y >> 16, w.z & 0xFFFFu, w.z >> 16, w.w & 0xFFFFu, w.w >> 16};
+        uint32_t sum = 0;
+#pragma unroll
+        for (int q = 0; q < 8; q++) sum += c[q];
+        uint32_t run = ts_wg_scan(sum, wsum, &s_total);     /* (its first barrier: every thread has read N) */
+        /* entry e becomes the START of the list of slot e - 1 ... and, once the placing below has bumped it by the
+         * list's length, the start of the list of slot e: list(i) = [lofs[i], lofs[i + 1]) */
+#pragma unroll
+        for (int q = 0; q < 8; q++) { const uint32_t t = c[q]; c[q] = run; run += t; }
+        *reinterpret_cast<uint4 *>(lofs32 + 4u * tid) = make_uint4(c[0] | c[1] << 16, c[2] | c[3] << 16, c[4] | c[5] << 16, c[6] | c[7] << 16);
+    }
+    ts_barrier_lds();
+    /* more hand-overs than the LDS left over holds (never seen on text: four in ten evictions hand over): the entries
+     * keep slot and eviction only and a look-up fetches the priority from xval[] */
+    const uint32_t etot = s_total;
+    const bool staged = etot <= ent_cap;
+#pragma unroll
+    for (int r = 0; r < TS_SRC; r++) {
+        if (xc[r]) {
+            const uint32_t x = xs0 + tid + (uint32_t)r * TS_BLOCK;
+            const uint32_t sh = 16u * (xc[r] & 1u);
+            const uint32_t at = (atomicAdd(&lofs32[xc[r] >> 1], 1u << sh) >> sh) & 0xFFFFu;
+            ent_sx[at] = (xc[r] - 1u) | ((x - xs0) << 16);
+            if (staged) ent_v[at] = xv[r];
+        }
+    }
+    ts_barrier_lds();
+    uint32_t co_first = 0;
+    if (tid < 8u * TS_BLOCK / TS_CG) co_first = lofs[TS_CG * tid];
+    ts_barrier_lds();                                       /* the counters have served: their place goes to the bytes and the batch arrays */
+    if (tid < 8u * TS_BLOCK / TS_CG) cofs[tid] = (uint16_t)co_first;
+#pragma unroll
+    for (int r = 0; r < BY_PER; r++) {
+        const uint32_t i = (tid + (uint32_t)r * TS_BLOCK) * 4u;
+        if (i < nb) *reinterpret_cast<uint32_t *>(by + i) = by_raw[r];
+    }
+    if (tid == 0) s_nbig = 0;
+    ts_barrier_lds();
+    /* cells by first byte: [fb_lo[c], fb_hi[c]) -- the run of a token of length 1, without a search */
+    for (uint32_t i = tid; i < N; i += TS_BLOCK) {
+        const uint32_t c = by[sorted[i]];
+        const uint32_t cp = i ? (uint32_t)by[sorted[i - 1]] : 256u;
+        if (c != cp) {
+            fb_lo[c] = (uint16_t)i;
+            if (i) fb_hi[cp] = (uint16_t)i;
+        }
+        if (i + 1 == N) fb_hi[c] = (uint16_t)N;
+    }
+    __syncthreads();
+    /* a cell of a later segment's look-back carries a rank, not its position: the tiles that see one (the first two of a
+     * segment) take every member through look[] and no short cut */
+    const bool has_look = wlo < nlook;
+    if (probe == 1) return;
+
+    const uint32_t omask = ob >= 32 ? 0xFFFFFFFFu : (1u << ob) - 1u;
+    for (uint32_t kb = k0; kb < k1; kb += TS_TB) {
+        const uint32_t nt = min(TS_TB, k1 - kb);
+        /* ---- A: the run of cells sharing the token's len bytes, and the run of entries that go with it; lane pair = (down, up) ---- */
+        {
+            const uint32_t ti = tid >> 1, up = tid & 1u;
+            if (ti < nt) {
+                const uint32_t p = kb == k0 ? p_pre : chain[kb + ti];
+                const uint32_t len = kb == k0 ? len_pre : (uint32_t)maxlen[p];
+                const uint32_t qo = p - wbase;
+                int edge = 0;
+                uint32_t eedge = 0;
+                if (len > 0) {
+                    uint32_t qw[4];
+#pragma unroll
+                    for (int w = 0; w < 4; w++) qw[w] = (uint32_t)(4 * w) < len ? ld32_at<true>(by, qo + 4 * w) : 0u;
+                    auto shares = [&](int i) -> bool {
+                        const uint32_t co = sorted[i];
+#pragma unroll
+                        for (int w = 0; w < 4; w++) {
+                            if ((uint32_t)(4 * w) < len) {
+                                uint32_t x = ld32_at<true>(by, co + 4 * w) ^ qw[w];
+                                const uint32_t rem = len - 4 * w;
+                                if (rem < 4) x &= (1u << (8 * rem)) - 1u;
+                                if (x) return false;
+                            }
+                        }
+                        for (uint32_t i2 = 16; i2 < len; i2 += 4) {
+                            uint32_t x = ld32_at<true>(by, co + i2) ^ ld32_at<true>(by, qo + i2);
+                            const uint32_t rem = len - i2;
+                            if (rem < 4) x &= (1u << (8 * rem)) - 1u;
+                            if (x) return false;
+                        }
+                        return true;
+                    };
+                    const int j = (int)inv[qo];
+                    if (len == 1) {
+                        edge = up ? (int)fb_hi[qw[0] & 0xFFu] : (int)fb_lo[qw[0] & 0xFFu];
+                    } else if (!up) {
+                        int lo = j, bad = -1, step = 1;           /* every slot of [lo, j) shares; slot `bad` does not */
+                        while (lo > 0) {
+                            const int t = lo > step ? lo - step : 0;
+                            if (shares(t)) { lo = t; step <<= 1; }
+                            else { bad = t; break; }
+                        }
+                        if (bad >= 0)
+                            while (lo - bad > 1) {
+                                const int m = (lo + bad) >> 1;
+                                if (shares(m)) lo = m; else bad = m;
+                            }
+                        edge = lo;
+                    } else {
+                        int hi = j + 1, bad = (int)N, step = 1;   /* every slot of (j, hi) shares; slot `bad` does not */
+                        while (hi < (int)N) {
+                            const int t = min(hi - 1 + step, (int)N - 1);
+                            if (shares(t)) { hi = t + 1; step <<= 1; }
+                            else { bad = t; break; }
+                        }
+                        while (hi < bad) {
+                            const int m = (hi + bad) >> 1;
+                            if (shares(m)) hi = m + 1; else bad = m;
+                        }
+                        edge = hi;
+                    }
+                    /* the first entry whose slot is not below the edge: from the coarse index, a few entries forward */
+                    uint32_t e = cofs[(uint32_t)edge / TS_CG];
+                    while (e < etot && (ent_sx[e] & 0xFFFFu) < (uint32_t)edge) e++;
+                    eedge = e;
+                }
+                const uint32_t o_edge = (uint32_t)__shfl_xor(edge, 1, 64), o_eedge = __shfl_xor(eedge, 1, 64);
+                if (!up) {
+                    tk_lo[ti] = (uint16_t)edge;
+                    tk_elo[ti] = (uint16_t)eedge;
+                    tk_pl[ti] = qo | (len << 16);
+                    tk_nm[ti] = (uint16_t)(o_edge - (uint32_t)edge);
+                    tk_ne[ti] = (uint16_t)(o_eedge - eedge);
+                }
+            }
+        }
+        __syncthreads();
+        /* ---- the runs laid end to end, members and entries ---- */
+        {
+            uint32_t nm = 0, ne = 0;
+            if (tid < nt) { nm = tk_nm[tid]; ne = tk_ne[tid]; }
+            /* a big run: its oldest member in the window is found by walking the window's positions (below) */
+            /* (its members stay in the count -- hi = lo + cum[ti + 1] - cum[ti] -- and B1 passes over them) */
+            if (nm >= big_min && !has_look) { big[atomicAdd(&s_nbig, 1u)] = (uint16_t)tid; tk_pl[tid] |= 0x80000000u; }
+            uint32_t em, ee;
+            ts_wg_scan2(nm, ne, wsum, wsum2, &s_total, &s_total2, em, ee);
+            if (tid < nt) { tk_cum[tid] = em; tk_cume[tid] = ee; tk_best[tid] = ~0ull; }
+            __syncthreads();
+        }
+        const uint32_t Wm = s_total, We = s_total2;
+        if (tid == 0) { tk_cum[nt] = Wm; tk_cume[nt] = We; }
+        __syncthreads();
+        if (probe == 2) continue;
+        /* ---- B1: every run member inside the token's window at the priority it came with ---- */
+        {
+            const uint32_t per = (Wm + TS_BLOCK - 1u) / TS_BLOCK;
+            const uint32_t w0 = tid * per, w1 = min(w0 + per, Wm);
+            if (w0 < w1) {
+                uint32_t lo_i = 0, hi_i = nt;               /* largest ti with cum[ti] <= w0 */
+                while (hi_i - lo_i > 1) {
+                    const uint32_t m = (lo_i + hi_i) >> 1;
+                    if (tk_cum[m] <= w0) lo_i = m; else hi_i = m;
+                }
+                uint32_t ti = lo_i;
+                uint32_t w = w0;
+                while (w < w1) {
+                    /* skip tokens without members (cum[ti + 1] == cum[ti]) */
+                    while (tk_cum[ti + 1] <= w) ti++;
+                    const uint32_t pl = tk_pl[ti], cbase = tk_cum[ti], cend = min(tk_cum[ti + 1], w1);
+                    const uint32_t p = wbase + (pl & 0xFFFFu);
+                    const uint32_t cmin = p > usb ? p - usb : 0u, wn = p - cmin;
+                    const uint32_t slot0 = (uint32_t)tk_lo[ti] - cbase;
+                    if (pl & 0x80000000u) { w = cend; continue; }        /* a big run: B' */
+                    if (!has_look) {
+                        /* own priorities are positions (+ voff): the lowest one is the oldest member (tree.c:102-105: a new node is a leaf) */
+                        uint32_t bc = 0xFFFFFFFFu;
+                        for (; w < cend; w++) {
+                            const uint32_t c = wbase + sorted[slot0 + w];
+                            bc = c - cmin < wn ? min(bc, c) : bc;
+                        }
+                        if (bc != 0xFFFFFFFFu) atomicMin(&tk_best[ti], ((unsigned long long)(bc + voff) << 32) | bc);
+                    } else {
+                        unsigned long long best = ~0ull;
+                        for (; w < cend; w++) {
+                            const uint32_t c = wbase + sorted[slot0 + w];
+                            if (c - cmin >= wn) continue;
+                            const uint32_t prio = c < nlook ? look[c] : c + voff;
+                            const unsigned long long key = ((unsigned long long)prio << 32) | c;
+                            best = key < best ? key : best;
+                        }
+                        if (best != ~0ull) atomicMin(&tk_best[ti], best);
+                    }
+                }
+            }
+        }
+        if (probe == 3) { __syncthreads(); continue; }
+        /* ---- B2: every hand-over into a member by an eviction before p (x + sb < p) ---- */
+        {
+            const uint32_t per = (We + TS_BLOCK - 1u) / TS_BLOCK;
+            const uint32_t w0 = tid * per, w1 = min(w0 + per, We);
+            if (w0 < w1) {
+                uint32_t lo_i = 0, hi_i = nt;
+                while (hi_i - lo_i > 1) {
+                    const uint32_t m = (lo_i + hi_i) >> 1;
+                    if (tk_cume[m] <= w0) lo_i = m; else hi_i = m;
+                }
+                uint32_t ti = lo_i;
+                uint32_t w = w0;
+                while (w < w1) {
+                    while (tk_cume[ti + 1] <= w) ti++;
+                    const uint32_t pl = tk_pl[ti], cbase = tk_cume[ti], cend = min(tk_cume[ti + 1], w1);
+                    const uint32_t p = wbase + (pl & 0xFFFFu);
+                    const uint32_t cmin = p > usb ? p - usb : 0u, wn = p - cmin;
+                    const uint32_t xlim = cmin;              /* an eviction x is before p: x + sb < p */
+                    const uint32_t e0 = (uint32_t)tk_elo[ti] - cbase;
+                    unsigned long long best = ~0ull;
+                    if (staged) {
+                        for (; w < cend; w++) {
+                            const uint32_t sx = ent_sx[e0 + w], v = ent_v[e0 + w];
+                            const uint32_t c = wbase + sorted[sx & 0xFFFFu], x = xs0 + (sx >> 16);
+                            const unsigned long long key = ((unsigned long long)v << 32) | c;
+                            best = (x < xlim && c - cmin < wn && key < best) ? key : best;
+                        }
+                    } else {
+                        for (; w < cend; w++) {
+                            const uint32_t sx = ent_sx[e0 + w];
+                            const uint32_t c = wbase + sorted[sx & 0xFFFFu], x = xs0 + (sx >> 16);
+                            if (x < xlim && c - cmin < wn) {
+                                const unsigned long long key = ((unsigned long long)xval[x] << 32) | c;
+                                best = key < best ? key : best;
+                            }
+                        }
+                    }
+                    if (best != ~0ull) atomicMin(&tk_best[ti], best);
+                }
+            }
+        }
+        if (probe == 4) { __syncthreads(); continue; }
+        /* ---- B': the big runs, sixteen lanes each: the oldest member of the window is the first position from p - sb
+         *      upwards whose slot lies in the run (a run of r cells is met after ~ sb / r positions: one or two steps) ---- */
+        {
+            const uint32_t nbig = s_nbig, lane = tid & 63u, wave = tid >> 6, grp = lane >> 4, gl = lane & 15u;
+            for (uint32_t bi0 = wave * 4u; bi0 < nbig; bi0 += (TS_BLOCK / 64u) * 4u) {
+                const uint32_t bi = bi0 + grp;
+                bool done = bi >= nbig;
+                const uint32_t ti = done ? 0u : (uint32_t)big[bi];
+                const uint32_t p = wbase + (tk_pl[ti] & 0xFFFFu), cmin = p > usb ? p - usb : 0u;
+                const uint32_t lo = tk_lo[ti], nrun = tk_cum[ti + 1] - tk_cum[ti];
+                uint32_t c0 = cmin;
+                for (;;) {
+                    const uint32_t c = c0 + gl;
+                    const bool in = !done && c < p;
+                    const bool ok = in && (uint32_t)inv[in ? c - wbase : 0u] - lo < nrun;
+                    const uint32_t h16 = (uint32_t)(__ballot(ok) >> (16u * grp)) & 0xFFFFu;
+                    if (!done && h16) {
+                        const uint32_t c1 = c0 + (uint32_t)__builtin_ctz(h16);
+                        if (gl == 0) atomicMin(&tk_best[ti], ((unsigned long long)(c1 + voff) << 32) | c1);
+                        done = true;
+                    }
+                    c0 += 16u;
+                    done = done || c0 >= p;
+                    if (!__ballot(!done)) break;
+                }
+            }
+        }
+        __syncthreads();
+        if (tid == 0) s_nbig = 0;                          /* (the next batch counts its own; ordered by the barriers of phase A) */
+        /* ---- C: the token ---- */
+        if (tid < nt) {
+            const uint32_t pl = tk_pl[tid], qo = pl & 0xFFFFu, len = (pl >> 16) & 0x7FFFu;
+            const uint32_t next = by[qo + len];
+            const uint32_t off = len ? wbase + qo - (uint32_t)(tk_best[tid] & 0xFFFFFFFFull) : 0u;
+            tokval[kb + tid] = (off & omask) | (len << ob) | (next << (ob + lb));
+        }
+        __syncthreads();
+    }
+}
+
+#ifdef LZ77X_VARIANTS   /* (round 4's form of the tie-break: hand-over lists per CELL, walked member by member -- the cross-check of
+                         * k_tokens_sorted, LZ77X_TS_V4=1) */
+__global__ __launch_bounds__(TS_BLOCK, 8) __attribute__((amdgpu_num_sgpr(80))) void k_tokens_sorted_v4(const uint8_t *__restrict__ in, uint32_t n, int sb, int la, int ob, int lb,
                                                             const uint32_t *__restrict__ chain, const uint32_t *__restrict__ tstart,
                                                             const uint8_t *__restrict__ maxlen, const uint32_t *__restrict__ ps,
                                                             const uint32_t *__restrict__ xval, uint32_t pos0, uint32_t pos1,
@@ -839,7 +1322,7 @@ __global__ __launch_bounds__(TS_BLOCK, 8) __attribute__((amdgpu_num_sgpr(80))) v
             uint32_t cnt = 0;
             if (tid < nt && (tk_pl[tid] >> 16)) cnt = (uint32_t)tk_hi[tid] - (uint32_t)tk_lo[tid];
             /* big runs: the first one a tile meets builds the bitmap of the slots whose cells have hand-overs */
-            if (cnt >= TS_BIG) s_want = 1u;
+            if (cnt >= TS_BIG_V4) s_want = 1u;
             __syncthreads();
             if (s_want) {
                 if (!hl_built) {
@@ -858,7 +1341,7 @@ __global__ __launch_bounds__(TS_BLOCK, 8) __attribute__((amdgpu_num_sgpr(80))) v
                     hl_built = true;
                     __syncthreads();
                 }
-                if (cnt >= TS_BIG) {
+                if (cnt >= TS_BIG_V4) {
                     /* ... a wavefront of its own (below) when few of its members have hand-overs, an eighth at most: a run
                      * that is dense with them is cheaper member by member, dealt over the whole workgroup */
                     const uint32_t lo = tk_lo[tid], hi = tk_hi[tid];
@@ -1018,6 +1501,7 @@ __global__ __launch_bounds__(TS_BLOCK, 8) __attribute__((amdgpu_num_sgpr(80))) v
         __syncthreads();
     }
 }
+#endif
 
 #ifdef LZ77X_VARIANTS   /* (round 1's large-window tie-break: the cross-check of k_tokens_rank, LZ77X_TOKEN_VARIANT=3) */
 /* ---- large windows (sb > 8192): the candidate index lives in global memory -------------------
@@ -1636,26 +2120,61 @@ hipError_t lz77k_tokens(const uint8_t *d_in, uint32_t n, const lz77x_geom &g, co
         const ts_grid G = ts_make_grid(g);
         const uint32_t tile0 = ts_tile_of(G, pos0), ntiles = ts_tile_of(G, pos1 - 1u) - tile0 + 1u;
         const uint32_t span = TS_TT + (uint32_t)g.sb + 16;
-        const uint32_t off_sorted = (span + (uint32_t)g.la + 16 + 15) & ~15u;
+        hipLaunchKernelGGL(k_tok_bounds_grid, dim3((ntok + 256) / 256), dim3(256), 0, s, d_chain, ntok, G, tile0, ntiles, d_tstart);
+        const uint32_t budget = 77u * 1024u - 256u;                       /* two workgroups per CU: 160 KB less 2 x 3 KB of static LDS */
+#ifdef LZ77X_VARIANTS
+        if (LZ77X_VENV("LZ77X_TS_V4")) {
+            /* round 4's kernel: lists per cell (the cross-check) */
+            const uint32_t off_sorted = (span + (uint32_t)g.la + 16 + 15) & ~15u;
+            const uint32_t off_inv = (off_sorted + 2 * span + 15) & ~15u;
+            const uint32_t off_lofs = (off_inv + 2 * TS_TT + 15) & ~15u;
+            const uint32_t off_tk = off_lofs + 2 * 8 * TS_BLOCK;                /* eight list offsets per thread: span + 2 <= 8192 */
+            const uint32_t off_lent = (off_tk + TS_TB * 8 + (TS_TB + 4) * 4 + TS_TB * 4 + TS_TB * 2 * 2 + 15) & ~15u;
+            /* a list entry is 6 bytes (eviction: uint16 from the tile's first, priority: uint32, two arrays); the area also
+             * holds a uint16 per eviction of a tile, what the lists fall back to when the priorities do not fit */
+            uint32_t ent_cap = ((budget - off_lent) / 6u) & ~1u;
+            if (const char *ec = LZ77X_VENV("LZ77X_TS_ENTCAP")) ent_cap = min(ent_cap, (uint32_t)atoi(ec) & ~1u);     /* test hook: the fallback lists */
+            const size_t lds = (size_t)off_lent + max((size_t)ent_cap * 6, (size_t)span * 2);
+            if (lds > 48 * 1024) {
+                hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_tokens_sorted_v4), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                if (e != hipSuccess) return e;
+            }
+            TIE_EV(0);
+            hipLaunchKernelGGL(k_tokens_sorted_v4, dim3((ntiles + 7u) / 8u * 8u), dim3(TS_BLOCK), lds, s, d_in, n, g.sb, g.la, g.ob, g.lb, d_chain, d_tstart, d_maxlen,
+                               d_ps, d_xval, pos0, pos1, d_tokval, ent_cap, off_sorted, off_inv, off_lofs, off_tk, off_lent, d_look, nlook, voff,
+                               reinterpret_cast<const uint16_t *>(d_ranks_all), g.RP, G, tile0, ntiles, d_total);
+            TIE_EV(1);
+            if (d_total) hipLaunchKernelGGL(k_ts_total, dim3(1), dim3(64), 0, s, d_total);
+            return hipGetLastError();
+        }
+#endif
+        /* [0, off_sorted): the 16-bit counters per slot while the lists are built, then the window bytes and the batch arrays */
+        const uint32_t off_tk = (span + (uint32_t)g.la + 16 + 15) & ~15u;
+        const uint32_t tk_bytes = TS_TB * 8 + 2 * (TS_TB + 4) * 4 + TS_TB * 4 + 2 * TS_TB * 2;
+        const uint32_t off_sorted = (max(off_tk + tk_bytes, 2u * 8u * TS_BLOCK) + 15) & ~15u;
         const uint32_t off_inv = (off_sorted + 2 * span + 15) & ~15u;
-        const uint32_t off_lofs = (off_inv + 2 * TS_TT + 15) & ~15u;
-        const uint32_t off_tk = off_lofs + 2 * 8 * TS_BLOCK;                /* eight list offsets per thread: span + 2 <= 8192 */
-        const uint32_t off_lent = (off_tk + TS_TB * 8 + (TS_TB + 4) * 4 + TS_TB * 4 + TS_TB * 2 * 2 + 15) & ~15u;
-        const uint32_t budget = 77u * 1024u - 256u;                       /* two workgroups per CU: 160 KB less 2 x 3 KB of static LDS (hl, big, the tables) */
-        /* a list entry is 6 bytes (eviction: uint16 from the tile's first, priority: uint32, two arrays); the area also
-         * holds a uint16 per eviction of a tile, what the lists fall back to when the priorities do not fit */
-        uint32_t ent_cap = ((budget - off_lent) / 6u) & ~1u;
-        if (const char *ec = LZ77X_VENV("LZ77X_TS_ENTCAP")) ent_cap = min(ent_cap, (uint32_t)atoi(ec) & ~1u);     /* test hook: the fallback lists */
-        const size_t lds = (size_t)off_lent + max((size_t)ent_cap * 6, (size_t)span * 2);
+        const uint32_t off_cofs = (off_inv + 2 * span + 15) & ~15u;
+        const uint32_t off_ent = (off_cofs + 2 * (8 * TS_BLOCK / TS_CG) + 15) & ~15u;
+        /* an entry is 8 bytes (slot | eviction << 16, priority: two arrays); the area also holds 4 bytes per eviction of a
+         * tile, what the entries fall back to when the priorities do not fit */
+        const uint32_t min_ent = (TS_TT + (uint32_t)g.sb) * 4u;
+        if (off_ent + min_ent > budget) return hipErrorInvalidValue;
+        uint32_t ent_cap = ((budget - off_ent) / 8u) & ~1u;
+        if (const char *ec = LZ77X_VENV("LZ77X_TS_ENTCAP")) ent_cap = min(ent_cap, (uint32_t)atoi(ec) & ~1u);     /* test hook: the fallback entries */
+        const size_t lds = (size_t)off_ent + max((size_t)ent_cap * 8, (size_t)min_ent);
         if (lds > 48 * 1024) {
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_tokens_sorted), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             if (e != hipSuccess) return e;
         }
-        hipLaunchKernelGGL(k_tok_bounds_grid, dim3((ntok + 256) / 256), dim3(256), 0, s, d_chain, ntok, G, tile0, ntiles, d_tstart);
         TIE_EV(0);
         hipLaunchKernelGGL(k_tokens_sorted, dim3((ntiles + 7u) / 8u * 8u), dim3(TS_BLOCK), lds, s, d_in, n, g.sb, g.la, g.ob, g.lb, d_chain, d_tstart, d_maxlen,
-                           d_ps, d_xval, pos0, pos1, d_tokval, ent_cap, off_sorted, off_inv, off_lofs, off_tk, off_lent, d_look, nlook, voff,
-                           reinterpret_cast<const uint16_t *>(d_ranks_all), g.RP, G, tile0, ntiles, d_total);
+                           d_ps, d_xval, pos0, pos1, d_tokval, ent_cap, off_tk, off_sorted, off_inv, off_cofs, off_ent, d_look, nlook, voff,
+                           reinterpret_cast<const uint16_t *>(d_ranks_all), g.RP, G, tile0, ntiles, d_total,
+                           (uint32_t)(LZ77X_VENV("LZ77X_TS_BIG") ? atoi(LZ77X_VENV("LZ77X_TS_BIG")) : TS_BIG)
+#ifdef LZ77X_VARIANTS
+                           , (uint32_t)(LZ77X_VENV("LZ77X_TS_PROBE") ? atoi(LZ77X_VENV("LZ77X_TS_PROBE")) : 0)
+#endif
+                           );
         TIE_EV(1);
         if (d_total) hipLaunchKernelGGL(k_ts_total, dim3(1), dim3(64), 0, s, d_total);
         return hipGetLastError();

@@ -332,7 +332,9 @@ struct CtxSet {
     Ctx primary;
     std::vector<Ctx *> more;
     bool busy = false;
+    size_t promised = 0;                  /* device memory this call's plan needs and does not hold yet (budget_commit) */
 };
+thread_local CtxSet *tl_set = nullptr;    /* the set leased by this thread's call */
 std::vector<CtxSet *> g_pool;
 std::mutex g_mu;
 std::condition_variable g_cv;
@@ -359,10 +361,13 @@ struct Lease {
             g_cv.wait(lk);
         }
         set->busy = true;
+        set->promised = 0;
+        tl_set = set;
     }
     ~Lease()
     {
-        { std::lock_guard<std::mutex> lk(g_mu); set->busy = false; }
+        { std::lock_guard<std::mutex> lk(g_mu); set->busy = false; set->promised = 0; }
+        tl_set = nullptr;
         g_cv.notify_one();
     }
     Lease(const Lease &) = delete;
@@ -381,16 +386,40 @@ int device_budget(Ctx &c, size_t *avail)
     size_t held = 0;
     for (DevBuf *b : c.dev_bufs()) held += b->cap;
     if (c.pipe) for (DevBuf *b : c.pipe->dev_bufs()) held += b->cap;
-    size_t busy = 0;
+    /* what the other callers inside the library were promised and have not allocated yet is not free: a first caller that
+     * sees busy == 1 plans with nearly everything, and without the reservation a second one would plan with the same bytes
+     * (a 288 GB device hides it, a shared or smaller one ends in hipErrorOutOfMemory).  A caller that has not planned yet counts
+     * for an equal share. */
+    size_t busy = 0, waiting = 0, reserved = 0;
     {
         std::lock_guard<std::mutex> lk(g_mu);
-        for (CtxSet *q : g_pool) busy += q->busy ? 1 : 0;
+        for (CtxSet *q : g_pool) {
+            if (!q->busy) continue;
+            busy++;
+            if (q == tl_set) continue;
+            if (q->promised) reserved += q->promised;
+            else waiting++;                            /* inside the library, not planned yet: an equal share */
+        }
     }
-    size_t a = fr / (busy ? busy : 1) + held;
+    (void)busy;
+    const size_t fr_eff = fr > reserved ? fr - reserved : 0;
+    size_t a = fr_eff / (waiting + 1) + held;
     const char *e = getenv("LZ77X_DEVICE_MEM_LIMIT");
     if (e && atoll(e) > 0 && (size_t)atoll(e) < a) a = (size_t)atoll(e);
     *avail = a;
     return LZ77X_OK;
+}
+
+/* the call's plan needs `planned` bytes of device memory in all: what it does not hold yet is reserved against the other
+ * callers' budgets until the call returns (Lease) */
+void budget_commit(Ctx &c, size_t planned)
+{
+    size_t held = 0;
+    for (DevBuf *b : c.dev_bufs()) held += b->cap;
+    if (c.pipe) for (DevBuf *b : c.pipe->dev_bufs()) held += b->cap;
+    if (!tl_set) return;
+    std::lock_guard<std::mutex> lk(g_mu);
+    tl_set->promised = planned > held ? planned - held : 0;
 }
 
 int ctx_init(Ctx &c, int device = -1)
@@ -1726,7 +1755,7 @@ int decode_resolve(Ctx &c, const lz77x_geom &g, uint32_t ntok, uint32_t n, hipSt
 }
 
 /* knobs of the range decoder: tokens per range (a multiple of eight) and bytes of output per range */
-void dec_range_plan(const lz77x_geom &g, size_t avail, uint32_t *range_tokens, uint32_t *range_bytes)
+void dec_range_plan(const lz77x_geom &g, size_t avail, uint32_t *range_tokens, uint32_t *range_bytes, size_t *planned = nullptr)
 {
     const char *e = getenv("LZ77X_DECODE_RANGE");
     uint64_t R = e && atoll(e) > 0 ? (uint64_t)atoll(e) : (uint64_t)1 << 26;
@@ -1741,7 +1770,10 @@ void dec_range_plan(const lz77x_geom &g, size_t avail, uint32_t *range_tokens, u
     /* a device with less to spare (device_budget) gets smaller ranges: per token two stream buffers + token words, lengths
      * and offsets; per output byte the byte itself + a 16-bit reference (segment walk) or a pointer and two work-list
      * entries (tile pass / per-byte pointers) */
-    const double per_tok = 2.0 * g.T / 8.0 + 12.5, per_byte = lz77k_dec_seg_supported(g) ? 4.3 : 14.3;     /* (two output buffers: RangeDrain) */
+    /* (a power-of-two window means distance-0 copies: decode_resolve follows the reference's staging buffer and takes the
+     * pointer paths, whatever the segment walk supports) */
+    const bool seg_walk = lz77k_dec_seg_supported(g) && (g.sb & (g.sb - 1)) != 0;
+    const double per_tok = 2.0 * g.T / 8.0 + 12.5, per_byte = seg_walk ? 4.3 : 14.3;     /* (two output buffers: RangeDrain) */
     const double need = 1.125 * (per_tok * (double)R + per_byte * (double)cap) + 64e6;
     if (avail && need > 0.9 * (double)avail) {
         const double f = 0.9 * (double)avail / need;
@@ -1752,6 +1784,7 @@ void dec_range_plan(const lz77x_geom &g, size_t avail, uint32_t *range_tokens, u
     }
     *range_tokens = (uint32_t)R;
     *range_bytes = (uint32_t)cap;
+    if (planned) *planned = (size_t)(1.125 * (per_tok * (double)R + per_byte * (double)cap) + 64e6);
 }
 
 int ctx_sibling(Ctx &c, Ctx **out);
@@ -1772,6 +1805,7 @@ struct RangeDrain {
     int rc = LZ77X_OK;
     char err[256] = "";
     bool stop = false, started = false;
+    bool abort = false;                   /* set by the destructor unless everything submitted was waited for: queued jobs are dropped */
     void run()
     {
         hipError_t e = hipSetDevice(dc->device);
@@ -1787,7 +1821,9 @@ struct RangeDrain {
             }
             int r = LZ77X_OK;
             g_err[0] = 0;
-            if (rc == LZ77X_OK) {
+            bool drop;
+            { std::lock_guard<std::mutex> lk(mu); drop = abort; }
+            if (rc == LZ77X_OK && !drop) {
                 if (hipStreamWaitEvent(dc->stream, j.ready, 0) != hipSuccess) r = LZ77X_E_HIP;
                 else r = sink->write(*dc, j.d, j.n, dc->stream);
             }
@@ -1828,7 +1864,9 @@ struct RangeDrain {
     ~RangeDrain()
     {
         if (!started) return;
-        { std::lock_guard<std::mutex> lk(mu); stop = true; }
+        /* a caller that leaves on an error has not waited for its jobs: no more output after a failed call (and no
+         * long pwrite before the error returns).  On the success path wait(0) has emptied the queue. */
+        { std::lock_guard<std::mutex> lk(mu); stop = true; if (submitted != done) abort = true; }
         cv.notify_all();
         th.join();
     }
@@ -1860,13 +1898,19 @@ int decode_stream(Ctx &c, Source &src, Sink *sink, hipStream_t s, uint64_t *n_ou
     uint32_t R = 0, cap = 0;
     size_t avail = 0;
     if ((rc = device_budget(c, &avail))) return rc;
-    dec_range_plan(g, avail, &R, &cap);
+    size_t planned = 0;
+    dec_range_plan(g, avail, &R, &cap, &planned);
     /* a stream whose size is known and lies inside one range is sized by what it holds: the range shrinks to the stream plus
      * one token (reading then meets the end of the stream inside it) */
     {
         const size_t hint = src.size_hint();
-        if (hint && hint / (size_t)g.T + 2 < (size_t)R / 8) R = (uint32_t)((hint / (size_t)g.T + 2) * 8);
+        if (hint && hint / (size_t)g.T + 2 < (size_t)R / 8) {
+            const uint32_t R0 = R;
+            R = (uint32_t)((hint / (size_t)g.T + 2) * 8);
+            planned = (size_t)((double)planned * (double)R / (double)R0) + ((size_t)64 << 20);      /* (tokens and bytes shrink together) */
+        }
     }
+    budget_commit(c, planned);
     const size_t rbytes = (size_t)R / 8 * (size_t)g.T;                        /* R tokens are exactly this many bytes */
     DevBuf *zb[2] = {&c.z, &c.z2};
     DevBuf *outb[2] = {&c.out, &c.out2};
@@ -2424,6 +2468,7 @@ int encode_stream_device(Ctx &c, Source &src, Sink &sink, const lz77x_geom &g, h
         if ((rc = device_budget(c, &avail))) return rc;
         const size_t per_pos = g.fast ? 34 : 70, slack = (size_t)384 << 20;    /* (the cached buffers carry an eighth of headroom each) */
         const size_t one_region = lz77k_match_scratch_bytes(g, 1);
+        size_t planned = 0;
         for (int pass = 0; pass < 2; pass++) {
             /* one context set while the input is one segment; two as soon as it is not (the second pass) */
             const bool two = pipelined && (pass == 1 || !(known && known <= seg));
@@ -2441,8 +2486,10 @@ int encode_stream_device(Ctx &c, Source &src, Sink &sink, const lz77x_geom &g, h
             const size_t seg_new = seg > seg_fit ? (seg_fit < lo ? lo : seg_fit) : seg;
             const bool multi = !(known && known <= seg_new);
             seg = seg_new;
+            planned = (fixed + per_pos * seg) * (two ? 2 : 1);
             if (two || !multi || !pipelined) break;              /* (else: it became several segments -- plan again for two in flight) */
         }
+        budget_commit(c, planned);
         if (trace_on())
             fprintf(stderr, "[lz77x] memory plan: %.1f MB to plan with, segments of %zu positions, %.1f MB of match scratch per launch\n", avail / 1e6,
                     seg, scratch_cap / 1e6);
@@ -2521,6 +2568,7 @@ int encode_stream_device(Ctx &c, Source &src, Sink &sink, const lz77x_geom &g, h
         SegJob *prev = nullptr;
         bool busy = false, stop = false, started = false, on = false;   /* on: a load has been handed over and not yet waited for */
         int rc = LZ77X_OK;
+        char err[256] = "";                   /* g_err is thread_local: what the loader thread wrote there comes back through here */
         void run()
         {
             const bool dev_ok = hipSetDevice(device) == hipSuccess;
@@ -2532,9 +2580,11 @@ int encode_stream_device(Ctx &c, Source &src, Sink &sink, const lz77x_geom &g, h
                 SegJob *p = prev;
                 req = -1;
                 lk.unlock();
+                g_err[0] = 0;
                 const int r = dev_ok ? fn(k, p) : LZ77X_E_HIP;
                 lk.lock();
                 rc = r;
+                if (r != LZ77X_OK) snprintf(err, sizeof err, "%s", dev_ok ? g_err : "hipSetDevice failed on the loader thread");
                 busy = false;
                 cv.notify_all();
             }
@@ -2556,6 +2606,7 @@ int encode_stream_device(Ctx &c, Source &src, Sink &sink, const lz77x_geom &g, h
             std::unique_lock<std::mutex> lk(mu);
             cv.wait(lk, [&] { return !busy; });
             on = false;
+            if (rc != LZ77X_OK) snprintf(g_err, sizeof g_err, "%s", err);
             return rc;
         }
         ~Loader()

@@ -361,11 +361,13 @@ def test_segments_give_identical_bytes(kind, seed, n, sb, la, seg, monkeypatch):
                                  {"LZ77X_SORT_VARIANT": "2"}, {"LZ77X_TOKEN_VARIANT": "1"}, {"LZ77X_TOKEN_VARIANT": "2"}, {"LZ77X_WALK_RUN": "256"}, {"LZ77X_WALK_RUN": "1000"},
                                  {"LZ77X_WALK_RUN": "4096"}, {"LZ77X_C1_SORT_V1": "1"}, {"LZ77X_MATCH_BATCH": "7"}, {"LZ77X_PRIO_SKIP": "1"},
                                  {"LZ77X_PRIO_SKIP": "1", "LZ77X_PRIO_BLOCK": "16384"}, {"LZ77X_PRIO_SKIP": "0", "LZ77X_PRIO_BLOCK": "16384"},
-                                 {"LZ77X_PRIO_BACK_SWEEP": "1"}, {"LZ77X_TS_ENTCAP": "64"}, {"LZ77X_TS_ENTCAP": "1500"}])
+                                 {"LZ77X_PRIO_BACK_SWEEP": "1"}, {"LZ77X_TS_ENTCAP": "64"}, {"LZ77X_TS_ENTCAP": "1500"}, {"LZ77X_TS_V4": "1"},
+                                 {"LZ77X_TS_V4": "1", "LZ77X_TS_ENTCAP": "64"}])
 def test_kernel_variants_agree(env, monkeypatch):
     """independent formulations of the same stage (exhaustive pair scan vs bitmap walkers, merge sort vs
     plain / blocked bitonic sort, three token kernels, sequential vs pointer-doubling boundary maps; LZ77X_TS_ENTCAP: the
-    tie-break's hand-over lists when the priorities do not fit the LDS) all reproduce the reference stream"""
+    tie-break's hand-over entries when the priorities do not fit the LDS; LZ77X_TS_V4: round 4's tie-break, hand-over lists
+    per cell walked member by member, beside the entries by slot of round 5) all reproduce the reference stream"""
     data = synth.mixed(3_000_000, 86)
     want = O.encode_bst(data)
     for k, v in env.items():
@@ -702,6 +704,34 @@ def test_cli_streams_large_files_and_pipes(tmp_path):
     r = subprocess.run([L.CLI_PATH, "-c", "-i", src, "-o", lz], capture_output=True,
                        env=dict(os.environ, LZ77X_SHARDS="2", LZ77X_FAKE_DEVICES="2"))
     assert r.returncode == 0 and open(lz, "rb").read() == L.encode(data[:3_000_000])
+
+
+def test_cli_io_error_contract_equals_reference(tmp_path):
+    """lz77.c:79-82: a failed read of the input (here: a directory, fread fails with EISDIR) is one line on STDOUT and exit
+    status 0 -- and a header-only stream in the output file (lz77.c:74-75 runs before the read); a decode whose input
+    cannot be read: perror + EXIT_FAILURE (lz77.c:273-277).  The product CLI and the reference's unmodified main.c linked
+    against the shim say what the reference binary says."""
+    lz = str(tmp_path / "o.lz")
+    d = str(tmp_path / "dir")
+    os.mkdir(d)
+    want = (0, "Error loading the data in the window.\n", "")
+    bins = [L.CLI_PATH]
+    if O.have_ref():
+        ref = subprocess.run([O.REF_BIN, "-c", "-i", d, "-o", lz], capture_output=True, text=True)
+        assert (ref.returncode, ref.stdout, ref.stderr) == want
+        shim = os.path.join(O.ORACLE_DIR, "_ref", "lz77_shimmed")
+        if os.path.exists(shim):
+            bins.append(shim)
+    for b in bins:
+        r = subprocess.run([b, "-c", "-i", d, "-o", lz], capture_output=True, text=True)
+        assert (r.returncode, r.stdout, r.stderr) == want, b
+    # LZ77X_FAST_EXIT=0 (and any LZ77X_TRACE run) leaves through exit(): same bytes, same status
+    src = str(tmp_path / "in")
+    synth.text(200_000, 5).tofile(src)
+    a = subprocess.run([L.CLI_PATH, "-c", "-i", src, "-o", lz], capture_output=True)
+    first = open(lz, "rb").read()
+    b = subprocess.run([L.CLI_PATH, "-c", "-i", src, "-o", lz], capture_output=True, env=dict(os.environ, LZ77X_FAST_EXIT="0"))
+    assert a.returncode == 0 and b.returncode == 0 and open(lz, "rb").read() == first == L.encode(synth.text(200_000, 5))
 
 
 def test_device_api_with_torch():
