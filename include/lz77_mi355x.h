@@ -148,7 +148,7 @@ typedef struct lz77x_stats {
     uint32_t match_launches;  /* launches of the region kernel in the call */
     uint32_t decode_rounds;   /* pointer-jumping rounds */
     double k_walk_ms;         /* of k_match_ms: the window-walker kernel alone (0 if that path was not taken) */
-    double k_tiebreak_ms;     /* of k_token_ms: the tie-break kernel alone (k_tokens_tile / k_tokens_big) */
+    double k_tiebreak_ms;     /* of k_token_ms: the tie-break kernel alone (k_tokens_sorted; large windows: k_tokens_rank_group) */
     uint32_t token_launches;  /* launches of the tie-break kernel in the call */
     uint32_t prio_iters;      /* gate iterations of the device priority recurrence (0: it ran on the host) */
     double k_prio_ms;         /* device priority recurrence (replaces host_stageb_ms when it runs) */

@@ -1,6 +1,6 @@
 /*
  * fileio.c -- whole-file-in-host-memory form of lz77x_encode_file (plain C).  The public entry point
- * (pipeline.cpp) streams the file through two pinned staging slots instead and only comes here when one
+ * (api.cpp, encode_pipe.cpp) streams the file through two pinned staging slots instead and only comes here when one
  * stream is cut into several shards (LZ77X_SHARDS > 1: the other devices need a host copy of the input).
  */
 #include "../../include/lz77_mi355x.h"

@@ -5,9 +5,8 @@
  *   - which node a tree.c:182-243 delete() promotes, restated as a priority
  *     hand-over between a position and its in-order successor       (SURVEY A.5 stage B).
  * Since round 3 both run on the DEVICE for every window size (k_chain.hip, k_prio.hip, k_priow.hip); the loops
- * here are what the host-assisted pipeline (encode_core_host in pipeline.cpp) runs -- the fallback when the
- * device's gate iteration does not converge, a large-window stream cut over several devices, and the
- * lz77x_stage_priorities cross-check of the parity tests.  O(1) per byte on per-position results of the match
+ * here are what the host-assisted pipeline (encode_core_host in encode_host.cpp) runs -- the fallback when the
+ * device's gate iteration does not converge -- and the lz77x_stage_priorities cross-check of the parity tests.  O(1) per byte on per-position results of the match
  * kernels.
  */
 #include "lz77x_internal.h"

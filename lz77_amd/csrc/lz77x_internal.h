@@ -1,6 +1,6 @@
 /*
  * lz77x_internal.h -- shared between the HIP translation units (k_*.hip), the
- * host pipeline (pipeline.cpp) and the sequential host stage (hoststage.c).
+ * host side (host.h: ctx, hostio, encode_pipe, encode_host, decode_pipe, shard, api) and the sequential host stage (hoststage.c).
  * Not part of the public ABI (that is include/lz77_mi355x.h).
  */
 #ifndef LZ77X_INTERNAL_H

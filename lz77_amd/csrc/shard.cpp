@@ -1,0 +1,600 @@
+/*
+ * shard.cpp -- ONE stream on SEVERAL devices, both directions, and the host-only shard arithmetic the C ABI exports (what the
+ * world-size-2 gloo test drives).
+ */
+#include "host.h"
+
+using namespace lz77x_host;
+
+extern "C" {
+
+/* host-only: how one stream of n bytes is cut for `shards` devices.  Returns the number of shards actually
+ * used (a shard is never smaller than 4*sb + 12 KiB) */
+int lz77x_shard_plan(size_t n, int sb, int la, int shards, lz77x_shard *out)
+{
+    if (check_geom(sb, la) != LZ77X_OK || shards < 1) return LZ77X_E_ARG;
+    const size_t usb = (size_t)sb, halo = (size_t)la + 64;
+    size_t D = (size_t)shards;
+    const size_t min_shard = 4 * usb + 3 * (size_t)4096;
+    while (D > 1 && n / D < min_shard) D--;
+    for (size_t d = 0; d < D && out; d++) {
+        lz77x_shard &j = out[d];
+        j.first_token_pos = (uint64_t)n * d / D;
+        j.end_token_pos = (uint64_t)n * (d + 1) / D;
+        j.lookback = d ? (uint32_t)usb : 0u;
+        j.local0 = j.first_token_pos - j.lookback;
+        const uint64_t end = d + 1 == D ? (uint64_t)n : (j.end_token_pos + halo < n ? j.end_token_pos + halo : (uint64_t)n);
+        j.local_bytes = end - j.local0;
+        j.steps = j.end_token_pos - j.local0 > usb ? j.end_token_pos - j.local0 - usb : 0;
+    }
+    return (int)D;
+}
+
+/* host-only: one shard's whole map of boundary cells applied to the cells it starts from (in place):
+ * cells[d] <- min(loc[d], min{ cells[c] : dest[c] = d }) */
+void lz77x_shard_compose_cells(const uint16_t *dest, const uint32_t *loc, int sb, uint32_t *cells)
+{
+    std::vector<uint32_t> vo(loc, loc + sb);
+    for (int i = 0; i < sb; i++)
+        if (dest[i] != 0xFFFFu && cells[i] < vo[dest[i]]) vo[dest[i]] = cells[i];
+    memcpy(cells, vo.data(), (size_t)sb * 4);
+}
+
+/* host-only: one shard's parse-chain map applied to the running (entry offset, token count) */
+void lz77x_shard_compose_chain(const uint8_t *exit_of, const uint32_t *tokens_of, uint32_t *entry, uint64_t *tokens)
+{
+    *tokens += tokens_of[*entry];
+    *entry = exit_of[*entry];
+}
+
+/* host-only, decode: where shard d's tokens begin */
+uint64_t lz77x_shard_token_cut(uint64_t ntok, int shards, int d)
+{
+    if (shards < 1 || d <= 0) return 0;
+    if (d >= shards) return ntok;
+    return (ntok * (uint64_t)d / (uint64_t)shards) & ~(uint64_t)7;
+}
+
+/* host-only, decode: one shard's map (the composition of its segments' tails) applied to the sb bytes before it */
+void lz77x_shard_compose_tail(const uint16_t *map, int sb, const uint8_t *incoming, uint8_t *outgoing)
+{
+    for (int i = 0; i < sb; i++) {
+        const uint16_t x = map[i];
+        outgoing[i] = (x & 0xC000u) == 0x8000u ? incoming[x & 0x3FFFu] : (uint8_t)x;
+    }
+}
+
+/* the same for windows above 8192 (the tile pass leaves 32-bit states: k_dec_tail_map) */
+void lz77x_shard_compose_tail32(const uint32_t *map, int sb, const uint8_t *incoming, uint8_t *outgoing)
+{
+    for (int i = 0; i < sb; i++) {
+        const uint32_t x = map[i];
+        outgoing[i] = (x & 0x10000u) ? incoming[x & 0xFFFFu] : (uint8_t)x;
+    }
+}
+
+}  // extern "C"
+
+LZ77X_HOST_NS {
+
+/* ONE stream decoded on SEVERAL devices: the tokens are cut into D contiguous ranges at multiples of
+ * eight tokens (every range then starts on a byte of the stream); device d parses and scans its range and walks
+ * its segments with the sb bytes before its first output byte as symbolic references, like any segment's
+ * (k_dec_seg ext0) -- nothing it does depends on another shard.  What crosses the cuts is, per shard, ONE map of sb
+ * states (a byte value, or "byte i of the bytes before me": the composition of all its segments' tails), chained on
+ * the host front to back (D steps of sb table look-ups), after which every shard is handed its sb incoming bytes,
+ * resolves its tails and patches its flagged bytes.  No device-to-device traffic, no collective; device memory per
+ * shard ~ its share of the tokens and of the output.  *handled = 0: not a case for this path (distance-0 copies,
+ * windows above 8192, a shard shorter than the window, too few tokens) -- the caller decodes on one device. */
+int decode_sharded(std::vector<Ctx *> &cs, const uint8_t *z, size_t zn, uint8_t **out, size_t *out_n, int *handled)
+{
+    const double t_begin = now_ms();
+    *handled = 0;
+    int rc;
+    DeviceRestore restore(cs[0]->device);
+    if (zn < 4) return LZ77X_E_FORMAT;
+    const int sb = z[0] | (z[1] << 8), la = z[2] | (z[3] << 8);               /* lz77.c:157-158 */
+    if (sb < 1 || la < 1) return LZ77X_E_FORMAT;
+    lz77x_geom g;
+    lz77x_make_geom(&g, sb, la);
+    if (g.T > 32) return LZ77X_E_FORMAT;
+    const uint64_t ntok64 = ((uint64_t)zn * 8 - 32) / (uint64_t)g.T;
+    if (ntok64 > LZ77X_MAX_N) return LZ77X_OK;                                  /* (the range decoder takes any length on one device) */
+    const uint32_t ntok = (uint32_t)ntok64;
+    const size_t D = cs.size();
+    if (la > 255 || LZ77X_VENV("LZ77X_DECODE_V1") || ntok < 64 * D) return LZ77X_OK;
+    /* windows the segment walk takes (sb <= 8192): symbolic tails per segment; above: the tile pass on [history | output]
+     * with the history still unknown (lz77k_dec_tail_map) */
+    const bool tiles = !lz77k_dec_seg_supported(g) || LZ77X_VENV("LZ77X_DECODE_VARIANT");
+    const size_t usb = (size_t)sb;
+    std::vector<uint32_t> k0(D + 1);
+    for (size_t d = 0; d <= D; d++) k0[d] = (uint32_t)lz77x_shard_token_cut(ntok, (int)D, (int)d);
+    struct Sh { uint32_t ntok = 0, n = 0; lz77k_dec_seg_state P; const uint16_t *d_smap = nullptr; };
+    std::vector<Sh> sh(D);
+    /* 1. every shard: its bytes of the stream behind a header of its own, parse, scan (a host thread per shard: the
+     *    copies out of the caller's pageable stream block their thread) */
+    rc = for_each_shard(D, [&](size_t d) -> int {
+        int rc;
+        Ctx &c = *cs[d];
+        HIPCHK(hipSetDevice(c.device));
+        hipStream_t s = c.stream;
+        Sh &S = sh[d];
+        S.ntok = k0[d + 1] - k0[d];
+        const size_t b0 = 4 + (size_t)k0[d] * g.T / 8, b1 = 4 + ((size_t)k0[d + 1] * g.T + 7) / 8;      /* k0 is a multiple of 8: b0 exact */
+        const size_t zb = 4 + (b1 - b0);
+        if ((rc = c.z.need(zb + 32))) return rc;
+        if ((rc = c.h_small.need(128))) return rc;
+        HIPCHK(hipMemsetAsync(c.z.as<uint8_t>() + zb, 0, 32, s));
+        HIPCHK(hipMemcpyAsync(c.z.p, z, 4, hipMemcpyHostToDevice, s));
+        HIPCHK(hipStreamSynchronize(s));
+        if ((rc = upload_pageable(c, c.z.as<uint8_t>() + 4, z + b0, b1 - b0))) return rc;
+        if ((rc = c.tokval.need(((size_t)S.ntok + 8) * 4))) return rc;
+        if ((rc = c.len1.need(((size_t)S.ntok + 8) * 4))) return rc;
+        if ((rc = c.dst.need(((size_t)S.ntok + 8) * 4))) return rc;
+        if ((rc = c.scantmp.need(lz77k_scan_tmp_bytes(S.ntok + 1)))) return rc;
+        if ((rc = c.flag.need(64))) return rc;
+        HIPCHK(hipMemsetAsync(c.flag.as<uint32_t>() + 8, 0, 8, s));
+        HIPCHK(lz77k_dec_parse(c.z.as<uint8_t>(), S.ntok, g, c.tokval.as<uint32_t>(), c.len1.as<uint32_t>(), s, c.flag.as<uint32_t>() + 8));
+        HIPCHK(hipMemsetAsync(c.len1.as<uint32_t>() + S.ntok, 0, 4, s));
+        HIPCHK(lz77k_sum_u32(c.len1.as<uint32_t>(), S.ntok, c.flag.as<unsigned long long>() + 2, s));
+        HIPCHK(lz77k_scan_u32(c.len1.as<uint32_t>(), c.dst.as<uint32_t>(), S.ntok + 1, c.scantmp.p, s));
+        uint32_t *h = c.h_small.as<uint32_t>();
+        HIPCHK(hipMemcpyAsync(h + 4, c.flag.as<unsigned long long>() + 2, 8, hipMemcpyDeviceToHost, s));
+        HIPCHK(hipMemcpyAsync(h + 8, c.flag.as<uint32_t>() + 8, 8, hipMemcpyDeviceToHost, s));
+        return LZ77X_OK;
+    });
+    if (rc) return rc;
+    uint64_t n = 0;
+    bool fits = true;
+    std::vector<uint64_t> o0(D + 1, 0);
+    for (size_t d = 0; d < D; d++) {
+        Ctx &c = *cs[d];
+        HIPCHK(hipSetDevice(c.device));
+        HIPCHK(hipStreamSynchronize(c.stream));
+        const uint32_t *h = c.h_small.as<uint32_t>();
+        const uint64_t nd = *reinterpret_cast<const unsigned long long *>(h + 4);
+        if (h[8] != 0 || h[9] != 0 || nd < usb || nd > LZ77X_MAX_N) fits = false;   /* distance-0 copies, distances beyond the window / a shard inside one window */
+        sh[d].n = (uint32_t)nd;
+        o0[d + 1] = o0[d] + nd;
+    }
+    n = o0[D];
+    if (!fits || n > LZ77X_MAX_N) { HIPCHK(hipSetDevice(cs[0]->device)); return LZ77X_OK; }
+    uint8_t *buf = nullptr;
+    const uint32_t pre = tiles ? (uint32_t)((usb + LZ77K_DEC_TILE_BYTES - 1) / LZ77K_DEC_TILE_BYTES * LZ77K_DEC_TILE_BYTES) : 0u;
+    std::vector<const unsigned long long *> d_unres(D, nullptr);
+    if (tiles) {
+        /* 2t. every shard, on a host thread of its own (the jumping rounds look at a counter between passes): tile pass and
+         *     jumping on [pre bytes of history | output]; the history counts as resolved, so afterwards every byte holds its
+         *     value or points at one that does -- inside the shard or in the history; then the shard's last sb bytes as a map */
+        std::vector<std::vector<uint32_t>> tmap(D, std::vector<uint32_t>(usb));
+        rc = for_each_shard(D, [&](size_t d) -> int {
+            int rc;
+            Ctx &c = *cs[d];
+            HIPCHK(hipSetDevice(c.device));
+            hipStream_t st = c.stream;
+            Sh &S = sh[d];
+            const uint32_t N = pre + S.n;
+            if ((rc = c.out.need((size_t)N + 16))) return rc;
+            if ((rc = c.ptr.need(((size_t)N + 8) * 4))) return rc;
+            if ((rc = c.ps.need(((size_t)N + 8) * 4))) return rc;
+            if ((rc = c.cells.need(((size_t)N + 8) * 4))) return rc;
+            if ((rc = c.tstart.need(lz77k_dec_tile_tmp_bytes(N) + usb * 4 + 256))) return rc;
+            if ((rc = c.flag.need(64))) return rc;
+            uint8_t *X = c.out.as<uint8_t>();
+            HIPCHK(hipMemsetAsync(X, 0, pre, st));
+            HIPCHK(lz77k_dec_tiles(c.tokval.as<uint32_t>(), c.dst.as<uint32_t>(), S.ntok, g, X, c.ptr.as<uint32_t>(), N, c.tstart.p, &d_unres[d], st,
+                                   lz77k_dec_stale(), pre));
+            uint32_t *lists[2] = {c.ps.as<uint32_t>(), c.cells.as<uint32_t>()};
+            uint32_t *hcount = c.h_small.as<uint32_t>() + 16;
+            uint32_t total = N, rounds = 0;
+            const uint32_t *in_list = nullptr;
+            for (;;) {
+                HIPCHK(hipMemsetAsync(c.flag.p, 0, 4, st));
+                HIPCHK(lz77k_dec_jump2(c.ptr.as<uint32_t>(), d_unres[d], total, in_list, lists[rounds & 1], c.flag.as<uint32_t>(), st));
+                HIPCHK(hipMemcpyAsync(hcount, c.flag.p, 4, hipMemcpyDeviceToHost, st));
+                HIPCHK(hipStreamSynchronize(st));
+                in_list = lists[rounds & 1];
+                total = *hcount;
+                rounds += 1;
+                if (!total || rounds > 80) break;
+            }
+            uint32_t *d_map = reinterpret_cast<uint32_t *>(reinterpret_cast<uint8_t *>(c.tstart.p) + ((lz77k_dec_tile_tmp_bytes(N) + 255) & ~(size_t)255));
+            HIPCHK(lz77k_dec_tail_map(X, c.ptr.as<uint32_t>(), d_unres[d], pre, N, (uint32_t)usb, d_map, st));
+            HIPCHK(hipMemcpyAsync(tmap[d].data(), d_map, usb * 4, hipMemcpyDeviceToHost, st));
+            HIPCHK(hipStreamSynchronize(st));
+            return LZ77X_OK;
+        });
+        if (rc) return rc;
+        /* 3t. the host chains the maps (nothing lies before the first shard: zeros) */
+        std::vector<std::vector<uint8_t>> incoming(D, std::vector<uint8_t>(usb, 0));
+        for (size_t d = 0; d + 1 < D; d++) lz77x_shard_compose_tail32(tmap[d].data(), sb, incoming[d].data(), incoming[d + 1].data());
+        /* 4t. every shard: its history in, the bytes that point somewhere gathered */
+        buf = (uint8_t *)malloc(n ? (size_t)n : 1);
+        if (!buf) return LZ77X_E_NOMEM;
+        for (size_t d = 0; d < D; d++) {
+            Ctx &c = *cs[d];
+            hipError_t e = hipSetDevice(c.device);
+            uint8_t *X = c.out.as<uint8_t>();
+            if (e == hipSuccess) e = hipMemcpyAsync(X + pre - usb, incoming[d].data(), usb, hipMemcpyHostToDevice, c.stream);
+            if (e == hipSuccess) e = hipStreamSynchronize(c.stream);                 /* (incoming[] is pageable) */
+            if (e == hipSuccess) e = lz77k_dec_gather2(X, c.ptr.as<uint32_t>(), d_unres[d], pre + sh[d].n, c.stream);
+            if (e != hipSuccess) { free(buf); snprintf(g_err, sizeof g_err, "HIP: %s", hipGetErrorString(e)); return LZ77X_E_HIP; }
+        }
+    } else {
+    /* 2. every shard: segment walk, tails composed into the shard's map */
+    std::vector<std::vector<uint16_t>> smap(D, std::vector<uint16_t>(usb));
+    for (size_t d = 0; d < D; d++) {
+        Ctx &c = *cs[d];
+        HIPCHK(hipSetDevice(c.device));
+        Sh &S = sh[d];
+        if ((rc = c.out.need((size_t)S.n + 16))) return rc;
+        if ((rc = c.ptr.need(((size_t)S.n + 8) * 4))) return rc;
+        if ((rc = c.tstart.need(lz77k_dec_seg_tmp_bytes(S.n, g)))) return rc;
+        HIPCHK(lz77k_dec_segments_front(c.tokval.as<uint32_t>(), c.dst.as<uint32_t>(), S.ntok, g, c.out.as<uint8_t>(), c.ptr.p, S.n, c.tstart.p,
+                                        c.stream, true, S.P, &S.d_smap));
+        HIPCHK(hipMemcpyAsync(smap[d].data(), S.d_smap, usb * 2, hipMemcpyDeviceToHost, c.stream));
+    }
+    /* 3. the host chains the maps: incoming bytes of every shard (nothing lies before the first: zero bytes, what a
+     *    copy from before the start of the output reads in the single-device decoder too) */
+    std::vector<std::vector<uint8_t>> incoming(D, std::vector<uint8_t>(usb, 0));
+    for (size_t d = 0; d + 1 < D; d++) {
+        Ctx &c = *cs[d];
+        HIPCHK(hipSetDevice(c.device));
+        HIPCHK(hipStreamSynchronize(c.stream));
+        lz77x_shard_compose_tail(smap[d].data(), sb, incoming[d].data(), incoming[d + 1].data());
+    }
+    /* 4. every shard: incoming bytes in, tails resolved, flagged bytes patched, output to the host */
+    buf = (uint8_t *)malloc(n ? (size_t)n : 1);
+    if (!buf) return LZ77X_E_NOMEM;
+    for (size_t d = 0; d < D; d++) {
+        Ctx &c = *cs[d];
+        hipError_t e = hipSetDevice(c.device);
+        if (e == hipSuccess) e = hipMemcpyAsync(sh[d].P.tres0, incoming[d].data(), usb, hipMemcpyHostToDevice, c.stream);
+        if (e == hipSuccess) e = lz77k_dec_segments_back(g, c.out.as<uint8_t>(), c.ptr.p, sh[d].n, sh[d].P, c.stream);
+        if (e != hipSuccess) { free(buf); snprintf(g_err, sizeof g_err, "HIP: %s", hipGetErrorString(e)); return LZ77X_E_HIP; }
+    }
+    }
+    rc = for_each_shard(D, [&](size_t d) -> int {           /* the gather: every device fetches its bytes at once */
+        Ctx &c = *cs[d];
+        HIPCHK(hipSetDevice(c.device));
+        HIPCHK(hipStreamSynchronize(c.stream));
+        return fetch_result(c, buf + o0[d], c.out.as<uint8_t>() + pre, sh[d].n);
+    });
+    if (rc) { free(buf); return rc; }
+    HIPCHK(hipSetDevice(cs[0]->device));
+    memset(&g_stats, 0, sizeof g_stats);
+    g_stats.n = n;
+    g_stats.zn = zn;
+    g_stats.ntok = ntok;
+    g_stats.total_ms = now_ms() - t_begin;
+    *out = buf;
+    *out_n = (size_t)n;
+    *handled = 1;
+    return LZ77X_OK;
+}
+
+struct ShardJob {
+    Ctx *c = nullptr;
+    uint64_t a = 0, b = 0, gpos0 = 0;      /* tokens [a, b) (global), local 0 = gpos0 */
+    uint32_t look = 0, nloc = 0, E = 0, nx = 0, entry = 0, start = 0, ntok = 0, nsub = 0;
+    uint64_t K0 = 0;
+    lz77k_prio_plan P;
+    const uint32_t *d_tbase = nullptr;
+    uint32_t *h = nullptr;                  /* pinned scratch of this shard (c->h_tbase) */
+};
+
+int encode_sharded(std::vector<Ctx *> &cs, const uint8_t *src, size_t n, const lz77x_geom &g, Sink &sink)
+{
+    const double t_begin = now_ms();
+    memset(&g_stats, 0, sizeof g_stats);
+    if (n > LZ77X_MAX_N) return LZ77X_E_TOOBIG;
+    const size_t usb = (size_t)g.sb;
+    const uint32_t csub = lz77k_chain_sub();
+    std::vector<lz77x_shard> plan(cs.size());
+    const int planned = lz77x_shard_plan(n, g.sb, g.la, (int)cs.size(), plan.data());
+    if (planned < 1) return LZ77X_E_ARG;
+    const size_t D = (size_t)planned;
+    std::vector<ShardJob> J(D);
+    int rc;
+    const char *tv = LZ77X_VENV("LZ77X_TOKEN_VARIANT");
+    const int tvariant = tv ? atoi(tv) : 0;
+    auto dev = [&](ShardJob &j) -> int { HIPCHK(hipSetDevice(j.c->device)); return LZ77X_OK; };
+    auto sync_all = [&]() -> int {
+        for (ShardJob &j : J) { HIPCHK(hipSetDevice(j.c->device)); HIPCHK(hipStreamSynchronize(j.c->stream)); }
+        return LZ77X_OK;
+    };
+    const size_t hwords = 4 * usb + 1024;                 /* pinned words per shard beyond the tbase copy */
+
+    /* -- phase A: every shard on its own: input, match stage, the parse chain's maps, round masks.  One host thread
+     *    per shard: the copy out of the caller's pageable buffer blocks its thread (hipMemcpyAsync stages it), and D of
+     *    them in sequence on one thread were D x n/D bytes of serial PCIe time before the last device saw a byte -- */
+    DeviceRestore restore(cs[0]->device);
+    double host_serial_ms = 0;                              /* host time between the phases that no device overlaps */
+    std::vector<uint32_t> launches_of(D, 0);
+    rc = for_each_shard(D, [&](size_t d) -> int {
+        int rc;
+        ShardJob &j = J[d];
+        j.c = cs[d];
+        Ctx &c = *j.c;
+        j.a = plan[d].first_token_pos;
+        j.b = plan[d].end_token_pos;
+        j.look = plan[d].lookback;
+        j.gpos0 = plan[d].local0;
+        j.nloc = (uint32_t)plan[d].local_bytes;
+        j.E = (uint32_t)(j.b - j.gpos0);
+        j.nx = (uint32_t)plan[d].steps;
+        if ((rc = dev(j))) return rc;
+        hipStream_t s = c.stream;
+        const size_t np = j.nloc;
+        const uint32_t nregions = (uint32_t)(((size_t)j.E + g.TILE - 1) / g.TILE) < (uint32_t)((np + g.TILE - 1) / g.TILE)
+                                      ? (uint32_t)(((size_t)j.E + g.TILE - 1) / g.TILE) : (uint32_t)((np + g.TILE - 1) / g.TILE);
+        uint32_t batch = nregions;
+        {
+            const size_t per = lz77k_match_scratch_bytes(g, 1);
+            const uint32_t fit = (uint32_t)(((size_t)2 << 30) / per);
+            if (batch > fit) batch = fit ? fit : 1;
+        }
+        const size_t span = (size_t)j.E - j.look;
+        const size_t idx_span = span + 3 * usb + 64;
+        if ((rc = c.in.need(np + LZ77X_PAD + 64))) return rc;
+        if ((rc = c.scratch.need(lz77k_match_scratch_bytes(g, batch)))) return rc;
+        if ((rc = c.ps.need((np + 8) * 4))) return rc;
+        if ((rc = c.maxlen.need(np + 64))) return rc;
+        if ((rc = c.xval.need((np + 8) * 4))) return rc;
+        if ((rc = c.chain.need((np + 8) * 4))) return rc;
+        if ((rc = c.tokval.need((np + 16) * 4))) return rc;
+        if ((rc = c.ofs.need((idx_span + 8) * 4))) return rc;
+        if ((rc = c.ent.need((idx_span + 8) * 8))) return rc;
+        if ((rc = c.scantmp.need(lz77k_scan_tmp_bytes((uint32_t)idx_span + 1)))) return rc;
+        if ((rc = c.tstart.need(lz77k_tokens_tmp_bytes((uint32_t)idx_span, g)))) return rc;
+        if ((rc = c.flag.need(64))) return rc;
+        if ((rc = c.prio_tmp.need(lz77k_prio_tmp_bytes(j.nx, g.sb)))) return rc;
+        if ((rc = c.chain_tmp.need(lz77k_chain_tmp_bytes((uint32_t)span, g.la)))) return rc;
+        if ((rc = c.h_small.need(128))) return rc;
+        /* large windows: the regions' rank + inverse arrays stay resident for the rank-order tie-break, and the (block,
+         * first byte) buckets of the tokens of length one (as in a segment of the single-device pipeline) */
+        if (!g.fast) {
+            if ((rc = c.ranks_all.need((size_t)nregions * (2 * (size_t)g.RP + 8) * sizeof(uint32_t)))) return rc;
+            if ((rc = c.bidx.need(lz77k_tokens_index_bytes(g, idx_span)))) return rc;
+        }
+        const uint32_t nsub_max = (uint32_t)((span + csub - 1) / csub);
+        if ((rc = c.h_tbase.need(((size_t)nsub_max + 2 + hwords) * 4))) return rc;
+        j.h = c.h_tbase.as<uint32_t>() + nsub_max + 2;
+        HIPCHK(hipMemsetAsync(c.flag.p, 0, 64, s));
+        if ((rc = upload_pageable(c, c.in.as<uint8_t>(), src + j.gpos0, np))) return rc;
+        HIPCHK(lz77k_fill_pad(c.in.as<uint8_t>(), j.nloc, s));
+        for (uint32_t r0 = 0; r0 < nregions; r0 += batch) {
+            const uint32_t nr = nregions - r0 < batch ? nregions - r0 : batch;
+            HIPCHK(lz77k_match(c.in.as<uint8_t>(), j.nloc, g, r0, nr, c.ps.as<uint32_t>(), c.maxlen.as<uint8_t>(), c.scratch.p, 0, s, nullptr,
+                               g.fast ? nullptr : c.ranks_all.as<uint32_t>()));
+            launches_of[d]++;
+        }
+        const uint8_t *d_wexit = nullptr;
+        const uint32_t *d_wcnt = nullptr;
+        HIPCHK(lz77k_chain_maps(c.maxlen.as<uint8_t>(), j.E, g.la, c.chain_tmp.p, s, j.look, true, &d_wexit, &d_wcnt));
+        HIPCHK(hipMemcpyAsync(j.h, d_wcnt, 256 * 4, hipMemcpyDeviceToHost, s));
+        HIPCHK(hipMemcpyAsync(j.h + 256, d_wexit, 256, hipMemcpyDeviceToHost, s));
+        HIPCHK(lz77k_prio_begin(j.P, c.ps.as<uint32_t>(), j.nx, g.sb, c.xval.as<uint32_t>(), c.prio_tmp.p, (uint32_t)j.gpos0, nullptr, s));
+        HIPCHK(hipStreamSynchronize(s));
+        return LZ77X_OK;
+    });
+    if (rc) return rc;
+    for (uint32_t l : launches_of) g_stats.match_launches += l;
+    double t_serial = now_ms();
+
+    /* -- the parse chain across the cuts (lz77.c:98): entry offset and first-token index of every shard -- */
+    {
+        uint32_t e = 0;
+        uint64_t K = 0;
+        for (ShardJob &j : J) {
+            j.entry = e;
+            j.K0 = K;
+            j.ntok = j.h[e];
+            lz77x_shard_compose_chain(reinterpret_cast<const uint8_t *>(j.h + 256), j.h, &e, &K);
+            j.start = j.look + j.entry;
+        }
+    }
+    for (ShardJob &j : J) {
+        Ctx &c = *j.c;
+        if ((rc = dev(j))) return rc;
+        HIPCHK(lz77k_chain_finish(c.maxlen.as<uint8_t>(), j.E, g.la, c.chain.as<uint32_t>(), c.chain_tmp.p, c.stream, j.look, j.entry, &j.d_tbase,
+                                  &j.nsub, nullptr));
+        HIPCHK(hipMemcpyAsync(c.h_tbase.p, j.d_tbase, ((size_t)j.nsub + 1) * 4, hipMemcpyDeviceToHost, c.stream));
+    }
+
+    /* -- the priority recurrence across the cuts (tree.c:202-231): all shards iterate together -- */
+    {
+        std::vector<uint32_t> v(usb);
+        std::vector<char> flipped(D, 0);
+        const uint16_t *d_sdest = nullptr;
+        const uint32_t *d_sloc = nullptr;
+        int max_iters = 1 << 30;
+        uint32_t iters = 0;
+        for (int it = 0; it < max_iters; it++) {
+            for (size_t d = 0; d + 1 < D; d++) {            /* the last shard's whole map is nobody's input */
+                ShardJob &j = J[d];
+                if ((rc = dev(j))) return rc;
+                HIPCHK(lz77k_prio_maps(j.P, j.c->stream, true, &d_sdest, &d_sloc));
+                if (j.nx) {
+                    HIPCHK(hipMemcpyAsync(j.h + 512, d_sloc, usb * 4, hipMemcpyDeviceToHost, j.c->stream));
+                    HIPCHK(hipMemcpyAsync(j.h + 512 + usb, d_sdest, usb * 2, hipMemcpyDeviceToHost, j.c->stream));
+                }
+            }
+            if (D > 0) {
+                ShardJob &j = J[D - 1];
+                if ((rc = dev(j))) return rc;
+                HIPCHK(lz77k_prio_maps(j.P, j.c->stream, false, nullptr, nullptr));
+            }
+            host_serial_ms += now_ms() - t_serial;
+            if ((rc = sync_all())) return rc;
+            t_serial = now_ms();
+            for (size_t i = 0; i < usb; i++) v[i] = (uint32_t)i;          /* the start of the input: every cell its own position */
+            for (size_t d = 0; d < D; d++) {
+                ShardJob &j = J[d];
+                if ((rc = dev(j))) return rc;
+                if (d > 0) {
+                    uint32_t *pin = j.h + 512 + 2 * usb;                /* pinned copy of the cells this shard starts from */
+                    memcpy(pin, v.data(), usb * 4);
+                    HIPCHK(lz77k_prio_set_in0(j.P, pin, hipMemcpyHostToDevice, j.c->stream));
+                }
+                if (d + 1 < D) {                                       /* v <- this shard's whole map applied to v */
+                    if (j.nx == 0) continue;                           /* no step: the cells pass through */
+                    lz77x_shard_compose_cells(reinterpret_cast<const uint16_t *>(j.h + 512 + usb), j.h + 512, g.sb, v.data());
+                }
+            }
+            for (ShardJob &j : J) {
+                if ((rc = dev(j))) return rc;
+                HIPCHK(lz77k_prio_sweep(j.P, j.c->stream, j.c->h_small.as<uint32_t>() + 8, nullptr));
+            }
+            host_serial_ms += now_ms() - t_serial;
+            if ((rc = sync_all())) return rc;
+            t_serial = now_ms();
+            iters++;
+            bool any = false, earlier = false;
+            for (size_t d = 0; d < D; d++) {
+                const uint32_t *hf = J[d].c->h_small.as<uint32_t>() + 8;
+                flipped[d] = hf[0] != 0;
+                /* a shard after one that still changes may be handed different cells next time: nothing of it is final */
+                lz77k_prio_advance(J[d].P, hf, earlier);
+                earlier = earlier || flipped[d];
+                any = any || flipped[d];
+            }
+            if (!any) break;
+        }
+        g_stats.prio_iters = iters;
+    }
+
+    /* -- tokens: every shard resolves its own (look-back priorities = the cells it started from) -- */
+    for (ShardJob &j : J) {
+        Ctx &c = *j.c;
+        if ((rc = dev(j))) return rc;
+        hipStream_t s = c.stream;
+        const uint32_t *h_tbase = c.h_tbase.as<uint32_t>();
+        if (h_tbase[j.nsub] != j.ntok) { snprintf(g_err, sizeof g_err, "shard chain mismatch: %u vs %u", h_tbase[j.nsub], j.ntok); return LZ77X_E_HIP; }
+        const uint32_t *look = j.look ? reinterpret_cast<const uint32_t *>(reinterpret_cast<const uint8_t *>(j.P.tmp) + j.P.o_in) : nullptr;
+        const size_t b = j.start, e = j.E;
+        if (e > b) {
+            const size_t x_done = e > usb ? e - usb : 0;
+            const uint32_t dbase = b > usb ? (uint32_t)(b - usb) : 0u;
+            const uint32_t xa = dbase > (uint32_t)g.sb ? dbase - (uint32_t)g.sb : 0u;
+            HIPCHK(lz77k_xfer_index(c.ps.as<uint32_t>(), c.xval.as<uint32_t>(), xa, (uint32_t)x_done, dbase, (uint32_t)e, c.ofs.as<uint32_t>(),
+                                    c.ent.as<uint2>(), c.scantmp.p, s, 0u, c.flag.as<unsigned long long>() + 1, g.fast ? (uint32_t)g.sb : 0u));
+            HIPCHK(lz77k_tokens(c.in.as<uint8_t>(), j.nloc, g, c.chain.as<uint32_t>(), j.ntok, c.maxlen.as<uint8_t>(), c.ofs.as<uint32_t>(),
+                                c.ent.as<uint2>(), dbase, (uint32_t)b, (uint32_t)e, c.tokval.as<uint32_t>() + 4, c.tstart.as<uint32_t>(),
+                                g.fast ? nullptr : c.bidx.p, tvariant, s, nullptr, g.fast ? nullptr : c.ranks_all.as<uint32_t>(), look, j.look,
+                                (uint32_t)j.gpos0));
+        }
+        const uint32_t have = j.ntok < 4 ? j.ntok : 4;
+        if (have) HIPCHK(hipMemcpyAsync(j.h, c.tokval.as<uint32_t>() + 4 + j.ntok - have, have * 4, hipMemcpyDeviceToHost, s));
+        j.h[8] = have;
+    }
+    if ((rc = sync_all())) return rc;
+
+    /* -- pack (lz77.c:246-252): each shard the stream words its tokens start in, with its predecessors' last
+     *    tokens in front; then the pieces leave in order -- */
+    const uint64_t T = (uint64_t)g.T;
+    const uint64_t K_all = D ? J[D - 1].K0 + J[D - 1].ntok : 0;
+    const uint64_t zn_total = stream_bytes(K_all, g.T);
+    uint32_t tail[4] = {0, 0, 0, 0};
+    uint32_t ntail = 0;
+    std::vector<uint64_t> piece(D, 0);
+    for (size_t d = 0; d < D; d++) {
+        ShardJob &j = J[d];
+        Ctx &c = *j.c;
+        if ((rc = dev(j))) return rc;
+        const bool last = d + 1 == D;
+        const uint64_t K0 = j.K0, K1 = K0 + j.ntok;
+        const uint64_t wlo = K0 == 0 ? 0 : (32 + K0 * T) / 32;
+        const uint64_t whi = last ? (zn_total + 3) / 4 : (32 + K1 * T) / 32;
+        const uint64_t nw = whi > wlo ? whi - wlo : 0;
+        if ((rc = c.out.need(nw * 4 + 16))) return rc;
+        uint32_t *pin = j.h + 16;
+        memcpy(pin, tail, sizeof tail);
+        if (ntail) HIPCHK(hipMemcpyAsync(c.tokval.as<uint32_t>() + 4 - ntail, pin + 4 - ntail, ntail * 4, hipMemcpyHostToDevice, c.stream));
+        HIPCHK(lz77k_pack_range(c.tokval.as<uint32_t>() + 4 - ntail, K0 - ntail, K1, g, c.out.as<uint32_t>(), wlo, nw, c.stream));
+        piece[d] = last ? zn_total - 4 * wlo : 4 * nw;
+        /* the last four tokens so far */
+        const uint32_t have = j.h[8];
+        uint32_t merged[8], m = 0;
+        for (uint32_t i = 0; i < ntail; i++) merged[m++] = tail[4 - ntail + i];
+        for (uint32_t i = 0; i < have; i++) merged[m++] = j.h[i];
+        ntail = m < 4 ? m : 4;
+        for (uint32_t i = 0; i < ntail; i++) tail[4 - ntail + i] = merged[m - ntail + i];
+    }
+    host_serial_ms += now_ms() - t_serial;
+    {
+        /* the pieces leave: every device fetches its own into the sink's memory at once when the sink is host memory
+         * (the gather north_star describes), else one after the other in stream order */
+        uint64_t all = 0;
+        std::vector<uint64_t> at(D, 0);
+        for (size_t d = 0; d < D; d++) { at[d] = all; all += piece[d]; }
+        std::vector<unsigned long long> cnt(D, 0);
+        uint8_t *base = sink.direct((size_t)all);
+        if (base) {
+            rc = for_each_shard(D, [&](size_t d) -> int {
+                ShardJob &j = J[d];
+                HIPCHK(hipSetDevice(j.c->device));
+                HIPCHK(hipStreamSynchronize(j.c->stream));
+                HIPCHK(hipMemcpy(&cnt[d], j.c->flag.as<unsigned long long>() + 1, 8, hipMemcpyDeviceToHost));
+                return fetch_result(*j.c, base + at[d], j.c->out.p, (size_t)piece[d]);
+            });
+            if (rc) return rc;
+        } else {
+            for (size_t d = 0; d < D; d++) {
+                ShardJob &j = J[d];
+                if ((rc = dev(j))) return rc;
+                if ((rc = sink.write(*j.c, j.c->out.as<uint8_t>(), (size_t)piece[d], j.c->stream))) return rc;
+                HIPCHK(hipMemcpy(&cnt[d], j.c->flag.as<unsigned long long>() + 1, 8, hipMemcpyDeviceToHost));
+            }
+        }
+        for (unsigned long long c : cnt) g_stats.transfers += c;
+    }
+    HIPCHK(hipSetDevice(cs[0]->device));
+    g_stats.host_chain_ms = 0;
+    g_stats.copy_ms = host_serial_ms;                      /* sharded: host time no device overlaps (exchange + enqueue) */
+    g_stats.n = n;
+    g_stats.zn = sink.total;
+    g_stats.ntok = K_all;
+    g_stats.total_ms = now_ms() - t_begin;
+    TRACE("encode_sharded total", t_begin);
+    return LZ77X_OK;
+}
+
+/* Which pipeline an encode takes: everything on the device when the geometry allows it (one device,
+ * sb <= 4096, production kernels), the round-1 pipeline with the two recurrences on host cores
+ * otherwise (LZ77X_HOST_STAGEB=1 forces it) or when the gate iteration gives up. */
+bool device_pipeline_ok(size_t ndev, const lz77x_geom &g)
+{
+    const char *hs = LZ77X_VENV("LZ77X_HOST_STAGEB"), *vs = LZ77X_VENV("LZ77X_MATCH_VARIANT");
+    return ndev == 1 && g.shifted && lz77k_prio_supported(g.sb) && !(hs && atoi(hs)) && !(vs && atoi(vs)) && !LZ77X_VENV("LZ77X_SERIAL");
+}
+
+/* memory -> sink.  src: host or device pointer of n bytes */
+int encode_any(std::vector<Ctx *> &cs, const void *src, bool src_on_device, size_t n, const lz77x_geom &g, hipStream_t s, Sink &sink)
+{
+    Ctx &c0 = *cs[0];
+    const void *host_src = src;
+    bool host_on_device = src_on_device;
+    uint32_t iters = 0;                                    /* gate iterations spent before giving up */
+    /* one stream over several devices: every window size on the device pipeline (large windows compose their shards'
+     * whole-plan maps through HBM, lz77kw_compose_all) */
+    if (cs.size() > 1 && !src_on_device && device_pipeline_ok(1, g))
+        return encode_sharded(cs, reinterpret_cast<const uint8_t *>(src), n, g, sink);
+    if (device_pipeline_ok(cs.size(), g)) {
+        MemSource ms(src, n, src_on_device);
+        bool fallback = false;
+        size_t nfb = 0;
+        const int rc = encode_stream_device(c0, ms, sink, g, s, &fallback, &nfb);
+        if (rc != LZ77X_OK || !fallback) return rc;
+        host_src = c0.in.p;                                /* single segment: the whole input is in c.in */
+        host_on_device = true;
+        iters = g_stats.prio_iters;
+    }
+    size_t zn = 0;
+    int rc = encode_core_host(cs, host_src, host_on_device, n, g, s, &zn);
+    g_stats.prio_iters = iters;
+    if (rc) return rc;
+    return sink.write(c0, c0.out.as<uint8_t>(), zn, s);
+}
+
+}  // namespace lz77x_host

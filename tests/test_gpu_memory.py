@@ -1,5 +1,5 @@
 """Device memory: the encoder sizes its segments and the decoder its ranges to what the device has to spare
-(device_budget in pipeline.cpp); the output bytes never depend on it.  LZ77X_DEVICE_MEM_LIMIT caps what a call may plan
+(device_budget in ctx.cpp); the output bytes never depend on it.  LZ77X_DEVICE_MEM_LIMIT caps what a call may plan
 with, so a tight device can be imitated on the test box's 288 GB."""
 import ctypes
 import hashlib

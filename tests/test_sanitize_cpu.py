@@ -1,7 +1,7 @@
 """Host side under AddressSanitizer + UndefinedBehaviorSanitizer ("host C can be built with
 -fsanitize=address,undefined in tests"; GPU sanitizers do not exist on this pool).
 
-`make -C lz77_amd/csrc asan` compiles every host translation unit of the product -- pipeline.cpp (the C ABI, contexts,
+`make -C lz77_amd/csrc asan` compiles every host translation unit of the product -- api.cpp, ctx.cpp, hostio.cpp, the pipelines and shard.cpp (the C ABI, contexts,
 memory planning, the shard host side), hoststage.c, fileio.c, main.c, shim.c -- with the ROCm clang's sanitizers and
 links them with the ordinary kernel objects.  The CPU ABI suite (tests/test_abi_cpu.py: host-only entry points against
 the oracle, the no-device error paths of every entry point, the CLI's argument handling, the shard plan and the
