@@ -25,7 +25,7 @@ CASES = [("text", 201, 400_000, 4095, 15), ("random", 202, 150_000, 4095, 15), (
          ("mixed", 204, 300_000, 1000, 10), ("lowent", 205, 300_000, 8191, 16), ("text", 206, 500_000, 20000, 40),
          ("mixed", 207, 600_000, 65535, 255), ("text", 208, 300_000, 4096, 16), ("lowent", 209, 120_000, 16, 4),
          ("mixed", 210, 250_000, 1024, 15), ("records", 211, 400_000, 32768, 255), ("zeros", 0, 60_000, 8, 7),
-         ("random", 212, 40_000, 2, 3), ("text", 213, 60_000, 1, 2), ("zeros", 0, 300_000, 4095, 15)]
+         ("random", 212, 40_000, 2, 3), ("text", 213, 60_000, 1, 2), ("zeros", 0, 150_000, 4095, 15)]
 
 
 @pytest.mark.parametrize("env", RANGE_ENVS, ids=RANGE_IDS)

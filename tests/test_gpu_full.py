@@ -11,6 +11,7 @@ import pytest
 
 import lz77_amd as L
 from lz77_amd import synth
+from full_inputs import full_input
 
 pytestmark = pytest.mark.gpu
 
@@ -24,8 +25,7 @@ def _run(name):
     if r["n"] >= 1 << 32:
         return _run_huge(r)
     n, sb, la = r["n"], r["sb"], r["la"]
-    data = synth.make(r["kind"], n, r["seed"])
-    assert hashlib.sha256(memoryview(data)).hexdigest() == r["sha256_in"], "generator drifted"
+    data = full_input(r)
     d_in = torch.from_numpy(data).cuda()
     cap = L.encode_bound(n, la, sb)
     d_z = torch.empty(cap, dtype=torch.uint8, device="cuda")
@@ -58,7 +58,7 @@ def _run_huge(r):
     libc.fclose.argtypes = [ctypes.c_void_p]
     with tempfile.TemporaryDirectory(dir="/dev/shm" if os.path.isdir("/dev/shm") else None) as d:
         fin, fout = os.path.join(d, "in"), os.path.join(d, "out")
-        data = synth.make(r["kind"], n, r["seed"])
+        data = full_input(r)
         assert hashlib.sha256(memoryview(data)).hexdigest() == r["sha256_in"], "generator drifted"
         data.tofile(fin)
         del data
@@ -134,7 +134,7 @@ def test_s4_sharded_over_8_contexts(monkeypatch):
     way in, the input's bytes on the way back (decode sharded by token ranges)"""
     r = FULL["S4"]
     n, sb, la = r["n"], r["sb"], r["la"]
-    data = synth.make(r["kind"], n, r["seed"])
+    data = full_input(r)
     monkeypatch.setenv("LZ77X_FAKE_DEVICES", "8")
     try:
         assert L.lib().lz77x_set_shards(8) == 0
@@ -156,7 +156,7 @@ def test_s3_sharded_over_4_contexts(monkeypatch):
     the reference's digest; the decode of the stream sharded by token ranges (the tile pass with the history unknown)"""
     r = FULL["S3"]
     n, sb, la = r["n"], r["sb"], r["la"]
-    data = synth.make(r["kind"], n, r["seed"])
+    data = full_input(r)
     monkeypatch.setenv("LZ77X_FAKE_DEVICES", "4")
     try:
         assert L.lib().lz77x_set_shards(4) == 0
@@ -195,7 +195,7 @@ def test_s4_from_host_memory_and_from_a_file(tmp_path):
     reference's, byte for byte, and come back through the same entry points"""
     r = FULL["S4"]
     n, sb, la = r["n"], r["sb"], r["la"]
-    data = synth.make(r["kind"], n, r["seed"])
+    data = full_input(r)
     z = L.encode(data, la, sb)                              # lz77x_encode: host memory -> host memory
     st = L.last_stats()
     assert len(z) == r["zn"] and st["ntok"] == r["ntok"]

@@ -11,6 +11,7 @@ import pytest
 
 import lz77_amd as L
 from lz77_amd import synth
+from full_inputs import full_input
 
 pytestmark = pytest.mark.gpu
 
@@ -40,7 +41,7 @@ def test_encode_and_decode_fit_a_memory_limit(name, limit, monkeypatch):
     import torch
     r = FULL[name]
     n, sb, la = r["n"], r["sb"], r["la"]
-    data = synth.make(r["kind"], n, r["seed"])
+    data = full_input(r)
     d_in = torch.from_numpy(data).cuda()
     cap = L.encode_bound(n, la, sb)
     d_z = torch.empty(cap, dtype=torch.uint8, device="cuda")
@@ -72,7 +73,7 @@ def test_default_footprint_is_bounded():
     import torch
     r = FULL["S4"]
     n, sb, la = r["n"], r["sb"], r["la"]
-    d_in = torch.from_numpy(synth.make(r["kind"], n, r["seed"])).cuda()
+    d_in = torch.from_numpy(full_input(r)).cuda()
     cap = L.encode_bound(n, la, sb)
     d_z = torch.empty(cap, dtype=torch.uint8, device="cuda")
     st = torch.cuda.current_stream().cuda_stream
@@ -104,7 +105,7 @@ def test_four_files_of_1gb_at_once(tmp_path):
     src = os.path.join(d, "lz77x_four.in")
     outs = [os.path.join(d, "lz77x_four_%d.lz" % i) for i in range(4)]
     try:
-        synth.make(r["kind"], n, r["seed"]).tofile(src)
+        full_input(r).tofile(src)
         L.lib().lz77x_shutdown()
         f0 = _free()
         FP = ctypes.c_void_p * 4

@@ -388,7 +388,7 @@ def test_large_window_sort_variants_agree(sortv, sb, la, monkeypatch):
 
 @pytest.mark.parametrize("env", [{}, {"LZ77X_BIG_SORT_V1": "1"}, {"LZ77X_WALK_BIG_V1": "1"}, {"LZ77X_WALK_RUN_WAVE": "1024"},
                                  {"LZ77X_WALK_RUN_WAVE": "65536"}, {"LZ77X_CHUNK_REGIONS": "1"}, {"LZ77X_CHUNK_REGIONS": "3"}])
-@pytest.mark.parametrize("sb,la,kind,n", [(65535, 255, "mixed", 1_300_000), (65530, 100, "text", 900_000), (65535, 16, "lowent", 700_000),
+@pytest.mark.parametrize("sb,la,kind,n", [(65535, 255, "mixed", 1_300_000), (65530, 100, "text", 900_000), (65535, 16, "lowent", 350_000),
                                           (65535, 255, "records", 600_000), (20000, 40, "mixed", 800_000), (32768, 255, "text", 700_000),
                                           (16385, 15, "lowent", 500_000), (49999, 200, "mixed", 900_000)])
 def test_large_window_shared_sort_and_wave_walkers(env, sb, la, kind, n, monkeypatch):
@@ -464,27 +464,44 @@ def test_periodic_inputs(sb, la, period):
     assert L.decode(z) == data.tobytes()
 
 
+_long_runs = {}
+
+
+def _long_runs_case():
+    if not _long_runs:
+        rng = np.random.default_rng(5)
+        parts = []
+        for i in range(60):
+            parts.append(np.full(int(rng.integers(1500, 9000)), [0, 0xFF, 0x20, 0][i % 4], dtype=np.uint8))
+            kind = i % 3
+            m = int(rng.integers(200, 6000))
+            if kind == 0:
+                parts.append(synth.text(m, 700 + i))
+            elif kind == 1:
+                parts.append(synth.random_bytes(m, 800 + i))
+            else:
+                parts.append(np.tile(np.frombuffer(b"ab\x00\x00cd\x00", dtype=np.uint8), m // 7 + 1)[:m])
+        _long_runs["data"] = np.concatenate(parts)
+        _long_runs["want"] = O.encode_bst(_long_runs["data"], 4095, 15)
+    return _long_runs["data"], _long_runs["want"]
+
+
+@pytest.mark.parametrize("big", ["", "16", "100000", "v4"])
 @pytest.mark.parametrize("entcap", ["", "64"])
 @pytest.mark.parametrize("seg", ["", "120000"])
-def test_long_runs_between_data(seg, entcap, monkeypatch):
+def test_long_runs_between_data(seg, entcap, big, monkeypatch):
     """binary-like input: stretches of one byte (thousands long: runs of the tie-break that span the window) between
     text, random bytes and short periods -- the tokens inside a stretch have more than a thousand equal candidates, few of
-    them with a handed-over priority: they take the tie-break's big-run path (the oldest candidate without a hand-over by
-    a walk over the window's positions, the others through a bitmap), in one segment and across segment cuts"""
-    rng = np.random.default_rng(5)
-    parts = []
-    for i in range(60):
-        parts.append(np.full(int(rng.integers(1500, 9000)), [0, 0xFF, 0x20, 0][i % 4], dtype=np.uint8))
-        kind = i % 3
-        m = int(rng.integers(200, 6000))
-        if kind == 0:
-            parts.append(synth.text(m, 700 + i))
-        elif kind == 1:
-            parts.append(synth.random_bytes(m, 800 + i))
-        else:
-            parts.append(np.tile(np.frombuffer(b"ab\x00\x00cd\x00", dtype=np.uint8), m // 7 + 1)[:m])
-    data = np.concatenate(parts)
-    want = O.encode_bst(data, 4095, 15)
+    them with a handed-over priority: they take the tie-break's big-run path (the oldest member of the window by a walk
+    over the window's positions, sixteen lanes a token; the hand-overs through the entries of the run's slots), in one
+    segment and across segment cuts (the tiles that see carried priorities take every member through look[]).
+    LZ77X_TS_BIG moves the threshold of that path (16: nearly every token; 100000: none), v4 is round 4's kernel
+    (a bitmap of the slots with hand-overs, lists per cell) -- the same stream every time."""
+    data, want = _long_runs_case()
+    if big == "v4":
+        monkeypatch.setenv("LZ77X_TS_V4", "1")
+    elif big:
+        monkeypatch.setenv("LZ77X_TS_BIG", big)
     if seg:
         monkeypatch.setenv("LZ77X_SEGMENT", seg)
     if entcap:
@@ -903,7 +920,7 @@ WIDE_CASES = [
     ("mixed", 65, 3 << 20, 65535, 255, {"LZ77X_PRIO_BLOCK": "65536", "LZ77X_PRIO_SCAN_GROUP": "2"}),
     ("random", 66, 1 << 20, 65535, 255, {}),
     ("records", 67, 2 << 20, 65535, 255, {}),
-    ("zeros", 0, 300000, 65535, 255, {}),
+    ("zeros", 0, 100000, 65535, 255, {}),            # (the oracle's tree is a chain of sb nodes on such input: 34 s per 100 K positions)
     ("text", 68, 140000, 65535, 255, {}),
     ("text", 68, 70000, 65535, 255, {}),
     # round 3's round masks (a 16-bit tag per cell) beside the ranked cells of round 4
