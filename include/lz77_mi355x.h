@@ -37,10 +37,10 @@ extern "C" {
                                    would be wider than 32 bits (la > 255 with a wide sb: main.c:103 never emits it) */
 #define LZ77X_E_CAP      (-6)   /* caller-provided output buffer too small (*out_n holds the need) */
 #define LZ77X_E_IO       (-7)   /* fread/fwrite failed */
-#define LZ77X_E_TOOBIG   (-8)   /* only the paths that hold a whole input at once: one stream cut over several devices
-                                   (lz77x_set_shards > 1) and the stage-level entry points, at >= 4 GiB (positions are
-                                   32-bit on a device).  lz77x_encode*, lz77x_decode* on one device take any length:
-                                   segments / token ranges through bounded device memory */
+#define LZ77X_E_TOOBIG   (-8)   /* only the stage-level entry points (lz77x_stage_*: the parity tests' view of one stage over a
+                                   whole input), at >= 4 GiB: positions are 32-bit on a device.  lz77x_encode*, lz77x_decode*
+                                   take any length on one device or several: segments / stretches of position shards /
+                                   token ranges through bounded device memory */
 
 #define LZ77X_DEFAULT_LA 15     /* lz77.c:21 */
 #define LZ77X_DEFAULT_SB 4095   /* lz77.c:22 */
@@ -88,8 +88,9 @@ int lz77x_decode_file(FILE *in, FILE *out);
 
 /* Number of logical shards the positions of one input are split into (default 1, or
  * env LZ77X_SHARDS).  Shards are spread round-robin over the visible devices; output
- * bytes are identical for every shard count.  lz77x_encode cuts the input by
- * positions, lz77x_decode cuts the stream by token ranges (the sb bytes before a range reach it
+ * bytes are identical for every shard count.  lz77x_encode / lz77x_encode_file cut the input by
+ * positions -- an input of any length in stretches of at most 4 GiB, every stretch over all the devices, the file
+ * entry point holding one stretch in host memory --, lz77x_decode cuts the stream by token ranges (the sb bytes before a range reach it
  * as a map chained on the host; lz77.c:172-192 across the cuts); streams it cannot cut that way
  * (distance-0 copies of a power-of-two -s, shards shorter than a window, streams of 4 GiB and more) decode on one
  * device, range by range. */

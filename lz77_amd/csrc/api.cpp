@@ -123,18 +123,28 @@ int lz77x_encode_file(FILE *in, FILE *out, int la, int sb)
     if (rc) return rc;
     int shards = g_shards;
     if (shards <= 0) { const char *e = getenv("LZ77X_SHARDS"); shards = e ? atoi(e) : 1; }
-    if (shards > 1) return lz77x_encode_file_buffered(in, out, la, sb);
     Lease lease;
     Ctx &g_ctx = lease.set->primary;
     (void)g_ctx;
     const double t0 = now_ms();
     std::vector<Ctx *> cs;
-    if ((rc = shard_contexts(*lease.set, 1, cs))) return rc;
+    if ((rc = shard_contexts(*lease.set, shards < 1 ? 1 : shards, cs))) return rc;
     TRACE("runtime + context init", t0);
     Ctx &c = g_ctx;
     lz77x_geom g;
     make_encode_geom(&g, sb == -1 ? LZ77X_DEFAULT_SB : sb, la == -1 ? LZ77X_DEFAULT_LA : la);
     size_t n = 0;
+    if (cs.size() > 1 && device_pipeline_ok(1, g)) {
+        /* one stream over several devices: stretch by stretch out of the file (the host holds one stretch), every stretch cut
+         * into position shards */
+        FileWindow win(in);
+        FileSink sink(out);
+        const double t1 = now_ms();
+        rc = encode_sharded(cs, win, g, sink);
+        TRACE("file -> devices -> file", t1);
+        return rc;
+    }
+    if (cs.size() > 1) cs.resize(1);                            /* (a geometry without the device pipeline: one device) */
     if (device_pipeline_ok(1, g)) {
         /* any size, any kind of file: segment by segment through bounded device memory */
         FileSource src(in);

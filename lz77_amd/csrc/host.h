@@ -665,6 +665,65 @@ struct RangeDrain {
     }
 };
 
+/* Host memory in front of the sharded encode: the bytes [off, off + got) of the input for increasing off (a stretch of a long
+ * stream and the look-back of the next one overlap); the pointer stays valid until the next get().  Out of the caller's
+ * buffer it is a pointer into it; out of a FILE* one stretch is held and what the next one needs again is moved to the front
+ * (the reference streams through a 3*SB+LA window, lz77.c:113-129: a file of any length, bounded host memory). */
+struct HostWindow {
+    virtual ~HostWindow() {}
+    virtual int get(uint64_t off, size_t want, const uint8_t **p, size_t *got) = 0;
+    virtual bool from_file() const { return false; }
+};
+
+struct MemWindow : HostWindow {
+    const uint8_t *base; size_t n;
+    MemWindow(const uint8_t *b, size_t bytes) : base(b), n(bytes) {}
+    int get(uint64_t off, size_t want, const uint8_t **p, size_t *got) override
+    {
+        const size_t left = off < n ? n - (size_t)off : 0;
+        *p = base + (off < n ? off : n);
+        *got = want < left ? want : left;
+        return LZ77X_OK;
+    }
+};
+
+struct FileWindow : HostWindow {
+    FILE *f;
+    uint8_t *buf = nullptr; size_t cap = 0, have = 0;      /* buf[0, have) = the file's bytes [at, at + have) */
+    uint64_t at = 0;
+    bool eof = false;
+    explicit FileWindow(FILE *file) : f(file) {}
+    ~FileWindow() override { free(buf); }
+    bool from_file() const override { return true; }
+    int get(uint64_t off, size_t want, const uint8_t **p, size_t *got) override
+    {
+        if (off < at) { snprintf(g_err, sizeof g_err, "FileWindow: offsets must not decrease"); return LZ77X_E_ARG; }
+        const size_t drop = (size_t)(off - at) < have ? (size_t)(off - at) : have;
+        if (drop) { memmove(buf, buf + drop, have - drop); have -= drop; at += drop; }
+        if (at < off) {                                       /* (never: consecutive stretches overlap) */
+            snprintf(g_err, sizeof g_err, "FileWindow: a gap between stretches");
+            return LZ77X_E_ARG;
+        }
+        if (want > cap) {
+            uint8_t *nb = (uint8_t *)realloc(buf, want);
+            if (!nb) return LZ77X_E_NOMEM;
+            buf = nb;
+            cap = want;
+        }
+        while (have < want && !eof) {
+            const size_t r = fread(buf + have, 1, want - have, f);
+            have += r;
+            if (r == 0) {
+                if (ferror(f)) return LZ77X_E_IO;
+                eof = true;
+            }
+        }
+        *p = buf;
+        *got = have < want ? have : want;
+        return LZ77X_OK;
+    }
+};
+
 /* ---- the pipelines ----------------------------------------------------------------------------------------------------- */
 /* encode_host.cpp */
 int encode_core_host(std::vector<Ctx *> &cs, const void *src, bool src_on_device, size_t n, const lz77x_geom &g, hipStream_t s, size_t *zn);
@@ -674,7 +733,8 @@ int encode_stream_device(Ctx &c, Source &src, Sink &sink, const lz77x_geom &g, h
 int decode_stream(Ctx &c, Source &src, Sink *sink, hipStream_t s, uint64_t *n_out);
 /* shard.cpp */
 int decode_sharded(std::vector<Ctx *> &cs, const uint8_t *z, size_t zn, uint8_t **out, size_t *out_n, int *handled);
-int encode_sharded(std::vector<Ctx *> &cs, const uint8_t *src, size_t n, const lz77x_geom &g, Sink &sink);
+int encode_sharded(std::vector<Ctx *> &cs, HostWindow &in, const lz77x_geom &g, Sink &sink);
+int shard_plan_range(size_t nbytes, size_t t0, size_t t1, int sb, int la, int shards, lz77x_shard *out);
 bool device_pipeline_ok(size_t ndev, const lz77x_geom &g);
 int encode_any(std::vector<Ctx *> &cs, const void *src, bool src_on_device, size_t n, const lz77x_geom &g, hipStream_t s, Sink &sink);
 

@@ -70,9 +70,7 @@ void lz77x_prio_free(lz77x_prio_state *st);
 uint32_t lz77x_prio_mask(int sb);
 void lz77x_prio_run(lz77x_prio_state *st, const uint32_t *ps, int sb, size_t upto, uint32_t *xval);
 
-/* whole-file-in-memory form of lz77x_encode_file for several shards (fileio.c) */
 #include <stdio.h>
-int lz77x_encode_file_buffered(FILE *in, FILE *out, int la, int sb);
 
 #ifdef __cplusplus
 }

@@ -13,21 +13,7 @@ extern "C" {
 int lz77x_shard_plan(size_t n, int sb, int la, int shards, lz77x_shard *out)
 {
     if (check_geom(sb, la) != LZ77X_OK || shards < 1) return LZ77X_E_ARG;
-    const size_t usb = (size_t)sb, halo = (size_t)la + 64;
-    size_t D = (size_t)shards;
-    const size_t min_shard = 4 * usb + 3 * (size_t)4096;
-    while (D > 1 && n / D < min_shard) D--;
-    for (size_t d = 0; d < D && out; d++) {
-        lz77x_shard &j = out[d];
-        j.first_token_pos = (uint64_t)n * d / D;
-        j.end_token_pos = (uint64_t)n * (d + 1) / D;
-        j.lookback = d ? (uint32_t)usb : 0u;
-        j.local0 = j.first_token_pos - j.lookback;
-        const uint64_t end = d + 1 == D ? (uint64_t)n : (j.end_token_pos + halo < n ? j.end_token_pos + halo : (uint64_t)n);
-        j.local_bytes = end - j.local0;
-        j.steps = j.end_token_pos - j.local0 > usb ? j.end_token_pos - j.local0 - usb : 0;
-    }
-    return (int)D;
+    return shard_plan_range(n, 0, n, sb, la, shards, out);
 }
 
 /* host-only: one shard's whole map of boundary cells applied to the cells it starts from (in place):
@@ -76,6 +62,30 @@ void lz77x_shard_compose_tail32(const uint32_t *map, int sb, const uint8_t *inco
 }  // extern "C"
 
 LZ77X_HOST_NS {
+
+/* The token positions [t0, t1) of a local buffer of nbytes bytes cut into at most `shards` contiguous shards; the positions
+ * before t0 are look-back (t0 = 0: the start of the input; t0 = sb: a later stretch of a long stream, whose first shard
+ * starts from carried cells like every other shard starts from its predecessor's), the bytes from t1 on look-ahead.
+ * -> shards used (a shard is never smaller than 4*sb + 12 KiB) */
+int shard_plan_range(size_t nbytes, size_t t0, size_t t1, int sb, int la, int shards, lz77x_shard *out)
+{
+    const size_t usb = (size_t)sb, halo = (size_t)la + 64;
+    size_t D = (size_t)shards;
+    const size_t min_shard = 4 * usb + 3 * (size_t)4096, span = t1 - t0;
+    while (D > 1 && span / D < min_shard) D--;
+    for (size_t d = 0; d < D && out; d++) {
+        lz77x_shard &j = out[d];
+        j.first_token_pos = t0 + (uint64_t)span * d / D;
+        j.end_token_pos = t0 + (uint64_t)span * (d + 1) / D;
+        j.lookback = (d || t0) ? (uint32_t)usb : 0u;
+        j.local0 = j.first_token_pos - j.lookback;
+        const uint64_t end = j.end_token_pos + halo < nbytes ? j.end_token_pos + halo : (uint64_t)nbytes;
+        j.local_bytes = end - j.local0;
+        j.steps = j.end_token_pos - j.local0 > usb ? j.end_token_pos - j.local0 - usb : 0;
+        j.reserved = 0;
+    }
+    return (int)D;
+}
 
 /* ONE stream decoded on SEVERAL devices: the tokens are cut into D contiguous ranges at multiples of
  * eight tokens (every range then starts on a byte of the stream); device d parses and scans its range and walks
@@ -283,15 +293,28 @@ struct ShardJob {
     uint32_t *h = nullptr;                  /* pinned scratch of this shard (c->h_tbase) */
 };
 
-int encode_sharded(std::vector<Ctx *> &cs, const uint8_t *src, size_t n, const lz77x_geom &g, Sink &sink)
+/* What one stretch of a long stream hands to the next (the SegCarry of encode_pipe.cpp, across ALL its shards): the state of
+ * lz77.c's two sequential loops at the cut -- where the next token starts, how many there were, the last four token words (a
+ * stream word can straddle the cut) and the sb live priorities renumbered by rank (the tie-break only compares them). */
+struct StretchCarry {
+    bool first = true;
+    uint64_t chain_pos = 0;        /* global position of the next token */
+    uint64_t ntok = 0;
+    uint32_t tail[4] = {0, 0, 0, 0};
+    uint32_t ntail = 0;
+    std::vector<uint32_t> cells;   /* sb ranks (after the first stretch) */
+};
+
+/* One stretch: the local buffer src[0, nbytes) starts at global position origin; its tokens are the chain positions in
+ * [t0, t1) (local; t0 = 0 for the first stretch, sb afterwards: the cells before t0 are look-back and hold the carried
+ * priorities), cut into position shards.  last: the input ends with this stretch. */
+static int encode_sharded_stretch(std::vector<Ctx *> &cs, const uint8_t *src, size_t nbytes, size_t t0, size_t t1, uint64_t origin, bool last_stretch,
+                                  StretchCarry &carry, const lz77x_geom &g, Sink &sink, double *host_serial_out)
 {
-    const double t_begin = now_ms();
-    memset(&g_stats, 0, sizeof g_stats);
-    if (n > LZ77X_MAX_N) return LZ77X_E_TOOBIG;
     const size_t usb = (size_t)g.sb;
     const uint32_t csub = lz77k_chain_sub();
     std::vector<lz77x_shard> plan(cs.size());
-    const int planned = lz77x_shard_plan(n, g.sb, g.la, (int)cs.size(), plan.data());
+    const int planned = shard_plan_range(nbytes, t0, t1, g.sb, g.la, (int)cs.size(), plan.data());
     if (planned < 1) return LZ77X_E_ARG;
     const size_t D = (size_t)planned;
     std::vector<ShardJob> J(D);
@@ -374,7 +397,15 @@ int encode_sharded(std::vector<Ctx *> &cs, const uint8_t *src, size_t n, const l
         HIPCHK(lz77k_chain_maps(c.maxlen.as<uint8_t>(), j.E, g.la, c.chain_tmp.p, s, j.look, true, &d_wexit, &d_wcnt));
         HIPCHK(hipMemcpyAsync(j.h, d_wcnt, 256 * 4, hipMemcpyDeviceToHost, s));
         HIPCHK(hipMemcpyAsync(j.h + 256, d_wexit, 256, hipMemcpyDeviceToHost, s));
-        HIPCHK(lz77k_prio_begin(j.P, c.ps.as<uint32_t>(), j.nx, g.sb, c.xval.as<uint32_t>(), c.prio_tmp.p, (uint32_t)j.gpos0, nullptr, s));
+        /* c.look: [0, sb) the cells the first shard of a later stretch starts from, [sb + 8, ..) the cells the last shard leaves */
+        if ((rc = c.look.need((size_t)2 * (usb + 8) * 4))) return rc;
+        const uint32_t *d_carried = nullptr;
+        if (d == 0 && !carry.first) {
+            HIPCHK(hipMemcpyAsync(c.look.p, carry.cells.data(), usb * 4, hipMemcpyHostToDevice, s));
+            HIPCHK(hipStreamSynchronize(s));                 /* (pageable source) */
+            d_carried = c.look.as<uint32_t>();
+        }
+        HIPCHK(lz77k_prio_begin(j.P, c.ps.as<uint32_t>(), j.nx, g.sb, c.xval.as<uint32_t>(), c.prio_tmp.p, (uint32_t)j.gpos0, d_carried, s));
         HIPCHK(hipStreamSynchronize(s));
         return LZ77X_OK;
     });
@@ -384,8 +415,9 @@ int encode_sharded(std::vector<Ctx *> &cs, const uint8_t *src, size_t n, const l
 
     /* -- the parse chain across the cuts (lz77.c:98): entry offset and first-token index of every shard -- */
     {
-        uint32_t e = 0;
-        uint64_t K = 0;
+        /* (a later stretch: the token its predecessor's last one led to; at most la past the cut) */
+        uint32_t e = carry.first ? 0u : (uint32_t)(carry.chain_pos - (origin + t0));
+        uint64_t K = carry.ntok;
         for (ShardJob &j : J) {
             j.entry = e;
             j.K0 = K;
@@ -393,6 +425,8 @@ int encode_sharded(std::vector<Ctx *> &cs, const uint8_t *src, size_t n, const l
             lz77x_shard_compose_chain(reinterpret_cast<const uint8_t *>(j.h + 256), j.h, &e, &K);
             j.start = j.look + j.entry;
         }
+        carry.chain_pos = origin + t1 + e;
+        carry.ntok = K;
     }
     for (ShardJob &j : J) {
         Ctx &c = *j.c;
@@ -428,7 +462,8 @@ int encode_sharded(std::vector<Ctx *> &cs, const uint8_t *src, size_t n, const l
             host_serial_ms += now_ms() - t_serial;
             if ((rc = sync_all())) return rc;
             t_serial = now_ms();
-            for (size_t i = 0; i < usb; i++) v[i] = (uint32_t)i;          /* the start of the input: every cell its own position */
+            if (carry.first) for (size_t i = 0; i < usb; i++) v[i] = (uint32_t)i;      /* the start of the input: every cell its own position */
+            else memcpy(v.data(), carry.cells.data(), usb * 4);                         /* a later stretch: the carried ranks */
             for (size_t d = 0; d < D; d++) {
                 ShardJob &j = J[d];
                 if ((rc = dev(j))) return rc;
@@ -442,9 +477,12 @@ int encode_sharded(std::vector<Ctx *> &cs, const uint8_t *src, size_t n, const l
                     lz77x_shard_compose_cells(reinterpret_cast<const uint16_t *>(j.h + 512 + usb), j.h + 512, g.sb, v.data());
                 }
             }
-            for (ShardJob &j : J) {
+            for (size_t d = 0; d < D; d++) {
+                ShardJob &j = J[d];
                 if ((rc = dev(j))) return rc;
-                HIPCHK(lz77k_prio_sweep(j.P, j.c->stream, j.c->h_small.as<uint32_t>() + 8, nullptr));
+                /* (the last shard of a stretch that is not the last: the sb cells left live after its last step) */
+                uint32_t *d_state = (d + 1 == D && !last_stretch) ? j.c->look.as<uint32_t>() + usb + 8 : nullptr;
+                HIPCHK(lz77k_prio_sweep(j.P, j.c->stream, j.c->h_small.as<uint32_t>() + 8, d_state));
             }
             host_serial_ms += now_ms() - t_serial;
             if ((rc = sync_all())) return rc;
@@ -461,7 +499,20 @@ int encode_sharded(std::vector<Ctx *> &cs, const uint8_t *src, size_t n, const l
             }
             if (!any) break;
         }
-        g_stats.prio_iters = iters;
+        g_stats.prio_iters += iters;
+        if (!last_stretch) {
+            /* the cells left live, renumbered by rank (sb values): what the next stretch starts from */
+            ShardJob &j = J[D - 1];
+            if ((rc = dev(j))) return rc;
+            std::vector<uint32_t> st(usb);
+            if (j.nx) HIPCHK(hipMemcpy(st.data(), j.c->look.as<uint32_t>() + usb + 8, usb * 4, hipMemcpyDeviceToHost));
+            else memcpy(st.data(), v.data(), usb * 4);      /* (no step in the last shard: what it was handed) */
+            std::vector<std::pair<uint32_t, uint32_t>> order(usb);
+            for (size_t i = 0; i < usb; i++) order[i] = {st[i], (uint32_t)i};
+            std::sort(order.begin(), order.end());
+            carry.cells.resize(usb);
+            for (size_t r = 0; r < usb; r++) carry.cells[order[r].second] = (uint32_t)r;
+        }
     }
 
     /* -- tokens: every shard resolves its own (look-back priorities = the cells it started from) -- */
@@ -494,15 +545,15 @@ int encode_sharded(std::vector<Ctx *> &cs, const uint8_t *src, size_t n, const l
      *    tokens in front; then the pieces leave in order -- */
     const uint64_t T = (uint64_t)g.T;
     const uint64_t K_all = D ? J[D - 1].K0 + J[D - 1].ntok : 0;
-    const uint64_t zn_total = stream_bytes(K_all, g.T);
-    uint32_t tail[4] = {0, 0, 0, 0};
-    uint32_t ntail = 0;
+    const uint64_t zn_total = stream_bytes(K_all, g.T);                /* (of the whole stream so far: it ends here when last_stretch) */
+    uint32_t tail[4] = {carry.tail[0], carry.tail[1], carry.tail[2], carry.tail[3]};
+    uint32_t ntail = carry.ntail;
     std::vector<uint64_t> piece(D, 0);
     for (size_t d = 0; d < D; d++) {
         ShardJob &j = J[d];
         Ctx &c = *j.c;
         if ((rc = dev(j))) return rc;
-        const bool last = d + 1 == D;
+        const bool last = d + 1 == D && last_stretch;
         const uint64_t K0 = j.K0, K1 = K0 + j.ntok;
         const uint64_t wlo = K0 == 0 ? 0 : (32 + K0 * T) / 32;
         const uint64_t whi = last ? (zn_total + 3) / 4 : (32 + K1 * T) / 32;
@@ -521,6 +572,9 @@ int encode_sharded(std::vector<Ctx *> &cs, const uint8_t *src, size_t n, const l
         ntail = m < 4 ? m : 4;
         for (uint32_t i = 0; i < ntail; i++) tail[4 - ntail + i] = merged[m - ntail + i];
     }
+    memcpy(carry.tail, tail, sizeof tail);
+    carry.ntail = ntail;
+    carry.first = false;
     host_serial_ms += now_ms() - t_serial;
     {
         /* the pieces leave: every device fetches its own into the sink's memory at once when the sink is host memory
@@ -550,11 +604,47 @@ int encode_sharded(std::vector<Ctx *> &cs, const uint8_t *src, size_t n, const l
         for (unsigned long long c : cnt) g_stats.transfers += c;
     }
     HIPCHK(hipSetDevice(cs[0]->device));
+    *host_serial_out += host_serial_ms;
+    return LZ77X_OK;
+}
+
+/* ONE stream on SEVERAL devices, any length (round 5: shards and stretches compose).  The input is taken in stretches of at
+ * most `stretch` token positions (LZ77X_SHARD_STRETCH; default one GiB per device, 256 MB per device when the bytes come out
+ * of a FILE*: the host then holds one stretch, not the file); a stretch is cut into position shards, one per device, and
+ * hands the next one the state of lz77.c's two loops (StretchCarry) exactly as a segment of the single-device pipeline does.
+ * Positions inside a stretch are 32-bit, token counts and stream offsets 64-bit: no LZ77X_E_TOOBIG. */
+int encode_sharded(std::vector<Ctx *> &cs, HostWindow &in, const lz77x_geom &g, Sink &sink)
+{
+    const double t_begin = now_ms();
+    memset(&g_stats, 0, sizeof g_stats);
+    const size_t usb = (size_t)g.sb, halo = (size_t)g.la + 64, D = cs.size();
+    size_t stretch = D * (in.from_file() ? (size_t)256 << 20 : (size_t)1 << 30);
+    if (const char *e = getenv("LZ77X_SHARD_STRETCH")) if (atoll(e) > 0) stretch = (size_t)atoll(e);
+    const size_t most = ((size_t)0xF0000000u) - usb - halo;            /* positions of a stretch are 32-bit (+ voff) */
+    if (stretch > most) stretch = most;
+    if (stretch < 4 * usb + 3 * (size_t)4096) stretch = 4 * usb + 3 * (size_t)4096;
+    StretchCarry carry;
+    uint64_t origin = 0, n_total = 0;
+    double host_serial_ms = 0;
+    for (;;) {
+        const size_t t0 = carry.first ? 0 : usb;
+        const size_t want = t0 + stretch + halo;
+        const uint8_t *p = nullptr;
+        size_t got = 0;
+        int rc = in.get(origin, want, &p, &got);
+        if (rc) return rc;
+        const bool last = got < want;
+        const size_t t1 = last ? got : t0 + stretch;
+        if ((rc = encode_sharded_stretch(cs, p, got, t0, t1, origin, last, carry, g, sink, &host_serial_ms))) return rc;
+        n_total = origin + got;
+        if (last) break;
+        origin += t1 - usb;
+    }
     g_stats.host_chain_ms = 0;
     g_stats.copy_ms = host_serial_ms;                      /* sharded: host time no device overlaps (exchange + enqueue) */
-    g_stats.n = n;
+    g_stats.n = n_total;
     g_stats.zn = sink.total;
-    g_stats.ntok = K_all;
+    g_stats.ntok = carry.ntok;
     g_stats.total_ms = now_ms() - t_begin;
     TRACE("encode_sharded total", t_begin);
     return LZ77X_OK;
@@ -578,8 +668,10 @@ int encode_any(std::vector<Ctx *> &cs, const void *src, bool src_on_device, size
     uint32_t iters = 0;                                    /* gate iterations spent before giving up */
     /* one stream over several devices: every window size on the device pipeline (large windows compose their shards'
      * whole-plan maps through HBM, lz77kw_compose_all) */
-    if (cs.size() > 1 && !src_on_device && device_pipeline_ok(1, g))
-        return encode_sharded(cs, reinterpret_cast<const uint8_t *>(src), n, g, sink);
+    if (cs.size() > 1 && !src_on_device && device_pipeline_ok(1, g)) {
+        MemWindow mw(reinterpret_cast<const uint8_t *>(src), n);
+        return encode_sharded(cs, mw, g, sink);
+    }
     if (device_pipeline_ok(cs.size(), g)) {
         MemSource ms(src, n, src_on_device);
         bool fallback = false;

@@ -78,6 +78,34 @@ def _run_huge(r):
                     break
                 h.update(b)
         assert h.hexdigest() == r["sha256_lz"], "stream differs from the reference's"
+        # ... the same file over FOUR device contexts (sharing the box's GPU): shards and stretches compose -- a stretch of
+        # 4 x 256 MB out of the file at a time, cut into four position shards, StretchCarry from one to the next -- through the
+        # CLI in a process of its own, whose peak resident set must stay far below the file (the reference streams through
+        # 3*SB+LA bytes, lz77.c:113-129; round 4 read the whole file into host memory on this path)
+        os.remove(fout)
+        import subprocess
+
+        def cli(env):
+            p = subprocess.Popen([L.CLI_PATH, "-c", "-i", fin, "-o", fout, "-s", str(sb), "-l", str(la)], env=dict(os.environ, **env))
+            _, status, ru = os.wait4(p.pid, 0)
+            assert status == 0
+            return ru.ru_maxrss * 1024
+        # (a process's resident set on this box counts the runtime's mappings -- 2 GB for a 1 GB file on ONE device, which
+        # streams segment by segment through two pinned slots, tools/rss_probe.py -- so the sharded path is held against that:
+        # one stretch of 4 x 256 MB more, not the file)
+        rss_one = cli({})
+        os.remove(fout)
+        rss_four = cli({"LZ77X_SHARDS": "4", "LZ77X_FAKE_DEVICES": "4"})
+        assert rss_four < rss_one + (3 << 29) and rss_four - rss_one < n // 3, \
+            "the sharded file encode held %d MB, the single-device one %d MB, of a %d MB file" % (rss_four >> 20, rss_one >> 20, n >> 20)
+        h = hashlib.sha256()
+        with open(fout, "rb") as f:
+            while True:
+                b = f.read(1 << 26)
+                if not b:
+                    break
+                h.update(b)
+        assert os.path.getsize(fout) == r["zn"] and h.hexdigest() == r["sha256_lz"], "the sharded stream differs from the reference's"
         # ... and back: lz77.c:160-195 decodes any length; the product's -d takes the stream range by range through
         # bounded device memory (the output replaces the input file: /dev/shm holds one copy of each)
         os.remove(fin)

@@ -227,6 +227,37 @@ def test_shards_give_identical_bytes(kind, seed, n, sb, la, monkeypatch):
         L.lib().lz77x_set_shards(1)
 
 
+@pytest.mark.parametrize("kind,seed,n,sb,la,stretch", [("text", 181, 2_500_000, 4095, 15, 400_000), ("random", 182, 900_000, 4095, 15, 150_000),
+                                                      ("mixed", 183, 1_500_000, 1000, 10, 100_000), ("lowent", 184, 1_200_000, 255, 7, 60_000),
+                                                      ("mixed", 185, 2_400_000, 65535, 255, 700_000), ("text", 186, 1_300_000, 20000, 40, 300_000),
+                                                      ("zeros", 0, 500_000, 4095, 15, 90_000), ("records", 187, 1_600_000, 4096, 16, 333_333),
+                                                      ("text", 188, 700_000, 4095, 15, 100_000_000)])
+def test_shards_and_stretches_compose(kind, seed, n, sb, la, stretch, tmp_path, monkeypatch):
+    """lz77.c:113-129 streams any length through 3*SB+LA bytes; one stream over SEVERAL devices takes a long input in
+    stretches (LZ77X_SHARD_STRETCH token positions, by default 1 GiB per device), every stretch cut into position shards,
+    and a stretch hands the next one what a segment of the single-device pipeline hands on: where the next token starts,
+    the last four token words (non-byte-aligned widths straddle the cut), the sb live priorities renumbered by rank.
+    Several stretches of 2/3/4 shards each, out of host memory and out of a FILE* (which holds one stretch at a time):
+    the reference's stream, bit for bit."""
+    data = synth.make(kind, n, seed)
+    want = O.encode_bst(data, sb, la)
+    monkeypatch.setenv("LZ77X_FAKE_DEVICES", "4")
+    monkeypatch.setenv("LZ77X_SHARD_STRETCH", str(stretch))
+    src, dst = str(tmp_path / "in"), str(tmp_path / "out.lz")
+    data.tofile(src)
+    try:
+        for shards in (2, 3, 4):
+            assert L.lib().lz77x_set_shards(shards) == 0
+            assert L.encode(data, la, sb) == want, shards
+            st = L.last_stats()
+            assert st["host_stageb_ms"] == 0 and st["n"] == n and st["zn"] == len(want), shards
+            L.encode_path(src, dst, la, sb)
+            assert open(dst, "rb").read() == want, shards
+            assert L.last_stats()["n"] == n
+    finally:
+        L.lib().lz77x_set_shards(1)
+
+
 @pytest.mark.parametrize("kind,seed,n,sb,la", [("text", 91, 3_000_000, 4095, 15), ("random", 92, 1_200_000, 4095, 15),
                                               ("mixed", 93, 2_000_000, 1000, 10), ("lowent", 94, 1_500_000, 8191, 16),
                                               ("zeros", 0, 700_000, 4095, 15), ("records", 95, 900_000, 255, 7),
