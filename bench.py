@@ -314,11 +314,13 @@ def shard_mode(a):
         dist.barrier()
     t0 = time.perf_counter()
     if rank == 0:
-        enc_ms, dec_ms, iters = [], [], 0
+        enc_ms, dec_ms, iters, serial_ms = [], [], 0, []
         for _ in range(a.steps):
             t1 = time.perf_counter()
             z = L.encode(data, a.la, a.sb)
-            iters = L.last_stats()["prio_iters"]
+            st_enc = L.last_stats()
+            iters = st_enc["prio_iters"]
+            serial_ms.append(st_enc["copy_ms"])
             t2 = time.perf_counter()
             back = L.decode(z)
             t3 = time.perf_counter()
@@ -332,8 +334,33 @@ def shard_mode(a):
         gold = golden_full(a.kind, n, seed, a.sb, a.la)
         sha_ok = None if gold is None else (len(z) == gold["zn"] and hashlib.sha256(z).hexdigest() == gold["sha256_lz"])
         plan = [p.__dict__ for p in __import__("lz77_amd.shard", fromlist=["plan"]).plan(n, max(shards, 1), a.sb, a.la)]
+        # the same stream on ONE context (the device pipeline out of host memory): what Amdahl's law is applied to
+        t_one = None
+        try:
+            assert L.lib().lz77x_set_shards(1) == 0
+            L.encode(data[:64_000_000], a.la, a.sb)
+            t4 = time.perf_counter()
+            z1 = L.encode(data, a.la, a.sb)
+            t_one = (time.perf_counter() - t4) * 1e3
+            assert z1 == z
+        finally:
+            L.lib().lz77x_set_shards(max(shards, 1))
+        hs = sum(serial_ms) / K
+        amdahl = None
+        if t_one:
+            amdahl = {"encode_ms_one_context": round(t_one, 1), "host_serial_ms": round(hs, 2),
+                      "host_serial_ms_per_gate_iteration": round(hs / max(iters, 1), 3),
+                      "bound_encode_ms": {str(d): round(hs + max(t_one - hs, 0.0) / d, 1) for d in (2, 4, 8)},
+                      "bound_speedup": {str(d): round(t_one / (hs + max(t_one - hs, 0.0) / d), 2) for d in (2, 4, 8)},
+                      "note": "prediction, not a measurement: T(D) >= host_serial + (T(1) - host_serial) / D with host_serial = the host "
+                              "time of THIS run that no device overlaps (per gate iteration: D boundary maps chained on the host, the "
+                              "cells handed back, the enqueue of every shard's sweep) -- it grows with D (one map per shard) and is "
+                              "measured here at D = %d on %d physical device(s)" % (len(plan), min(len(plan), L.lib().lz77x_device_count()))}
         out = {"metric": "encode+decode MB/s on enwik9-like synthetic text, s=%d l=%d, ONE stream position-sharded" % (a.sb, a.la),
-               "value": round(n * K / dt / 1e6, 3), "unit": "MB/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+               "value": round(n * K / dt / 1e6, 3), "unit": "MB/s",
+               "n_gpus": min(len(plan), L.lib().lz77x_device_count()),         # one process drives every device: physical devices used
+               "contexts": len(plan), "scaling_measured": bool(min(len(plan), L.lib().lz77x_device_count()) > 1),
+               "steps": a.steps, "warmup": a.warmup,
                "ms_per_step": round(dt / K * 1e3, 3), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
                "dtype": "u8", "data": "synthetic",
                "config": {"workload": "S4 enwik9-like text (lz77_amd.synth.text, seed 0x5EED0004), %d bytes, s=%d l=%d, cut into %d shards "
@@ -342,6 +369,7 @@ def shard_mode(a):
                                       (n, a.sb, a.la, len(plan), min(len(plan), L.lib().lz77x_device_count())),
                           "mode": "shard", "shards": len(plan), "max_local_bytes": max(p["local_bytes"] for p in plan)},
                "encode_ms": round(sum(enc_ms) / K, 2), "decode_ms": round(sum(dec_ms) / K, 2), "prio_iters": iters,
+               "host_serial_ms": round(hs, 2), "amdahl": amdahl,
                "roundtrip_ok": bool(back == data.tobytes()), "stream_sha_ok": sha_ok,
                "serial_terms": "per gate iteration one host exchange of 6 KB per shard (priority cells), one of 1.3 KB per shard for "
                                "the parse chain, 16 bytes per cut for packing; decode: one map of sb 16-bit states per shard, chained "

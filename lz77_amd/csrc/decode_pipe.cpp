@@ -66,7 +66,7 @@ void dec_pass_walk(const uint32_t *hdst, uint32_t ntok, const lz77x_geom &g, uin
 /* The copy resolution of one range: tokens c.tokval / c.dst [0, ntok) -> n bytes at *d_bytes (inside c.out), complete in
  * stream order on s.  K == null: the range is the whole stream. */
 int decode_resolve(Ctx &c, const lz77x_geom &g, uint32_t ntok, uint32_t n, hipStream_t s, bool stale, bool general, DecCarry *K,
-                   uint8_t **d_bytes, uint32_t *rounds_out, DevBuf &outb)
+                   uint8_t **d_bytes, uint32_t *rounds_out, DevBuf &outb, const uint8_t *d_z_fused = nullptr, const uint32_t *d_bofs = nullptr)
 {
     int rc;
     uint32_t rounds = 0;
@@ -112,7 +112,9 @@ int decode_resolve(Ctx &c, const lz77x_geom &g, uint32_t ntok, uint32_t n, hipSt
         const bool ext0 = K && K->produced > 0;
         if ((rc = c.tstart.need(lz77k_dec_seg_tmp_bytes(n, g)))) return rc;
         lz77k_dec_seg_state P;
-        HIPCHK(lz77k_dec_segments_front(c.tokval.as<uint32_t>(), c.dst.as<uint32_t>(), ntok, g, X, c.ptr.p, n, c.tstart.p, s, ext0, P, nullptr));
+        /* (d_z_fused: the walk reads the stream itself; c.tokval / c.dst were not filled) */
+        HIPCHK(lz77k_dec_segments_front(c.tokval.as<uint32_t>(), c.dst.as<uint32_t>(), ntok, g, X, c.ptr.p, n, c.tstart.p, s, ext0, P, nullptr,
+                                        d_z_fused, d_bofs));
         if (ext0 && P.tres0)
             HIPCHK(hipMemcpyAsync(P.tres0, K->d_carry[K->cur] + (K->cb - (uint32_t)g.sb), (size_t)g.sb, hipMemcpyDeviceToDevice, s));
         HIPCHK(lz77k_dec_segments_back(g, X, c.ptr.p, n, P, s));
@@ -252,6 +254,9 @@ int decode_stream(Ctx &c, Source &src, Sink *sink, hipStream_t s, uint64_t *n_ou
     const bool pipelined = !(getenv("LZ77X_PIPELINE") && atoi(getenv("LZ77X_PIPELINE")) == 0);
     DecCarry K;
     bool have_k = false;
+    /* (the conditions of decode_resolve's segment walk that are known before the range is looked at) */
+    const bool fused_ok = lz77k_dec_seg_supported(g) && (sb & (sb - 1)) != 0 && la <= 255 && !LZ77X_VENV("LZ77X_DECODE_VARIANT") &&
+                          !LZ77X_VENV("LZ77X_DECODE_V1") && !LZ77X_VENV("LZ77X_DECODE_UNFUSED");
     uint64_t total_out = 0, total_tok = 0, zn = 4;
     size_t L = 0;                                                             /* bytes of zb[cur] already there (read past the last cut) */
     int cur = 0;
@@ -276,23 +281,50 @@ int decode_stream(Ctx &c, Source &src, Sink *sink, hipStream_t s, uint64_t *n_ou
         uint32_t ntok = (uint32_t)ntok64;
         HIPCHK(hipMemsetAsync(zr.as<uint8_t>() + 4 + avail, 0, 32, s));
         HIPCHK(hipEventRecord(c.ev[0], s));
-        if ((rc = c.tokval.need(((size_t)ntok + 8) * 4))) return rc;
-        if ((rc = c.len1.need(((size_t)ntok + 8) * 4))) return rc;
-        if ((rc = c.dst.need(((size_t)ntok + 8) * 4))) return rc;
-        if ((rc = c.scantmp.need(lz77k_scan_tmp_bytes(ntok + 1)))) return rc;
-        HIPCHK(hipMemsetAsync(c.flag.as<uint32_t>() + 8, 0, 8, s));
-        HIPCHK(lz77k_dec_parse(zr.as<uint8_t>(), ntok, g, c.tokval.as<uint32_t>(), c.len1.as<uint32_t>(), s, c.flag.as<uint32_t>() + 8));
-        HIPCHK(hipMemsetAsync(c.len1.as<uint32_t>() + ntok, 0, 4, s));
-        HIPCHK(lz77k_scan_u32(c.len1.as<uint32_t>(), c.dst.as<uint32_t>(), ntok + 1, c.scantmp.p, s));     /* ntok << lb fits 32 bits (dec_range_plan) */
         uint32_t *tot = reinterpret_cast<uint32_t *>(hdr + 16);
-        HIPCHK(hipMemcpyAsync(tot, c.dst.as<uint32_t>() + ntok, 4, hipMemcpyDeviceToHost, s));
-        HIPCHK(hipMemcpyAsync(tot + 1, c.flag.as<uint32_t>() + 8, 8, hipMemcpyDeviceToHost, s));
-        HIPCHK(hipStreamSynchronize(s));
-        uint32_t n = tot[0], use = ntok;
-        const bool stale = tot[1] != 0;             /* the range copies from distance 0 somewhere (power-of-two -s) */
-        /* distances beyond the window, or a lookahead field no CLI run can produce (main.c:103 caps -l at 255; a token
-         * may then span several tiles): the per-byte pointer path, which assumes nothing about either */
-        const bool general = tot[2] != 0 || la > 255;
+        /* The segment walk reads the stream itself (k_dec_seg<true>): all it needs in front of it are the sums of len + 1 per
+         * block of tokens and their scan.  A range that turns out to need anything else -- a distance-0 copy, a distance
+         * beyond the window, more bytes than the range's cap -- goes through the token words, lengths and offsets of the
+         * full parse + scan below (those streams pay the sums twice). */
+        bool fused = fused_ok && !(have_k && K.track);
+        const uint32_t *d_bofs = nullptr;
+        uint32_t n = 0, use = ntok;
+        bool stale = false, general = la > 255;
+        if (fused) {
+            const uint32_t nblk = (ntok + lz77k_dec_sum_block() - 1u) / lz77k_dec_sum_block();
+            if ((rc = c.len1.need(((size_t)nblk + 8) * 4))) return rc;
+            if ((rc = c.dst.need(((size_t)nblk + 8) * 4))) return rc;
+            if ((rc = c.scantmp.need(lz77k_scan_tmp_bytes(nblk + 1)))) return rc;
+            HIPCHK(hipMemsetAsync(c.flag.as<uint32_t>() + 8, 0, 8, s));
+            HIPCHK(lz77k_dec_sums(zr.as<uint8_t>(), ntok, g, c.len1.as<uint32_t>(), c.flag.as<uint32_t>() + 8, s));
+            HIPCHK(lz77k_scan_u32(c.len1.as<uint32_t>(), c.dst.as<uint32_t>(), nblk + 1, c.scantmp.p, s));
+            HIPCHK(hipMemcpyAsync(tot, c.dst.as<uint32_t>() + nblk, 4, hipMemcpyDeviceToHost, s));
+            HIPCHK(hipMemcpyAsync(tot + 1, c.flag.as<uint32_t>() + 8, 8, hipMemcpyDeviceToHost, s));
+            HIPCHK(hipStreamSynchronize(s));
+            n = tot[0];
+            stale = tot[1] != 0;
+            general = tot[2] != 0 || la > 255;
+            if (stale || general || n > cap) fused = false;
+            else d_bofs = c.dst.as<uint32_t>();
+        }
+        if (!fused) {
+            if ((rc = c.tokval.need(((size_t)ntok + 8) * 4))) return rc;
+            if ((rc = c.len1.need(((size_t)ntok + 8) * 4))) return rc;
+            if ((rc = c.dst.need(((size_t)ntok + 8) * 4))) return rc;
+            if ((rc = c.scantmp.need(lz77k_scan_tmp_bytes(ntok + 1)))) return rc;
+            HIPCHK(hipMemsetAsync(c.flag.as<uint32_t>() + 8, 0, 8, s));
+            HIPCHK(lz77k_dec_parse(zr.as<uint8_t>(), ntok, g, c.tokval.as<uint32_t>(), c.len1.as<uint32_t>(), s, c.flag.as<uint32_t>() + 8));
+            HIPCHK(hipMemsetAsync(c.len1.as<uint32_t>() + ntok, 0, 4, s));
+            HIPCHK(lz77k_scan_u32(c.len1.as<uint32_t>(), c.dst.as<uint32_t>(), ntok + 1, c.scantmp.p, s));     /* ntok << lb fits 32 bits (dec_range_plan) */
+            HIPCHK(hipMemcpyAsync(tot, c.dst.as<uint32_t>() + ntok, 4, hipMemcpyDeviceToHost, s));
+            HIPCHK(hipMemcpyAsync(tot + 1, c.flag.as<uint32_t>() + 8, 8, hipMemcpyDeviceToHost, s));
+            HIPCHK(hipStreamSynchronize(s));
+            n = tot[0];
+            stale = tot[1] != 0;             /* the range copies from distance 0 somewhere (power-of-two -s) */
+            /* distances beyond the window, or a lookahead field no CLI run can produce (main.c:103 caps -l at 255; a token
+             * may then span several tiles): the per-byte pointer path, which assumes nothing about either */
+            general = tot[2] != 0 || la > 255;
+        }
         if (n > cap) {
             HIPCHK(lz77k_dec_cut(c.dst.as<uint32_t>(), ntok, cap, c.flag.as<uint32_t>() + 12, s));
             HIPCHK(hipMemcpyAsync(tot + 4, c.flag.as<uint32_t>() + 12, 8, hipMemcpyDeviceToHost, s));
@@ -334,7 +366,8 @@ int decode_stream(Ctx &c, Source &src, Sink *sink, hipStream_t s, uint64_t *n_ou
             const bool async = have_k && pipelined && sink->blocks_on_host();
             if (use_drain && (rc = drain.wait(1))) return rc;
             DevBuf &ob = *outb[async ? (range_idx & 1u) : 0u];
-            if ((rc = decode_resolve(c, g, use, n, s, stale, general, have_k ? &K : nullptr, &d_bytes, &rounds, ob))) return rc;
+            if ((rc = decode_resolve(c, g, use, n, s, stale, general, have_k ? &K : nullptr, &d_bytes, &rounds, ob,
+                                     fused ? zr.as<uint8_t>() : nullptr, d_bofs))) return rc;
             HIPCHK(hipEventRecord(c.ev[1], s));
             if (async) {
                 if (!use_drain) {

@@ -430,13 +430,102 @@ __global__ void k_dec_bounds_ts(const uint32_t *__restrict__ dst, uint32_t ntok,
 #define DS_PF 2                                      /* tokens per thread fetched a step ahead (2 * 512 cover text and random bytes) */
 #define DS_MAX_STEPS 1024u                           /* steps per segment (segment <= 4 MB) */
 
-__global__ __launch_bounds__(DS_BLOCK) void k_dec_seg(const uint32_t *__restrict__ tokval, const uint32_t *__restrict__ dst, uint32_t ntok,
+/* ---- round 5: the walk reads the STREAM.  Until then k_dec_parse wrote a token word and a
+ * length per token, a grid-wide scan turned the lengths into output offsets, and the walk read both back: 16 bytes of
+ * HBM traffic per token beside the 3 of the stream, three kernels in front of the walk.  Tokens have a fixed width
+ * (lz77.c:260-283: token k is bits [32 + kT, ..)), so the walk extracts its tokens from the stream itself, and the only
+ * thing it cannot know alone -- where its first token's bytes go -- is one offset per 4 KB step: k_dec_sums adds up len + 1
+ * per block of 2048 tokens (and raises the distance-0 / beyond-the-window flags k_dec_parse raised), a scan of those few
+ * sums gives every block its base, k_dec_bounds_fused rescans inside the blocks and records, per step, the token that covers
+ * the step's first byte and, per aligned group of 64 tokens, the offset of the group's first one (ntok / 16 bytes).  The walk
+ * takes a step's tokens from the aligned group of its first one on, so a wavefront's 64 tokens are exactly one group: a
+ * token's offset = its group's + an exclusive scan of len + 1 over the lanes below it (DPP row shifts and broadcasts: no
+ * LDS, no barrier; the first version scanned 512 tokens across the workgroup through LDS -- one barrier a chunk and a
+ * second array of per-step offsets that took the fourth workgroup off a CU: 0.30 -> 0.46 ms). */
+#define DF_TPT 8u                                    /* tokens per thread of the sums / bounds kernels */
+#define DF_BLOCK 256u
+
+__device__ __forceinline__ uint32_t dec_token_at(const uint8_t *__restrict__ z, uint32_t k, int T)
+{
+    const uint64_t bit = 32 + (uint64_t)k * (uint64_t)T;
+    const uint64_t v = ld64u(z + (bit >> 3)) >> (bit & 7);
+    return (uint32_t)(T >= 32 ? v : v & ((1ull << T) - 1));
+}
+
+__global__ __launch_bounds__(DF_BLOCK) void k_dec_sums(const uint8_t *__restrict__ z, uint32_t ntok, int ob, int lb, int T, uint32_t sb,
+                                                       uint32_t *__restrict__ bsum, uint32_t *__restrict__ stale_flag)
+{
+    __shared__ uint32_t ws[DF_BLOCK / 64];
+    const uint32_t tid = threadIdx.x, k0 = (blockIdx.x * DF_BLOCK + tid) * DF_TPT;
+    const uint32_t omask = ob ? (1u << ob) - 1u : 0u, lmask = (1u << lb) - 1u;
+    uint32_t sum = 0, f0 = 0, f1 = 0;
+#pragma unroll
+    for (uint32_t i = 0; i < DF_TPT; i++) {
+        const uint32_t k = k0 + i;
+        const uint32_t v = dec_token_at(z, min(k, ntok - 1u), T);
+        const uint32_t off = v & omask, len = (v >> ob) & lmask;
+        if (k < ntok) {
+            sum += len + 1u;
+            f0 |= (off == 0 && len > 0) ? 1u : 0u;           /* a copy from distance 0 (power-of-two -s) */
+            f1 |= (off > sb && len > 0) ? 1u : 0u;           /* a distance beyond the window: the general path */
+        }
+    }
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) sum += __shfl_xor(sum, d, 64);
+    if ((tid & 63u) == 0) ws[tid >> 6] = sum;
+    if (__ballot(f0 != 0) && (tid & 63u) == 0) stale_flag[0] = 1u;
+    if (__ballot(f1 != 0) && (tid & 63u) == 0) stale_flag[1] = 1u;
+    __syncthreads();
+    if (tid == 0) bsum[blockIdx.x] = ws[0] + ws[1] + ws[2] + ws[3];
+}
+
+__global__ __launch_bounds__(DF_BLOCK) void k_dec_bounds_fused(const uint8_t *__restrict__ z, uint32_t ntok, int ob, int lb, int T,
+                                                               const uint32_t *__restrict__ bofs, uint32_t *__restrict__ tfirst,
+                                                               uint32_t *__restrict__ d64 /* [g] = output offset of token 64 g */)
+{
+    __shared__ uint32_t ws[DF_BLOCK / 64];
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6, k0 = (blockIdx.x * DF_BLOCK + tid) * DF_TPT;
+    const uint32_t lmask = (1u << lb) - 1u;
+    uint32_t l1[DF_TPT], sum = 0;
+#pragma unroll
+    for (uint32_t i = 0; i < DF_TPT; i++) {
+        const uint32_t k = k0 + i;
+        const uint32_t v = dec_token_at(z, min(k, ntok - 1u), T);
+        l1[i] = k < ntok ? ((v >> ob) & lmask) + 1u : 0u;
+        sum += l1[i];
+    }
+    uint32_t incl = sum;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t t = __shfl_up(incl, d, 64);
+        if (lane >= (uint32_t)d) incl += t;
+    }
+    if (lane == 63) ws[wave] = incl;
+    __syncthreads();
+    uint32_t a = bofs[blockIdx.x] + incl - sum;
+    for (uint32_t w = 0; w < wave; w++) a += ws[w];
+    if ((k0 & 63u) == 0 && k0 < ntok) d64[k0 >> 6] = a;
+#pragma unroll
+    for (uint32_t i = 0; i < DF_TPT; i++) {
+        const uint32_t b = a + l1[i];
+        const uint32_t t = (a + DS_TS - 1u) / DS_TS;
+        if (l1[i] && (uint64_t)t * DS_TS < b) tfirst[t] = k0 + i;
+        a = b;
+    }
+}
+
+/* (four workgroups a CU = eight waves per SIMD: at most 64 VGPRs and 80 SGPRs -- the 64-bit token extraction took the fused
+ * form to 66 / 106 and with them a workgroup off every CU; tools/kres.py) */
+template <bool FUSED>
+__global__ __launch_bounds__(DS_BLOCK, 8) __attribute__((amdgpu_num_sgpr(80))) void k_dec_seg(const uint32_t *__restrict__ tokval, const uint32_t *__restrict__ dst, uint32_t ntok,
                                                       int ob, int lb, uint8_t *__restrict__ out, uint16_t *__restrict__ ref16,
                                                       unsigned long long *__restrict__ flags, uint32_t n, uint32_t seg_bytes, uint32_t nseg,
                                                       const uint32_t *__restrict__ tfirst, uint32_t sb, uint16_t *__restrict__ tail,
                                                       uint32_t ext0 /* a shard of a stream cut by token ranges: the sb bytes before output byte 0
                                                                        exist elsewhere (EXT references like any segment's), and the last
-                                                                       segment's tail is wanted too */)
+                                                                       segment's tail is wanted too */,
+                                                      const uint8_t *__restrict__ z /* FUSED: the stream itself */, int T,
+                                                      const uint32_t *__restrict__ d64 /* FUSED: output offset of every 64th token */)
 {
     __shared__ uint16_t ring[DS_R];
     __shared__ uint32_t s_tf[DS_MAX_STEPS + 2];
@@ -448,8 +537,16 @@ __global__ __launch_bounds__(DS_BLOCK) void k_dec_seg(const uint32_t *__restrict
     if (sg > 0 || ext0)
         for (uint32_t i = tid; i < sb; i += DS_BLOCK) ring[(a - sb + i) & (DS_R - 1u)] = (uint16_t)(DS_EXT | i);
     /* first token of every step (and of the step after the last one, when there is one) */
-    for (uint32_t i = tid; i <= nsteps; i += DS_BLOCK) s_tf[i] = (uint64_t)a + (uint64_t)i * DS_TS < n ? tfirst[a / DS_TS + i] : ntok;
+    for (uint32_t i = tid; i <= nsteps; i += DS_BLOCK) {
+        const bool in = (uint64_t)a + (uint64_t)i * DS_TS < n;
+        s_tf[i] = in ? tfirst[a / DS_TS + i] : ntok;
+    }
+
     __syncthreads();
+    auto token = [&](uint32_t k) -> uint32_t {
+        if constexpr (FUSED) return dec_token_at(z, k, T);
+        else return tokval[k];
+    };
     const uint32_t omask = ob ? (1u << ob) - 1u : 0u, lmask = (1u << lb) - 1u;
     auto krange = [&](uint32_t si, uint32_t &k0, uint32_t &k1) {
         const uint32_t ts = a + si * DS_TS, te = b - ts < DS_TS ? b : ts + DS_TS;
@@ -460,8 +557,13 @@ __global__ __launch_bounds__(DS_BLOCK) void k_dec_seg(const uint32_t *__restrict
     {
         uint32_t k0, k1;
         krange(0, k0, k1);
+        if constexpr (FUSED) k0 &= ~63u;                     /* from the aligned group of the step's first token on */
 #pragma unroll
-        for (int q = 0; q < DS_PF; q++) { const uint32_t k = min(k0 + tid + q * DS_BLOCK, ntok - 1u); cv[q] = tokval[k]; cd[q] = dst[k]; }
+        for (int q = 0; q < DS_PF; q++) {
+            const uint32_t k = min(k0 + tid + q * DS_BLOCK, ntok - 1u);
+            cv[q] = token(k);
+            cd[q] = FUSED ? d64[k >> 6] : dst[k];
+        }
     }
     for (uint32_t si = 0; si < nsteps; si++) {
         const uint32_t ts = a + si * DS_TS;
@@ -472,8 +574,13 @@ __global__ __launch_bounds__(DS_BLOCK) void k_dec_seg(const uint32_t *__restrict
             /* the next step's tokens travel while this step runs (unconditional loads, clamped index) */
             uint32_t f0 = k0, f1 = k1;
             if (si + 1 < nsteps) krange(si + 1, f0, f1);
+            if constexpr (FUSED) f0 &= ~63u;
 #pragma unroll
-            for (int q = 0; q < DS_PF; q++) { const uint32_t k = min(f0 + tid + q * DS_BLOCK, ntok - 1u); nv[q] = tokval[k]; nd[q] = dst[k]; }
+            for (int q = 0; q < DS_PF; q++) {
+                const uint32_t k = min(f0 + tid + q * DS_BLOCK, ntok - 1u);
+                nv[q] = token(k);
+                nd[q] = FUSED ? d64[k >> 6] : dst[k];
+            }
         }
         /* lz77.c:178-194 as data flow, one thread per token */
         auto expand = [&](uint32_t v, uint32_t d) {
@@ -494,10 +601,33 @@ __global__ __launch_bounds__(DS_BLOCK) void k_dec_seg(const uint32_t *__restrict
                 ring[j & (DS_R - 1u)] = (uint16_t)st;
             }
         };
+        if constexpr (FUSED) {
+            /* a wavefront's 64 tokens are one aligned group: offset = the group's + the lengths of the lanes below */
+            const uint32_t kA = k0 & ~63u;
+            auto place = [&](uint32_t v, uint32_t g0, uint32_t k) {
+                const uint32_t l1 = k < ntok ? ((v >> ob) & lmask) + 1u : 0u;
+                uint32_t incl = l1;
+                incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x111, 0xF, 0xF, false);      /* row_shr:1 */
+                incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x112, 0xF, 0xF, false);      /* row_shr:2 */
+                incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x114, 0xF, 0xF, false);      /* row_shr:4 */
+                incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x118, 0xF, 0xF, false);      /* row_shr:8 */
+                incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x142, 0xA, 0xF, false);      /* row_bcast:15 into rows 1 and 3 */
+                incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x143, 0xC, 0xF, false);      /* row_bcast:31 into rows 2 and 3 */
+                if (k >= k0 && k < k1) expand(v, g0 + incl - l1);
+            };
 #pragma unroll
-        for (int q = 0; q < DS_PF; q++)
-            if (k0 + tid + q * DS_BLOCK < k1) expand(cv[q], cd[q]);
-        for (uint32_t k = k0 + tid + DS_PF * DS_BLOCK; k < k1; k += DS_BLOCK) expand(tokval[k], dst[k]);
+            for (int q = 0; q < DS_PF; q++)
+                if (kA + q * DS_BLOCK < k1) place(cv[q], cd[q], kA + tid + q * DS_BLOCK);
+            for (uint32_t kc = kA + DS_PF * DS_BLOCK; kc < k1; kc += DS_BLOCK) {
+                const uint32_t k = kc + tid, kq = min(k, ntok - 1u);
+                place(token(kq), d64[kq >> 6], k);
+            }
+        } else {
+#pragma unroll
+            for (int q = 0; q < DS_PF; q++)
+                if (k0 + tid + q * DS_BLOCK < k1) expand(cv[q], cd[q]);
+            for (uint32_t k = k0 + tid + DS_PF * DS_BLOCK; k < k1; k += DS_BLOCK) expand(tokval[k], dst[k]);
+        }
         __syncthreads();
         /* pointer doubling inside the step (16-bit states: a racing reader sees a state further along the chain) */
         uint32_t pending = (1u << (DS_TS / DS_BLOCK)) - 1u;
@@ -676,8 +806,8 @@ size_t lz77k_dec_seg_tmp_bytes(uint32_t n, const lz77x_geom &g)
 {
     uint32_t sbytes, nseg;
     dec_seg_plan(n, &sbytes, &nseg);
-    return ((size_t)n / DS_TS + 8) * 4 + ((size_t)n / 64 + 8) * 8 + (size_t)nseg * g.sb * 2 + ((size_t)nseg + 1) * g.sb +
-           ((size_t)nseg / 8 + 40) * g.sb * 3 + (size_t)g.sb * 2 + 8 * 256;
+    return ((size_t)n / DS_TS + 8) * 4 + ((size_t)n / 64 + 8) * 4 /* (d64: a token is a byte at least) */ + ((size_t)n / 64 + 8) * 8 + (size_t)nseg * g.sb * 2 + ((size_t)nseg + 1) * g.sb +
+           ((size_t)nseg / 8 + 40) * g.sb * 3 + (size_t)g.sb * 2 + 9 * 256;
 }
 
 /* The copy resolution in two phases, so that a stream cut by token ranges over several devices can exchange the sb bytes
@@ -690,7 +820,7 @@ size_t lz77k_dec_seg_tmp_bytes(uint32_t n, const lz77x_geom &g)
  *          bytes patched. */
 hipError_t lz77k_dec_segments_front(const uint32_t *d_tokval, const uint32_t *d_dst, uint32_t ntok, const lz77x_geom &g, uint8_t *d_out,
                                     void *d_ref, uint32_t n, void *d_tmp, hipStream_t s, bool ext0, lz77k_dec_seg_state &P,
-                                    const uint16_t **d_smap)
+                                    const uint16_t **d_smap, const uint8_t *d_z, const uint32_t *d_bofs)
 {
     P = lz77k_dec_seg_state();
     if (n == 0 || ntok == 0) return hipSuccess;
@@ -707,9 +837,18 @@ hipError_t lz77k_dec_segments_front(const uint32_t *d_tokval, const uint32_t *d_
     P.gres = take(((size_t)nseg / 8 + 40) * g.sb);
     P.smap = reinterpret_cast<uint16_t *>(take((size_t)g.sb * 2));
     P.ext0 = ext0;
-    hipLaunchKernelGGL(k_dec_bounds_ts, dim3((ntok + 255) / 256), dim3(256), 0, s, d_dst, ntok, P.tfirst);
-    hipLaunchKernelGGL(k_dec_seg, dim3(nseg), dim3(DS_BLOCK), 0, s, d_tokval, d_dst, ntok, g.ob, g.lb, d_out, reinterpret_cast<uint16_t *>(d_ref),
-                       P.flags, n, P.sbytes, nseg, P.tfirst, usb, P.tail, ext0 ? 1u : 0u);
+    if (d_z) {
+        /* the walk reads the stream: d_bofs[b] = output offset of the first token of block b (lz77k_dec_sums + a scan) */
+        uint32_t *d64 = reinterpret_cast<uint32_t *>(take(((size_t)ntok / 64 + 8) * 4));
+        const uint32_t nblk = (ntok + DF_BLOCK * DF_TPT - 1u) / (DF_BLOCK * DF_TPT);
+        hipLaunchKernelGGL(k_dec_bounds_fused, dim3(nblk), dim3(DF_BLOCK), 0, s, d_z, ntok, g.ob, g.lb, g.T, d_bofs, P.tfirst, d64);
+        hipLaunchKernelGGL(k_dec_seg<true>, dim3(nseg), dim3(DS_BLOCK), 0, s, (const uint32_t *)nullptr, (const uint32_t *)nullptr, ntok, g.ob, g.lb, d_out,
+                           reinterpret_cast<uint16_t *>(d_ref), P.flags, n, P.sbytes, nseg, P.tfirst, usb, P.tail, ext0 ? 1u : 0u, d_z, g.T, d64);
+    } else {
+        hipLaunchKernelGGL(k_dec_bounds_ts, dim3((ntok + 255) / 256), dim3(256), 0, s, d_dst, ntok, P.tfirst);
+        hipLaunchKernelGGL(k_dec_seg<false>, dim3(nseg), dim3(DS_BLOCK), 0, s, d_tokval, d_dst, ntok, g.ob, g.lb, d_out, reinterpret_cast<uint16_t *>(d_ref),
+                           P.flags, n, P.sbytes, nseg, P.tfirst, usb, P.tail, ext0 ? 1u : 0u, (const uint8_t *)nullptr, g.T, (const uint32_t *)nullptr);
+    }
     P.ntails = ext0 ? nseg : nseg - 1u;
     if (P.ntails) {
         uint32_t G = 1;
@@ -748,9 +887,22 @@ hipError_t lz77k_dec_segments(const uint32_t *d_tokval, const uint32_t *d_dst, u
                               void *d_ref, uint32_t n, void *d_tmp, hipStream_t s)
 {
     lz77k_dec_seg_state P;
-    hipError_t e = lz77k_dec_segments_front(d_tokval, d_dst, ntok, g, d_out, d_ref, n, d_tmp, s, false, P, nullptr);
+    hipError_t e = lz77k_dec_segments_front(d_tokval, d_dst, ntok, g, d_out, d_ref, n, d_tmp, s, false, P, nullptr, nullptr, nullptr);
     if (e != hipSuccess) return e;
     return lz77k_dec_segments_back(g, d_out, d_ref, n, P, s);
+}
+
+/* d_bsum[b] = the bytes the tokens of block b (lz77k_dec_sum_block() tokens) decode to; d_bsum[nblk] = 0 (the scan's total slot) */
+uint32_t lz77k_dec_sum_block(void) { return DF_BLOCK * DF_TPT; }
+
+hipError_t lz77k_dec_sums(const uint8_t *d_z, uint32_t ntok, const lz77x_geom &g, uint32_t *d_bsum, uint32_t *d_stale_flag, hipStream_t s)
+{
+    if (ntok == 0) return hipSuccess;
+    const uint32_t nblk = (ntok + DF_BLOCK * DF_TPT - 1u) / (DF_BLOCK * DF_TPT);
+    hipError_t e = hipMemsetAsync(d_bsum + nblk, 0, 4, s);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k_dec_sums, dim3(nblk), dim3(DF_BLOCK), 0, s, d_z, ntok, g.ob, g.lb, g.T, (uint32_t)g.sb, d_bsum, d_stale_flag);
+    return hipGetLastError();
 }
 
 hipError_t lz77k_dec_parse(const uint8_t *d_z, uint32_t ntok, const lz77x_geom &g, uint32_t *d_tokval, uint32_t *d_len1, hipStream_t s,

@@ -291,9 +291,12 @@ struct lz77k_dec_seg_state {
     uint16_t *tail = nullptr, *gmap = nullptr, *smap = nullptr;
     uint8_t *tres0 = nullptr, *gres = nullptr;      /* tres0[0..sb): the bytes before output byte 0 (ext0: filled by the caller before _back) */
 };
+/* d_z != nullptr: the walk reads the stream itself (d_tokval / d_dst unused), d_bofs = the scanned block sums of lz77k_dec_sums */
 hipError_t lz77k_dec_segments_front(const uint32_t *d_tokval, const uint32_t *d_dst, uint32_t ntok, const lz77x_geom &g, uint8_t *d_out,
                                     void *d_ref, uint32_t n, void *d_tmp, hipStream_t s, bool ext0, lz77k_dec_seg_state &P,
-                                    const uint16_t **d_smap);
+                                    const uint16_t **d_smap, const uint8_t *d_z = nullptr, const uint32_t *d_bofs = nullptr);
+uint32_t lz77k_dec_sum_block(void);
+hipError_t lz77k_dec_sums(const uint8_t *d_z, uint32_t ntok, const lz77x_geom &g, uint32_t *d_bsum, uint32_t *d_stale_flag, hipStream_t s);
 hipError_t lz77k_dec_segments_back(const lz77x_geom &g, uint8_t *d_out, void *d_ref, uint32_t n, const lz77k_dec_seg_state &P, hipStream_t s);
 hipError_t lz77k_dec_gather2(uint8_t *d_out, const uint32_t *d_ptr, const unsigned long long *d_unres, uint32_t n, hipStream_t s);
 #endif

@@ -161,3 +161,25 @@ def test_late_distance_0_copy_is_refused(monkeypatch):
     toks = [(0, 3, 64)] + toks                             # the first range holds one: followed throughout
     z = _stream(toks, 4095, 15)
     assert L.decode(z) == O.decode(z)
+
+
+@pytest.mark.parametrize("env", [{}, {"LZ77X_DECODE_RANGE": "4096"}, {"LZ77X_DECODE_RANGE_BYTES": "50000"}, {"LZ77X_DECODE_SEGMENT": "65536"}],
+                         ids=["one", "r4096", "b50000", "seg64k"])
+@pytest.mark.parametrize("kind,seed,n,sb,la", [("text", 301, 2_000_000, 4095, 15), ("random", 302, 700_000, 4095, 15), ("mixed", 303, 900_000, 1000, 10),
+                                              ("lowent", 304, 800_000, 255, 7), ("zeros", 0, 300_000, 4095, 15), ("records", 305, 600_000, 8191, 255),
+                                              ("text", 306, 100_000, 3, 2), ("random", 307, 5_000, 4095, 15), ("text", 308, 1, 4095, 15), ("text", 309, 200_000, 4096, 16)])
+def test_walk_that_reads_the_stream_equals_the_walk_on_token_words(kind, seed, n, sb, la, env, monkeypatch):
+    """lz77.c:260-283: token k is bits [32 + kT, ..) of the stream.  Round 5's segment walk extracts its tokens from the
+    stream itself and scans their lengths per 4 KB step (k_dec_sums, k_dec_bounds_fused, k_dec_seg<true>); the walk of
+    rounds 2-4 read token words and output offsets that a parse kernel and a grid-wide scan had written
+    (LZ77X_DECODE_UNFUSED=1, variants build).  Both give the reference's bytes, in one range and in many, with small
+    decode segments, for token widths that are not whole bytes (T = 19, 22) and steps of thousands of tokens (random)."""
+    data = synth.make(kind, n, seed)
+    z = O.encode_bst(data, sb, la)
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    want = O.decode(z)                                    # (== data unless -s is a power of two: lz77.c:172-188 reads stale bytes then)
+    assert want == data.tobytes() or (sb & (sb - 1)) == 0
+    assert L.decode(z) == want
+    monkeypatch.setenv("LZ77X_DECODE_UNFUSED", "1")
+    assert L.decode(z) == want
