@@ -25,6 +25,9 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+CLOCK_HZ = 2.4e9               # MI355X_MICROARCH.md: max clock
+N_SIMD = 256 * 4               # 256 CUs x 4 SIMDs
+VALU_CYCLES = 3.5              # cycles a wave64 VALU instruction occupies its SIMD: measured 2.8 - 4.5 (tests/ubench/issue_rates.hip)
 
 
 def cpu_baseline(data, sb, la, budget_bytes):
@@ -546,10 +549,26 @@ def main():
         achieved = alg_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
         t_device_ms = sum(mean(enc_stats, k) for k in ("k_match_ms", "k_chain_ms", "k_prio_ms", "k_token_ms"))
         traffic = None
+        issue = None
         tfile = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tfile) and dom_key:
             try:
-                traffic = json.load(open(tfile))["hbm_bytes_per_launch"].get(dom_key)
+                tj = json.load(open(tfile))
+                traffic = tj["hbm_bytes_per_launch"].get(dom_key)
+                valu = tj.get("valu_wave_insts_per_launch", {}).get(dom_key)
+                if valu and dom_ms > 0:
+                    # none of the encode's kernels is HBM-bound: the view that prices them is instruction issue.  A wave64 VALU
+                    # instruction occupies its SIMD for 2.8 (v_add / v_xor) to 4.5 cycles (v_cndmask, v_alignbyte, 64-bit shifts,
+                    # v_bfe / v_mbcnt) with two or more waves per SIMD -- tests/ubench/issue_rates.hip, profiles/r05_issue_rates.txt
+                    simd_cycles = dom_ms / dom_launches * 1e-3 * CLOCK_HZ * N_SIMD
+                    issue = {"valu_wave_insts_per_launch": valu, "cycles_per_valu_inst": VALU_CYCLES, "simd_cycles_per_launch": int(simd_cycles),
+                             "issue_frac": round(valu * VALU_CYCLES / simd_cycles, 4),
+                             "issue_frac_range": [round(valu * 2.8 / simd_cycles, 4), round(valu * 4.5 / simd_cycles, 4)],
+                             "salu_wave_insts_per_launch": tj.get("salu_wave_insts_per_launch", {}).get(dom_key),
+                             "wait_any_over_wave_cycles": tj.get("wait_any_over_wave_cycles", {}).get(dom_key),
+                             "source": "instruction counts: profiles/traffic.json (SQ_INSTS_VALU of the committed rocprofv3 --pmc run, per launch); "
+                                       "duration: this run's hipEvent pair; cycles per instruction: the measured range of the ubench, 3.5 taken for "
+                                       "a mix of compares, selects, funnel shifts and adds"}
             except Exception:
                 traffic = None
         out = {
@@ -572,6 +591,7 @@ def main():
             "roofline": {"bound": "hbm", "kernel": dom_name + " -- the largest GPU kernel of the step",
                          "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic,
+                         "issue_frac": issue["issue_frac"] if issue else None, "issue": issue,
                          "traffic_source": "profiles/traffic.json (PMC passes of the committed rocprofv3 run, per launch; not measured in this run)",
                          "frac_op": round(alg_bytes / (t_device_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 6) if t_device_ms > 0 else 0.0,
                          "frac_op_def": "SURVEY 8d: algorithmic bytes / SUM of the encode's kernel times (match + chain + recurrence + "

@@ -230,7 +230,7 @@ def test_shards_give_identical_bytes(kind, seed, n, sb, la, monkeypatch):
 @pytest.mark.parametrize("kind,seed,n,sb,la,stretch", [("text", 181, 2_500_000, 4095, 15, 400_000), ("random", 182, 900_000, 4095, 15, 150_000),
                                                       ("mixed", 183, 1_500_000, 1000, 10, 100_000), ("lowent", 184, 1_200_000, 255, 7, 60_000),
                                                       ("mixed", 185, 2_400_000, 65535, 255, 700_000), ("text", 186, 1_300_000, 20000, 40, 300_000),
-                                                      ("zeros", 0, 500_000, 4095, 15, 90_000), ("records", 187, 1_600_000, 4096, 16, 333_333),
+                                                      ("zeros", 0, 300_000, 4095, 15, 90_000), ("records", 187, 1_600_000, 4096, 16, 333_333),
                                                       ("text", 188, 700_000, 4095, 15, 100_000_000)])
 def test_shards_and_stretches_compose(kind, seed, n, sb, la, stretch, tmp_path, monkeypatch):
     """lz77.c:113-129 streams any length through 3*SB+LA bytes; one stream over SEVERAL devices takes a long input in
@@ -260,7 +260,7 @@ def test_shards_and_stretches_compose(kind, seed, n, sb, la, stretch, tmp_path, 
 
 @pytest.mark.parametrize("kind,seed,n,sb,la", [("text", 91, 3_000_000, 4095, 15), ("random", 92, 1_200_000, 4095, 15),
                                               ("mixed", 93, 2_000_000, 1000, 10), ("lowent", 94, 1_500_000, 8191, 16),
-                                              ("zeros", 0, 700_000, 4095, 15), ("records", 95, 900_000, 255, 7),
+                                              ("zeros", 0, 300_000, 4095, 15), ("records", 95, 900_000, 255, 7),
                                               ("mixed", 96, 2_500_000, 65535, 255), ("text", 97, 1_500_000, 20000, 40),
                                               ("lowent", 98, 1_200_000, 8193, 255)])
 def test_sharded_decode_gives_identical_bytes(kind, seed, n, sb, la, monkeypatch):
