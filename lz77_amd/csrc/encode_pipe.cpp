@@ -168,10 +168,10 @@ int seg_mid(SegJob &J, const lz77x_geom &g, SegCarry &carry, bool allow_fallback
          * C1, 9-13 at C2 except record-structured data (31: the flips decay slowly but steadily, and the seven iterations
          * past 24 are cheaper than starting over on the host).  Twice the largest count seen; an iteration costs 1/20
          * (C2) to 1/100 (C1, text) of the host loop, so a pathological input is bounded at about three times its cost */
-        int max_iters = allow_fallback ? 64 : 1 << 30;
+        int max_iters = 64;
         {
             const char *me = getenv("LZ77X_PRIO_MAX_ITERS");
-            if (me && atoi(me) > 0 && allow_fallback) max_iters = atoi(me);
+            if (me && atoi(me) > 0) max_iters = atoi(me);
         }
         HIPCHK(hipEventRecord(c.match_ev[2], s));
         const double tw0 = now_ms();
@@ -179,7 +179,27 @@ int seg_mid(SegJob &J, const lz77x_geom &g, SegCarry &carry, bool allow_fallback
         HIPCHK(lz77k_prio(c.ps.as<uint32_t>(), J.nx, g.sb, c.xval.as<uint32_t>(), c.prio_tmp.p, s, c.h_small.as<uint32_t>() + 8, max_iters,
                           &iters, &converged, &c.match_ev[4], prio_ms3, 0u, J.first ? nullptr : look_cur, J.last ? nullptr : look_next));
         HIPCHK(hipEventRecord(c.match_ev[3], s));
-        if (!J.last) HIPCHK(hipMemcpyAsync(h_state, look_next, usb * 4, hipMemcpyDeviceToHost, s));
+        bool host_cells = false;
+        if (!converged && !allow_fallback) {
+            /* A segment of a multi-segment input whose gate iteration gave up (an error front: input that repeats with a
+             * period of about a window, lz77k_prio): the whole encode cannot start over on the host-assisted pipeline -- its
+             * predecessors' words have left -- so THIS segment's recurrence alone goes to a host core: ps out, the exact loop
+             * (hoststage.c lz77x_prio_run_cells, from the carried cells), xval and the cells it leaves behind back.  Round 4
+             * iterated without a bound here: a block per iteration, 16 K iterations for a segment of 2^30 positions. */
+            std::vector<uint32_t> h_ps, h_xv, cells_out(usb);
+            try { h_ps.resize((size_t)J.nx + 16); h_xv.resize((size_t)J.nx + 16); } catch (...) { return LZ77X_E_NOMEM; }
+            HIPCHK(hipMemcpyAsync(h_ps.data(), c.ps.p, (size_t)J.nx * 4, hipMemcpyDeviceToHost, s));
+            HIPCHK(hipStreamSynchronize(s));
+            const double th = now_ms();
+            if (!lz77x_prio_run_cells(h_ps.data(), J.nx, g.sb, J.first ? nullptr : carry.cells.data(), 0u, h_xv.data(), cells_out.data())) return LZ77X_E_NOMEM;
+            g_stats.host_stageb_ms += now_ms() - th;
+            HIPCHK(hipMemcpyAsync(c.xval.p, h_xv.data(), (size_t)J.nx * 4, hipMemcpyHostToDevice, s));
+            HIPCHK(hipStreamSynchronize(s));                    /* (pageable source) */
+            memcpy(h_state, cells_out.data(), usb * 4);
+            host_cells = true;
+            converged = 1;
+        }
+        if (!J.last && !host_cells) HIPCHK(hipMemcpyAsync(h_state, look_next, usb * 4, hipMemcpyDeviceToHost, s));
         HIPCHK(hipStreamSynchronize(s));                       /* (nx == 0: the recurrence did not sync) */
         HIPCHK(hipEventSynchronize(c.pipe_ev[2]));             /* tbase has landed */
         HIPCHK(hipStreamWaitEvent(s, c.pipe_ev[2], 0));        /* chain[] is there for the tie-break */

@@ -158,3 +158,37 @@ void lz77x_prio_run(lz77x_prio_state *st, const uint32_t *restrict ps, int sb, s
     LZ77X_STREAM_FENCE();
     st->next = t;
 }
+
+/* The same recurrence on what the DEVICE pipeline holds: ps[x] = P | S << 16 as distances (0 = no such neighbour), the sb
+ * cells a segment starts from (cells_in: the carried ranks of a later segment of a long input, or NULL: every cell its own
+ * position + voff) and the sb cells it leaves behind (cells_out, may be NULL) -- k_prio_fwd's exact sweep as one plain loop.
+ * encode_pipe.cpp comes here when the device's gate iteration meets an error front (k_prio.hip, lz77k_prio) in a segment of
+ * a multi-segment input, where starting the whole encode over on the host-assisted pipeline is not an option; about 2 ns a
+ * step, against an iteration per block of the segment. */
+int lz77x_prio_run_cells(const uint32_t *restrict ps, size_t nx, int sb, const uint32_t *cells_in, uint32_t voff, uint32_t *restrict xval,
+                         uint32_t *cells_out)
+{
+    const uint32_t mask = lz77x_prio_mask(sb);
+    const size_t usb = (size_t)sb;
+    uint32_t *ring = (uint32_t *)malloc(sizeof(uint32_t) * ((size_t)mask + 1));
+    if (!ring) return 0;
+    for (size_t i = 0; i < usb; i++) ring[i & mask] = cells_in ? cells_in[i] : (uint32_t)i + voff;
+    for (size_t x = 0; x < nx; x++) {
+        const uint32_t v = ps[x], p = v & 0xFFFFu, s = v >> 16;
+        const uint32_t mine = ring[x & mask];
+        uint32_t out = LZ77X_NONE32;
+        if (p && s) {
+            const uint32_t pp = ring[(x + p) & mask], sp = ring[(x + s) & mask];
+            if (mine < pp && mine < sp) {                 /* tree.c:202-231: both children hang below x -- the successor takes its place */
+                ring[(x + s) & mask] = mine;
+                out = mine;
+            }
+        }
+        xval[x] = out;
+        ring[(x + usb) & mask] = (uint32_t)(x + usb) + voff;    /* tree.c:102-105: the new node is a leaf */
+    }
+    if (cells_out)
+        for (size_t i = 0; i < usb; i++) cells_out[i] = ring[(nx + i) & mask];
+    free(ring);
+    return 1;
+}

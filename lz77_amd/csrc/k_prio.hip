@@ -1020,6 +1020,8 @@ hipError_t lz77k_prio(const uint32_t *d_ps, uint32_t nx, int sb_i, uint32_t *d_x
     lz77k_prio_plan P;
     hipError_t e;
     if ((e = lz77k_prio_begin(P, d_ps, nx, sb_i, d_xval, d_tmp, voff, d_carried, s)) != hipSuccess) return e;
+    /* the last six iterations' flips and first flipped blocks (the front test below) */
+    uint32_t hist_f[6] = {0, 0, 0, 0, 0, 0}, hist_b[6] = {0, 0, 0, 0, 0, 0};
     for (int it = 0;; it++) {
         if (it >= max_iters) { *converged = 0; break; }
         if (ev4 && (e = hipEventRecord(ev4[3], s)) != hipSuccess) return e;
@@ -1040,6 +1042,28 @@ hipError_t lz77k_prio(const uint32_t *d_ps, uint32_t nx, int sb_i, uint32_t *d_x
         if (getenv("LZ77X_PRIO_TRACE"))
             fprintf(stderr, "prio it %d: B %u NB %u first %u flips %u min flipped block %u\n", it, P.B, P.NB, P.first, h_flag[0], h_flag[1]);
         if (h_flag[0] == 0) break;
+        /* An error FRONT: on input that repeats with a period of about a window (a repeated random block of 4096 bytes; rows
+         * of an image) the flips fall to a few dozen within five iterations and then stay there, all of them in the first
+         * block that is not final yet -- its wrong gates make its map wrong, the next block's entry cells with it, and every
+         * iteration repairs exactly one block: NB iterations (tools/worst_cases.py found it; `prio it` traces in DESIGN 2.2d).
+         * No number of iterations the caller can afford ends that; when the last three iterations flipped as many gates
+         * as the three before them, finalised at most two blocks each, and the blocks still open outnumber twice the
+         * iterations left, give up NOW and leave the recurrence to the sequential form (the caller's fallback) instead of
+         * after max_iters sweeps of the whole input (64 x 0.8 ms per 100 MB).  Only where the caller has a fallback. */
+        for (int q = 0; q < 5; q++) { hist_f[q] = hist_f[q + 1]; hist_b[q] = hist_b[q + 1]; }
+        hist_f[5] = h_flag[0];
+        hist_b[5] = h_flag[1];
+        if (it >= 7 && max_iters < (1 << 29)) {
+            const uint64_t late = (uint64_t)hist_f[3] + hist_f[4] + hist_f[5], early = (uint64_t)hist_f[0] + hist_f[1] + hist_f[2];
+            const bool flat = late * 5 >= early * 4;
+            const bool crawling = hist_b[5] >= hist_b[2] && hist_b[5] - hist_b[2] <= 6u;
+            const uint32_t open = P.NB > hist_b[5] ? P.NB - hist_b[5] : 0u;
+            if (flat && crawling && (uint64_t)open > 2ull * (uint64_t)(max_iters - it - 1)) {
+                if (getenv("LZ77X_PRIO_TRACE")) fprintf(stderr, "prio: an error front, one block an iteration, %u blocks open: giving up after %d iterations\n", open, it + 1);
+                *converged = 0;
+                break;
+            }
+        }
         lz77k_prio_advance(P, h_flag, false);
     }
     return hipGetLastError();

@@ -69,6 +69,7 @@ void lz77x_prio_free(lz77x_prio_state *st);
  * missing) must be available for x < upto - sb; writes xval[x] for those x. */
 uint32_t lz77x_prio_mask(int sb);
 void lz77x_prio_run(lz77x_prio_state *st, const uint32_t *ps, int sb, size_t upto, uint32_t *xval);
+int lz77x_prio_run_cells(const uint32_t *ps, size_t nx, int sb, const uint32_t *cells_in, uint32_t voff, uint32_t *xval, uint32_t *cells_out);
 
 #include <stdio.h>
 

@@ -444,6 +444,11 @@ static int encode_sharded_stretch(std::vector<Ctx *> &cs, const uint8_t *src, si
         const uint32_t *d_sloc = nullptr;
         int max_iters = 1 << 30;
         uint32_t iters = 0;
+        /* the error front of lz77k_prio (k_prio.hip), across the shards: flips and the first open block of the last six iterations */
+        uint64_t hist_f[6] = {0, 0, 0, 0, 0, 0}, hist_b[6] = {0, 0, 0, 0, 0, 0};
+        int front_budget = 64;
+        if (const char *me = getenv("LZ77X_PRIO_MAX_ITERS")) if (atoi(me) > 0) front_budget = atoi(me);
+        bool on_host = false;
         for (int it = 0; it < max_iters; it++) {
             for (size_t d = 0; d + 1 < D; d++) {            /* the last shard's whole map is nobody's input */
                 ShardJob &j = J[d];
@@ -489,15 +494,53 @@ static int encode_sharded_stretch(std::vector<Ctx *> &cs, const uint8_t *src, si
             t_serial = now_ms();
             iters++;
             bool any = false, earlier = false;
+            uint64_t flips = 0, blocks_before = 0, first_open = 0, blocks_all = 0;
             for (size_t d = 0; d < D; d++) {
                 const uint32_t *hf = J[d].c->h_small.as<uint32_t>() + 8;
                 flipped[d] = hf[0] != 0;
+                flips += hf[0];
+                if (flipped[d] && !any) first_open = blocks_before + hf[1];
+                blocks_before += J[d].P.NB;
                 /* a shard after one that still changes may be handed different cells next time: nothing of it is final */
                 lz77k_prio_advance(J[d].P, hf, earlier);
                 earlier = earlier || flipped[d];
                 any = any || flipped[d];
             }
+            blocks_all = blocks_before;
             if (!any) break;
+            for (int q = 0; q < 5; q++) { hist_f[q] = hist_f[q + 1]; hist_b[q] = hist_b[q + 1]; }
+            hist_f[5] = flips;
+            hist_b[5] = first_open;
+            const bool flat = (hist_f[3] + hist_f[4] + hist_f[5]) * 5 >= (hist_f[0] + hist_f[1] + hist_f[2]) * 4;
+            const bool crawling = hist_b[5] >= hist_b[2] && hist_b[5] - hist_b[2] <= 6;
+            if ((int)iters >= front_budget ||
+                (iters >= 8 && flat && crawling && blocks_all - first_open > 2ull * (uint64_t)(front_budget > (int)iters ? front_budget - (int)iters : 0))) {
+                /* one block an iteration (input that repeats with a period of about a window): the recurrence of the whole
+                 * stretch on a host core instead, shard after shard -- each shard's evictions follow its predecessor's, the
+                 * cells one leaves behind are the cells the next starts from (hoststage.c lz77x_prio_run_cells) */
+                if (carry.first) for (size_t i = 0; i < usb; i++) v[i] = (uint32_t)i;
+                else memcpy(v.data(), carry.cells.data(), usb * 4);
+                const double th = now_ms();
+                for (size_t d = 0; d < D; d++) {
+                    ShardJob &j = J[d];
+                    if ((rc = dev(j))) return rc;
+                    std::vector<uint32_t> h_ps, h_xv, out(usb);
+                    try { h_ps.resize((size_t)j.nx + 16); h_xv.resize((size_t)j.nx + 16); } catch (...) { return LZ77X_E_NOMEM; }
+                    HIPCHK(hipMemcpy(h_ps.data(), j.c->ps.p, (size_t)j.nx * 4, hipMemcpyDeviceToHost));
+                    if (d > 0) {
+                        uint32_t *pin = j.h + 512 + 2 * usb;            /* the cells this shard REALLY starts from: the tie-break's look-back */
+                        memcpy(pin, v.data(), usb * 4);
+                        HIPCHK(lz77k_prio_set_in0(j.P, pin, hipMemcpyHostToDevice, j.c->stream));
+                        HIPCHK(hipStreamSynchronize(j.c->stream));
+                    }
+                    if (!lz77x_prio_run_cells(h_ps.data(), j.nx, g.sb, v.data(), (uint32_t)j.gpos0, h_xv.data(), out.data())) return LZ77X_E_NOMEM;
+                    HIPCHK(hipMemcpy(j.c->xval.p, h_xv.data(), (size_t)j.nx * 4, hipMemcpyHostToDevice));
+                    v = out;
+                }
+                g_stats.host_stageb_ms += now_ms() - th;
+                on_host = true;
+                break;
+            }
         }
         g_stats.prio_iters += iters;
         if (!last_stretch) {
@@ -505,7 +548,8 @@ static int encode_sharded_stretch(std::vector<Ctx *> &cs, const uint8_t *src, si
             ShardJob &j = J[D - 1];
             if ((rc = dev(j))) return rc;
             std::vector<uint32_t> st(usb);
-            if (j.nx) HIPCHK(hipMemcpy(st.data(), j.c->look.as<uint32_t>() + usb + 8, usb * 4, hipMemcpyDeviceToHost));
+            if (on_host) memcpy(st.data(), v.data(), usb * 4);  /* (the host loop's last cells) */
+            else if (j.nx) HIPCHK(hipMemcpy(st.data(), j.c->look.as<uint32_t>() + usb + 8, usb * 4, hipMemcpyDeviceToHost));
             else memcpy(st.data(), v.data(), usb * 4);      /* (no step in the last shard: what it was handed) */
             std::vector<std::pair<uint32_t, uint32_t>> order(usb);
             for (size_t i = 0; i < usb; i++) order[i] = {st[i], (uint32_t)i};

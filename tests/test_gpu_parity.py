@@ -258,6 +258,33 @@ def test_shards_and_stretches_compose(kind, seed, n, sb, la, stretch, tmp_path, 
         L.lib().lz77x_set_shards(1)
 
 
+@pytest.mark.parametrize("kind,seed,n,sb,la,stretch", [("text", 281, 1_500_000, 4095, 15, 100_000_000), ("mixed", 283, 1_500_000, 1000, 10, 400_000),
+                                                      ("mixed", 285, 1_600_000, 65535, 255, 100_000_000), ("lowent", 286, 900_000, 20000, 40, 350_000),
+                                                      ("periodic", 287, 5_000_000, 4095, 15, 100_000_000)])
+def test_sharded_error_front_goes_to_the_host(kind, seed, n, sb, la, stretch, monkeypatch):
+    """the shards iterate their gates jointly; when that iteration gives up (an error front across the shards, or -- here --
+    LZ77X_PRIO_MAX_ITERS=1) the recurrence of the stretch runs on a host core shard after shard, every shard from the cells
+    its predecessor left (which also become its tie-break's look-back), and the stream is still the reference's.  The
+    `periodic` case reaches it with no knob set: 78 blocks over two or three shards, an error front that the test of
+    k_prio.hip's lz77k_prio (restated across the shards) gives up on after nine iterations."""
+    if kind == "periodic":
+        rng = np.random.default_rng(seed)
+        data = np.tile(rng.integers(0, 256, 4096, dtype=np.uint8), n // 4096 + 1)[:n].copy()
+    else:
+        data = synth.make(kind, n, seed)
+        monkeypatch.setenv("LZ77X_PRIO_MAX_ITERS", "1")
+    want = O.encode_bst(data, sb, la)
+    monkeypatch.setenv("LZ77X_FAKE_DEVICES", "4")
+    monkeypatch.setenv("LZ77X_SHARD_STRETCH", str(stretch))
+    try:
+        for shards in (2, 3):
+            assert L.lib().lz77x_set_shards(shards) == 0
+            assert L.encode(data, la, sb) == want, shards
+            assert L.last_stats()["host_stageb_ms"] > 0, shards
+    finally:
+        L.lib().lz77x_set_shards(1)
+
+
 @pytest.mark.parametrize("kind,seed,n,sb,la", [("text", 91, 3_000_000, 4095, 15), ("random", 92, 1_200_000, 4095, 15),
                                               ("mixed", 93, 2_000_000, 1000, 10), ("lowent", 94, 1_500_000, 8191, 16),
                                               ("zeros", 0, 300_000, 4095, 15), ("records", 95, 900_000, 255, 7),
@@ -368,6 +395,36 @@ def test_device_and_host_pipelines_agree(kind, seed, n, sb, la, env, monkeypatch
         assert st["host_stageb_ms"] > 0                      # gave up after one iteration: host path took over
     else:
         assert st["prio_iters"] >= 1 and st["host_stageb_ms"] == 0 and st["host_chain_ms"] == 0
+
+
+@pytest.mark.parametrize("seg", ["50000", "300001"])
+@pytest.mark.parametrize("kind,seed,n,sb,la", [("mixed", 193, 1_500_000, 4095, 15), ("text", 194, 700_000, 1000, 10), ("lowent", 195, 400_000, 255, 7),
+                                              ("records", 196, 600_000, 4096, 16), ("zeros", 0, 200_000, 4095, 15),
+                                              ("mixed", 197, 1_400_000, 65535, 255), ("text", 198, 900_000, 20000, 40)])
+def test_a_segment_whose_gate_iteration_gives_up_runs_its_recurrence_on_the_host(kind, seed, n, sb, la, seg, monkeypatch):
+    """tree.c:202-231 for one SEGMENT of a multi-segment input on a host core (hoststage.c lz77x_prio_run_cells: the exact
+    loop from the carried cells; xval and the cells left behind go back to the device): where the library goes when the gate
+    iteration of a segment gives up (an error front, test_periodic_input_...) and the encode cannot start over because the
+    segments before have left.  Forced here by LZ77X_PRIO_MAX_ITERS=1 for every segment, every window size."""
+    data = synth.make(kind, n, seed)
+    want = O.encode_bst(data, sb, la)
+    monkeypatch.setenv("LZ77X_SEGMENT", seg)
+    monkeypatch.setenv("LZ77X_PRIO_MAX_ITERS", "1")
+    assert L.encode(data, la, sb) == want
+    assert L.last_stats()["host_stageb_ms"] > 0 or kind == "zeros"      # (no hand-over at all: one iteration is the fixed point)
+
+
+def test_periodic_input_in_segments_stays_bounded(monkeypatch):
+    """the error front inside the segments of a long input: two segments of 107 blocks each; round 4 iterated a block per
+    iteration without a bound there (16 K iterations for a segment of 2^30 positions)"""
+    rng = np.random.default_rng(11)
+    n = 14_000_000
+    data = np.tile(rng.integers(0, 256, 4096, dtype=np.uint8), n // 4096 + 1)[:n].copy()
+    monkeypatch.setenv("LZ77X_SEGMENT", "7000000")
+    z = L.encode(data)
+    st = L.last_stats()
+    assert z == O.encode_bst(data, 4095, 15)
+    assert st["host_stageb_ms"] > 0 and st["prio_iters"] < 40
 
 
 @pytest.mark.parametrize("seg", ["1", "50000", "300001"])
@@ -539,6 +596,24 @@ def test_long_runs_between_data(seg, entcap, big, monkeypatch):
         monkeypatch.setenv("LZ77X_TS_ENTCAP", entcap)        # (variants build) the lists without staged priorities
     z = L.encode(data)
     assert z == want
+    assert L.decode(z) == data.tobytes()
+
+
+@pytest.mark.parametrize("period", [4096, 4095, 8190])
+def test_periodic_input_reaches_the_fallback_without_a_knob(period):
+    """The worst case tools/worst_cases.py found (profiles/r05_worst_cases.json): a random block of about a window, repeated.
+    The gate iteration of the priority recurrence then repairs exactly ONE block per iteration (an error front: ~50 flips,
+    all in the first block that is not final), so no affordable number of iterations converges; the library notices the
+    front after nine iterations and hands the recurrence to its sequential form on a host core (encode_host.cpp,
+    hoststage.c) -- the only input class known to take that path with no knob set.  The stream still equals the
+    reference's (tree.c:202-231 on every eviction, in order)."""
+    rng = np.random.default_rng(period)
+    n = 6_300_000                                            # ~96 blocks of 64 K steps: more than the iterations left
+    data = np.tile(rng.integers(0, 256, period, dtype=np.uint8), n // period + 1)[:n].copy()
+    z = L.encode(data)
+    st = L.last_stats()
+    assert z == O.encode_bst(data, 4095, 15)
+    assert st["host_stageb_ms"] > 0, "the gate iteration converged on its own: update DESIGN 2.2d and this test"
     assert L.decode(z) == data.tobytes()
 
 
