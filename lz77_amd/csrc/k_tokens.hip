@@ -680,33 +680,28 @@ __global__ __launch_bounds__(TS_BLOCK, 8) __attribute__((amdgpu_num_sgpr(80))) v
     /* ---- everything the tile needs from HBM is requested at once (one latency, not seven in a row): the region's
      *      order, the token range, the evictions, the window bytes; the barriers in between only order LDS traffic
      *      (ts_barrier_lds does not wait for loads in flight) ---- */
-    uint32_t mine[16];
+    /* (the slots stay PACKED, two a word: sixteen unpacked registers on top of the fourteen eviction words below were more
+     * than the 64 the kernel may hold -- the compiler spilled twelve of the eviction loads one by one, each behind
+     * s_waitcnt vmcnt(0): twelve round trips in a row where one was meant, and 3.5 of the kernel's 4.8 GB of HBM traffic) */
+    uint32_t mw[8];
     {
         const uint32_t K = RP / TS_BLOCK;                  /* 4, 8 or 16 consecutive slots per thread */
         const uint16_t *ord = order_all + (size_t)region * RP + (size_t)tid * K;
+#pragma unroll
+        for (int q = 0; q < 8; q++) mw[q] = 0xFFFFFFFFu;    /* (0xFFFF is no slot of a region: RP <= 16384) */
         if (K == 16) {
             const uint4 v0 = *reinterpret_cast<const uint4 *>(ord), v1 = *reinterpret_cast<const uint4 *>(ord + 8);
-            const uint32_t w[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
-#pragma unroll
-            for (int q = 0; q < 8; q++) { mine[2 * q] = w[q] & 0xFFFFu; mine[2 * q + 1] = w[q] >> 16; }
+            mw[0] = v0.x; mw[1] = v0.y; mw[2] = v0.z; mw[3] = v0.w; mw[4] = v1.x; mw[5] = v1.y; mw[6] = v1.z; mw[7] = v1.w;
         } else if (K == 8) {
             const uint4 v0 = *reinterpret_cast<const uint4 *>(ord);
-            const uint32_t w[4] = {v0.x, v0.y, v0.z, v0.w};
-#pragma unroll
-            for (int q = 0; q < 4; q++) { mine[2 * q] = w[q] & 0xFFFFu; mine[2 * q + 1] = w[q] >> 16; }
-#pragma unroll
-            for (int q = 8; q < 16; q++) mine[q] = 0xFFFFFFFFu;
+            mw[0] = v0.x; mw[1] = v0.y; mw[2] = v0.z; mw[3] = v0.w;
         } else {
             const uint2 v0 = *reinterpret_cast<const uint2 *>(ord);
-            mine[0] = v0.x & 0xFFFFu; mine[1] = v0.x >> 16; mine[2] = v0.y & 0xFFFFu; mine[3] = v0.y >> 16;
-#pragma unroll
-            for (int q = 4; q < 16; q++) mine[q] = 0xFFFFFFFFu;
+            mw[0] = v0.x; mw[1] = v0.y;
         }
     }
+    auto mine_at = [&](int q) -> uint32_t { return (q & 1) ? mw[q >> 1] >> 16 : mw[q >> 1] & 0xFFFFu; };
     const uint32_t k0 = tstart[tl], k1 = tstart[tl + 1];
-    /* the first batch's token positions (and, once they are here, their lengths) travel with the tile's other requests:
-     * under the batch loop they were two exposed round trips, one behind the other */
-    const uint32_t p_pre = chain[min(k0 + (tid >> 1), max(k1, 1u) - 1u)];
     /* the evictions [xs0, xs1) (every load unconditional, clamped: the compiler keeps them in flight) */
     const uint32_t xs0 = wlo > usb ? wlo - usb : 0u, xs1 = b > usb ? b - usb : 0u;
     uint32_t xv[TS_SRC], xc[TS_SRC];                        /* priority handed over / the cell it goes to, then 1 + its slot */
@@ -721,33 +716,37 @@ __global__ __launch_bounds__(TS_BLOCK, 8) __attribute__((amdgpu_num_sgpr(80))) v
         }
     }
     constexpr int BY_PER = (TS_TT + 4096 + 256 + 16 + 4 * TS_BLOCK - 1) / (4 * TS_BLOCK);
-    uint32_t by_raw[BY_PER];
     const uint32_t nb = (b + (uint32_t)la + 8 - wbase + 3) & ~3u;
-#pragma unroll
-    for (int r = 0; r < BY_PER; r++) {
-        const uint32_t i = (tid + (uint32_t)r * TS_BLOCK) * 4u;
-        by_raw[r] = i < nb ? *reinterpret_cast<const uint32_t *>(in + wbase + i) : 0u;
-    }
     *reinterpret_cast<uint4 *>(lofs32 + 4u * tid) = make_uint4(0u, 0u, 0u, 0u);     /* the counters (ordered before the counting by the scan's barriers) */
     /* the region's order, filtered down to the cells of [wlo, b) */
     {
         const uint32_t wl = wlo - t0r, wn = b - wlo;        /* region-local window */
         uint32_t cnt = 0;
 #pragma unroll
-        for (int q = 0; q < 16; q++) cnt += (mine[q] - wl < wn) ? 1u : 0u;
+        for (int q = 0; q < 16; q++) cnt += (mine_at(q) - wl < wn) ? 1u : 0u;
         uint32_t run = ts_wg_scan(cnt, wsum, &s_total);
         const uint32_t shift = t0r - wbase;
 #pragma unroll
         for (int q = 0; q < 16; q++) {
-            if (mine[q] - wl < wn) {
-                const uint32_t co = mine[q] + shift;
+            const uint32_t m = mine_at(q);
+            if (m - wl < wn) {
+                const uint32_t co = m + shift;
                 sorted[run] = (uint16_t)co;
                 inv[co] = (uint16_t)run;
                 run++;
             }
         }
     }
-    const uint32_t len_pre = maxlen[p_pre];
+    /* the slots' registers are free now: the window bytes and the first batch's token positions (and, once they are here,
+     * their lengths) are requested here and travel while the entries are counted and placed -- under the batch loop the
+     * positions and lengths were two exposed round trips, one behind the other */
+    uint32_t by_raw[BY_PER];
+#pragma unroll
+    for (int r = 0; r < BY_PER; r++) {
+        const uint32_t i = (tid + (uint32_t)r * TS_BLOCK) * 4u;
+        by_raw[r] = i < nb ? *reinterpret_cast<const uint32_t *>(in + wbase + i) : 0u;
+    }
+    const uint32_t p_pre = chain[min(k0 + (tid >> 1), max(k1, 1u) - 1u)];
     ts_barrier_lds();                                       /* every cell has its slot */
     const uint32_t N = s_total;                             /* = b - wlo: every cell of the window is in the region */
     /* hand-overs per slot: counter of slot i = entry i + 1 (entry 0 stays 0), two entries per word */
@@ -770,6 +769,7 @@ __global__ __launch_bounds__(TS_BLOCK, 8) __attribute__((amdgpu_num_sgpr(80))) v
         for (int d = 32; d > 0; d >>= 1) own += __shfl_xor(own, d, 64);
         if ((tid & 63u) == 0) s_own[tid >> 6] = own;
     }
+    const uint32_t len_pre = maxlen[p_pre];
     ts_barrier_lds();
     if (total && tid == 0) {
         /* one atomic per workgroup, spread over TS_SLOTS words: atomics to ONE address queue in the L2 at ~100 cycles each

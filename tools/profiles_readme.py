@@ -1,0 +1,164 @@
+"""profiles/README.md, the round-5 part: GENERATED from the files tools/r05_evidence.sh wrote (the numbers in the
+README come out of the evidence files, not out of an editor).
+
+    python tools/profiles_readme.py            # rewrites the block between <!-- r05:begin --> and <!-- r05:end -->
+"""
+import csv
+import json
+import os
+import re
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+P = os.path.join(ROOT, "profiles")
+TAG = "r05"
+
+
+def load(name):
+    """a JSON file, or a log whose last line is the JSON line"""
+    try:
+        with open(os.path.join(P, name)) as f:
+            txt = f.read().strip()
+    except OSError:
+        return None
+    for cand in (txt, txt.splitlines()[-1] if txt else ""):
+        try:
+            return json.loads(cand)
+        except ValueError:
+            pass
+    return None
+
+
+def kstats(name):
+    out = {}
+    try:
+        for r in csv.DictReader(open(os.path.join(P, name))):
+            k = r["Name"]
+            k = k[5:] if k.startswith("void ") else k
+            out[k.split("(")[0]] = (int(r["Calls"]), float(r["AverageNs"]) / 1e6, float(r["TotalDurationNs"]) / 1e6)
+    except OSError:
+        pass
+    return out
+
+
+def f(x, nd=2):
+    return ("%." + str(nd) + "f") % x if isinstance(x, (int, float)) else "n/a"
+
+
+rows = []
+b = load(TAG + "_bench.json")
+if b:
+    r, rd, e = b["roofline"], b["roofline_decode"], b["encode_breakdown_ms"]
+    cfg = {c["name"]: c for c in b.get("configs", []) if "name" in c}
+    ff = b.get("file_to_file", {})
+    cb = b.get("cpu_baseline", {})
+    line = ("the JSON line `python bench.py` printed in the evidence run: encode+decode **%s MB/s** (%s ms per step: encode %s, decode %s), "
+            "`stream_sha_ok` %s, `roofline.frac` %s on `%s` (%s ms by its own hipEvent pair), `frac_op` %s, `issue_frac` %s (VALU instructions x %s cycles "
+            "/ SIMD-cycles), decode `frac` %s" % (f(b["value"], 0), f(b["ms_per_step"], 2), f(e["total_ms"]), f(b["decode_breakdown_ms"]["total_ms"]),
+                                                  b["stream_sha_ok"], r["frac"], r["kernel"].split(" ")[0], r["kernel_ms_per_launch"], r["frac_op"],
+                                                  r.get("issue_frac"), (r.get("issue") or {}).get("cycles_per_valu_inst"), rd["frac"]))
+    for nm in ("S2", "S3"):
+        c = cfg.get(nm)
+        if c and "encode_ms" in c:
+            line += "; %s encode %s ms / %s GB/s, digest %s" % (nm, f(c["encode_ms"], 1), f(c["encode_MBps"] / 1e3, 2), c["stream_sha_ok"])
+    if ff and "warm" in ff:
+        line += "; file to file through the CLI %s / %s MB/s (best of three: %s / %s ms; `process_start_ms` %s)" % (
+            f(ff["encode_MBps"], 0), f(ff["decode_MBps"], 0), ff["warm"]["encode_ms"], ff["warm"]["decode_ms"], ff["process_start_ms"])
+    if cb:
+        line += "; reference CPU (%s, %s core) %s MB/s" % (cb.get("kind"), cb.get("cores"), cb.get("value"))
+    rows.append(("`%s_bench.json`" % TAG, line))
+
+ks = kstats(TAG + "_bench_kernel_stats.csv")
+if ks:
+    want = ["k_tokens_sorted", "k_c1_chunks", "k_match<true, 3>", "k_prio_fwd<true>", "k_prio_back2", "k_prio_prep", "k_walk", "k_walk_final_lds",
+            "k_chain_emit", "k_dec_seg<true>", "k_dec_patch_seg", "k_dec_sums", "k_dec_bounds_fused"]
+    parts = ["`%s` %s x %d" % (k, f(ks[k][1], 3), ks[k][0]) for k in want if k in ks]
+    rows.append(("`%s_bench_kernel_stats.csv`" % TAG, "`rocprofv3 --kernel-trace --stats -- python bench.py --steps 3 --warmup 1 ...` (4 encodes + 4 decodes), average ms x launches: "
+                 + ", ".join(parts)))
+u = load(TAG + "_bench_under_rocprof.json")
+if u:
+    rows.append(("`%s_bench_under_rocprof.json`" % TAG, "the line bench.py printed IN that profiled run (%s MB/s): its own hipEvent figure for the roofline kernel, "
+                 "`kernel_ms_per_launch` %s, next to rocprofv3's average above" % (f(u["value"], 0), u["roofline"]["kernel_ms_per_launch"])))
+t = load("traffic.json")
+if t:
+    h = t["hbm_bytes_per_launch"]
+    top = sorted(h, key=lambda k: -h[k] * t["launches"].get(k, 1))[:7]
+    rows.append(("`traffic.json`", "HBM bytes per launch of every kernel = (2 x FETCH_SIZE + WRITE_SIZE) x 1024 (the gfx950 correction of MI355X_MICROARCH.md), the VALU / SALU / LDS wave "
+                 "instructions per launch, `SQ_WAIT_ANY / SQ_WAVE_CYCLES` and the LDS bank-conflict share, from separate `--pmc` passes.  Whole encode **%s GB**, decode %s GB; largest: %s"
+                 % (f(t.get("encode_hbm_bytes", 0) / 1e9), f(t.get("decode_hbm_bytes", 0) / 1e9),
+                    ", ".join("`%s` %s GB x %d" % (k, f(h[k] / 1e9), t["launches"].get(k, 1)) for k in top))))
+    vi = t.get("valu_wave_insts_per_launch", {})
+    wa = t.get("wait_any_over_wave_cycles", {})
+    lc = t.get("lds_conflict_over_active", {})
+    ks3 = [k for k in ("k_tokens_sorted", "k_c1_chunks", "k_match") if k in vi]
+    rows.append(("`%s_bench_pmc_summary.csv`" % TAG, "per-kernel counters per launch.  VALU wave instructions / `SQ_WAIT_ANY` share of wave time / LDS conflict share: "
+                 + "; ".join("`%s` %s M / %s / %s" % (k, f(vi[k] / 1e6, 0), wa.get(k), lc.get(k)) for k in ks3)))
+for name, what in (("_issue_rates.txt", "`tests/ubench/issue_rates.bin`: cycles a wave64 instruction occupies a SIMD at 1, 2, 4, 8 waves per SIMD (independent and dependent chains), "
+                    "`ds_read_b32` throughput and round trip, `s_barrier` in 256- and 1024-thread workgroups -- what `roofline.issue` prices the counters with"),
+                   ("_valu_rates.txt", "`tests/ubench/valu_rates.bin`: wave instructions per clock per SIMD of the VALU ops the kernels are made of"),
+                   ("_ts_probe.txt", "`bash tools/ts_probe.sh`: `SQ_INSTS_VALU` of `k_tokens_sorted` when the variants build leaves the kernel after the set-up / phase A / B1 / B2")):
+    if os.path.exists(os.path.join(P, TAG + name)):
+        rows.append(("`%s%s`" % (TAG, name), what))
+c = load(TAG + "_configs.json")
+if c:
+    rows.append(("`%s_configs.json`" % TAG, "`python tools/measure_configs.py`: " + "; ".join(
+        "%s: encode %s ms (%s GB/s), decode %s GB/s, %d gate iterations" % (x["config"].split(",")[0], f(x["encode_ms"], 1), f(x["encode_MBps"] / 1e3, 2),
+                                                                            f(x["decode_MBps"] / 1e3, 0), x["prio_iters"]) for x in c["configs"])))
+pc = load(TAG + "_prio_classes.json")
+if pc:
+    cl = [x for x in pc["classes"] if x["bytes"] == 100_000_000]
+    text = next((x for x in cl if x["kind"] == "text"), None)
+    rows.append(("`%s_prio_classes.json`" % TAG, "`python tools/prio_classes.py`: per data class at C1, 100 MB -- encode ms (x text): " + ", ".join(
+        "%s %s (%s)" % (x["kind"], f(x["encode_ms"], 1), f(x["encode_ms"] / text["encode_ms"], 2) if text else "") for x in cl)))
+k2 = kstats(TAG + "_c2_kernel_stats.csv")
+if k2:
+    top = sorted(k2, key=lambda k: -k2[k][2])[:10]
+    rows.append(("`%s_c2_kernel_stats.csv`" % TAG, "rocprofv3 kernel stats of one S3 encode (`tools/time_c2.py`), total ms: " + ", ".join("`%s` %s" % (k, f(k2[k][2], 1)) for k in top)))
+w = load(TAG + "_worst_cases.json")
+if w:
+    parts = []
+    for g, v in w["geometries"].items():
+        worst = v["worst_by_ms_per_100MB"][0] if v["worst_by_ms_per_100MB"] else None
+        parts.append("%s: %d candidates, most gate iterations %d, %d took the host fallback, worst `%s` at %s ms per 100 MB (text of the same size: %s)" % (
+            g, v["candidates"], v["max_prio_iters"], len([1 for r in v["worst_by_ms_per_100MB"] + v["worst_by_iterations"] if r.get("fell_back_to_the_host")]),
+            worst["input"] if worst else "", f(worst["ms_per_100MB"], 1) if worst else "", f(v["text_for_scale"]["ms_per_100MB"], 1)))
+    rows.append(("`%s_worst_cases.json`" % TAG, "`python tools/worst_cases.py 300`: adversarial families (periods around the lookahead and the window, cut runs, tiny alphabets, "
+                 "repeated blocks, text with planted runs) scored by gate iterations and encode ms per 100 MB.  " + "; ".join(parts)))
+hr = load(TAG + "_host_rates.json")
+if hr:
+    rows.append(("`%s_host_rates.json`" % TAG, "`python tools/host_rates.py` (host buffers, PCIe inclusive, the C calls): " + "; ".join(
+        "%d MB: encode %s GB/s, decode %s GB/s" % (x["bytes"] // 1_000_000, x["c_call_encode_GBps"], x["c_call_decode_GBps"]) for x in hr)))
+fr = load(TAG + "_file_rates.json")
+if fr:
+    rows.append(("`%s_file_rates.json`" % TAG, "`python tools/file_rates.py` (FILE* entry points inside one warm process, tmpfs): " + json.dumps(fr)[:400]))
+mp = load(TAG + "_mem_probe.json")
+if mp:
+    rows.append(("`%s_mem_probe.json`" % TAG, "`python tools/mem_probe.py`: device memory held after an encode / a decode per size and geometry (hipMemGetInfo deltas)"))
+sh = load(TAG + "_shard_fake8.json")
+if sh:
+    a = sh.get("amdahl") or {}
+    rows.append(("`%s_shard_fake8.json`" % TAG, "`LZ77X_FAKE_DEVICES=8 python bench.py --mode shard --gpus 8 --steps 2 --warmup 1` on ONE MI355X (eight contexts sharing it: `n_gpus` %s, "
+                 "`scaling_measured` %s -- no physical scaling is measured or claimed): S4 1 GB in 8 position shards, encode %s ms, decode %s ms, digest %s, %s joint gate iterations, "
+                 "`host_serial_ms` %s (%s per gate iteration); Amdahl bound from this run's serial part: %s" % (
+                     sh.get("n_gpus"), sh.get("scaling_measured"), sh.get("encode_ms"), sh.get("decode_ms"), sh.get("stream_sha_ok"), sh.get("prio_iters"),
+                     sh.get("host_serial_ms"), a.get("host_serial_ms_per_gate_iteration"), json.dumps(a.get("bound_speedup")))))
+n2 = load(TAG + "_n2_gloo_one_gpu.json")
+if n2:
+    rows.append(("`%s_n2_gloo_one_gpu.json`" % TAG, "`LZ77_BENCH_BACKEND=gloo LZ77X_FAKE_DEVICES=2 python bench.py --gpus 2 ...` with NO launcher around it: bench.py re-executes itself under "
+                 "`torch.distributed.run` with two ranks (sharing the one GPU: a plumbing check, not a scaling measurement) and prints `n_gpus` %s, %s MB/s" % (n2.get("n_gpus"), f(n2.get("value"), 0))))
+for name, what in (("_cli_trace.txt", "`bash tools/cli_trace.sh`: `LZ77X_TRACE=1 lz77 -c / -d` on 100 MB, where the wall time of a CLI run goes"),
+                   ("_rss_probe.txt", "`python tools/rss_probe.py`: peak resident set of the CLI on a 1 GB file, one device and four contexts, stretches of 1 GiB and 256 MB")):
+    if os.path.exists(os.path.join(P, TAG + name)):
+        rows.append(("`%s%s`" % (TAG, name), what))
+
+block = "<!-- r05:begin (generated by tools/profiles_readme.py from the files named in the first column) -->\n| file | what |\n|---|---|\n" + \
+        "\n".join("| %s | %s |" % (a, b_.replace("|", "/")) for a, b_ in rows) + "\n<!-- r05:end -->"
+path = os.path.join(P, "README.md")
+txt = open(path).read()
+if "<!-- r05:begin" in txt:
+    txt = re.sub(r"<!-- r05:begin.*?<!-- r05:end -->", lambda m: block, txt, flags=re.S)
+else:
+    head, sep, rest = txt.partition("| file | what |")
+    txt = head + "## Round 5\n\n`bash tools/r05_evidence.sh` (one gpurun call) writes every r05 file below; `python tools/profiles_readme.py` writes this table from them.\n\n" + block + \
+        "\n\n## Rounds 1-4 (as written then)\n\n" + sep + rest
+open(path, "w").write(txt)
+print("rows", len(rows))
