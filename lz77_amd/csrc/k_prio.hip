@@ -318,6 +318,7 @@ __global__ __launch_bounds__(64) void k_prio_fwd(const uint32_t *__restrict__ ps
     if (lane == 0 && nflip) {
         atomicAdd(&summary[0], nflip);
         atomicMin(&summary[1], b);
+        atomicMax(&summary[2], b);
     }
     if (lane == 0 && gates_changed) gates_changed[b] = nflip ? 1u : 0u;
 }
@@ -714,6 +715,7 @@ __global__ void k_prio_reset(uint32_t *summary)
 {
     summary[0] = 0;
     summary[1] = PRIO_NONE;
+    summary[2] = 0;                      /* the last block with a flip (with [1]: how wide the stretch of wrong gates is) */
 }
 
 /* ------------------------------------------------------------------ host driver ------- */
@@ -899,7 +901,7 @@ hipError_t lz77k_prio_maps(lz77k_prio_plan &P, hipStream_t s, bool whole, const 
  * the flip summary lands in h_flag (8 bytes, pinned) once the stream has drained */
 hipError_t lz77k_prio_sweep(lz77k_prio_plan &P, hipStream_t s, uint32_t *h_flag, uint32_t *d_out_state, hipEvent_t *ev3)
 {
-    if (P.nx == 0) { h_flag[0] = 0; h_flag[1] = PRIO_NONE; return hipSuccess; }
+    if (P.nx == 0) { h_flag[0] = 0; h_flag[1] = PRIO_NONE; h_flag[2] = 0; return hipSuccess; }
     const size_t lds_fwd = (size_t)P.ring_n * 4;
     const size_t lds_scan = (size_t)P.sb_r * (4 + 4 + 2 + 2);
     uint16_t *dest = PRIO_PTR(uint16_t, P.o_dest), *gdest = PRIO_PTR(uint16_t, P.o_gdest);
@@ -988,7 +990,7 @@ hipError_t lz77k_prio_sweep(lz77k_prio_plan &P, hipStream_t s, uint32_t *h_flag,
                        PRIO_PTR(uint64_t, P.o_cmask), PRIO_PTR(uint64_t, P.o_gate[P.cur]), PRIO_PTR(uint64_t, P.o_gate[P.cur ^ 1]), in, P.xval, summary, P.voff, d_out_state,
                        gates_changed, (const uint32_t *)in_changed);
     if (ev3 && (e = hipEventRecord(ev3[2], s)) != hipSuccess) return e;
-    return hipMemcpyAsync(h_flag, summary, 8, hipMemcpyDeviceToHost, s);
+    return hipMemcpyAsync(h_flag, summary, 12, hipMemcpyDeviceToHost, s);
 }
 
 /* after the stream has drained: take the sweep's gates as current.  Gates before the first flip are final
@@ -1020,8 +1022,8 @@ hipError_t lz77k_prio(const uint32_t *d_ps, uint32_t nx, int sb_i, uint32_t *d_x
     lz77k_prio_plan P;
     hipError_t e;
     if ((e = lz77k_prio_begin(P, d_ps, nx, sb_i, d_xval, d_tmp, voff, d_carried, s)) != hipSuccess) return e;
-    /* the last six iterations' flips and first flipped blocks (the front test below) */
-    uint32_t hist_f[6] = {0, 0, 0, 0, 0, 0}, hist_b[6] = {0, 0, 0, 0, 0, 0};
+    /* the last six iterations' flips and first flipped blocks (lz77x_prio_hopeless) */
+    uint64_t hist_f[6] = {0, 0, 0, 0, 0, 0}, hist_b[6] = {0, 0, 0, 0, 0, 0};
     for (int it = 0;; it++) {
         if (it >= max_iters) { *converged = 0; break; }
         if (ev4 && (e = hipEventRecord(ev4[3], s)) != hipSuccess) return e;
@@ -1040,29 +1042,20 @@ hipError_t lz77k_prio(const uint32_t *d_ps, uint32_t nx, int sb_i, uint32_t *d_x
         }
         if (P.W > 64u) lz77kw_debug_dump();
         if (getenv("LZ77X_PRIO_TRACE"))
-            fprintf(stderr, "prio it %d: B %u NB %u first %u flips %u min flipped block %u\n", it, P.B, P.NB, P.first, h_flag[0], h_flag[1]);
+            fprintf(stderr, "prio it %d: B %u NB %u first %u flips %u min flipped block %u max %u\n", it, P.B, P.NB, P.first, h_flag[0], h_flag[1], h_flag[2]);
         if (h_flag[0] == 0) break;
-        /* An error FRONT: on input that repeats with a period of about a window (a repeated random block of 4096 bytes; rows
-         * of an image) the flips fall to a few dozen within five iterations and then stay there, all of them in the first
-         * block that is not final yet -- its wrong gates make its map wrong, the next block's entry cells with it, and every
-         * iteration repairs exactly one block: NB iterations (tools/worst_cases.py found it; `prio it` traces in DESIGN 2.2d).
-         * No number of iterations the caller can afford ends that; when the last three iterations flipped as many gates
-         * as the three before them, finalised at most two blocks each, and the blocks still open outnumber twice the
-         * iterations left, give up NOW and leave the recurrence to the sequential form (the caller's fallback) instead of
-         * after max_iters sweeps of the whole input (64 x 0.8 ms per 100 MB).  Only where the caller has a fallback. */
+        /* On input that repeats with a period of about a window (a repeated random block of 4096 bytes; rows of an image) the
+         * iteration repairs a block or a few per iteration -- an error front -- or, with noise in the repeats, decays by a
+         * tenth per iteration everywhere: NB iterations, or a hundred.  When the last six iterations say that
+         * the budget will not do (lz77x_prio_hopeless), give up NOW and leave the recurrence to the sequential form (the
+         * caller's fallback) instead of after max_iters sweeps of the whole input.  Only where the caller has a budget. */
         for (int q = 0; q < 5; q++) { hist_f[q] = hist_f[q + 1]; hist_b[q] = hist_b[q + 1]; }
         hist_f[5] = h_flag[0];
         hist_b[5] = h_flag[1];
-        if (it >= 7 && max_iters < (1 << 29)) {
-            const uint64_t late = (uint64_t)hist_f[3] + hist_f[4] + hist_f[5], early = (uint64_t)hist_f[0] + hist_f[1] + hist_f[2];
-            const bool flat = late * 5 >= early * 4;
-            const bool crawling = hist_b[5] >= hist_b[2] && hist_b[5] - hist_b[2] <= 6u;
-            const uint32_t open = P.NB > hist_b[5] ? P.NB - hist_b[5] : 0u;
-            if (flat && crawling && (uint64_t)open > 2ull * (uint64_t)(max_iters - it - 1)) {
-                if (getenv("LZ77X_PRIO_TRACE")) fprintf(stderr, "prio: an error front, one block an iteration, %u blocks open: giving up after %d iterations\n", open, it + 1);
-                *converged = 0;
-                break;
-            }
+        if (lz77x_prio_hopeless(hist_f, hist_b, P.NB > h_flag[1] ? P.NB - h_flag[1] : 0u, it + 1, max_iters)) {
+            if (getenv("LZ77X_PRIO_TRACE")) fprintf(stderr, "prio: %u flips, first open block %u of %u: the budget of %d iterations will not do; giving up after %d\n", h_flag[0], h_flag[1], P.NB, max_iters, it + 1);
+            *converged = 0;
+            break;
         }
         lz77k_prio_advance(P, h_flag, false);
     }

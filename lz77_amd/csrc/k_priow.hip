@@ -747,6 +747,7 @@ __global__ __launch_bounds__(W) void k_pw_fwd(const uint32_t *__restrict__ ps, u
     if (tid == 0 && s_flip) {
         atomicAdd(&summary[0], s_flip);
         atomicMin(&summary[1], b);
+        atomicMax(&summary[2], b);
     }
 }
 

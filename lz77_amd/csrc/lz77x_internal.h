@@ -172,6 +172,35 @@ hipError_t lz77kw_compose_all(const uint16_t *d_dest, const uint32_t *d_loc, uin
 hipError_t lz77kw_scan(const uint16_t *d_dest, const uint32_t *d_loc, uint32_t *d_in, uint32_t sb, uint32_t rs, uint32_t first, uint32_t nmaps, uint32_t G,
                        uint16_t *d_gdest, uint32_t *d_gloc, uint32_t *d_gin, void *d_tmp, hipStream_t s);
 
+/* Will the gate iteration end within its budget?  f[0..5] / b[0..5]: the flips and the first block with a flip of the last
+ * six iterations (oldest first), open: blocks from there to the end, it: iterations done.  Two ways it does not (DESIGN
+ * 2.2d, tools/worst_cases.py): an error FRONT -- the flips stop decaying (a few dozen, in a band behind the first open
+ * block) and the band moves a few blocks an iteration: open / rate iterations to go --, and a slow global decay (a
+ * repeated block with noise: flips everywhere, x 0.85-0.9 an iteration): ln(flips) / -ln(rho) to go.  Classes that converge
+ * decay by 0.2-0.8 an iteration while their flips are many (text is through before six samples exist; record-structured data
+ * at C2 takes 25-31 iterations, most of them below a thousand flips). */
+static inline bool lz77x_prio_hopeless(const uint64_t f[6], const uint64_t b[6], uint64_t open, int it, int max_iters)
+{
+    if (it < 6 || max_iters >= (1 << 29)) return false;
+    const double early = (double)(f[0] + f[1] + f[2]), late = (double)(f[3] + f[4] + f[5]);
+    if (early <= 0 || late <= 0) return false;
+    const double rho = __builtin_cbrt(late / early);
+    double to_go;
+    if (rho >= 0.97) {
+        /* (a plateau of a handful of flips is also how a slow class ENDS -- record-structured data at C2: 6, 8, 9, 10, 6, 8
+         * flips, then three more iterations -- so a front only counts when it is three budgets away, not one) */
+        const double rate = b[5] > b[0] ? (double)(b[5] - b[0]) / 5.0 : 0.0;
+        to_go = (double)open / (rate > 0.2 ? rate : 0.2) / 3.0;
+    } else {
+        /* (below a thousand flips the decay is no longer geometric -- the last few hundred collapse within a handful of
+         * iterations: record-structured data at C2 went 159, 141, 98, ... to 0 in nine -- so only a decay that is slow while
+         * the flips are still many counts as hopeless) */
+        if (f[5] < 1024) return false;
+        to_go = __builtin_log((double)f[5]) / -__builtin_log(rho);
+    }
+    return (double)it + to_go > (double)max_iters;
+}
+
 hipError_t lz77k_prio_begin(lz77k_prio_plan &P, const uint32_t *d_ps, uint32_t nx, int sb, uint32_t *d_xval, void *d_tmp, uint32_t voff,
                             const uint32_t *d_carried, hipStream_t s);
 hipError_t lz77k_prio_set_in0(lz77k_prio_plan &P, const uint32_t *h_or_d_in0, hipMemcpyKind kind, hipStream_t s);

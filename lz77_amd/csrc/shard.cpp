@@ -511,10 +511,7 @@ static int encode_sharded_stretch(std::vector<Ctx *> &cs, const uint8_t *src, si
             for (int q = 0; q < 5; q++) { hist_f[q] = hist_f[q + 1]; hist_b[q] = hist_b[q + 1]; }
             hist_f[5] = flips;
             hist_b[5] = first_open;
-            const bool flat = (hist_f[3] + hist_f[4] + hist_f[5]) * 5 >= (hist_f[0] + hist_f[1] + hist_f[2]) * 4;
-            const bool crawling = hist_b[5] >= hist_b[2] && hist_b[5] - hist_b[2] <= 6;
-            if ((int)iters >= front_budget ||
-                (iters >= 8 && flat && crawling && blocks_all - first_open > 2ull * (uint64_t)(front_budget > (int)iters ? front_budget - (int)iters : 0))) {
+            if ((int)iters >= front_budget || lz77x_prio_hopeless(hist_f, hist_b, blocks_all - first_open, (int)iters, front_budget)) {
                 /* one block an iteration (input that repeats with a period of about a window): the recurrence of the whole
                  * stretch on a host core instead, shard after shard -- each shard's evictions follow its predecessor's, the
                  * cells one leaves behind are the cells the next starts from (hoststage.c lz77x_prio_run_cells) */

@@ -415,12 +415,12 @@ def test_a_segment_whose_gate_iteration_gives_up_runs_its_recurrence_on_the_host
 
 
 def test_periodic_input_in_segments_stays_bounded(monkeypatch):
-    """the error front inside the segments of a long input: two segments of 107 blocks each; round 4 iterated a block per
+    """the error front inside the segments of a long input: two segments of 140 blocks each; round 4 iterated a block per
     iteration without a bound there (16 K iterations for a segment of 2^30 positions)"""
     rng = np.random.default_rng(11)
-    n = 14_000_000
+    n = 4_600_000
     data = np.tile(rng.integers(0, 256, 4096, dtype=np.uint8), n // 4096 + 1)[:n].copy()
-    monkeypatch.setenv("LZ77X_SEGMENT", "7000000")
+    monkeypatch.setenv("LZ77X_SEGMENT", "2300000")
     z = L.encode(data)
     st = L.last_stats()
     assert z == O.encode_bst(data, 4095, 15)
@@ -608,7 +608,7 @@ def test_periodic_input_reaches_the_fallback_without_a_knob(period):
     hoststage.c) -- the only input class known to take that path with no knob set.  The stream still equals the
     reference's (tree.c:202-231 on every eviction, in order)."""
     rng = np.random.default_rng(period)
-    n = 6_300_000                                            # ~96 blocks of 64 K steps: more than the iterations left
+    n = 3_200_000                                            # ~195 blocks of 16 K steps: more than twice the iterations left
     data = np.tile(rng.integers(0, 256, period, dtype=np.uint8), n // period + 1)[:n].copy()
     z = L.encode(data)
     st = L.last_stats()
