@@ -1271,6 +1271,7 @@ __global__ __launch_bounds__(64) void k_walk(const uint16_t *__restrict__ subs, 
  * bound by the texture path (round 1); out of LDS they are bank accesses.  One workgroup per walker run; the
  * workgroup of the input's first run also answers y < sb (wb0). */
 #define WFIN_BLOCK 256
+#define WFIN_PER 8                                   /* positions per thread whose walker results are fetched ahead (runs of 2048) */
 __global__ __launch_bounds__(WFIN_BLOCK) void k_walk_final_lds(const uint8_t *__restrict__ in, uint32_t n, int sb, int la, uint32_t SBu,
                                                                uint32_t TILE, uint32_t region0, uint32_t nregions, uint32_t run_len,
                                                                uint32_t runs_per_tile, const uint16_t *__restrict__ subs,
@@ -1314,6 +1315,19 @@ __global__ __launch_bounds__(WFIN_BLOCK) void k_walk_final_lds(const uint8_t *__
         for (uint32_t i = tid * 4; i < nb; i += WFIN_BLOCK * 4)
             *reinterpret_cast<uint32_t *>(s_by + i) = *reinterpret_cast<const uint32_t *>(src + i);
     }
+    /* the walkers' answers for this thread's positions travel with the staging loads (round 5: under the loop below every
+     * iteration began with its own round trip; run_len <= WFIN_BLOCK * WFIN_PER) */
+    uint32_t fv[WFIN_PER], bv[WFIN_PER];
+    const bool pre = run_len <= WFIN_BLOCK * WFIN_PER;
+    if (pre) {
+#pragma unroll
+        for (int q = 0; q < WFIN_PER; q++) {
+            const uint32_t t = min(tid + (uint32_t)q * WFIN_BLOCK, tb - 1u);
+            const size_t rel = (size_t)reg * TILE + lo + t;
+            fv[q] = wf[rel];
+            bv[q] = wb[rel];
+        }
+    }
     __syncthreads();
     const uint32_t usb = (uint32_t)sb;
     auto longest = [&](uint32_t b, uint32_t ly /* relative to lo */) -> uint32_t {
@@ -1327,18 +1341,28 @@ __global__ __launch_bounds__(WFIN_BLOCK) void k_walk_final_lds(const uint8_t *__
         }
         return best;
     };
-    for (uint32_t t = tid; t < tb; t += WFIN_BLOCK) {
+    auto one = [&](uint32_t t, uint32_t f, uint32_t bw) {
         const uint32_t lx = lo + t, x = t0 + lx;
-        const size_t rel = (size_t)reg * TILE + lx;
         const bool evicted = (uint64_t)x + usb < n;                                /* only evicted positions matter */
-        const uint32_t f = wf[rel];
         uint32_t P = 0, S = 0;
         if (evicted) {
             if ((f & 0xFFFFu) != WALK_NONE) S = (uint32_t)s_ix[f & 0xFFFFu] - t;
             if ((f >> 16) != WALK_NONE) P = (uint32_t)s_ix[f >> 16] - t;
         }
         ps[x] = P | (S << 16);
-        if (evicted) maxlen[x + usb] = (uint8_t)longest(wb[rel], t + usb);
+        if (evicted) maxlen[x + usb] = (uint8_t)longest(bw, t + usb);
+    };
+    if (pre) {
+#pragma unroll
+        for (int q = 0; q < WFIN_PER; q++) {
+            const uint32_t t = tid + (uint32_t)q * WFIN_BLOCK;
+            if (t < tb) one(t, fv[q], bv[q]);
+        }
+    } else {
+        for (uint32_t t = tid; t < tb; t += WFIN_BLOCK) {
+            const size_t rel = (size_t)reg * TILE + lo + t;
+            one(t, wf[rel], wb[rel]);
+        }
     }
     if (region0 + reg == 0 && run == 0) {
         const uint32_t lim = min(usb, n);

@@ -73,9 +73,19 @@ __global__ __launch_bounds__(256) void k_prio_prep(const uint32_t *__restrict__ 
     for (uint32_t i = lane; i < tagn; i += 64) tag[i] = 0u;
     wave_sync();
     uint32_t ver = 1;                                     /* < 2^26: a wavefront sees at most ngroups / 8192 groups of <= 64 rounds */
-    for (uint32_t g = blockIdx.x * 4u + wave; g < ngroups; g += gridDim.x * 4u) {
+    /* the next group's neighbours travel while this one's rounds run (an unconditional, clamped load: under a branch the
+     * compiler would wait for it at once).  Until round 5 every group began with its own round trip to HBM -- two waves per
+     * SIMD hide none of it: ~2100 cycles a group where the rounds themselves take ~500, 0.66 ms per 100 MB */
+    const uint32_t gstep = gridDim.x * 4u, xlast = nx - 1u;
+    uint32_t g = blockIdx.x * 4u + wave;
+    uint32_t vnext = g < ngroups ? ps[min(g * 64u + lane, xlast)] : 0u;
+    for (; g < ngroups; g += gstep) {
         const uint32_t x = g * 64u + lane;
-        const uint32_t v = x < nx ? ps[x] : 0u;
+        const uint32_t v = x < nx ? vnext : 0u;
+        {
+            const uint32_t gn = g + gstep;
+            vnext = ps[min((gn < ngroups ? gn : g) * 64u + lane, xlast)];
+        }
         const uint32_t p = v & 0xFFFFu, s = v >> 16;
         const bool has = p && s;
         const uint32_t cp = lane + p, cs = lane + s;
