@@ -161,6 +161,31 @@ int seg_mid(SegJob &J, const lz77x_geom &g, SegCarry &carry, bool allow_fallback
         HIPCHK(hipEventRecord(c.pipe_ev[2], sc));
         J.nsub = nsub;
 
+#ifdef LZ77X_VARIANTS
+        static hipEvent_t probe_ev = nullptr;
+        bool probe_on = false;
+        if (LZ77X_VENV("LZ77X_TS_OVERLAP_PROBE") && lz77k_tokens_builds_lists(g, 0, J.d_order)) {
+            /* TIMING PROBE (wrong priorities, its token words are overwritten by the real launch later): what does the
+             * tie-break cost the recurrence, and the recurrence the tie-break, when they share the chip?   */
+            static hipStream_t probe_stream = nullptr;
+            if (!probe_ev) HIPCHK(hipEventCreateWithFlags(&probe_ev, hipEventDisableTiming));
+            if (!probe_stream) {
+                int lo = 0, hi = 0;
+                HIPCHK(hipDeviceGetStreamPriorityRange(&lo, &hi));
+                HIPCHK(hipStreamCreateWithPriority(&probe_stream, hipStreamNonBlocking, atoi(LZ77X_VENV("LZ77X_TS_OVERLAP_PROBE")) == 2 ? hi : lo));
+            }
+            HIPCHK(hipEventSynchronize(c.pipe_ev[2]));
+            const uint32_t ntok_p = h_tbase[nsub];
+            if ((rc = c.tokval.need((np + 16) * 4))) return rc;
+            if ((rc = c.tstart.need(lz77k_tokens_tmp_bytes((uint32_t)np + 2 * (uint32_t)usb + 16, g)))) return rc;
+            HIPCHK(hipStreamWaitEvent(probe_stream, c.pipe_ev[2], 0));
+            HIPCHK(lz77k_tokens(c.in.as<uint8_t>(), J.nloc, g, c.chain.as<uint32_t>(), ntok_p, c.maxlen.as<uint8_t>(), nullptr, nullptr, 0u, start, E,
+                                c.tokval.as<uint32_t>() + 4, c.tstart.as<uint32_t>(), nullptr, 0, probe_stream, nullptr, J.d_order, J.first ? nullptr : look_cur,
+                                J.nlook, 0u, c.ps.as<uint32_t>(), c.xval.as<uint32_t>(), nullptr));
+            HIPCHK(hipEventRecord(probe_ev, probe_stream));
+            probe_on = true;
+        }
+#endif
         /* -- priority recurrence (tree.c:202-231) over steps [0, nx) from the carried cells -- */
         int iters = 0, converged = 1;
         /* a sweep finalises at least one more block: it always ends.  The guard before the host loop takes over comes from
@@ -179,6 +204,9 @@ int seg_mid(SegJob &J, const lz77x_geom &g, SegCarry &carry, bool allow_fallback
         HIPCHK(lz77k_prio(c.ps.as<uint32_t>(), J.nx, g.sb, c.xval.as<uint32_t>(), c.prio_tmp.p, s, c.h_small.as<uint32_t>() + 8, max_iters,
                           &iters, &converged, &c.match_ev[4], prio_ms3, 0u, J.first ? nullptr : look_cur, J.last ? nullptr : look_next));
         HIPCHK(hipEventRecord(c.match_ev[3], s));
+#ifdef LZ77X_VARIANTS
+        if (probe_on) HIPCHK(hipStreamWaitEvent(s, probe_ev, 0));     /* the real tie-break starts when the probe's is through */
+#endif
         bool host_cells = false;
         if (!converged && !allow_fallback) {
             /* A segment of a multi-segment input whose gate iteration gave up (an error front: input that repeats with a
