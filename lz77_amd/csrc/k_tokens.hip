@@ -619,6 +619,9 @@ __device__ __forceinline__ void ts_wg_scan2(uint32_t a, uint32_t b, uint32_t *ws
  * entries, and 8 bytes an entry (slot | eviction << 16, priority).  A long run (TS_BIG cells) needs no bitmap any
  * more: its oldest member is found by walking the window's positions upwards, `inv[c]` in [lo, hi), and its hand-overs are
  * entries like everybody's. */
+#ifndef TS_SMALL
+#define TS_SMALL 8u                                                   /* a token with at most this many members and entries is settled by its own lane pair (measured: 2 2.54 ms, 4 2.48, 8 2.45; as loops with a run-time bound 8 2.53, 16 2.56, 32 2.71) */
+#endif
 #define TS_CG 16u                                                     /* slots per coarse list offset */
 
 __global__ __launch_bounds__(TS_BLOCK, 8) __attribute__((amdgpu_num_sgpr(80))) void k_tokens_sorted(const uint8_t *__restrict__ in, uint32_t n, int sb, int la, int ob, int lb,
@@ -906,11 +909,45 @@ __global__ __launch_bounds__(TS_BLOCK, 8) __attribute__((amdgpu_num_sgpr(80))) v
                 }
                 const uint32_t o_edge = (uint32_t)__shfl_xor(edge, 1, 64), o_eedge = __shfl_xor(eedge, 1, 64);
                 if (!up) {
+                    uint32_t nm = o_edge - (uint32_t)edge, ne = o_eedge - eedge;
                     tk_lo[ti] = (uint16_t)edge;
                     tk_elo[ti] = (uint16_t)eedge;
                     tk_pl[ti] = qo | (len << 16);
-                    tk_nm[ti] = (uint16_t)(o_edge - (uint32_t)edge);
-                    tk_ne[ti] = (uint16_t)(o_eedge - eedge);
+                    if (len > 0 && nm <= TS_SMALL && ne <= TS_SMALL) {
+                        /* a token with a handful of candidates (most tokens of three bytes and more) is settled right here
+                         * by the lane that found its run: dealt with the others it cost every thread whose piece it touched a
+                         * per-token prologue -- half of what B1 and B2 executed was such prologues */
+                        const uint32_t cmin = p > usb ? p - usb : 0u, wn = p - cmin;
+                        unsigned long long best = ~0ull;
+#pragma unroll
+                        for (uint32_t k = 0; k < TS_SMALL; k++) {
+                            if (k < nm) {
+                                const uint32_t c = wbase + sorted[(uint32_t)edge + k];
+                                if (c - cmin < wn) {
+                                    const uint32_t prio = c < nlook ? look[c] : c + voff;
+                                    const unsigned long long key = ((unsigned long long)prio << 32) | c;
+                                    best = key < best ? key : best;
+                                }
+                            }
+                        }
+#pragma unroll
+                        for (uint32_t k = 0; k < TS_SMALL; k++) {
+                            if (k < ne) {
+                                const uint32_t sx = ent_sx[eedge + k];
+                                const uint32_t c = wbase + sorted[sx & 0xFFFFu], x = xs0 + (sx >> 16);
+                                if (x < cmin && c - cmin < wn) {
+                                    const uint32_t v = staged ? ent_v[eedge + k] : xval[x];
+                                    const unsigned long long key = ((unsigned long long)v << 32) | c;
+                                    best = key < best ? key : best;
+                                }
+                            }
+                        }
+                        /* (its winner's cell goes where its counts would have gone: bit 15 set, no members, no entries) */
+                        nm = 0x8000u | ((uint32_t)best - wbase);
+                        ne = 0;
+                    }
+                    tk_nm[ti] = (uint16_t)nm;
+                    tk_ne[ti] = (uint16_t)ne;
                 }
             }
         }
@@ -918,13 +955,15 @@ __global__ __launch_bounds__(TS_BLOCK, 8) __attribute__((amdgpu_num_sgpr(80))) v
         /* ---- the runs laid end to end, members and entries ---- */
         {
             uint32_t nm = 0, ne = 0;
+            unsigned long long settled = ~0ull;
             if (tid < nt) { nm = tk_nm[tid]; ne = tk_ne[tid]; }
+            if (nm & 0x8000u) { settled = (unsigned long long)(wbase + (nm & 0x7FFFu)); nm = 0; }     /* settled in phase A */
             /* a big run: its oldest member in the window is found by walking the window's positions (below) */
             /* (its members stay in the count -- hi = lo + cum[ti + 1] - cum[ti] -- and B1 passes over them) */
             if (nm >= big_min && !has_look) { big[atomicAdd(&s_nbig, 1u)] = (uint16_t)tid; tk_pl[tid] |= 0x80000000u; }
             uint32_t em, ee;
             ts_wg_scan2(nm, ne, wsum, wsum2, &s_total, &s_total2, em, ee);
-            if (tid < nt) { tk_cum[tid] = em; tk_cume[tid] = ee; tk_best[tid] = ~0ull; }
+            if (tid < nt) { tk_cum[tid] = em; tk_cume[tid] = ee; tk_best[tid] = settled; }
             __syncthreads();
         }
         const uint32_t Wm = s_total, We = s_total2;
