@@ -8,6 +8,7 @@ import oracle_lib as O
 from test_gpu_fuzz import _cases, _make
 
 import random
+os.environ.setdefault("LZ77X_FAKE_DEVICES", "4")
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
 t_end = time.time() + budget
@@ -20,12 +21,23 @@ while time.time() < t_end:
         data = _make(n, alpha, mode, s)
         want = O.encode_bst(data, sb, la)
         # the encoder in one segment or a few, the decoder in one range or many (the knobs never change a byte)
-        for k in ("LZ77X_SEGMENT", "LZ77X_DECODE_RANGE", "LZ77X_DECODE_RANGE_BYTES"):
+        for k in ("LZ77X_SEGMENT", "LZ77X_DECODE_RANGE", "LZ77X_DECODE_RANGE_BYTES", "LZ77X_SHARD_STRETCH", "LZ77X_PRIO_MAX_ITERS"):
             os.environ.pop(k, None)
         if rng.random() < 0.3:
             os.environ["LZ77X_SEGMENT"] = str(rng.choice([1, 30000, 100000]))
-        got = L.encode(data, la, sb)
-        assert got == want, (seed, sb, la, n, alpha, mode, s, dict(os.environ).get("LZ77X_SEGMENT"))
+        # round 5: one stream over 2-4 contexts in stretches, and the recurrence of a segment / a stretch on a host core
+        # (the path an error front takes) now and then
+        shards = rng.choice([1, 1, 1, 2, 3, 4])
+        if shards > 1:
+            os.environ["LZ77X_SHARD_STRETCH"] = str(rng.choice([20000, 70000, 10 ** 9]))
+        if rng.random() < 0.15:
+            os.environ["LZ77X_PRIO_MAX_ITERS"] = str(rng.choice([1, 2, 7]))
+        L.lib().lz77x_set_shards(shards)
+        try:
+            got = L.encode(data, la, sb)
+        finally:
+            L.lib().lz77x_set_shards(1)
+        assert got == want, (seed, sb, la, n, alpha, mode, s, shards, {k: v for k, v in os.environ.items() if k.startswith("LZ77X_")})
         r = rng.random()
         if r < 0.3:
             os.environ["LZ77X_DECODE_RANGE"] = str(rng.choice([8, 64, 1000, 20000]))
