@@ -237,17 +237,48 @@ __device__ __forceinline__ void stage_rev(uint8_t *lby, uint32_t N, const uint8_
     }
 }
 
+/* copy s of load_key16's four (s = 1..3): byte o of it = byte o + s of the REV staging = input byte base + N - 1 - o - s; its
+ * top s bytes would be the s bytes BEFORE base: no key reads them (0xFF) */
+template <uint32_t NT>
+__device__ __forceinline__ void stage_rev_shifted(uint8_t *copy, uint32_t s, uint32_t N, const uint8_t *in, uint64_t base, uint32_t n, uint32_t tid)
+{
+    const uint64_t lim = (uint64_t)n + LZ77X_PAD;
+    for (uint32_t i = tid * 4; i < N; i += NT * 4) {
+        uint32_t v;
+        if (base + i >= s) v = base + i - s + 4 <= lim ? ld32u(in + (base + i - s)) : 0xFFFFFFFFu;
+        else {
+            v = 0;
+#pragma unroll
+            for (uint32_t q = 0; q < 4; q++) v |= (base + i + q >= s ? (uint32_t)in[base + i + q - s] : 0xFFu) << (8u * q);
+        }
+        *reinterpret_cast<uint32_t *>(copy + (N - 4u - i)) = __builtin_bswap32(v);
+    }
+}
+
 /* The merge levels compare whole 16-byte key heads held in registers (big-endian dwords, bytes past
  * `la` masked off): with a 4-byte prefix nearly every step had SOME lane of the wave tie and drag all
  * 64 through the byte-loop fallback -- neighbours in key order share long prefixes.  For la <= 16
  * (C1) a compare never touches memory again. */
 struct key16 { uint64_t hi, lo; };
 
-template <bool BYTES_LDS, bool REV = false>
+/* CS > 0 (REV only): the staged bytes exist FOUR times, copy s (at by + s * CS) shifted down by s bytes, so that the sixteen
+ * bytes of any key are four ALIGNED dwords of copy (offset & 3): two ds_read2_b32 and no funnel shifts, where one copy takes
+ * five reads and four v_alignbyte.  The chunk sort is bound by its LDS index pipe as much as by its VALU (SQ_LDS_IDX_ACTIVE
+ * 0.86 G of the launch's 1.0 G CU-cycles, 63 % of them bank conflicts of exactly these reads): a fifth fewer dwords. */
+template <bool BYTES_LDS, bool REV = false, uint32_t CS = 0>
 __device__ __forceinline__ key16 load_key16(const uint8_t *by, uint32_t a, bool valid, const uint32_t (&m)[4], uint32_t top = 0)
 {
     uint32_t k[4];
-    if constexpr (REV) {
+    if constexpr (REV && CS > 0) {
+        (void)valid;
+        const uint32_t lo = top - 12u - a;
+        const uint32_t *w = reinterpret_cast<const uint32_t *>(by + (lo & 3u) * CS + (lo & ~3u));
+        k[3] = w[0]; k[2] = w[1]; k[1] = w[2]; k[0] = w[3];
+        key16 r;
+        r.hi = (((uint64_t)k[0] << 32) | k[1]) & (((uint64_t)m[0] << 32) | m[1]);
+        r.lo = (((uint64_t)k[2] << 32) | k[3]) & (((uint64_t)m[2] << 32) | m[3]);
+        return r;
+    } else if constexpr (REV) {
         /* REV staging: every slot's bytes exist in LDS (padding slots and everything past the input read 0xFF, which sorts
          * them last like the `valid` selects of the forward form did); `a` is clamped by the caller.  k[j] = the dword at
          * offset top - a - 4j */
@@ -315,7 +346,7 @@ __device__ __forceinline__ bool sort_less16(const uint8_t *by, uint32_t a, const
 }
 
 /* v[0..16) = outputs d .. d+15 of the merge of the sorted runs A[0..L) and A[L..2L) */
-template <class IdxT, bool BYTES_LDS, bool REV = false>
+template <class IdxT, bool BYTES_LDS, bool REV = false, uint32_t CS = 0>
 __device__ __forceinline__ void merge16(const IdxT *A, uint32_t L, uint32_t d, const uint8_t *by, uint32_t R, int la,
                                         uint32_t (&v)[16], uint32_t top = 0, uint32_t slots = 0 /* REV: slots with staged bytes (an exhausted run's index is clamped to it) */)
 {
@@ -330,13 +361,13 @@ __device__ __forceinline__ void merge16(const IdxT *A, uint32_t L, uint32_t d, c
     while (lo < hi) {                                        /* merge path: how many of the first d outputs come from A */
         const uint32_t mid = (lo + hi) >> 1;
         const uint32_t a = A[mid], b = B[d - 1 - mid];
-        const key16 ka = load_key16<BYTES_LDS, REV>(by, a, a < R, m, top), kb = load_key16<BYTES_LDS, REV>(by, b, b < R, m, top);
+        const key16 ka = load_key16<BYTES_LDS, REV, CS>(by, a, a < R, m, top), kb = load_key16<BYTES_LDS, REV, CS>(by, b, b < R, m, top);
         if (sort_less16<BYTES_LDS, REV>(by, a, ka, b, kb, R, la, top)) lo = mid + 1; else hi = mid;
     }
     uint32_t ia = lo, ib = d - lo;
     bool va = ia < L, vb = ib < L;
     uint32_t a = va ? (uint32_t)A[ia] : 0xFFFFFFFFu, b = vb ? (uint32_t)B[ib] : 0xFFFFFFFFu;
-    key16 ka = load_key16<BYTES_LDS, REV>(by, REV ? min(a, slots) : a, a < R, m, top), kb = load_key16<BYTES_LDS, REV>(by, REV ? min(b, slots) : b, b < R, m, top);
+    key16 ka = load_key16<BYTES_LDS, REV, CS>(by, REV ? min(a, slots) : a, a < R, m, top), kb = load_key16<BYTES_LDS, REV, CS>(by, REV ? min(b, slots) : b, b < R, m, top);
 #pragma unroll
     for (int r = 0; r < 16; r++) {
         const bool take_a = !vb || (va && sort_less16<BYTES_LDS, REV>(by, a, ka, b, kb, R, la, top));
@@ -347,7 +378,7 @@ __device__ __forceinline__ void merge16(const IdxT *A, uint32_t L, uint32_t d, c
         const uint32_t pos = take_a ? ia : L + ib;
         const bool valid = (take_a ? ia : ib) < L;
         const uint32_t nv = valid ? (uint32_t)A[pos] : 0xFFFFFFFFu;
-        const key16 nk = load_key16<BYTES_LDS, REV>(by, REV ? min(nv, slots) : nv, nv < R, m, top);
+        const key16 nk = load_key16<BYTES_LDS, REV, CS>(by, REV ? min(nv, slots) : nv, nv < R, m, top);
         if (take_a) { a = nv; ka = nk; va = valid; } else { b = nv; kb = nk; vb = valid; }
     }
 }
@@ -405,7 +436,7 @@ __device__ __forceinline__ void merge_run_global(const uint32_t *A, uint32_t L, 
  * (key, index) is a strict total order, so the merge path is unique.  O(CH log CH) key compares
  * instead of the bitonic network's O(CH log^2 CH): ~3.5x fewer random LDS reads per region.
  */
-template <class IdxT, bool BYTES_LDS, uint32_t NT = MATCH_BLOCK, bool REV = false>
+template <class IdxT, bool BYTES_LDS, uint32_t NT = MATCH_BLOCK, bool REV = false, uint32_t CS = 0>
 __device__ __forceinline__ void region_sort_merge(IdxT *ix, const uint8_t *by, uint32_t R, int la, uint32_t tid,
                                                   uint32_t L_first = 0 /* > 0: ix[] already holds sorted runs of L_first slots */,
                                                   uint32_t top = 0 /* REV: offset of the dword that holds the bytes 0..3 (be32_at) */)
@@ -497,7 +528,7 @@ __device__ __forceinline__ void region_sort_merge(IdxT *ix, const uint8_t *by, u
         const bool wide = 2 * L > 1024;
         barrier(wide);
         const uint32_t o0 = 16 * tid, base = o0 & ~(2 * L - 1);
-        merge16<IdxT, BYTES_LDS, REV>(ix + base, L, o0 - base, by, R, la, v, top, CH - 1u);
+        merge16<IdxT, BYTES_LDS, REV, CS>(ix + base, L, o0 - base, by, R, la, v, top, CH - 1u);
         barrier(wide);
         store_mine();
     }
@@ -513,20 +544,25 @@ __device__ __forceinline__ void region_sort_merge(IdxT *ix, const uint8_t *by, u
  * instead of 4/3x the data. */
 #define C1_CH 4096u
 #define C1_BLOCK 256
+#define C1_CS (C1_CH + 256 + 32)                     /* bytes between the four copies of a chunk's staged bytes */
 
 __global__ __launch_bounds__(C1_BLOCK) __attribute__((amdgpu_num_sgpr(80), amdgpu_waves_per_eu(6, 6))) void k_c1_chunks(const uint8_t *__restrict__ in, uint32_t n, int la, uint64_t pos0,
                                                        uint16_t *__restrict__ out)
 {
     __shared__ __attribute__((aligned(16))) uint16_t ix[C1_CH];
-    __shared__ __attribute__((aligned(16))) uint8_t lby[C1_CH + 256 + 32];
+    __shared__ __attribute__((aligned(16))) uint8_t lby[4 * C1_CS];    /* the REV staging and its three shifted copies (load_key16) */
     const uint32_t tid = threadIdx.x;
     const uint64_t base = pos0 + (uint64_t)blockIdx.x * C1_CH;
     const uint32_t Rl = base >= n ? 0u : (n - (uint32_t)base < C1_CH ? n - (uint32_t)base : C1_CH);
     constexpr uint32_t NB = C1_CH + 256 + 24;             /* every slot's key: 4096 positions + la <= 255 + the key loads' slack */
-    if (Rl) stage_rev<C1_BLOCK>(lby, NB, in, base, n, tid);
+    if (Rl) {
+        stage_rev<C1_BLOCK>(lby, NB, in, base, n, tid);
+#pragma unroll
+        for (uint32_t sft = 1; sft < 4; sft++) stage_rev_shifted<C1_BLOCK>(lby + sft * C1_CS, sft, NB, in, base, n, tid);
+    }
     for (uint32_t i = tid; i < C1_CH; i += C1_BLOCK) ix[i] = (uint16_t)i;
     __syncthreads();
-    if (Rl) region_sort_merge<uint16_t, true, C1_BLOCK, true>(ix, lby, Rl, la, tid, 0, NB - 4u);
+    if (Rl) region_sort_merge<uint16_t, true, C1_BLOCK, true, C1_CS>(ix, lby, Rl, la, tid, 0, NB - 4u);
     uint16_t *o = out + (size_t)blockIdx.x * C1_CH;
     for (uint32_t e = tid * 8; e < C1_CH; e += C1_BLOCK * 8) *reinterpret_cast<uint4 *>(o + e) = *reinterpret_cast<const uint4 *>(ix + e);
 }
