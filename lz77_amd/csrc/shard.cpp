@@ -109,10 +109,25 @@ int decode_sharded(std::vector<Ctx *> &cs, const uint8_t *z, size_t zn, uint8_t 
     lz77x_make_geom(&g, sb, la);
     if (g.T > 32) return LZ77X_E_FORMAT;
     const uint64_t ntok64 = ((uint64_t)zn * 8 - 32) / (uint64_t)g.T;
-    if (ntok64 > LZ77X_MAX_N) return LZ77X_OK;                                  /* (the range decoder takes any length on one device) */
-    const uint32_t ntok = (uint32_t)ntok64;
     const size_t D = cs.size();
-    if (la > 255 || LZ77X_VENV("LZ77X_DECODE_V1") || ntok < 64 * D) return LZ77X_OK;
+    if (la > 255 || LZ77X_VENV("LZ77X_DECODE_V1") || ntok64 < 64 * D) return LZ77X_OK;
+    /* Round 5: a stream of any length, in STRETCHES of tokens (a multiple of eight: a stretch starts on a byte of the stream),
+     * every stretch cut over all the devices.  What a stretch needs from everything before it is the last sb bytes of the
+     * output -- the incoming bytes of its first shard, where the first stretch has zeros (lz77.c:172-192: a copy reaches at
+     * most sb back).  Offsets inside a shard are 32-bit, so a shard takes at most 0xF0000000 / (la + 1) tokens. */
+    uint64_t stretch_tok = (uint64_t)D * (((uint64_t)0xF0000000u / (uint64_t)(la + 1)) & ~(uint64_t)7);
+    if (const char *e = getenv("LZ77X_DECODE_SHARD_STRETCH")) if (atoll(e) > 0) stretch_tok = ((uint64_t)atoll(e) + 7) & ~(uint64_t)7;
+    if (stretch_tok < 64 * D) stretch_tok = (64 * D + 7) & ~(size_t)7;
+    uint8_t *buf = nullptr;                                  /* the whole output, grown stretch by stretch */
+    size_t buf_cap = 0;
+    uint64_t n_done = 0;
+    std::vector<uint8_t> carry_in((size_t)sb, 0);            /* the sb bytes before the stretch (zeros before the first) */
+    struct BufGuard { uint8_t **p; bool keep = false; ~BufGuard() { if (!keep) { free(*p); *p = nullptr; } } } guard{&buf};
+    for (uint64_t T0 = 0; T0 < ntok64;) {
+    uint64_t T1 = T0 + stretch_tok < ntok64 ? T0 + stretch_tok : ntok64;
+    if (ntok64 - T1 < 64 * D) T1 = ntok64;                   /* (no tail too short to cut) */
+    const uint32_t ntok = (uint32_t)(T1 - T0);
+    const uint8_t *zs = z + (size_t)(T0 / 8) * (size_t)g.T;  /* the stretch's tokens begin at zs + 4 */
     /* windows the segment walk takes (sb <= 8192): symbolic tails per segment; above: the tile pass on [history | output]
      * with the history still unknown (lz77k_dec_tail_map) */
     const bool tiles = !lz77k_dec_seg_supported(g) || LZ77X_VENV("LZ77X_DECODE_VARIANT");
@@ -131,13 +146,14 @@ int decode_sharded(std::vector<Ctx *> &cs, const uint8_t *z, size_t zn, uint8_t 
         Sh &S = sh[d];
         S.ntok = k0[d + 1] - k0[d];
         const size_t b0 = 4 + (size_t)k0[d] * g.T / 8, b1 = 4 + ((size_t)k0[d + 1] * g.T + 7) / 8;      /* k0 is a multiple of 8: b0 exact */
+
         const size_t zb = 4 + (b1 - b0);
         if ((rc = c.z.need(zb + 32))) return rc;
         if ((rc = c.h_small.need(128))) return rc;
         HIPCHK(hipMemsetAsync(c.z.as<uint8_t>() + zb, 0, 32, s));
         HIPCHK(hipMemcpyAsync(c.z.p, z, 4, hipMemcpyHostToDevice, s));
         HIPCHK(hipStreamSynchronize(s));
-        if ((rc = upload_pageable(c, c.z.as<uint8_t>() + 4, z + b0, b1 - b0))) return rc;
+        if ((rc = upload_pageable(c, c.z.as<uint8_t>() + 4, zs + b0, b1 - b0))) return rc;       /* (zs: this stretch's part of the stream) */
         if ((rc = c.tokval.need(((size_t)S.ntok + 8) * 4))) return rc;
         if ((rc = c.len1.need(((size_t)S.ntok + 8) * 4))) return rc;
         if ((rc = c.dst.need(((size_t)S.ntok + 8) * 4))) return rc;
@@ -168,8 +184,15 @@ int decode_sharded(std::vector<Ctx *> &cs, const uint8_t *z, size_t zn, uint8_t 
         o0[d + 1] = o0[d] + nd;
     }
     n = o0[D];
-    if (!fits || n > LZ77X_MAX_N) { HIPCHK(hipSetDevice(cs[0]->device)); return LZ77X_OK; }
-    uint8_t *buf = nullptr;
+    if (!fits) { HIPCHK(hipSetDevice(cs[0]->device)); return LZ77X_OK; }        /* (what the stretches before produced is dropped: one device) */
+    if (n_done + n > buf_cap) {
+        size_t ncap = buf_cap ? buf_cap : (size_t)1 << 20;
+        while (ncap < n_done + n) ncap += ncap / 2 + ((size_t)64 << 20);
+        uint8_t *nb = (uint8_t *)realloc(buf, ncap);
+        if (!nb) return LZ77X_E_NOMEM;
+        buf = nb;
+        buf_cap = ncap;
+    }
     const uint32_t pre = tiles ? (uint32_t)((usb + LZ77K_DEC_TILE_BYTES - 1) / LZ77K_DEC_TILE_BYTES * LZ77K_DEC_TILE_BYTES) : 0u;
     std::vector<const unsigned long long *> d_unres(D, nullptr);
     if (tiles) {
@@ -216,11 +239,11 @@ int decode_sharded(std::vector<Ctx *> &cs, const uint8_t *z, size_t zn, uint8_t 
         });
         if (rc) return rc;
         /* 3t. the host chains the maps (nothing lies before the first shard: zeros) */
-        std::vector<std::vector<uint8_t>> incoming(D, std::vector<uint8_t>(usb, 0));
-        for (size_t d = 0; d + 1 < D; d++) lz77x_shard_compose_tail32(tmap[d].data(), sb, incoming[d].data(), incoming[d + 1].data());
+        std::vector<std::vector<uint8_t>> incoming(D + 1, std::vector<uint8_t>(usb, 0));
+        incoming[0] = carry_in;
+        for (size_t d = 0; d < D; d++) lz77x_shard_compose_tail32(tmap[d].data(), sb, incoming[d].data(), incoming[d + 1].data());
+        carry_in = incoming[D];                              /* the next stretch's history */
         /* 4t. every shard: its history in, the bytes that point somewhere gathered */
-        buf = (uint8_t *)malloc(n ? (size_t)n : 1);
-        if (!buf) return LZ77X_E_NOMEM;
         for (size_t d = 0; d < D; d++) {
             Ctx &c = *cs[d];
             hipError_t e = hipSetDevice(c.device);
@@ -228,7 +251,7 @@ int decode_sharded(std::vector<Ctx *> &cs, const uint8_t *z, size_t zn, uint8_t 
             if (e == hipSuccess) e = hipMemcpyAsync(X + pre - usb, incoming[d].data(), usb, hipMemcpyHostToDevice, c.stream);
             if (e == hipSuccess) e = hipStreamSynchronize(c.stream);                 /* (incoming[] is pageable) */
             if (e == hipSuccess) e = lz77k_dec_gather2(X, c.ptr.as<uint32_t>(), d_unres[d], pre + sh[d].n, c.stream);
-            if (e != hipSuccess) { free(buf); snprintf(g_err, sizeof g_err, "HIP: %s", hipGetErrorString(e)); return LZ77X_E_HIP; }
+            if (e != hipSuccess) { snprintf(g_err, sizeof g_err, "HIP: %s", hipGetErrorString(e)); return LZ77X_E_HIP; }
         }
     } else {
     /* 2. every shard: segment walk, tails composed into the shard's map */
@@ -246,39 +269,45 @@ int decode_sharded(std::vector<Ctx *> &cs, const uint8_t *z, size_t zn, uint8_t 
     }
     /* 3. the host chains the maps: incoming bytes of every shard (nothing lies before the first: zero bytes, what a
      *    copy from before the start of the output reads in the single-device decoder too) */
-    std::vector<std::vector<uint8_t>> incoming(D, std::vector<uint8_t>(usb, 0));
-    for (size_t d = 0; d + 1 < D; d++) {
+    std::vector<std::vector<uint8_t>> incoming(D + 1, std::vector<uint8_t>(usb, 0));
+    incoming[0] = carry_in;
+    for (size_t d = 0; d < D; d++) {
         Ctx &c = *cs[d];
         HIPCHK(hipSetDevice(c.device));
         HIPCHK(hipStreamSynchronize(c.stream));
         lz77x_shard_compose_tail(smap[d].data(), sb, incoming[d].data(), incoming[d + 1].data());
     }
+    carry_in = incoming[D];                                  /* the next stretch's history */
     /* 4. every shard: incoming bytes in, tails resolved, flagged bytes patched, output to the host */
-    buf = (uint8_t *)malloc(n ? (size_t)n : 1);
-    if (!buf) return LZ77X_E_NOMEM;
     for (size_t d = 0; d < D; d++) {
         Ctx &c = *cs[d];
         hipError_t e = hipSetDevice(c.device);
         if (e == hipSuccess) e = hipMemcpyAsync(sh[d].P.tres0, incoming[d].data(), usb, hipMemcpyHostToDevice, c.stream);
         if (e == hipSuccess) e = lz77k_dec_segments_back(g, c.out.as<uint8_t>(), c.ptr.p, sh[d].n, sh[d].P, c.stream);
-        if (e != hipSuccess) { free(buf); snprintf(g_err, sizeof g_err, "HIP: %s", hipGetErrorString(e)); return LZ77X_E_HIP; }
+        if (e != hipSuccess) { snprintf(g_err, sizeof g_err, "HIP: %s", hipGetErrorString(e)); return LZ77X_E_HIP; }
     }
     }
     rc = for_each_shard(D, [&](size_t d) -> int {           /* the gather: every device fetches its bytes at once */
         Ctx &c = *cs[d];
         HIPCHK(hipSetDevice(c.device));
         HIPCHK(hipStreamSynchronize(c.stream));
-        return fetch_result(c, buf + o0[d], c.out.as<uint8_t>() + pre, sh[d].n);
+        return fetch_result(c, buf + n_done + o0[d], c.out.as<uint8_t>() + pre, sh[d].n);
     });
-    if (rc) { free(buf); return rc; }
+    if (rc) return rc;
+    n_done += n;
+    T0 = T1;
+    }   /* stretches */
     HIPCHK(hipSetDevice(cs[0]->device));
     memset(&g_stats, 0, sizeof g_stats);
-    g_stats.n = n;
+    g_stats.n = n_done;
     g_stats.zn = zn;
-    g_stats.ntok = ntok;
+    g_stats.ntok = ntok64;
     g_stats.total_ms = now_ms() - t_begin;
+    if (!buf) buf = (uint8_t *)malloc(1);
+    if (!buf) return LZ77X_E_NOMEM;
+    guard.keep = true;
     *out = buf;
-    *out_n = (size_t)n;
+    *out_n = (size_t)n_done;
     *handled = 1;
     return LZ77X_OK;
 }

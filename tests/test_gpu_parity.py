@@ -290,7 +290,8 @@ def test_sharded_error_front_goes_to_the_host(kind, seed, n, sb, la, stretch, mo
                                               ("zeros", 0, 300_000, 4095, 15), ("records", 95, 900_000, 255, 7),
                                               ("mixed", 96, 2_500_000, 65535, 255), ("text", 97, 1_500_000, 20000, 40),
                                               ("lowent", 98, 1_200_000, 8193, 255)])
-def test_sharded_decode_gives_identical_bytes(kind, seed, n, sb, la, monkeypatch):
+@pytest.mark.parametrize("stretch", ["", "40000"])
+def test_sharded_decode_gives_identical_bytes(kind, seed, n, sb, la, stretch, monkeypatch):
     """SURVEY 8e, decode side: the tokens cut into 2/3/4/8 ranges (one device context each, sharing the test box's GPU),
     every range decoded with the sb bytes before it as symbolic references, the shards' maps chained on the host
     (lz77.c:172-192 across the cuts): the same bytes as the reference's decoder; small decode segments so that a
@@ -299,8 +300,13 @@ def test_sharded_decode_gives_identical_bytes(kind, seed, n, sb, la, monkeypatch
     z = O.encode_bst(data, sb, la)
     monkeypatch.setenv("LZ77X_FAKE_DEVICES", "8")
     monkeypatch.setenv("LZ77X_DECODE_SEGMENT", "65536")
+    if stretch:
+        # round 5: the stream in stretches of tokens, every stretch over all the contexts, the last sb bytes of one the
+        # history of the next (a stream of 4 GiB and more takes this way with stretches of 0xF0000000 / (la + 1) tokens a shard)
+        # (a shard shorter than a window decodes on one device: large windows get stretches of six windows and two shards)
+        monkeypatch.setenv("LZ77X_DECODE_SHARD_STRETCH", stretch if sb <= 8192 else str(6 * sb))
     try:
-        for shards in (2, 3, 4, 8):
+        for shards in ((2, 3, 4, 8) if not stretch or sb <= 8192 else (2,)):
             assert L.lib().lz77x_set_shards(shards) == 0
             assert L.decode(z) == data.tobytes(), shards
             assert L.last_stats()["k_decode_ms"] == 0, "the single-device decoder ran"
