@@ -91,9 +91,9 @@ int lz77x_decode_file(FILE *in, FILE *out);
  * bytes are identical for every shard count.  lz77x_encode / lz77x_encode_file cut the input by
  * positions -- an input of any length in stretches of at most 4 GiB, every stretch over all the devices, the file
  * entry point holding one stretch in host memory --, lz77x_decode cuts the stream by token ranges (the sb bytes before a range reach it
- * as a map chained on the host; lz77.c:172-192 across the cuts); streams it cannot cut that way
- * (distance-0 copies of a power-of-two -s, shards shorter than a window, streams of 4 GiB and more) decode on one
- * device, range by range. */
+ * as a map chained on the host; lz77.c:172-192 across the cuts), a long stream in stretches of tokens, every stretch
+ * over all the devices; streams it cannot cut that way (distance-0 copies of a power-of-two -s, shards shorter than a
+ * window) decode on one device, range by range. */
 int lz77x_set_shards(int shards);
 int lz77x_device_count(void);
 /* Release every cached device/pinned buffer, stream and event (they are otherwise kept for the

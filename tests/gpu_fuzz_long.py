@@ -43,9 +43,18 @@ while time.time() < t_end:
             os.environ["LZ77X_DECODE_RANGE"] = str(rng.choice([8, 64, 1000, 20000]))
         elif r < 0.45:
             os.environ["LZ77X_DECODE_RANGE_BYTES"] = str(rng.choice([3000, 40000]))
-        dec = L.decode(want)
+        # round 5: the decoder over 2-4 contexts too, in stretches of tokens now and then
+        dshards = rng.choice([1, 1, 2, 3, 4])
+        os.environ.pop("LZ77X_DECODE_SHARD_STRETCH", None)
+        if dshards > 1 and rng.random() < 0.5:
+            os.environ["LZ77X_DECODE_SHARD_STRETCH"] = str(rng.choice([4000, 30000]))
+        L.lib().lz77x_set_shards(dshards)
+        try:
+            dec = L.decode(want)
+        finally:
+            L.lib().lz77x_set_shards(1)
         assert dec == (data.tobytes() if sb & (sb - 1) else O.decode(want)), (seed, sb, la, n, alpha, mode, s, os.environ.get("LZ77X_DECODE_RANGE"),
-                                                                             os.environ.get("LZ77X_DECODE_RANGE_BYTES"))
+                                                                             os.environ.get("LZ77X_DECODE_RANGE_BYTES"), dshards, os.environ.get("LZ77X_DECODE_SHARD_STRETCH"))
         runs += 1
     seed += 1
 print("fuzz ok: %d cases, seeds up to %d" % (runs, seed - 1))
