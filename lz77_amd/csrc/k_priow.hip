@@ -24,9 +24,11 @@
  */
 #include "kernels_common.h"
 #include <stdio.h>
+#include <type_traits>
 
 #define PW_NONE 0xFFFFFFFFu
 #define PW_DEAD 0xFFFFu
+#define PW_RANK0 0xFFFFFFFEu             /* k_pw_fwd: xval marker of old rank r = PW_RANK0 - r, until the block's last pass */
 #define PW_SORT_CAP 32768u              /* keys sorted per pass of the rank prologue (128 KB of LDS) */
 
 /* LZ77X_PW_DEBUG=1: cycle stamps of workgroup 0 of the last back / fwd / prep launch (development aid) */
@@ -323,6 +325,15 @@ template <> struct pw_ring<true> {
     }
 };
 
+/* the plane word of sixteen consecutive codes c0 .. c0 + 15: their bits 16-17 change at most once, at the multiple of 2^16 */
+__device__ __forceinline__ uint32_t pw_plane_word(uint32_t c0)
+{
+    const uint32_t h0 = (c0 >> 16) & 3u, t16 = 0x10000u - (c0 & 0xFFFFu);
+    uint32_t hw = h0 * 0x55555555u;
+    if (t16 < 16u) hw ^= (((h0 ^ (h0 + 1u)) & 3u) * 0x55555555u) & ~((1u << (2u * t16)) - 1u);
+    return hw;
+}
+
 /* exclusive prefix of one value per thread over the workgroup (W threads); *total = the sum.  Two barriers. */
 template <int W>
 __device__ __forceinline__ uint32_t pw_block_excl(uint32_t v, uint32_t *s_w /* W/64 + 1 words */, uint32_t *total)
@@ -380,15 +391,44 @@ __global__ __launch_bounds__(W) void k_pw_fwd(const uint32_t *__restrict__ ps, u
     if (tid == 0) s_flip = 0;
     const uint32_t *inb = in + (size_t)b * rs;
     PW_STAMP(8);
+    /* PACK: entry i = q*W + tid lives in a register from the one coalesced read of the row to the ring */
+    constexpr uint32_t EPT = PACK ? 65536u / W : 1u;        /* entries per thread, at most (sb <= 65535) */
+    uint32_t val[EPT];
+    if constexpr (PACK) {
+#pragma unroll
+        for (uint32_t q = 0; q < EPT; q++) { uint32_t tq = tid; asm volatile("" : "+v"(tq)); val[q] = inb[min(q * W + tq, sb - 1u)]; }
+    }
     {
         /* the sweep is a function of the entry cells alone: the same cells as last time give the same xval[] and the gates
          * the maps of this iteration were built from -- nothing to do, no flip.  (The tail iterations change the cells
-         * of a fraction of the blocks.) */
+         * of a fraction of the blocks.)  Rows of loads in flight at a time: one load, one compare, one store at a time
+         * was 64 round trips to HBM in a row, 130 K of a block's 1.2 M cycles -- and all there is to a skipped block. */
         uint32_t *pb = in_prev + (size_t)b * rs;
         bool diff = !have_prev;
-        for (uint32_t i = tid; i < sb; i += W) {
-            const uint32_t a = inb[i];
-            if (a != pb[i]) { diff = true; pb[i] = a; }
+        if constexpr (PACK) {
+            constexpr uint32_t CB = 16;
+#pragma unroll
+            for (uint32_t q0 = 0; q0 < EPT; q0 += CB) {
+                uint32_t pv[CB];
+#pragma unroll
+                for (uint32_t k = 0; k < CB; k++) { uint32_t tq = tid; asm volatile("" : "+v"(tq)); pv[k] = pb[min((q0 + k) * W + tq, sb - 1u)]; }
+#pragma unroll
+                for (uint32_t k = 0; k < CB; k++) {
+                    uint32_t tq = tid; asm volatile("" : "+v"(tq)); const uint32_t i = (q0 + k) * W + tq;
+                    if (i < sb && val[q0 + k] != pv[k]) { diff = true; pb[i] = val[q0 + k]; }
+                }
+            }
+        } else {
+            for (uint32_t i0 = tid; i0 < sb; i0 += 8u * W) {
+                uint32_t a[8], pv[8];
+#pragma unroll
+                for (uint32_t j = 0; j < 8; j++) { const uint32_t i = min(i0 + j * W, sb - 1u); a[j] = inb[i]; pv[j] = pb[i]; }
+#pragma unroll
+                for (uint32_t j = 0; j < 8; j++) {
+                    const uint32_t i = i0 + j * W;
+                    if (i < sb && a[j] != pv[j]) { diff = true; pb[i] = a[j]; }
+                }
+            }
         }
         if (!__syncthreads_or(diff) && !(out_state && x1 == nx)) {
             for (uint32_t i = tid; i < (x1 - x0 + 63u) / 64u; i += W) gnew[(x0 >> 6) + i] = gold[(x0 >> 6) + i];
@@ -405,7 +445,6 @@ __global__ __launch_bounds__(W) void k_pw_fwd(const uint32_t *__restrict__ ps, u
          *      the pass is the number of set bits below its own (word popcounts, two levels of prefix sums).  The few
          *      that lie further back (priorities are handed down for ever) are sorted.  A bitonic sort of all old values
          *      (19 K of the 65535 on the S3 stream) took 300 us per block, twice the sweep proper. ---- */
-        constexpr uint32_t EPT = 65536u / W;                /* entries per thread, at most (sb <= 65535) */
         constexpr uint32_t BM_WORDS = 24576u, BM_BITS = BM_WORDS * 32u;     /* D = 786432 = 3 << 18 positions: 96 KB */
         constexpr uint32_t NPASS = 6u;                      /* 4.7 M positions back; beyond: the sorted tail */
         constexpr uint32_t NCO = BM_BITS / 1024u;           /* coarse prefix entries (1024 bits each) */
@@ -416,51 +455,59 @@ __global__ __launch_bounds__(W) void k_pw_fwd(const uint32_t *__restrict__ ps, u
         uint32_t *cb = codes + (size_t)b * rs, *gv = gval + (size_t)b * rs;
         const bool all_old = b == 0 && ncarried != 0;       /* carried cells hold ranks of their own: none is "its own position" */
         const uint32_t hi = all_old ? sb : x0 + voff;       /* every old value is below hi */
-        const uint64_t lt = (1ull << lane) - 1ull;
         __shared__ uint32_t s_cls[NPASS + 2];               /* old values per pass; [NPASS] the tail */
-        uint32_t val[EPT];
-#pragma unroll
-        for (uint32_t q = 0; q < EPT; q++) { uint32_t tq = tid; asm volatile("" : "+v"(tq)); val[q] = inb[min(q * W + tq, sb - 1u)]; }
         if (tid < NPASS + 2) s_cls[tid] = 0;
         __syncthreads();
-        /* class of an entry: its bitmap pass, NPASS = tail, 7 = not old / beyond the row */
-        uint64_t oldm = 0;                                  /* bit q: entry q is old and has no rank yet */
-        uint64_t old0 = 0;                                  /* bit q: entry q is old */
-        uint32_t mycnt[NPASS];
-#pragma unroll
-        for (uint32_t r = 0; r < NPASS; r++) mycnt[r] = 0;
+        /* class of an entry: its bitmap pass, NPASS = tail, 7 = not old / beyond the row.  Counted in eight 8-bit fields
+         * of one 64-bit word per thread (at most 64 entries a class) -- six compare-and-add pairs and a ballot with a
+         * branch per entry made this loop 125 instructions an entry, 160 K of a block's 950 K cycles. */
+        uint32_t c03 = 0, c47 = 0, olo = 0, ohi = 0;
 #pragma unroll
         for (uint32_t q = 0; q < EPT; q++) {
             uint32_t tq = tid; asm volatile("" : "+v"(tq)); const uint32_t i = q * W + tq;
             const uint32_t v = val[q];
             const bool old = i < sb && (all_old || v != x0 + i + voff);
             const uint32_t u = hi - 1u - v;
-            const uint32_t r = old ? (u >> 18) / 3u : 7u;
-            if (old) { oldm |= 1ull << q; old0 |= 1ull << q; }
+            const uint32_t r = old ? min((u >> 18) / 3u, NPASS) : 7u;
+            const uint32_t inc = 1u << (8u * (r & 3u));
+            c03 += r < 4u ? inc : 0u;
+            c47 += r < 4u ? 0u : inc;
+            if (q < 32) olo |= old ? 1u << (q & 31u) : 0u;
+            else ohi |= old ? 1u << (q & 31u) : 0u;
+            asm volatile("" : "+v"(c03), "+v"(c47), "+v"(olo), "+v"(ohi));     /* (a chain, not a tree of 64 live terms) */
+        }
+        uint64_t oldm = ((uint64_t)ohi << 32) | olo;        /* bit q: entry q is old and has no rank yet */
+        const uint64_t cnt = ((uint64_t)c47 << 32) | c03;
+        const uint64_t old0 = oldm;                         /* bit q: entry q is old */
+        {
+            /* per wavefront: 16-bit fields (64 lanes x 64 entries), classes 0 2 4 6 and 1 3 5 7 */
+            uint64_t ce = cnt & 0x00FF00FF00FF00FFull, co = (cnt >> 8) & 0x00FF00FF00FF00FFull;
 #pragma unroll
-            for (uint32_t k = 0; k < NPASS; k++) mycnt[k] += r == k ? 1u : 0u;
-            /* tail values go straight into the sort buffer (any order does) */
-            const bool tail = old && r >= NPASS;
-            const uint64_t bmk = __ballot(tail);
-            if (bmk) {
-                uint32_t base = 0;
-                if (lane == (uint32_t)__builtin_ctzll(bmk)) base = atomicAdd(&s_cls[NPASS], (uint32_t)__popcll(bmk));
-                base = (uint32_t)__shfl((int)base, __builtin_ctzll(bmk), 64);
-                const uint32_t slot = base + (uint32_t)__popcll(bmk & lt);
-                if (tail) {
-                    if (slot < sort_cap) skey[slot] = v;
-                    cb[i] = slot;                           /* only read back when the tail needs several passes */
-                }
+            for (int d = 32; d >= 1; d >>= 1) {
+                ce += (uint64_t)__shfl_xor((unsigned long long)ce, d, 64);
+                co += (uint64_t)__shfl_xor((unsigned long long)co, d, 64);
+            }
+            if (lane <= NPASS) {
+                const uint32_t t = (uint32_t)(((lane & 1u) ? co : ce) >> (16u * (lane >> 1))) & 0xFFFFu;
+                if (t) atomicAdd(&s_cls[lane], t);
             }
         }
-#pragma unroll
-        for (uint32_t k = 0; k < NPASS; k++) {
-            uint32_t t = mycnt[k];
-#pragma unroll
-            for (int d = 32; d >= 1; d >>= 1) t += (uint32_t)__shfl_xor((int)t, d, 64);
-            if (lane == 0 && t) atomicAdd(&s_cls[k], t);
-        }
         __syncthreads();
+        if (s_cls[NPASS]) {
+            /* tail values into the sort buffer (any order does): rare -- priorities handed down for more than 4.7 M positions */
+            uint32_t tot;
+            uint32_t slot = pw_block_excl<W>((uint32_t)(cnt >> (8u * NPASS)) & 0xFFu, s_w, &tot);
+#pragma unroll
+            for (uint32_t q = 0; q < EPT; q++) {
+                uint32_t tq = tid; asm volatile("" : "+v"(tq)); const uint32_t i = q * W + tq;
+                if (((oldm >> q) & 1ull) && (hi - 1u - val[q]) / BM_BITS >= NPASS) {
+                    if (slot < sort_cap) skey[slot] = val[q];
+                    cb[i] = slot;                           /* only read back when the tail needs several passes */
+                    slot++;
+                }
+            }
+            __syncthreads();
+        }
         const uint32_t Kt = s_cls[NPASS];
         PW_STAMP(11);
         /* ---- the tail: sorted, sort_cap keys a pass (one pass unless most of the window holds ancient priorities) ---- */
@@ -595,25 +642,22 @@ __global__ __launch_bounds__(W) void k_pw_fwd(const uint32_t *__restrict__ ps, u
         if (blockIdx.x == 0 && tid == 0) PW_NOTE(14, Kt);
         /* ---- codes into the ring: own positions are sb + i (the plane is filled as if every cell held its own, then
          *      the old entries clear their bits: ranks are below 2^16) ---- */
-        for (uint32_t wd = tid; wd < ring_n / 16u; wd += W) {
-            uint32_t hw = 0;
-#pragma unroll
-            for (uint32_t k = 0; k < 16; k++) hw |= (((sb + wd * 16u + k) >> 16) & 3u) << (2u * k);
-            ring.hi[wd] = hw;
-        }
+        for (uint32_t wd = tid; wd < ring_n / 16u; wd += W) ring.hi[wd] = pw_plane_word(sb + wd * 16u);
         __syncthreads();
+        /* (a plane word is sixteen consecutive cells = a DPP row of one entry index: the row's last lane writes it -- an
+         * atomic per old entry made sixteen lanes queue on every word) */
 #pragma unroll
         for (uint32_t q = 0; q < EPT; q++) {
             uint32_t tq = tid; asm volatile("" : "+v"(tq)); const uint32_t i = q * W + tq;
-            if (i < sb) {
-                const bool own = !((old0 >> q) & 1ull);
-                const uint32_t code = own ? sb + i : val[q];
-                ring.lo[i] = (uint16_t)code;
-                if (!own) {
-                    const uint32_t hb = ((sb + i) >> 16) & 3u;
-                    if (hb) atomicAnd(&ring.hi[i >> 4], ~(hb << ((i & 15u) * 2u)));
-                }
-            }
+            const bool own = !((old0 >> q) & 1ull);             /* (beyond the row: own) */
+            const uint32_t code = own ? sb + i : val[q];
+            if (i < sb) ring.lo[i] = (uint16_t)code;
+            uint32_t hv = ((code >> 16) & 3u) << ((tid & 15u) * 2u);
+            hv |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)hv, 0x111, 0xF, 0xF, false);      /* row_shr:1 */
+            hv |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)hv, 0x112, 0xF, 0xF, false);      /* row_shr:2 */
+            hv |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)hv, 0x114, 0xF, 0xF, false);      /* row_shr:4 */
+            hv |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)hv, 0x118, 0xF, 0xF, false);      /* row_shr:8 */
+            if ((tid & 15u) == 15u && i < ring_n) ring.hi[i >> 4] = hv;
         }
         for (uint32_t r = sb + tid; r < ring_n; r += W) ring.lo[r] = (uint16_t)(sb + r);
     } else {
@@ -623,6 +667,8 @@ __global__ __launch_bounds__(W) void k_pw_fwd(const uint32_t *__restrict__ ps, u
 
     PW_STAMP(9);
     constexpr uint32_t NW = W / 64;
+    static_assert(NW == 4 || NW == 16, "the round counts' prefix runs along a DPP row");
+    const uint32_t wave_s = (uint32_t)__builtin_amdgcn_readfirstlane((int)wave);
     const uint32_t xlast = x1 - 1u;
     uint32_t off = 0;                                       /* ring slot of cell xg */
     uint32_t nflip = 0;
@@ -641,97 +687,121 @@ __global__ __launch_bounds__(W) void k_pw_fwd(const uint32_t *__restrict__ ps, u
         }
     };
     fetch(x0, v, rmw, gow);
-    uint32_t pend_x = PW_NONE, pend_v = PW_NONE;           /* PACK: a handed-over old rank on its way through gval[] */
-    for (uint32_t xs = x0; xs < x1 && !(probe & 1u); xs += SG * W) {
-        fetch(xs + SG * W, vn, rmn, gon);
-#pragma unroll
-        for (int k = 0; k < SG; k++) {
-            const uint32_t xg = xs + (uint32_t)k * W;
-            if (xg >= x1) continue;                         /* (workgroup-uniform) */
-            const uint32_t x = xg + tid;
-            const uint32_t vv = x < x1 ? v[k] : 0u;
-            const uint32_t p = vv & 0xFFFFu, s = vv >> 16;
-            const bool has = p && s;
-            /* my round: round starts at or before me, minus one; rounds of the group */
-            uint32_t before = 0, nr = 0;
-            const uint32_t pc = (uint32_t)__popcll(rmw[k]);
-#pragma unroll
-            for (uint32_t w = 0; w < NW; w++) {
-                const uint32_t t = (uint32_t)__builtin_amdgcn_readlane((int)pc, (int)w);
-                before += w < wave ? t : 0u;
-                nr += t;
+    /* One group of W steps.  FULL: every lane has a step -- and every vector-memory operation of the group is
+     * unconditional: `s_waitcnt vmcnt` counts loads and stores in ONE order, so a wait for a prefetched operand behind a
+     * store whose issue the compiler cannot count (a branch around it) becomes vmcnt(0) and pays the store's round trip
+     * (microseconds) in every group.  Until round 5 the look-up of a handed-over old rank in gval[] sat in this loop,
+     * one group deferred, behind exactly such a wait: 7400 cycles per group, of which the rounds are 2000.  Now an old
+     * rank r leaves as the marker PW_RANK0 - r (no priority is that high: positions end at LZ77X_MAX_N, voff <= sb) and
+     * every thread translates the markers it wrote itself when the block is through. */
+    auto group = [&](auto full_tag, uint32_t xg, uint32_t vk, uint64_t rmk, uint64_t gok) {
+        constexpr bool FULL = decltype(full_tag)::value;
+        const uint32_t x = xg + tid;
+        const uint32_t vv = FULL || x < x1 ? vk : 0u;
+        const uint32_t p = vv & 0xFFFFu, s = vv >> 16;
+        const bool has = p && s;
+        /* my round: round starts at or before me, minus one; rounds of the group.  Lane l holds the mask word of
+         * wavefront l mod NW: the counts' prefix sums run along a row of 16 lanes (DPP), this wavefront's word and the
+         * rounds before it are two scalar reads -- the loop over NW readlanes with a vector compare against the
+         * wavefront number was 100 of a group's 320 instructions, sixteen wavefronts over. */
+        const uint32_t pc = (uint32_t)__popcll(rmk);
+        uint32_t incl = pc;
+        incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x111, 0xF, 0xF, false);      /* row_shr:1 */
+        incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x112, 0xF, 0xF, false);      /* row_shr:2 */
+        if constexpr (NW > 4) {
+            incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x114, 0xF, 0xF, false);  /* row_shr:4 */
+            incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x118, 0xF, 0xF, false);  /* row_shr:8 */
+        }
+        const uint32_t nr = (uint32_t)__builtin_amdgcn_readlane((int)incl, (int)NW - 1);
+        const uint32_t before = (uint32_t)__builtin_amdgcn_readlane((int)(incl - pc), (int)wave_s);
+        const uint32_t mlo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)rmk, (int)wave_s);
+        const uint32_t mhi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(rmk >> 32), (int)wave_s);
+        /* bits 0 .. lane of the word = bit 0 + the bits below the lane of the word shifted down by one */
+        const uint32_t myr = before + (mlo & 1u) - 1u +
+                             __builtin_amdgcn_mbcnt_hi(mhi >> 1, __builtin_amdgcn_mbcnt_lo((mlo >> 1) | (mhi << 31), 0u));
+        uint32_t ix = off + tid;
+        ix -= ix >= ring_n ? ring_n : 0u;
+        uint32_t ip = ix + p;
+        ip -= ip >= ring_n ? ring_n : 0u;
+        uint32_t is = ix + s;
+        is -= is >= ring_n ? ring_n : 0u;
+        uint32_t ng = 0, out = PW_NONE;
+        for (uint32_t r = 0; r < nr; r++) {
+            /* a round in two halves: every step of the round reads, then every step writes.  The round masks only
+             * split where a step READS what an earlier step of the round writes; a later step of the round may well
+             * write what an earlier one reads (its successor cell = the other's predecessor cell), and across
+             * wavefronts nothing but a barrier orders that write behind the read (inside one wavefront the lanes run
+             * in lockstep: k_prio_fwd) */
+            const bool mine = has && myr == r;
+            uint32_t a = 0, sv = 0;
+            bool hand = false;
+            if (mine) {
+                a = ring.rd(ix);
+                const uint32_t w = ring.rd(ip);
+                sv = ring.rd(is);
+                const bool gate = a < w;
+                ng = gate ? 1u : 0u;                        /* the gate: x's predecessor hangs below x */
+                hand = gate && a < sv;
             }
-            const uint64_t myw = ((uint64_t)(uint32_t)__shfl((int)(uint32_t)(rmw[k] >> 32), (int)wave, 64) << 32) |
-                                 (uint32_t)__shfl((int)(uint32_t)rmw[k], (int)wave, 64);
-            const uint32_t myr = before + (uint32_t)__popcll(myw & ((2ull << lane) - 1ull)) - 1u;
-            uint32_t ix = off + tid;
-            ix -= ix >= ring_n ? ring_n : 0u;
-            uint32_t ip = ix + p;
-            ip -= ip >= ring_n ? ring_n : 0u;
-            uint32_t is = ix + s;
-            is -= is >= ring_n ? ring_n : 0u;
-            uint32_t ng = 0, out = PW_NONE;
-            for (uint32_t r = 0; r < nr; r++) {
-                /* a round in two halves: every step of the round reads, then every step writes.  The round masks only
-                 * split where a step READS what an earlier step of the round writes; a later step of the round may well
-                 * write what an earlier one reads (its successor cell = the other's predecessor cell), and across
-                 * wavefronts nothing but a barrier orders that write behind the read (inside one wavefront the lanes run
-                 * in lockstep: k_prio_fwd) */
-                const bool mine = has && myr == r;
-                uint32_t a = 0, sv = 0;
-                bool hand = false;
-                if (mine) {
-                    a = ring.rd(ix);
-                    const uint32_t w = ring.rd(ip);
-                    sv = ring.rd(is);
-                    const bool gate = a < w;
-                    ng = gate ? 1u : 0u;                        /* the gate: x's predecessor hangs below x */
-                    hand = gate && a < sv;
-                }
-                pw_lds_barrier();
-                if (hand) { ring.wr(is, a, sv); out = a; }      /* tree.c:202-231: S takes x's place */
-                pw_lds_barrier();
-            }
-            const uint64_t gnb = __ballot(ng != 0u);
-            nflip += xg + 64u * wave < x1 ? (uint32_t)__popcll(gnb ^ gow[k]) : 0u;
-            if (lane == 0 && xg + 64u * wave < x1) gnew[(xg >> 6) + wave] = gnb;
-            if constexpr (PACK) {
-                /* the store of the group before: its table look-up had this group's rounds to arrive */
-                if (pend_x != PW_NONE) xval[pend_x] = pend_v;
-                pend_x = PW_NONE;
-                if (x < x1) {
-                    if (out != PW_NONE && out < sb) { pend_x = x; pend_v = gval[(size_t)b * rs + out]; }
-                    else xval[x] = out == PW_NONE ? PW_NONE : x0 + (out - sb) + voff;
-                }
-            } else {
-                if (x < x1) xval[x] = out;
-            }
-            /* cell xg + ring_n + tid becomes live with the next group; its slot held cell xg + tid (the lanes past the
-             * last step keep their cells: out_state) */
-            if constexpr (PACK) {
-                const uint32_t nc = sb + (xg + ring_n + tid - x0);
-                if (xg + W <= x1) {
-                    /* whole group: the plane a word (16 cells, 16 consecutive codes) at a time -- an exclusive or per cell
-                     * made 16 lanes queue on every word */
-                    ring.lo[ix] = (uint16_t)nc;
-                    if ((tid & 15u) == 0) {
-                        uint32_t hw = 0;
-#pragma unroll
-                        for (uint32_t q = 0; q < 16; q++) hw |= (((nc + q) >> 16) & 3u) << (2u * q);
-                        ring.hi[ix >> 4] = hw;
-                    }
-                } else if (x < x1) ring.put(ix, nc);
-            } else {
-                if (x < x1) ring.put(ix, xg + ring_n + tid + voff);
-            }
-            off += W;
-            off -= off >= ring_n ? ring_n : 0u;
+            pw_lds_barrier();
+            if (hand) { ring.wr(is, a, sv); out = a; }      /* tree.c:202-231: S takes x's place */
             pw_lds_barrier();
         }
+        const uint64_t gnb = __ballot(ng != 0u);
+        const bool wave_in = FULL || xg + 64u * wave < x1;
+        nflip += wave_in ? (uint32_t)__popcll(gnb ^ gok) : 0u;
+        if (lane == 0 && wave_in) gnew[(xg >> 6) + wave] = gnb;
+        uint32_t o = out;
+        if constexpr (PACK) o = out == PW_NONE ? PW_NONE : (out < sb ? PW_RANK0 - out : x0 + (out - sb) + voff);
+        if (FULL || x < x1) xval[x] = o;
+        /* cell xg + ring_n + tid becomes live with the next group; its slot held cell xg + tid (the lanes past the
+         * last step keep their cells: out_state) */
+        if constexpr (PACK) {
+            const uint32_t nc = sb + (xg + ring_n + tid - x0);
+            if (FULL) {
+                /* whole group: the plane a word (16 cells, 16 consecutive codes) at a time -- an exclusive or per cell
+                 * made 16 lanes queue on every word */
+                ring.lo[ix] = (uint16_t)nc;
+                if ((tid & 15u) == 0) ring.hi[ix >> 4] = pw_plane_word(nc);
+            } else if (x < x1) ring.put(ix, nc);
+        } else {
+            if (FULL || x < x1) ring.put(ix, xg + ring_n + tid + voff);
+        }
+        off += W;
+        off -= off >= ring_n ? ring_n : 0u;
+        pw_lds_barrier();
+    };
+    uint32_t xs = x0;
+    if (!(probe & 1u)) {
+        for (; x1 - xs >= SG * W; xs += SG * W) {
+            fetch(xs + SG * W, vn, rmn, gon);
 #pragma unroll
-        for (int k = 0; k < SG; k++) { v[k] = vn[k]; rmw[k] = rmn[k]; gow[k] = gon[k]; }
+            for (int k = 0; k < SG; k++) group(std::true_type{}, xs + (uint32_t)k * W, v[k], rmw[k], gow[k]);
+#pragma unroll
+            for (int k = 0; k < SG; k++) { v[k] = vn[k]; rmw[k] = rmn[k]; gow[k] = gon[k]; }
+        }
+#pragma unroll
+        for (int k = 0; k < SG; k++)
+            if (xs + (uint32_t)k * W < x1) group(std::false_type{}, xs + (uint32_t)k * W, v[k], rmw[k], gow[k]);   /* (workgroup-uniform) */
     }
-    if constexpr (PACK) { if (pend_x != PW_NONE) xval[pend_x] = pend_v; }
+    if constexpr (PACK) {
+        /* the markers of this thread's own stores (x = x0 + tid mod W): rank -> value */
+        const uint32_t *gvb = gval + (size_t)b * rs;
+        constexpr int TB = 8;
+        for (uint32_t xb = x0 + tid; xb < x1; xb += TB * W) {
+            uint32_t c[TB];
+#pragma unroll
+            for (int j = 0; j < TB; j++) c[j] = xval[min(xb + (uint32_t)j * W, xlast)];
+#pragma unroll
+            for (int j = 0; j < TB; j++) {
+                const bool mk = xb + (uint32_t)j * W < x1 && c[j] != PW_NONE && c[j] > PW_RANK0 - 65536u;
+                c[j] = mk ? gvb[PW_RANK0 - c[j]] : PW_NONE;
+            }
+#pragma unroll
+            for (int j = 0; j < TB; j++)
+                if (c[j] != PW_NONE) xval[xb + (uint32_t)j * W] = c[j];
+        }
+    }
     PW_STAMP(10);
     if (out_state && x1 == nx) {
         /* cells nx .. nx+sb-1, what the next segment of a long input starts from: the ring holds the cells [x1, x1 + ring_n) */
@@ -901,60 +971,88 @@ __global__ __launch_bounds__(W) void k_pw_back(const uint32_t *__restrict__ ps, 
 typedef uint32_t pw_u32x4 __attribute__((ext_vector_type(4)));
 typedef uint16_t pw_u16x4 __attribute__((ext_vector_type(4)));
 
-__device__ __forceinline__ void pw_apply_map(const uint32_t *cur, const uint16_t *__restrict__ dj, const uint32_t *__restrict__ lj,
-                                             uint32_t sb, uint32_t *acc, uint32_t *out)
-{
-    const uint32_t tid = threadIdx.x;
-    const uint32_t sb4 = (sb + 3u) / 4u;                    /* quads of cells; the rows are padded to a multiple of 8 cells */
-    const pw_u32x4 *lj4 = reinterpret_cast<const pw_u32x4 *>(lj);
-    const pw_u16x4 *dj4 = reinterpret_cast<const pw_u16x4 *>(dj);
-    const pw_u32x4 *cur4 = reinterpret_cast<const pw_u32x4 *>(cur);
-    pw_u32x4 *out4 = reinterpret_cast<pw_u32x4 *>(out), *acc4 = reinterpret_cast<pw_u32x4 *>(acc);
-    for (uint32_t h = 0; h < 2; h++) {
-        const uint32_t base = h * PW_MAP_HALF, q0 = base / 4u, q1 = min(q0 + PW_MAP_HALF / 4u, sb4);
-#pragma unroll 4
-        for (uint32_t q = q0 + tid; q < q1; q += PW_MAP_T) acc4[q - q0] = lj4[q];
-        pw_lds_barrier();
-        if (cur) {
-#pragma unroll 4
-            for (uint32_t q = tid; q < sb4; q += PW_MAP_T) {
-                const pw_u16x4 d = dj4[q];
-                const pw_u32x4 val = cur4[q];
-#pragma unroll
-                for (int k = 0; k < 4; k++) {
-                    const uint32_t dk = d[k], vk = val[k];
-                    if (4u * q + (uint32_t)k < sb && dk != PW_DEAD && (dk >> 15) == h && vk != PW_NONE) atomicMin(&acc[dk - base], vk);
-                }
-            }
-        }
-        pw_lds_barrier();
-#pragma unroll 4
-        for (uint32_t q = q0 + tid; q < q1; q += PW_MAP_T) out4[q] = acc4[q - q0];
-        pw_lds_barrier();
-    }
-    pw_fence_wg();                                            /* the row is written: the next map reads it */
-    __syncthreads();
-}
-
 /* group g = blockIdx.x applies its maps m0 .. m1-1 (map number m is row `first + m` of dest / loc) in sequence.
  * REPLAY: from row g of vin; row `first + m + 1` of `v` receives the vector after map m.
  * else (compose, loc half): from "nothing" (the identity map); row g of `v` receives what the group's maps send to each
- * exit cell from inside the group; the running vector alternates between two rows of `tmp` (2 rows a group) */
+ * exit cell from inside the group; the running vector alternates between two rows of `tmp` (2 rows a group).
+ *
+ * One map: out[d] = min(loc[d], min{cur[c] : dest[c] = d}), the destinations in two halves of 32 K cells through LDS
+ * (`acc`, 128 KB).  The maps of a group are a chain, and until round 5 every link was six round trips to memory in a row
+ * (loc half -> LDS, dest + cur, the result out, a fence; twice) -- 30 us a map, 12 maps a launch, 5 launches an iteration.
+ * Now only the chain's own data waits: a thread reads back the quads of `cur` it stored itself (program order, no fence),
+ * loc and dest do not depend on the chain and are in registers one phase / one map ahead, and the thread that reads a
+ * slot of `acc` out puts the next phase's loc value in its place (no barrier between the two). */
 template <bool REPLAY>
 __global__ __launch_bounds__(PW_MAP_T) void k_pw_maps(const uint16_t *__restrict__ dest, const uint32_t *__restrict__ loc, uint32_t sb, uint32_t rs, uint32_t first,
                                                       uint32_t nmaps, uint32_t G, const uint32_t *vin, uint32_t *v, uint32_t *tmp)
 {
     extern __shared__ uint32_t pw_lds[];
-    const uint32_t g = blockIdx.x;
+    const uint32_t g = blockIdx.x, tid = threadIdx.x;
     const uint32_t m0 = g * G, m1 = min(m0 + G, nmaps);
     if (m0 >= m1) return;
+    constexpr uint32_t HQ = PW_MAP_HALF / 4u, NK = HQ / PW_MAP_T;       /* quads a half, quads a thread and half */
+    const uint32_t sb4 = (sb + 3u) / 4u;                    /* quads of cells; the rows are padded to a multiple of 8 cells */
+    uint32_t *acc = pw_lds;
+    pw_u32x4 *acc4 = reinterpret_cast<pw_u32x4 *>(pw_lds);
     const uint32_t *cur = REPLAY ? vin + (size_t)g * rs : nullptr;
+    pw_u32x4 lq[NK];                                        /* loc of the next phase (a phase = one half of one map) */
+    pw_u16x4 dq[2 * NK];                                    /* dest of the map at hand */
+    auto load_loc = [&](size_t j, uint32_t h) {
+        const pw_u32x4 *lj4 = reinterpret_cast<const pw_u32x4 *>(loc + j * rs);
+#pragma unroll
+        for (uint32_t k = 0; k < NK; k++) { uint32_t tq = tid; asm volatile("" : "+v"(tq)); lq[k] = lj4[min(h * HQ + tq + k * PW_MAP_T, sb4 - 1u)]; }
+    };
+    auto load_dest = [&](size_t j) {
+        const pw_u16x4 *dj4 = reinterpret_cast<const pw_u16x4 *>(dest + j * rs);
+#pragma unroll
+        for (uint32_t k = 0; k < 2 * NK; k++) { uint32_t tq = tid; asm volatile("" : "+v"(tq)); dq[k] = dj4[min(tq + k * PW_MAP_T, sb4 - 1u)]; }
+    };
+    load_loc((size_t)first + m0, 0);
+    if (cur) load_dest((size_t)first + m0);
+#pragma unroll
+    for (uint32_t k = 0; k < NK; k++) acc4[tid + k * PW_MAP_T] = lq[k];
     for (uint32_t m = m0; m < m1; m++) {
         const size_t j = (size_t)first + m;
         uint32_t *out;
         if constexpr (REPLAY) out = v + (j + 1) * rs;
         else out = m + 1u == m1 ? v + (size_t)g * rs : tmp + ((size_t)2 * g + ((m - m0) & 1u)) * rs;
-        pw_apply_map(cur, dest + j * rs, loc + j * rs, sb, pw_lds, out);
+        pw_u32x4 *out4 = reinterpret_cast<pw_u32x4 *>(out);
+        const pw_u32x4 *cur4 = reinterpret_cast<const pw_u32x4 *>(cur);
+        for (uint32_t h = 0; h < 2; h++) {
+            const bool more = h == 0 || m + 1u < m1;
+            if (more) load_loc(h == 0 ? j : j + 1, h ^ 1u);
+            pw_lds_barrier();                               /* acc holds the loc half */
+            if (cur) {
+                const uint32_t base = h * PW_MAP_HALF;
+#pragma unroll
+                for (uint32_t bt = 0; bt < 2; bt++) {
+                    pw_u32x4 cv[NK];
+#pragma unroll
+                    for (uint32_t k = 0; k < NK; k++) { uint32_t tq = tid; asm volatile("" : "+v"(tq)); cv[k] = cur4[min(tq + (bt * NK + k) * PW_MAP_T, sb4 - 1u)]; }
+#pragma unroll
+                    for (uint32_t k = 0; k < NK; k++) {
+                        const uint32_t q = tid + (bt * NK + k) * PW_MAP_T;
+                        const pw_u16x4 d = dq[bt * NK + k];
+#pragma unroll
+                        for (int c = 0; c < 4; c++) {
+                            const uint32_t dk = d[c], vk = cv[k][c];
+                            if (4u * q + (uint32_t)c < sb && dk != PW_DEAD && (dk >> 15) == h && vk != PW_NONE) atomicMin(&acc[dk - base], vk);
+                        }
+                    }
+                }
+            }
+            if (h == 1 && m + 1u < m1) load_dest(j + 1);   /* (dq is free: the map's last atomics are out) */
+            pw_lds_barrier();                               /* the half is complete */
+            const uint32_t q1 = min((h + 1u) * HQ, sb4);
+#pragma unroll
+            for (uint32_t k = 0; k < NK; k++) {
+                uint32_t tq = tid; asm volatile("" : "+v"(tq));
+                const uint32_t sl = tq + k * PW_MAP_T, q = h * HQ + sl;
+                const pw_u32x4 x = acc4[sl];
+                if (more) acc4[sl] = lq[k];
+                if (q < q1) out4[q] = x;
+            }
+        }
         cur = out;
     }
 }
