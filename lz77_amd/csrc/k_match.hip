@@ -1671,10 +1671,22 @@ __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v)
 
 #define WW_WAVES 4u                                 /* wavefronts that share a run's bitmap (below) */
 
+/* inclusive OR over the lanes up to mine (DPP: rows of 16, then the rows' last lanes) */
+__device__ __forceinline__ uint32_t wave_incl_or(uint32_t x)
+{
+    x |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xF, 0xF, false);      /* row_shr:1 */
+    x |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xF, 0xF, false);      /* row_shr:2 */
+    x |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xF, 0xF, false);      /* row_shr:4 */
+    x |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x118, 0xF, 0xF, false);      /* row_shr:8 */
+    x |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x142, 0xA, 0xF, false);      /* row_bcast:15 into rows 1 and 3 */
+    x |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x143, 0xC, 0xF, false);      /* row_bcast:31 into rows 2 and 3 */
+    return x;
+}
+
 __global__ __launch_bounds__(64 * WW_WAVES) void k_walk_wave(const uint32_t *__restrict__ ranks, uint32_t n, int sb, uint32_t RP,
                                                              uint32_t TILE, uint32_t region0, uint32_t nregions, uint32_t run_len,
                                                              uint32_t runs_per_tile, uint2 *__restrict__ wf, uint2 *__restrict__ wb,
-                                                             uint2 *__restrict__ wb0)
+                                                             uint2 *__restrict__ wb0, uint32_t fringe_v4 /* variants build: rounds 3-4's fringe */)
 {
     /* FOUR wavefronts share a run and its bitmap (round 3).  A group of 64 steps is (1) clear, (2) core queries, (4) set --
      * which must follow one another group after group -- and (3) the fringe all-to-all, 64 x 8 compare/select/min-max:
@@ -1684,6 +1696,7 @@ __global__ __launch_bounds__(64 * WW_WAVES) void k_walk_wave(const uint32_t *__r
      * fringe whenever it likes and does (1)(2)(4) when the turn counter in LDS reaches its group. */
     extern __shared__ uint32_t wv_bm[];
     __shared__ uint32_t s_turn, s_lo, s_hi, s_mn[WW_WAVES], s_mx[WW_WAVES];
+    __shared__ uint32_t s_ftab[128 * WW_WAVES];                 /* per wavefront: local rank of a fringe value -> the rank */
     const uint32_t NW = RP >> 5, NS = (NW + 31) >> 5;
     uint32_t *word = wv_bm, *summ = wv_bm + NW;
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
@@ -1812,9 +1825,9 @@ __global__ __launch_bounds__(64 * WW_WAVES) void k_walk_wave(const uint32_t *__r
          *    forward query of lanes i < j, N_j for both queries of lanes i > j.  Ranks are distinct; "closer than the
          *    current answer" in unsigned arithmetic with NONE = 0xFFFFFFFF as "no successor" and pred stored + 1 (0 = none). */
         uint32_t fs = NONE, bs = NONE, fp1 = 0u, bp1 = 0u;
-        {
-            /* branch-free: which lanes a fringe rank is admissible for is a wave-uniform mask of j, so a candidate
-             * costs compare + mask + select + min/max */
+#ifdef LZ77X_VARIANTS
+        if (fringe_v4) {
+            /* rounds 3-4: all-to-all, a candidate costs compare + mask + select + min/max (the cross-check of the form below) */
             const uint64_t hasx = __ballot(rx != NONE), hasy = __ballot(ry != NONE);
             for (int j = 0; j < 64; j++) {
                 const uint32_t co = (uint32_t)__builtin_amdgcn_readlane((int)rx, j);
@@ -1836,6 +1849,66 @@ __global__ __launch_bounds__(64 * WW_WAVES) void k_walk_wave(const uint32_t *__r
                 fs = min(fs, (me_nf && cn > rx) ? cn : NONE);
                 fp1 = max(fp1, (me_nf && cn < rx) ? cn + 1u : 0u);
             }
+        } else
+#endif
+        {
+            /* Round 5.  The fringe is the walk itself in small: S = O_0 .. O_63 N_0 .. N_63 is a sequence of 128 ranks, lane
+             * i's backward query asks for the neighbours of S[64+i] in the window S[i .. i+63] and its forward query for
+             * those of S[i] in S[i+1 .. i+63].  So: rank the 128 values among themselves (the only all-to-all left: two
+             * broadcasts, four compare-and-adds a step), make the windows 128-bit sets of LOCAL ranks -- the O bits of the
+             * lanes from i on are all O bits minus a prefix OR, the N bits below i a prefix OR (DPP scans) -- and a query is
+             * a find-first-bit on either side of the value's own bit; a 128-entry table per wavefront turns the local rank
+             * back into the rank.  800 instructions a group where the eight select/min-max per pair took 4200. */
+            uint32_t Lx = 0, Ly = 0;
+            for (int j = 0; j < 64; j++) {
+                const uint32_t co = (uint32_t)__builtin_amdgcn_readlane((int)rx, j);
+                const uint32_t cn = (uint32_t)__builtin_amdgcn_readlane((int)ry, j);
+                Lx += (co < rx ? 1u : 0u) + (cn < rx ? 1u : 0u);     /* (NONE is below nothing) */
+                Ly += (co < ry ? 1u : 0u) + (cn < ry ? 1u : 0u);
+            }
+            const bool vx = rx != NONE, vy = ry != NONE;
+            uint32_t *tab = s_ftab + 128u * wave;
+            if (vx) tab[Lx] = rx;
+            if (vy) tab[Ly] = ry;
+            uint32_t ox[4], io[4], in_[4];
+#pragma unroll
+            for (uint32_t k = 0; k < 4; k++) {
+                ox[k] = vx && (Lx >> 5) == k ? 1u << (Lx & 31u) : 0u;
+                const uint32_t nyk = vy && (Ly >> 5) == k ? 1u << (Ly & 31u) : 0u;
+                io[k] = wave_incl_or(ox[k]);
+                in_[k] = wave_incl_or(nyk) & ~nyk;                   /* N bits of the lanes below mine */
+            }
+            uint32_t wbk[4], wfk[4];
+#pragma unroll
+            for (uint32_t k = 0; k < 4; k++) {
+                const uint32_t to = (uint32_t)__builtin_amdgcn_readlane((int)io[k], 63);   /* every O bit */
+                wbk[k] = (to & ~(io[k] & ~ox[k])) | in_[k];         /* O bits of the lanes from mine on, N bits below */
+                wfk[k] = wbk[k] & ~ox[k];
+            }
+            const uint64_t wb_lo = ((uint64_t)wbk[1] << 32) | wbk[0], wb_hi = ((uint64_t)wbk[3] << 32) | wbk[2];
+            const uint64_t wf_lo = ((uint64_t)wfk[1] << 32) | wfk[0], wf_hi = ((uint64_t)wfk[3] << 32) | wfk[2];
+            auto succ128 = [](uint64_t lo, uint64_t hi, uint32_t L) -> uint32_t {      /* first member above L, 128: none */
+                const uint64_t a_lo = L < 64u ? lo & ~((2ull << (L & 63u)) - 1ull) : 0ull;
+                const uint64_t a_hi = L < 64u ? hi : hi & ~((2ull << (L & 63u)) - 1ull);
+                return a_lo ? (uint32_t)__builtin_ctzll(a_lo) : a_hi ? 64u + (uint32_t)__builtin_ctzll(a_hi) : 128u;
+            };
+            auto pred128 = [](uint64_t lo, uint64_t hi, uint32_t L) -> uint32_t {      /* last member below L, 128: none */
+                const uint64_t b_hi = L >= 64u ? hi & ((1ull << (L & 63u)) - 1ull) : 0ull;
+                const uint64_t b_lo = L >= 64u ? lo : lo & ((1ull << (L & 63u)) - 1ull);
+                return b_hi ? 127u - (uint32_t)__builtin_clzll(b_hi) : b_lo ? 63u - (uint32_t)__builtin_clzll(b_lo) : 128u;
+            };
+            const uint32_t sb_ = succ128(wb_lo, wb_hi, Ly), pb_ = pred128(wb_lo, wb_hi, Ly);
+            const uint32_t sf_ = succ128(wf_lo, wf_hi, Lx), pf_ = pred128(wf_lo, wf_hi, Lx);
+            wsync();                                                 /* the table is written */
+            if (vy) {
+                if (sb_ < 128u) bs = tab[sb_];
+                if (pb_ < 128u) bp1 = tab[pb_] + 1u;
+            }
+            if (vx) {
+                if (sf_ < 128u) fs = tab[sf_];
+                if (pf_ < 128u) fp1 = tab[pf_] + 1u;
+            }
+            wsync();                                                 /* (read before the next group of this wavefront writes) */
         }
         /* my turn: the groups before mine have left the bitmap as my window's */
         while (__hip_atomic_load(&s_turn, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != gi) __builtin_amdgcn_s_sleep(2);
@@ -2356,7 +2429,7 @@ hipError_t lz77k_match(const uint8_t *d_in, uint32_t n, const lz77x_geom &g, uin
                 if (e != hipSuccess) return e;
             }
             hipLaunchKernelGGL(k_walk_wave, dim3((uint32_t)walkers), dim3(64 * WW_WAVES), wlds, s, ranks, n, g.sb, g.RP, g.TILE, region0, nregions, run_len,
-                               runs, wf, wb, wb0);
+                               runs, wf, wb, wb0, LZ77X_VENV("LZ77X_WALK_FRINGE_V4") ? 1u : 0u);
         } else {
 #ifdef LZ77X_VARIANTS
             hipLaunchKernelGGL(k_walk_big, dim3((uint32_t)((walkers + 63) / 64)), dim3(64), 0, s, ranks, n, g.sb, g.RP, g.TILE,

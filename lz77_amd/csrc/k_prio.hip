@@ -803,6 +803,7 @@ static void prio_layout(lz77k_prio_plan &P)
     }
     if (sb > 4096u) P.o_scan = take(lz77kw_scan_tmp_bytes(P.NG, P.rs));
     if (P.W > 64u) P.o_inprev = take(((size_t)P.NB + 2) * rs * 4);        /* the cells every block's last sweep started from */
+    if (P.W > 64u) P.o_destx = take(lz77kw_back_scratch_bytes(P.NB, P.B, P.ring_n, P.W));
     P.total = o;
 }
 
@@ -875,7 +876,7 @@ hipError_t lz77k_prio_maps(lz77k_prio_plan &P, hipStream_t s, bool whole, const 
     const uint32_t nb = P.NB - P.first;
     if (P.W > 64u) {
         hipError_t e = lz77kw_back(P.ps, P.nx, P.sb, P.rs, P.B, P.ring_n, P.W, P.first, nb, PRIO_PTR(uint64_t, P.o_gate[P.cur]), dest, loc, P.voff, P.ncarried,
-                                   PRIO_PTR(uint32_t, P.o_dirty), s);
+                                   PRIO_PTR(uint32_t, P.o_dirty), PRIO_PTR(uint16_t, P.o_destx), s);
         if (e != hipSuccess) return e;
         if (whole && P.sb > 4096u) {
             /* the whole-plan map of a shard, through HBM like the boundary scan (a vector of sb priorities does not fit LDS

@@ -26,6 +26,10 @@
 #include <stdio.h>
 #include <type_traits>
 
+typedef uint32_t pw_u32x4 __attribute__((ext_vector_type(4)));
+typedef uint16_t pw_u16x4 __attribute__((ext_vector_type(4)));
+typedef uint16_t pw_u16x8 __attribute__((ext_vector_type(8)));
+
 #define PW_NONE 0xFFFFFFFFu
 #define PW_DEAD 0xFFFFu
 #define PW_RANK0 0xFFFFFFFEu             /* k_pw_fwd: xval marker of old rank r = PW_RANK0 - r, until the block's last pass */
@@ -825,120 +829,168 @@ __global__ __launch_bounds__(W) void k_pw_fwd(const uint32_t *__restrict__ ps, u
 
 /* dest[b][i]: the exit cell (relative to the block's end x1) that the chain of open gates starting at entry cell b*B+i
  * reaches, or DEAD when it ends inside the block; loc[b][d]: the lowest position of the block whose chain reaches exit
- * cell d.  loc lives in HBM (32 bits x sb do not fit beside the ring): initialised here, lowered atomically. */
+ * cell d.
+ *
+ * Round 5: two phases a block.  Until then every step whose chain left the block lowered loc[d] in HBM with an atomic
+ * (loc, 32 bits x sb, does not fit beside the ring), deduplicated per group through a table in LDS -- but a group of 4096
+ * steps reaches ~1400 different exit cells, 80-110 K atomics a block went out (counted: LZ77X_PW_DEBUG), and the L2 does
+ * about 50 G of them a second: 0.7 of a block's 1.0-1.5 M cycles.  Now phase 1 (the backward sweep) only stores every
+ * step's exit cell, 16 bits, in a scratch row of the workgroup (`destx`), and phase 2 -- the ring is no longer needed --
+ * has the LDS for loc itself, half the exit cells at a time: initialise, one pass of LDS atomics over the row, write out.
+ * The grid is persistent (a workgroup takes the blocks blockIdx.x, + gridDim.x, ...): a scratch row per workgroup. */
 template <int W>
 __global__ __launch_bounds__(W) void k_pw_back(const uint32_t *__restrict__ ps, uint32_t nx, uint32_t sb, uint32_t rs /* row stride of dest / loc */, uint32_t B, uint32_t ring_n,
-                                               uint32_t b_first, const uint64_t *__restrict__ gates, uint16_t *__restrict__ dest,
+                                               uint32_t b_first, uint32_t nb, const uint64_t *__restrict__ gates, uint16_t *__restrict__ dest,
                                                uint32_t *__restrict__ loc, uint32_t voff, uint32_t ncarried,
-                                               const uint32_t *__restrict__ gates_changed)
+                                               const uint32_t *__restrict__ gates_changed, uint16_t *__restrict__ destx_all)
 {
+    constexpr int SPT = 4;                                             /* steps a thread: a group is GW = SPT * W steps */
+    constexpr uint32_t GW = (uint32_t)SPT * W;
     extern __shared__ uint32_t pw_lds[];
-    __shared__ uint32_t s_d[W];
-    __shared__ int s_p[W];
+    __shared__ uint16_t s_d[GW];
+    __shared__ int16_t s_p[GW];
     __shared__ uint32_t s_any[2];
-    __shared__ uint32_t s_tab[4096];                                   /* per group: (exit cell, lowest step that reaches it) */
     uint16_t *dr = reinterpret_cast<uint16_t *>(pw_lds);               /* ring_n entries */
     const uint32_t tid = threadIdx.x, wave = tid >> 6, lane = tid & 63u;
-    const uint32_t b = b_first + blockIdx.x;
-    if (gates_changed && !gates_changed[b]) return;                    /* the block's map of the last iteration still holds */
-    const uint32_t x0 = b * B;
-    const uint32_t x1 = nx - x0 < B ? nx : x0 + B;
-    uint32_t *lb = loc + (size_t)b * rs;
-    PW_STAMP(0);
-    /* what reaches exit cell x1+i when nothing older comes in: its own priority -- unless it is a carried cell (a short
-     * first block of a later segment: its value comes in through in[0]) */
-    for (uint32_t i = tid; i < sb; i += W) pw_st_wg(lb + i, x1 + i >= ncarried ? x1 + i + voff : PW_NONE);
-    for (uint32_t i = tid; i < ring_n; i += W) dr[i] = (uint16_t)PW_DEAD;
-    if (tid < 2) s_any[tid] = 0;
-    for (uint32_t i = tid; i < 4096u; i += W) s_tab[i] = 0xFFFFFFFFu;
-    pw_fence_wg();                                                     /* the rows are where the atomics will find them */
-    __syncthreads();
+    uint16_t *destx = destx_all + (size_t)blockIdx.x * ((size_t)B + 16u);
     uint32_t anyk = 0;                                                 /* parity of the "anything pending" flag in use */
-    PW_STAMP(1);
-    const uint32_t ngr = (x1 - x0 + W - 1u) / W;
-    const uint32_t xlast = x1 - 1u;
-    constexpr int SG = 4;                                              /* groups fetched together: a group is far shorter than a
-                                                                          round trip to HBM, the next SG are in flight meanwhile */
-    const uint32_t nsg = (ngr + SG - 1u) / SG;
-    uint32_t off_run = (uint32_t)(((uint64_t)nsg * SG * W) % ring_n);
-    uint32_t v[SG], vn[SG];
-    uint64_t gw[SG], gwn[SG];
-    auto fetch = [&](int32_t sgi, uint32_t (&vv)[SG], uint64_t (&gg)[SG]) {       /* unconditional, clamped loads (see k_prio_fwd) */
-        const uint32_t xs = x0 + (uint32_t)(sgi < 0 ? 0 : sgi) * SG * W;
+    if (tid < 2) s_any[tid] = 0;
+    for (uint32_t bi = blockIdx.x; bi < nb; bi += gridDim.x) {
+        const uint32_t b = b_first + bi;
+        if (gates_changed && !gates_changed[b]) continue;              /* the block's map of the last iteration still holds (uniform) */
+        const uint32_t x0 = b * B;
+        const uint32_t x1 = nx - x0 < B ? nx : x0 + B;
+        uint32_t *lb = loc + (size_t)b * rs;
+        PW_STAMP(0);
+        __syncthreads();                                               /* (the block before is through with the LDS) */
+        for (uint32_t i = tid; i < ring_n; i += W) dr[i] = (uint16_t)PW_DEAD;
+        __syncthreads();
+        PW_STAMP(1);
+        /* ---- phase 1: groups of GW steps from the last to the first, a thread SPT of them (before: W steps a group, one
+         *      hop a round).  The chains inside a group are followed by pointer jumping through LDS, two hops a round: a
+         *      pointer triples its reach. ---- */
+        const uint32_t ngr = (x1 - x0 + GW - 1u) / GW;
+        const uint32_t xlast = x1 - 1u;
+        uint32_t off_run = (uint32_t)(((uint64_t)ngr * GW) % ring_n);
+        uint32_t v[SPT], vn[SPT];
+        uint64_t gw[SPT], gwn[SPT];
+        auto fetch = [&](int32_t gi, uint32_t (&vv)[SPT], uint64_t (&gg)[SPT]) {       /* unconditional, clamped loads (see k_prio_fwd) */
+            const uint32_t xs = x0 + (uint32_t)(gi < 0 ? 0 : gi) * GW;
 #pragma unroll
-        for (int k = 0; k < SG; k++) {
-            vv[k] = ps[min(xs + (uint32_t)k * W + tid, xlast)];
-            gg[k] = gates[min(xs + (uint32_t)k * W + 64u * wave, xlast) >> 6];
-        }
-    };
-    fetch((int32_t)nsg - 1, v, gw);
-    for (int32_t sgi = (int32_t)nsg - 1; sgi >= 0; sgi--) {
-        fetch(sgi - 1, vn, gwn);
+            for (int k = 0; k < SPT; k++) {
+                vv[k] = ps[min(xs + (uint32_t)k * W + tid, xlast)];
+                gg[k] = gates[min(xs + (uint32_t)k * W + 64u * wave, xlast) >> 6];
+            }
+        };
+        fetch((int32_t)ngr - 1, v, gw);
+        for (int32_t gi = (int32_t)ngr - 1; gi >= 0; gi--) {
+            fetch(gi - 1, vn, gwn);
+            const uint32_t xg = x0 + (uint32_t)gi * GW;
+            off_run = off_run >= GW ? off_run - GW : off_run + ring_n - GW;                /* = (xg - x0) % ring_n */
+            uint32_t d[SPT];
+            int ptr[SPT];
 #pragma unroll
-        for (int k = SG - 1; k >= 0; k--) {
-            const uint32_t xg = x0 + ((uint32_t)sgi * SG + (uint32_t)k) * W;
-            off_run = off_run >= (uint32_t)W ? off_run - W : off_run + ring_n - W;     /* = (xg - x0) % ring_n */
-            if (xg >= x1) continue;                                    /* (workgroup-uniform) */
-            const uint32_t x = xg + tid;
-            const bool valid = x < x1;
-            const uint32_t s = (valid ? v[k] : 0u) >> 16;
-            const bool gate = valid && xg + 64u * wave < x1 && ((gw[k] >> lane) & 1ull);
-            const uint32_t t = x + s;
-            uint32_t it = off_run + tid + (gate ? s : 0u);
-            it -= it >= ring_n ? ring_n : 0u;
-            const uint32_t dring = dr[it];
-            const bool past = t >= x1, near = t < xg + W;
-            uint32_t d = !gate ? (uint32_t)PW_DEAD : past ? t - x1 : near ? (uint32_t)PW_DEAD : dring;
-            int ptr = gate && !past && near ? (int)(t - xg) : -1;
-            /* chains inside the group: pointer jumping through LDS (pointers only lead to later steps).  s_any[k]: some
-             * step still has a pointer; the flag of the other parity is cleared while this one is in use (LDS-only
-             * barriers: the prefetched operands and the atomics stay in flight) */
+            for (int k = 0; k < SPT; k++) {
+                const uint32_t li = (uint32_t)k * W + tid, x = xg + li;
+                const bool valid = x < x1;
+                const uint32_t sk = (valid ? v[k] : 0u) >> 16;
+                const bool gate = valid && xg + (uint32_t)k * W + 64u * wave < x1 && ((gw[k] >> lane) & 1ull);
+                const uint32_t t = x + sk;
+                uint32_t it = off_run + li + (gate ? sk : 0u);
+                it -= it >= ring_n ? ring_n : 0u;
+                it -= it >= ring_n ? ring_n : 0u;
+                const uint32_t dring = dr[it];
+                const bool past = t >= x1, near = t < xg + GW;
+                d[k] = !gate ? (uint32_t)PW_DEAD : past ? t - x1 : near ? (uint32_t)PW_DEAD : dring;
+                ptr[k] = gate && !past && near ? (int)(t - xg) : -1;
+            }
+            /* chains inside the group (pointers only lead to later steps).  s_any[k]: some step still has a pointer; the
+             * flag of the other parity is cleared while this one is in use (LDS-only barriers: the prefetched operands
+             * stay in flight) */
             for (;;) {
-                s_d[tid] = d;
-                s_p[tid] = ptr;
-                if (__ballot(ptr >= 0) && lane == 0) s_any[anyk] = 1u;
+                bool pend = false;
+#pragma unroll
+                for (int k = 0; k < SPT; k++) {
+                    s_d[(uint32_t)k * W + tid] = (uint16_t)d[k];
+                    s_p[(uint32_t)k * W + tid] = (int16_t)ptr[k];
+                    pend = pend || ptr[k] >= 0;
+                }
+                if (__ballot(pend) && lane == 0) s_any[anyk] = 1u;
                 pw_lds_barrier();
                 const bool any = s_any[anyk] != 0u;
                 if (tid == 0) s_any[anyk ^ 1u] = 0u;
                 anyk ^= 1u;
                 if (!any) break;
-                if (ptr >= 0) {
-                    const uint32_t dn = s_d[ptr];
-                    const int pn = s_p[ptr];
-                    if (pn < 0) { d = dn; ptr = -1; } else ptr = pn;
+#pragma unroll
+                for (int k = 0; k < SPT; k++) {
+                    if (ptr[k] >= 0) {
+                        const uint32_t d1 = s_d[ptr[k]];
+                        const int p1 = s_p[ptr[k]];
+                        if (p1 < 0) { d[k] = d1; ptr[k] = -1; }
+                        else {
+                            const uint32_t d2 = s_d[p1];
+                            const int p2 = s_p[p1];
+                            if (p2 < 0) { d[k] = d2; ptr[k] = -1; } else ptr[k] = p2;
+                        }
+                    }
                 }
                 pw_lds_barrier();
             }
-            /* x's own priority reaches d -- unless x is a carried cell of a later segment (its value comes in through
-             * in[0]).  The chains of a block merge: hundreds of steps of a group reach the same few exit cells, and
-             * same-address atomics queue in the L2 at ~100 cycles each (10 K cycles a group) -- only the lowest step per
-             * exit cell goes out (a 4096-slot table; a slot taken by another cell's step: both go) */
-            const bool want = valid && d != PW_DEAD && x >= ncarried;
-            const uint32_t slot = d & 4095u;
-            if (want) atomicMin(&s_tab[slot], (d << 10) | tid);
-            pw_lds_barrier();
-            if (valid) {
-                uint32_t ix = off_run + tid;
+            /* (every read of the ring by this group came before the loop's first barrier) */
+#pragma unroll
+            for (int k = 0; k < SPT; k++) {
+                const uint32_t li = (uint32_t)k * W + tid;
+                uint32_t ix = off_run + li;
                 ix -= ix >= ring_n ? ring_n : 0u;
-                dr[ix] = (uint16_t)d;
-                if (want) {
-                    const uint32_t e = s_tab[slot];
-                    if ((e >> 10) != d || (e & 1023u) == tid) pw_min_wg(&lb[d], x + voff);
+                if (xg + li < x1) {
+                    dr[ix] = (uint16_t)d[k];
+                    destx[xg - x0 + li] = (uint16_t)d[k];
                 }
             }
             pw_lds_barrier();
-            if (want) s_tab[slot] = 0xFFFFFFFFu;                       /* (the next group's first barrier comes before its first use) */
-        }
 #pragma unroll
-        for (int k = 0; k < SG; k++) { v[k] = vn[k]; gw[k] = gwn[k]; }
+            for (int k = 0; k < SPT; k++) { v[k] = vn[k]; gw[k] = gwn[k]; }
+        }
+        PW_STAMP(2);
+        for (uint32_t i = tid; i < sb; i += W) {
+            /* an entry cell that is not evicted inside a (short, last) block is still live at its end */
+            dest[(size_t)b * rs + i] = x0 + i < x1 ? dr[i] : (uint16_t)(i - (x1 - x0));
+        }
+        /* ---- phase 2: loc.  What reaches exit cell x1+d when nothing older comes in is its own priority -- unless it is a
+         *      carried cell (a short first block of a later segment: its value comes in through in[0]); x's own priority
+         *      reaches its exit cell -- unless x is a carried cell. ---- */
+        pw_fence_wg();                                                 /* the scratch row is written */
+        __syncthreads();
+        {
+            const uint32_t nst = x1 - x0;
+            const uint32_t CH = (ring_n / 2u) & ~3u;                   /* exit cells a pass: the ring's space, 32 bits a cell */
+            const pw_u16x8 *dx8 = reinterpret_cast<const pw_u16x8 *>(destx);
+            for (uint32_t c0 = 0; c0 < sb; c0 += CH) {
+                const uint32_t c1 = min(c0 + CH, sb);
+                for (uint32_t i = tid; i < c1 - c0; i += W) pw_lds[i] = x1 + c0 + i >= ncarried ? x1 + c0 + i + voff : PW_NONE;
+                pw_lds_barrier();
+                for (uint32_t q0 = 0; q0 * 8u < nst; q0 += 4u * W) {
+                    pw_u16x8 dq[4];
+#pragma unroll
+                    for (uint32_t u = 0; u < 4; u++) { uint32_t tq = tid; asm volatile("" : "+v"(tq)); dq[u] = dx8[min(q0 + u * W + tq, (nst - 1u) / 8u)]; }
+#pragma unroll
+                    for (uint32_t u = 0; u < 4; u++) {
+                        const uint32_t l0 = (q0 + u * W + tid) * 8u;
+#pragma unroll
+                        for (uint32_t j = 0; j < 8; j++) {
+                            const uint32_t dj = dq[u][j], li = l0 + j;
+                            if (li < nst && dj - c0 < c1 - c0 && dj != PW_DEAD && x0 + li >= ncarried) atomicMin(&pw_lds[dj - c0], x0 + li + voff);
+                        }
+                    }
+                }
+                pw_lds_barrier();
+                for (uint32_t i = tid; i < c1 - c0; i += W) lb[c0 + i] = pw_lds[i];
+                pw_lds_barrier();
+            }
+        }
+        PW_STAMP(3);
+        if (blockIdx.x == 0 && threadIdx.x == 0) PW_NOTE(4, ngr);
     }
-    PW_STAMP(2);
-    for (uint32_t i = tid; i < sb; i += W) {
-        /* an entry cell that is not evicted inside a (short, last) block is still live at its end */
-        dest[(size_t)b * rs + i] = x0 + i < x1 ? dr[i] : (uint16_t)(i - (x1 - x0));
-    }
-    PW_STAMP(3);
-    if (blockIdx.x == 0 && threadIdx.x == 0) PW_NOTE(4, ngr);
 }
 
 /* ------------------------------------------------------------------ boundary scan ---- */
@@ -968,8 +1020,8 @@ __global__ __launch_bounds__(W) void k_pw_back(const uint32_t *__restrict__ ps, 
 
 /* (rows are 16-byte aligned: four cells a lane per load -- a workgroup's rate is its bytes in flight over the latency,
  * and with one cell a lane a map took 54 us) */
-typedef uint32_t pw_u32x4 __attribute__((ext_vector_type(4)));
-typedef uint16_t pw_u16x4 __attribute__((ext_vector_type(4)));
+
+
 
 /* group g = blockIdx.x applies its maps m0 .. m1-1 (map number m is row `first + m` of dest / loc) in sequence.
  * REPLAY: from row g of vin; row `first + m + 1` of `v` receives the vector after map m.
@@ -1171,18 +1223,34 @@ hipError_t lz77kw_fwd(const uint32_t *d_ps, uint32_t nx, uint32_t sb, uint32_t r
     return hipGetLastError();
 }
 
+uint32_t lz77kw_back_slots(uint32_t ring_n, uint32_t W)
+{
+    /* workgroups that can be resident at once (256 CUs; the ring + the static arrays against 160 KB of LDS), at most four a CU */
+    const size_t per = (size_t)ring_n * 2 + (size_t)W * 4 * 4 + 512;
+    size_t k = (size_t)160 * 1024 / per;
+    k = k < 1 ? 1 : k > 4 ? 4 : k;
+    return (uint32_t)(256u * k);
+}
+
+size_t lz77kw_back_scratch_bytes(uint32_t NB, uint32_t B, uint32_t ring_n, uint32_t W)
+{
+    const uint32_t slots = lz77kw_back_slots(ring_n, W);
+    return (size_t)(NB < slots ? NB : slots) * ((size_t)B + 16u) * 2 + 256;
+}
+
 hipError_t lz77kw_back(const uint32_t *d_ps, uint32_t nx, uint32_t sb, uint32_t rs, uint32_t B, uint32_t ring_n, uint32_t W, uint32_t b_first, uint32_t nb,
                        const uint64_t *d_gates, uint16_t *d_dest, uint32_t *d_loc, uint32_t voff, uint32_t ncarried, const uint32_t *d_gates_changed,
-                       hipStream_t s)
+                       uint16_t *d_destx /* lz77kw_back_scratch_bytes */, hipStream_t s)
 {
     const size_t lds = (size_t)ring_n * 2;
+    const uint32_t slots = lz77kw_back_slots(ring_n, W), grid = nb < slots ? nb : slots;
     hipError_t e;
     if (W == 1024u) {
         if ((e = pw_lds_attr(k_pw_back<1024>, lds)) != hipSuccess) return e;
-        hipLaunchKernelGGL(k_pw_back<1024>, dim3(nb), dim3(1024), lds, s, d_ps, nx, sb, rs, B, ring_n, b_first, d_gates, d_dest, d_loc, voff, ncarried, d_gates_changed);
+        hipLaunchKernelGGL(k_pw_back<1024>, dim3(grid), dim3(1024), lds, s, d_ps, nx, sb, rs, B, ring_n, b_first, nb, d_gates, d_dest, d_loc, voff, ncarried, d_gates_changed, d_destx);
     } else {
         if ((e = pw_lds_attr(k_pw_back<256>, lds)) != hipSuccess) return e;
-        hipLaunchKernelGGL(k_pw_back<256>, dim3(nb), dim3(256), lds, s, d_ps, nx, sb, rs, B, ring_n, b_first, d_gates, d_dest, d_loc, voff, ncarried, d_gates_changed);
+        hipLaunchKernelGGL(k_pw_back<256>, dim3(grid), dim3(256), lds, s, d_ps, nx, sb, rs, B, ring_n, b_first, nb, d_gates, d_dest, d_loc, voff, ncarried, d_gates_changed, d_destx);
     }
     return hipGetLastError();
 }

@@ -1982,7 +1982,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80))) void k_to
                                                            const uint8_t *__restrict__ maxlen, const uint32_t *__restrict__ ofs,
                                                            const uint2 *__restrict__ ent, uint32_t dbase, uint32_t *__restrict__ tokval,
                                                            const uint32_t *__restrict__ look, uint32_t nlook, uint32_t voff,
-                                                           uint32_t whole_order, sx_index X)
+                                                           uint32_t whole_order, sx_index X,
+                                                           uint32_t probe /* variants build, timing only (wrong output): 1 no deferred tokens, 2 no bucket tokens, 4 no long runs */)
 {
     constexpr uint32_t H = LPT / 2, TPW = 64 / LPT;
     const uint32_t lane = threadIdx.x & 63;
@@ -2007,7 +2008,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80))) void k_to
     const bool whole_wave = len == 1 && X.off_c;                           /* the buckets: all 64 lanes, below */
     bool open = valid && len > 0 && !whole_wave;                           /* my direction of my token */
     uint64_t best = ~0ull;
-    for (uint32_t r = 0; r < RANKG_ROUNDS && __ballot(open); r++) {
+    constexpr uint32_t NROUNDS = LPT == 4 ? 2u * RANKG_ROUNDS : RANKG_ROUNDS;
+    for (uint32_t r = 0; r < NROUNDS && __ballot(open); r++) {
         const uint32_t d = 1u + r * H + sub;
         const bool live = open && (up ? ry + d < R : d <= ry);
         uint32_t e = 0;
@@ -2054,7 +2056,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80))) void k_to
         const uint32_t omask = ob >= 32 ? 0xFFFFFFFFu : (1u << ob) - 1u;
         tokval[k] = (off & omask) | (len << ob) | (next << (ob + lb));
     }
-    for (uint64_t dm = __ballot(defer && gl == 0 && valid); dm; dm &= dm - 1) {
+    uint64_t dm = __ballot(defer && gl == 0 && valid);
+#ifdef LZ77X_VARIANTS
+    if (probe & 1u) dm = 0;
+    if (probe & 2u) dm &= ~__ballot(whole_wave);
+    if (probe & 4u) dm &= __ballot(whole_wave);
+#endif
+    for (; dm; dm &= dm - 1) {
         const uint32_t kd = (uint32_t)__builtin_amdgcn_readlane((int)k, __builtin_ctzll(dm));
         rank_token(kd, lane, in, n, sb, ob, lb, RP, TILE, ranks_all, chain, maxlen, ofs, ent, dbase, tokval, look, nlook, voff, whole_order, X);
     }
@@ -2124,10 +2132,11 @@ hipError_t lz77k_tokens(const uint8_t *d_in, uint32_t n, const lz77x_geom &g, co
                 hipLaunchKernelGGL(k_tokens_rank, dim3((ntok + 3) / 4), dim3(256), 0, s, d_in, n, g.sb, g.ob, g.lb, g.RP, g.TILE, d_ranks_all,
                                    d_chain, ntok, d_maxlen, d_ofs, d_ent, dbase, d_tokval, d_look, nlook, voff, (uint32_t)lz77k_big_sort_shared(g), X);
             else {
-                const uint32_t tpw = 64u / (lpt == 8 ? 8u : 16u), waves = (ntok + tpw - 1u) / tpw;
-                auto fn = lpt == 8 ? k_tokens_rank_group<8> : k_tokens_rank_group<16>;
+                const uint32_t tpw = 64u / (lpt == 8 ? 8u : lpt == 4 ? 4u : 16u), waves = (ntok + tpw - 1u) / tpw;
+                auto fn = lpt == 8 ? k_tokens_rank_group<8> : lpt == 4 ? k_tokens_rank_group<4> : k_tokens_rank_group<16>;
                 hipLaunchKernelGGL(fn, dim3((waves + 3u) / 4u), dim3(256), 0, s, d_in, n, g.sb, g.ob, g.lb, g.RP, g.TILE, d_ranks_all, d_chain, ntok,
-                                   d_maxlen, d_ofs, d_ent, dbase, d_tokval, d_look, nlook, voff, (uint32_t)lz77k_big_sort_shared(g), X);
+                                   d_maxlen, d_ofs, d_ent, dbase, d_tokval, d_look, nlook, voff, (uint32_t)lz77k_big_sort_shared(g), X,
+                                   LZ77X_VENV("LZ77X_RANK_PROBE") ? (uint32_t)atoi(LZ77X_VENV("LZ77X_RANK_PROBE")) : 0u);
             }
         }
         TIE_EV(1);

@@ -147,6 +147,7 @@ struct lz77k_prio_plan {
     bool pack18 = false;      /* W > 64: the ring holds 18-bit codes (rank of an old value | block-local position), not priorities */
     size_t o_gate[2] = {0, 0}, o_rmask = 0, o_cmask = 0, o_dest = 0, o_loc = 0, o_in = 0, o_gdest = 0, o_gloc = 0, o_gin = 0, o_sum = 0, o_dirty = 0, total = 0;
     size_t o_g2dest = 0, o_g2loc = 0, o_g2in = 0;                  /* sb <= 4096: the groups of groups of the boundary scan */
+    size_t o_destx = 0;                                            /* W > 64: the backward sweep's scratch rows (every step's exit cell, a row per resident workgroup) */
     size_t o_codes = 0, o_gval = 0, o_scan = 0, o_inprev = 0;      /* pack18: per-block rows entry cell -> code, rank -> value; sb > 4096: the HBM scan's running pairs */
     int cur = 0;              /* gate buffer the next maps/sweep read */
     uint32_t sweeps = 0;      /* sweeps so far (the first one visits every block) */
@@ -165,7 +166,8 @@ hipError_t lz77kw_fwd(const uint32_t *d_ps, uint32_t nx, uint32_t sb, uint32_t r
                       uint32_t *d_in_prev, uint32_t have_prev, uint32_t *d_gates_changed, hipStream_t s);
 hipError_t lz77kw_back(const uint32_t *d_ps, uint32_t nx, uint32_t sb, uint32_t rs, uint32_t B, uint32_t ring_n, uint32_t W, uint32_t b_first, uint32_t nb,
                        const uint64_t *d_gates, uint16_t *d_dest, uint32_t *d_loc, uint32_t voff, uint32_t ncarried, const uint32_t *d_gates_changed,
-                       hipStream_t s);
+                       uint16_t *d_destx, hipStream_t s);
+size_t lz77kw_back_scratch_bytes(uint32_t NB, uint32_t B, uint32_t ring_n, uint32_t W);
 size_t lz77kw_scan_tmp_bytes(uint32_t NG, uint32_t rs);
 hipError_t lz77kw_compose_all(const uint16_t *d_dest, const uint32_t *d_loc, uint32_t sb, uint32_t rs, uint32_t nmaps, uint32_t G,
                               uint16_t *d_gdest, uint32_t *d_gloc, void *d_tmp, hipStream_t s);

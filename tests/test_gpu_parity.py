@@ -481,7 +481,8 @@ def test_large_window_sort_variants_agree(sortv, sb, la, monkeypatch):
 
 
 @pytest.mark.parametrize("env", [{}, {"LZ77X_BIG_SORT_V1": "1"}, {"LZ77X_WALK_BIG_V1": "1"}, {"LZ77X_WALK_RUN_WAVE": "1024"},
-                                 {"LZ77X_WALK_RUN_WAVE": "65536"}, {"LZ77X_CHUNK_REGIONS": "1"}, {"LZ77X_CHUNK_REGIONS": "3"}])
+                                 {"LZ77X_WALK_RUN_WAVE": "65536"}, {"LZ77X_CHUNK_REGIONS": "1"}, {"LZ77X_CHUNK_REGIONS": "3"},
+                                 {"LZ77X_WALK_FRINGE_V4": "1"}])
 @pytest.mark.parametrize("sb,la,kind,n", [(65535, 255, "mixed", 1_300_000), (65530, 100, "text", 900_000), (65535, 16, "lowent", 350_000),
                                           (65535, 255, "records", 600_000), (20000, 40, "mixed", 800_000), (32768, 255, "text", 700_000),
                                           (16385, 15, "lowent", 500_000), (49999, 200, "mixed", 900_000)])
@@ -490,7 +491,8 @@ def test_large_window_shared_sort_and_wave_walkers(env, sb, la, kind, n, monkeyp
     overlapping regions (16 K chunks in LDS once, grid-wide merge levels; a region's order then also holds the
     positions past its own TILE + sb) and the wavefront-per-run walkers with the rank bitmap in LDS, against the
     per-region sort kernel / the per-lane global-bitmap walkers, for several launch shapes (one region per launch:
-    every region is the first and the last of its launch) -- all equal to the reference stream"""
+    every region is the first and the last of its launch; LZ77X_WALK_FRINGE_V4: the all-to-all fringe of rounds 3-4
+    beside round 5's local ranks and 128-bit windows) -- all equal to the reference stream"""
     data = synth.make(kind, n, 89)
     want = O.encode_bst(data, sb, la)
     for k, v in env.items():
