@@ -1834,11 +1834,14 @@ __device__ __forceinline__ void rank_token(uint32_t k, const uint32_t lane, cons
                                            uint32_t *__restrict__ tokval, const uint32_t *__restrict__ look, uint32_t nlook, uint32_t voff,
                                            uint32_t whole_order /* the order holds every position < n of the region's RP slots
                                                                    (lz77k_big_sort_shared), not only its first R */,
-                                           const sx_index &X /* off_c == null: no index, length-1 tokens walk like the others */)
+                                           const sx_index &X /* off_c == null: no index, length-1 tokens walk like the others */,
+                                           bool known = false, uint32_t kp = 0, uint32_t klen = 0, uint32_t knext = 0, uint32_t kry = 0
+                                           /* known: the caller has the token's position, length, next byte and rank (k_tokens_rank_group:
+                                              four dependent round trips a deferred token need not repeat) */)
 {
-    const uint32_t p = chain[k];
-    const uint32_t len = maxlen[p];
-    const uint32_t next = in[p + len];
+    const uint32_t p = known ? kp : chain[k];
+    const uint32_t len = known ? klen : maxlen[p];
+    const uint32_t next = known ? knext : in[p + len];
     const uint32_t usb = (uint32_t)sb;
     uint32_t off = 0;
     if (len == 1 && X.off_c) {
@@ -1850,7 +1853,7 @@ __device__ __forceinline__ void rank_token(uint32_t k, const uint32_t lane, cons
         const uint32_t R = (rend < n ? (uint32_t)rend : n) - t0;            /* ranks [0, R) are sorted positions */
         const uint32_t *rk = ranks_all + (size_t)reg * (2 * (size_t)RP + 8), *ix = rk + RP + 8;
         const uint8_t *by = in + t0, *q = in + p;
-        const uint32_t ry = rk[ly];
+        const uint32_t ry = known ? kry : rk[ly];
         const bool up = lane >= 32;
         const uint32_t sub = lane & 31;
         bool open_dn = true, open_up = true;                             /* wave-uniform */
@@ -2008,8 +2011,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80))) void k_to
     const bool whole_wave = len == 1 && X.off_c;                           /* the buckets: all 64 lanes, below */
     bool open = valid && len > 0 && !whole_wave;                           /* my direction of my token */
     uint64_t best = ~0ull;
-    constexpr uint32_t NROUNDS = LPT == 4 ? 2u * RANKG_ROUNDS : RANKG_ROUNDS;
-    for (uint32_t r = 0; r < NROUNDS && __ballot(open); r++) {
+    for (uint32_t r = 0; r < RANKG_ROUNDS && __ballot(open); r++) {
         const uint32_t d = 1u + r * H + sub;
         const bool live = open && (up ? ry + d < R : d <= ry);
         uint32_t e = 0;
@@ -2063,8 +2065,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80))) void k_to
     if (probe & 4u) dm &= __ballot(whole_wave);
 #endif
     for (; dm; dm &= dm - 1) {
-        const uint32_t kd = (uint32_t)__builtin_amdgcn_readlane((int)k, __builtin_ctzll(dm));
-        rank_token(kd, lane, in, n, sb, ob, lb, RP, TILE, ranks_all, chain, maxlen, ofs, ent, dbase, tokval, look, nlook, voff, whole_order, X);
+        const int src = __builtin_ctzll(dm);
+        const uint32_t kd = (uint32_t)__builtin_amdgcn_readlane((int)k, src);
+        rank_token(kd, lane, in, n, sb, ob, lb, RP, TILE, ranks_all, chain, maxlen, ofs, ent, dbase, tokval, look, nlook, voff, whole_order, X, true,
+                   (uint32_t)__builtin_amdgcn_readlane((int)p, src), (uint32_t)__builtin_amdgcn_readlane((int)len, src),
+                   (uint32_t)__builtin_amdgcn_readlane((int)next, src), (uint32_t)__builtin_amdgcn_readlane((int)ry, src));
     }
 }
 
@@ -2132,8 +2137,8 @@ hipError_t lz77k_tokens(const uint8_t *d_in, uint32_t n, const lz77x_geom &g, co
                 hipLaunchKernelGGL(k_tokens_rank, dim3((ntok + 3) / 4), dim3(256), 0, s, d_in, n, g.sb, g.ob, g.lb, g.RP, g.TILE, d_ranks_all,
                                    d_chain, ntok, d_maxlen, d_ofs, d_ent, dbase, d_tokval, d_look, nlook, voff, (uint32_t)lz77k_big_sort_shared(g), X);
             else {
-                const uint32_t tpw = 64u / (lpt == 8 ? 8u : lpt == 4 ? 4u : 16u), waves = (ntok + tpw - 1u) / tpw;
-                auto fn = lpt == 8 ? k_tokens_rank_group<8> : lpt == 4 ? k_tokens_rank_group<4> : k_tokens_rank_group<16>;
+                const uint32_t tpw = 64u / (lpt == 8 ? 8u : 16u), waves = (ntok + tpw - 1u) / tpw;
+                auto fn = lpt == 8 ? k_tokens_rank_group<8> : k_tokens_rank_group<16>;
                 hipLaunchKernelGGL(fn, dim3((waves + 3u) / 4u), dim3(256), 0, s, d_in, n, g.sb, g.ob, g.lb, g.RP, g.TILE, d_ranks_all, d_chain, ntok,
                                    d_maxlen, d_ofs, d_ent, dbase, d_tokval, d_look, nlook, voff, (uint32_t)lz77k_big_sort_shared(g), X,
                                    LZ77X_VENV("LZ77X_RANK_PROBE") ? (uint32_t)atoi(LZ77X_VENV("LZ77X_RANK_PROBE")) : 0u);
