@@ -852,6 +852,8 @@ __global__ __launch_bounds__(W) void k_pw_back(const uint32_t *__restrict__ ps, 
     __shared__ uint32_t s_any[2];
     uint16_t *dr = reinterpret_cast<uint16_t *>(pw_lds);               /* ring_n entries */
     const uint32_t tid = threadIdx.x, wave = tid >> 6, lane = tid & 63u;
+    /* (a group must fit the ring: small windows under LZ77X_PRIO_WIDE take fewer steps a thread) */
+    const uint32_t spt = min((uint32_t)SPT, ring_n / (uint32_t)W), gwr = spt * (uint32_t)W;
     uint16_t *destx = destx_all + (size_t)blockIdx.x * ((size_t)B + 16u);
     uint32_t anyk = 0;                                                 /* parity of the "anything pending" flag in use */
     if (tid < 2) s_any[tid] = 0;
@@ -869,13 +871,13 @@ __global__ __launch_bounds__(W) void k_pw_back(const uint32_t *__restrict__ ps, 
         /* ---- phase 1: groups of GW steps from the last to the first, a thread SPT of them (before: W steps a group, one
          *      hop a round).  The chains inside a group are followed by pointer jumping through LDS, two hops a round: a
          *      pointer triples its reach. ---- */
-        const uint32_t ngr = (x1 - x0 + GW - 1u) / GW;
+        const uint32_t ngr = (x1 - x0 + gwr - 1u) / gwr;
         const uint32_t xlast = x1 - 1u;
-        uint32_t off_run = (uint32_t)(((uint64_t)ngr * GW) % ring_n);
+        uint32_t off_run = (uint32_t)(((uint64_t)ngr * gwr) % ring_n);
         uint32_t v[SPT], vn[SPT];
         uint64_t gw[SPT], gwn[SPT];
         auto fetch = [&](int32_t gi, uint32_t (&vv)[SPT], uint64_t (&gg)[SPT]) {       /* unconditional, clamped loads (see k_prio_fwd) */
-            const uint32_t xs = x0 + (uint32_t)(gi < 0 ? 0 : gi) * GW;
+            const uint32_t xs = x0 + (uint32_t)(gi < 0 ? 0 : gi) * gwr;
 #pragma unroll
             for (int k = 0; k < SPT; k++) {
                 vv[k] = ps[min(xs + (uint32_t)k * W + tid, xlast)];
@@ -885,22 +887,22 @@ __global__ __launch_bounds__(W) void k_pw_back(const uint32_t *__restrict__ ps, 
         fetch((int32_t)ngr - 1, v, gw);
         for (int32_t gi = (int32_t)ngr - 1; gi >= 0; gi--) {
             fetch(gi - 1, vn, gwn);
-            const uint32_t xg = x0 + (uint32_t)gi * GW;
-            off_run = off_run >= GW ? off_run - GW : off_run + ring_n - GW;                /* = (xg - x0) % ring_n */
+            const uint32_t xg = x0 + (uint32_t)gi * gwr;
+            off_run = off_run >= gwr ? off_run - gwr : off_run + ring_n - gwr;                /* = (xg - x0) % ring_n */
             uint32_t d[SPT];
             int ptr[SPT];
 #pragma unroll
             for (int k = 0; k < SPT; k++) {
                 const uint32_t li = (uint32_t)k * W + tid, x = xg + li;
-                const bool valid = x < x1;
+                const bool valid = x < x1 && (uint32_t)k < spt;
                 const uint32_t sk = (valid ? v[k] : 0u) >> 16;
                 const bool gate = valid && xg + (uint32_t)k * W + 64u * wave < x1 && ((gw[k] >> lane) & 1ull);
                 const uint32_t t = x + sk;
-                uint32_t it = off_run + li + (gate ? sk : 0u);
+                uint32_t it = valid ? off_run + li + (gate ? sk : 0u) : 0u;
                 it -= it >= ring_n ? ring_n : 0u;
                 it -= it >= ring_n ? ring_n : 0u;
                 const uint32_t dring = dr[it];
-                const bool past = t >= x1, near = t < xg + GW;
+                const bool past = t >= x1, near = t < xg + gwr;
                 d[k] = !gate ? (uint32_t)PW_DEAD : past ? t - x1 : near ? (uint32_t)PW_DEAD : dring;
                 ptr[k] = gate && !past && near ? (int)(t - xg) : -1;
             }
@@ -942,7 +944,7 @@ __global__ __launch_bounds__(W) void k_pw_back(const uint32_t *__restrict__ ps, 
                 const uint32_t li = (uint32_t)k * W + tid;
                 uint32_t ix = off_run + li;
                 ix -= ix >= ring_n ? ring_n : 0u;
-                if (xg + li < x1) {
+                if (xg + li < x1 && (uint32_t)k < spt) {
                     dr[ix] = (uint16_t)d[k];
                     destx[xg - x0 + li] = (uint16_t)d[k];
                 }
@@ -1114,16 +1116,35 @@ __global__ __launch_bounds__(PW_MAP_T) void k_pw_maps(const uint16_t *__restrict
 __global__ __launch_bounds__(PW_SCAN_T) void k_pw_cdest(const uint16_t *__restrict__ dest, uint32_t sb, uint32_t rs, uint32_t first, uint32_t nmaps, uint32_t G,
                                                         uint16_t *__restrict__ gdest)
 {
+    /* (round 5: the map's row goes through LDS -- it is in registers one map ahead, a gather is 128 LDS reads a thread; out
+     * of the L2 a map was 15 us of dependent 2-byte reads) */
+    extern __shared__ uint32_t pw_lds[];
+    const uint16_t *row = reinterpret_cast<const uint16_t *>(pw_lds);
+    pw_u32x4 *row4 = reinterpret_cast<pw_u32x4 *>(pw_lds);
     const uint32_t g = blockIdx.x, tid = threadIdx.x;
     const uint32_t m0 = g * G, m1 = min(m0 + G, nmaps);
     if (m0 >= m1) return;
+    constexpr uint32_t NQ = 65536u * 2u / 16u / PW_SCAN_T;   /* 16-byte pieces of a row a thread (rs <= 65536) */
+    const uint32_t nq4 = rs / 8u;                            /* (rs is a multiple of 8) */
     uint32_t cd[PW_SCAN_EPT];
 #pragma unroll
     for (uint32_t q = 0; q < PW_SCAN_EPT; q++) cd[q] = q * PW_SCAN_T + tid < sb ? q * PW_SCAN_T + tid : (uint32_t)PW_DEAD;
-    for (uint32_t m = m0; m < m1; m++) {
-        const uint16_t *dj = dest + ((size_t)first + m) * rs;
+    pw_u32x4 pre[NQ];
+    auto load_row = [&](uint32_t m) {
+        const pw_u32x4 *dj4 = reinterpret_cast<const pw_u32x4 *>(dest + ((size_t)first + m) * rs);
 #pragma unroll
-        for (uint32_t q = 0; q < PW_SCAN_EPT; q++) cd[q] = cd[q] == PW_DEAD ? (uint32_t)PW_DEAD : (uint32_t)dj[min(cd[q], sb - 1u)];
+        for (uint32_t k = 0; k < NQ; k++) { uint32_t tq = tid; asm volatile("" : "+v"(tq)); pre[k] = dj4[min(tq + k * PW_SCAN_T, nq4 - 1u)]; }
+    };
+    load_row(m0);
+    for (uint32_t m = m0; m < m1; m++) {
+#pragma unroll
+        for (uint32_t k = 0; k < NQ; k++)
+            if (tid + k * PW_SCAN_T < nq4) row4[tid + k * PW_SCAN_T] = pre[k];
+        if (m + 1u < m1) load_row(m + 1u);
+        pw_lds_barrier();
+#pragma unroll
+        for (uint32_t q = 0; q < PW_SCAN_EPT; q++) cd[q] = cd[q] == PW_DEAD ? (uint32_t)PW_DEAD : (uint32_t)row[min(cd[q], sb - 1u)];
+        pw_lds_barrier();
     }
 #pragma unroll
     for (uint32_t q = 0; q < PW_SCAN_EPT; q++)
@@ -1276,6 +1297,7 @@ hipError_t lz77kw_compose_all(const uint16_t *d_dest, const uint32_t *d_loc, uin
     const size_t lds = (size_t)PW_MAP_HALF * 4;
     hipError_t e;
     if ((e = pw_lds_attr(k_pw_maps<false>, lds)) != hipSuccess) return e;
+    if ((e = pw_lds_attr(k_pw_cdest, (size_t)rs * 2)) != hipSuccess) return e;
     uint32_t G2 = 1;
     while ((uint64_t)G2 * G2 < NG) G2++;
     const size_t NG2 = (NG + G2 - 1) / G2 + 6;              /* (the layout of lz77kw_scan_tmp_bytes) */
@@ -1284,10 +1306,10 @@ hipError_t lz77kw_compose_all(const uint16_t *d_dest, const uint32_t *d_loc, uin
     uint32_t *rows2 = rows1 + (size_t)2 * NG * rs;
     uint16_t *out_dest = d_gdest + (size_t)(NG + 1u) * rs;
     uint32_t *out_loc = d_gloc + (size_t)(NG + 1u) * rs;
-    hipLaunchKernelGGL(k_pw_cdest, dim3(NG), dim3(PW_SCAN_T), 0, s, d_dest, sb, rs, 0u, nmaps, G, d_gdest);
+    hipLaunchKernelGGL(k_pw_cdest, dim3(NG), dim3(PW_SCAN_T), (size_t)rs * 2, s, d_dest, sb, rs, 0u, nmaps, G, d_gdest);
     hipLaunchKernelGGL(k_pw_maps<false>, dim3(NG), dim3(PW_MAP_T), lds, s, d_dest, d_loc, sb, rs, 0u, nmaps, G, (const uint32_t *)nullptr, d_gloc, rows1);
     /* the NG group maps (rows 0 .. NG-1 of gdest / gloc) in sequence */
-    hipLaunchKernelGGL(k_pw_cdest, dim3(1), dim3(PW_SCAN_T), 0, s, d_gdest, sb, rs, 0u, NG, NG, out_dest);
+    hipLaunchKernelGGL(k_pw_cdest, dim3(1), dim3(PW_SCAN_T), (size_t)rs * 2, s, d_gdest, sb, rs, 0u, NG, NG, out_dest);
     hipLaunchKernelGGL(k_pw_maps<false>, dim3(1), dim3(PW_MAP_T), lds, s, d_gdest, d_gloc, sb, rs, 0u, NG, NG, (const uint32_t *)nullptr, out_loc, rows2);
     return hipGetLastError();
 }
@@ -1305,6 +1327,7 @@ hipError_t lz77kw_scan(const uint16_t *d_dest, const uint32_t *d_loc, uint32_t *
     hipError_t e;
     if ((e = pw_lds_attr(k_pw_maps<true>, lds)) != hipSuccess) return e;
     if ((e = pw_lds_attr(k_pw_maps<false>, lds)) != hipSuccess) return e;
+    if ((e = pw_lds_attr(k_pw_cdest, (size_t)rs * 2)) != hipSuccess) return e;
     const uint32_t *vin = d_in + (size_t)first * rs;
     if (NG > 1) {
         /* workspace: [second level: gloc2, gin2, gdest2] [compose rows of this level] [compose rows of the second level] */
@@ -1318,7 +1341,7 @@ hipError_t lz77kw_scan(const uint16_t *d_dest, const uint32_t *d_loc, uint32_t *
         uint32_t *rows1 = reinterpret_cast<uint32_t *>(t + ((NG2 * rs * 10 + 255) & ~(size_t)255));
         uint32_t *rows2 = rows1 + (size_t)2 * NG * rs;
         /* the groups' composed maps (the last group's is nobody's input) */
-        hipLaunchKernelGGL(k_pw_cdest, dim3(NG - 1u), dim3(PW_SCAN_T), 0, s, d_dest, sb, rs, first, nmaps, G, d_gdest);
+        hipLaunchKernelGGL(k_pw_cdest, dim3(NG - 1u), dim3(PW_SCAN_T), (size_t)rs * 2, s, d_dest, sb, rs, first, nmaps, G, d_gdest);
         hipLaunchKernelGGL(k_pw_maps<false>, dim3(NG - 1u), dim3(PW_MAP_T), lds, s, d_dest, d_loc, sb, rs, first, nmaps, G, (const uint32_t *)nullptr, d_gloc, rows1);
         /* gin[0] = in[first]; gin[g+1] = group map g applied to gin[g] */
         if ((e = hipMemcpyAsync(d_gin, d_in + (size_t)first * rs, (size_t)sb * 4, hipMemcpyDeviceToDevice, s)) != hipSuccess) return e;
@@ -1326,7 +1349,7 @@ hipError_t lz77kw_scan(const uint16_t *d_dest, const uint32_t *d_loc, uint32_t *
             /* the group maps scanned the same way, one level up */
             const uint32_t n2 = NG - 1u, NGG = (n2 + G2 - 1u) / G2;
             if (NGG > 1) {
-                hipLaunchKernelGGL(k_pw_cdest, dim3(NGG - 1u), dim3(PW_SCAN_T), 0, s, d_gdest, sb, rs, 0u, n2, G2, gdest2);
+                hipLaunchKernelGGL(k_pw_cdest, dim3(NGG - 1u), dim3(PW_SCAN_T), (size_t)rs * 2, s, d_gdest, sb, rs, 0u, n2, G2, gdest2);
                 hipLaunchKernelGGL(k_pw_maps<false>, dim3(NGG - 1u), dim3(PW_MAP_T), lds, s, d_gdest, d_gloc, sb, rs, 0u, n2, G2, (const uint32_t *)nullptr, gloc2, rows2);
                 if ((e = hipMemcpyAsync(gin2, d_gin, (size_t)sb * 4, hipMemcpyDeviceToDevice, s)) != hipSuccess) return e;
                 hipLaunchKernelGGL(k_pw_maps<true>, dim3(1), dim3(PW_MAP_T), lds, s, gdest2, gloc2, sb, rs, 0u, NGG - 1u, NGG - 1u, gin2, gin2, (uint32_t *)nullptr);
