@@ -1783,38 +1783,63 @@ __device__ __forceinline__ uint32_t sx_query(const sx_index &X, uint32_t p, uint
     const uint32_t b = p / usb;
     const uint32_t cmin = p > usb ? p - usb : 0u;
     uint64_t best = ~0ull;
-    {
-        const uint32_t bucket = (b - X.bl0) * 256u + v;
-        for (uint32_t i = X.off_c[bucket] + lane, e = X.off_c[bucket + 1]; i < e; i += 64) {
-            const uint32_t c = X.cells[i].x;
-            if (c < p) {                                                   /* (a cell of block b is never older than p - sb) */
+    /* The four scans, SXU steps of 64 records each with their loads in flight together (a bucket holds ~256 records: one
+     * or two round trips a scan where a load per step made four or five; round 5) */
+    constexpr uint32_t SXU = 4;
+    const uint32_t bk0 = (b - X.bl0) * 256u + v;
+    const bool prev = b > X.bl0;
+    const uint32_t bk1 = prev ? bk0 - 256u : bk0;
+    const uint32_t c0a = X.off_c[bk0], c0e = X.off_c[bk0 + 1], h0a = X.off_h[bk0], h0e = X.off_h[bk0 + 1];
+    const uint32_t c1a = prev ? X.off_c[bk1] : 0u, c1e = prev ? X.off_c[bk1 + 1] : 0u;
+    const uint32_t h1a = prev ? X.off_h[bk1] : 0u, h1e = prev ? X.off_h[bk1 + 1] : 0u;
+    const uint64_t T = (uint64_t)b * usb;
+    for (uint32_t i0 = c0a + lane; i0 < c0e; i0 += 64 * SXU) {
+        uint32_t cc[SXU];
+#pragma unroll
+        for (uint32_t u = 0; u < SXU; u++) cc[u] = X.cells[min(i0 + 64u * u, c0e - 1u)].x;
+#pragma unroll
+        for (uint32_t u = 0; u < SXU; u++) {
+            const uint32_t c = cc[u];
+            if (i0 + 64u * u < c0e && c < p) {                                 /* (a cell of block b is never older than p - sb) */
                 const uint64_t key = ((uint64_t)sx_own(c, look, nlook, voff) << 32) | c;
                 best = key < best ? key : best;
             }
         }
-        for (uint32_t i = X.off_h[bucket] + lane, e = X.off_h[bucket + 1]; i < e; i += 64) {
-            const uint2 t = X.hx[i];
-            if ((uint64_t)t.x + usb < p) {
-                const uint64_t key = ((uint64_t)t.y << 32) | X.hd[i];
+    }
+    for (uint32_t i0 = h0a + lane; i0 < h0e; i0 += 64 * SXU) {
+        uint2 t[SXU];
+        uint32_t d[SXU];
+#pragma unroll
+        for (uint32_t u = 0; u < SXU; u++) { const uint32_t i = min(i0 + 64u * u, h0e - 1u); t[u] = X.hx[i]; d[u] = X.hd[i]; }
+#pragma unroll
+        for (uint32_t u = 0; u < SXU; u++) {
+            if (i0 + 64u * u < h0e && (uint64_t)t[u].x + usb < p) {
+                const uint64_t key = ((uint64_t)t[u].y << 32) | d[u];
                 best = key < best ? key : best;
             }
         }
     }
-    if (b > X.bl0) {
-        const uint32_t bucket = (b - 1u - X.bl0) * 256u + v;
-        const uint64_t T = (uint64_t)b * usb;
-        for (uint32_t i = X.off_c[bucket] + lane, e = X.off_c[bucket + 1]; i < e; i += 64) {
-            const uint2 t = X.cells[i];
-            if (t.x >= cmin) {
-                const uint64_t key = ((uint64_t)t.y << 32) | t.x;
+    for (uint32_t i0 = c1a + lane; i0 < c1e; i0 += 64 * SXU) {
+        uint2 t[SXU];
+#pragma unroll
+        for (uint32_t u = 0; u < SXU; u++) t[u] = X.cells[min(i0 + 64u * u, c1e - 1u)];
+#pragma unroll
+        for (uint32_t u = 0; u < SXU; u++) {
+            if (i0 + 64u * u < c1e && t[u].x >= cmin) {
+                const uint64_t key = ((uint64_t)t[u].y << 32) | t[u].x;
                 best = key < best ? key : best;
             }
         }
-        for (uint32_t i = X.off_h[bucket] + lane, e = X.off_h[bucket + 1]; i < e; i += 64) {
-            const uint2 t = X.hx[i];
-            const uint32_t d = X.hd[i];
-            if ((uint64_t)t.x + usb >= T && (uint64_t)t.x + usb < p && d >= cmin) {
-                const uint64_t key = ((uint64_t)t.y << 32) | d;
+    }
+    for (uint32_t i0 = h1a + lane; i0 < h1e; i0 += 64 * SXU) {
+        uint2 t[SXU];
+        uint32_t d[SXU];
+#pragma unroll
+        for (uint32_t u = 0; u < SXU; u++) { const uint32_t i = min(i0 + 64u * u, h1e - 1u); t[u] = X.hx[i]; d[u] = X.hd[i]; }
+#pragma unroll
+        for (uint32_t u = 0; u < SXU; u++) {
+            if (i0 + 64u * u < h1e && (uint64_t)t[u].x + usb >= T && (uint64_t)t[u].x + usb < p && d[u] >= cmin) {
+                const uint64_t key = ((uint64_t)t[u].y << 32) | d[u];
                 best = key < best ? key : best;
             }
         }
