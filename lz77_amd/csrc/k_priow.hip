@@ -791,7 +791,7 @@ __global__ __launch_bounds__(W) void k_pw_fwd(const uint32_t *__restrict__ ps, u
     if constexpr (PACK) {
         /* the markers of this thread's own stores (x = x0 + tid mod W): rank -> value */
         const uint32_t *gvb = gval + (size_t)b * rs;
-        constexpr int TB = 8;
+        constexpr int TB = 16;
         for (uint32_t xb = x0 + tid; xb < x1; xb += TB * W) {
             uint32_t c[TB];
 #pragma unroll
