@@ -837,7 +837,7 @@ hipError_t lz77k_prio_begin(lz77k_prio_plan &P, const uint32_t *d_ps, uint32_t n
     if (nx == 0) return hipSuccess;
     hipError_t e;
     if (P.W > 64u) {
-        if ((e = lz77kw_prep(d_ps, nx, P.sb_r, P.W, PRIO_PTR(uint64_t, P.o_rmask), PRIO_PTR(uint64_t, P.o_gate[0]), s)) != hipSuccess) return e;
+        if ((e = lz77kw_prep(d_ps, nx, P.sb_r, P.W, PRIO_PTR(uint64_t, P.o_rmask), PRIO_PTR(uint64_t, P.o_gate[0]), PRIO_PTR(uint64_t, P.o_cmask), s)) != hipSuccess) return e;
     } else {
         const uint32_t tagn = P.ring_n + 64u;
         const size_t lds = (size_t)4 * tagn * sizeof(uint32_t);
@@ -991,7 +991,7 @@ hipError_t lz77k_prio_sweep(lz77k_prio_plan &P, hipStream_t s, uint32_t *h_flag,
     }
     if (ev3 && (e = hipEventRecord(ev3[1], s)) != hipSuccess) return e;
     if (P.W > 64u) {
-        if ((e = lz77kw_fwd(P.ps, P.nx, sb, P.rs, P.B, P.ring_n, P.W, first, nb, PRIO_PTR(uint64_t, P.o_rmask), PRIO_PTR(uint64_t, P.o_gate[P.cur]),
+        if ((e = lz77kw_fwd(P.ps, P.nx, sb, P.rs, P.B, P.ring_n, P.W, first, nb, PRIO_PTR(uint64_t, P.o_rmask), PRIO_PTR(uint64_t, P.o_cmask), PRIO_PTR(uint64_t, P.o_gate[P.cur]),
                             PRIO_PTR(uint64_t, P.o_gate[P.cur ^ 1]), in, P.xval, summary, P.voff, d_out_state, P.ncarried,
                             P.pack18 ? PRIO_PTR(uint32_t, P.o_codes) : nullptr, P.pack18 ? PRIO_PTR(uint32_t, P.o_gval) : nullptr,
                             PRIO_PTR(uint32_t, P.o_inprev), have_prev, gates_changed, s)) != hipSuccess)

@@ -108,7 +108,7 @@ __device__ __forceinline__ uint32_t pw_rd16(const uint32_t *tab, uint32_t idx)
  * replaces an older one and nothing is reset between rounds (every 63 rounds the table is cleared). */
 template <int W>
 __global__ __launch_bounds__(W) void k_pw_prep(const uint32_t *__restrict__ ps, uint32_t nx, uint32_t tagn,
-                                               uint64_t *__restrict__ rmask, uint64_t *__restrict__ gate0)
+                                               uint64_t *__restrict__ rmask, uint64_t *__restrict__ gate0, uint64_t *__restrict__ cmask /* no chains here: zeros */)
 {
     extern __shared__ uint32_t pw_tab[];
     __shared__ uint32_t s_first[2];
@@ -162,7 +162,7 @@ __global__ __launch_bounds__(W) void k_pw_prep(const uint32_t *__restrict__ ps, 
         }
         const uint64_t rm = __ballot(isstart), hm = __ballot(has);
         const uint32_t wi = ((g * W) >> 6) + wave;
-        if (lane == 0 && g * W + wave * 64u < nx) { rmask[wi] = rm; gate0[wi] = hm; }
+        if (lane == 0 && g * W + wave * 64u < nx) { rmask[wi] = rm; gate0[wi] = hm; cmask[wi] = 0ull; }
     }
     PW_STAMP(17);
     if (blockIdx.x == 0 && threadIdx.x == 0) { PW_NOTE(18, nrounds_dbg); PW_NOTE(19, (ngroups + gridDim.x - 1) / gridDim.x); }
@@ -180,7 +180,8 @@ __global__ __launch_bounds__(W) void k_pw_prep(const uint32_t *__restrict__ ps, 
 #define PWP_T 256
 template <int W>
 __global__ __launch_bounds__(PWP_T, 8) void k_pw_prep_ranked(const uint32_t *__restrict__ ps, uint32_t nx, uint32_t tagn,
-                                                           uint64_t *__restrict__ rmask, uint64_t *__restrict__ gate0)
+                                                           uint64_t *__restrict__ rmask, uint64_t *__restrict__ gate0,
+                                                           uint64_t *__restrict__ cmask /* steps whose own cell the step before them writes in their round (k_prio.hip, "chains inside a round") */)
 {
     constexpr int ITEMS = W / PWP_T;
     extern __shared__ uint32_t pwp_lds[];
@@ -248,6 +249,7 @@ __global__ __launch_bounds__(PWP_T, 8) void k_pw_prep_ranked(const uint32_t *__r
             r2[q] = has[q] ? rank(c2) : 0u;
         }
         uint32_t isstart = tid == 0 ? 1u : 0u;               /* bit q: item q opens a round */
+        uint32_t islink = 0;                                 /* bit q: item q is a link of a chain inside its round */
         uint32_t start = 0;
         for (;;) {
             const uint32_t code = 0x3FFFFEu - ver;
@@ -258,17 +260,23 @@ __global__ __launch_bounds__(PWP_T, 8) void k_pw_prep_ranked(const uint32_t *__r
             }
             pw_lds_barrier();
             if (tid == 0) s_first[par ^ 1] = W;
-            uint32_t first_mine = W;
+            uint32_t first_mine = W, linked_now = 0;
 #pragma unroll
             for (int q = 0; q < ITEMS; q++) {
                 const uint32_t i = (uint32_t)q * PWP_T + tid;
                 bool blocked = false;
                 if (has[q] && i > start) {
                     const uint32_t t0 = tab[r0[q]], t1 = tab[r1[q]], t2 = tab[r2[q]];
-                    const bool b0 = (t0 >> 10) == code && (t0 & 1023u) < i;
+                    /* the step before this one hands its priority to THIS cell (S[x-1] = 1: runs of equal bytes): not a new
+                     * round -- the sweep resolves such chains with a scan.  One writer per cell and round: a second one would
+                     * read the first one's successor cell and start a round of its own (b2). */
+                    const bool own = (t0 >> 10) == code && (t0 & 1023u) < i;
+                    const bool linked = own && (t0 & 1023u) + 1u == i;
+                    const bool b0 = own && !linked;
                     const bool b1 = (t1 >> 10) == code && (t1 & 1023u) < i;
                     const bool b2 = (t2 >> 10) == code && (t2 & 1023u) < i;
                     blocked = b0 | b1 | b2;
+                    linked_now |= linked ? 1u << q : 0u;
                 }
                 const uint64_t bm = __ballot(blocked);
                 if (bm) first_mine = min(first_mine, (uint32_t)q * PWP_T + wave * 64u + (uint32_t)__builtin_ctzll(bm));
@@ -278,17 +286,26 @@ __global__ __launch_bounds__(PWP_T, 8) void k_pw_prep_ranked(const uint32_t *__r
             const uint32_t first = s_first[par];
             ver++;
             par ^= 1;
+            /* the steps [start, first) are a round; what they saw of each other is final */
+#pragma unroll
+            for (int q = 0; q < ITEMS; q++)
+                if ((uint32_t)q * PWP_T + tid < first) islink |= linked_now & (1u << q);
             if (first >= (uint32_t)W) break;
             start = first;
 #pragma unroll
             for (int q = 0; q < ITEMS; q++)
                 if ((uint32_t)q * PWP_T + tid == first) isstart |= 1u << q;
         }
+        /* (bit 0 of a group's first round-mask word says nothing -- step 0 always opens a round: cleared, it flags a group
+         * with chains, as in k_prio_prep) */
+        const bool any_link = __syncthreads_or(islink != 0u);
 #pragma unroll
         for (int q = 0; q < ITEMS; q++) {
-            const uint64_t rm = __ballot((isstart >> q) & 1u), hm = __ballot(has[q]);
+            uint64_t rm = __ballot((isstart >> q) & 1u);
+            const uint64_t hm = __ballot(has[q]), cm = __ballot((islink >> q) & 1u);
             const uint32_t x0 = g * W + (uint32_t)q * PWP_T + wave * 64u;
-            if (lane == 0 && x0 < nx) { rmask[x0 >> 6] = rm; gate0[x0 >> 6] = hm; }
+            if (any_link && q == 0 && wave == 0) rm &= ~1ull;
+            if (lane == 0 && x0 < nx) { rmask[x0 >> 6] = rm; gate0[x0 >> 6] = hm; cmask[x0 >> 6] = cm; }
         }
     }
 }
@@ -329,6 +346,39 @@ template <> struct pw_ring<true> {
     }
 };
 
+/* chains inside a round (k_prio.hip has the derivation): threshold maps f(a) = a < t ? a : c, closed under composition */
+struct pw_tc { uint32_t t, c; };
+
+__device__ __forceinline__ pw_tc pw_tc_then(pw_tc first, pw_tc second)
+{
+    pw_tc r;
+    r.t = min(first.t, second.t);
+    r.c = second.t < first.t ? second.c : (first.c < second.t ? first.c : second.c);
+    return r;
+}
+
+template <int CTRL, int ROWS>
+__device__ __forceinline__ pw_tc pw_tc_dpp(pw_tc v)
+{
+    /* lanes without a source (or outside the row mask) get the identity (t = 2^32 - 1 passes every value) */
+    pw_tc e;
+    e.t = (uint32_t)__builtin_amdgcn_update_dpp((int)0xFFFFFFFFu, (int)v.t, CTRL, ROWS, 0xF, false);
+    e.c = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v.c, CTRL, ROWS, 0xF, false);
+    return e;
+}
+
+/* inclusive scan over the 64 lanes: lane i <- v[i] o v[i-1] o ... o v[0] */
+__device__ __forceinline__ pw_tc pw_tc_scan(pw_tc v)
+{
+    v = pw_tc_then(pw_tc_dpp<0x111, 0xF>(v), v);          /* row_shr:1 */
+    v = pw_tc_then(pw_tc_dpp<0x112, 0xF>(v), v);          /* row_shr:2 */
+    v = pw_tc_then(pw_tc_dpp<0x114, 0xF>(v), v);          /* row_shr:4 */
+    v = pw_tc_then(pw_tc_dpp<0x118, 0xF>(v), v);          /* row_shr:8 */
+    v = pw_tc_then(pw_tc_dpp<0x142, 0xA>(v), v);          /* row_bcast:15 into rows 1 and 3 */
+    v = pw_tc_then(pw_tc_dpp<0x143, 0xC>(v), v);          /* row_bcast:31 into rows 2 and 3 */
+    return v;
+}
+
 /* the plane word of sixteen consecutive codes c0 .. c0 + 15: their bits 16-17 change at most once, at the multiple of 2^16 */
 __device__ __forceinline__ uint32_t pw_plane_word(uint32_t c0)
 {
@@ -368,7 +418,9 @@ __device__ __forceinline__ uint32_t pw_block_excl(uint32_t v, uint32_t *s_w /* W
  * PACK: codes[b][i] / gval[b][r] are the block's scratch rows (code of entry cell i; value of old rank r). */
 template <int W, bool PACK>
 __global__ __launch_bounds__(W) void k_pw_fwd(const uint32_t *__restrict__ ps, uint32_t nx, uint32_t sb, uint32_t rs /* row stride of in / in_prev / codes / gval */, uint32_t B, uint32_t ring_n,
-                                              uint32_t b_first, const uint64_t *__restrict__ rmask, const uint64_t *__restrict__ gold,
+                                              uint32_t b_first, const uint64_t *__restrict__ rmask,
+                                              const uint64_t *__restrict__ cmask /* steps that are links of a chain inside their round (k_pw_prep_ranked) */,
+                                              const uint64_t *__restrict__ gold,
                                               uint64_t *__restrict__ gnew, const uint32_t *__restrict__ in, uint32_t *__restrict__ xval,
                                               uint32_t *__restrict__ summary, uint32_t voff, uint32_t *__restrict__ out_state,
                                               uint32_t ncarried, uint32_t *__restrict__ codes, uint32_t *__restrict__ gval,
@@ -381,6 +433,7 @@ __global__ __launch_bounds__(W) void k_pw_fwd(const uint32_t *__restrict__ ps, u
     extern __shared__ uint32_t pw_lds[];
     __shared__ uint32_t s_w[W / 64 + 1];
     __shared__ uint32_t s_flip;
+    __shared__ uint32_t s_tc[2 * (W / 64)];                  /* chains inside a round: a wavefront's composed map (t, c) */
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     const uint32_t b = b_first + blockIdx.x;
     const uint32_t x0 = b * B;
@@ -708,6 +761,9 @@ __global__ __launch_bounds__(W) void k_pw_fwd(const uint32_t *__restrict__ ps, u
          * wavefront l mod NW: the counts' prefix sums run along a row of 16 lanes (DPP), this wavefront's word and the
          * rounds before it are two scalar reads -- the loop over NW readlanes with a vector compare against the
          * wavefront number was 100 of a group's 320 instructions, sixteen wavefronts over. */
+        /* (bit 0 of the group's first word: cleared = some round of the group holds a chain) */
+        const bool chains = ((uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)rmk, 0) & 1u) == 0u;
+        rmk |= (lane & (NW - 1u)) == 0u ? 1ull : 0ull;
         const uint32_t pc = (uint32_t)__popcll(rmk);
         uint32_t incl = pc;
         incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x111, 0xF, 0xF, false);      /* row_shr:1 */
@@ -730,6 +786,47 @@ __global__ __launch_bounds__(W) void k_pw_fwd(const uint32_t *__restrict__ ps, u
         uint32_t is = ix + s;
         is -= is >= ring_n ? ring_n : 0u;
         uint32_t ng = 0, out = PW_NONE;
+        if (__builtin_expect(chains, 0)) {
+            /* Round 5 (the run cliff of the large windows: runs of 1000-2000 equal bytes swept 7-13x slower than text).  A step
+             * whose own cell the step before it writes in the same round is a link: along such a chain the step is the
+             * threshold map f(a) = a < min(w, c) ? a : c on ONE value, so the round resolves its chains with a scan of the
+             * maps -- along the wavefront by DPP, across the sixteen wavefronts through 16 pairs in LDS, between the two
+             * barriers a round has anyway -- instead of a round (two barriers) per link.  A step that is no link enters as a
+             * constant map, which cuts off whatever lies to its left. */
+            const uint64_t cmw = cmask[min(xg + 64u * wave, xlast) >> 6];
+            const bool clink = (cmw >> lane) & 1ull;
+            for (uint32_t r = 0; r < nr; r++) {
+                const bool mine = has && myr == r;
+                const bool linked = mine && clink;
+                uint32_t a = 0, w = 0, sv = 0;
+                if (mine) { a = ring.rd(ix); w = ring.rd(ip); sv = ring.rd(is); }
+                pw_tc f;
+                f.t = min(w, sv);
+                f.c = sv;
+                if (!linked) { f.c = a < f.t ? a : f.c; f.t = 0u; }     /* its own cell is what the ring holds: a constant */
+                if (!mine) { f.t = 0u; f.c = 0u; }
+                f = pw_tc_scan(f);
+                if (lane == 63u) { s_tc[2u * wave] = f.t; s_tc[2u * wave + 1u] = f.c; }
+                pw_lds_barrier();                               /* every read of the round is done; the wavefronts' maps are out */
+                uint32_t cin = 0;                               /* what the last step of the wavefront before mine leaves behind */
+                for (uint32_t ww = 0; ww < wave_s; ww++) {
+                    const uint32_t tt = s_tc[2u * ww], tcv = s_tc[2u * ww + 1u];
+                    cin = cin < tt ? cin : tcv;
+                }
+                const uint32_t mine_out = cin < f.t ? cin : f.c;   /* the cell my step leaves behind */
+                uint32_t left = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)mine_out, 0x138 /* wave_shr:1 */, 0xF, 0xF, false);
+                if (lane == 0u) left = cin;
+                if (linked) a = left;
+                bool hand = false;
+                if (mine) {
+                    const bool gate = a < w;
+                    ng = gate ? 1u : 0u;
+                    hand = gate && a < sv;
+                }
+                if (hand) { ring.wr(is, a, sv); out = a; }
+                pw_lds_barrier();
+            }
+        } else
         for (uint32_t r = 0; r < nr; r++) {
             /* a round in two halves: every step of the round reads, then every step writes.  The round masks only
              * split where a step READS what an earlier step of the round writes; a later step of the round may well
@@ -1181,7 +1278,7 @@ template <class K> static hipError_t pw_lds_attr(K kern, size_t lds)
     return hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
 }
 
-hipError_t lz77kw_prep(const uint32_t *d_ps, uint32_t nx, uint32_t sb_r, uint32_t W, uint64_t *d_rmask, uint64_t *d_gate0, hipStream_t s)
+hipError_t lz77kw_prep(const uint32_t *d_ps, uint32_t nx, uint32_t sb_r, uint32_t W, uint64_t *d_rmask, uint64_t *d_gate0, uint64_t *d_cmask, hipStream_t s)
 {
     const uint32_t tagn = sb_r + W;                        /* cells a group can touch, relative to its first step */
     const uint32_t ngroups = (nx + W - 1u) / W;
@@ -1192,10 +1289,10 @@ hipError_t lz77kw_prep(const uint32_t *d_ps, uint32_t nx, uint32_t sb_r, uint32_
         if (W == 1024u) {
             if ((e = pw_lds_attr(k_pw_prep<1024>, lds)) != hipSuccess) return e;
             const uint32_t per_cu = (uint32_t)std::max<size_t>(1, std::min<size_t>(2, ((size_t)160 * 1024) / (lds + 64)));
-            hipLaunchKernelGGL(k_pw_prep<1024>, dim3(std::min(ngroups, 256u * per_cu)), dim3(1024), lds, s, d_ps, nx, tagn, d_rmask, d_gate0);
+            hipLaunchKernelGGL(k_pw_prep<1024>, dim3(std::min(ngroups, 256u * per_cu)), dim3(1024), lds, s, d_ps, nx, tagn, d_rmask, d_gate0, d_cmask);
         } else {
             if ((e = pw_lds_attr(k_pw_prep<256>, lds)) != hipSuccess) return e;
-            hipLaunchKernelGGL(k_pw_prep<256>, dim3(std::min(ngroups, 256u * 8u)), dim3(256), lds, s, d_ps, nx, tagn, d_rmask, d_gate0);
+            hipLaunchKernelGGL(k_pw_prep<256>, dim3(std::min(ngroups, 256u * 8u)), dim3(256), lds, s, d_ps, nx, tagn, d_rmask, d_gate0, d_cmask);
         }
         return hipGetLastError();
     }
@@ -1204,16 +1301,16 @@ hipError_t lz77kw_prep(const uint32_t *d_ps, uint32_t nx, uint32_t sb_r, uint32_
     const uint32_t per_cu = (uint32_t)std::max<size_t>(1, std::min<size_t>(8, ((size_t)160 * 1024) / (lds + 128)));
     if (W == 1024u) {
         if ((e = pw_lds_attr(k_pw_prep_ranked<1024>, lds)) != hipSuccess) return e;
-        hipLaunchKernelGGL(k_pw_prep_ranked<1024>, dim3(std::min(ngroups, 256u * per_cu)), dim3(PWP_T), lds, s, d_ps, nx, tagn, d_rmask, d_gate0);
+        hipLaunchKernelGGL(k_pw_prep_ranked<1024>, dim3(std::min(ngroups, 256u * per_cu)), dim3(PWP_T), lds, s, d_ps, nx, tagn, d_rmask, d_gate0, d_cmask);
     } else {
         if ((e = pw_lds_attr(k_pw_prep_ranked<256>, lds)) != hipSuccess) return e;
-        hipLaunchKernelGGL(k_pw_prep_ranked<256>, dim3(std::min(ngroups, 256u * per_cu)), dim3(PWP_T), lds, s, d_ps, nx, tagn, d_rmask, d_gate0);
+        hipLaunchKernelGGL(k_pw_prep_ranked<256>, dim3(std::min(ngroups, 256u * per_cu)), dim3(PWP_T), lds, s, d_ps, nx, tagn, d_rmask, d_gate0, d_cmask);
     }
     return hipGetLastError();
 }
 
 hipError_t lz77kw_fwd(const uint32_t *d_ps, uint32_t nx, uint32_t sb, uint32_t rs, uint32_t B, uint32_t ring_n, uint32_t W, uint32_t b_first, uint32_t nb,
-                      const uint64_t *d_rmask, const uint64_t *d_gold, uint64_t *d_gnew, const uint32_t *d_in, uint32_t *d_xval,
+                      const uint64_t *d_rmask, const uint64_t *d_cmask, const uint64_t *d_gold, uint64_t *d_gnew, const uint32_t *d_in, uint32_t *d_xval,
                       uint32_t *d_summary, uint32_t voff, uint32_t *d_out_state, uint32_t ncarried, uint32_t *d_codes, uint32_t *d_gval,
                       uint32_t *d_in_prev, uint32_t have_prev, uint32_t *d_gates_changed, hipStream_t s)
 {
@@ -1228,7 +1325,7 @@ hipError_t lz77kw_fwd(const uint32_t *d_ps, uint32_t nx, uint32_t sb, uint32_t r
 #define PW_FWD(WW, PK, LDS)                                                                                                        \
     do {                                                                                                                           \
         if ((e = pw_lds_attr(k_pw_fwd<WW, PK>, (LDS))) != hipSuccess) return e;                                                    \
-        hipLaunchKernelGGL((k_pw_fwd<WW, PK>), dim3(nb), dim3(WW), (LDS), s, d_ps, nx, sb, rs, B, ring_n, b_first, d_rmask, d_gold, d_gnew, \
+        hipLaunchKernelGGL((k_pw_fwd<WW, PK>), dim3(nb), dim3(WW), (LDS), s, d_ps, nx, sb, rs, B, ring_n, b_first, d_rmask, d_cmask, d_gold, d_gnew, \
                            d_in, d_xval, d_summary, voff, d_out_state, ncarried, d_codes, d_gval, sort_cap, probe, d_in_prev, have_prev, d_gates_changed); \
     } while (0)
     if (pack) {
