@@ -733,17 +733,18 @@ __global__ __launch_bounds__(W) void k_pw_fwd(const uint32_t *__restrict__ ps, u
      * k_prio_fwd): a group is about as long as a round trip to HBM under load, one group ahead was not enough */
     constexpr int SG = 4;
     uint32_t v[SG], vn[SG];
-    uint64_t rmw[SG], rmn[SG], gow[SG], gon[SG];
-    auto fetch = [&](uint32_t xs, uint32_t (&vv)[SG], uint64_t (&rr)[SG], uint64_t (&gg)[SG]) {
+    uint64_t rmw[SG], rmn[SG], gow[SG], gon[SG], cmw[SG], cmn[SG];
+    auto fetch = [&](uint32_t xs, uint32_t (&vv)[SG], uint64_t (&rr)[SG], uint64_t (&gg)[SG], uint64_t (&cc)[SG]) {
 #pragma unroll
         for (int k = 0; k < SG; k++) {
             const uint32_t xk = xs + (uint32_t)k * W;
             vv[k] = ps[min(xk + tid, xlast)];
             rr[k] = rmask[min(xk + 64u * (lane & (NW - 1u)), xlast) >> 6];
             gg[k] = gold[min(xk + 64u * wave, xlast) >> 6];
+            cc[k] = cmask[min(xk + 64u * wave_s, xlast) >> 6];          /* (a wave-uniform address: a scalar load) */
         }
     };
-    fetch(x0, v, rmw, gow);
+    fetch(x0, v, rmw, gow, cmw);
     /* One group of W steps.  FULL: every lane has a step -- and every vector-memory operation of the group is
      * unconditional: `s_waitcnt vmcnt` counts loads and stores in ONE order, so a wait for a prefetched operand behind a
      * store whose issue the compiler cannot count (a branch around it) becomes vmcnt(0) and pays the store's round trip
@@ -751,7 +752,7 @@ __global__ __launch_bounds__(W) void k_pw_fwd(const uint32_t *__restrict__ ps, u
      * one group deferred, behind exactly such a wait: 7400 cycles per group, of which the rounds are 2000.  Now an old
      * rank r leaves as the marker PW_RANK0 - r (no priority is that high: positions end at LZ77X_MAX_N, voff <= sb) and
      * every thread translates the markers it wrote itself when the block is through. */
-    auto group = [&](auto full_tag, uint32_t xg, uint32_t vk, uint64_t rmk, uint64_t gok) {
+    auto group = [&](auto full_tag, uint32_t xg, uint32_t vk, uint64_t rmk, uint64_t gok, uint64_t cmk /* my wavefront's chain links */) {
         constexpr bool FULL = decltype(full_tag)::value;
         const uint32_t x = xg + tid;
         const uint32_t vv = FULL || x < x1 ? vk : 0u;
@@ -793,11 +794,11 @@ __global__ __launch_bounds__(W) void k_pw_fwd(const uint32_t *__restrict__ ps, u
              * maps -- along the wavefront by DPP, across the sixteen wavefronts through 16 pairs in LDS, between the two
              * barriers a round has anyway -- instead of a round (two barriers) per link.  A step that is no link enters as a
              * constant map, which cuts off whatever lies to its left. */
-            const uint64_t cmw = cmask[min(xg + 64u * wave, xlast) >> 6];
-            const bool clink = (cmw >> lane) & 1ull;
+            const bool clink = (cmk >> lane) & 1ull;
             for (uint32_t r = 0; r < nr; r++) {
                 const bool mine = has && myr == r;
                 const bool linked = mine && clink;
+                const bool wl = __ballot(linked) != 0ull;       /* links among my wavefront's steps of this round? */
                 uint32_t a = 0, w = 0, sv = 0;
                 if (mine) { a = ring.rd(ix); w = ring.rd(ip); sv = ring.rd(is); }
                 pw_tc f;
@@ -805,18 +806,20 @@ __global__ __launch_bounds__(W) void k_pw_fwd(const uint32_t *__restrict__ ps, u
                 f.c = sv;
                 if (!linked) { f.c = a < f.t ? a : f.c; f.t = 0u; }     /* its own cell is what the ring holds: a constant */
                 if (!mine) { f.t = 0u; f.c = 0u; }
-                f = pw_tc_scan(f);
+                if (wl) f = pw_tc_scan(f);                      /* (without a link every map is a constant: the scan would change nothing) */
                 if (lane == 63u) { s_tc[2u * wave] = f.t; s_tc[2u * wave + 1u] = f.c; }
                 pw_lds_barrier();                               /* every read of the round is done; the wavefronts' maps are out */
-                uint32_t cin = 0;                               /* what the last step of the wavefront before mine leaves behind */
-                for (uint32_t ww = 0; ww < wave_s; ww++) {
-                    const uint32_t tt = s_tc[2u * ww], tcv = s_tc[2u * ww + 1u];
-                    cin = cin < tt ? cin : tcv;
+                if (wl) {
+                    uint32_t cin = 0;                           /* what the last step of the wavefront before mine leaves behind */
+                    for (uint32_t ww = 0; ww < wave_s; ww++) {
+                        const uint32_t tt = s_tc[2u * ww], tcv = s_tc[2u * ww + 1u];
+                        cin = cin < tt ? cin : tcv;
+                    }
+                    const uint32_t mine_out = cin < f.t ? cin : f.c;   /* the cell my step leaves behind */
+                    uint32_t left = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)mine_out, 0x138 /* wave_shr:1 */, 0xF, 0xF, false);
+                    if (lane == 0u) left = cin;
+                    if (linked) a = left;
                 }
-                const uint32_t mine_out = cin < f.t ? cin : f.c;   /* the cell my step leaves behind */
-                uint32_t left = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)mine_out, 0x138 /* wave_shr:1 */, 0xF, 0xF, false);
-                if (lane == 0u) left = cin;
-                if (linked) a = left;
                 bool hand = false;
                 if (mine) {
                     const bool gate = a < w;
@@ -875,15 +878,15 @@ __global__ __launch_bounds__(W) void k_pw_fwd(const uint32_t *__restrict__ ps, u
     uint32_t xs = x0;
     if (!(probe & 1u)) {
         for (; x1 - xs >= SG * W; xs += SG * W) {
-            fetch(xs + SG * W, vn, rmn, gon);
+            fetch(xs + SG * W, vn, rmn, gon, cmn);
 #pragma unroll
-            for (int k = 0; k < SG; k++) group(std::true_type{}, xs + (uint32_t)k * W, v[k], rmw[k], gow[k]);
+            for (int k = 0; k < SG; k++) group(std::true_type{}, xs + (uint32_t)k * W, v[k], rmw[k], gow[k], cmw[k]);
 #pragma unroll
-            for (int k = 0; k < SG; k++) { v[k] = vn[k]; rmw[k] = rmn[k]; gow[k] = gon[k]; }
+            for (int k = 0; k < SG; k++) { v[k] = vn[k]; rmw[k] = rmn[k]; gow[k] = gon[k]; cmw[k] = cmn[k]; }
         }
 #pragma unroll
         for (int k = 0; k < SG; k++)
-            if (xs + (uint32_t)k * W < x1) group(std::false_type{}, xs + (uint32_t)k * W, v[k], rmw[k], gow[k]);   /* (workgroup-uniform) */
+            if (xs + (uint32_t)k * W < x1) group(std::false_type{}, xs + (uint32_t)k * W, v[k], rmw[k], gow[k], cmw[k]);   /* (workgroup-uniform) */
     }
     if constexpr (PACK) {
         /* the markers of this thread's own stores (x = x0 + tid mod W): rank -> value */
