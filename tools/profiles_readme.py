@@ -123,6 +123,20 @@ if w:
             worst["input"] if worst else "", f(worst["ms_per_100MB"], 1) if worst else "", f(v["text_for_scale"]["ms_per_100MB"], 1)))
     rows.append(("`%s_worst_cases.json`" % TAG, "`python tools/worst_cases.py 300`: adversarial families (periods around the lookahead and the window, cut runs, tiny alphabets, "
                  "repeated blocks, text with planted runs) scored by gate iterations and encode ms per 100 MB.  " + "; ".join(parts)))
+try:
+    rc_lines = [json.loads(l) for l in open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "profiles", TAG + "_run_cliff.jsonl")) if l.startswith("{")]
+except OSError:
+    rc_lines = []
+if rc_lines:
+    rows.append(("`%s_run_cliff.jsonl`" % TAG, "`python tools/run_cliff.py 12000000`: runs of equal bytes at both geometries, encode ms per 100 MB (gate iterations): " + "; ".join(
+        "%s `%s` %s (%d)" % (r["geometry"].split()[0], r["input"], f(r["ms_per_100MB"], 0), r["prio_iters"]) for r in rc_lines)))
+fz = None
+try:
+    fz = open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "profiles", TAG + "_fuzz_long.txt")).read().strip().splitlines()[-1]
+except (OSError, IndexError):
+    pass
+if fz:
+    rows.append(("`%s_fuzz_long.txt`" % TAG, "`python tests/gpu_fuzz_long.py 200 <seed>` (shards, stretches, segments, ranges and the host recurrence drawn at random, every case against the oracle): " + fz))
 hr = load(TAG + "_host_rates.json")
 if hr:
     rows.append(("`%s_host_rates.json`" % TAG, "`python tools/host_rates.py` (host buffers, PCIe inclusive, the C calls): " + "; ".join(

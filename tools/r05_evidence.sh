@@ -48,5 +48,12 @@ python tools/rss_probe.py > $out/${tag}_rss_probe.txt 2>&1
 LZ77X_FAKE_DEVICES=8 python bench.py --mode shard --gpus 8 --steps 2 --warmup 1 > $out/${tag}_shard_fake8.json 2> $out/shard.err
 LZ77_BENCH_BACKEND=gloo LZ77X_FAKE_DEVICES=2 python bench.py --gpus 2 --steps 3 --warmup 1 --no-shard-record > $out/${tag}_n2_gloo_one_gpu.json 2> $out/n2.err
 
+# 8. the worst cases on the record, the run cliff of the large windows, an open-ended fuzz (EVIDENCE_QUICK=1 skips them: ~9 minutes)
+if [ -z "$EVIDENCE_QUICK" ]; then
+  timeout 420 python tools/worst_cases.py 240 > $out/${tag}_worst_cases.json 2> $out/worst.err
+  timeout 200 python tools/run_cliff.py 12000000 2>/dev/null | grep "^{" > $out/${tag}_run_cliff.jsonl
+  timeout 260 python tests/gpu_fuzz_long.py 200 6000 2>/dev/null | tail -1 > $out/${tag}_fuzz_long.txt
+fi
+
 rm -rf $out/trace $out/pmc_*/
 ls -la $out
