@@ -113,6 +113,25 @@ k2 = kstats(TAG + "_c2_kernel_stats.csv")
 if k2:
     top = sorted(k2, key=lambda k: -k2[k][2])[:10]
     rows.append(("`%s_c2_kernel_stats.csv`" % TAG, "rocprofv3 kernel stats of one S3 encode (`tools/time_c2.py`), total ms: " + ", ".join("`%s` %s" % (k, f(k2[k][2], 1)) for k in top)))
+try:
+    c2p = list(csv.DictReader(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "profiles", TAG + "_c2_pmc_summary.csv"))))
+except OSError:
+    c2p = []
+if c2p and k2:
+    parts = []
+    for r in c2p[:9]:
+        k = r["kernel"]
+        n = int(r["launches_per_encode_plus_decode"])
+        g = lambda c: float(r.get(c + "_per_launch", 0) or 0)
+        ms = k2.get(k, (0, 0, 0))[2]
+        if not ms:
+            continue
+        hbm = (2 * g("FETCH_SIZE") + g("WRITE_SIZE")) * 1024 * n / 1e9
+        issue = g("SQ_INSTS_VALU") * n * 3.5 / (ms * 1e-3 * 2.4e9 * 1024)
+        wait = g("SQ_WAIT_ANY") / g("SQ_WAVE_CYCLES") if g("SQ_WAVE_CYCLES") else 0
+        parts.append("`%s` %s GB in %s ms (%s TB/s), issue %s, waiting %s" % (k, f(hbm, 1), f(ms, 1), f(hbm / ms, 2), f(issue, 2), f(wait, 2)))
+    rows.append(("`%s_c2_pmc_summary.csv`" % TAG, "`bash tools/c2_pmc.sh`: counters of one S3 encode per kernel and launch, four separate `--pmc` passes.  HBM bytes ((2 x FETCH_SIZE + WRITE_SIZE) x 1024) over the "
+                 "kernel's time in `%s_c2_kernel_stats.csv`, VALU wave instructions x 3.5 cycles over its SIMD-cycles, `SQ_WAIT_ANY / SQ_WAVE_CYCLES`: " % TAG + "; ".join(parts)))
 w = load(TAG + "_worst_cases.json")
 if w:
     parts = []
