@@ -155,6 +155,7 @@ int lz77x_encode_file(FILE *in, FILE *out, int la, int sb)
         TRACE("file -> device -> file", t1);
         trace_allocs("  of which allocations:");
         if (rc || !fallback) return rc;                         /* fallback: the whole (single-segment) input sits in c.in */
+        HIPCHK(hipDeviceSynchronize());                         /* (nothing of the attempt in flight when the other pipeline takes the context over) */
     } else {
         const double t1 = now_ms();
         if ((rc = stream_in(c, in, c.in, LZ77X_PAD + 16, &n))) return rc;

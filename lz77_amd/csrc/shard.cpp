@@ -748,6 +748,8 @@ int encode_any(std::vector<Ctx *> &cs, const void *src, bool src_on_device, size
         size_t nfb = 0;
         const int rc = encode_stream_device(c0, ms, sink, g, s, &fallback, &nfb);
         if (rc != LZ77X_OK || !fallback) return rc;
+        /* (the other pipeline takes the context over: nothing of the attempt may still be in flight on any of its streams) */
+        HIPCHK(hipDeviceSynchronize());
         host_src = c0.in.p;                                /* single segment: the whole input is in c.in */
         host_on_device = true;
         iters = g_stats.prio_iters;
