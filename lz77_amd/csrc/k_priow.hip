@@ -18,9 +18,12 @@
  * sort of the old entry values in LDS before the sweep (the ring's space, not yet in use); what is handed over leaves as
  * a true priority again through a per-block table rank -> value.
  *
- * The backward sweep (the blocks' maps) keeps a uint16 ring of exit cells and sends the per-exit-cell minima to HBM
- * atomically; the boundary scan (k_pw_scan_*) applies a map as one grid-wide launch per step, because two vectors of
- * 65535 priorities do not fit LDS either.
+ * The backward sweep (the blocks' maps) keeps a uint16 ring of exit cells, stores every step's exit cell in a scratch row and
+ * takes the per-exit-cell minima from that row with LDS atomics once the ring is no longer needed (round 5: until then it
+ * sent them to HBM atomically, 80-110 K atomics a block); the boundary scan (k_pw_maps, k_pw_cdest) applies the maps of a
+ * group in sequence, half the cells at a time through LDS, because two vectors of 65535 priorities do not fit LDS either.
+ * Runs of equal bytes (a step whose own cell the step before it writes) are chains inside a round, resolved with a scan of
+ * threshold maps across the workgroup's wavefronts like in k_prio.hip (round 5).
  */
 #include "kernels_common.h"
 #include <stdio.h>
@@ -53,26 +56,13 @@ __device__ __forceinline__ void pw_lds_barrier()
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
-/* Rows that ONE workgroup writes, lowers atomically and reads back within one launch (the blocks' loc rows, the rows of
- * the boundary scan).  Everything stays at WORKGROUP scope: the atomics are performed in the L2 of the workgroup's XCD,
- * where its own loads (sc0: never a line its L1 held from before) and stores meet them; other launches see the rows after
- * the launch boundary.  Agent scope is the wrong tool on this part (eight XCDs, an L2 each): agent-scope atomics and sc1
- * accesses are performed beyond the L2 -- a round trip of several microseconds that every s_waitcnt vmcnt behind them
- * pays -- and an agent-scope fence (__threadfence()) is `buffer_wbl2 sc1` + `buffer_inv sc1`, a write-back and
- * invalidate of the whole L2.  Ordering inside the workgroup: pw_fence_wg (the operations have been performed:
- * s_waitcnt vmcnt(0)) + a barrier. */
-__device__ __forceinline__ uint32_t pw_ld_wg(const uint32_t *p)
-{
-    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-}
-__device__ __forceinline__ void pw_st_wg(uint32_t *p, uint32_t v)
-{
-    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-}
-__device__ __forceinline__ void pw_min_wg(uint32_t *p, uint32_t v)
-{
-    (void)__hip_atomic_fetch_min(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-}
+/* Rows that ONE workgroup writes and reads back within one launch (the scratch row of k_pw_back) stay at WORKGROUP scope: its
+ * own loads and stores meet in the L2 of its XCD; other launches see the rows after the launch boundary.  Agent scope is the
+ * wrong tool on this part (eight XCDs, an L2 each): agent-scope atomics and sc1 accesses are performed beyond the L2 -- a
+ * round trip of several microseconds that every s_waitcnt vmcnt behind them pays -- and an agent-scope fence
+ * (__threadfence()) is `buffer_wbl2 sc1` + `buffer_inv sc1`, a write-back and invalidate of the whole L2.  (Until round 5 the
+ * blocks' loc rows were lowered with workgroup-scope atomics in HBM: ~50 G a second for the whole chip, section 2.2b of
+ * DESIGN.md.)  Ordering inside the workgroup: pw_fence_wg (the operations have been performed: s_waitcnt vmcnt(0)) + a barrier. */
 __device__ __forceinline__ void pw_fence_wg()
 {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
