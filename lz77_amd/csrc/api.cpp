@@ -17,7 +17,7 @@ size_t lz77x_encode_bound(size_t n, int sb, int la)
 }
 
 int lz77x_encode(const uint8_t *in, size_t n, int sb, int la, uint8_t **out, size_t *out_n)
-{
+try {
     if (!out || !out_n || (!in && n)) return LZ77X_E_ARG;
     int rc = check_geom(sb, la);
     if (rc) return rc;
@@ -39,10 +39,10 @@ int lz77x_encode(const uint8_t *in, size_t n, int sb, int la, uint8_t **out, siz
     *out_n = sink.total;
     *out = sink.release();
     return *out ? LZ77X_OK : LZ77X_E_NOMEM;
-}
+} LZ77X_API_CATCH
 
 int lz77x_encode_device(const void *d_in, size_t n, int sb, int la, void *d_out, size_t out_cap, size_t *out_n, void *stream)
-{
+try {
     if (!out_n || (!d_in && n) || !d_out) return LZ77X_E_ARG;
     int rc = check_geom(sb, la);
     if (rc) return rc;
@@ -59,10 +59,10 @@ int lz77x_encode_device(const void *d_in, size_t n, int sb, int la, void *d_out,
     *out_n = sink.total;
     HIPCHK(hipStreamSynchronize(s));
     return sink.total > out_cap ? LZ77X_E_CAP : LZ77X_OK;
-}
+} LZ77X_API_CATCH
 
 int lz77x_decode(const uint8_t *z, size_t zn, uint8_t **out, size_t *out_n)
-{
+try {
     if (!out || !out_n || (!z && zn)) return LZ77X_E_ARG;
     Lease lease;
     Ctx &g_ctx = lease.set->primary;
@@ -89,10 +89,10 @@ int lz77x_decode(const uint8_t *z, size_t zn, uint8_t **out, size_t *out_n)
     *out_n = sink.total;
     *out = sink.release();
     return *out ? LZ77X_OK : LZ77X_E_NOMEM;
-}
+} LZ77X_API_CATCH
 
 int lz77x_decode_device(const void *d_z, size_t zn, void *d_out, size_t out_cap, size_t *out_n, void *stream)
-{
+try {
     if (!out_n || (!d_z && zn)) return LZ77X_E_ARG;
     Lease lease;
     Ctx &g_ctx = lease.set->primary;
@@ -113,11 +113,11 @@ int lz77x_decode_device(const void *d_z, size_t zn, void *d_out, size_t out_cap,
     *out_n = (size_t)n;
     HIPCHK(hipStreamSynchronize(s));
     return n > out_cap ? LZ77X_E_CAP : LZ77X_OK;
-}
+} LZ77X_API_CATCH
 
 /* lz77.h:14 encode(file, out, la, sb) as called at main.c:150 */
 int lz77x_encode_file(FILE *in, FILE *out, int la, int sb)
-{
+try {
     if (!in || !out) return LZ77X_E_ARG;
     int rc = check_geom(sb, la);
     if (rc) return rc;
@@ -169,11 +169,11 @@ int lz77x_encode_file(FILE *in, FILE *out, int la, int sb)
     rc = stream_out(c, out, c.out.p, zn);
     TRACE("device -> file", t3);
     return rc;
-}
+} LZ77X_API_CATCH
 
 /* lz77.h:15 decode(file, out) as called at main.c:161 */
 int lz77x_decode_file(FILE *in, FILE *out)
-{
+try {
     if (!in || !out) return LZ77X_E_ARG;
     Lease lease;
     Ctx &g_ctx = lease.set->primary;
@@ -191,7 +191,7 @@ int lz77x_decode_file(FILE *in, FILE *out)
     TRACE("file -> device -> file (decode)", t1);
     trace_allocs("  of which allocations:");
     return rc;
-}
+} LZ77X_API_CATCH
 
 void lz77x_free(void *p) { free(p); }
 
@@ -286,7 +286,7 @@ static int run_match_only(CtxSet &S, const uint8_t *in, size_t n, int sb, int la
 }
 
 int lz77x_stage_maxlen(const uint8_t *in, size_t n, int sb, int la, uint8_t *maxlen)
-{
+try {
     if ((!in || !maxlen) && n) return LZ77X_E_ARG;
     Lease lease;
     Ctx &g_ctx = lease.set->primary;
@@ -296,10 +296,10 @@ int lz77x_stage_maxlen(const uint8_t *in, size_t n, int sb, int la, uint8_t *max
     if (rc) return rc;
     if (n) HIPCHK(hipMemcpy(maxlen, g_ctx.maxlen.p, n, hipMemcpyDeviceToHost));
     return LZ77X_OK;
-}
+} LZ77X_API_CATCH
 
 int lz77x_stage_neighbours(const uint8_t *in, size_t n, int sb, int la, uint16_t *P, uint16_t *S)
-{
+try {
     if ((!in || !P || !S) && n) return LZ77X_E_ARG;
     Lease lease;
     Ctx &g_ctx = lease.set->primary;
@@ -315,10 +315,10 @@ int lz77x_stage_neighbours(const uint8_t *in, size_t n, int sb, int la, uint16_t
     for (size_t i = 0; i < n; i++) { P[i] = (uint16_t)(tmp[i] & 0xFFFF); S[i] = (uint16_t)(tmp[i] >> 16); }
     free(tmp);
     return LZ77X_OK;
-}
+} LZ77X_API_CATCH
 
 int lz77x_stage_priorities(const uint16_t *P, const uint16_t *S, size_t n, int sb, uint32_t *xval)
-{
+try {
     if ((!P || !S || !xval) && n) return LZ77X_E_ARG;
     if (sb < 1 || sb > 65535) return LZ77X_E_ARG;
     uint32_t *ps = (uint32_t *)malloc((n + 1) * 4);
@@ -334,10 +334,10 @@ int lz77x_stage_priorities(const uint16_t *P, const uint16_t *S, size_t n, int s
     lz77x_prio_free(&st);
     free(ps);
     return LZ77X_OK;
-}
+} LZ77X_API_CATCH
 
 int lz77x_stage_priorities_device(const uint16_t *P, const uint16_t *S, size_t n, int sb, uint32_t *xval, int *iters_out)
-{
+try {
     if ((!P || !S || !xval) && n) return LZ77X_E_ARG;
     if (!lz77k_prio_supported(sb) || n > LZ77X_MAX_N) return LZ77X_E_ARG;
     Lease lease;
@@ -375,10 +375,10 @@ int lz77x_stage_priorities_device(const uint16_t *P, const uint16_t *S, size_t n
     free(ps);
     if (iters_out) *iters_out = converged ? iters : -iters;
     return rc;
-}
+} LZ77X_API_CATCH
 
 int lz77x_stage_chain_device(const uint8_t *maxlen, size_t n, int la, uint32_t *chain, size_t *ntok)
-{
+try {
     if ((!maxlen || !chain) && n) return LZ77X_E_ARG;
     if (!ntok || la < 2 || la > 255 || n > LZ77X_MAX_N) return LZ77X_E_ARG;
     Lease lease;
@@ -399,7 +399,7 @@ int lz77x_stage_chain_device(const uint8_t *maxlen, size_t n, int la, uint32_t *
     if (total) HIPCHK(hipMemcpy(chain, c.chain.p, (size_t)total * 4, hipMemcpyDeviceToHost));
     *ntok = total;
     return LZ77X_OK;
-}
+} LZ77X_API_CATCH
 
 /* several files at once: a thread per file in flight, each leasing its own device context (the lease blocks
  * further threads until a context is free), which is what overlaps the kernels of one file with the host
@@ -420,7 +420,10 @@ static int run_files(int n_files, FILE **in, FILE **out, int la, int sb, int *rc
     { const char *e = getenv("LZ77X_MAX_CONTEXTS"); if (e && atoi(e) > 0) lanes = atoi(e); }
     if (lanes > n_files) lanes = n_files;
     std::vector<std::thread> th;
-    for (int t = 1; t < lanes; t++) th.emplace_back(work);
+    try {
+        th.reserve((size_t)(lanes > 1 ? lanes - 1 : 0));
+        for (int t = 1; t < lanes; t++) th.emplace_back(work);
+    } catch (...) { /* (a lane that could not start: the others take its files; a joinable std::thread must not be destroyed) */ }
     if (n_files) work();
     for (auto &t : th) t.join();
     int first = LZ77X_OK;
@@ -431,7 +434,9 @@ static int run_files(int n_files, FILE **in, FILE **out, int la, int sb, int *rc
     return first;
 }
 
-int lz77x_encode_files(int n_files, FILE **in, FILE **out, int la, int sb, int *rc) { return run_files(n_files, in, out, la, sb, rc, true); }
-int lz77x_decode_files(int n_files, FILE **in, FILE **out, int *rc) { return run_files(n_files, in, out, 0, 0, rc, false); }
+int lz77x_encode_files(int n_files, FILE **in, FILE **out, int la, int sb, int *rc)
+try { return run_files(n_files, in, out, la, sb, rc, true); } LZ77X_API_CATCH
+int lz77x_decode_files(int n_files, FILE **in, FILE **out, int *rc)
+try { return run_files(n_files, in, out, 0, 0, rc, false); } LZ77X_API_CATCH
 
 }  // extern "C"

@@ -26,6 +26,37 @@ bool trace_on()
     return on == 1;
 }
 
+bool poison_on()
+{
+    static int on = -1;
+    if (on < 0) { const char *e = getenv("LZ77X_POISON"); on = e && atoi(e) ? 1 : 0; }
+    return on == 1;
+}
+
+/* LZ77X_POISON=1: what the set's contexts cached from earlier calls holds 0xA5 when the next call starts */
+static void poison_ctx(Ctx &c)
+{
+    if (c.pipe) poison_ctx(*c.pipe);
+    if (c.drain) poison_ctx(*c.drain);
+    if (!c.ready) return;
+    hipError_t e = hipSetDevice(c.device);
+    for (DevBuf *b : c.dev_bufs())
+        if (b->p) e = hipMemset(b->p, 0xA5, b->cap);
+    e = hipDeviceSynchronize();
+    (void)e;
+    for (PinBuf *b : c.pin_bufs())
+        if (b->p) memset(b->p, 0xA5, b->cap);
+}
+
+void poison_set(CtxSet &S)
+{
+    int cur = -1;
+    if (hipGetDevice(&cur) != hipSuccess) cur = -1;
+    poison_ctx(S.primary);
+    for (Ctx *c : S.more) poison_ctx(*c);
+    if (cur >= 0) { hipError_t e = hipSetDevice(cur); (void)e; }
+}
+
 double now_ms()
 {
     using namespace std::chrono;

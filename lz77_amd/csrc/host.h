@@ -83,6 +83,13 @@ extern int g_shards;
         }                                                                                      \
     } while (0)
 
+/* No C++ exception crosses the C ABI: the entry points are function-try-blocks that end in this (a std::bad_alloc of a
+ * vector, the std::system_error of a thread that could not start -- std::terminate inside a C caller otherwise) */
+#define LZ77X_API_CATCH                                                                                            \
+    catch (const std::bad_alloc &) { snprintf(g_err, sizeof g_err, "out of host memory"); return LZ77X_E_NOMEM; }  \
+    catch (const std::exception &ex_) { snprintf(g_err, sizeof g_err, "host exception: %s", ex_.what()); return LZ77X_E_HIP; } \
+    catch (...) { snprintf(g_err, sizeof g_err, "host exception"); return LZ77X_E_HIP; }
+
 #define TRACE(label, t0)                                                                  \
     do { if (trace_on()) fprintf(stderr, "[lz77x] %-28s %8.2f ms\n", label, now_ms() - (t0)); } while (0)
 
@@ -91,6 +98,11 @@ extern int g_shards;
 extern __thread double g_alloc_ms, g_pin_ms, g_fread_ms, g_fwrite_ms;
 extern __thread size_t g_alloc_bytes, g_pin_bytes;
 
+
+/* LZ77X_POISON=1 (debug aid, never changes the output of correct code): every cached device and pinned buffer is filled with
+ * 0xA5 when a call leases its context set and when a buffer grows -- a kernel or host loop that reads what this call has not
+ * written then sees garbage instead of the zeroes of fresh memory or the plausible values of the call before (ctx.cpp) */
+bool poison_on();
 
 struct DevBuf {
     void *p = nullptr;
@@ -103,6 +115,7 @@ struct DevBuf {
         size_t want = bytes + bytes / 8 + 4096;
         HIPCHK(hipMalloc(&p, want));
         cap = want;
+        if (poison_on()) HIPCHK(hipMemset(p, 0xA5, want));
         if (trace_on()) { g_alloc_ms += now_ms() - t0; g_alloc_bytes += want; }
         return LZ77X_OK;
     }
@@ -147,6 +160,7 @@ struct PinBuf {
                     p = q;
                     cap = want;
                     registered = true;
+                    if (poison_on()) memset(p, 0xA5, cap);
                     return LZ77X_OK;
                 }
                 (void)hipGetLastError();
@@ -155,6 +169,7 @@ struct PinBuf {
         }
         HIPCHK(hipHostMalloc(&p, want, hipHostMallocPortable));   /* every shard's device copies to/from it */
         cap = want;
+        if (poison_on()) memset(p, 0xA5, cap);
         return LZ77X_OK;
     }
     template <class T> T *as() const { return reinterpret_cast<T *>(p); }
@@ -348,6 +363,8 @@ extern std::vector<CtxSet *> g_pool;
 extern std::mutex g_mu;
 extern std::condition_variable g_cv;
 
+void poison_set(CtxSet &S);
+
 struct Lease {
     CtxSet *set = nullptr;
     Lease()
@@ -372,6 +389,8 @@ struct Lease {
         set->busy = true;
         set->promised = 0;
         tl_set = set;
+        lk.unlock();
+        if (poison_on()) poison_set(*set);
     }
     ~Lease()
     {

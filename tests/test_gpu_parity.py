@@ -619,21 +619,13 @@ def test_periodic_input_reaches_the_fallback_without_a_knob(period):
     rng = np.random.default_rng(period)
     n = 3_200_000                                            # ~195 blocks of 16 K steps: more than twice the iterations left
     data = np.tile(rng.integers(0, 256, period, dtype=np.uint8), n // period + 1)[:n].copy()
-    # The encode runs in a CHILD process: one full-suite run of round 5's last day aborted inside lz77x_encode on this
-    # test (SIGABRT without a message -- the release build of the HIP runtime aborts that way -- after ~590 tests in the
-    # same process; 180 encodes of the same inputs in a fresh process under rocgdb did not reproduce it).
-    # A child costs one test if that happens again, leaves its stderr in the report, and keeps the rest of the suite.
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    code = ("import sys, numpy as np; sys.path.insert(0, %r); import lz77_amd as L\n"
-            "rng = np.random.default_rng(%d); n = %d\n"
-            "data = np.tile(rng.integers(0, 256, %d, dtype=np.uint8), n // %d + 1)[:n].copy()\n"
-            "z = L.encode(data); st = L.last_stats()\n"
-            "assert st['host_stageb_ms'] > 0, 'the gate iteration converged on its own: update DESIGN 2.2d and this test'\n"
-            "assert L.decode(z) == data.tobytes()\n"
-            "sys.stdout.buffer.write(z)\n" % (root, period, n, period, period))
-    r = subprocess.run([sys.executable, "-c", code], capture_output=True, timeout=600, env={**os.environ, "LZ77X_NO_TORCH": "1"})
-    assert r.returncode == 0, (r.returncode, r.stderr.decode(errors="replace")[-3000:])
-    assert r.stdout == O.encode_bst(data, 4095, 15)
+    # In-process again (round 5 ran it in a child after one unexplained SIGABRT inside the full suite; DESIGN section 6 has
+    # what round 6 found).  tests/test_gpu_soak.py repeats the hand-over after hundreds of mixed calls in one process.
+    z = L.encode(data)
+    st = L.last_stats()
+    assert st["host_stageb_ms"] > 0, "the gate iteration converged on its own: update DESIGN 2.2d and this test"
+    assert z == O.encode_bst(data, 4095, 15)
+    assert L.decode(z) == data.tobytes()
 
 
 def test_roundtrip_incompressible_large():
