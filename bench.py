@@ -309,43 +309,58 @@ def shard_mode(a):
         shards = min(a.gpus, ndev) if not os.environ.get("LZ77X_FAKE_DEVICES") else a.gpus
         data = synth.make(a.kind, n, seed)
         assert L.lib().lz77x_set_shards(max(shards, 1)) == 0
-        z = b""
         for _ in range(a.warmup):
-            z = L.encode(data, a.la, a.sb)
-            L.decode(z[:4 + 3 * 1000])
+            with L.encode_c(data, a.la, a.sb) as zc:
+                L.decode(zc.view[:4 + 3 * 1000])
     if world > 1:
         dist.barrier()
     t0 = time.perf_counter()
     if rank == 0:
+        # every clock of this mode is around the C entry points themselves (lz77x_encode / lz77x_decode into the buffers the
+        # library allocates): L.encode()'s copy of a 467 MB stream into a Python bytes object is not part of the product
         enc_ms, dec_ms, iters, serial_ms = [], [], 0, []
+        zc = back = None
         for _ in range(a.steps):
+            if zc is not None:
+                zc.close()
+                back.close()
             t1 = time.perf_counter()
-            z = L.encode(data, a.la, a.sb)
+            zc = L.encode_c(data, a.la, a.sb)
+            t2 = time.perf_counter()
             st_enc = L.last_stats()
             iters = st_enc["prio_iters"]
             serial_ms.append(st_enc["copy_ms"])
-            t2 = time.perf_counter()
-            back = L.decode(z)
+            t2b = time.perf_counter()
+            back = L.decode_c(zc.view)
             t3 = time.perf_counter()
             enc_ms.append((t2 - t1) * 1e3)
-            dec_ms.append((t3 - t2) * 1e3)
+            dec_ms.append((t3 - t2b) * 1e3)
     if world > 1:
         dist.barrier()
     dt = time.perf_counter() - t0
     if rank == 0:
         K = max(a.steps, 1)
+        z = zc.tobytes()
+        roundtrip_ok = bool(np.array_equal(back.view, data))
+        back.close()
         gold = golden_full(a.kind, n, seed, a.sb, a.la)
         sha_ok = None if gold is None else (len(z) == gold["zn"] and hashlib.sha256(z).hexdigest() == gold["sha256_lz"])
         plan = [p.__dict__ for p in __import__("lz77_amd.shard", fromlist=["plan"]).plan(n, max(shards, 1), a.sb, a.la)]
-        # the same stream on ONE context (the device pipeline out of host memory): what Amdahl's law is applied to
+        # the same stream on ONE context (the device pipeline out of host memory), on the same clock: what Amdahl's law is applied to
         t_one = None
         try:
             assert L.lib().lz77x_set_shards(1) == 0
-            L.encode(data[:64_000_000], a.la, a.sb)
-            t4 = time.perf_counter()
-            z1 = L.encode(data, a.la, a.sb)
-            t_one = (time.perf_counter() - t4) * 1e3
-            assert z1 == z
+            L.encode_c(data[:64_000_000], a.la, a.sb).close()
+            best = None
+            for _ in range(2):
+                t4 = time.perf_counter()
+                z1 = L.encode_c(data, a.la, a.sb)
+                t5 = (time.perf_counter() - t4) * 1e3
+                best = t5 if best is None else min(best, t5)
+                same = z1.n == len(z) and bool(np.array_equal(z1.view, np.frombuffer(z, dtype=np.uint8)))
+                z1.close()
+                assert same
+            t_one = best
         finally:
             L.lib().lz77x_set_shards(max(shards, 1))
         hs = sum(serial_ms) / K
@@ -355,9 +370,11 @@ def shard_mode(a):
                       "host_serial_ms_per_gate_iteration": round(hs / max(iters, 1), 3),
                       "bound_encode_ms": {str(d): round(hs + max(t_one - hs, 0.0) / d, 1) for d in (2, 4, 8)},
                       "bound_speedup": {str(d): round(t_one / (hs + max(t_one - hs, 0.0) / d), 2) for d in (2, 4, 8)},
+                      "clock": "time.perf_counter around lz77x_encode itself (lz77_amd.encode_c: no copy into a bytes object), for T(1) and for the sharded run alike",
                       "note": "prediction, not a measurement: T(D) >= host_serial + (T(1) - host_serial) / D with host_serial = the host "
-                              "time of THIS run that no device overlaps (per gate iteration: D boundary maps chained on the host, the "
-                              "cells handed back, the enqueue of every shard's sweep) -- it grows with D (one map per shard) and is "
+                              "time of THIS run during which no device has work (the parse chain's exchange, per gate iteration the D "
+                              "boundary maps chained on the host and the D flip summaries read -- every shard is driven by a host thread "
+                              "of its own --, the pack enqueue) -- it grows with D (one map per shard) and is "
                               "measured here at D = %d on %d physical device(s)" % (len(plan), min(len(plan), L.lib().lz77x_device_count()))}
         out = {"metric": "encode+decode MB/s on enwik9-like synthetic text, s=%d l=%d, ONE stream position-sharded" % (a.sb, a.la),
                "value": round(n * K / dt / 1e6, 3), "unit": "MB/s",
@@ -373,7 +390,7 @@ def shard_mode(a):
                           "mode": "shard", "shards": len(plan), "max_local_bytes": max(p["local_bytes"] for p in plan)},
                "encode_ms": round(sum(enc_ms) / K, 2), "decode_ms": round(sum(dec_ms) / K, 2), "prio_iters": iters,
                "host_serial_ms": round(hs, 2), "amdahl": amdahl,
-               "roundtrip_ok": bool(back == data.tobytes()), "stream_sha_ok": sha_ok,
+               "roundtrip_ok": roundtrip_ok, "stream_sha_ok": sha_ok,
                "serial_terms": "per gate iteration one host exchange of 6 KB per shard (priority cells), one of 1.3 KB per shard for "
                                "the parse chain, 16 bytes per cut for packing; decode: one map of sb 16-bit states per shard, chained "
                                "on the host; everything else is shard-local"}

@@ -40,12 +40,41 @@ static void poison_ctx(Ctx &c)
     if (c.drain) poison_ctx(*c.drain);
     if (!c.ready) return;
     hipError_t e = hipSetDevice(c.device);
-    for (DevBuf *b : c.dev_bufs())
-        if (b->p) e = hipMemset(b->p, 0xA5, b->cap);
+    /* LZ77X_POISON_MASK: bit i = the i-th buffer of dev_bufs(), bit 32 + i = the i-th of pin_bufs() (to find WHICH stale
+     * buffer a failure depends on); default: all */
+    static unsigned long long mask = 0;
+    static bool have_mask = false;
+    if (!have_mask) { const char *m = getenv("LZ77X_POISON_MASK"); mask = m ? strtoull(m, nullptr, 0) : ~0ull; have_mask = true; }
+    int i = 0;
+    for (DevBuf *b : c.dev_bufs()) {
+        if (b->p && ((mask >> i) & 1ull)) e = hipMemset(b->p, 0xA5, b->cap);
+        i++;
+    }
     e = hipDeviceSynchronize();
     (void)e;
-    for (PinBuf *b : c.pin_bufs())
-        if (b->p) memset(b->p, 0xA5, b->cap);
+    i = 32;
+    for (PinBuf *b : c.pin_bufs()) {
+        if (b->p && ((mask >> i) & 1ull)) memset(b->p, 0xA5, b->cap);
+        i++;
+    }
+}
+
+bool poison_fresh(const DevBuf *b)
+{
+    static unsigned long long mask = 0;
+    static bool have = false;
+    if (!have) { const char *m = getenv("LZ77X_POISON_FRESH_MASK"); mask = m ? strtoull(m, nullptr, 0) : ~0ull; have = true; }
+    if (mask == ~0ull || !tl_set) return mask != 0;
+    std::vector<Ctx *> all = {&tl_set->primary};
+    for (Ctx *c : tl_set->more) all.push_back(c);
+    for (size_t k = 0; k < all.size(); k++) {
+        Ctx *c = all[k];
+        if (c->pipe) all.push_back(c->pipe);
+        if (c->drain) all.push_back(c->drain);
+        int i = 0;
+        for (DevBuf *q : c->dev_bufs()) { if (q == b) return (mask >> i) & 1ull; i++; }
+    }
+    return true;
 }
 
 void poison_set(CtxSet &S)

@@ -103,6 +103,8 @@ extern __thread size_t g_alloc_bytes, g_pin_bytes;
  * 0xA5 when a call leases its context set and when a buffer grows -- a kernel or host loop that reads what this call has not
  * written then sees garbage instead of the zeroes of fresh memory or the plausible values of the call before (ctx.cpp) */
 bool poison_on();
+struct DevBuf;
+bool poison_fresh(const DevBuf *b);   /* LZ77X_POISON_FRESH_MASK: which buffers (bit i = the i-th of Ctx::dev_bufs()) are poisoned when they are allocated */
 
 struct DevBuf {
     void *p = nullptr;
@@ -115,7 +117,7 @@ struct DevBuf {
         size_t want = bytes + bytes / 8 + 4096;
         HIPCHK(hipMalloc(&p, want));
         cap = want;
-        if (poison_on()) HIPCHK(hipMemset(p, 0xA5, want));
+        if (poison_on() && poison_fresh(this)) HIPCHK(hipMemset(p, 0xA5, want));
         if (trace_on()) { g_alloc_ms += now_ms() - t0; g_alloc_bytes += want; }
         return LZ77X_OK;
     }
@@ -314,6 +316,42 @@ template <class F> int for_each_shard(size_t D, F fn)
     if (spawn_failed)
         for (size_t d = th.size() + 1; d < D; d++) run(d);
     for (auto &t : th) t.join();
+    for (size_t d = 0; d < D; d++)
+        if (rcs[d]) { snprintf(g_err, sizeof g_err, "%s", msgs[d].c_str()); return rcs[d]; }
+    return LZ77X_OK;
+}
+
+/* fn(d) for every shard d on D host threads that ALL exist before any of them starts: the shards of a joint iteration meet
+ * at barriers (shard.cpp), so a thread that could not start must not leave the others waiting -- then none runs and the
+ * call fails.  The first shard runs on the calling thread; the first error wins, its text ends up in the caller's g_err. */
+template <class F> int run_team(size_t D, F fn)
+{
+    std::vector<int> rcs(D, LZ77X_OK);
+    std::vector<std::string> msgs(D);
+    std::mutex m;
+    std::condition_variable cv;
+    int state = 0;                                          /* 0: wait, 1: go, 2: cancelled */
+    auto run = [&](size_t d, bool gated) {
+        if (gated) {
+            std::unique_lock<std::mutex> lk(m);
+            cv.wait(lk, [&] { return state != 0; });
+            if (state == 2) return;
+        }
+        g_err[0] = 0;
+        rcs[d] = fn(d);
+        if (rcs[d]) msgs[d] = g_err;
+    };
+    std::vector<std::thread> th;
+    bool ok = true;
+    try {
+        th.reserve(D);
+        for (size_t d = 1; d < D; d++) th.emplace_back(run, d, true);
+    } catch (...) { ok = false; }
+    { std::lock_guard<std::mutex> lk(m); state = ok ? 1 : 2; }
+    cv.notify_all();
+    if (ok && D) run(0, false);
+    for (auto &t : th) t.join();
+    if (!ok) { snprintf(g_err, sizeof g_err, "could not start a host thread per shard"); return LZ77X_E_NOMEM; }
     for (size_t d = 0; d < D; d++)
         if (rcs[d]) { snprintf(g_err, sizeof g_err, "%s", msgs[d].c_str()); return rcs[d]; }
     return LZ77X_OK;

@@ -1406,239 +1406,8 @@ __global__ __launch_bounds__(WFIN_BLOCK) void k_walk_final_lds(const uint8_t *__
     }
 }
 
-#ifdef LZ77X_VARIANTS   /* (round 1's walkers: the cross-check of k_walk_wave) */
-/* ---- large windows (RP > 16384): same walk, bitmap in global memory (L2 resident), 32-bit ranks.
- * The walker converts neighbour ranks to distances itself: forward results go straight to ps[],
- * backward ones (candidates of the longest match) to wb[] / wb0[] for k_walk_final_big. ---- */
-__global__ __launch_bounds__(64) void k_walk_big(const uint32_t *__restrict__ ranks, uint32_t n, int sb, uint32_t RP,
-                                                 uint32_t TILE, uint32_t region0, uint32_t nregions, uint32_t run_len,
-                                                 uint32_t runs_per_tile, uint32_t *__restrict__ bitmaps,
-                                                 uint2 *__restrict__ wf, uint2 *__restrict__ wb, uint2 *__restrict__ wb0, int dbg)
-{
-    const uint32_t NW = RP >> 5, NS = (NW + 31) >> 5;
-    const uint32_t id = blockIdx.x * 64u + threadIdx.x;
-    const uint32_t run = id % runs_per_tile;
-    const uint32_t reg = id / runs_per_tile;
-    const uint32_t usb = (uint32_t)sb;
-    /* lanes without a walker stay for the cooperative fill (every lane reads one rank per round) */
-    const uint64_t t0_64 = (uint64_t)(region0 + reg) * TILE;
-    bool alive = reg < nregions && t0_64 < n;
-    const uint32_t t0 = alive ? (uint32_t)t0_64 : 0u;
-    const uint64_t rend64 = (uint64_t)t0 + TILE + usb;
-    const uint32_t R = (rend64 < n ? (uint32_t)rend64 : n) - t0;
-    const uint32_t lt1 = n - t0 < TILE ? n - t0 : TILE;
-    const uint32_t ta = run * run_len;
-    alive = alive && ta < lt1;
-    const uint32_t tb = min(ta + run_len, lt1);
-    /* explicit global address space: pointers that are selected or rebuilt per lane would otherwise
-     * decay to FLAT accesses, which count in lgkmcnt -- every cross-lane shuffle of the fill would then
-     * wait for all stores in flight */
-    const g_u32 *rk = (const g_u32 *)ranks + (size_t)(alive ? reg : 0u) * (2 * (size_t)RP + 8);
-    g_u32 *word = (g_u32 *)bitmaps + (size_t)id * (NW + NS);   /* every word is written by the fill below */
-    g_u32 *summ = word + NW;
-    const uint32_t NONE = 0xFFFFFFFFu;
-    const bool first = alive && region0 + reg == 0 && run == 0;
-    const uint32_t lane = threadIdx.x;
-
-    /* The bitmap is private to this wavefront, so WORKGROUP scope is all the coherence it needs: the
-     * accesses are served by this XCD's L2.  Agent scope (coherent across the eight XCDs) sends every
-     * one of them to the memory side of the fabric -- measured 15 us per step instead of ~2. */
-    auto ldw = [&](const g_u32 *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); };
-    auto stw = [&](g_u32 *p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); };
-    /* no set bit lies in a word below lo_w or above hi_w (see k_walk): loose after the ballot fill, widened
-     * by sets, tightened by every scan that finds nothing */
-    uint32_t lo_w = 0, hi_w = NW - 1;
-    auto set_bit = [&](uint32_t r) {
-        __hip_atomic_fetch_or(&word[r >> 5], 1u << (r & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        __hip_atomic_fetch_or(&summ[r >> 10], 1u << ((r >> 5) & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        lo_w = min(lo_w, r >> 5);
-        hi_w = max(hi_w, r >> 5);
-    };
-    /* These bitmaps live in HBM (34 KB per walker, hundreds of MB per launch): every access is a random
-     * 64-byte line and the walk is bound by how many of them a step needs.  So a query looks at its own
-     * word, then at the ADJACENT word (same line 15 times out of 16; at 25 % fill a word is empty one
-     * time in 10^4), and only then at the summary -- which is still maintained, so that the nearly empty
-     * windows at the start of the input cost O(1) per query too.  Results leave as ranks; the lookups
-     * rank -> position are k_walk_final_big's (there they are independent and massively parallel). */
-    /* robust against a summary bit whose word is empty: such a word is skipped */
-    auto up_slow = [&](uint32_t w) -> uint32_t {             /* first set rank in words > w, or NONE */
-        if (w >= hi_w) return NONE;
-        uint32_t sw = w >> 5, sm = ldw(&summ[sw]) & ~((2u << (w & 31)) - 1u);
-        for (;;) {
-            while (!sm && ++sw <= (hi_w >> 5)) sm = ldw(&summ[sw]);
-            if (!sm) { hi_w = w; return NONE; }
-            const uint32_t w2 = (sw << 5) + (uint32_t)__builtin_ctz(sm);
-            const uint32_t m = ldw(&word[w2]);
-            if (m) return (w2 << 5) + (uint32_t)__builtin_ctz(m);
-            sm &= sm - 1;
-        }
-    };
-    auto down_slow = [&](uint32_t w) -> uint32_t {           /* last set rank in words < w, or NONE */
-        if (w <= lo_w) return NONE;
-        int32_t sw = (int32_t)(w >> 5);
-        uint32_t sm = ldw(&summ[sw]) & ((1u << (w & 31)) - 1u);
-        for (;;) {
-            while (!sm && --sw >= (int32_t)(lo_w >> 5)) sm = ldw(&summ[sw]);
-            if (!sm) { lo_w = w; return NONE; }
-            const uint32_t top = 31u - (uint32_t)__builtin_clz(sm);
-            const uint32_t w2 = ((uint32_t)sw << 5) + top;
-            const uint32_t m = ldw(&word[w2]);
-            if (m) return (w2 << 5) + 31u - (uint32_t)__builtin_clz(m);
-            sm &= ~(1u << top);
-        }
-    };
-    /* successor / predecessor of bit b0 of word w0, given that word and its two neighbours */
-    auto succ_of = [&](uint32_t w0, uint32_t b0, uint32_t here, uint32_t next) -> uint32_t {
-        const uint32_t m1 = here & ~((2u << b0) - 1u);
-        if (m1) return (w0 << 5) + (uint32_t)__builtin_ctz(m1);
-        if (w0 + 1 < NW && next) return ((w0 + 1) << 5) + (uint32_t)__builtin_ctz(next);
-        return w0 + 1 < NW ? up_slow(w0 + 1) : NONE;
-    };
-    auto pred_of = [&](uint32_t w0, uint32_t b0, uint32_t here, uint32_t prev) -> uint32_t {
-        const uint32_t m1 = here & ((1u << b0) - 1u);
-        if (m1) return (w0 << 5) + 31u - (uint32_t)__builtin_clz(m1);
-        if (w0 > 0 && prev) return ((w0 - 1) << 5) + 31u - (uint32_t)__builtin_clz(prev);
-        return w0 > 0 ? down_slow(w0 - 1) : NONE;
-    };
-    auto back = [&](uint32_t q) -> uint2 {                   /* ranks of q's two neighbours */
-        const uint32_t w0 = q >> 5, b0 = q & 31;
-        const uint32_t here = ldw(&word[w0]), next = ldw(&word[min(w0 + 1, NW - 1)]), prev = ldw(&word[w0 ? w0 - 1 : 0]);
-        return make_uint2(succ_of(w0, b0, here, next), pred_of(w0, b0, here, prev));
-    };
-    /* First window minus its last position, [ta, ta+sb-1).  The wave builds its 64 bitmaps one after the
-     * other.  The first walker of a region in the wave gets its bitmap straight from the sorted order:
-     * 64 lanes read the positions of 64 consecutive ranks (one coalesced load), test them against the
-     * window, and the ballot IS the next two bitmap words -- plain stores, no atomics, no pre-zeroed
-     * memory, and the summary falls out of the same loop.  Every further walker of that region starts
-     * run_len positions later, i.e. from the SAME window minus run_len positions plus run_len others:
-     * it copies its predecessor's bitmap and applies the difference (33 KB copied and 2*run_len bit
-     * updates instead of a pass over the region's 262144 ranks).  The first walker of the input starts
-     * empty: it answers y < sb as it fills, and its successor is built from the order. */
-    {
-        const uint32_t a = ta, len = first ? 0u : min(ta + usb - 1, R) - ta;
-        uint64_t todo = (dbg & 1) ? 0ull : __ballot(alive);
-        while (todo) {
-            const int src = __builtin_ctzll(todo);
-            const uint32_t sreg = __shfl(reg, src, 64);
-            const uint64_t group = __ballot(alive && reg == sreg);
-            todo &= ~group;
-            const g_u32 *srk = (const g_u32 *)ranks + (size_t)sreg * (2 * (size_t)RP + 8);
-            const g_u32 *six = srk + RP + 8;
-            int prev = -1;
-            for (uint64_t mem = group; mem; mem &= mem - 1) {
-                const int m = __builtin_ctzll(mem);
-                const uint32_t wa = __shfl(a, m, 64), wlen = __shfl(len, m, 64);
-                g_u32 *sword = (g_u32 *)bitmaps + ((size_t)blockIdx.x * 64u + (uint32_t)m) * (NW + NS);
-                const bool m_first = __shfl((int)first, m, 64) != 0;
-                if (prev < 0) {
-                    /* from the order: 16 rounds (1024 ranks = one summary word) per iteration, all 16 loads
-                     * issued before the first ballot.  RP >= 32768 here. */
-                    for (uint32_t r0 = 0; r0 < RP; r0 += 1024) {
-                        uint32_t pos[16];
-#pragma unroll
-                        for (int u = 0; u < 16; u++) pos[u] = six[r0 + 64 * u + lane];   /* slots >= R hold indices >= R: never inside */
-                        uint32_t sacc = 0;
-#pragma unroll
-                        for (int u = 0; u < 16; u++) {
-                            const uint64_t mask = __ballot(pos[u] - wa < wlen);
-                            if (lane == 0) *(g_u64 *)(sword + (r0 >> 5) + 2 * u) = mask;     /* two words, little endian */
-                            sacc |= (((uint32_t)mask != 0u ? 1u : 0u) | ((uint32_t)(mask >> 32) != 0u ? 2u : 0u)) << (2 * u);
-                        }
-                        if (lane == 0) sword[NW + (r0 >> 10)] = sacc;
-                    }
-                } else {
-                    const uint32_t pa = __shfl(a, prev, 64), plen = __shfl(len, prev, 64);
-                    const g_u32 *pword = (const g_u32 *)bitmaps + ((size_t)blockIdx.x * 64u + (uint32_t)prev) * (NW + NS);
-                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-                    /* eight loads in flight per lane: this copy and the two loops below are round trips */
-                    for (uint32_t w = lane; w < NW + NS; w += 64 * 8) {
-                        uint32_t t[8];
-#pragma unroll
-                        for (int u = 0; u < 8; u++) t[u] = w + 64 * u < NW + NS ? ldw(&pword[w + 64 * u]) : 0u;
-#pragma unroll
-                        for (int u = 0; u < 8; u++) if (w + 64 * u < NW + NS) stw(&sword[w + 64 * u], t[u]);
-                    }
-                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-                    /* leave: [pa, min(wa, pa+plen))   enter: [max(pa+plen, wa), wa+wlen).  The clears do not
-                     * wait for their result */
-                    const uint32_t le = min(wa, pa + plen);
-                    for (uint32_t i = pa + lane; i < le; i += 64 * 4) {
-                        uint32_t r[4];
-#pragma unroll
-                        for (int u = 0; u < 4; u++) r[u] = i + 64 * u < le ? srk[i + 64 * u] : 0xFFFFFFFFu;
-#pragma unroll
-                        for (int u = 0; u < 4; u++)
-                            if (r[u] != 0xFFFFFFFFu)
-                                __hip_atomic_fetch_and(&sword[r[u] >> 5], ~(1u << (r[u] & 31)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    }
-                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-                    /* second pass over the leavers: words they emptied lose their summary bit (runs of equal
-                     * bytes empty whole words at a time, and a query would step through every stale bit) */
-                    for (uint32_t i = pa + lane; i < le; i += 64 * 4) {
-                        uint32_t r[4], wv[4];
-#pragma unroll
-                        for (int u = 0; u < 4; u++) r[u] = i + 64 * u < le ? srk[i + 64 * u] : 0xFFFFFFFFu;
-#pragma unroll
-                        for (int u = 0; u < 4; u++) wv[u] = r[u] != 0xFFFFFFFFu ? ldw(&sword[r[u] >> 5]) : 1u;
-#pragma unroll
-                        for (int u = 0; u < 4; u++)
-                            if (!wv[u])
-                                __hip_atomic_fetch_and(&sword[NW + (r[u] >> 10)], ~(1u << ((r[u] >> 5) & 31)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    }
-                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-                    const uint32_t eb = max(pa + plen, wa), ee = wa + wlen;
-                    for (uint32_t i = eb + lane; i < ee; i += 64 * 4) {
-                        uint32_t r[4];
-#pragma unroll
-                        for (int u = 0; u < 4; u++) r[u] = i + 64 * u < ee ? srk[i + 64 * u] : 0xFFFFFFFFu;
-#pragma unroll
-                        for (int u = 0; u < 4; u++)
-                            if (r[u] != 0xFFFFFFFFu) {
-                                __hip_atomic_fetch_or(&sword[r[u] >> 5], 1u << (r[u] & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                                __hip_atomic_fetch_or(&sword[NW + (r[u] >> 10)], 1u << ((r[u] >> 5) & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                            }
-                    }
-                }
-                prev = m_first ? -1 : m;
-            }
-        }
-    }
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-    if (!alive || (dbg & 2)) return;
-    g_uint2 *out0 = (g_uint2 *)wb0;
-    if (first) {
-        const uint32_t b = min(usb - 1, R);
-        for (uint32_t i = 0; i < b; i++) {
-            const uint32_t r = rk[i];
-            const uint2 v = back(r);
-            out0[i].x = v.x; out0[i].y = v.y;
-            set_bit(r);
-        }
-        if (usb - 1 < R) { const uint2 v = back(rk[usb - 1]); out0[usb - 1].x = v.x; out0[usb - 1].y = v.y; }
-    }
-    g_uint2 *of = (g_uint2 *)wf + (size_t)reg * TILE, *ob = (g_uint2 *)wb + (size_t)reg * TILE;
-    auto fetch = [&](uint32_t i) -> uint32_t { return i < R ? rk[i] : NONE; };
-    uint32_t q = rk[ta], ry = fetch(ta + usb), r_add = fetch(ta + usb - 1);
-    for (uint32_t t = ta; t < tb; t++) {
-        const uint32_t qn = t + 1 < tb ? rk[t + 1] : 0u;
-        const uint32_t ryn = fetch(t + 1 + usb);
-        if (r_add != NONE) set_bit(r_add);
-        /* both queries read the bitmap before q is cleared: the forward one never looks at q's own bit */
-        const bool hasy = ry != NONE;
-        const uint32_t wq = q >> 5, bq = q & 31, wy = hasy ? ry >> 5 : wq, by_ = ry & 31;
-        const uint32_t hq = ldw(&word[wq]), hy = ldw(&word[wy]);
-        const uint32_t nq = ldw(&word[min(wq + 1, NW - 1)]), pq = ldw(&word[wq ? wq - 1 : 0]);
-        const uint32_t ny = ldw(&word[min(wy + 1, NW - 1)]), py = ldw(&word[wy ? wy - 1 : 0]);
-        const uint32_t left = hq & ~(1u << bq);
-        stw(&word[wq], left);
-        if (!left) __hip_atomic_fetch_and(&summ[wq >> 5], ~(1u << (wq & 31)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        const uint32_t rs = succ_of(wq, bq, hq, nq), rp = pred_of(wq, bq, hq, pq);
-        const uint32_t ys = hasy ? succ_of(wy, by_, hy, ny) : NONE, yp = hasy ? pred_of(wy, by_, hy, py) : NONE;
-        of[t].x = rs; of[t].y = rp;
-        ob[t].x = ys; ob[t].y = yp;
-        r_add = ry; q = qn; ry = ryn;
-    }
-}
+#ifdef LZ77X_VARIANTS   /* (round 1's large-window walkers (a bitmap per lane in HBM)) */
+#include "variants/walk_big.inc"
 #endif
 
 /* ---- large windows, production: ONE WAVEFRONT per run, the bitmap in LDS, 64 steps at a time -------------

@@ -333,104 +333,8 @@ __global__ __launch_bounds__(64) void k_prio_fwd(const uint32_t *__restrict__ ps
     if (lane == 0 && gates_changed) gates_changed[b] = nflip ? 1u : 0u;
 }
 
-#ifdef LZ77X_VARIANTS   /* (the sequential form of the maps: the cross-check of k_prio_back2) */
-/* ------------------------------------------------------------------ backward sweep --- */
-
-/* dest[b][i]: the exit cell (relative to the block's end x1) that the chain of open gates starting at
- * entry cell b*B+i reaches, or DEAD when it ends inside the block; loc[b][d]: the lowest position of
- * the block whose chain reaches exit cell d (what arrives there when nothing older comes in). */
-__global__ __launch_bounds__(64) void k_prio_back(const uint32_t *__restrict__ ps, uint32_t nx, uint32_t sb, uint32_t B,
-                                                  uint32_t ring_n, uint32_t b_first, const uint64_t *__restrict__ gates,
-                                                  uint16_t *__restrict__ dest, uint32_t *__restrict__ loc, uint32_t voff,
-                                                  uint32_t ncarried /* cells < ncarried hold carried values, not their own position */,
-                                                  const uint32_t *__restrict__ gates_changed /* [b] = 0: the block's map of the last iteration still holds */)
-{
-    extern __shared__ uint32_t back_lds[];
-    if (gates_changed && !gates_changed[b_first + blockIdx.x]) return;
-    __builtin_amdgcn_s_setprio(3);      /* a chain of dependent instructions: issue ahead of any co-resident throughput kernel */
-    uint32_t *lloc = back_lds;                                         /* sb_r words */
-    uint16_t *dr = reinterpret_cast<uint16_t *>(back_lds + (ring_n - 64u));   /* ring_n entries */
-    const uint32_t lane = threadIdx.x;
-    const uint32_t b = b_first + blockIdx.x;
-    const uint32_t x0 = b * B;
-    const uint32_t x1 = nx - x0 < B ? nx : x0 + B;
-    /* what reaches exit cell x1+i when nothing older comes in: its own priority -- unless it is a carried
-     * cell (a short first block of a later segment: its value comes in through in[0]) */
-    for (uint32_t i = lane; i < sb; i += 64) lloc[i] = x1 + i >= ncarried ? x1 + i + voff : PRIO_NONE;
-    for (uint32_t i = lane; i < ring_n; i += 64) dr[i] = PRIO_DEAD;
-    wave_sync();
-    const uint32_t nsg = (x1 - x0 + 64u * PRIO_SG - 1u) / (64u * PRIO_SG);
-    uint32_t v[PRIO_SG], vn[PRIO_SG];
-    uint64_t g_l = 0, g_n = 0;
-    const uint32_t xlast = x1 - 1u;
-    auto fetch = [&](int32_t sgi, uint32_t (&vv)[PRIO_SG], uint64_t &gl) {         /* unconditional loads, see k_prio_fwd */
-        const uint32_t xs = x0 + 64u * PRIO_SG * (uint32_t)(sgi < 0 ? 0 : sgi);
-#pragma unroll
-        for (uint32_t k = 0; k < PRIO_SG; k++) {
-            const uint32_t x = xs + 64u * k + lane;
-            const uint32_t t = ps[min(x, xlast)];
-            vv[k] = x < x1 ? t : 0u;
-        }
-        const uint32_t xq = min(xs + 64u * (lane & (PRIO_SG - 1u)), xlast);
-        gl = gates[xq >> 6];
-    };
-    fetch((int32_t)nsg - 1, v, g_l);
-    /* ring slot of cell xg, stepped down with the groups (64 < ring_n): a % per group is ten scalar instructions */
-    uint32_t off_run = (64u * PRIO_SG * nsg) % ring_n;
-    for (int32_t sgi = (int32_t)nsg - 1; sgi >= 0; sgi--) {
-        fetch(sgi - 1, vn, g_n);
-        const uint32_t xs = x0 + 64u * PRIO_SG * (uint32_t)sgi;
-#pragma unroll
-        for (int k = (int)PRIO_SG - 1; k >= 0; k--) {
-            const uint32_t xg = xs + 64u * (uint32_t)k;
-            off_run = off_run >= 64u ? off_run - 64u : off_run + ring_n - 64u;
-            if (xg < x1) {
-                const uint64_t gm = readlane64(g_l, k);
-                const uint32_t s = v[k] >> 16;
-                const uint32_t x = xg + lane;
-                const bool valid = x < x1;
-                const bool gate = valid && ((gm >> lane) & 1ull);
-                const uint32_t off = off_run;                         /* = (xg - x0) % ring_n */
-                /* three cases by where x + s lies -- beyond the block (an exit cell), in a later lane of this group (a
-                 * pointer, jumped below), or in between (the ring) -- as selects on ONE unconditional ring read: nested
-                 * branches cost a lone wavefront more in exec-mask bookkeeping than the read they save */
-                const uint32_t t = x + s;
-                uint32_t it = off + lane + (gate ? s : 0u);
-                it -= it >= ring_n ? ring_n : 0u;
-                const uint32_t dring = dr[it];
-                const bool past = t >= x1, near = t < xg + 64u;
-                uint32_t d = !gate ? (uint32_t)PRIO_DEAD : past ? t - x1 : near ? (uint32_t)PRIO_DEAD : dring;
-                int ptr = gate && !past && near ? (int)(t - xg) : -1;
-                while (__ballot(ptr >= 0)) {                          /* chains inside the group: pointer jumping */
-                    const int src = ptr >= 0 ? ptr : (int)lane;
-                    const uint32_t dn = (uint32_t)__shfl((int)d, src, 64);
-                    const int pn = __shfl(ptr, src, 64);
-                    const bool on = ptr >= 0, done = pn < 0;
-                    d = on && done ? dn : d;
-                    ptr = on ? (done ? -1 : pn) : -1;
-                }
-                if (valid) {
-                    uint32_t ix = off + lane;
-                    ix -= ix >= ring_n ? ring_n : 0u;
-                    dr[ix] = (uint16_t)d;
-                    /* x's own priority reaches d -- unless x is a carried cell of a later segment: its value
-                     * comes in through in[0] (a rank that need not be below its local position) */
-                    if (d != PRIO_DEAD && x >= ncarried) atomicMin(&lloc[d], x + voff);
-                }
-                wave_sync();
-            }
-        }
-#pragma unroll
-        for (uint32_t k = 0; k < PRIO_SG; k++) v[k] = vn[k];
-        g_l = g_n;
-    }
-    for (uint32_t i = lane; i < sb; i += 64) {
-        /* an entry cell that is not evicted inside a (short, last) block is still live at its end */
-        dest[(size_t)b * sb + i] = x0 + i < x1 ? dr[i] : (uint16_t)(i - (x1 - x0));
-        loc[(size_t)b * sb + i] = lloc[i];
-    }
-}
-
+#ifdef LZ77X_VARIANTS   /* (the sequential form of the boundary maps) */
+#include "variants/prio_back.inc"
 #endif
 
 /* The same maps WITHOUT a sequential sweep (round 3).  With the gates fixed a block is a forest of pointers

@@ -90,74 +90,8 @@ __device__ __forceinline__ uint32_t pw_rd16(const uint32_t *tab, uint32_t idx)
     return (reinterpret_cast<const uint16_t *>(tab))[idx];  /* (re-read after every barrier: pw_lds_barrier clobbers memory) */
 }
 
-#ifdef LZ77X_VARIANTS   /* (round 3's form: the cross-check of k_pw_prep_ranked, LZ77X_PW_PREP_V1) */
-/* Per group of W consecutive steps: the initial gates (every step that has both neighbours) and the round mask -- bit
- * i set <=> step i starts a new round because some step j of the current round (j < i) writes a cell step i reads (its
- * own, its predecessor's or its successor's).  tab[c - xg] = (version, lowest step of the current round that writes
- * cell c), 16 bits per cell, kept with a compare-and-swap minimum: versions count DOWN, so a newer entry always
- * replaces an older one and nothing is reset between rounds (every 63 rounds the table is cleared). */
-template <int W>
-__global__ __launch_bounds__(W) void k_pw_prep(const uint32_t *__restrict__ ps, uint32_t nx, uint32_t tagn,
-                                               uint64_t *__restrict__ rmask, uint64_t *__restrict__ gate0, uint64_t *__restrict__ cmask /* no chains here: zeros */)
-{
-    extern __shared__ uint32_t pw_tab[];
-    __shared__ uint32_t s_first[2];
-    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-    const uint32_t ngroups = (nx + W - 1u) / W;
-    for (uint32_t i = tid; i < tagn / 2u; i += W) pw_tab[i] = 0xFFFFFFFFu;
-    if (tid < 2) s_first[tid] = W;
-    __syncthreads();
-    uint32_t ver = 0;                                       /* 0 .. 62; code 62 - ver; code 63 = a cleared entry */
-    int par = 0;
-    PW_STAMP(16);
-    [[maybe_unused]] uint32_t nrounds_dbg = 0;
-    uint32_t vnext = blockIdx.x < ngroups ? ps[min(blockIdx.x * W + tid, nx - 1u)] : 0u;
-    for (uint32_t g = blockIdx.x; g < ngroups; g += gridDim.x) {
-        const uint32_t x = g * W + tid;
-        const uint32_t v = x < nx ? vnext : 0u;
-        vnext = ps[min((g + gridDim.x) * W + tid, nx - 1u)];          /* the next group's steps arrive during this one's rounds */
-        const uint32_t p = v & 0xFFFFu, s = v >> 16;
-        const bool has = p && s;
-        bool isstart = tid == 0;
-        uint32_t start = 0;
-        for (;;) {
-            if (ver == 63u) {
-                pw_lds_barrier();
-                for (uint32_t i = tid; i < tagn / 2u; i += W) pw_tab[i] = 0xFFFFFFFFu;
-                ver = 0;
-                pw_lds_barrier();
-            }
-            const uint32_t code = 62u - ver;
-            if (has && tid >= start) pw_cas_min16(pw_tab, tid + s, (code << 10) | tid);
-            pw_lds_barrier();
-            if (tid == 0) s_first[par ^ 1] = W;
-            bool blocked = false;
-            if (has && tid > start) {
-                const uint32_t t0 = pw_rd16(pw_tab, tid), t1 = pw_rd16(pw_tab, tid + p), t2 = pw_rd16(pw_tab, tid + s);
-                const bool b0 = (t0 >> 10) == code && (t0 & 1023u) < tid;
-                const bool b1 = (t1 >> 10) == code && (t1 & 1023u) < tid;
-                const bool b2 = (t2 >> 10) == code && (t2 & 1023u) < tid;
-                blocked = b0 | b1 | b2;
-            }
-            const uint64_t bm = __ballot(blocked);
-            if (bm && lane == 0) atomicMin(&s_first[par], wave * 64u + (uint32_t)__builtin_ctzll(bm));
-            pw_lds_barrier();
-            const uint32_t first = s_first[par];
-            nrounds_dbg++;
-            ver++;
-            par ^= 1;
-            if (first >= (uint32_t)W) break;
-            start = first;
-            if (tid == first) isstart = true;
-        }
-        const uint64_t rm = __ballot(isstart), hm = __ballot(has);
-        const uint32_t wi = ((g * W) >> 6) + wave;
-        if (lane == 0 && g * W + wave * 64u < nx) { rmask[wi] = rm; gate0[wi] = hm; cmask[wi] = 0ull; }
-    }
-    PW_STAMP(17);
-    if (blockIdx.x == 0 && threadIdx.x == 0) { PW_NOTE(18, nrounds_dbg); PW_NOTE(19, (ngroups + gridDim.x - 1) / gridDim.x); }
-}
-
+#ifdef LZ77X_VARIANTS   /* (round 3's round masks of the large windows (a tag per cell)) */
+#include "variants/pw_prep.inc"
 #endif
 
 /* The same round masks with the cells RANKED first (round 4).  k_pw_prep keeps a 16-bit tag for each of the W + sb cells a

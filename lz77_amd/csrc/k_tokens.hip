@@ -1095,575 +1095,12 @@ __global__ __launch_bounds__(TS_BLOCK, 8) __attribute__((amdgpu_num_sgpr(80))) v
     }
 }
 
-#ifdef LZ77X_VARIANTS   /* (round 4's form of the tie-break: hand-over lists per CELL, walked member by member -- the cross-check of
-                         * k_tokens_sorted, LZ77X_TS_V4=1) */
-__global__ __launch_bounds__(TS_BLOCK, 8) __attribute__((amdgpu_num_sgpr(80))) void k_tokens_sorted_v4(const uint8_t *__restrict__ in, uint32_t n, int sb, int la, int ob, int lb,
-                                                            const uint32_t *__restrict__ chain, const uint32_t *__restrict__ tstart,
-                                                            const uint8_t *__restrict__ maxlen, const uint32_t *__restrict__ ps,
-                                                            const uint32_t *__restrict__ xval, uint32_t pos0, uint32_t pos1,
-                                                            uint32_t *__restrict__ tokval, uint32_t ent_cap, uint32_t off_sorted,
-                                                            uint32_t off_inv, uint32_t off_lofs, uint32_t off_tk, uint32_t off_lent,
-                                                            const uint32_t *__restrict__ look, uint32_t nlook, uint32_t voff,
-                                                            const uint16_t *__restrict__ order_all, uint32_t RP, ts_grid G, uint32_t tile0, uint32_t ntiles,
-                                                            unsigned long long *__restrict__ total /* [1 + a slot] += hand-overs of the evictions [a - sb, b - sb) (a statistic) */)
-{
-    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    uint8_t *by = smem;
-    uint16_t *sorted = reinterpret_cast<uint16_t *>(smem + off_sorted);        /* window cells (offsets from wbase) in key order */
-    uint16_t *inv = reinterpret_cast<uint16_t *>(smem + off_inv);              /* slot of every tile position */
-    uint16_t *lofs = reinterpret_cast<uint16_t *>(smem + off_lofs);            /* 8 * TS_BLOCK entries */
-    uint32_t *lofs32 = reinterpret_cast<uint32_t *>(smem + off_lofs);
-    unsigned long long *tk_best = reinterpret_cast<unsigned long long *>(smem + off_tk);   /* TS_TB */
-    uint32_t *tk_cum = reinterpret_cast<uint32_t *>(tk_best + TS_TB);                      /* TS_TB + 1 */
-    uint32_t *tk_pl = tk_cum + TS_TB + 4;                                                   /* TS_TB: offset | len << 16 */
-    uint16_t *tk_lo = reinterpret_cast<uint16_t *>(tk_pl + TS_TB);                         /* TS_TB */
-    uint16_t *tk_hi = tk_lo + TS_TB;                                                        /* TS_TB */
-    uint16_t *lentx = reinterpret_cast<uint16_t *>(smem + off_lent);                       /* eviction - xs0 of every list entry */
-    uint32_t *lentv = reinterpret_cast<uint32_t *>(smem + off_lent + 2u * ent_cap);        /* staged: the priority it handed over */
-    __shared__ uint32_t wsum[TS_BLOCK / 64], s_own[TS_BLOCK / 64];
-    __shared__ uint32_t s_total, s_nbig, s_want;
-    __shared__ uint16_t fb_lo[256], fb_hi[256];
-    __shared__ unsigned long long hl[(TS_TT + 4096 + 64 + 63) / 64];      /* bit i: the cell of sorted slot i has hand-overs (or a carried priority) */
-    __shared__ uint16_t big[TS_TB];                                       /* the batch's tokens with a run of TS_BIG cells or more */
-
-    const uint32_t tid = threadIdx.x;
-    const uint32_t usb = (uint32_t)sb;
-    /* consecutive workgroups go to different XCDs (eight L2s): give each XCD a contiguous stretch of tiles, so that
-     * the tiles that share a region's order array and overlap in their windows meet in the same L2 */
-    const uint32_t per_xcd = gridDim.x >> 3;
-    const uint32_t tl = (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);
-    if (tl >= ntiles) return;
-    uint32_t a, b, region;
-    ts_tile_range(G, tile0 + tl, a, b, region);
-    a = max(a, pos0);
-    b = min(b, pos1);
-    if (a >= b) return;
-    const uint32_t t0r = region * G.TILE;
-    const uint32_t wlo = a > usb ? a - usb : 0u;
-    const uint32_t wbase = wlo & ~3u;
-    /* ---- everything the tile needs from HBM is requested at once (one latency, not seven in a row): the region's
-     *      order, the token range, the evictions, the window bytes; the barriers in between only order LDS traffic
-     *      (ts_barrier_lds does not wait for loads in flight) ---- */
-    uint32_t mine[16];
-    {
-        const uint32_t K = RP / TS_BLOCK;                  /* 4, 8 or 16 consecutive slots per thread */
-        const uint16_t *ord = order_all + (size_t)region * RP + (size_t)tid * K;
-        if (K == 16) {
-            const uint4 v0 = *reinterpret_cast<const uint4 *>(ord), v1 = *reinterpret_cast<const uint4 *>(ord + 8);
-            const uint32_t w[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
-#pragma unroll
-            for (int q = 0; q < 8; q++) { mine[2 * q] = w[q] & 0xFFFFu; mine[2 * q + 1] = w[q] >> 16; }
-        } else if (K == 8) {
-            const uint4 v0 = *reinterpret_cast<const uint4 *>(ord);
-            const uint32_t w[4] = {v0.x, v0.y, v0.z, v0.w};
-#pragma unroll
-            for (int q = 0; q < 4; q++) { mine[2 * q] = w[q] & 0xFFFFu; mine[2 * q + 1] = w[q] >> 16; }
-#pragma unroll
-            for (int q = 8; q < 16; q++) mine[q] = 0xFFFFFFFFu;
-        } else {
-            const uint2 v0 = *reinterpret_cast<const uint2 *>(ord);
-            mine[0] = v0.x & 0xFFFFu; mine[1] = v0.x >> 16; mine[2] = v0.y & 0xFFFFu; mine[3] = v0.y >> 16;
-#pragma unroll
-            for (int q = 4; q < 16; q++) mine[q] = 0xFFFFFFFFu;
-        }
-    }
-    const uint32_t k0 = tstart[tl], k1 = tstart[tl + 1];
-    /* the first batch's token positions (and, once they are here, their lengths) travel with the tile's other requests:
-     * under the batch loop they were two exposed round trips, one behind the other */
-    const uint32_t p_pre = chain[min(k0 + (tid >> 1), max(k1, 1u) - 1u)];
-    /* the evictions [xs0, xs1) (every load unconditional, clamped: the compiler keeps them in flight) */
-    const uint32_t xs0 = wlo > usb ? wlo - usb : 0u, xs1 = b > usb ? b - usb : 0u;
-    uint32_t xv[TS_SRC], xc[TS_SRC];                        /* priority handed over / the cell it goes to (offset from wbase) */
-    {
-        const uint32_t xl = xs1 ? xs1 - 1u : 0u;
-#pragma unroll
-        for (int r = 0; r < TS_SRC; r++) {
-            const uint32_t x = xs0 + tid + (uint32_t)r * TS_BLOCK;
-            const uint32_t xq = min(x, xl);
-            xv[r] = xval[xq];
-            xc[r] = ps[xq];
-        }
-    }
-    constexpr int BY_PER = (TS_TT + 4096 + 256 + 16 + 4 * TS_BLOCK - 1) / (4 * TS_BLOCK);
-    uint32_t by_raw[BY_PER];
-    const uint32_t nb = (b + (uint32_t)la + 8 - wbase + 3) & ~3u;
-#pragma unroll
-    for (int r = 0; r < BY_PER; r++) {
-        const uint32_t i = (tid + (uint32_t)r * TS_BLOCK) * 4u;
-        by_raw[r] = i < nb ? *reinterpret_cast<const uint32_t *>(in + wbase + i) : 0u;
-    }
-    *reinterpret_cast<uint4 *>(lofs32 + 4u * tid) = make_uint4(0u, 0u, 0u, 0u);     /* the counters (ordered before the counting by the scan's barriers) */
-    /* the region's order, filtered down to the cells of [wlo, b) */
-    uint32_t N;
-    {
-        const uint32_t wl = wlo - t0r, wn = b - wlo;        /* region-local window */
-        uint32_t cnt = 0;
-#pragma unroll
-        for (int q = 0; q < 16; q++) cnt += (mine[q] - wl < wn) ? 1u : 0u;
-        uint32_t run = ts_wg_scan(cnt, wsum, &s_total);
-        const uint32_t shift = t0r - wbase, ta = a - wbase;
-#pragma unroll
-        for (int q = 0; q < 16; q++) {
-            if (mine[q] - wl < wn) {
-                const uint32_t co = mine[q] + shift;
-                sorted[run] = (uint16_t)co;
-                if (co >= ta) inv[co - ta] = (uint16_t)run;
-                run++;
-            }
-        }
-    }
-    const uint32_t len_pre = maxlen[p_pre];
-#pragma unroll
-    for (int r = 0; r < BY_PER; r++) {
-        const uint32_t i = (tid + (uint32_t)r * TS_BLOCK) * 4u;
-        if (i < nb) *reinterpret_cast<uint32_t *>(by + i) = by_raw[r];
-    }
-    /* hand-overs per cell: counter of cell co = entry co + 1 (entry 0 stays 0), two entries per word */
-    {
-        uint32_t own = 0;
-#pragma unroll
-        for (int r = 0; r < TS_SRC; r++) {
-            const uint32_t x = xs0 + tid + (uint32_t)r * TS_BLOCK;
-            const uint32_t dst = x + (xc[r] >> 16);
-            const bool ok = x < xs1 && xv[r] != LZ77X_NONE32 && dst >= wlo;
-            own += (ok && x + usb >= a) ? 1u : 0u;
-            xc[r] = ok ? dst - wbase + 1u : 0u;
-            if (ok) atomicAdd(&lofs32[xc[r] >> 1], 1u << (16u * (xc[r] & 1u)));
-        }
-#pragma unroll
-        for (int d = 32; d > 0; d >>= 1) own += __shfl_xor(own, d, 64);
-        if ((tid & 63u) == 0) s_own[tid >> 6] = own;
-    }
-    ts_barrier_lds();
-    N = s_total;                                            /* = b - wlo: every cell of the window is in the region */
-    if (total && tid == 0) {
-        /* one atomic per workgroup, spread over TS_SLOTS words: atomics to ONE address queue in the L2 at ~100 cycles each
-         * (one per wavefront -- 781 K of them per 100 MB -- took 7 ms) */
-        uint32_t own = 0;
-        for (uint32_t w = 0; w < TS_BLOCK / 64; w++) own += s_own[w];
-        if (own) atomicAdd(&total[1u + (blockIdx.x & (TS_SLOTS - 1u))], (unsigned long long)own);
-    }
-    bool staged;
-    {
-        /* prefix sums in place: eight entries a thread */
-        const uint4 w = *reinterpret_cast<const uint4 *>(lofs32 + 4u * tid);
-        uint32_t c[8] = {w.x & 0xFFFFu, w.x >> 16, w.y & 0xFFFFu, w.y >> 16, w.z & 0xFFFFu, w.z >> 16, w.w & 0xFFFFu, w.w >> 16};
-        uint32_t sum = 0;
-#pragma unroll
-        for (int q = 0; q < 8; q++) sum += c[q];
-        uint32_t run = ts_wg_scan(sum, wsum, &s_total);     /* (its first barrier: every thread has read N) */
-        /* entry e becomes the START of the list of cell e - 1 ... and, once the placing below has bumped it by the
-         * list's length, the start of the list of cell e: list(co) = [lofs[co], lofs[co + 1]) */
-#pragma unroll
-        for (int q = 0; q < 8; q++) { const uint32_t t = c[q]; c[q] = run; run += t; }
-        *reinterpret_cast<uint4 *>(lofs32 + 4u * tid) = make_uint4(c[0] | c[1] << 16, c[2] | c[3] << 16, c[4] | c[5] << 16, c[6] | c[7] << 16);
-    }
-    /* cells by first byte: [fb_lo[c], fb_hi[c]) -- the run of a token of length 1, without a search */
-    for (uint32_t i = tid; i < N; i += TS_BLOCK) {
-        const uint32_t c = by[sorted[i]];
-        const uint32_t cp = i ? (uint32_t)by[sorted[i - 1]] : 256u;
-        if (c != cp) {
-            fb_lo[c] = (uint16_t)i;
-            if (i) fb_hi[cp] = (uint16_t)i;
-        }
-        if (i + 1 == N) fb_hi[c] = (uint16_t)N;
-    }
-    ts_barrier_lds();
-    /* more hand-overs than the LDS left over holds (never seen on text: four in ten evictions hand over): the lists
-     * keep the evictions only and a look-up fetches the priority from xval[] */
-    staged = s_total <= ent_cap;
-#pragma unroll
-    for (int r = 0; r < TS_SRC; r++) {
-        if (xc[r]) {
-            const uint32_t x = xs0 + tid + (uint32_t)r * TS_BLOCK;
-            const uint32_t sh = 16u * (xc[r] & 1u);
-            const uint32_t slot = (atomicAdd(&lofs32[xc[r] >> 1], 1u << sh) >> sh) & 0xFFFFu;
-            lentx[slot] = (uint16_t)(x - xs0);
-            if (staged) lentv[slot] = xv[r];
-        }
-    }
-    __syncthreads();
-    if (tid == 0) { s_nbig = 0; s_want = 0; }
-    __syncthreads();
-    bool hl_built = false;                                 /* the bitmap of B' exists (built when the tile meets its first big run) */
-
-    const uint32_t omask = ob >= 32 ? 0xFFFFFFFFu : (1u << ob) - 1u;
-    for (uint32_t kb = k0; kb < k1; kb += TS_TB) {
-        const uint32_t nt = min(TS_TB, k1 - kb);
-        /* ---- A: the run of cells sharing the token's len bytes; lane pair = (down, up) ---- */
-        {
-            const uint32_t ti = tid >> 1, up = tid & 1u;
-            if (ti < nt) {
-                const uint32_t p = kb == k0 ? p_pre : chain[kb + ti];
-                const uint32_t len = kb == k0 ? len_pre : (uint32_t)maxlen[p];
-                const uint32_t qo = p - wbase;
-                int edge = 0;
-                if (len > 0) {
-                    uint32_t qw[4];
-#pragma unroll
-                    for (int w = 0; w < 4; w++) qw[w] = (uint32_t)(4 * w) < len ? ld32_at<true>(by, qo + 4 * w) : 0u;
-                    auto shares = [&](int i) -> bool {
-                        const uint32_t co = sorted[i];
-#pragma unroll
-                        for (int w = 0; w < 4; w++) {
-                            if ((uint32_t)(4 * w) < len) {
-                                uint32_t x = ld32_at<true>(by, co + 4 * w) ^ qw[w];
-                                const uint32_t rem = len - 4 * w;
-                                if (rem < 4) x &= (1u << (8 * rem)) - 1u;
-                                if (x) return false;
-                            }
-                        }
-                        for (uint32_t i2 = 16; i2 < len; i2 += 4) {
-                            uint32_t x = ld32_at<true>(by, co + i2) ^ ld32_at<true>(by, qo + i2);
-                            const uint32_t rem = len - i2;
-                            if (rem < 4) x &= (1u << (8 * rem)) - 1u;
-                            if (x) return false;
-                        }
-                        return true;
-                    };
-                    const int j = (int)inv[p - a];
-                    if (len == 1) {
-                        edge = up ? (int)fb_hi[qw[0] & 0xFFu] : (int)fb_lo[qw[0] & 0xFFu];
-                    } else if (!up) {
-                        int lo = j, bad = -1, step = 1;           /* every slot of [lo, j) shares; slot `bad` does not */
-                        while (lo > 0) {
-                            const int t = lo > step ? lo - step : 0;
-                            if (shares(t)) { lo = t; step <<= 1; }
-                            else { bad = t; break; }
-                        }
-                        if (bad >= 0)
-                            while (lo - bad > 1) {
-                                const int m = (lo + bad) >> 1;
-                                if (shares(m)) lo = m; else bad = m;
-                            }
-                        edge = lo;
-                    } else {
-                        int hi = j + 1, bad = (int)N, step = 1;   /* every slot of (j, hi) shares; slot `bad` does not */
-                        while (hi < (int)N) {
-                            const int t = min(hi - 1 + step, (int)N - 1);
-                            if (shares(t)) { hi = t + 1; step <<= 1; }
-                            else { bad = t; break; }
-                        }
-                        while (hi < bad) {
-                            const int m = (hi + bad) >> 1;
-                            if (shares(m)) hi = m + 1; else bad = m;
-                        }
-                        edge = hi;
-                    }
-                }
-                if (up) tk_hi[ti] = (uint16_t)edge;
-                else { tk_lo[ti] = (uint16_t)edge; tk_pl[ti] = qo | (len << 16); }
-            }
-        }
-        __syncthreads();
-        /* ---- the runs laid end to end ---- */
-        {
-            uint32_t cnt = 0;
-            if (tid < nt && (tk_pl[tid] >> 16)) cnt = (uint32_t)tk_hi[tid] - (uint32_t)tk_lo[tid];
-            /* big runs: the first one a tile meets builds the bitmap of the slots whose cells have hand-overs */
-            if (cnt >= TS_BIG_V4) s_want = 1u;
-            __syncthreads();
-            if (s_want) {
-                if (!hl_built) {
-                    /* (a wavefront's 64 consecutive slots are a word; a cell of a later segment's look-back counts as having
-                     * one: its carried priority is a rank, not its position) */
-                    for (uint32_t i0 = (tid & ~63u); i0 < N; i0 += TS_BLOCK) {
-                        const uint32_t i = i0 + (tid & 63u);
-                        bool h = false;
-                        if (i < N) {
-                            const uint32_t co = sorted[i];
-                            h = lofs[co + 1] != lofs[co] || wbase + co < nlook;
-                        }
-                        const unsigned long long m = __ballot(h);
-                        if ((tid & 63u) == 0) hl[i0 >> 6] = m;
-                    }
-                    hl_built = true;
-                    __syncthreads();
-                }
-                if (cnt >= TS_BIG_V4) {
-                    /* ... a wavefront of its own (below) when few of its members have hand-overs, an eighth at most: a run
-                     * that is dense with them is cheaper member by member, dealt over the whole workgroup */
-                    const uint32_t lo = tk_lo[tid], hi = tk_hi[tid];
-                    uint32_t withl = 0;
-                    for (uint32_t wd = lo >> 6; wd <= ((hi - 1u) >> 6); wd++) {
-                        unsigned long long m = hl[wd];
-                        if (wd == (lo >> 6)) m &= ~0ull << (lo & 63u);
-                        if (wd == ((hi - 1u) >> 6) && (hi & 63u)) m &= ~0ull >> (64u - (hi & 63u));
-                        withl += (uint32_t)__popcll(m);
-                    }
-                    if (withl * 8u <= cnt) { big[atomicAdd(&s_nbig, 1u)] = (uint16_t)tid; cnt = 0; }
-                }
-            }
-            const uint32_t ex = ts_wg_scan(cnt, wsum, &s_total);
-            if (tid < nt) { tk_cum[tid] = ex; tk_best[tid] = ~0ull; }
-            __syncthreads();
-        }
-        const uint32_t W = s_total;
-        if (tid == 0) tk_cum[nt] = W;
-        /* ---- B: every run member: inside the token's window?  then its priority at time p ---- */
-        {
-            const uint32_t per = (W + TS_BLOCK - 1u) / TS_BLOCK;
-            const uint32_t w0 = tid * per, w1 = min(w0 + per, W);
-            __syncthreads();                                /* tk_cum[nt] */
-            if (w0 < w1) {
-                uint32_t lo_i = 0, hi_i = nt;               /* largest ti with cum[ti] <= w0 */
-                while (hi_i - lo_i > 1) {
-                    const uint32_t m = (lo_i + hi_i) >> 1;
-                    if (tk_cum[m] <= w0) lo_i = m; else hi_i = m;
-                }
-                uint32_t ti = lo_i;
-                uint32_t w = w0;
-                while (w < w1) {
-                    /* skip tokens without members (cum[ti + 1] == cum[ti]) */
-                    while (tk_cum[ti + 1] <= w) ti++;
-                    const uint32_t pl = tk_pl[ti], cbase = tk_cum[ti], cend = min(tk_cum[ti + 1], w1);
-                    const uint32_t p = wbase + (pl & 0xFFFFu);
-                    const uint32_t cmin = p > usb ? p - usb : 0u;
-                    const uint32_t xlim = cmin;              /* an eviction x is before p: x + sb < p */
-                    const uint32_t slot0 = (uint32_t)tk_lo[ti] - cbase;
-                    unsigned long long best = ~0ull;
-                    for (; w < cend; w++) {
-                        const uint32_t co = sorted[slot0 + w];
-                        const uint32_t c = wbase + co;
-                        if (c < cmin || c >= p) continue;
-                        /* the latest hand-over into c by an eviction before p (x + sb < p), else what c came with */
-                        /* A hand-over only ever LOWERS its cell (k_prio_fwd stores xval[x] under `gate & lower`; tree.c:202-231:
-                         * the successor moves UP into x's place), so the latest one before p is also the smallest one before p: a
-                         * plain minimum over the list's entries in time, nothing to track */
-                        uint32_t prio = c < nlook ? look[c] : c + voff;
-                        const uint32_t e1 = lofs[co + 1];
-                        if (staged) {
-                            for (uint32_t e = lofs[co]; e < e1; e++) {
-                                const uint32_t x = xs0 + lentx[e], v = lentv[e];
-                                prio = x < xlim ? min(prio, v) : prio;
-                            }
-                        } else {
-                            for (uint32_t e = lofs[co]; e < e1; e++) {
-                                const uint32_t x = xs0 + lentx[e];
-                                if (x < xlim) prio = min(prio, xval[x]);
-                            }
-                        }
-                        const unsigned long long key = ((unsigned long long)prio << 32) | c;
-                        best = key < best ? key : best;
-                    }
-                    if (best != ~0ull) atomicMin(&tk_best[ti], best);
-                }
-            }
-        }
-        /* ---- B': the big runs, a wavefront each ---- */
-        {
-            const uint32_t nbig = s_nbig, lane = tid & 63u, wave = tid >> 6;
-            for (uint32_t bi = wave; bi < nbig; bi += TS_BLOCK / 64u) {
-                const uint32_t ti = big[bi];
-                const uint32_t pl = tk_pl[ti], qo = pl & 0xFFFFu, len = pl >> 16;
-                const uint32_t p = wbase + qo, cmin = p > usb ? p - usb : 0u, xlim = cmin;
-                const uint32_t lo = tk_lo[ti], hi = tk_hi[ti];
-                unsigned long long best = ~0ull;
-                /* (1) the members some eviction handed a priority to: the set bits of hl over the slots [lo, hi), a word a lane */
-                for (uint32_t wd = (lo >> 6) + lane; wd <= ((hi - 1u) >> 6); wd += 64u) {
-                    unsigned long long m = hl[wd];
-                    if (wd == (lo >> 6)) m &= ~0ull << (lo & 63u);
-                    if (wd == ((hi - 1u) >> 6) && (hi & 63u)) m &= ~0ull >> (64u - (hi & 63u));
-                    while (m) {
-                        const uint32_t i = wd * 64u + (uint32_t)__builtin_ctzll(m);
-                        m &= m - 1ull;
-                        const uint32_t co = sorted[i], c = wbase + co;
-                        if (c < cmin || c >= p) continue;
-                        uint32_t prio = c < nlook ? look[c] : c + voff, latest = 0, at = 0;
-                        bool any = false;
-                        const uint32_t e1 = lofs[co + 1];
-                        for (uint32_t e = lofs[co]; e < e1; e++) {
-                            const uint32_t x = xs0 + lentx[e];
-                            if (x < xlim && (!any || x > latest)) { any = true; latest = x; at = e; }
-                        }
-                        if (any) {
-                            prio = lentv[min(at, ent_cap - 1u)];
-                            if (!staged) prio = xval[latest];
-                        }
-                        const unsigned long long key = ((unsigned long long)prio << 32) | c;
-                        best = key < best ? key : best;
-                    }
-                }
-                /* (2) the oldest member of the window without one: its priority is its position */
-                {
-                    uint32_t qw[4];
-#pragma unroll
-                    for (int w = 0; w < 4; w++) qw[w] = (uint32_t)(4 * w) < len ? ld32_at<true>(by, qo + 4 * w) : 0u;
-                    for (uint32_t c0 = max(cmin, nlook); c0 < p; c0 += 64u) {
-                        const uint32_t c = c0 + lane;
-                        bool ok = false;
-                        if (c < p) {
-                            const uint32_t co = c - wbase;
-                            ok = lofs[co + 1] == lofs[co];
-#pragma unroll
-                            for (int w = 0; w < 4; w++) {
-                                if ((uint32_t)(4 * w) < len) {
-                                    uint32_t x = ld32_at<true>(by, co + 4 * w) ^ qw[w];
-                                    const uint32_t rem = len - 4 * w;
-                                    if (rem < 4) x &= (1u << (8 * rem)) - 1u;
-                                    ok = ok && x == 0u;
-                                }
-                            }
-                            for (uint32_t i2 = 16; i2 < len && ok; i2 += 4) {
-                                uint32_t x = ld32_at<true>(by, co + i2) ^ ld32_at<true>(by, qo + i2);
-                                const uint32_t rem = len - i2;
-                                if (rem < 4) x &= (1u << (8 * rem)) - 1u;
-                                ok = x == 0u;
-                            }
-                        }
-                        const unsigned long long hit = __ballot(ok);
-                        if (hit) {
-                            const uint32_t c1 = c0 + (uint32_t)__builtin_ctzll(hit);
-                            const unsigned long long key = ((unsigned long long)(c1 + voff) << 32) | c1;
-                            best = key < best ? key : best;
-                            break;
-                        }
-                    }
-                }
-#pragma unroll
-                for (int d = 32; d > 0; d >>= 1) {
-                    const unsigned long long o = __shfl_xor(best, d, 64);
-                    best = o < best ? o : best;
-                }
-                if (lane == 0 && best != ~0ull) atomicMin(&tk_best[ti], best);
-            }
-        }
-        __syncthreads();
-        if (tid == 0) { s_nbig = 0; s_want = 0; }          /* (the next batch counts its own; ordered by the barriers of phase A) */
-        /* ---- C: the token ---- */
-        if (tid < nt) {
-            const uint32_t pl = tk_pl[tid], qo = pl & 0xFFFFu, len = pl >> 16;
-            const uint32_t next = by[qo + len];
-            const uint32_t off = len ? wbase + qo - (uint32_t)(tk_best[tid] & 0xFFFFFFFFull) : 0u;
-            tokval[kb + tid] = (off & omask) | (len << ob) | (next << (ob + lb));
-        }
-        __syncthreads();
-    }
-}
+#ifdef LZ77X_VARIANTS   /* (round 4's tie-break for LDS-sized windows (hand-over lists per cell, a bitmap for long runs)) */
+#include "variants/tokens_sorted_v4.inc"
 #endif
 
-#ifdef LZ77X_VARIANTS   /* (round 1's large-window tie-break: the cross-check of k_tokens_rank, LZ77X_TOKEN_VARIANT=3) */
-/* ---- large windows (sb > 8192): the candidate index lives in global memory -------------------
- * Per tile of BIG_TT positions, every candidate position (tile + its SB look-back) is bucketed by
- * its first two bytes (exact 16-bit key, so a length-1 token reads the 256 adjacent buckets of its
- * first byte).  After the fill pass bucket k is blist[ (k ? bs[k-1] : 0) .. bs[k] ). ---- */
-#define BIG_TT 131072u
-#define BIG_KEYS 65536u
-
-__global__ __launch_bounds__(256) void k_bidx_count(const uint8_t *__restrict__ in, int sb, uint32_t pos0, uint32_t pos1,
-                                                    uint32_t *__restrict__ bs)
-{
-    const uint32_t tile = blockIdx.y;
-    const uint32_t t0 = pos0 + tile * BIG_TT, t1 = min(t0 + BIG_TT, pos1);
-    const uint32_t w0 = t0 > (uint32_t)sb ? t0 - (uint32_t)sb : 0u;
-    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
-    if (w0 + i >= t1) return;
-    const uint32_t c = w0 + i;
-    atomicAdd(&bs[(size_t)tile * BIG_KEYS + (((uint32_t)in[c] << 8) | in[c + 1])], 1u);
-}
-
-__global__ __launch_bounds__(1024) void k_bidx_scan(uint32_t *__restrict__ bs)
-{
-    __shared__ uint32_t wsum[16];
-    uint32_t *b = bs + (size_t)blockIdx.x * BIG_KEYS;
-    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    uint32_t v[64], tot = 0;
-#pragma unroll
-    for (int i = 0; i < 64; i += 4) {
-        const uint4 t = *reinterpret_cast<const uint4 *>(b + tid * 64 + i);
-        v[i] = t.x; v[i + 1] = t.y; v[i + 2] = t.z; v[i + 3] = t.w;
-        tot += t.x + t.y + t.z + t.w;
-    }
-    uint32_t incl = tot;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const uint32_t t = __shfl_up(incl, d, 64);
-        if (lane >= (uint32_t)d) incl += t;
-    }
-    if (lane == 63) wsum[wave] = incl;
-    __syncthreads();
-    uint32_t run = incl - tot;
-    for (uint32_t w = 0; w < wave; w++) run += wsum[w];
-#pragma unroll
-    for (int i = 0; i < 64; i++) { const uint32_t c = v[i]; v[i] = run; run += c; }
-#pragma unroll
-    for (int i = 0; i < 64; i += 4)
-        *reinterpret_cast<uint4 *>(b + tid * 64 + i) = make_uint4(v[i], v[i + 1], v[i + 2], v[i + 3]);
-}
-
-__global__ __launch_bounds__(256) void k_bidx_fill(const uint8_t *__restrict__ in, int sb, uint32_t pos0, uint32_t pos1,
-                                                   uint32_t *__restrict__ bs, uint32_t *__restrict__ blist, uint32_t span)
-{
-    const uint32_t tile = blockIdx.y;
-    const uint32_t t0 = pos0 + tile * BIG_TT, t1 = min(t0 + BIG_TT, pos1);
-    const uint32_t w0 = t0 > (uint32_t)sb ? t0 - (uint32_t)sb : 0u;
-    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
-    if (w0 + i >= t1) return;
-    const uint32_t c = w0 + i;
-    const uint32_t slot = atomicAdd(&bs[(size_t)tile * BIG_KEYS + (((uint32_t)in[c] << 8) | in[c + 1])], 1u);
-    blist[(size_t)tile * span + slot] = c;
-}
-
-__global__ __launch_bounds__(256) void k_tokens_big(const uint8_t *__restrict__ in, uint32_t n, int sb, int ob, int lb,
-                                                    const uint32_t *__restrict__ chain, uint32_t ntok,
-                                                    const uint8_t *__restrict__ maxlen,
-                                                    const uint32_t *__restrict__ ofs, const uint2 *__restrict__ ent, uint32_t dbase,
-                                                    uint32_t pos0, const uint32_t *__restrict__ bs, const uint32_t *__restrict__ blist,
-                                                    uint32_t span, uint32_t *__restrict__ tokval, const uint32_t *__restrict__ look,
-                                                    uint32_t nlook, uint32_t voff)
-{
-    const uint32_t lane = threadIdx.x & 63;
-    const uint32_t k = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    if (k >= ntok) return;
-    const uint32_t p = chain[k];
-    const uint32_t len = maxlen[p];
-    const uint32_t next = in[p + len];
-    uint32_t off = 0;
-    if (len > 0) {
-        const uint32_t tile = (p - pos0) / BIG_TT;
-        const uint32_t *b = bs + (size_t)tile * BIG_KEYS;
-        const uint32_t *list = blist + (size_t)tile * span;
-        const uint32_t klo = len >= 2 ? (((uint32_t)in[p] << 8) | in[p + 1]) : ((uint32_t)in[p] << 8);
-        const uint32_t khi = len >= 2 ? klo : (klo | 0xFFu);
-        const uint32_t i0 = klo ? b[klo - 1] : 0u, i1 = b[khi];
-        const uint32_t cmin = p > (uint32_t)sb ? p - (uint32_t)sb : 0u;
-        const uint8_t *q = in + p;
-        uint64_t best = ~0ull;
-        for (uint32_t i = i0 + lane; i < i1; i += 64) {
-            const uint32_t c = list[i];
-            if (c < cmin || c >= p) continue;
-            const uint8_t *r = in + c;
-            bool same = true;
-            for (uint32_t j = 0; j < len; j += 4) {
-                uint32_t x = ld32u(r + j) ^ ld32u(q + j);
-                const uint32_t rem = len - j;
-                if (rem < 4) x &= (1u << (8 * rem)) - 1u;
-                if (x) { same = false; break; }
-            }
-            if (!same) continue;
-            uint32_t prio = c < nlook ? look[c] : c + voff, latest = 0;
-            bool any = false;
-            const uint32_t lo = c > dbase ? ofs[c - dbase - 1] : 0, hi = c >= dbase ? ofs[c - dbase] : 0;
-            for (uint32_t e = lo; e < hi; e++) {
-                const uint2 t = ent[e];
-                if ((uint64_t)t.x + (uint32_t)sb < p && (!any || t.x > latest)) { any = true; latest = t.x; prio = t.y; }
-            }
-            const uint64_t key = ((uint64_t)prio << 32) | c;
-            best = key < best ? key : best;
-        }
-#pragma unroll
-        for (int d = 32; d > 0; d >>= 1) {
-            const uint64_t o = (uint64_t)__shfl_xor((unsigned long long)best, d, 64);
-            best = o < best ? o : best;
-        }
-        off = p - (uint32_t)(best & 0xFFFFFFFFu);
-    }
-    if (lane == 0) {
-        const uint32_t omask = ob >= 32 ? 0xFFFFFFFFu : (1u << ob) - 1u;
-        tokval[k] = (off & omask) | (len << ob) | (next << (ob + lb));
-    }
-}
-
+#ifdef LZ77X_VARIANTS   /* (round 1's large-window tie-break (a two-byte index over the window)) */
+#include "variants/tokens_big.inc"
 #endif
 
 /* ---- large windows, production: candidates in RANK order -----------------------------------------

@@ -118,6 +118,12 @@ int decode_sharded(std::vector<Ctx *> &cs, const uint8_t *z, size_t zn, uint8_t 
     uint64_t stretch_tok = (uint64_t)D * (((uint64_t)0xF0000000u / (uint64_t)(la + 1)) & ~(uint64_t)7);
     if (const char *e = getenv("LZ77X_DECODE_SHARD_STRETCH")) if (atoll(e) > 0) stretch_tok = ((uint64_t)atoll(e) + 7) & ~(uint64_t)7;
     if (stretch_tok < 64 * D) stretch_tok = (64 * D + 7) & ~(size_t)7;
+    /* a stretch's token count and its cuts are 32-bit (k0[], Sh::ntok): with a short lookahead D * 0xF0000000 / (la + 1) passes 2^32.
+     * The tail merged into the last stretch (below) is at most (64 + sb) * D tokens more. */
+    {
+        const uint64_t cap32 = ((uint64_t)0xFFFFFFF8u - (uint64_t)(64 + sb) * D) & ~(uint64_t)7;
+        if (stretch_tok > cap32) stretch_tok = cap32;
+    }
     uint8_t *buf = nullptr;                                  /* the whole output, grown stretch by stretch */
     size_t buf_cap = 0;
     uint64_t n_done = 0;
@@ -125,7 +131,11 @@ int decode_sharded(std::vector<Ctx *> &cs, const uint8_t *z, size_t zn, uint8_t 
     struct BufGuard { uint8_t **p; bool keep = false; ~BufGuard() { if (!keep) { free(*p); *p = nullptr; } } } guard{&buf};
     for (uint64_t T0 = 0; T0 < ntok64;) {
     uint64_t T1 = T0 + stretch_tok < ntok64 ? T0 + stretch_tok : ntok64;
-    if (ntok64 - T1 < 64 * D) T1 = ntok64;                   /* (no tail too short to cut) */
+    /* no tail too short to cut: a shard must produce at least a window of bytes (its map is over its last sb bytes), and a
+     * token at least one -- a tail of fewer than (64 + sb) tokens per device joins the stretch before it instead of failing
+     * the `fits` test below, which would drop everything the earlier stretches decoded */
+    if (ntok64 - T1 < (64 + (uint64_t)sb) * D) T1 = ntok64;
+    if (T1 - T0 > (uint64_t)0xFFFFFFF8u) return LZ77X_OK;     /* (cannot happen with the cap above; one device rather than a wrapped count) */
     const uint32_t ntok = (uint32_t)(T1 - T0);
     const uint8_t *zs = z + (size_t)(T0 / 8) * (size_t)g.T;  /* the stretch's tokens begin at zs + 4 */
     /* windows the segment walk takes (sb <= 8192): symbolic tails per segment; above: the tile pass on [history | output]
@@ -195,6 +205,9 @@ int decode_sharded(std::vector<Ctx *> &cs, const uint8_t *z, size_t zn, uint8_t 
     }
     const uint32_t pre = tiles ? (uint32_t)((usb + LZ77K_DEC_TILE_BYTES - 1) / LZ77K_DEC_TILE_BYTES * LZ77K_DEC_TILE_BYTES) : 0u;
     std::vector<const unsigned long long *> d_unres(D, nullptr);
+    /* (pageable, and the source of asynchronous copies in both branches: it lives until the shards' streams have been
+     * synchronised by the gather below) */
+    std::vector<std::vector<uint8_t>> incoming(D + 1, std::vector<uint8_t>(usb, 0));
     if (tiles) {
         /* 2t. every shard, on a host thread of its own (the jumping rounds look at a counter between passes): tile pass and
          *     jumping on [pre bytes of history | output]; the history counts as resolved, so afterwards every byte holds its
@@ -239,7 +252,6 @@ int decode_sharded(std::vector<Ctx *> &cs, const uint8_t *z, size_t zn, uint8_t 
         });
         if (rc) return rc;
         /* 3t. the host chains the maps (nothing lies before the first shard: zeros) */
-        std::vector<std::vector<uint8_t>> incoming(D + 1, std::vector<uint8_t>(usb, 0));
         incoming[0] = carry_in;
         for (size_t d = 0; d < D; d++) lz77x_shard_compose_tail32(tmap[d].data(), sb, incoming[d].data(), incoming[d + 1].data());
         carry_in = incoming[D];                              /* the next stretch's history */
@@ -269,7 +281,6 @@ int decode_sharded(std::vector<Ctx *> &cs, const uint8_t *z, size_t zn, uint8_t 
     }
     /* 3. the host chains the maps: incoming bytes of every shard (nothing lies before the first: zero bytes, what a
      *    copy from before the start of the output reads in the single-device decoder too) */
-    std::vector<std::vector<uint8_t>> incoming(D + 1, std::vector<uint8_t>(usb, 0));
     incoming[0] = carry_in;
     for (size_t d = 0; d < D; d++) {
         Ctx &c = *cs[d];
@@ -351,10 +362,6 @@ static int encode_sharded_stretch(std::vector<Ctx *> &cs, const uint8_t *src, si
     const char *tv = LZ77X_VENV("LZ77X_TOKEN_VARIANT");
     const int tvariant = tv ? atoi(tv) : 0;
     auto dev = [&](ShardJob &j) -> int { HIPCHK(hipSetDevice(j.c->device)); return LZ77X_OK; };
-    auto sync_all = [&]() -> int {
-        for (ShardJob &j : J) { HIPCHK(hipSetDevice(j.c->device)); HIPCHK(hipStreamSynchronize(j.c->stream)); }
-        return LZ77X_OK;
-    };
     const size_t hwords = 4 * usb + 1024;                 /* pinned words per shard beyond the tbase copy */
 
     /* -- phase A: every shard on its own: input, match stage, the parse chain's maps, round masks.  One host thread
@@ -465,108 +472,149 @@ static int encode_sharded_stretch(std::vector<Ctx *> &cs, const uint8_t *src, si
         HIPCHK(hipMemcpyAsync(c.h_tbase.p, j.d_tbase, ((size_t)j.nsub + 1) * 4, hipMemcpyDeviceToHost, c.stream));
     }
 
-    /* -- the priority recurrence across the cuts (tree.c:202-231): all shards iterate together -- */
+    /* -- the priority recurrence across the cuts (tree.c:202-231): all shards iterate together.  Round 6: every shard has a
+     *    host thread of its own for the whole iteration (as phase A has): it enqueues its maps, waits for ITS device, and
+     *    after the exchange enqueues its sweep and waits again -- D devices work side by side and no thread waits for a
+     *    device that is not its own.  What is serial is what thread 0 does alone between two barriers: chaining the D maps
+     *    (D x sb look-ups) and reading the D flip summaries.  Round 5 drove every shard from one thread -- per iteration
+     *    2 D hipSetDevice + enqueue rounds and two sync_all loops over all devices. -- */
     {
         std::vector<uint32_t> v(usb);
         std::vector<char> flipped(D, 0);
-        const uint16_t *d_sdest = nullptr;
-        const uint32_t *d_sloc = nullptr;
-        int max_iters = 1 << 30;
         uint32_t iters = 0;
         /* the error front of lz77k_prio (k_prio.hip), across the shards: flips and the first open block of the last six iterations */
         uint64_t hist_f[6] = {0, 0, 0, 0, 0, 0}, hist_b[6] = {0, 0, 0, 0, 0, 0};
         int front_budget = 64;
         if (const char *me = getenv("LZ77X_PRIO_MAX_ITERS")) if (atoi(me) > 0) front_budget = atoi(me);
         bool on_host = false;
-        for (int it = 0; it < max_iters; it++) {
-            for (size_t d = 0; d + 1 < D; d++) {            /* the last shard's whole map is nobody's input */
-                ShardJob &j = J[d];
-                if ((rc = dev(j))) return rc;
-                HIPCHK(lz77k_prio_maps(j.P, j.c->stream, true, &d_sdest, &d_sloc));
-                if (j.nx) {
-                    HIPCHK(hipMemcpyAsync(j.h + 512, d_sloc, usb * 4, hipMemcpyDeviceToHost, j.c->stream));
-                    HIPCHK(hipMemcpyAsync(j.h + 512 + usb, d_sdest, usb * 2, hipMemcpyDeviceToHost, j.c->stream));
+        struct Team {
+            size_t D; std::mutex m; std::condition_variable cv; size_t waiting = 0; uint64_t gen = 0;
+            std::atomic<int> failed{0};
+            bool done = false, hopeless = false;
+            void barrier()
+            {
+                std::unique_lock<std::mutex> lk(m);
+                const uint64_t g0 = gen;
+                if (++waiting == D) { waiting = 0; gen++; cv.notify_all(); }
+                else cv.wait(lk, [&] { return gen != g0; });
+            }
+        } team;
+        team.D = D;
+        host_serial_ms += now_ms() - t_serial;               /* (the chain's exchange and the enqueue of its second half) */
+        double serial_it = 0;                                 /* thread 0 alone between two barriers */
+        rc = run_team(D, [&](size_t d) -> int {
+            ShardJob &j = J[d];
+            int my_rc = LZ77X_OK;
+            /* a failing shard keeps meeting the barriers; everybody leaves together at the end of the iteration */
+            auto step = [&](auto fn) { if (my_rc == LZ77X_OK && !team.failed.load()) { my_rc = fn(); if (my_rc) team.failed.store(1); } };
+            for (;;) {
+                /* 1. this shard's maps from its current gates; all but the last shard: the whole plan as ONE map, to the host */
+                step([&]() -> int {
+                    const uint16_t *d_sdest = nullptr;
+                    const uint32_t *d_sloc = nullptr;
+                    HIPCHK(hipSetDevice(j.c->device));
+                    if (d + 1 < D) {
+                        HIPCHK(lz77k_prio_maps(j.P, j.c->stream, true, &d_sdest, &d_sloc));
+                        if (j.nx) {
+                            HIPCHK(hipMemcpyAsync(j.h + 512, d_sloc, usb * 4, hipMemcpyDeviceToHost, j.c->stream));
+                            HIPCHK(hipMemcpyAsync(j.h + 512 + usb, d_sdest, usb * 2, hipMemcpyDeviceToHost, j.c->stream));
+                        }
+                    } else
+                        HIPCHK(lz77k_prio_maps(j.P, j.c->stream, false, nullptr, nullptr));   /* the last shard's whole map is nobody's input */
+                    if (d + 1 < D) HIPCHK(hipStreamSynchronize(j.c->stream));                 /* (the last shard's maps only precede its own sweep) */
+                    return LZ77X_OK;
+                });
+                team.barrier();
+                /* 2. thread 0: the cells every shard starts from -- the maps chained front to back (lz77x_shard_compose_cells) */
+                if (d == 0 && !team.failed.load()) {
+                    const double ts = now_ms();
+                    if (carry.first) for (size_t i = 0; i < usb; i++) v[i] = (uint32_t)i;      /* the start of the input: every cell its own position */
+                    else memcpy(v.data(), carry.cells.data(), usb * 4);                         /* a later stretch: the carried ranks */
+                    for (size_t q = 0; q < D; q++) {
+                        ShardJob &jq = J[q];
+                        if (q > 0) memcpy(jq.h + 512 + 2 * usb, v.data(), usb * 4);            /* pinned copy of the cells shard q starts from */
+                        if (q + 1 < D && jq.nx)                                               /* v <- shard q's whole map applied to v (no step: the cells pass through) */
+                            lz77x_shard_compose_cells(reinterpret_cast<const uint16_t *>(jq.h + 512 + usb), jq.h + 512, g.sb, v.data());
+                    }
+                    serial_it += now_ms() - ts;
                 }
+                team.barrier();
+                /* 3. the cells in, the exact sweep of every block that is not final, the flip summary out */
+                step([&]() -> int {
+                    HIPCHK(hipSetDevice(j.c->device));
+                    if (d > 0) HIPCHK(lz77k_prio_set_in0(j.P, j.h + 512 + 2 * usb, hipMemcpyHostToDevice, j.c->stream));
+                    /* (the last shard of a stretch that is not the last: the sb cells left live after its last step) */
+                    uint32_t *d_state = (d + 1 == D && !last_stretch) ? j.c->look.as<uint32_t>() + usb + 8 : nullptr;
+                    HIPCHK(lz77k_prio_sweep(j.P, j.c->stream, j.c->h_small.as<uint32_t>() + 8, d_state));
+                    HIPCHK(hipStreamSynchronize(j.c->stream));
+                    return LZ77X_OK;
+                });
+                team.barrier();
+                /* 4. thread 0: who flipped, which blocks are final, is the budget enough */
+                if (d == 0) {
+                    const double ts = now_ms();
+                    if (team.failed.load()) team.done = true;
+                    else {
+                        iters++;
+                        bool any = false, earlier = false;
+                        uint64_t flips = 0, blocks_before = 0, first_open = 0;
+                        for (size_t q = 0; q < D; q++) {
+                            const uint32_t *hf = J[q].c->h_small.as<uint32_t>() + 8;
+                            flipped[q] = hf[0] != 0;
+                            flips += hf[0];
+                            if (flipped[q] && !any) first_open = blocks_before + hf[1];
+                            blocks_before += J[q].P.NB;
+                            /* a shard after one that still changes may be handed different cells next time: nothing of it is final */
+                            lz77k_prio_advance(J[q].P, hf, earlier);
+                            earlier = earlier || flipped[q];
+                            any = any || flipped[q];
+                        }
+                        if (!any) team.done = true;
+                        else {
+                            for (int q = 0; q < 5; q++) { hist_f[q] = hist_f[q + 1]; hist_b[q] = hist_b[q + 1]; }
+                            hist_f[5] = flips;
+                            hist_b[5] = first_open;
+                            if ((int)iters >= front_budget || lz77x_prio_hopeless(hist_f, hist_b, blocks_before - first_open, (int)iters, front_budget))
+                                team.done = team.hopeless = true;
+                        }
+                    }
+                    serial_it += now_ms() - ts;
+                }
+                team.barrier();
+                if (team.done) break;
             }
-            if (D > 0) {
-                ShardJob &j = J[D - 1];
-                if ((rc = dev(j))) return rc;
-                HIPCHK(lz77k_prio_maps(j.P, j.c->stream, false, nullptr, nullptr));
-            }
-            host_serial_ms += now_ms() - t_serial;
-            if ((rc = sync_all())) return rc;
-            t_serial = now_ms();
-            if (carry.first) for (size_t i = 0; i < usb; i++) v[i] = (uint32_t)i;      /* the start of the input: every cell its own position */
-            else memcpy(v.data(), carry.cells.data(), usb * 4);                         /* a later stretch: the carried ranks */
+            return my_rc;
+        });
+        if (rc) return rc;
+        host_serial_ms += serial_it;
+        t_serial = now_ms();
+        if (team.hopeless) {
+            /* one block an iteration (input that repeats with a period of about a window): the recurrence of the whole
+             * stretch on a host core instead, shard after shard -- each shard's evictions follow its predecessor's, the
+             * cells one leaves behind are the cells the next starts from (hoststage.c lz77x_prio_run_cells) */
+            if (carry.first) for (size_t i = 0; i < usb; i++) v[i] = (uint32_t)i;
+            else memcpy(v.data(), carry.cells.data(), usb * 4);
+            const double th = now_ms();
             for (size_t d = 0; d < D; d++) {
                 ShardJob &j = J[d];
                 if ((rc = dev(j))) return rc;
+                std::vector<uint32_t> h_ps, h_xv, out(usb);
+                h_ps.resize((size_t)j.nx + 16);
+                h_xv.resize((size_t)j.nx + 16);
+                HIPCHK(hipMemcpy(h_ps.data(), j.c->ps.p, (size_t)j.nx * 4, hipMemcpyDeviceToHost));
                 if (d > 0) {
-                    uint32_t *pin = j.h + 512 + 2 * usb;                /* pinned copy of the cells this shard starts from */
+                    uint32_t *pin = j.h + 512 + 2 * usb;            /* the cells this shard REALLY starts from: the tie-break's look-back */
                     memcpy(pin, v.data(), usb * 4);
                     HIPCHK(lz77k_prio_set_in0(j.P, pin, hipMemcpyHostToDevice, j.c->stream));
+                    HIPCHK(hipStreamSynchronize(j.c->stream));
                 }
-                if (d + 1 < D) {                                       /* v <- this shard's whole map applied to v */
-                    if (j.nx == 0) continue;                           /* no step: the cells pass through */
-                    lz77x_shard_compose_cells(reinterpret_cast<const uint16_t *>(j.h + 512 + usb), j.h + 512, g.sb, v.data());
-                }
+                if (!lz77x_prio_run_cells(h_ps.data(), j.nx, g.sb, v.data(), (uint32_t)j.gpos0, h_xv.data(), out.data())) return LZ77X_E_NOMEM;
+                HIPCHK(hipMemcpy(j.c->xval.p, h_xv.data(), (size_t)j.nx * 4, hipMemcpyHostToDevice));
+                v = out;
             }
-            for (size_t d = 0; d < D; d++) {
-                ShardJob &j = J[d];
-                if ((rc = dev(j))) return rc;
-                /* (the last shard of a stretch that is not the last: the sb cells left live after its last step) */
-                uint32_t *d_state = (d + 1 == D && !last_stretch) ? j.c->look.as<uint32_t>() + usb + 8 : nullptr;
-                HIPCHK(lz77k_prio_sweep(j.P, j.c->stream, j.c->h_small.as<uint32_t>() + 8, d_state));
-            }
-            host_serial_ms += now_ms() - t_serial;
-            if ((rc = sync_all())) return rc;
-            t_serial = now_ms();
-            iters++;
-            bool any = false, earlier = false;
-            uint64_t flips = 0, blocks_before = 0, first_open = 0, blocks_all = 0;
-            for (size_t d = 0; d < D; d++) {
-                const uint32_t *hf = J[d].c->h_small.as<uint32_t>() + 8;
-                flipped[d] = hf[0] != 0;
-                flips += hf[0];
-                if (flipped[d] && !any) first_open = blocks_before + hf[1];
-                blocks_before += J[d].P.NB;
-                /* a shard after one that still changes may be handed different cells next time: nothing of it is final */
-                lz77k_prio_advance(J[d].P, hf, earlier);
-                earlier = earlier || flipped[d];
-                any = any || flipped[d];
-            }
-            blocks_all = blocks_before;
-            if (!any) break;
-            for (int q = 0; q < 5; q++) { hist_f[q] = hist_f[q + 1]; hist_b[q] = hist_b[q + 1]; }
-            hist_f[5] = flips;
-            hist_b[5] = first_open;
-            if ((int)iters >= front_budget || lz77x_prio_hopeless(hist_f, hist_b, blocks_all - first_open, (int)iters, front_budget)) {
-                /* one block an iteration (input that repeats with a period of about a window): the recurrence of the whole
-                 * stretch on a host core instead, shard after shard -- each shard's evictions follow its predecessor's, the
-                 * cells one leaves behind are the cells the next starts from (hoststage.c lz77x_prio_run_cells) */
-                if (carry.first) for (size_t i = 0; i < usb; i++) v[i] = (uint32_t)i;
-                else memcpy(v.data(), carry.cells.data(), usb * 4);
-                const double th = now_ms();
-                for (size_t d = 0; d < D; d++) {
-                    ShardJob &j = J[d];
-                    if ((rc = dev(j))) return rc;
-                    std::vector<uint32_t> h_ps, h_xv, out(usb);
-                    try { h_ps.resize((size_t)j.nx + 16); h_xv.resize((size_t)j.nx + 16); } catch (...) { return LZ77X_E_NOMEM; }
-                    HIPCHK(hipMemcpy(h_ps.data(), j.c->ps.p, (size_t)j.nx * 4, hipMemcpyDeviceToHost));
-                    if (d > 0) {
-                        uint32_t *pin = j.h + 512 + 2 * usb;            /* the cells this shard REALLY starts from: the tie-break's look-back */
-                        memcpy(pin, v.data(), usb * 4);
-                        HIPCHK(lz77k_prio_set_in0(j.P, pin, hipMemcpyHostToDevice, j.c->stream));
-                        HIPCHK(hipStreamSynchronize(j.c->stream));
-                    }
-                    if (!lz77x_prio_run_cells(h_ps.data(), j.nx, g.sb, v.data(), (uint32_t)j.gpos0, h_xv.data(), out.data())) return LZ77X_E_NOMEM;
-                    HIPCHK(hipMemcpy(j.c->xval.p, h_xv.data(), (size_t)j.nx * 4, hipMemcpyHostToDevice));
-                    v = out;
-                }
-                g_stats.host_stageb_ms += now_ms() - th;
-                on_host = true;
-                break;
-            }
+            g_stats.host_stageb_ms += now_ms() - th;
+            on_host = true;
+            t_serial = now_ms();                               /* (the host loop is reported as host_stageb_ms, not as exchange time) */
         }
         g_stats.prio_iters += iters;
         if (!last_stretch) {
@@ -585,11 +633,28 @@ static int encode_sharded_stretch(std::vector<Ctx *> &cs, const uint8_t *src, si
         }
     }
 
-    /* -- tokens: every shard resolves its own (look-back priorities = the cells it started from) -- */
-    for (ShardJob &j : J) {
+    /* -- tokens: every shard resolves its own (look-back priorities = the cells it started from), a host thread per shard:
+     *    each waits for its own device only, and the output piece's buffer is allocated here, beside the kernels -- */
+    const uint64_t T = (uint64_t)g.T;
+    const uint64_t K_all = D ? J[D - 1].K0 + J[D - 1].ntok : 0;
+    const uint64_t zn_total = stream_bytes(K_all, g.T);                /* (of the whole stream so far: it ends here when last_stretch) */
+    auto words_of = [&](size_t d, uint64_t *wlo_out) -> uint64_t {
+        const ShardJob &j = J[d];
+        const bool last = d + 1 == D && last_stretch;
+        const uint64_t K0 = j.K0, K1 = K0 + j.ntok;
+        const uint64_t wlo = K0 == 0 ? 0 : (32 + K0 * T) / 32;
+        const uint64_t whi = last ? (zn_total + 3) / 4 : (32 + K1 * T) / 32;
+        *wlo_out = wlo;
+        return whi > wlo ? whi - wlo : 0;
+    };
+    host_serial_ms += now_ms() - t_serial;
+    rc = for_each_shard(D, [&](size_t d) -> int {
+        int rc;
+        ShardJob &j = J[d];
         Ctx &c = *j.c;
-        if ((rc = dev(j))) return rc;
+        HIPCHK(hipSetDevice(c.device));
         hipStream_t s = c.stream;
+        HIPCHK(hipStreamSynchronize(s));                                   /* (h_tbase has landed) */
         const uint32_t *h_tbase = c.h_tbase.as<uint32_t>();
         if (h_tbase[j.nsub] != j.ntok) { snprintf(g_err, sizeof g_err, "shard chain mismatch: %u vs %u", h_tbase[j.nsub], j.ntok); return LZ77X_E_HIP; }
         const uint32_t *look = j.look ? reinterpret_cast<const uint32_t *>(reinterpret_cast<const uint8_t *>(j.P.tmp) + j.P.o_in) : nullptr;
@@ -607,15 +672,17 @@ static int encode_sharded_stretch(std::vector<Ctx *> &cs, const uint8_t *src, si
         }
         const uint32_t have = j.ntok < 4 ? j.ntok : 4;
         if (have) HIPCHK(hipMemcpyAsync(j.h, c.tokval.as<uint32_t>() + 4 + j.ntok - have, have * 4, hipMemcpyDeviceToHost, s));
+        uint64_t wlo = 0;
+        if ((rc = c.out.need(words_of(d, &wlo) * 4 + 16))) return rc;     /* (beside the tie-break: hipMalloc of a new piece takes milliseconds) */
+        HIPCHK(hipStreamSynchronize(s));
         j.h[8] = have;
-    }
-    if ((rc = sync_all())) return rc;
+        return LZ77X_OK;
+    });
+    if (rc) return rc;
+    t_serial = now_ms();
 
     /* -- pack (lz77.c:246-252): each shard the stream words its tokens start in, with its predecessors' last
      *    tokens in front; then the pieces leave in order -- */
-    const uint64_t T = (uint64_t)g.T;
-    const uint64_t K_all = D ? J[D - 1].K0 + J[D - 1].ntok : 0;
-    const uint64_t zn_total = stream_bytes(K_all, g.T);                /* (of the whole stream so far: it ends here when last_stretch) */
     uint32_t tail[4] = {carry.tail[0], carry.tail[1], carry.tail[2], carry.tail[3]};
     uint32_t ntail = carry.ntail;
     std::vector<uint64_t> piece(D, 0);
@@ -625,10 +692,8 @@ static int encode_sharded_stretch(std::vector<Ctx *> &cs, const uint8_t *src, si
         if ((rc = dev(j))) return rc;
         const bool last = d + 1 == D && last_stretch;
         const uint64_t K0 = j.K0, K1 = K0 + j.ntok;
-        const uint64_t wlo = K0 == 0 ? 0 : (32 + K0 * T) / 32;
-        const uint64_t whi = last ? (zn_total + 3) / 4 : (32 + K1 * T) / 32;
-        const uint64_t nw = whi > wlo ? whi - wlo : 0;
-        if ((rc = c.out.need(nw * 4 + 16))) return rc;
+        uint64_t wlo = 0;
+        const uint64_t nw = words_of(d, &wlo);
         uint32_t *pin = j.h + 16;
         memcpy(pin, tail, sizeof tail);
         if (ntail) HIPCHK(hipMemcpyAsync(c.tokval.as<uint32_t>() + 4 - ntail, pin + 4 - ntail, ntail * 4, hipMemcpyHostToDevice, c.stream));
