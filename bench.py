@@ -103,6 +103,19 @@ def concurrent_streams(L, synth, torch, a, n, k):
             "roundtrip_ok": ok, "note": "not the benchmark value: k independent %d-byte streams on one GPU" % n}
 
 
+def kernel_source_hash():
+    """sha256 over the device sources (csrc/*.hip, kernels_common.h, lz77x_internal.h), in name order: profiles/traffic.json carries
+    the hash it was measured on (tools/pmc_summary.py), and a bench line only quotes its counters while the kernels are those."""
+    import glob
+    import hashlib
+    src = os.path.join(ROOT, "lz77_amd", "csrc")
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(src, "*.hip")) + [os.path.join(src, "kernels_common.h"), os.path.join(src, "lz77x_internal.h")]):
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
 def file_to_file(L, data, sb, la):
     """what a CLI user sees -- `lz77 -c` then `lz77 -d` as separate processes on a tmpfs file: process
     start, HIP runtime init, file -> pinned slots -> device -> file, process exit.  Three pairs: `first` pays whatever
@@ -137,7 +150,9 @@ def file_to_file(L, data, sb, la):
     w = {"encode_ms": min(r["encode_ms"] for r in runs), "decode_ms": min(r["decode_ms"] for r in runs)}
     return {"encode_MBps": round(n / w["encode_ms"] / 1e3, 1), "decode_MBps": round(n / w["decode_ms"] / 1e3, 1),
             "encode_plus_decode_MBps": round(n / (w["encode_ms"] + w["decode_ms"]) / 1e3, 1),
-            "cold_start_ms": round(runs[0]["encode_ms"] - w["encode_ms"], 1), "process_start_ms": round(min(starts), 1),
+            # what the first process of the box pays beyond a later one: the first encode against the best of the OTHER runs
+            # (round 5 subtracted the minimum over all three, the first included: 0.0 whenever the first was the fastest)
+            "cold_start_ms": round(runs[0]["encode_ms"] - min(r["encode_ms"] for r in runs[1:]), 1), "process_start_ms": round(min(starts), 1),
             "first": runs[0], "warm": w, "runs": runs, "process_start_runs_ms": [round(x, 1) for x in starts],
             "roundtrip_ok": ok, "bytes": n,
             "note": "whole-process wall time of lz77_amd/lz77 on a tmpfs file (process start, HIP runtime init -- 56-250 ms by itself, "
@@ -566,13 +581,20 @@ def main():
         achieved = alg_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
         t_device_ms = sum(mean(enc_stats, k) for k in ("k_match_ms", "k_chain_ms", "k_prio_ms", "k_token_ms"))
         traffic = None
+        traffic_total = None
+        traffic_hash = None
+        traffic_current = False
         issue = None
         tfile = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tfile) and dom_key:
             try:
                 tj = json.load(open(tfile))
-                traffic = tj["hbm_bytes_per_launch"].get(dom_key)
-                valu = tj.get("valu_wave_insts_per_launch", {}).get(dom_key)
+                traffic_hash = tj.get("kernel_source_hash")
+                traffic_current = traffic_hash is not None and traffic_hash == kernel_source_hash()
+                if traffic_current:
+                    traffic = tj["hbm_bytes_per_launch"].get(dom_key)
+                    traffic_total = tj.get("encode_hbm_bytes")
+                valu = tj.get("valu_wave_insts_per_launch", {}).get(dom_key) if traffic_current else None
                 if valu and dom_ms > 0:
                     # none of the encode's kernels is HBM-bound: the view that prices them is instruction issue.  A wave64 VALU
                     # instruction occupies its SIMD for 2.8 (v_add / v_xor) to 4.5 cycles (v_cndmask, v_alignbyte, 64-bit shifts,
@@ -609,7 +631,12 @@ def main():
                          "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic,
                          "issue_frac": issue["issue_frac"] if issue else None, "issue": issue,
-                         "traffic_source": "profiles/traffic.json (PMC passes of the committed rocprofv3 run, per launch; not measured in this run)",
+                         "traffic_total": traffic_total,
+                         "traffic_total_def": "HBM bytes of ALL kernels of one encode by the same counters (beside frac_op: the whole operation's traffic against its algorithmic bytes)",
+                         "traffic_source": ("profiles/traffic.json (PMC passes of the committed rocprofv3 run, per launch; not measured in this run), taken on the "
+                                            "kernel sources of this tree (hash %s)" % traffic_hash) if traffic_current else
+                                           ("null: profiles/traffic.json was measured on other kernel sources (hash %s, this tree %s) -- rerun tools/evidence.sh"
+                                            % (traffic_hash, kernel_source_hash())),
                          "frac_op": round(alg_bytes / (t_device_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 6) if t_device_ms > 0 else 0.0,
                          "frac_op_def": "SURVEY 8d: algorithmic bytes / SUM of the encode's kernel times (match + chain + recurrence + "
                                         "tie-break with its hand-over lists, and pack) / peak -- the whole operation, beside the dominant kernel's `frac`",

@@ -118,7 +118,7 @@ def use_variants(on: bool) -> None:
 VARIANT_KNOBS = ("LZ77X_MATCH_VARIANT", "LZ77X_TOKEN_VARIANT", "LZ77X_SORT_VARIANT", "LZ77X_DECODE_V1", "LZ77X_DECODE_VARIANT",
                  "LZ77X_XFER_V1", "LZ77X_WALK_BIG_V1", "LZ77X_TOKENS_BUCKET", "LZ77X_C1_SORT_V1", "LZ77X_BIG_SORT_V1",
                  "LZ77X_PRIO_BACK_SWEEP", "LZ77X_PW_PREP_V1", "LZ77X_PW_PROBE", "LZ77X_PW_DEBUG", "LZ77X_WALK_DEBUG", "LZ77X_SERIAL", "LZ77X_SPLIT",
-                 "LZ77X_CHAIN_STREAM", "LZ77X_PRIO_SORTCAP", "LZ77X_PRIO_WIDE", "LZ77X_HOST_STAGEB", "LZ77X_TS_ENTCAP", "LZ77X_TS_V4", "LZ77X_TS_PROBE", "LZ77X_TS_BIG", "LZ77X_DECODE_UNFUSED", "LZ77X_TS_OVERLAP_PROBE", "LZ77X_WALK_FRINGE_V4", "LZ77X_RANK_PROBE", "LZ77X_NO_SHORT_INDEX", "LZ77X_RANK_LPT")
+                 "LZ77X_CHAIN_STREAM", "LZ77X_PRIO_SORTCAP", "LZ77X_PRIO_WIDE", "LZ77X_HOST_STAGEB", "LZ77X_TS_ENTCAP", "LZ77X_TS_V4", "LZ77X_TS_PROBE", "LZ77X_TS_BIG", "LZ77X_DECODE_UNFUSED", "LZ77X_TS_OVERLAP_PROBE", "LZ77X_WALK_FRINGE_V4", "LZ77X_RANK_PROBE", "LZ77X_NO_SHORT_INDEX", "LZ77X_RANK_LPT", "LZ77X_NO_RANK_INDEX")
 
 
 def lib():

@@ -117,7 +117,9 @@ struct DevBuf {
         size_t want = bytes + bytes / 8 + 4096;
         HIPCHK(hipMalloc(&p, want));
         cap = want;
-        if (poison_on() && poison_fresh(this)) HIPCHK(hipMemset(p, 0xA5, want));
+        /* (hipMemset may return before the fill has run, and the null stream does not order it against the non-blocking
+         * streams the kernels use: without the synchronize the poison lands on top of what the call has written since) */
+        if (poison_on() && poison_fresh(this)) { HIPCHK(hipMemset(p, 0xA5, want)); HIPCHK(hipDeviceSynchronize()); }
         if (trace_on()) { g_alloc_ms += now_ms() - t0; g_alloc_bytes += want; }
         return LZ77X_OK;
     }

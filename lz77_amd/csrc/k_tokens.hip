@@ -1448,6 +1448,183 @@ __device__ __forceinline__ void rank_token(uint32_t k, const uint32_t lane, cons
 }
 
 
+/* ---- hand-overs by RANK of their cell (round 6) ----------------------------------------------------------------------
+ * The walk above pays three requests at unrelated addresses for every cell of a token's run that lies in its window (the
+ * cell's own priority or look[], the bounds of its hand-over list, the list): 158 GB of HBM traffic for S3's 327 MB of
+ * algorithmic bytes, a 128-byte line for every 4-byte word (profiles/r05_c2_pmc_summary.csv).  But (tree.c:202-231)
+ *     prio_p(c) = min( what c came with,  the hand-overs into c by evictions before p )
+ * and the token wants the argmin over the members of its run inside its window, a minimum over a UNION:
+ *  (a) a member's own priority is its position (+ voff: tree.c:102-105, a new node is a leaf), monotone in c -- among the own
+ *      priorities the winner is the OLDEST member in the window: no look-up per cell, only positions (the region's order
+ *      ix[] read along the run, coalesced; or, for a run of more than 512 cells, the window's ranks rk[] read upwards from
+ *      p - sb until one falls inside the run);
+ *  (b) a hand-over (x -> c, v) competes with its v where c is a member, c >= p - sb and x + sb < p; a stale one never wins
+ *      (the one that replaced it in the same cell is lower).  With a region's hand-overs sorted by the RANK of their cell in
+ *      the region's key order, the hand-overs of a run [r_lo, r_hi] are ONE contiguous range of 10-byte records
+ *      (k_hr_count / scan / k_hr_scatter, per token launch: a counting sort whose key is a permutation).
+ * Cells of a later segment's look-back carry a rank, not their position (look[]): a token whose window reaches into them
+ * keeps the walk above. */
+struct hr_index {
+    const uint32_t *hofs;                            /* per region of the launch RP + 8 words: [r] = first record of the cell at rank r, [r + 1] its end; null: no index */
+    const uint32_t *hv;                              /* the priority handed over */
+    const uint32_t *hc;                              /* its destination cell */
+    const uint16_t *hdx;                             /* cell - eviction (1 .. sb) */
+    uint32_t reg0;                                   /* first region of the index */
+};
+
+__device__ __forceinline__ uint32_t hr_region_cells(uint32_t reg, uint32_t RP, uint32_t TILE, uint32_t usb, uint32_t n, uint32_t whole_order)
+{
+    const uint64_t t0 = (uint64_t)reg * TILE, rend = t0 + (whole_order ? RP : TILE + usb);
+    return (uint32_t)((rend < n ? rend : (uint64_t)n) - t0);
+}
+
+__global__ __launch_bounds__(256) void k_hr_count(const uint32_t *__restrict__ ranks_all, uint32_t RP, uint32_t TILE, uint32_t usb, uint32_t n,
+                                                  uint32_t whole_order, uint32_t reg0, const uint32_t *__restrict__ ofs, uint32_t dbase, uint32_t c1,
+                                                  uint32_t *__restrict__ hcnt)
+{
+    const uint32_t reg = reg0 + blockIdx.y, e = blockIdx.x * 256u + threadIdx.x;
+    if ((uint64_t)reg * TILE >= n) return;
+    const uint32_t R = hr_region_cells(reg, RP, TILE, usb, n, whole_order);
+    if (e >= R) return;
+    const uint32_t c = reg * TILE + e;
+    if (c < dbase || c >= c1) return;
+    const uint32_t lo = c > dbase ? ofs[c - dbase - 1] : 0u, hi = ofs[c - dbase];
+    if (hi > lo) hcnt[(size_t)blockIdx.y * (RP + 8) + (ranks_all + (size_t)reg * (2 * (size_t)RP + 8))[e]] = hi - lo;
+}
+
+__global__ __launch_bounds__(256) void k_hr_scatter(const uint32_t *__restrict__ ranks_all, uint32_t RP, uint32_t TILE, uint32_t usb, uint32_t n,
+                                                    uint32_t whole_order, uint32_t reg0, const uint32_t *__restrict__ ofs, const uint2 *__restrict__ ent,
+                                                    uint32_t dbase, uint32_t c1, const uint32_t *__restrict__ hofs, uint32_t *__restrict__ hv,
+                                                    uint32_t *__restrict__ hc, uint16_t *__restrict__ hdx)
+{
+    const uint32_t reg = reg0 + blockIdx.y, e = blockIdx.x * 256u + threadIdx.x;
+    if ((uint64_t)reg * TILE >= n) return;
+    const uint32_t R = hr_region_cells(reg, RP, TILE, usb, n, whole_order);
+    if (e >= R) return;
+    const uint32_t c = reg * TILE + e;
+    if (c < dbase || c >= c1) return;
+    const uint32_t lo = c > dbase ? ofs[c - dbase - 1] : 0u, hi = ofs[c - dbase];
+    if (hi <= lo) return;
+    uint32_t at = hofs[(size_t)blockIdx.y * (RP + 8) + (ranks_all + (size_t)reg * (2 * (size_t)RP + 8))[e]];
+    for (uint32_t i = lo; i < hi; i++, at++) {
+        const uint2 t = ent[i];                      /* (eviction, priority handed over) */
+        hv[at] = t.y;
+        hc[at] = c;
+        hdx[at] = (uint16_t)(c - t.x);
+    }
+}
+
+#define HR_ENUM 512u                                 /* runs up to this many cells: the oldest member in the window by reading the order along the run */
+
+/* One token, the whole wavefront, from the index above.  dn / up: cells of the run already known below / above the token's
+ * own rank (the group phase of k_tokens_rank_group found them), open_*: that direction may go on. */
+__device__ __forceinline__ void rank_token_hr(uint32_t k, const uint32_t lane, const uint8_t *__restrict__ in, uint32_t n, uint32_t usb, int ob, int lb,
+                                              uint32_t RP, uint32_t TILE, const uint32_t *__restrict__ ranks_all, uint32_t *__restrict__ tokval,
+                                              uint32_t voff, uint32_t whole_order, const hr_index &H, uint32_t p, uint32_t len, uint32_t next, uint32_t ry,
+                                              uint32_t dn, bool open_dn, uint32_t up, bool open_up)
+{
+    const uint32_t reg = p >= usb ? (p - usb) / TILE : 0u;
+    const uint32_t t0 = reg * TILE, ly = p - t0;
+    const uint32_t R = hr_region_cells(reg, RP, TILE, usb, n, whole_order);
+    const uint32_t *rk = ranks_all + (size_t)reg * (2 * (size_t)RP + 8), *ix = rk + RP + 8;
+    const uint32_t *hofs = H.hofs + (size_t)(reg - H.reg0) * (RP + 8);
+    const uint8_t *by = in + t0, *q = in + p;
+    auto shares = [&](uint32_t pos) -> bool {                        /* len bytes at pos == len bytes at p ? */
+        const uint8_t *r = by + pos;
+        for (uint32_t j = 0; j < len; j += 8) {
+            uint64_t x = ld64u(r + j) ^ ld64u(q + j);
+            const uint32_t rem = len - j;
+            if (rem < 8) x &= (1ull << (8 * rem)) - 1ull;
+            if (x) return false;
+        }
+        return true;
+    };
+    /* where the run ends: "shares" is monotone along the order, a 64-ary search from what is known */
+    auto extent = [&](bool updir, uint32_t known) -> uint32_t {
+        uint32_t lo = known, hi = (updir ? R - 1u - ry : ry) + 1u;   /* true at lo, false (out of range) at hi */
+        while (hi - lo > 1) {
+            const uint64_t span = hi - lo;
+            const uint32_t d = lo + (uint32_t)(span * (lane + 1) / 65);              /* lo <= d < hi, increasing in lane */
+            const bool ok = d == lo || shares(ix[updir ? ry + d : ry - d]);
+            const uint64_t m = __ballot(ok);
+            const uint32_t top = m == ~0ull ? 64u : (uint32_t)__builtin_ctzll(~m);   /* lanes 0 .. top-1 are in */
+            const uint32_t nlo = top ? lo + (uint32_t)(span * top / 65) : lo;
+            const uint32_t nhi = top < 64 ? lo + (uint32_t)(span * (top + 1) / 65) : hi;
+            lo = nlo;
+            hi = nhi;
+        }
+        return lo;
+    };
+    const uint32_t d_dn = open_dn ? extent(false, dn) : dn, d_up = open_up ? extent(true, up) : up;
+    const uint32_t r_lo = ry - d_dn, r_hi = ry + d_up, run_len = d_dn + d_up + 1u;
+    const uint32_t w_lo = ly > usb ? ly - usb : 0u;                  /* the window's first cell (local) */
+    /* (a) the oldest member of the run inside the window */
+    uint32_t oldest = ~0u;
+    bool window_seen = false;
+    if (run_len > HR_ENUM) {
+        /* a member every 4 RP / run_len positions on average: the window's ranks upwards from its first cell, at most as many
+         * loads as reading the run itself would take */
+        const uint32_t cap = run_len / 64u;
+        uint32_t e0 = w_lo;
+        for (uint32_t st = 0; e0 < ly && st < cap && oldest == ~0u; e0 += 256u, st += 4u) {
+            uint32_t rc[4];
+#pragma unroll
+            for (uint32_t u = 0; u < 4; u++) rc[u] = rk[min(e0 + 64u * u + lane, ly - 1u)];
+#pragma unroll
+            for (uint32_t u = 0; u < 4; u++) {
+                const uint32_t e = e0 + 64u * u + lane;
+                const uint64_t m = __ballot(e < ly && rc[u] >= r_lo && rc[u] <= r_hi);
+                if (m && oldest == ~0u) oldest = e0 + 64u * u + (uint32_t)__builtin_ctzll(m);      /* (wave-uniform) */
+            }
+        }
+        window_seen = oldest == ~0u && e0 >= ly;            /* (no member in the window: cannot happen for len > 0) */
+    }
+    if (oldest == ~0u && !window_seen) {
+        for (uint32_t r0 = r_lo; r0 <= r_hi; r0 += 256u) {
+            uint32_t ee[4];
+#pragma unroll
+            for (uint32_t u = 0; u < 4; u++) ee[u] = ix[min(r0 + 64u * u + lane, r_hi)];
+#pragma unroll
+            for (uint32_t u = 0; u < 4; u++)
+                if (r0 + 64u * u + lane <= r_hi && ee[u] >= w_lo && ee[u] < ly) oldest = min(oldest, ee[u]);
+        }
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) oldest = min(oldest, (uint32_t)__shfl_xor((int)oldest, d, 64));
+    }
+    uint64_t best = ~0ull;
+    if (oldest != ~0u) best = ((uint64_t)(t0 + oldest + voff) << 32) | (t0 + oldest);
+    /* (b) the hand-overs into the run's cells: one contiguous range of records */
+    const uint32_t i0 = hofs[r_lo], i1 = hofs[r_hi + 1u];
+    for (uint32_t ib = i0; ib < i1; ib += 256u) {
+        uint32_t cc[4], vv[4], dx[4];
+#pragma unroll
+        for (uint32_t u = 0; u < 4; u++) {
+            const uint32_t i = min(ib + 64u * u + lane, i1 - 1u);
+            cc[u] = H.hc[i];
+            dx[u] = H.hdx[i];
+            vv[u] = H.hv[i];
+        }
+#pragma unroll
+        for (uint32_t u = 0; u < 4; u++) {
+            /* the eviction lies before the window, its cell inside it (a cell is below p: c = x + S[x] < x + sb < p) */
+            if (ib + 64u * u + lane < i1 && (uint64_t)(cc[u] - dx[u]) + usb < p && (uint64_t)cc[u] + usb >= p) {
+                const uint64_t key = ((uint64_t)vv[u] << 32) | cc[u];
+                best = key < best ? key : best;
+            }
+        }
+    }
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) {
+        const uint64_t o = (uint64_t)__shfl_xor((unsigned long long)best, d, 64);
+        best = o < best ? o : best;
+    }
+    if (lane == 0) {
+        const uint32_t off = p - (uint32_t)(best & 0xFFFFFFFFu);
+        const uint32_t omask = ob >= 32 ? 0xFFFFFFFFu : (1u << ob) - 1u;
+        tokval[k] = (off & omask) | (len << ob) | (next << (ob + lb));
+    }
+}
+
 __global__ __launch_bounds__(256) void k_tokens_rank(const uint8_t *__restrict__ in, uint32_t n, int sb, int ob, int lb,
                                                      uint32_t RP, uint32_t TILE, const uint32_t *__restrict__ ranks_all,
                                                      const uint32_t *__restrict__ chain, uint32_t ntok,
@@ -1474,13 +1651,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80))) void k_to
                                                            const uint8_t *__restrict__ maxlen, const uint32_t *__restrict__ ofs,
                                                            const uint2 *__restrict__ ent, uint32_t dbase, uint32_t *__restrict__ tokval,
                                                            const uint32_t *__restrict__ look, uint32_t nlook, uint32_t voff,
-                                                           uint32_t whole_order, sx_index X,
+                                                           uint32_t whole_order, sx_index X, hr_index H,
                                                            uint32_t probe /* variants build, timing only (wrong output): 1 no deferred tokens, 2 no bucket tokens, 4 no long runs */)
 {
-    constexpr uint32_t H = LPT / 2, TPW = 64 / LPT;
+    constexpr uint32_t HL = LPT / 2, TPW = 64 / LPT;
     const uint32_t lane = threadIdx.x & 63;
-    const uint32_t grp = lane / LPT, gl = lane % LPT, sub = gl % H;
-    const bool up = gl >= H;
+    const uint32_t grp = lane / LPT, gl = lane % LPT, sub = gl % HL;
+    const bool up = gl >= HL;
     const uint32_t kk = (blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * TPW + grp;
     const bool valid = kk < ntok;
     const uint32_t k = valid ? kk : ntok - 1u;
@@ -1498,15 +1675,21 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80))) void k_to
     const uint64_t q0 = ld64u(q);                                          /* (the input is padded past n) */
     const uint64_t m0 = len >= 8 ? ~0ull : (1ull << (8 * len)) - 1ull;
     const bool whole_wave = len == 1 && X.off_c;                           /* the buckets: all 64 lanes, below */
+    /* the hand-overs by rank serve a token whose whole window lies past the look-back cells (their priorities are carried
+     * ranks, not positions) */
+    const bool by_rank = H.hofs && (nlook == 0u || p >= nlook + usb);
+    const uint32_t *hofs = by_rank ? H.hofs + (size_t)(reg - H.reg0) * (RP + 8) : nullptr;
     bool open = valid && len > 0 && !whole_wave;                           /* my direction of my token */
+    uint32_t found = 0;                                                    /* cells of the run seen in my direction */
     uint64_t best = ~0ull;
     for (uint32_t r = 0; r < RANKG_ROUNDS && __ballot(open); r++) {
-        const uint32_t d = 1u + r * H + sub;
+        const uint32_t d = 1u + r * HL + sub;
         const bool live = open && (up ? ry + d < R : d <= ry);
+        const uint32_t rr = up ? ry + d : ry - d;
         uint32_t e = 0;
         bool same = false;
         if (live) {
-            e = ix[up ? ry + d : ry - d];
+            e = ix[rr];
             const uint8_t *c = by + e;
             same = ((ld64u(c) ^ q0) & m0) == 0ull;
             for (uint32_t j = 8; same && j < len; j += 8) {
@@ -1518,24 +1701,36 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80))) void k_to
         }
         /* my direction's lanes of this round: how many from the nearest on share? */
         const uint64_t okm = __ballot(same);
-        const uint32_t mine = (uint32_t)(okm >> (grp * LPT + (up ? H : 0u))) & ((1u << H) - 1u);
-        const uint32_t lead = mine == (1u << H) - 1u ? H : (uint32_t)__builtin_ctz(~mine);
+        const uint32_t mine = (uint32_t)(okm >> (grp * LPT + (up ? HL : 0u))) & ((1u << HL) - 1u);
+        const uint32_t lead = mine == (1u << HL) - 1u ? HL : (uint32_t)__builtin_ctz(~mine);
         if (same && sub < lead && e < ly && ly - e <= usb) {
             const uint32_t c = t0 + e;
-            uint32_t prio = c < nlook ? look[c] : c + voff, latest = 0;
-            bool any = false;
-            const uint32_t lo = c > dbase ? ofs[c - dbase - 1] : 0, hi = c >= dbase ? ofs[c - dbase] : 0;
-            for (uint32_t i = lo; i < hi; i++) {
-                const uint2 t = ent[i];
-                if ((uint64_t)t.x + usb < p && (!any || t.x > latest)) { any = true; latest = t.x; prio = t.y; }
+            uint32_t prio;
+            if (by_rank) {
+                /* the cell's records sit at its RANK: the bounds of neighbouring lanes are neighbouring words */
+                prio = c + voff;
+                const uint32_t lo = hofs[rr], hi = hofs[rr + 1u];
+                for (uint32_t i = lo; i < hi; i++)
+                    if ((uint64_t)(c - H.hdx[i]) + usb < p) prio = min(prio, H.hv[i]);      /* (a hand-over only lowers its cell: the latest is the smallest) */
+            } else {
+                uint32_t latest = 0;
+                bool any = false;
+                prio = c < nlook ? look[c] : c + voff;
+                const uint32_t lo = c > dbase ? ofs[c - dbase - 1] : 0, hi = c >= dbase ? ofs[c - dbase] : 0;
+                for (uint32_t i = lo; i < hi; i++) {
+                    const uint2 t = ent[i];
+                    if ((uint64_t)t.x + usb < p && (!any || t.x > latest)) { any = true; latest = t.x; prio = t.y; }
+                }
             }
             const uint64_t key = ((uint64_t)prio << 32) | c;
             best = key < best ? key : best;
         }
-        open = open && lead == H;
+        if (open) found += lead;
+        open = open && lead == HL;
     }
     /* a direction still open, or a token for the buckets: the whole token goes to the whole wavefront */
-    const uint64_t om = __ballot(open || (valid && whole_wave));
+    const uint64_t openm = __ballot(open);
+    const uint64_t om = openm | __ballot(valid && whole_wave);
     const bool defer = ((om >> (grp * LPT)) & ((1ull << LPT) - 1ull)) != 0ull;
 #pragma unroll
     for (int d = LPT / 2; d > 0; d >>= 1) {
@@ -1548,6 +1743,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80))) void k_to
         tokval[k] = (off & omask) | (len << ob) | (next << (ob + lb));
     }
     uint64_t dm = __ballot(defer && gl == 0 && valid);
+    const uint64_t rankm = __ballot(by_rank && !whole_wave);
 #ifdef LZ77X_VARIANTS
     if (probe & 1u) dm = 0;
     if (probe & 2u) dm &= ~__ballot(whole_wave);
@@ -1556,19 +1752,41 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80))) void k_to
     for (; dm; dm &= dm - 1) {
         const int src = __builtin_ctzll(dm);
         const uint32_t kd = (uint32_t)__builtin_amdgcn_readlane((int)k, src);
-        rank_token(kd, lane, in, n, sb, ob, lb, RP, TILE, ranks_all, chain, maxlen, ofs, ent, dbase, tokval, look, nlook, voff, whole_order, X, true,
-                   (uint32_t)__builtin_amdgcn_readlane((int)p, src), (uint32_t)__builtin_amdgcn_readlane((int)len, src),
-                   (uint32_t)__builtin_amdgcn_readlane((int)next, src), (uint32_t)__builtin_amdgcn_readlane((int)ry, src));
+        const uint32_t pd = (uint32_t)__builtin_amdgcn_readlane((int)p, src), ld = (uint32_t)__builtin_amdgcn_readlane((int)len, src);
+        const uint32_t nd = (uint32_t)__builtin_amdgcn_readlane((int)next, src), rd = (uint32_t)__builtin_amdgcn_readlane((int)ry, src);
+        if ((rankm >> src) & 1ull)
+            rank_token_hr(kd, lane, in, n, usb, ob, lb, RP, TILE, ranks_all, tokval, voff, whole_order, H, pd, ld, nd, rd,
+                          (uint32_t)__builtin_amdgcn_readlane((int)found, src), ((openm >> src) & 1ull) != 0ull,
+                          (uint32_t)__builtin_amdgcn_readlane((int)found, src + (int)HL), ((openm >> (src + (int)HL)) & 1ull) != 0ull);
+        else
+            rank_token(kd, lane, in, n, sb, ob, lb, RP, TILE, ranks_all, chain, maxlen, ofs, ent, dbase, tokval, look, nlook, voff, whole_order, X, true, pd, ld, nd, rd);
     }
+}
+
+/* the hand-overs-by-rank index of a token launch over npos positions: regions, records (a cell lies in at most two regions) */
+static void hr_plan(const lz77x_geom &g, size_t npos, size_t *nreg, size_t *cap)
+{
+    *nreg = npos / g.TILE + 3;
+    *cap = 2 * (npos + 3 * (size_t)g.sb) + 1024;
 }
 
 /* bytes of the global candidate index for token positions spanning npos (0 when the LDS tile kernel applies) */
 size_t lz77k_tokens_index_bytes(const lz77x_geom &g, size_t npos)
 {
-    if (g.sb <= 8192) return 0;
-    /* the (block, first byte) buckets of the length-1 tokens: npos token positions look back over npos + sb cells */
-    const size_t nc = npos + (size_t)g.sb + 16, nbk = (nc / (size_t)g.sb + 3) * 256;
-    size_t need = 4 * ((nbk + 1) * 4 + 256) + lz77k_scan_tmp_bytes((uint32_t)nbk + 1) + 256 + nc * 8 + (nc + g.sb + 16) * 12 + 3 * 256;
+    if (g.fast) return 0;
+    size_t need = 0;
+    if (g.sb > 8192) {
+        /* the (block, first byte) buckets of the length-1 tokens: npos token positions look back over npos + sb cells */
+        const size_t nc = npos + (size_t)g.sb + 16, nbk = (nc / (size_t)g.sb + 3) * 256;
+        need = 4 * ((nbk + 1) * 4 + 256) + lz77k_scan_tmp_bytes((uint32_t)nbk + 1) + 256 + nc * 8 + (nc + g.sb + 16) * 12 + 3 * 256;
+    }
+    {
+        /* the hand-overs by rank (hr_index): RP + 8 offsets per region, ten bytes a record */
+        size_t nreg, cap;
+        hr_plan(g, npos, &nreg, &cap);
+        const size_t nslots = nreg * ((size_t)g.RP + 8);
+        need += (nslots + 1) * 4 + lz77k_scan_tmp_bytes((uint32_t)nslots + 1) + cap * 10 + 6 * 256;
+    }
 #ifdef LZ77X_VARIANTS
     const size_t ntiles = (npos + BIG_TT - 1) / BIG_TT;
     const size_t v3 = ntiles * ((size_t)BIG_KEYS + BIG_TT + (size_t)g.sb + 8) * sizeof(uint32_t) + 256;
@@ -1594,14 +1812,15 @@ hipError_t lz77k_tokens(const uint8_t *d_in, uint32_t n, const lz77x_geom &g, co
     if (variant == 0 && !g.fast && d_ranks_all) {
         TIE_EV(0);
         sx_index X = {};
+        hr_index Hx = {};
+        uint8_t *base = reinterpret_cast<uint8_t *>(d_index);
+        size_t o = 0;
+        auto take = [&](size_t bytes) { uint8_t *q = base + o; o += (bytes + 255) & ~(size_t)255; return q; };
         if (d_index && g.sb > 8192 && !LZ77X_VENV("LZ77X_NO_SHORT_INDEX")) {
             /* the (block, first byte) buckets of the cells [dbase, pos1) and of the hand-overs into them: what the tokens of
              * length one are resolved from (sx_query) */
             const uint32_t usb = (uint32_t)g.sb, c0 = dbase, c1 = pos1, nc = c1 - c0;
             const uint32_t bl0 = c0 / usb, nbl = (c1 - 1u) / usb - bl0 + 1u, nbk = nbl * 256u;
-            uint8_t *base = reinterpret_cast<uint8_t *>(d_index);
-            size_t o = 0;
-            auto take = [&](size_t bytes) { uint8_t *q = base + o; o += (bytes + 255) & ~(size_t)255; return q; };
             uint32_t *off_c = reinterpret_cast<uint32_t *>(take(((size_t)nbk + 1) * 4)), *off_h = reinterpret_cast<uint32_t *>(take(((size_t)nbk + 1) * 4));
             uint32_t *cur_c = reinterpret_cast<uint32_t *>(take((size_t)nbk * 4)), *cur_h = reinterpret_cast<uint32_t *>(take((size_t)nbk * 4));
             void *stmp = take(lz77k_scan_tmp_bytes(nbk + 1));
@@ -1618,6 +1837,28 @@ hipError_t lz77k_tokens(const uint8_t *d_in, uint32_t n, const lz77x_geom &g, co
                                hd, d_look, nlook, voff);
             X.off_c = off_c; X.off_h = off_h; X.cells = cells; X.hx = hx; X.hd = hd; X.bl0 = bl0; X.nbl = nbl;
         }
+        if (d_index && !LZ77X_VENV("LZ77X_NO_RANK_INDEX")) {
+            /* the hand-overs into the cells [dbase, pos1) by (region, rank of the cell): a counting sort whose key is a
+             * permutation -- counts at the ranks, one scan over all regions' slots, the records behind their offsets */
+            const uint32_t usb = (uint32_t)g.sb, whole = (uint32_t)lz77k_big_sort_shared(g);
+            const uint32_t reg0 = pos0 >= usb ? (pos0 - usb) / g.TILE : 0u, reg1 = pos1 - 1u >= usb ? (pos1 - 1u - usb) / g.TILE : 0u;
+            const uint32_t nreg = reg1 - reg0 + 1u;
+            size_t nreg_max, cap;
+            hr_plan(g, (size_t)pos1 - pos0, &nreg_max, &cap);
+            if (nreg > nreg_max) return hipErrorInvalidValue;
+            const size_t nslots = (size_t)nreg * ((size_t)g.RP + 8);
+            uint32_t *hofs = reinterpret_cast<uint32_t *>(take((nslots + 1) * 4));
+            void *stmp = take(lz77k_scan_tmp_bytes((uint32_t)nslots + 1));
+            uint32_t *hv = reinterpret_cast<uint32_t *>(take(cap * 4)), *hc = reinterpret_cast<uint32_t *>(take(cap * 4));
+            uint16_t *hdx = reinterpret_cast<uint16_t *>(take(cap * 2));
+            hipError_t e = hipMemsetAsync(hofs, 0, (nslots + 1) * 4, s);
+            if (e != hipSuccess) return e;
+            const dim3 grid((g.RP + 255u) / 256u, nreg);
+            hipLaunchKernelGGL(k_hr_count, grid, dim3(256), 0, s, d_ranks_all, g.RP, g.TILE, usb, n, whole, reg0, d_ofs, dbase, pos1, hofs);
+            if ((e = lz77k_scan_u32(hofs, hofs, (uint32_t)nslots + 1u, stmp, s)) != hipSuccess) return e;
+            hipLaunchKernelGGL(k_hr_scatter, grid, dim3(256), 0, s, d_ranks_all, g.RP, g.TILE, usb, n, whole, reg0, d_ofs, d_ent, dbase, pos1, hofs, hv, hc, hdx);
+            Hx.hofs = hofs; Hx.hv = hv; Hx.hc = hc; Hx.hdx = hdx; Hx.reg0 = reg0;
+        }
         {
             /* several tokens per wavefront (LZ77X_RANK_LPT=64 in the variants build: one) */
             const char *le = LZ77X_VENV("LZ77X_RANK_LPT");
@@ -1629,7 +1870,7 @@ hipError_t lz77k_tokens(const uint8_t *d_in, uint32_t n, const lz77x_geom &g, co
                 const uint32_t tpw = 64u / (lpt == 8 ? 8u : 16u), waves = (ntok + tpw - 1u) / tpw;
                 auto fn = lpt == 8 ? k_tokens_rank_group<8> : k_tokens_rank_group<16>;
                 hipLaunchKernelGGL(fn, dim3((waves + 3u) / 4u), dim3(256), 0, s, d_in, n, g.sb, g.ob, g.lb, g.RP, g.TILE, d_ranks_all, d_chain, ntok,
-                                   d_maxlen, d_ofs, d_ent, dbase, d_tokval, d_look, nlook, voff, (uint32_t)lz77k_big_sort_shared(g), X,
+                                   d_maxlen, d_ofs, d_ent, dbase, d_tokval, d_look, nlook, voff, (uint32_t)lz77k_big_sort_shared(g), X, Hx,
                                    LZ77X_VENV("LZ77X_RANK_PROBE") ? (uint32_t)atoi(LZ77X_VENV("LZ77X_RANK_PROBE")) : 0u);
             }
         }

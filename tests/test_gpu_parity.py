@@ -529,8 +529,9 @@ def test_large_window_token_variants_agree(tokv, sb, la, kind, monkeypatch):
 
 
 @pytest.mark.parametrize("env", [{}, {"LZ77X_NO_SHORT_INDEX": "1"}, {"LZ77X_TOKEN_CHUNK": "150000"},
-                                 {"LZ77X_SEGMENT": "400000", "LZ77X_TOKEN_CHUNK": "100000"}, {"LZ77X_RANK_LPT": "64"}, {"LZ77X_RANK_LPT": "16"}],
-                         ids=["index", "walk", "chunks", "segments", "lpt64", "lpt16"])
+                                 {"LZ77X_SEGMENT": "400000", "LZ77X_TOKEN_CHUNK": "100000"}, {"LZ77X_RANK_LPT": "64"}, {"LZ77X_RANK_LPT": "16"},
+                                 {"LZ77X_NO_RANK_INDEX": "1"}, {"LZ77X_NO_RANK_INDEX": "1", "LZ77X_NO_SHORT_INDEX": "1"}],
+                         ids=["index", "walk", "chunks", "segments", "lpt64", "lpt16", "norank", "norank-walk"])
 @pytest.mark.parametrize("sb,la,kind,n", [(65535, 255, "random", 1_200_000), (65535, 255, "mixed", 2_500_000), (9000, 3, "text", 600_000),
                                           (40000, 2, "random", 500_000), (65535, 2, "lowent", 100_000)])
 def test_large_window_short_token_index(env, sb, la, kind, n, monkeypatch):
@@ -626,6 +627,35 @@ def test_periodic_input_reaches_the_fallback_without_a_knob(period):
     assert st["host_stageb_ms"] > 0, "the gate iteration converged on its own: update DESIGN 2.2d and this test"
     assert z == O.encode_bst(data, 4095, 15)
     assert L.decode(z) == data.tobytes()
+
+
+@pytest.mark.parametrize("env", [{}, {"LZ77X_NO_RANK_INDEX": "1"}, {"LZ77X_NO_SHORT_INDEX": "1"}, {"LZ77X_TOKEN_CHUNK": "300000"},
+                                 {"LZ77X_SEGMENT": "700000", "LZ77X_TOKEN_CHUNK": "200000"}, {"LZ77X_SHARDS": "3", "LZ77X_FAKE_DEVICES": "3"}],
+                         ids=["rank", "walk", "rank-no-buckets", "chunks", "segments", "shards"])
+@pytest.mark.parametrize("sb,la,kind,n", [(65535, 255, "records", 1_500_000), (65535, 255, "runs", 1_500_000), (65535, 255, "zeros", 400_000),
+                                          (20000, 40, "lowent", 900_000), (8191, 255, "code", 700_000), (5000, 9, "text", 500_000),
+                                          (65535, 255, "text", 2_000_000)])
+def test_large_window_hand_overs_by_rank(env, sb, la, kind, n, monkeypatch):
+    """large windows (tree.c:136-141: among equal-length matches find() meets the node nearest the root first).  Round 6: a
+    region's hand-overs sorted by the RANK of their cell in the region's key order -- the hand-overs of a run are one
+    contiguous range of records, the oldest member of the run in the window comes from the order / the window's ranks, no
+    look-up per cell (hr_index, rank_token_hr) -- against the reference stream and against the walk cell by cell
+    (LZ77X_NO_RANK_INDEX, variants build); record-structured data and runs of thousands of equal bytes make the runs long
+    (the path of more than 512 cells), several token chunks / segments / shards move the regions of a launch and bring the
+    look-back cells whose tokens keep the walk."""
+    if kind == "runs":
+        rng = np.random.default_rng(5)
+        parts = []
+        while sum(len(x) for x in parts) < n:
+            parts.append(np.full(int(rng.integers(900, 2500)), int(rng.integers(0, 4)), dtype=np.uint8))
+            parts.append(synth.text(int(rng.integers(50, 4000)), int(rng.integers(1 << 30))))
+        data = np.concatenate(parts)[:n].copy()
+    else:
+        data = synth.make(kind, n, 131)
+    want = O.encode_bst(data, sb, la)
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    assert L.encode(data, la, sb) == want
 
 
 def test_roundtrip_incompressible_large():

@@ -1,10 +1,10 @@
 #!/bin/bash
-# Regenerates EVERY r05 file of profiles/ from ONE gpurun call, then the table in profiles/README.md from those files
+# Regenerates EVERY <tag> file of profiles/ from ONE gpurun call, then the table in profiles/README.md from those files
 # (numbers generated, not typed):
-#     gpurun --timeout 2400 -- 'bash tools/r05_evidence.sh'        # results under gpurun_out/r05/
-#     cp gpurun_out/r05/r05_* gpurun_out/r05/traffic.json profiles/ && python tools/profiles_readme.py
+#     gpurun --timeout 2400 -- 'bash tools/evidence.sh'        # results under gpurun_out/<tag>/
+#     cp gpurun_out/<tag>/<tag>_* gpurun_out/<tag>/traffic.json profiles/ && python tools/profiles_readme.py
 # PMC counters are collected in passes of their own with --kernel-trace only (MI355X_MICROARCH.md, HBM / rocprofv3).
-tag=r05
+tag=${TAG:-r06}
 cd /tmp && export TMPDIR=/tmp
 cd "${GRAFT_REPO_ROOT:-$(dirname "$0")/..}"
 out=gpurun_out/$tag; rm -rf $out; mkdir -p $out

@@ -1,6 +1,6 @@
-"""rocprofv3 counter_collection csvs of tools/r05_evidence.sh -> <tag>_bench_pmc_summary.csv and traffic.json.
+"""rocprofv3 counter_collection csvs of tools/evidence.sh -> <tag>_bench_pmc_summary.csv and traffic.json.
 usage: python tools/pmc_summary.py <out dir> <tag>"""
-import collections, csv, glob, json, sys
+import collections, csv, glob, json, os, sys
 out, tag = sys.argv[1], sys.argv[2]
 acc = collections.defaultdict(lambda: collections.defaultdict(float))
 launches = collections.defaultdict(set)
@@ -45,6 +45,10 @@ tr = {"round": tag,
       "lds_conflict_over_active": {short(k): round(per_launch(k, "SQ_LDS_BANK_CONFLICT") / per_launch(k, "SQ_LDS_IDX_ACTIVE"), 3) for k in ks if per_launch(k, "SQ_LDS_IDX_ACTIVE")}}
 enc = [k for k in ks if not short(k).startswith(("k_dec", "k_scan"))]
 dec = [k for k in ks if short(k).startswith(("k_dec", "k_scan"))]
+# the device sources these counters were taken on: bench.py quotes them only while csrc/*.hip hash to the same value
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+import bench
+tr["kernel_source_hash"] = bench.kernel_source_hash()
 tr["encode_hbm_bytes"] = sum(hbm(k) * nl[k] for k in enc)
 tr["decode_hbm_bytes"] = sum(hbm(k) * nl[k] for k in dec)
 json.dump(tr, open(out + "/traffic.json", "w"), indent=1)

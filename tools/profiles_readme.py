@@ -1,4 +1,4 @@
-"""profiles/README.md, the round-5 part: GENERATED from the files tools/r05_evidence.sh wrote (the numbers in the
+"""profiles/README.md, the round-5 part: GENERATED from the files tools/evidence.sh wrote (the numbers in the
 README come out of the evidence files, not out of an editor).
 
     python tools/profiles_readme.py            # rewrites the block between <!-- r05:begin --> and <!-- r05:end -->
@@ -191,7 +191,7 @@ if "<!-- r05:begin" in txt:
     txt = re.sub(r"<!-- r05:begin.*?<!-- r05:end -->", lambda m: block, txt, flags=re.S)
 else:
     head, sep, rest = txt.partition("| file | what |")
-    txt = head + "## Round 5\n\n`bash tools/r05_evidence.sh` (one gpurun call) writes every r05 file below; `python tools/profiles_readme.py` writes this table from them.\n\n" + block + \
+    txt = head + "## Round 5\n\n`bash tools/evidence.sh` (one gpurun call) writes every r05 file below; `python tools/profiles_readme.py` writes this table from them.\n\n" + block + \
         "\n\n## Rounds 1-4 (as written then)\n\n" + sep + rest
 open(path, "w").write(txt)
 print("rows", len(rows))
