@@ -44,6 +44,25 @@ struct SegJob {
     size_t scratch_cap = 0;          /* match-stage scratch per launch (0: the default of the geometry) */
     size_t token_chunk = (size_t)128 << 20;   /* positions per token launch (LZ77X_TOKEN_CHUNK, read once per call) */
     std::vector<char> tie_timed;
+    /* Round 6: the match stage's scratch (16 B per position at C1, the largest buffer of an encode) is dead once its last
+     * launch is enqueued, and everything the later stages of THIS segment allocate -- xval, the parse chain, the token words,
+     * the recurrence's gates and maps, the hand-over index -- is only touched by kernels behind it on the same stream: those
+     * arrays are carved out of the scratch buffer (stream order is the only synchronisation needed; a piece that does not
+     * fit keeps its own cached buffer).  `out` is NOT among them: its words leave through the drain thread while this
+     * context's next match stage already runs. */
+    uint8_t *a_base = nullptr;
+    size_t a_cap = 0, a_at = 0;
+    uint32_t *d_xval = nullptr, *d_chain = nullptr, *d_tokval = nullptr, *d_ofs = nullptr, *d_tstart = nullptr;
+    uint2 *d_ent = nullptr;
+    void *d_prio_tmp = nullptr, *d_chain_tmp = nullptr, *d_scantmp = nullptr, *d_index = nullptr;
+    /* bytes for a later stage: from the dead scratch, else from the stage's own cached buffer; null: out of memory (g_err set) */
+    void *place(DevBuf &own, size_t bytes)
+    {
+        const size_t need = (bytes + 255) & ~(size_t)255;
+        if (a_base && a_at + need <= a_cap) { void *q = a_base + a_at; a_at += need; return q; }
+        if (own.need(bytes) != LZ77X_OK) return nullptr;
+        return own.p;
+    }
 };
 
 int seg_front(SegJob &J, const lz77x_geom &g)
@@ -88,11 +107,11 @@ int seg_front(SegJob &J, const lz77x_geom &g)
     /* large windows: rank + inverse arrays, (2RP + 8) words per region, for the rank-order tie-break */
     if (keep_order && (rc = c.ranks_all.need(g.fast ? (size_t)nregions * g.RP * 2 + 64 : (size_t)nregions * (2 * (size_t)g.RP + 8) * sizeof(uint32_t)))) return rc;
     J.d_order = keep_order ? c.ranks_all.as<uint32_t>() : nullptr;
-    /* large windows: the (block, first byte) buckets the tokens of length one are resolved from (built per token chunk) */
-    if (!g.fast) {
-        size_t chunk_pos = J.token_chunk;
-        chunk_pos += lz77k_chain_sub();
-        if ((rc = c.bidx.need(lz77k_tokens_index_bytes(g, chunk_pos < (size_t)J.nloc ? chunk_pos : (size_t)J.nloc)))) return rc;
+    {
+        const char *ae = getenv("LZ77X_NO_ALIAS");           /* (memory probe: every stage in its own cached buffer, as until round 5) */
+        J.a_base = ae && atoi(ae) ? nullptr : c.scratch.as<uint8_t>();
+        J.a_cap = c.scratch.cap;
+        J.a_at = 0;
     }
     const uint32_t nlaunch = (nregions + batch - 1) / batch;
     while (c.sort_ev.size() < 4 * (size_t)nlaunch) { hipEvent_t e; HIPCHK(hipEventCreate(&e)); c.sort_ev.push_back(e); }
@@ -129,11 +148,11 @@ int seg_mid(SegJob &J, const lz77x_geom &g, SegCarry &carry, bool allow_fallback
     if (E > start) {
         const uint32_t csub = lz77k_chain_sub();
         const size_t np = (size_t)J.nloc, span = (size_t)E - start;
-        if ((rc = c.xval.need((np + 8) * 4))) return rc;
-        if ((rc = c.chain.need((np + 8) * 4))) return rc;
+        if (!(J.d_xval = reinterpret_cast<uint32_t *>(J.place(c.xval, (np + 8) * 4)))) return LZ77X_E_HIP;
+        if (!(J.d_chain = reinterpret_cast<uint32_t *>(J.place(c.chain, (np + 8) * 4)))) return LZ77X_E_HIP;
         if ((rc = c.flag.need(1024))) return rc;          /* [64, 64 + 8 * 33): the hand-over count and the slots the tiles spread it over */
-        if ((rc = c.prio_tmp.need(lz77k_prio_tmp_bytes(J.nx, g.sb)))) return rc;
-        if ((rc = c.chain_tmp.need(lz77k_chain_tmp_bytes(E - start, g.la)))) return rc;
+        if (!(J.d_prio_tmp = J.place(c.prio_tmp, lz77k_prio_tmp_bytes(J.nx, g.sb)))) return LZ77X_E_HIP;
+        if (!(J.d_chain_tmp = J.place(c.chain_tmp, lz77k_chain_tmp_bytes(E - start, g.la)))) return LZ77X_E_HIP;
         if ((rc = c.look.need((size_t)2 * (usb + 8) * 4))) return rc;
         const uint32_t nsub_max = (uint32_t)((span + csub - 1) / csub);
         if ((rc = c.h_tbase.need(((size_t)nsub_max + 2) * 4 + (usb + 8) * 4))) return rc;
@@ -154,7 +173,7 @@ int seg_mid(SegJob &J, const lz77x_geom &g, SegCarry &carry, bool allow_fallback
         hipStream_t sc = LZ77X_VENV("LZ77X_CHAIN_STREAM") ? c.tok : s;   /* measured: beside the recurrence it costs the recurrence more (6.0 -> 6.5 ms) than it hides (0.4) */
         if (sc != s) HIPCHK(hipStreamWaitEvent(sc, c.ev[1], 0));               /* the match stage is through */
         HIPCHK(hipEventRecord(c.match_ev[0], sc));
-        HIPCHK(lz77k_chain(c.maxlen.as<uint8_t>(), E, g.la, c.chain.as<uint32_t>(), c.chain_tmp.p, sc, &d_tbase, &nsub, start, &d_exit));
+        HIPCHK(lz77k_chain(c.maxlen.as<uint8_t>(), E, g.la, J.d_chain, J.d_chain_tmp, sc, &d_tbase, &nsub, start, &d_exit));
         HIPCHK(hipEventRecord(c.match_ev[1], sc));
         HIPCHK(hipMemcpyAsync(h_tbase, d_tbase, ((size_t)nsub + 1) * 4, hipMemcpyDeviceToHost, sc));
         HIPCHK(hipMemcpyAsync(c.h_small.as<uint32_t>() + 16, d_exit, 4, hipMemcpyDeviceToHost, sc));
@@ -179,9 +198,9 @@ int seg_mid(SegJob &J, const lz77x_geom &g, SegCarry &carry, bool allow_fallback
             if ((rc = c.tokval.need((np + 16) * 4))) return rc;
             if ((rc = c.tstart.need(lz77k_tokens_tmp_bytes((uint32_t)np + 2 * (uint32_t)usb + 16, g)))) return rc;
             HIPCHK(hipStreamWaitEvent(probe_stream, c.pipe_ev[2], 0));
-            HIPCHK(lz77k_tokens(c.in.as<uint8_t>(), J.nloc, g, c.chain.as<uint32_t>(), ntok_p, c.maxlen.as<uint8_t>(), nullptr, nullptr, 0u, start, E,
+            HIPCHK(lz77k_tokens(c.in.as<uint8_t>(), J.nloc, g, J.d_chain, ntok_p, c.maxlen.as<uint8_t>(), nullptr, nullptr, 0u, start, E,
                                 c.tokval.as<uint32_t>() + 4, c.tstart.as<uint32_t>(), nullptr, 0, probe_stream, nullptr, J.d_order, J.first ? nullptr : look_cur,
-                                J.nlook, 0u, c.ps.as<uint32_t>(), c.xval.as<uint32_t>(), nullptr));
+                                J.nlook, 0u, c.ps.as<uint32_t>(), J.d_xval, nullptr));
             HIPCHK(hipEventRecord(probe_ev, probe_stream));
             probe_on = true;
         }
@@ -201,7 +220,7 @@ int seg_mid(SegJob &J, const lz77x_geom &g, SegCarry &carry, bool allow_fallback
         HIPCHK(hipEventRecord(c.match_ev[2], s));
         const double tw0 = now_ms();
         float prio_ms3[3] = {0, 0, 0};
-        HIPCHK(lz77k_prio(c.ps.as<uint32_t>(), J.nx, g.sb, c.xval.as<uint32_t>(), c.prio_tmp.p, s, c.h_small.as<uint32_t>() + 8, max_iters,
+        HIPCHK(lz77k_prio(c.ps.as<uint32_t>(), J.nx, g.sb, J.d_xval, J.d_prio_tmp, s, c.h_small.as<uint32_t>() + 8, max_iters,
                           &iters, &converged, &c.match_ev[4], prio_ms3, 0u, J.first ? nullptr : look_cur, J.last ? nullptr : look_next));
         HIPCHK(hipEventRecord(c.match_ev[3], s));
 #ifdef LZ77X_VARIANTS
@@ -221,7 +240,7 @@ int seg_mid(SegJob &J, const lz77x_geom &g, SegCarry &carry, bool allow_fallback
             const double th = now_ms();
             if (!lz77x_prio_run_cells(h_ps.data(), J.nx, g.sb, J.first ? nullptr : carry.cells.data(), 0u, h_xv.data(), cells_out.data())) return LZ77X_E_NOMEM;
             g_stats.host_stageb_ms += now_ms() - th;
-            HIPCHK(hipMemcpyAsync(c.xval.p, h_xv.data(), (size_t)J.nx * 4, hipMemcpyHostToDevice, s));
+            HIPCHK(hipMemcpyAsync(J.d_xval, h_xv.data(), (size_t)J.nx * 4, hipMemcpyHostToDevice, s));
             HIPCHK(hipStreamSynchronize(s));                    /* (pageable source) */
             memcpy(h_state, cells_out.data(), usb * 4);
             host_cells = true;
@@ -276,17 +295,27 @@ int seg_tokens(SegJob &J, const lz77x_geom &g, const SegCarry &carry)
         const uint32_t nchunks = (uint32_t)((span + chunk_pos - 1) / chunk_pos);
         J.nchunks = nchunks;
         const size_t idx_span = (chunk_pos < span ? chunk_pos : span) + 2 * usb + 16;
-        if ((rc = c.tokval.need((np + 16) * 4))) return rc;
-        if ((rc = c.ofs.need((idx_span + 8) * 4))) return rc;
-        if ((rc = c.ent.need((idx_span + 8) * 8))) return rc;
-        if ((rc = c.scantmp.need(lz77k_scan_tmp_bytes((uint32_t)idx_span + 1)))) return rc;
-        if ((rc = c.tstart.need(lz77k_tokens_tmp_bytes((uint32_t)idx_span, g)))) return rc;
+        const bool fused_lists = lz77k_tokens_builds_lists(g, J.tvariant, J.d_order);
+        if (!(J.d_tokval = reinterpret_cast<uint32_t *>(J.place(c.tokval, (np + 16) * 4)))) return LZ77X_E_HIP;
+        if (!(J.d_tstart = reinterpret_cast<uint32_t *>(J.place(c.tstart, lz77k_tokens_tmp_bytes((uint32_t)idx_span, g))))) return LZ77X_E_HIP;
+        J.d_ofs = nullptr; J.d_ent = nullptr; J.d_scantmp = nullptr; J.d_index = nullptr;
+        if (!fused_lists) {
+            /* (LDS-sized windows build their hand-over lists per tile: no index in HBM) */
+            if (!(J.d_ofs = reinterpret_cast<uint32_t *>(J.place(c.ofs, (idx_span + 8) * 4)))) return LZ77X_E_HIP;
+            if (!(J.d_ent = reinterpret_cast<uint2 *>(J.place(c.ent, (idx_span + 8) * 8)))) return LZ77X_E_HIP;
+            if (!(J.d_scantmp = J.place(c.scantmp, lz77k_scan_tmp_bytes((uint32_t)idx_span + 1)))) return LZ77X_E_HIP;
+        }
+        if (!g.fast) {
+            /* large windows: the (block, first byte) buckets of the tokens of length one and the hand-overs by rank (built per token chunk) */
+            const size_t ib = lz77k_tokens_index_bytes(g, (chunk_pos < span ? chunk_pos : span) + csub);
+            if (ib && !(J.d_index = J.place(c.bidx, ib))) return LZ77X_E_HIP;
+        }
         while (c.tie_ev.size() < 2 * (size_t)nchunks + 8) { hipEvent_t e; HIPCHK(hipEventCreate(&e)); c.tie_ev.push_back(e); }
         uint32_t *look_cur = c.look.as<uint32_t>();
         const uint32_t *h_tbase = c.h_tbase.as<uint32_t>();
         /* -- tokens: per chunk, the hand-over index of the evictions that can matter and the tie-break.  Tokens
          *    land behind four slots that hold the predecessor's last tokens (for the first stream word) -- */
-        uint32_t *tokbuf = c.tokval.as<uint32_t>();
+        uint32_t *tokbuf = J.d_tokval;
         if (carry.ntail) HIPCHK(hipMemcpyAsync(tokbuf + 4 - carry.ntail, carry.tail + 4 - carry.ntail, carry.ntail * 4, hipMemcpyHostToDevice, s));
         J.tie_timed.assign(nchunks, 0);
         HIPCHK(hipEventRecord(c.ev[2], s));
@@ -300,21 +329,21 @@ int seg_tokens(SegJob &J, const lz77x_geom &g, const SegCarry &carry)
             /* (destination blocks build their lists in LDS from the evictions of the sb positions before them: a 9-fold
              * re-read at sb = 65535; large windows count and place through HBM instead) */
             /* (LDS-sized windows: the tie-break builds the lists of a tile's window in LDS, straight from ps/xval) */
-            const bool fused = lz77k_tokens_builds_lists(g, J.tvariant, J.d_order);
+            const bool fused = fused_lists;
             if (!fused)
-                HIPCHK(lz77k_xfer_index(c.ps.as<uint32_t>(), c.xval.as<uint32_t>(), xa, (uint32_t)x_done, dbase, (uint32_t)e, c.ofs.as<uint32_t>(),
-                                        c.ent.as<uint2>(), c.scantmp.p, s, (uint32_t)x_new, c.flag.as<unsigned long long>() + 8, g.fast ? (uint32_t)g.sb : 0u));
-            HIPCHK(lz77k_tokens(c.in.as<uint8_t>(), J.nloc, g, c.chain.as<uint32_t>() + ta, tb - ta, c.maxlen.as<uint8_t>(), c.ofs.as<uint32_t>(),
-                                c.ent.as<uint2>(), dbase, (uint32_t)b, (uint32_t)e, tokbuf + 4 + ta, c.tstart.as<uint32_t>(),
-                                g.fast ? nullptr : c.bidx.p,
+                HIPCHK(lz77k_xfer_index(c.ps.as<uint32_t>(), J.d_xval, xa, (uint32_t)x_done, dbase, (uint32_t)e, J.d_ofs,
+                                        J.d_ent, J.d_scantmp, s, (uint32_t)x_new, c.flag.as<unsigned long long>() + 8, g.fast ? (uint32_t)g.sb : 0u));
+            HIPCHK(lz77k_tokens(c.in.as<uint8_t>(), J.nloc, g, J.d_chain + ta, tb - ta, c.maxlen.as<uint8_t>(), J.d_ofs,
+                                J.d_ent, dbase, (uint32_t)b, (uint32_t)e, tokbuf + 4 + ta, J.d_tstart,
+                                g.fast ? nullptr : J.d_index,
                                 J.tvariant, s, &c.tie_ev[2 * ci], J.d_order, J.first ? nullptr : look_cur, J.nlook, 0u,
-                                fused ? c.ps.as<uint32_t>() : nullptr, fused ? c.xval.as<uint32_t>() : nullptr, c.flag.as<unsigned long long>() + 8));
+                                fused ? c.ps.as<uint32_t>() : nullptr, fused ? J.d_xval : nullptr, c.flag.as<unsigned long long>() + 8));
             J.tie_timed[ci] = tb > ta;
         }
         HIPCHK(hipMemcpyAsync(c.h_small.as<unsigned long long>() + 2, c.flag.as<unsigned long long>() + 8, 8, hipMemcpyDeviceToHost, s));
     } else {
-        if ((rc = c.tokval.need(64))) return rc;
-        uint32_t *tokbuf = c.tokval.as<uint32_t>();
+        if (!(J.d_tokval = reinterpret_cast<uint32_t *>(J.place(c.tokval, 64)))) return LZ77X_E_HIP;
+        uint32_t *tokbuf = J.d_tokval;
         if (carry.ntail) HIPCHK(hipMemcpyAsync(tokbuf + 4 - carry.ntail, carry.tail + 4 - carry.ntail, carry.ntail * 4, hipMemcpyHostToDevice, s));
         HIPCHK(hipEventRecord(c.ev[2], s));
     }
@@ -327,12 +356,12 @@ int seg_tokens(SegJob &J, const lz77x_geom &g, const SegCarry &carry)
     const uint64_t whi = J.last ? (zn_total + 3) / 4 : (32 + K1 * T) / 32;
     const uint64_t nw = whi > wlo ? whi - wlo : 0;
     if ((rc = c.out.need(nw * 4 + 16))) return rc;
-    HIPCHK(lz77k_pack_range(c.tokval.as<uint32_t>() + 4 - carry.ntail, K0 - carry.ntail, K1, g, c.out.as<uint32_t>(), wlo, nw, s));
+    HIPCHK(lz77k_pack_range(J.d_tokval + 4 - carry.ntail, K0 - carry.ntail, K1, g, c.out.as<uint32_t>(), wlo, nw, s));
     HIPCHK(hipEventRecord(c.ev[3], s));
     /* carry: the last four tokens seen so far */
     J.have_tail = ntok + carry.ntail < 4 ? ntok + carry.ntail : 4;
     if (J.have_tail)
-        HIPCHK(hipMemcpyAsync(c.h_small.as<uint32_t>() + 20, c.tokval.as<uint32_t>() + 4 + ntok - J.have_tail, J.have_tail * 4, hipMemcpyDeviceToHost, s));
+        HIPCHK(hipMemcpyAsync(c.h_small.as<uint32_t>() + 20, J.d_tokval + 4 + ntok - J.have_tail, J.have_tail * 4, hipMemcpyDeviceToHost, s));
     J.out_bytes = J.last ? zn_total - 4 * wlo : 4 * nw;
     return LZ77X_OK;
 }

@@ -629,10 +629,13 @@ def test_periodic_input_reaches_the_fallback_without_a_knob(period):
     assert L.decode(z) == data.tobytes()
 
 
+_HR_CASES = {}
+
+
 @pytest.mark.parametrize("env", [{}, {"LZ77X_NO_RANK_INDEX": "1"}, {"LZ77X_NO_SHORT_INDEX": "1"}, {"LZ77X_TOKEN_CHUNK": "300000"},
                                  {"LZ77X_SEGMENT": "700000", "LZ77X_TOKEN_CHUNK": "200000"}, {"LZ77X_SHARDS": "3", "LZ77X_FAKE_DEVICES": "3"}],
                          ids=["rank", "walk", "rank-no-buckets", "chunks", "segments", "shards"])
-@pytest.mark.parametrize("sb,la,kind,n", [(65535, 255, "records", 1_500_000), (65535, 255, "runs", 1_500_000), (65535, 255, "zeros", 400_000),
+@pytest.mark.parametrize("sb,la,kind,n", [(65535, 255, "records", 1_500_000), (65535, 255, "runs", 500_000), (65535, 255, "zeros", 12_000),
                                           (20000, 40, "lowent", 900_000), (8191, 255, "code", 700_000), (5000, 9, "text", 500_000),
                                           (65535, 255, "text", 2_000_000)])
 def test_large_window_hand_overs_by_rank(env, sb, la, kind, n, monkeypatch):
@@ -643,16 +646,23 @@ def test_large_window_hand_overs_by_rank(env, sb, la, kind, n, monkeypatch):
     (LZ77X_NO_RANK_INDEX, variants build); record-structured data and runs of thousands of equal bytes make the runs long
     (the path of more than 512 cells), several token chunks / segments / shards move the regions of a launch and bring the
     look-back cells whose tokens keep the walk."""
-    if kind == "runs":
-        rng = np.random.default_rng(5)
-        parts = []
-        while sum(len(x) for x in parts) < n:
-            parts.append(np.full(int(rng.integers(900, 2500)), int(rng.integers(0, 4)), dtype=np.uint8))
-            parts.append(synth.text(int(rng.integers(50, 4000)), int(rng.integers(1 << 30))))
-        data = np.concatenate(parts)[:n].copy()
-    else:
-        data = synth.make(kind, n, 131)
-    want = O.encode_bst(data, sb, la)
+    # (the oracle is the reference's unbalanced BST: equal keys are a spine as deep as the run -- tree.c:77-97 -- so the inputs
+    # with long runs are small, and the oracle's stream is computed once per input, not once per knob)
+    key = (sb, la, kind, n)
+    if key not in _HR_CASES:
+        if kind == "runs":
+            rng = np.random.default_rng(5)
+            parts = []
+            while sum(len(x) for x in parts) < n:
+                parts.append(np.full(int(rng.integers(600, 1500)), int(rng.integers(0, 4)), dtype=np.uint8))
+                parts.append(synth.text(int(rng.integers(50, 4000)), int(rng.integers(1 << 30))))
+            data = np.concatenate(parts)[:n].copy()
+        else:
+            data = synth.make(kind, n, 131)
+        _HR_CASES[key] = (data, O.encode_bst(data, sb, la))
+    data, want = _HR_CASES[key]
+    if n < 300_000 and "LZ77X_SHARDS" in env:
+        pytest.skip("shorter than three shards")
     for k, v in env.items():
         monkeypatch.setenv(k, v)
     assert L.encode(data, la, sb) == want

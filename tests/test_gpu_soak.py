@@ -59,7 +59,7 @@ def test_soak_mixed_calls_then_fifty_fallbacks(monkeypatch):
             monkeypatch.setenv(k, v)
         z = L.encode(data, la, sb)
         calls += 1
-        if n <= 70000:
+        if n <= (20000 if kind == "zeros" else 70000):         # (equal keys are a spine in the oracle's BST, tree.c:77-97: slow)
             assert z == O.encode_bst(data, sb, la), (it, kind, n, sb, la, knobs)
         back = L.decode(z)
         calls += 1
