@@ -221,7 +221,7 @@ int decode_stream(Ctx &c, Source &src, Sink *sink, hipStream_t s, uint64_t *n_ou
     size_t got = 0;
     if ((rc = src.read(c, c.z.as<uint8_t>(), 4, s, &got))) return rc;
     if (got < 4) return LZ77X_E_FORMAT;
-    HIPCHK(hipMemcpyAsync(hdr, c.z.p, 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(small_d2h(c.h_small, hdr, c.z.p, 4, s));
     HIPCHK(hipStreamSynchronize(s));
     const int sb = hdr[0] | (hdr[1] << 8), la = hdr[2] | (hdr[3] << 8);       /* lz77.c:157-158 */
     if (sb < 1 || la < 1) return LZ77X_E_FORMAT;
@@ -298,8 +298,8 @@ int decode_stream(Ctx &c, Source &src, Sink *sink, hipStream_t s, uint64_t *n_ou
             HIPCHK(hipMemsetAsync(c.flag.as<uint32_t>() + 8, 0, 8, s));
             HIPCHK(lz77k_dec_sums(zr.as<uint8_t>(), ntok, g, c.len1.as<uint32_t>(), c.flag.as<uint32_t>() + 8, s));
             HIPCHK(lz77k_scan_u32(c.len1.as<uint32_t>(), c.dst.as<uint32_t>(), nblk + 1, c.scantmp.p, s));
-            HIPCHK(hipMemcpyAsync(tot, c.dst.as<uint32_t>() + nblk, 4, hipMemcpyDeviceToHost, s));
-            HIPCHK(hipMemcpyAsync(tot + 1, c.flag.as<uint32_t>() + 8, 8, hipMemcpyDeviceToHost, s));
+            HIPCHK(small_d2h(c.h_small, tot, c.dst.as<uint32_t>() + nblk, 4, s));
+            HIPCHK(small_d2h(c.h_small, tot + 1, c.flag.as<uint32_t>() + 8, 8, s));
             HIPCHK(hipStreamSynchronize(s));
             n = tot[0];
             stale = tot[1] != 0;
@@ -316,8 +316,8 @@ int decode_stream(Ctx &c, Source &src, Sink *sink, hipStream_t s, uint64_t *n_ou
             HIPCHK(lz77k_dec_parse(zr.as<uint8_t>(), ntok, g, c.tokval.as<uint32_t>(), c.len1.as<uint32_t>(), s, c.flag.as<uint32_t>() + 8));
             HIPCHK(hipMemsetAsync(c.len1.as<uint32_t>() + ntok, 0, 4, s));
             HIPCHK(lz77k_scan_u32(c.len1.as<uint32_t>(), c.dst.as<uint32_t>(), ntok + 1, c.scantmp.p, s));     /* ntok << lb fits 32 bits (dec_range_plan) */
-            HIPCHK(hipMemcpyAsync(tot, c.dst.as<uint32_t>() + ntok, 4, hipMemcpyDeviceToHost, s));
-            HIPCHK(hipMemcpyAsync(tot + 1, c.flag.as<uint32_t>() + 8, 8, hipMemcpyDeviceToHost, s));
+            HIPCHK(small_d2h(c.h_small, tot, c.dst.as<uint32_t>() + ntok, 4, s));
+            HIPCHK(small_d2h(c.h_small, tot + 1, c.flag.as<uint32_t>() + 8, 8, s));
             HIPCHK(hipStreamSynchronize(s));
             n = tot[0];
             stale = tot[1] != 0;             /* the range copies from distance 0 somewhere (power-of-two -s) */
@@ -327,7 +327,7 @@ int decode_stream(Ctx &c, Source &src, Sink *sink, hipStream_t s, uint64_t *n_ou
         }
         if (n > cap) {
             HIPCHK(lz77k_dec_cut(c.dst.as<uint32_t>(), ntok, cap, c.flag.as<uint32_t>() + 12, s));
-            HIPCHK(hipMemcpyAsync(tot + 4, c.flag.as<uint32_t>() + 12, 8, hipMemcpyDeviceToHost, s));
+            HIPCHK(small_d2h(c.h_small, tot + 4, c.flag.as<uint32_t>() + 12, 8, s));
             HIPCHK(hipStreamSynchronize(s));
             use = tot[4];
             n = tot[5];

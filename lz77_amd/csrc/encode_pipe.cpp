@@ -92,7 +92,7 @@ int seg_front(SegJob &J, const lz77x_geom &g)
          * launch takes its fill + 2048 steps whatever its size), a second launch is a second 0.75 ms */
         const size_t per = lz77k_match_scratch_bytes(g, 1);
         /* (large windows: 16 GB -- their walkers are latency bound too and a region's scratch is 16x a small window's) */
-        const size_t cap = J.scratch_cap ? J.scratch_cap : (size_t)(g.fast ? 3 : 16) << 30;      /* (encode_mem_plan lowers it on a tight device) */
+        const size_t cap = J.scratch_cap ? J.scratch_cap : (size_t)(g.fast ? 3 : LZ77X_BIG_SCRATCH_GB) << 30;      /* (encode_mem_plan lowers it on a tight device) */
         const uint32_t fit = (uint32_t)(cap / per);
         if (batch > fit) batch = fit ? fit : 1;
         const char *gs = getenv("LZ77X_MATCH_BATCH");
@@ -175,8 +175,8 @@ int seg_mid(SegJob &J, const lz77x_geom &g, SegCarry &carry, bool allow_fallback
         HIPCHK(hipEventRecord(c.match_ev[0], sc));
         HIPCHK(lz77k_chain(c.maxlen.as<uint8_t>(), E, g.la, J.d_chain, J.d_chain_tmp, sc, &d_tbase, &nsub, start, &d_exit));
         HIPCHK(hipEventRecord(c.match_ev[1], sc));
-        HIPCHK(hipMemcpyAsync(h_tbase, d_tbase, ((size_t)nsub + 1) * 4, hipMemcpyDeviceToHost, sc));
-        HIPCHK(hipMemcpyAsync(c.h_small.as<uint32_t>() + 16, d_exit, 4, hipMemcpyDeviceToHost, sc));
+        HIPCHK(small_d2h(c.h_tbase, h_tbase, d_tbase, ((size_t)nsub + 1) * 4, sc));
+        HIPCHK(small_d2h(c.h_small, c.h_small.as<uint32_t>() + 16, d_exit, 4, sc));
         HIPCHK(hipEventRecord(c.pipe_ev[2], sc));
         J.nsub = nsub;
 
@@ -246,7 +246,7 @@ int seg_mid(SegJob &J, const lz77x_geom &g, SegCarry &carry, bool allow_fallback
             host_cells = true;
             converged = 1;
         }
-        if (!J.last && !host_cells) HIPCHK(hipMemcpyAsync(h_state, look_next, usb * 4, hipMemcpyDeviceToHost, s));
+        if (!J.last && !host_cells) HIPCHK(small_d2h(c.h_tbase, h_state, look_next, usb * 4, s));
         HIPCHK(hipStreamSynchronize(s));                       /* (nx == 0: the recurrence did not sync) */
         HIPCHK(hipEventSynchronize(c.pipe_ev[2]));             /* tbase has landed */
         HIPCHK(hipStreamWaitEvent(s, c.pipe_ev[2], 0));        /* chain[] is there for the tie-break */
@@ -340,7 +340,7 @@ int seg_tokens(SegJob &J, const lz77x_geom &g, const SegCarry &carry)
                                 fused ? c.ps.as<uint32_t>() : nullptr, fused ? J.d_xval : nullptr, c.flag.as<unsigned long long>() + 8));
             J.tie_timed[ci] = tb > ta;
         }
-        HIPCHK(hipMemcpyAsync(c.h_small.as<unsigned long long>() + 2, c.flag.as<unsigned long long>() + 8, 8, hipMemcpyDeviceToHost, s));
+        HIPCHK(small_d2h(c.h_small, c.h_small.as<unsigned long long>() + 2, c.flag.as<unsigned long long>() + 8, 8, s));
     } else {
         if (!(J.d_tokval = reinterpret_cast<uint32_t *>(J.place(c.tokval, 64)))) return LZ77X_E_HIP;
         uint32_t *tokbuf = J.d_tokval;
@@ -361,7 +361,7 @@ int seg_tokens(SegJob &J, const lz77x_geom &g, const SegCarry &carry)
     /* carry: the last four tokens seen so far */
     J.have_tail = ntok + carry.ntail < 4 ? ntok + carry.ntail : 4;
     if (J.have_tail)
-        HIPCHK(hipMemcpyAsync(c.h_small.as<uint32_t>() + 20, J.d_tokval + 4 + ntok - J.have_tail, J.have_tail * 4, hipMemcpyDeviceToHost, s));
+        HIPCHK(small_d2h(c.h_small, c.h_small.as<uint32_t>() + 20, J.d_tokval + 4 + ntok - J.have_tail, J.have_tail * 4, s));
     J.out_bytes = J.last ? zn_total - 4 * wlo : 4 * nw;
     return LZ77X_OK;
 }
@@ -508,7 +508,7 @@ int encode_stream_device(Ctx &c, Source &src, Sink &sink, const lz77x_geom &g, h
             /* one context set while the input is one segment; two as soon as it is not (the second pass) */
             const bool two = pipelined && (pass == 1 || !(known && known <= seg));
             const size_t share = avail / 10 * 9 / (two ? 2 : 1);
-            scratch_cap = (size_t)(g.fast ? 3 : 16) << 30;
+            scratch_cap = (size_t)(g.fast ? 3 : LZ77X_BIG_SCRATCH_GB) << 30;
             if (scratch_cap > share / 4) scratch_cap = share / 4;
             if (scratch_cap < one_region) scratch_cap = one_region;
             const size_t fixed = scratch_cap + slack + (g.fast ? 0 : (size_t)1 << 30);

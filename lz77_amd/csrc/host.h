@@ -99,6 +99,13 @@ extern __thread double g_alloc_ms, g_pin_ms, g_fread_ms, g_fwrite_ms;
 extern __thread size_t g_alloc_bytes, g_pin_bytes;
 
 
+/* match-stage scratch per launch at the large windows, GB (16 until round 6: S3's 1079 regions in one launch; the stage's kernels
+ * are throughput-bound there -- grid-wide sorts, 25 rounds of walker workgroups -- so a second launch costs little and the
+ * footprint of a 212 MB encode drops by 4 GB) */
+#ifndef LZ77X_BIG_SCRATCH_GB
+#define LZ77X_BIG_SCRATCH_GB 12
+#endif
+
 /* LZ77X_POISON=1 (debug aid, never changes the output of correct code): every cached device and pinned buffer is filled with
  * 0xA5 when a call leases its context set and when a buffer grows -- a kernel or host loop that reads what this call has not
  * written then sees garbage instead of the zeroes of fresh memory or the plausible values of the call before (ctx.cpp) */
@@ -178,6 +185,14 @@ struct PinBuf {
     }
     template <class T> T *as() const { return reinterpret_cast<T *>(p); }
 };
+
+/* a small result (whole words) from device memory into a pinned buffer of the context: by kernel where the buffer came from
+ * hipHostMalloc (lz77k_publish), by the runtime's copy where it is registered memory */
+inline hipError_t small_d2h(const PinBuf &pb, void *h_dst, const void *d_src, size_t bytes, hipStream_t s)
+{
+    if (!pb.registered && (bytes & 3) == 0 && bytes <= ((size_t)1 << 20)) return lz77k_publish(h_dst, d_src, (uint32_t)(bytes / 4), s);
+    return hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, s);
+}
 
 /* ---- host copies between the caller's pageable memory and the pinned staging slots --------------------------------
  * hipMemcpy on pageable memory is staged by the runtime on ONE thread (~5 GB/s: 100 MB in and 47 MB out cost an encode

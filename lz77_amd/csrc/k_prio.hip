@@ -905,7 +905,7 @@ hipError_t lz77k_prio_sweep(lz77k_prio_plan &P, hipStream_t s, uint32_t *h_flag,
                        PRIO_PTR(uint64_t, P.o_cmask), PRIO_PTR(uint64_t, P.o_gate[P.cur]), PRIO_PTR(uint64_t, P.o_gate[P.cur ^ 1]), in, P.xval, summary, P.voff, d_out_state,
                        gates_changed, (const uint32_t *)in_changed);
     if (ev3 && (e = hipEventRecord(ev3[2], s)) != hipSuccess) return e;
-    return hipMemcpyAsync(h_flag, summary, 12, hipMemcpyDeviceToHost, s);
+    return lz77k_publish(h_flag, summary, 3, s);              /* (h_flag: pinned by hipHostMalloc -- every caller passes its context's h_small) */
 }
 
 /* after the stream has drained: take the sweep's gates as current.  Gates before the first flip are final

@@ -1466,11 +1466,11 @@ __device__ __forceinline__ void rank_token(uint32_t k, const uint32_t lane, cons
  * keeps the walk above. */
 struct hr_index {
     const uint32_t *hofs;                            /* per region of the launch RP + 8 words: [r] = first record of the cell at rank r, [r + 1] its end; null: no index */
-    const uint32_t *hv;                              /* the priority handed over */
-    const uint32_t *hc;                              /* its destination cell */
-    const uint16_t *hdx;                             /* cell - eviction (1 .. sb) */
+    const uint4 *rec;                                /* a record: x = the priority handed over, y = its destination cell, z = cell - eviction (1 .. sb); one 16-byte store / load */
+    unsigned long long *rcache;                      /* per region HR_CACHE words: the rank bounds of a run, by a hash of its bytes (below) */
     uint32_t reg0;                                   /* first region of the index */
 };
+#define HR_CACHE 2048u
 
 __device__ __forceinline__ uint32_t hr_region_cells(uint32_t reg, uint32_t RP, uint32_t TILE, uint32_t usb, uint32_t n, uint32_t whole_order)
 {
@@ -1494,8 +1494,7 @@ __global__ __launch_bounds__(256) void k_hr_count(const uint32_t *__restrict__ r
 
 __global__ __launch_bounds__(256) void k_hr_scatter(const uint32_t *__restrict__ ranks_all, uint32_t RP, uint32_t TILE, uint32_t usb, uint32_t n,
                                                     uint32_t whole_order, uint32_t reg0, const uint32_t *__restrict__ ofs, const uint2 *__restrict__ ent,
-                                                    uint32_t dbase, uint32_t c1, const uint32_t *__restrict__ hofs, uint32_t *__restrict__ hv,
-                                                    uint32_t *__restrict__ hc, uint16_t *__restrict__ hdx)
+                                                    uint32_t dbase, uint32_t c1, const uint32_t *__restrict__ hofs, uint4 *__restrict__ rec)
 {
     const uint32_t reg = reg0 + blockIdx.y, e = blockIdx.x * 256u + threadIdx.x;
     if ((uint64_t)reg * TILE >= n) return;
@@ -1508,9 +1507,7 @@ __global__ __launch_bounds__(256) void k_hr_scatter(const uint32_t *__restrict__
     uint32_t at = hofs[(size_t)blockIdx.y * (RP + 8) + (ranks_all + (size_t)reg * (2 * (size_t)RP + 8))[e]];
     for (uint32_t i = lo; i < hi; i++, at++) {
         const uint2 t = ent[i];                      /* (eviction, priority handed over) */
-        hv[at] = t.y;
-        hc[at] = c;
-        hdx[at] = (uint16_t)(c - t.x);
+        rec[at] = make_uint4(t.y, c, c - t.x, 0u);
     }
 }
 
@@ -1539,23 +1536,58 @@ __device__ __forceinline__ void rank_token_hr(uint32_t k, const uint32_t lane, c
         }
         return true;
     };
-    /* where the run ends: "shares" is monotone along the order, a 64-ary search from what is known */
-    auto extent = [&](bool updir, uint32_t known) -> uint32_t {
-        uint32_t lo = known, hi = (updir ? R - 1u - ry : ry) + 1u;   /* true at lo, false (out of range) at hi */
-        while (hi - lo > 1) {
-            const uint64_t span = hi - lo;
-            const uint32_t d = lo + (uint32_t)(span * (lane + 1) / 65);              /* lo <= d < hi, increasing in lane */
-            const bool ok = d == lo || shares(ix[updir ? ry + d : ry - d]);
-            const uint64_t m = __ballot(ok);
-            const uint32_t top = m == ~0ull ? 64u : (uint32_t)__builtin_ctzll(~m);   /* lanes 0 .. top-1 are in */
-            const uint32_t nlo = top ? lo + (uint32_t)(span * top / 65) : lo;
-            const uint32_t nhi = top < 64 ? lo + (uint32_t)(span * (top + 1) / 65) : hi;
-            lo = nlo;
-            hi = nhi;
+    /* Where the run ends.  Tokens that share their len bytes share their run, and the tokens that come here are the ones with
+     * the common prefixes: the bounds of a run are kept per region under a hash of (len, bytes) -- ONE 64-bit word, so a torn
+     * or colliding entry is impossible / harmless: whatever the word says is VALIDATED with four probes in one round (both
+     * ends share, their outer neighbours do not, the token's own rank lies between) before it is believed.  A miss searches
+     * -- "shares" is monotone along the order: a 32-ary search per direction, both directions at once, from what the group
+     * phase already knows -- and leaves its result behind. */
+    uint32_t d_dn = dn, d_up = up;
+    if (open_dn || open_up) {
+        unsigned long long *slot;
+        {
+            uint64_t h = ld64u(q) & (len >= 8 ? ~0ull : (1ull << (8 * len)) - 1ull);
+            if (len > 8) h ^= ld64u(q + len - 8) * 0x9E3779B97F4A7C15ull;
+            h = (h ^ len) * 0xD6E8FEB86659FD93ull;
+            slot = H.rcache + (size_t)(reg - H.reg0) * HR_CACHE + (uint32_t)(h >> 53);           /* HR_CACHE = 2^11 */
         }
-        return lo;
-    };
-    const uint32_t d_dn = open_dn ? extent(false, dn) : dn, d_up = open_up ? extent(true, up) : up;
+        const unsigned long long w = *slot;
+        const uint32_t ca = (uint32_t)w, cb = (uint32_t)(w >> 32);                               /* r_lo + 1, r_hi + 1; 0: empty */
+        bool hit = false;
+        if (ca != 0u && ca - 1u <= ry && cb - 1u >= ry && cb <= R) {
+            const uint32_t a = ca - 1u, b = cb - 1u;
+            /* lanes 0..3: rank a, rank b (must share), a - 1, b + 1 (must not, where they exist) */
+            const uint32_t rr = lane == 0 ? a : lane == 1 ? b : lane == 2 ? (a ? a - 1u : a) : (b + 1u < R ? b + 1u : b);
+            const bool exists = lane < 2 || (lane == 2 ? a > 0u : b + 1u < R);
+            bool ok = true;
+            if (lane < 4) { const bool sh = shares(ix[rr]); ok = lane < 2 ? sh : (!exists || !sh); }
+            hit = __ballot(!ok) == 0ull;
+            if (hit) { d_dn = ry - a; d_up = b - ry; }
+        }
+        if (!hit) {
+            const bool updir = lane >= 32;
+            const uint32_t sl = lane & 31u;
+            uint32_t lo = updir ? up : dn, hi = (updir ? R - 1u - ry : ry) + 1u;             /* true at lo, false (out of range) at hi */
+            if (!(updir ? open_up : open_dn)) hi = lo + 1u;                                   /* (this direction is settled) */
+            while (__ballot(hi - lo > 1u)) {
+                const uint64_t span = hi - lo;
+                const uint32_t d = lo + (uint32_t)(span * (sl + 1u) / 33u);                   /* lo <= d < hi, increasing in the lane */
+                const bool ok = hi - lo <= 1u || d == lo || shares(ix[updir ? ry + d : ry - d]);
+                const uint64_t m = __ballot(ok);
+                const uint32_t mine = (uint32_t)(m >> (updir ? 32 : 0));
+                const uint32_t top = mine == 0xFFFFFFFFu ? 32u : (uint32_t)__builtin_ctz(~mine); /* lanes 0 .. top-1 of my half are in */
+                if (hi - lo > 1u) {
+                    const uint32_t nlo = top ? lo + (uint32_t)(span * top / 33u) : lo;
+                    const uint32_t nhi = top < 32u ? lo + (uint32_t)(span * (top + 1u) / 33u) : hi;
+                    lo = nlo;
+                    hi = nhi;
+                }
+            }
+            d_dn = (uint32_t)__builtin_amdgcn_readlane((int)lo, 0);
+            d_up = (uint32_t)__builtin_amdgcn_readlane((int)lo, 32);
+            if (lane == 0) *slot = (unsigned long long)(ry - d_dn + 1u) | ((unsigned long long)(ry + d_up + 1u) << 32);
+        }
+    }
     const uint32_t r_lo = ry - d_dn, r_hi = ry + d_up, run_len = d_dn + d_up + 1u;
     const uint32_t w_lo = ly > usb ? ly - usb : 0u;                  /* the window's first cell (local) */
     /* (a) the oldest member of the run inside the window */
@@ -1596,19 +1628,14 @@ __device__ __forceinline__ void rank_token_hr(uint32_t k, const uint32_t lane, c
     /* (b) the hand-overs into the run's cells: one contiguous range of records */
     const uint32_t i0 = hofs[r_lo], i1 = hofs[r_hi + 1u];
     for (uint32_t ib = i0; ib < i1; ib += 256u) {
-        uint32_t cc[4], vv[4], dx[4];
+        uint4 rr[4];
 #pragma unroll
-        for (uint32_t u = 0; u < 4; u++) {
-            const uint32_t i = min(ib + 64u * u + lane, i1 - 1u);
-            cc[u] = H.hc[i];
-            dx[u] = H.hdx[i];
-            vv[u] = H.hv[i];
-        }
+        for (uint32_t u = 0; u < 4; u++) rr[u] = H.rec[min(ib + 64u * u + lane, i1 - 1u)];
 #pragma unroll
         for (uint32_t u = 0; u < 4; u++) {
             /* the eviction lies before the window, its cell inside it (a cell is below p: c = x + S[x] < x + sb < p) */
-            if (ib + 64u * u + lane < i1 && (uint64_t)(cc[u] - dx[u]) + usb < p && (uint64_t)cc[u] + usb >= p) {
-                const uint64_t key = ((uint64_t)vv[u] << 32) | cc[u];
+            if (ib + 64u * u + lane < i1 && (uint64_t)(rr[u].y - rr[u].z) + usb < p && (uint64_t)rr[u].y + usb >= p) {
+                const uint64_t key = ((uint64_t)rr[u].x << 32) | rr[u].y;
                 best = key < best ? key : best;
             }
         }
@@ -1710,8 +1737,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80))) void k_to
                 /* the cell's records sit at its RANK: the bounds of neighbouring lanes are neighbouring words */
                 prio = c + voff;
                 const uint32_t lo = hofs[rr], hi = hofs[rr + 1u];
-                for (uint32_t i = lo; i < hi; i++)
-                    if ((uint64_t)(c - H.hdx[i]) + usb < p) prio = min(prio, H.hv[i]);      /* (a hand-over only lowers its cell: the latest is the smallest) */
+                for (uint32_t i = lo; i < hi; i++) {
+                    const uint4 t = H.rec[i];
+                    if ((uint64_t)(c - t.z) + usb < p) prio = min(prio, t.x);              /* (a hand-over only lowers its cell: the latest is the smallest) */
+                }
             } else {
                 uint32_t latest = 0;
                 bool any = false;
@@ -1781,11 +1810,11 @@ size_t lz77k_tokens_index_bytes(const lz77x_geom &g, size_t npos)
         need = 4 * ((nbk + 1) * 4 + 256) + lz77k_scan_tmp_bytes((uint32_t)nbk + 1) + 256 + nc * 8 + (nc + g.sb + 16) * 12 + 3 * 256;
     }
     {
-        /* the hand-overs by rank (hr_index): RP + 8 offsets per region, ten bytes a record */
+        /* the hand-overs by rank (hr_index): RP + 8 offsets per region, sixteen bytes a record, the run cache */
         size_t nreg, cap;
         hr_plan(g, npos, &nreg, &cap);
         const size_t nslots = nreg * ((size_t)g.RP + 8);
-        need += (nslots + 1) * 4 + lz77k_scan_tmp_bytes((uint32_t)nslots + 1) + cap * 10 + 6 * 256;
+        need += (nslots + 1) * 4 + lz77k_scan_tmp_bytes((uint32_t)nslots + 1) + cap * 16 + nreg * HR_CACHE * 8 + 6 * 256;
     }
 #ifdef LZ77X_VARIANTS
     const size_t ntiles = (npos + BIG_TT - 1) / BIG_TT;
@@ -1849,15 +1878,16 @@ hipError_t lz77k_tokens(const uint8_t *d_in, uint32_t n, const lz77x_geom &g, co
             const size_t nslots = (size_t)nreg * ((size_t)g.RP + 8);
             uint32_t *hofs = reinterpret_cast<uint32_t *>(take((nslots + 1) * 4));
             void *stmp = take(lz77k_scan_tmp_bytes((uint32_t)nslots + 1));
-            uint32_t *hv = reinterpret_cast<uint32_t *>(take(cap * 4)), *hc = reinterpret_cast<uint32_t *>(take(cap * 4));
-            uint16_t *hdx = reinterpret_cast<uint16_t *>(take(cap * 2));
+            uint4 *rec = reinterpret_cast<uint4 *>(take(cap * 16));
+            unsigned long long *rcache = reinterpret_cast<unsigned long long *>(take((size_t)nreg * HR_CACHE * 8));
             hipError_t e = hipMemsetAsync(hofs, 0, (nslots + 1) * 4, s);
             if (e != hipSuccess) return e;
+            if ((e = hipMemsetAsync(rcache, 0, (size_t)nreg * HR_CACHE * 8, s)) != hipSuccess) return e;
             const dim3 grid((g.RP + 255u) / 256u, nreg);
             hipLaunchKernelGGL(k_hr_count, grid, dim3(256), 0, s, d_ranks_all, g.RP, g.TILE, usb, n, whole, reg0, d_ofs, dbase, pos1, hofs);
             if ((e = lz77k_scan_u32(hofs, hofs, (uint32_t)nslots + 1u, stmp, s)) != hipSuccess) return e;
-            hipLaunchKernelGGL(k_hr_scatter, grid, dim3(256), 0, s, d_ranks_all, g.RP, g.TILE, usb, n, whole, reg0, d_ofs, d_ent, dbase, pos1, hofs, hv, hc, hdx);
-            Hx.hofs = hofs; Hx.hv = hv; Hx.hc = hc; Hx.hdx = hdx; Hx.reg0 = reg0;
+            hipLaunchKernelGGL(k_hr_scatter, grid, dim3(256), 0, s, d_ranks_all, g.RP, g.TILE, usb, n, whole, reg0, d_ofs, d_ent, dbase, pos1, hofs, rec);
+            Hx.hofs = hofs; Hx.rec = rec; Hx.rcache = rcache; Hx.reg0 = reg0;
         }
         {
             /* several tokens per wavefront (LZ77X_RANK_LPT=64 in the variants build: one) */

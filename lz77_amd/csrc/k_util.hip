@@ -151,3 +151,24 @@ hipError_t lz77k_sum_u32(const uint32_t *d_in, uint32_t m, unsigned long long *d
     hipLaunchKernelGGL(k_sum64, dim3(blocks), dim3(256), 0, s, d_in, m, d_out);
     return hipGetLastError();
 }
+
+
+/* A few words from device memory straight into PINNED host memory (hipHostMalloc: mapped into the device's address space,
+ * coherent), by a kernel instead of hipMemcpyAsync: the runtime performs a small device-to-host copy as a blit kernel of its
+ * own that takes ~21 us on the stream (profiles/r05_bench_kernel_stats.csv: 70 x __amd_rocclr_copyBuffer in four steps), and the
+ * flags, counts and last tokens an encode or decode hands to the host are 4-16 bytes each, a dozen of them on the critical
+ * path of every step.  The host reads them after it has synchronised the stream (a kernel's stores to host memory are
+ * visible when the kernel has completed). */
+__global__ void k_publish(uint32_t *__restrict__ h_dst, const uint32_t *__restrict__ d_src, uint32_t nwords)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < nwords) h_dst[i] = d_src[i];
+}
+
+hipError_t lz77k_publish(void *h_dst_pinned, const void *d_src, uint32_t nwords, hipStream_t s)
+{
+    if (nwords == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_publish, dim3((nwords + 255u) / 256u), dim3(256), 0, s, reinterpret_cast<uint32_t *>(h_dst_pinned),
+                       reinterpret_cast<const uint32_t *>(d_src), nwords);
+    return hipGetLastError();
+}

@@ -115,6 +115,9 @@ hipError_t lz77k_ps_cells(const uint32_t *d_ps, uint32_t *d_cells, uint32_t x0, 
 /* exclusive scan of m uint32 (in place allowed); d_tmp needs lz77k_scan_tmp_bytes(m) */
 size_t lz77k_scan_tmp_bytes(uint32_t m);
 hipError_t lz77k_scan_u32(const uint32_t *d_in, uint32_t *d_out, uint32_t m, void *d_tmp, hipStream_t s);
+/* nwords 32-bit words from device memory into pinned host memory (hipHostMalloc, not hipHostRegister) by a kernel: a tenth of what
+ * the runtime's blit of a small device-to-host copy costs the stream */
+hipError_t lz77k_publish(void *h_dst_pinned, const void *d_src, uint32_t nwords, hipStream_t s);
 
 /* ---- device-resident sequential stages (k_prio.hip, k_chain.hip) ---- */
 

@@ -1,7 +1,7 @@
 #!/bin/bash
 # PMC counters of ONE S3 encode (212 MB mixed, s=65535 l=255; tools/time_c2.py), one rocprofv3 pass per counter set, --kernel-trace only
-# (MI355X_MICROARCH.md, HBM / rocprofv3):   gpurun --timeout 900 -- 'bash tools/c2_pmc.sh'   -> gpurun_out/r05c2/r05c2_bench_pmc_summary.csv
-tag=r05c2
+# (MI355X_MICROARCH.md, HBM / rocprofv3):   gpurun --timeout 900 -- 'bash tools/c2_pmc.sh'   -> gpurun_out/<tag>c2/<tag>c2_bench_pmc_summary.csv
+tag=${TAG:-r06}c2
 cd /tmp && export TMPDIR=/tmp
 cd "${GRAFT_REPO_ROOT:-$(dirname "$0")/..}"
 out=gpurun_out/$tag; rm -rf $out; mkdir -p $out

@@ -37,10 +37,13 @@ python tools/measure_configs.py > $out/${tag}_configs.json 2> $out/configs.err
 python tools/prio_classes.py > $out/${tag}_prio_classes.json 2> $out/prio_classes.err
 bash tools/prof_cmd.sh ${tag}_c2 ITERS=1 -- python tools/time_c2.py > $out/c2.log 2>&1; cp gpurun_out/${tag}_c2_kernel_stats.csv $out/
 
+bash tools/c2_pmc.sh > $out/c2_pmc.log 2>&1; cp gpurun_out/${tag}c2/${tag}c2_bench_pmc_summary.csv $out/${tag}_c2_pmc_summary.csv
+
 # 6. host paths: buffers, files, CLI, memory
 python tools/host_rates.py > $out/host_rates.log 2>&1; cp gpurun_out/host_rates.json $out/${tag}_host_rates.json
 timeout 300 python tools/file_rates.py > $out/file_rates.log 2>&1; cp gpurun_out/file_rates.json $out/${tag}_file_rates.json
 python tools/mem_probe.py > $out/mem_probe.log 2>&1; cp gpurun_out/mem_probe.json $out/${tag}_mem_probe.json
+./tools/scratch_hold_probe > $out/${tag}_scratch_hold.txt 2>&1      # what the runtime keeps of a queue's scratch: the "leak" of mem_probe
 bash tools/cli_trace.sh > $out/${tag}_cli_trace.txt 2>&1
 python tools/rss_probe.py > $out/${tag}_rss_probe.txt 2>&1
 

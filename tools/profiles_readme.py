@@ -1,7 +1,7 @@
-"""profiles/README.md, the round-5 part: GENERATED from the files tools/evidence.sh wrote (the numbers in the
+"""profiles/README.md, one round's part: GENERATED from the files tools/evidence.sh wrote (the numbers in the
 README come out of the evidence files, not out of an editor).
 
-    python tools/profiles_readme.py            # rewrites the block between <!-- r05:begin --> and <!-- r05:end -->
+    python tools/profiles_readme.py [tag]      # (default r06) rewrites the block between <!-- <tag>:begin --> and <!-- <tag>:end -->
 """
 import csv
 import json
@@ -10,7 +10,8 @@ import re
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 P = os.path.join(ROOT, "profiles")
-TAG = "r05"
+import sys
+TAG = sys.argv[1] if len(sys.argv) > 1 else "r06"
 
 
 def load(name):
@@ -183,15 +184,16 @@ for name, what in (("_cli_trace.txt", "`bash tools/cli_trace.sh`: `LZ77X_TRACE=1
     if os.path.exists(os.path.join(P, TAG + name)):
         rows.append(("`%s%s`" % (TAG, name), what))
 
-block = "<!-- r05:begin (generated by tools/profiles_readme.py from the files named in the first column) -->\n| file | what |\n|---|---|\n" + \
-        "\n".join("| %s | %s |" % (a, b_.replace("|", "/")) for a, b_ in rows) + "\n<!-- r05:end -->"
+block = "<!-- %s:begin (generated by tools/profiles_readme.py from the files named in the first column) -->\n| file | what |\n|---|---|\n" % TAG + \
+        "\n".join("| %s | %s |" % (a, b_.replace("|", "/")) for a, b_ in rows) + "\n<!-- %s:end -->" % TAG
 path = os.path.join(P, "README.md")
 txt = open(path).read()
-if "<!-- r05:begin" in txt:
-    txt = re.sub(r"<!-- r05:begin.*?<!-- r05:end -->", lambda m: block, txt, flags=re.S)
+if "<!-- %s:begin" % TAG in txt:
+    txt = re.sub(r"<!-- %s:begin.*?<!-- %s:end -->" % (TAG, TAG), lambda m: block, txt, flags=re.S)
 else:
-    head, sep, rest = txt.partition("| file | what |")
-    txt = head + "## Round 5\n\n`bash tools/evidence.sh` (one gpurun call) writes every r05 file below; `python tools/profiles_readme.py` writes this table from them.\n\n" + block + \
-        "\n\n## Rounds 1-4 (as written then)\n\n" + sep + rest
+    # a new round's table goes in front of the earlier rounds'
+    head, sep, rest = txt.partition("## Round ")
+    txt = head + "## Round %s\n\n`TAG=%s bash tools/evidence.sh` (one gpurun call) writes every %s file below; `python tools/profiles_readme.py %s` writes this table from them.\n\n" % (
+        TAG[1:].lstrip("0"), TAG, TAG, TAG) + block + "\n\n" + sep + rest
 open(path, "w").write(txt)
 print("rows", len(rows))
