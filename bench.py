@@ -387,9 +387,10 @@ def shard_mode(a):
                       "bound_speedup": {str(d): round(t_one / (hs + max(t_one - hs, 0.0) / d), 2) for d in (2, 4, 8)},
                       "clock": "time.perf_counter around lz77x_encode itself (lz77_amd.encode_c: no copy into a bytes object), for T(1) and for the sharded run alike",
                       "note": "prediction, not a measurement: T(D) >= host_serial + (T(1) - host_serial) / D with host_serial = the host "
-                              "time of THIS run during which no device has work (the parse chain's exchange, per gate iteration the D "
-                              "boundary maps chained on the host and the D flip summaries read -- every shard is driven by a host thread "
-                              "of its own --, the pack enqueue) -- it grows with D (one map per shard) and is "
+                              "time of THIS run during which no device has work: the parse chain's exchange; per gate iteration, twice, from the "
+                              "moment the LAST shard's device finished a phase to the moment the FIRST shard's thread enqueues the next "
+                              "(the D boundary maps chained on the host, the D flip summaries read, and the wake-ups of the barriers the "
+                              "per-shard host threads meet at); the pack enqueue -- it grows with D (one map per shard) and is "
                               "measured here at D = %d on %d physical device(s)" % (len(plan), min(len(plan), L.lib().lz77x_device_count()))}
         out = {"metric": "encode+decode MB/s on enwik9-like synthetic text, s=%d l=%d, ONE stream position-sharded" % (a.sb, a.la),
                "value": round(n * K / dt / 1e6, 3), "unit": "MB/s",

@@ -15,7 +15,9 @@
  * Plain C, plain pointers and sizes.  No global state is required between calls;
  * lazily created per-process contexts cache device scratch buffers.  Thread safe: concurrent
  * callers each lease a context of their own (up to LZ77X_MAX_CONTEXTS, default 4; others wait).
- * All functions return 0 on success or a negative LZ77X_E_* code and never print.
+ * All functions return 0 on success or a negative LZ77X_E_* code and never print.  The library is C++ inside;
+ * no C++ exception ever crosses this boundary (a failed host allocation or a host thread that cannot start comes back
+ * as LZ77X_E_NOMEM / LZ77X_E_HIP with lz77x_last_error() set).
  */
 #ifndef LZ77_MI355X_H
 #define LZ77_MI355X_H
@@ -92,8 +94,9 @@ int lz77x_decode_file(FILE *in, FILE *out);
  * positions -- an input of any length in stretches of at most 4 GiB, every stretch over all the devices, the file
  * entry point holding one stretch in host memory --, lz77x_decode cuts the stream by token ranges (the sb bytes before a range reach it
  * as a map chained on the host; lz77.c:172-192 across the cuts), a long stream in stretches of tokens, every stretch
- * over all the devices; streams it cannot cut that way (distance-0 copies of a power-of-two -s, shards shorter than a
- * window) decode on one device, range by range. */
+ * over all the devices (a tail too short for a window of output per device joins the stretch before it); streams it cannot
+ * cut that way (distance-0 copies: a power-of-two -s, whose staging-buffer image at a cut is a function of everything
+ * before it, lz77.c:172-188) decode on one device, range by range.  The shards of one call are driven by one host thread each. */
 int lz77x_set_shards(int shards);
 int lz77x_device_count(void);
 /* Release every cached device/pinned buffer, stream and event (they are otherwise kept for the

@@ -465,6 +465,9 @@ int encode_stream_device(Ctx &c, Source &src, Sink &sink, const lz77x_geom &g, h
     size_t seg = (size_t)1 << 30, scratch_cap = 0, token_chunk = (size_t)128 << 20;
     {
         const char *ce = getenv("LZ77X_TOKEN_CHUNK");
+        /* (large windows: 64 M -- a chunk's hand-over index, first-byte buckets and hand-overs by rank are ~70 bytes of
+         * reservation per position, and half the chunk lets them all live in the dead match scratch, SegJob::place) */
+        if (!g.fast) token_chunk = (size_t)64 << 20;
         if (ce && atoll(ce) > 0) token_chunk = (size_t)atoll(ce);
         if (token_chunk > ((size_t)1 << 31)) token_chunk = (size_t)1 << 31;
     }

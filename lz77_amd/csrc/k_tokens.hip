@@ -1542,7 +1542,8 @@ __device__ __forceinline__ void rank_token_hr(uint32_t k, const uint32_t lane, c
      * ends share, their outer neighbours do not, the token's own rank lies between) before it is believed.  A miss searches
      * -- "shares" is monotone along the order: a 32-ary search per direction, both directions at once, from what the group
      * phase already knows -- and leaves its result behind. */
-    uint32_t d_dn = dn, d_up = up;
+    uint32_t d_dn = dn, d_up = up, sp0 = 0, sp1 = 0;
+    bool have_sp = false;
     if (open_dn || open_up) {
         unsigned long long *slot;
         {
@@ -1554,7 +1555,11 @@ __device__ __forceinline__ void rank_token_hr(uint32_t k, const uint32_t lane, c
         const unsigned long long w = *slot;
         const uint32_t ca = (uint32_t)w, cb = (uint32_t)(w >> 32);                               /* r_lo + 1, r_hi + 1; 0: empty */
         bool hit = false;
-        if (ca != 0u && ca - 1u <= ry && cb - 1u >= ry && cb <= R) {
+        const bool cand = ca != 0u && ca - 1u <= ry && cb - 1u >= ry && cb <= R;
+        /* (the record range of the cached run travels with the validation's probes: one round trip less on a hit) */
+        sp0 = hofs[cand ? ca - 1u : ry];
+        sp1 = hofs[(cand ? cb - 1u : ry) + 1u];
+        if (cand) {
             const uint32_t a = ca - 1u, b = cb - 1u;
             /* lanes 0..3: rank a, rank b (must share), a - 1, b + 1 (must not, where they exist) */
             const uint32_t rr = lane == 0 ? a : lane == 1 ? b : lane == 2 ? (a ? a - 1u : a) : (b + 1u < R ? b + 1u : b);
@@ -1562,7 +1567,7 @@ __device__ __forceinline__ void rank_token_hr(uint32_t k, const uint32_t lane, c
             bool ok = true;
             if (lane < 4) { const bool sh = shares(ix[rr]); ok = lane < 2 ? sh : (!exists || !sh); }
             hit = __ballot(!ok) == 0ull;
-            if (hit) { d_dn = ry - a; d_up = b - ry; }
+            if (hit) { d_dn = ry - a; d_up = b - ry; have_sp = true; }
         }
         if (!hit) {
             const bool updir = lane >= 32;
@@ -1626,7 +1631,7 @@ __device__ __forceinline__ void rank_token_hr(uint32_t k, const uint32_t lane, c
     uint64_t best = ~0ull;
     if (oldest != ~0u) best = ((uint64_t)(t0 + oldest + voff) << 32) | (t0 + oldest);
     /* (b) the hand-overs into the run's cells: one contiguous range of records */
-    const uint32_t i0 = hofs[r_lo], i1 = hofs[r_hi + 1u];
+    const uint32_t i0 = have_sp ? sp0 : hofs[r_lo], i1 = have_sp ? sp1 : hofs[r_hi + 1u];
     for (uint32_t ib = i0; ib < i1; ib += 256u) {
         uint4 rr[4];
 #pragma unroll

@@ -464,13 +464,7 @@ static int encode_sharded_stretch(std::vector<Ctx *> &cs, const uint8_t *src, si
         carry.chain_pos = origin + t1 + e;
         carry.ntok = K;
     }
-    for (ShardJob &j : J) {
-        Ctx &c = *j.c;
-        if ((rc = dev(j))) return rc;
-        HIPCHK(lz77k_chain_finish(c.maxlen.as<uint8_t>(), j.E, g.la, c.chain.as<uint32_t>(), c.chain_tmp.p, c.stream, j.look, j.entry, &j.d_tbase,
-                                  &j.nsub, nullptr));
-        HIPCHK(hipMemcpyAsync(c.h_tbase.p, j.d_tbase, ((size_t)j.nsub + 1) * 4, hipMemcpyDeviceToHost, c.stream));
-    }
+    /* (the second half of the chain -- every shard's tokens from its entry on -- is enqueued by the shard's own thread below) */
 
     /* -- the priority recurrence across the cuts (tree.c:202-231): all shards iterate together.  Round 6: every shard has a
      *    host thread of its own for the whole iteration (as phase A has): it enqueues its maps, waits for ITS device, and
@@ -501,14 +495,30 @@ static int encode_sharded_stretch(std::vector<Ctx *> &cs, const uint8_t *src, si
         } team;
         team.D = D;
         host_serial_ms += now_ms() - t_serial;               /* (the chain's exchange and the enqueue of its second half) */
-        double serial_it = 0;                                 /* thread 0 alone between two barriers */
+        /* What is serial in the joint iteration, honestly: from the moment the LAST shard's device has finished a phase to the
+         * moment the FIRST shard's thread starts enqueuing the next one -- thread 0's work between the barriers AND the
+         * wake-ups of the barriers themselves (all stamps are one steady clock). */
+        double serial_it = 0;
+        std::vector<double> t_done(D, 0.0), t_begin(D, 0.0);
+        auto last_done = [&]() { double m = 0; for (double t : t_done) m = t > m ? t : m; return m; };
+        auto first_begin = [&]() { double m = t_begin[0]; for (double t : t_begin) m = t < m ? t : m; return m; };
+        bool have_done = false;                               /* t_done holds the stamps of a finished phase */
         rc = run_team(D, [&](size_t d) -> int {
             ShardJob &j = J[d];
             int my_rc = LZ77X_OK;
             /* a failing shard keeps meeting the barriers; everybody leaves together at the end of the iteration */
             auto step = [&](auto fn) { if (my_rc == LZ77X_OK && !team.failed.load()) { my_rc = fn(); if (my_rc) team.failed.store(1); } };
+            step([&]() -> int {
+                Ctx &c = *j.c;
+                HIPCHK(hipSetDevice(c.device));
+                HIPCHK(lz77k_chain_finish(c.maxlen.as<uint8_t>(), j.E, g.la, c.chain.as<uint32_t>(), c.chain_tmp.p, c.stream, j.look, j.entry, &j.d_tbase,
+                                          &j.nsub, nullptr));
+                HIPCHK(hipMemcpyAsync(c.h_tbase.p, j.d_tbase, ((size_t)j.nsub + 1) * 4, hipMemcpyDeviceToHost, c.stream));
+                return LZ77X_OK;
+            });
             for (;;) {
                 /* 1. this shard's maps from its current gates; all but the last shard: the whole plan as ONE map, to the host */
+                t_begin[d] = now_ms();
                 step([&]() -> int {
                     const uint16_t *d_sdest = nullptr;
                     const uint32_t *d_sloc = nullptr;
@@ -524,10 +534,12 @@ static int encode_sharded_stretch(std::vector<Ctx *> &cs, const uint8_t *src, si
                     if (d + 1 < D) HIPCHK(hipStreamSynchronize(j.c->stream));                 /* (the last shard's maps only precede its own sweep) */
                     return LZ77X_OK;
                 });
+                const double my_done1 = now_ms();
                 team.barrier();
                 /* 2. thread 0: the cells every shard starts from -- the maps chained front to back (lz77x_shard_compose_cells) */
                 if (d == 0 && !team.failed.load()) {
-                    const double ts = now_ms();
+                    /* (the gap behind the sweeps of the iteration before: its last device done -> this iteration's first enqueue) */
+                    if (have_done) serial_it += first_begin() - last_done();
                     if (carry.first) for (size_t i = 0; i < usb; i++) v[i] = (uint32_t)i;      /* the start of the input: every cell its own position */
                     else memcpy(v.data(), carry.cells.data(), usb * 4);                         /* a later stretch: the carried ranks */
                     for (size_t q = 0; q < D; q++) {
@@ -536,9 +548,10 @@ static int encode_sharded_stretch(std::vector<Ctx *> &cs, const uint8_t *src, si
                         if (q + 1 < D && jq.nx)                                               /* v <- shard q's whole map applied to v (no step: the cells pass through) */
                             lz77x_shard_compose_cells(reinterpret_cast<const uint16_t *>(jq.h + 512 + usb), jq.h + 512, g.sb, v.data());
                     }
-                    serial_it += now_ms() - ts;
                 }
                 team.barrier();
+                t_done[d] = my_done1;                          /* (thread 0 has read the stamps of the phase before: two barriers ago) */
+                t_begin[d] = now_ms();
                 /* 3. the cells in, the exact sweep of every block that is not final, the flip summary out */
                 step([&]() -> int {
                     HIPCHK(hipSetDevice(j.c->device));
@@ -549,10 +562,12 @@ static int encode_sharded_stretch(std::vector<Ctx *> &cs, const uint8_t *src, si
                     HIPCHK(hipStreamSynchronize(j.c->stream));
                     return LZ77X_OK;
                 });
+                const double my_done3 = now_ms();
                 team.barrier();
                 /* 4. thread 0: who flipped, which blocks are final, is the budget enough */
                 if (d == 0) {
-                    const double ts = now_ms();
+                    /* (the gap behind the maps: their last device done -> the first sweep enqueued) */
+                    serial_it += first_begin() - last_done();
                     if (team.failed.load()) team.done = true;
                     else {
                         iters++;
@@ -578,16 +593,17 @@ static int encode_sharded_stretch(std::vector<Ctx *> &cs, const uint8_t *src, si
                                 team.done = team.hopeless = true;
                         }
                     }
-                    serial_it += now_ms() - ts;
                 }
                 team.barrier();
+                t_done[d] = my_done3;
+                have_done = true;                              /* (every thread writes the same value) */
                 if (team.done) break;
             }
             return my_rc;
         });
         if (rc) return rc;
         host_serial_ms += serial_it;
-        t_serial = now_ms();
+        t_serial = last_done();                                /* (the tail: from the last sweep's end on) */
         if (team.hopeless) {
             /* one block an iteration (input that repeats with a period of about a window): the recurrence of the whole
              * stretch on a host core instead, shard after shard -- each shard's evictions follow its predecessor's, the

@@ -21,8 +21,12 @@ while time.time() < t_end:
         data = _make(n, alpha, mode, s)
         want = O.encode_bst(data, sb, la)
         # the encoder in one segment or a few, the decoder in one range or many (the knobs never change a byte)
-        for k in ("LZ77X_SEGMENT", "LZ77X_DECODE_RANGE", "LZ77X_DECODE_RANGE_BYTES", "LZ77X_SHARD_STRETCH", "LZ77X_PRIO_MAX_ITERS"):
+        for k in ("LZ77X_SEGMENT", "LZ77X_DECODE_RANGE", "LZ77X_DECODE_RANGE_BYTES", "LZ77X_SHARD_STRETCH", "LZ77X_PRIO_MAX_ITERS", "LZ77X_TOKEN_CHUNK"):
             os.environ.pop(k, None)
+        # round 6: several token launches per segment now and then (the large windows build their hand-overs by rank per launch:
+        # other regions, other offsets)
+        if rng.random() < 0.2:
+            os.environ["LZ77X_TOKEN_CHUNK"] = str(rng.choice([20000, 90000, 300000]))
         if rng.random() < 0.3:
             os.environ["LZ77X_SEGMENT"] = str(rng.choice([1, 30000, 100000]))
         # round 5: one stream over 2-4 contexts in stretches, and the recurrence of a segment / a stretch on a host core
