@@ -231,18 +231,27 @@ def shard_record(L, synth, a, shards):
     data = synth.make("text", n, seed)
     ndev = L.lib().lz77x_device_count()
     assert L.lib().lz77x_set_shards(max(shards, 1)) == 0
+    import numpy as np
     try:
-        L.decode(L.encode(data[:64_000_000], a.la, a.sb))                # contexts, buffers, code objects on every device
+        # the clocks are around the C entry points themselves (encode_c / decode_c: the stream stays in the buffer the library
+        # allocated; lz77_amd.encode() would add the copy of a 467 MB stream into a Python bytes object to every figure)
+        with L.encode_c(data[:64_000_000], a.la, a.sb) as w:            # contexts, buffers, code objects on every device
+            L.decode_c(w.view).close()
         t0 = time.perf_counter()
-        z = L.encode(data, a.la, a.sb)
-        st = L.last_stats()
+        zc = L.encode_c(data, a.la, a.sb)
         t1 = time.perf_counter()
-        back = L.decode(z)
+        st = L.last_stats()
+        t1b = time.perf_counter()
+        bc = L.decode_c(zc.view)
         t2 = time.perf_counter()
+        z = zc.tobytes()
+        roundtrip_ok = bool(np.array_equal(bc.view, data))
+        zc.close()
+        bc.close()
     finally:
         L.lib().lz77x_set_shards(1)
     gold = golden_full("text", n, seed, a.sb, a.la)
-    enc_ms, dec_ms = (t1 - t0) * 1e3, (t2 - t1) * 1e3
+    enc_ms, dec_ms = (t1 - t0) * 1e3, (t2 - t1b) * 1e3
     return {"workload": "S4 enwik9-like text, %d bytes, s=%d l=%d, ONE stream cut into %d position shards on %d physical device(s); "
                         "host buffers in and out (PCIe-inclusive)" % (n, a.sb, a.la, shards, min(shards, ndev)),
             "shards": shards, "physical_devices": min(shards, ndev),
@@ -251,10 +260,11 @@ def shard_record(L, synth, a, shards):
             "host_serial_ms": round(st["copy_ms"], 2), "host_serial_frac_of_encode": round(st["copy_ms"] / enc_ms, 4) if enc_ms else None,
             "prio_iters": st["prio_iters"],
             "stream_sha_ok": None if gold is None else bool(len(z) == gold["zn"] and hashlib.sha256(z).hexdigest() == gold["sha256_lz"]),
-            "roundtrip_ok": bool(back == data.tobytes()),
+            "roundtrip_ok": roundtrip_ok,
             "scaling_measured": bool(min(shards, ndev) > 1),
-            "note": "strong scaling of one stream; `value` above is the weak-scaling files mode. host_serial_ms = host time between the "
-                    "phases that no device overlaps (per gate iteration: the shards' boundary maps chained on the host, enqueue)"}
+            "note": "strong scaling of one stream (clocks around lz77x_encode / lz77x_decode themselves); `value` above is the weak-scaling "
+                    "files mode. host_serial_ms = host time during which no device has work (the parse chain's exchange; per gate iteration, "
+                    "from the last shard's device finishing a phase to the first shard's thread enqueuing the next; the pack enqueue)"}
 
 
 def golden_full(kind, n, seed, sb, la):
@@ -391,7 +401,9 @@ def shard_mode(a):
                               "moment the LAST shard's device finished a phase to the moment the FIRST shard's thread enqueues the next "
                               "(the D boundary maps chained on the host, the D flip summaries read, and the wake-ups of the barriers the "
                               "per-shard host threads meet at); the pack enqueue -- it grows with D (one map per shard) and is "
-                              "measured here at D = %d on %d physical device(s)" % (len(plan), min(len(plan), L.lib().lz77x_device_count()))}
+                              "measured here at D = %d on %d physical device(s).  The bound ignores the LATENCY floor of the per-shard stages: a forward sweep "
+                              "of the recurrence takes ~0.45 ms per gate iteration whatever the shard's size, the window walkers 0.8 ms (DESIGN.md "
+                              "section 2.2), so T(8) on a 1 GB stream is nearer 25 ms than T(1) / 8 = 15" % (len(plan), min(len(plan), L.lib().lz77x_device_count()))}
         out = {"metric": "encode+decode MB/s on enwik9-like synthetic text, s=%d l=%d, ONE stream position-sharded" % (a.sb, a.la),
                "value": round(n * K / dt / 1e6, 3), "unit": "MB/s",
                "n_gpus": min(len(plan), L.lib().lz77x_device_count()),         # one process drives every device: physical devices used
