@@ -596,7 +596,7 @@ static int encode_sharded_stretch(std::vector<Ctx *> &cs, const uint8_t *src, si
                 }
                 team.barrier();
                 t_done[d] = my_done3;
-                have_done = true;                              /* (every thread writes the same value) */
+                if (d == 0) have_done = true;                  /* (read by thread 0 only) */
                 if (team.done) break;
             }
             return my_rc;

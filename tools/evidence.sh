@@ -29,8 +29,9 @@ for pass in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_
 done
 python tools/pmc_summary.py $out $tag > $out/pmc_summary.log 2>&1
 
-# 4. where the tie-break's instructions go (variants build: the kernel leaves after a phase)
-bash tools/ts_probe.sh > $out/${tag}_ts_probe.txt 2>&1
+# 4. where the tie-break's instructions go (variants build: the kernel leaves after a phase).  k_tokens_sorted did not change in
+#    round 6 (profiles/r05_ts_probe.txt stands): EVIDENCE_TS_PROBE=1 reruns it
+if [ -n "$EVIDENCE_TS_PROBE" ]; then bash tools/ts_probe.sh > $out/${tag}_ts_probe.txt 2>&1; fi
 
 # 5. the other configurations, data classes, large-window kernels
 python tools/measure_configs.py > $out/${tag}_configs.json 2> $out/configs.err
@@ -38,6 +39,10 @@ python tools/prio_classes.py > $out/${tag}_prio_classes.json 2> $out/prio_classe
 bash tools/prof_cmd.sh ${tag}_c2 ITERS=1 -- python tools/time_c2.py > $out/c2.log 2>&1; cp gpurun_out/${tag}_c2_kernel_stats.csv $out/
 
 bash tools/c2_pmc.sh > $out/c2_pmc.log 2>&1; cp gpurun_out/${tag}c2/${tag}c2_bench_pmc_summary.csv $out/${tag}_c2_pmc_summary.csv
+# the large-window tie-break by parts (variants build, timing only): all / no deferred tokens / only the bucket tokens deferred / the walk of round 5
+for v in "LZ77X_RANK_PROBE=0" "LZ77X_RANK_PROBE=1" "LZ77X_RANK_PROBE=4" "LZ77X_NO_RANK_INDEX=1"; do
+  echo "== $v"; env $v ITERS=2 python tools/time_c2.py 2>&1 | grep encode | tail -1
+done > $out/${tag}_c2_rank_probe.txt 2>&1
 
 # 6. host paths: buffers, files, CLI, memory
 python tools/host_rates.py > $out/host_rates.log 2>&1; cp gpurun_out/host_rates.json $out/${tag}_host_rates.json
@@ -53,7 +58,7 @@ LZ77_BENCH_BACKEND=gloo LZ77X_FAKE_DEVICES=2 python bench.py --gpus 2 --steps 3 
 
 # 8. the worst cases on the record, the run cliff of the large windows, an open-ended fuzz (EVIDENCE_QUICK=1 skips them: ~9 minutes)
 if [ -z "$EVIDENCE_QUICK" ]; then
-  timeout 420 python tools/worst_cases.py 240 > $out/${tag}_worst_cases.json 2> $out/worst.err
+  timeout 300 python tools/worst_cases.py 150 > $out/${tag}_worst_cases.json 2> $out/worst.err
   timeout 200 python tools/run_cliff.py 12000000 2>/dev/null | grep "^{" > $out/${tag}_run_cliff.jsonl
   timeout 260 python tests/gpu_fuzz_long.py 200 6000 2>/dev/null | tail -1 > $out/${tag}_fuzz_long.txt
 fi
