@@ -166,15 +166,41 @@ if fr:
     rows.append(("`%s_file_rates.json`" % TAG, "`python tools/file_rates.py` (FILE* entry points inside one warm process, tmpfs): " + json.dumps(fr)[:400]))
 mp = load(TAG + "_mem_probe.json")
 if mp:
-    rows.append(("`%s_mem_probe.json`" % TAG, "`python tools/mem_probe.py`: device memory held after an encode / a decode per size and geometry (hipMemGetInfo deltas)"))
+    rows.append(("`%s_mem_probe.json`" % TAG, "`python tools/mem_probe.py`: device memory held after an encode / a decode per size and geometry (hipMemGetInfo deltas); encode bytes per input byte: "
+                 + ", ".join("%s %d MB s=%d %s%s" % (m["kind"], m["n"] // 1000000, m["sb"], m["encode_B_per_input_B"], " (segments of 256 MB)" if m.get("env") else "") for m in mp)
+                 + "; `leak_MB` (still held after `lz77x_shutdown()`) is the HIP runtime's queue scratch, see `%s_scratch_hold.txt`" % TAG))
+try:
+    sh_txt = open(os.path.join(P, TAG + "_scratch_hold.txt")).read().strip().splitlines()
+    rows.append(("`%s_scratch_hold.txt`" % TAG, "`./tools/scratch_hold_probe`: device memory before / after a kernel with S bytes of private segment per lane, and after its buffer is freed "
+                 "and its stream destroyed -- the runtime keeps the scratch it gave the hardware queue (what `leak_MB` of the memory probe sees): "
+                 + "; ".join(l.split(":")[0].strip() + ": " + l.split("still")[1].split("below")[0].strip() + " kept" for l in sh_txt if "still" in l)))
+except (OSError, IndexError):
+    pass
+try:
+    rp = open(os.path.join(P, TAG + "_c2_rank_probe.txt")).read().strip().splitlines()
+    parts = []
+    for i in range(0, len(rp) - 1, 2):
+        if rp[i].startswith("==") and "encode" in rp[i + 1]:
+            ms = rp[i + 1].split("encode")[1].split("ms")[0].strip()
+            tb = rp[i + 1].split("'k_tiebreak_ms':")[1].split(",")[0].strip() if "'k_tiebreak_ms':" in rp[i + 1] else "?"
+            parts.append("`%s` encode %s ms, tie-break stage %s ms" % (rp[i][3:].strip(), ms, tb))
+    rows.append(("`%s_c2_rank_probe.txt`" % TAG, "the large-window tie-break by parts on S3 (variants build; `LZ77X_RANK_PROBE` 1 = no deferred tokens, 4 = only the bucket tokens deferred: timing "
+                 "only, wrong output; `LZ77X_NO_RANK_INDEX=1` = the walk cell by cell of round 5): " + "; ".join(parts)))
+except (OSError, IndexError):
+    pass
+if os.path.exists(os.path.join(P, TAG + "_suite_one_process.txt")):
+    tail = [l for l in open(os.path.join(P, TAG + "_suite_one_process.txt")).read().splitlines() if " passed" in l]
+    rows.append(("`%s_suite_one_process.txt`" % TAG, "`bash tools/suite_one_process.sh`: the whole GPU suite in ONE process with the native stderr kept (`--capture=sys`), the soak of "
+                 "`tests/test_gpu_soak.py` last: " + (tail[-1].strip("= ") if tail else "n/a")))
 sh = load(TAG + "_shard_fake8.json")
 if sh:
     a = sh.get("amdahl") or {}
     rows.append(("`%s_shard_fake8.json`" % TAG, "`LZ77X_FAKE_DEVICES=8 python bench.py --mode shard --gpus 8 --steps 2 --warmup 1` on ONE MI355X (eight contexts sharing it: `n_gpus` %s, "
                  "`scaling_measured` %s -- no physical scaling is measured or claimed): S4 1 GB in 8 position shards, encode %s ms, decode %s ms, digest %s, %s joint gate iterations, "
-                 "`host_serial_ms` %s (%s per gate iteration); Amdahl bound from this run's serial part: %s" % (
+                 "`host_serial_ms` %s (%s per gate iteration: last device done -> first enqueue of the next phase); T(1) on the same clock %s ms; Amdahl bound from this run's serial part "
+                 "(it ignores the latency floor of the per-shard stages): %s" % (
                      sh.get("n_gpus"), sh.get("scaling_measured"), sh.get("encode_ms"), sh.get("decode_ms"), sh.get("stream_sha_ok"), sh.get("prio_iters"),
-                     sh.get("host_serial_ms"), a.get("host_serial_ms_per_gate_iteration"), json.dumps(a.get("bound_speedup")))))
+                     sh.get("host_serial_ms"), a.get("host_serial_ms_per_gate_iteration"), a.get("encode_ms_one_context"), json.dumps(a.get("bound_speedup")))))
 n2 = load(TAG + "_n2_gloo_one_gpu.json")
 if n2:
     rows.append(("`%s_n2_gloo_one_gpu.json`" % TAG, "`LZ77_BENCH_BACKEND=gloo LZ77X_FAKE_DEVICES=2 python bench.py --gpus 2 ...` with NO launcher around it: bench.py re-executes itself under "
