@@ -28,9 +28,8 @@ bool trace_on()
 
 bool poison_on()
 {
-    static int on = -1;
-    if (on < 0) { const char *e = getenv("LZ77X_POISON"); on = e && atoi(e) ? 1 : 0; }
-    return on == 1;
+    static const bool on = [] { const char *e = getenv("LZ77X_POISON"); return e && atoi(e); }();      /* (read once, by whichever thread comes first) */
+    return on;
 }
 
 /* LZ77X_POISON=1: what the set's contexts cached from earlier calls holds 0xA5 when the next call starts */
@@ -42,9 +41,7 @@ static void poison_ctx(Ctx &c)
     hipError_t e = hipSetDevice(c.device);
     /* LZ77X_POISON_MASK: bit i = the i-th buffer of dev_bufs(), bit 32 + i = the i-th of pin_bufs() (to find WHICH stale
      * buffer a failure depends on); default: all */
-    static unsigned long long mask = 0;
-    static bool have_mask = false;
-    if (!have_mask) { const char *m = getenv("LZ77X_POISON_MASK"); mask = m ? strtoull(m, nullptr, 0) : ~0ull; have_mask = true; }
+    static const unsigned long long mask = [] { const char *m = getenv("LZ77X_POISON_MASK"); return m ? strtoull(m, nullptr, 0) : ~0ull; }();
     int i = 0;
     for (DevBuf *b : c.dev_bufs()) {
         if (b->p && ((mask >> i) & 1ull)) e = hipMemset(b->p, 0xA5, b->cap);
@@ -61,9 +58,7 @@ static void poison_ctx(Ctx &c)
 
 bool poison_fresh(const DevBuf *b)
 {
-    static unsigned long long mask = 0;
-    static bool have = false;
-    if (!have) { const char *m = getenv("LZ77X_POISON_FRESH_MASK"); mask = m ? strtoull(m, nullptr, 0) : ~0ull; have = true; }
+    static const unsigned long long mask = [] { const char *m = getenv("LZ77X_POISON_FRESH_MASK"); return m ? strtoull(m, nullptr, 0) : ~0ull; }();
     if (mask == ~0ull || !tl_set) return mask != 0;
     std::vector<Ctx *> all = {&tl_set->primary};
     for (Ctx *c : tl_set->more) all.push_back(c);

@@ -87,19 +87,21 @@ int seg_front(SegJob &J, const lz77x_geom &g)
         return LZ77X_OK;
     }
     uint32_t batch = nregions;
+    size_t scratch_limit = 0;
     {
         /* 3 GB of scratch: 100 MB at C1 (8138 regions of 287 KB) in ONE launch -- the walkers are latency bound (a
          * launch takes its fill + 2048 steps whatever its size), a second launch is a second 0.75 ms */
         const size_t per = lz77k_match_scratch_bytes(g, 1);
-        /* (large windows: 16 GB -- their walkers are latency bound too and a region's scratch is 16x a small window's) */
+        /* (large windows: LZ77X_BIG_SCRATCH_GB -- a region's scratch is 16x a small window's; host.h has why it is 12 and not 16) */
         const size_t cap = J.scratch_cap ? J.scratch_cap : (size_t)(g.fast ? 3 : LZ77X_BIG_SCRATCH_GB) << 30;      /* (encode_mem_plan lowers it on a tight device) */
         const uint32_t fit = (uint32_t)(cap / per);
         if (batch > fit) batch = fit ? fit : 1;
+        scratch_limit = cap;
         const char *gs = getenv("LZ77X_MATCH_BATCH");
         if (gs && atoi(gs) > 0 && (uint32_t)atoi(gs) < batch) batch = (uint32_t)atoi(gs);
     }
     const size_t np = (size_t)J.nloc;
-    if ((rc = c.scratch.need(lz77k_match_scratch_bytes(g, batch)))) return rc;
+    if ((rc = c.scratch.need(lz77k_match_scratch_bytes(g, batch), scratch_limit))) return rc;
     if ((rc = c.ps.need((np + 8) * 4))) return rc;
     if ((rc = c.maxlen.need(np + 64))) return rc;
     /* the regions' sorted order stays resident for the tie-break (RP uint16 per region: 2.7 B per input byte) */

@@ -116,12 +116,17 @@ bool poison_fresh(const DevBuf *b);   /* LZ77X_POISON_FRESH_MASK: which buffers 
 struct DevBuf {
     void *p = nullptr;
     size_t cap = 0;
-    int need(size_t bytes)
+    /* limit: the headroom (an eighth, against re-allocation when the next input is a little larger) stops there -- a buffer
+     * that is sized by a cap, like the match stage's scratch per launch, does not grow past it */
+    int need(size_t bytes, size_t limit = 0)
     {
         if (bytes <= cap) return LZ77X_OK;
         const double t0 = trace_on() ? now_ms() : 0;
         if (p) { hipError_t e0 = hipFree(p); (void)e0; p = nullptr; cap = 0; }
-        size_t want = bytes + bytes / 8 + 4096;
+        /* headroom against re-allocation when the next input is a little larger: an eighth, at most 64 MB (round 5 gave
+         * every buffer an eighth whatever its size: 2 GB of a 30 GB large-window encode were headroom) */
+        size_t want = bytes + (bytes / 8 < ((size_t)64 << 20) ? bytes / 8 : ((size_t)64 << 20)) + 4096;
+        if (limit && want > limit) want = bytes > limit ? bytes : limit;
         HIPCHK(hipMalloc(&p, want));
         cap = want;
         /* (hipMemset may return before the fill has run, and the null stream does not order it against the non-blocking
@@ -316,7 +321,10 @@ template <class F> int for_each_shard(size_t D, F fn)
     std::vector<std::string> msgs(D);
     auto run = [&](size_t d) {
         g_err[0] = 0;
-        rcs[d] = fn(d);
+        /* (a worker thread has no function-try-block of the C ABI above it: nothing may leave fn) */
+        try { rcs[d] = fn(d); }
+        catch (const std::bad_alloc &) { rcs[d] = LZ77X_E_NOMEM; snprintf(g_err, sizeof g_err, "out of host memory"); }
+        catch (...) { rcs[d] = LZ77X_E_HIP; snprintf(g_err, sizeof g_err, "host exception on a shard's thread"); }
         if (rcs[d]) msgs[d] = g_err;
     };
     std::vector<std::thread> th;
@@ -355,7 +363,11 @@ template <class F> int run_team(size_t D, F fn)
             if (state == 2) return;
         }
         g_err[0] = 0;
-        rcs[d] = fn(d);
+        /* (fn meets the other shards at barriers: it must not throw between them -- the joint iteration allocates nothing;
+         * what could still throw is turned into an error code here, on the thread it happened on) */
+        try { rcs[d] = fn(d); }
+        catch (const std::bad_alloc &) { rcs[d] = LZ77X_E_NOMEM; snprintf(g_err, sizeof g_err, "out of host memory"); }
+        catch (...) { rcs[d] = LZ77X_E_HIP; snprintf(g_err, sizeof g_err, "host exception on a shard's thread"); }
         if (rcs[d]) msgs[d] = g_err;
     };
     std::vector<std::thread> th;
