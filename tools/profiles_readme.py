@@ -188,6 +188,9 @@ try:
                  "only, wrong output; `LZ77X_NO_RANK_INDEX=1` = the walk cell by cell of round 5): " + "; ".join(parts)))
 except (OSError, IndexError):
     pass
+if os.path.exists(os.path.join(P, TAG + "_fuzz_c2.txt")):
+    rows.append(("`%s_fuzz_c2.txt`" % TAG, "`python tests/gpu_fuzz_c2.py 600 20000` (large windows only, several regions, long runs of equal candidates; every stream against the oracle): "
+                 + open(os.path.join(P, TAG + "_fuzz_c2.txt")).read().strip()))
 if os.path.exists(os.path.join(P, TAG + "_suite_one_process_poison.txt")):
     tail = [l for l in open(os.path.join(P, TAG + "_suite_one_process_poison.txt")).read().splitlines() if " passed" in l]
     rows.append(("`%s_suite_one_process_poison.txt`" % TAG, "`bash tools/poison_suite_and_fuzz.sh`: the same run with `LZ77X_POISON=1` (every cached device and pinned buffer filled with 0xA5 when a "
