@@ -188,6 +188,9 @@ try:
                  "only, wrong output; `LZ77X_NO_RANK_INDEX=1` = the walk cell by cell of round 5): " + "; ".join(parts)))
 except (OSError, IndexError):
     pass
+if os.path.exists(os.path.join(P, TAG + "_fallback_soak.txt")):
+    rows.append(("`%s_fallback_soak.txt`" % TAG, "`python tools/fallback_soak.py 540`: the hand-over from the device pipeline to the host-assisted one (the path of round 5's abort) in one "
+                 "process between calls of every other kind: " + open(os.path.join(P, TAG + "_fallback_soak.txt")).read().strip()))
 if os.path.exists(os.path.join(P, TAG + "_fuzz_c2.txt")):
     rows.append(("`%s_fuzz_c2.txt`" % TAG, "`python tests/gpu_fuzz_c2.py 600 20000` (large windows only, several regions, long runs of equal candidates; every stream against the oracle): "
                  + open(os.path.join(P, TAG + "_fuzz_c2.txt")).read().strip()))
